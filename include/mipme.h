@@ -1,0 +1,170 @@
+/*
+ * mipme.h -- C-ABI of libmipme.so, the MI355X (gfx950) native PME / P3M hot path.
+ *
+ * The reference (lab-cosmo/torch-pme) has no FFI of its own: its boundary is the Python
+ * nn.Module API, and every "kernel" is a chain of ATen ops.  This header is the boundary a
+ * maintainer would bind (ctypes) to replace those ATen chains.  Each
+ * entry point cites the reference code it replaces (paths relative to src/torchpme/).
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no C++/torch types.  Every function returns 0 on
+ *     success or a negative MIPME_E* code; mipme_last_error() gives the thread-local message.
+ *     Nothing throws, nothing synchronises the device, nothing allocates device memory except
+ *     mipme_fft_plan_create (hipFFT work area).
+ *   - All array arguments are DEVICE pointers unless marked "host".  The caller owns every
+ *     buffer.  `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued on it in order, so calls are HIP-graph capturable.
+ *   - `dtype` selects the real type of every floating array (MIPME_F32: float, MIPME_F64:
+ *     double).  Index arrays are int64 (MIPME_I64) or int32 (MIPME_I32).
+ *   - Layouts follow the reference: positions (N,3) row-major; charges / potentials (N,C)
+ *     row-major; cell (3,3) row-major with ROWS = lattice vectors; mesh (C,nx,ny,nz) row-major
+ *     (z fastest); half-complex mesh (C,nx,ny,nz/2+1) interleaved re/im; pairs (P,2).
+ */
+#ifndef MIPME_H
+#define MIPME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPME_VERSION 100
+
+enum { MIPME_F32 = 0, MIPME_F64 = 1 };
+enum { MIPME_I64 = 0, MIPME_I32 = 1 };
+enum { MIPME_LAGRANGE = 0, MIPME_P3M = 1 };          /* MeshInterpolator(method=...) */
+enum { MIPME_COULOMB = 0, MIPME_INVERSE_POWER_LAW = 1 };
+
+enum {
+  MIPME_OK = 0,
+  MIPME_EINVAL = -1,   /* bad argument (the Python layer raises ValueError) */
+  MIPME_EHIP = -2,     /* HIP runtime error */
+  MIPME_EFFT = -3,     /* hipFFT error */
+  MIPME_EUNSUPPORTED = -4
+};
+
+/* Pair potential 1/r^p with Gaussian range separation: potentials/potential.py:31-57,
+ * potentials/coulomb.py:71-78, potentials/inversepowerlaw.py:40-52. */
+typedef struct {
+  int32_t kind;             /* MIPME_COULOMB (p=1) or MIPME_INVERSE_POWER_LAW */
+  int32_t exponent;         /* p in 1..6 (ignored for Coulomb) */
+  double smearing;          /* sigma; <= 0 means "None": no range separation, no k-space part */
+  double prefactor;
+  double exclusion_radius;  /* <= 0 means None */
+  int32_t exclusion_degree;
+  int32_t _pad;
+} mipme_potential_t;
+
+/* Mesh geometry for one cell: what MeshInterpolator.update (lib/mesh_interpolator.py:81-125) and
+ * KSpaceFilter._prep_kvectors (lib/kspace_filter.py:199-222) derive from (cell, ns_mesh). */
+typedef struct {
+  int32_t scheme;      /* MIPME_LAGRANGE (orders 3..7) or MIPME_P3M (orders 1..5) */
+  int32_t order;       /* interpolation_nodes */
+  int32_t nx, ny, nz;  /* ns_mesh */
+  int32_t n_channels;  /* C */
+  double cell[9];      /* host copy, row-major, rows = lattice vectors */
+  double inv_cell[9];  /* inverse of cell */
+  double volume;       /* |det cell| */
+} mipme_mesh_t;
+
+typedef struct mipme_fft_plan mipme_fft_plan;
+
+const char* mipme_last_error(void);
+int mipme_version(void);
+
+/* ---- reciprocal-space convolution: KSpaceFilter.forward, lib/kspace_filter.py:122-197 -------- */
+
+/* hipFFT R2C + C2R plans for a (batch, nx, ny, nz) real mesh on the current device. */
+int mipme_fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out);
+int mipme_fft_plan_destroy(mipme_fft_plan* plan);
+
+/* G(k) on the rfft half grid, shape (nx,ny,nz/2+1) reals.
+ * PME:  G = v_LR^(k^2)                     KSpaceFilter.update        lib/kspace_filter.py:97-120
+ * P3M:  G = v_LR^(k^2) / U^2(k)  (mode 0)  P3MKSpaceFilter.update     lib/kspace_filter.py:293-329,349-361
+ * k-grid: generate_kvectors_for_mesh      lib/kvectors.py:24-74;  kernels: potentials/coulomb.py:122-142,
+ * potentials/inversepowerlaw.py:109-141, lib/math.py:85-104. */
+int mipme_kfilter_build(void* stream, int dtype, const mipme_mesh_t* mesh, const mipme_potential_t* pot, void* G);
+
+/* mesh_out = irfftn(rfftn(mesh_in) * G), both transforms unnormalised.
+ * hat_out  (C,nx,ny,nz/2+1) complex: receives rfftn(mesh_in) (kept for the cell gradient);
+ * hat_work same shape, scratch;  dc_out (C reals, nullable): Re hat[c,0,0,0] = sum of mesh_in[c]. */
+int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, const void* G, void* hat_out, void* hat_work,
+                   void* mesh_out, void* dc_out);
+
+/* ---- particle <-> mesh: MeshInterpolator, lib/mesh_interpolator.py:303-457 ------------------- */
+
+/* mesh[c,ix,iy,iz] = sum_i values[i,c] * wx*wy*wz  (compute_weights + points_to_mesh, :303-426).
+ * The mesh is zeroed by this call. */
+int mipme_spread(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
+                 const void* values, void* mesh_out);
+
+/* out[i,c] = sum_stencil mesh[c,ix,iy,iz] * wx*wy*wz  (compute_weights + mesh_to_points, :428-457). */
+int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
+                 const void* mesh_in, void* out);
+
+/* ---- PMECalculator._compute_kspace, calculators/pme.py:88-143 (P3M: calculators/p3m.py:45-84) -- */
+
+/* out_lr[i,c] = 1/2 [ gather(convolve(spread(q)))/V - q*self - 2*bg*Q_c/V ]      (no slab term)
+ * Work buffers (caller allocated): rho_mesh, phi_mesh (C,nx,ny,nz); rho_hat, hat_work complex half grids;
+ * dc (C).  phi_mesh, rho_hat, dc and out_phi (N,C, nullable: the raw gather/V) are what the backward needs. */
+int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
+                         const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
+                         const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
+                         void* out_lr, void* out_phi);
+
+/* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
+ * (In the reference this is PyTorch autograd through the ATen chain)
+ * grad_positions (N,3), grad_charges (N,C), grad_cell (9) are OVERWRITTEN; each may be NULL.
+ * Work: psi_mesh, chi_mesh (C,nx,ny,nz); psi_hat, hat_work complex half grids; dc (C);
+ * partials: float64 scratch of >= mipme_cellgrad_partials_size() elements (only used when grad_cell != NULL,
+ * which also requires rho_hat, rho_dc, phi_atoms and grad_positions). */
+int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
+                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
+                          const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
+                          const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
+                          void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
+                          void* grad_cell);
+int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
+
+/* 2-D slab correction, potentials/coulomb.py:6-40 (active when exactly two axes are periodic).
+ * forward: pot[i,c] += 1/2 * prefactor * E_slab[i,c].  moments: float64 scratch of 6*C elements.
+ * backward: ACCUMULATES into grad_positions / grad_charges / grad_cell (each nullable). */
+int mipme_slab_forward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,
+                       const void* positions, const void* charges, void* moments, void* pot);
+int mipme_slab_backward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,
+                        const void* positions, const void* charges, const void* grad_out, void* moments,
+                        void* grad_positions, void* grad_charges, void* grad_cell);
+
+/* ---- Calculator._compute_rspace, calculators/calculator.py:43-87 ------------------------------ */
+
+/* pot[i,c] (+)= 1/2 sum_pairs q[j,c] v_SR(d)   (+ the (j,i) direction for a half list, :82-84)
+ * v_SR: Potential.sr_from_dist / from_dist / f_cutoff, potentials/potential.py:59-138.
+ * pair_mask: nullable uint8/bool (P).  accumulate = 0 zeroes pot first. */
+int mipme_rspace_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
+                         const void* pairs, const void* dist, const void* charges, const void* pair_mask,
+                         int full_list, const mipme_potential_t* pot, int accumulate, void* out_pot);
+
+/* grad_dist[p] = 1/2 v_SR'(d_p) sum_c (g[i,c] q[j,c] + g[j,c] q[i,c])   (overwritten, nullable)
+ * grad_charges (N,C): ACCUMULATED atomically (nullable). */
+int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
+                          const void* pairs, const void* dist, const void* charges, const void* pair_mask,
+                          int full_list, const mipme_potential_t* pot, const void* grad_out, void* grad_dist,
+                          void* grad_charges);
+
+/* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
+
+/* d[p] = | r[j] - r[i] + shifts[p] @ cell |.  cell: DEVICE (9 reals); shifts (P,3) reals (nullable = 0). */
+int mipme_pair_distance_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, const void* pairs,
+                                const void* positions, const void* cell, const void* shifts, void* out_dist);
+/* grad_positions (N,3): zeroed then accumulated.  grad_cell (9, nullable): overwritten; partials: float64 scratch
+ * of >= mipme_pair_partials_size(n_pairs) elements, required when grad_cell != NULL. */
+int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms,
+                                 const void* pairs, const void* positions, const void* cell, const void* shifts,
+                                 const void* grad_dist, void* partials, void* grad_positions, void* grad_cell);
+int64_t mipme_pair_partials_size(int64_t n_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPME_H */

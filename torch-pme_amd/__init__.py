@@ -1,0 +1,27 @@
+"""MI355X (gfx950) native PME / P3M long-range calculators -- drop-in for the hot path of
+lab-cosmo/torch-pme: ``PMECalculator / P3MCalculator.forward(charges, cell, positions,
+neighbor_indices, neighbor_distances)`` and its autograd.
+
+The directory is named ``torch-pme_amd``; import it as ``torchpme_amd`` (see ``torchpme_amd.py`` at the
+repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI in ``include/mipme.h``).
+"""
+
+from . import lib, prefactors  # noqa: F401
+from ._lib import LIB_PATH, MipmeError  # noqa: F401
+from .calculators import Calculator, P3MCalculator, PMECalculator
+from .neighbors import neighbor_list
+from .ops import pair_distances
+from .potentials import CoulombPotential, InversePowerLawPotential, Potential
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "Calculator",
+    "P3MCalculator",
+    "PMECalculator",
+    "CoulombPotential",
+    "InversePowerLawPotential",
+    "Potential",
+    "pair_distances",
+    "neighbor_list",
+]

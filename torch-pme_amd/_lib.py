@@ -1,0 +1,186 @@
+"""ctypes binding of ``libmipme.so`` (C-ABI declared in ``include/mipme.h``).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the product
+path raises.  ``import torch`` happens before the ``dlopen`` so that ``libamdhip64.so.7`` /
+``libhipfft.so.0`` resolve to the copies PyTorch already loaded (one HIP runtime per process, so
+``torch.cuda.current_stream().cuda_stream`` is a valid ``hipStream_t`` for the library).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmipme.so")
+
+F32, F64 = 0, 1
+I64, I32 = 0, 1
+LAGRANGE, P3M = 0, 1
+COULOMB, INVERSE_POWER_LAW = 0, 1
+
+EXPORTS = (
+    "mipme_last_error", "mipme_version", "mipme_fft_plan_create", "mipme_fft_plan_destroy", "mipme_kfilter_build",
+    "mipme_convolve", "mipme_spread", "mipme_gather", "mipme_kspace_forward", "mipme_kspace_backward",
+    "mipme_cellgrad_partials_size", "mipme_slab_forward", "mipme_slab_backward", "mipme_rspace_forward",
+    "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
+    "mipme_pair_partials_size",
+)
+
+
+class PotentialDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("exponent", C.c_int32),
+        ("smearing", C.c_double),
+        ("prefactor", C.c_double),
+        ("exclusion_radius", C.c_double),
+        ("exclusion_degree", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("scheme", C.c_int32),
+        ("order", C.c_int32),
+        ("nx", C.c_int32),
+        ("ny", C.c_int32),
+        ("nz", C.c_int32),
+        ("n_channels", C.c_int32),
+        ("cell", C.c_double * 9),
+        ("inv_cell", C.c_double * 9),
+        ("volume", C.c_double),
+    ]
+
+
+class MipmeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i64, ci, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    MP, PP = C.POINTER(MeshDesc), C.POINTER(PotentialDesc)
+    lib.mipme_last_error.restype = C.c_char_p
+    lib.mipme_last_error.argtypes = []
+    lib.mipme_version.restype = ci
+    lib.mipme_version.argtypes = []
+    sig = {
+        "mipme_fft_plan_create": [ci, ci, ci, ci, ci, C.POINTER(vp)],
+        "mipme_fft_plan_destroy": [vp],
+        "mipme_kfilter_build": [vp, ci, MP, PP, vp],
+        "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
+        "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 10,
+        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 17,
+        "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
+        "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
+        "mipme_rspace_backward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, vp, vp, vp],
+        "mipme_pair_distance_forward": [vp, ci, ci, i64, vp, vp, vp, vp, vp],
+        "mipme_pair_distance_backward": [vp, ci, ci, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = ci
+        fn.argtypes = argtypes
+    lib.mipme_cellgrad_partials_size.restype = i64
+    lib.mipme_cellgrad_partials_size.argtypes = [MP, i64]
+    lib.mipme_pair_partials_size.restype = i64
+    lib.mipme_pair_partials_size.argtypes = [i64]
+
+
+def load():
+    """Load (once) and return the ctypes handle of libmipme.so; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MipmeError(
+                f"HIP extension {LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C torch-pme_amd/csrc`). There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    """Translate a C-ABI status into a Python exception (ValueError for MIPME_EINVAL)."""
+    if rc == 0:
+        return
+    msg = load().mipme_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise MipmeError(f"libmipme error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise TypeError(f"libmipme supports float32 and float64 tensors, got {dtype}")
+
+
+def index_code(dtype) -> int:
+    if dtype == torch.int64:
+        return I64
+    if dtype == torch.int32:
+        return I32
+    raise TypeError(f"neighbor indices must be int64 or int32, got {dtype}")
+
+
+def current_stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(t, name: str):
+    if not t.is_cuda:
+        raise MipmeError(
+            f"`{name}` lives on {t.device}: the MI355X-native path only runs on HIP devices "
+            "(tensors on 'cuda'); there is no CPU fallback."
+        )
+
+
+class FFTPlan:
+    """Owning wrapper of a ``mipme_fft_plan`` (hipFFT R2C + C2R)."""
+
+    def __init__(self, device, dtype, ns, batch):
+        self.key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch))
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            check(load().mipme_fft_plan_create(dtype_code(dtype), int(ns[0]), int(ns[1]), int(ns[2]), int(batch), C.byref(handle)))
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.mipme_fft_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_PLANS: dict = {}
+
+
+def get_plan(device, dtype, ns, batch) -> FFTPlan:
+    key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch))
+    plan = _PLANS.get(key)
+    if plan is None:
+        if len(_PLANS) >= 32:
+            _PLANS.pop(next(iter(_PLANS)))
+        plan = FFTPlan(device, dtype, ns, batch)
+        _PLANS[key] = plan
+    return plan

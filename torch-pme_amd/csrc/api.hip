@@ -1,0 +1,425 @@
+// extern "C" entry points of libmipme.so (declared in include/mipme.h) and the composite
+// k-space forward / backward sequences (reference calculators/pme.py:88-143 and its autograd).
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace mipme {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+// implemented in mesh.hip / kfilter.hip / rspace.hip
+template <typename T> int spread_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, double, void*);
+template <typename T> int gather_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
+template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
+template <typename T> int apply_filter_cellgrad_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*, const void*, const void*, void*, void*, void*);
+template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
+int64_t cellgrad_blocks(const mipme_mesh_t*);
+int fft_plan_create(int, int, int, int, int, mipme_fft_plan**);
+int fft_plan_destroy(mipme_fft_plan*);
+int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
+int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
+template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
+template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, void*, void*);
+template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
+template <typename T, typename I> int distance_backward_impl(hipStream_t, int64_t, int64_t, const void*, const void*, const void*, const void*, const void*, void*, void*, void*);
+int64_t pair_partials_blocks(int64_t);
+
+struct FftDims { int dtype, nx, ny, nz, batch; };
+FftDims fft_plan_dims(const mipme_fft_plan*);
+
+// self / background corrections: potentials/coulomb.py:144-158, potentials/inversepowerlaw.py:143-166
+static void correction_terms(const mipme_potential_t* pot, double& self_c, double& bg_c) {
+  const int p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  const double two_s2 = 2.0 * pot->smearing * pot->smearing;
+  self_c = pot->prefactor / std::tgamma(0.5 * p + 1.0) / std::pow(two_s2, 0.5 * p);
+  if (p >= 3)
+    bg_c = 0.0;
+  else
+    bg_c = pot->prefactor * std::pow(3.14159265358979323846, 1.5) * std::pow(two_s2, 0.5 * (3 - p)) /
+           ((3 - p) * std::tgamma(0.5 * p));
+}
+
+static int check_plan(const mipme_fft_plan* plan, int dtype, const mipme_mesh_t* m) {
+  MIPME_REQUIRE(plan != nullptr, "FFT plan is NULL");
+  const FftDims d = fft_plan_dims(plan);
+  MIPME_REQUIRE(d.dtype == dtype && d.nx == m->nx && d.ny == m->ny && d.nz == m->nz && d.batch == m->n_channels,
+                "The real-space mesh is inconsistent with the k-space grid.");
+  return MIPME_OK;
+}
+
+template <typename T>
+static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
+                            int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
+                            void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi) {
+  int rc;
+  if ((rc = spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh))) return rc;
+  if ((rc = fft_forward(plan, st, rho_mesh, rho_hat))) return rc;
+  const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+  if ((rc = apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc))) return rc;
+  if ((rc = fft_inverse(plan, st, hat_work, phi_mesh))) return rc;
+  double self_c, bg_c;
+  correction_terms(pot, self_c, bg_c);
+  return gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi);
+}
+
+template <typename T>
+static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
+                             int64_t N, const void* pos, const void* q, const void* gout, const void* G,
+                             const void* phi_mesh, const void* rho_hat, const void* rho_dc, const void* phi_atoms,
+                             void* psi_mesh, void* psi_hat, void* hat_work, void* chi_mesh, void* dc, void* partials,
+                             void* grad_pos, void* grad_q, void* grad_cell) {
+  int rc;
+  double self_c, bg_c;
+  correction_terms(pot, self_c, bg_c);
+  // psi = spread(g / 2V); chi = F psi
+  if ((rc = spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh))) return rc;
+  if ((rc = fft_forward(plan, st, psi_mesh, psi_hat))) return rc;
+  const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+  if (grad_cell) {
+    MIPME_REQUIRE(rho_hat && rho_dc && phi_atoms && partials && grad_pos,
+                  "cell gradient needs rho_hat, rho_dc, phi_atoms, partials and grad_positions buffers");
+    if ((rc = apply_filter_cellgrad_impl<T>(st, m, pot, psi_hat, rho_hat, G, hat_work, dc, partials))) return rc;
+  } else {
+    if ((rc = apply_filter_impl<T>(st, Mh, m->n_channels, psi_hat, G, hat_work, dc))) return rc;
+  }
+  if ((rc = fft_inverse(plan, st, hat_work, chi_mesh))) return rc;
+  if ((rc = gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q)))
+    return rc;
+  if (grad_cell)
+    return cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, grad_cell);
+  return MIPME_OK;
+}
+
+// ---- slab (2-D periodic) correction: potentials/coulomb.py:6-40 ---------------------------------
+// moments[c*6 + {0..5}] = Q, M, M2 (charges) and S0, S1, S2 (g/2) per channel
+template <typename T>
+__global__ __launch_bounds__(1024) void slab_moments_kernel(int axis, int64_t N, int C, const T* __restrict__ pos,
+                                                           const T* __restrict__ q, const T* __restrict__ g,
+                                                           double* __restrict__ moments) {
+  __shared__ double red[16][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < C; ++c) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t a = threadIdx.x; a < N; a += blockDim.x) {
+      const double z = double(pos[3 * a + axis]);
+      const double qc = double(q[a * C + c]);
+      acc[0] += qc;
+      acc[1] += qc * z;
+      acc[2] += qc * z * z;
+      if (g) {
+        const double gh = 0.5 * double(g[a * C + c]);
+        acc[3] += gh;
+        acc[4] += gh * z;
+        acc[5] += gh * z * z;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double v = 0.0;
+      for (int w = 0; w < int(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];
+      moments[c * 6 + threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void slab_forward_kernel(int axis, int64_t N, int C, double c0, double Lz, const T* __restrict__ pos,
+                                    const double* __restrict__ mom, T* __restrict__ pot) {
+  const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const double z = double(pos[3 * a + axis]);
+  for (int c = 0; c < C; ++c) {
+    const double Q = mom[c * 6], M = mom[c * 6 + 1], M2 = mom[c * 6 + 2];
+    const double e = c0 * (z * M - 0.5 * (M2 + Q * z * z) - Q * Lz * Lz / 12.0);
+    pot[a * C + c] += T(0.5 * e);
+  }
+}
+
+template <typename T>
+__global__ void slab_backward_kernel(int axis, int64_t N, int C, double c0, double Lz, const T* __restrict__ pos,
+                                     const T* __restrict__ q, const T* __restrict__ g,
+                                     const double* __restrict__ mom, T* __restrict__ grad_pos, T* __restrict__ grad_q) {
+  const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const double z = double(pos[3 * a + axis]);
+  double dz = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double Q = mom[c * 6], M = mom[c * 6 + 1];
+    const double S0 = mom[c * 6 + 3], S1 = mom[c * 6 + 4], S2 = mom[c * 6 + 5];
+    const double gh = 0.5 * double(g[a * C + c]);
+    dz += gh * (M - Q * z) + double(q[a * C + c]) * (S1 - z * S0);
+    if (grad_q) grad_q[a * C + c] += T(c0 * (z * S1 - 0.5 * z * z * S0 - 0.5 * S2 - S0 * Lz * Lz / 12.0));
+  }
+  if (grad_pos) grad_pos[3 * a + axis] += T(c0 * dz);
+}
+
+template <typename T>
+__global__ void slab_cell_kernel(int axis, int C, mipme_mesh_t m, double c0, double Lz, const double* __restrict__ mom,
+                                 T* __restrict__ grad_cell) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sval = 0.0, dl = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double Q = mom[c * 6], M = mom[c * 6 + 1], M2 = mom[c * 6 + 2];
+    const double S0 = mom[c * 6 + 3], S1 = mom[c * 6 + 4], S2 = mom[c * 6 + 5];
+    sval += c0 * (S1 * M - 0.5 * (S0 * M2 + Q * S2) - Q * S0 * Lz * Lz / 12.0);
+    dl += c0 * (-Q * S0 * Lz / 6.0);
+  }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double v = -sval * m.inv_cell[3 * b + a];
+      if (a == axis) v += dl * m.cell[3 * a + b] / Lz;
+      grad_cell[3 * a + b] += T(v);
+    }
+}
+
+static double axis_length(const mipme_mesh_t* m, int axis) {
+  const double* a = m->cell + 3 * axis;
+  return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+}
+
+template <typename T>
+static int slab_forward_t(hipStream_t st, int axis, const mipme_mesh_t* m, double pref, int64_t N, const void* pos,
+                          const void* q, void* moments, void* pot) {
+  if (N == 0) return MIPME_OK;
+  const int C = m->n_channels;
+  const double c0 = pref * 4.0 * 3.14159265358979323846 / m->volume;
+  slab_moments_kernel<T><<<1, 1024, 0, st>>>(axis, N, C, (const T*)pos, (const T*)q, (const T*)nullptr, (double*)moments);
+  MIPME_LAUNCH_CHECK();
+  slab_forward_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(axis, N, C, c0, axis_length(m, axis), (const T*)pos,
+                                                                    (const double*)moments, (T*)pot);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+static int slab_backward_t(hipStream_t st, int axis, const mipme_mesh_t* m, double pref, int64_t N, const void* pos,
+                           const void* q, const void* g, void* moments, void* grad_pos, void* grad_q, void* grad_cell) {
+  if (N == 0) return MIPME_OK;
+  const int C = m->n_channels;
+  const double c0 = pref * 4.0 * 3.14159265358979323846 / m->volume;
+  const double Lz = axis_length(m, axis);
+  slab_moments_kernel<T><<<1, 1024, 0, st>>>(axis, N, C, (const T*)pos, (const T*)q, (const T*)g, (double*)moments);
+  MIPME_LAUNCH_CHECK();
+  if (grad_pos || grad_q) {
+    slab_backward_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
+        axis, N, C, c0, Lz, (const T*)pos, (const T*)q, (const T*)g, (const double*)moments, (T*)grad_pos, (T*)grad_q);
+    MIPME_LAUNCH_CHECK();
+  }
+  if (grad_cell) {
+    slab_cell_kernel<T><<<1, 64, 0, st>>>(axis, C, *m, c0, Lz, (const double*)moments, (T*)grad_cell);
+    MIPME_LAUNCH_CHECK();
+  }
+  return MIPME_OK;
+}
+
+}  // namespace mipme
+
+using namespace mipme;
+
+#define DT_SWITCH(dtype, CALL_F32, CALL_F64)                    \
+  do {                                                          \
+    if ((dtype) == MIPME_F32) return CALL_F32;                  \
+    if ((dtype) == MIPME_F64) return CALL_F64;                  \
+    set_error("invalid dtype %d", int(dtype));                  \
+    return MIPME_EINVAL;                                        \
+  } while (0)
+
+extern "C" {
+
+const char* mipme_last_error(void) { return g_error; }
+int mipme_version(void) { return MIPME_VERSION; }
+
+int mipme_fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {
+  return fft_plan_create(dtype, nx, ny, nz, batch, out);
+}
+int mipme_fft_plan_destroy(mipme_fft_plan* plan) { return fft_plan_destroy(plan); }
+
+int mipme_kfilter_build(void* stream, int dtype, const mipme_mesh_t* mesh, const mipme_potential_t* pot, void* G) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  MIPME_REQUIRE(G != nullptr, "G is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, kfilter_build_impl<float>(st, mesh, pot, G), kfilter_build_impl<double>(st, mesh, pot, G));
+}
+
+int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, const void* G, void* hat_out, void* hat_work,
+                   void* mesh_out, void* dc_out) {
+  MIPME_REQUIRE(plan != nullptr, "FFT plan is NULL");
+  MIPME_REQUIRE(mesh_in && G && hat_out && hat_work && mesh_out, "NULL buffer passed to mipme_convolve");
+  hipStream_t st = (hipStream_t)stream;
+  const FftDims d = fft_plan_dims(plan);
+  const int64_t Mh = int64_t(d.nx) * d.ny * (d.nz / 2 + 1);
+  int rc;
+  if ((rc = fft_forward(plan, st, mesh_in, hat_out))) return rc;
+  if (d.dtype == MIPME_F32)
+    rc = apply_filter_impl<float>(st, Mh, d.batch, hat_out, G, hat_work, dc_out);
+  else
+    rc = apply_filter_impl<double>(st, Mh, d.batch, hat_out, G, hat_work, dc_out);
+  if (rc) return rc;
+  return fft_inverse(plan, st, hat_work, mesh_out);
+}
+
+int mipme_spread(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
+                 const void* values, void* mesh_out) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  MIPME_REQUIRE(n_atoms >= 0 && mesh_out && (n_atoms == 0 || (positions && values)), "NULL buffer passed to mipme_spread");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, spread_impl<float>(st, mesh, n_atoms, positions, values, 1.0, mesh_out),
+            spread_impl<double>(st, mesh, n_atoms, positions, values, 1.0, mesh_out));
+}
+
+int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
+                 const void* mesh_in, void* out) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  MIPME_REQUIRE(n_atoms >= 0 && mesh_in && (n_atoms == 0 || (positions && out)), "NULL buffer passed to mipme_gather");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, gather_impl<float>(st, mesh, n_atoms, positions, mesh_in, out),
+            gather_impl<double>(st, mesh, n_atoms, positions, mesh_in, out));
+}
+
+int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
+                         const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
+                         const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
+                         void* out_lr, void* out_phi) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  if ((rc = check_plan(plan, dtype, mesh))) return rc;
+  MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
+  MIPME_REQUIRE(G && rho_mesh && rho_hat && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
+                                    phi_mesh, dc, out_lr, out_phi),
+            kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
+                                     phi_mesh, dc, out_lr, out_phi));
+}
+
+int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
+                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
+                          const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
+                          const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
+                          void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
+                          void* grad_cell) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  if ((rc = check_plan(plan, dtype, mesh))) return rc;
+  MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
+  MIPME_REQUIRE(G && phi_mesh && psi_mesh && psi_hat && hat_work && chi_mesh && dc,
+                "NULL work buffer passed to mipme_kspace_backward");
+  MIPME_REQUIRE(n_atoms == 0 || (positions && charges && grad_out), "NULL atom buffer passed to mipme_kspace_backward");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            kspace_backward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
+                                     rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
+                                     grad_positions, grad_charges, grad_cell),
+            kspace_backward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
+                                      rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
+                                      grad_positions, grad_charges, grad_cell));
+}
+
+int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms) {
+  (void)n_atoms;
+  if (!mesh) return 0;
+  return 12 * cellgrad_blocks(mesh);
+}
+
+int mipme_slab_forward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,
+                       const void* positions, const void* charges, void* moments, void* pot) {
+  MIPME_REQUIRE(mesh && axis >= 0 && axis < 3 && moments, "invalid arguments to mipme_slab_forward");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, slab_forward_t<float>(st, axis, mesh, prefactor, n_atoms, positions, charges, moments, pot),
+            slab_forward_t<double>(st, axis, mesh, prefactor, n_atoms, positions, charges, moments, pot));
+}
+
+int mipme_slab_backward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,
+                        const void* positions, const void* charges, const void* grad_out, void* moments,
+                        void* grad_positions, void* grad_charges, void* grad_cell) {
+  MIPME_REQUIRE(mesh && axis >= 0 && axis < 3 && moments && grad_out, "invalid arguments to mipme_slab_backward");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            slab_backward_t<float>(st, axis, mesh, prefactor, n_atoms, positions, charges, grad_out, moments,
+                                   grad_positions, grad_charges, grad_cell),
+            slab_backward_t<double>(st, axis, mesh, prefactor, n_atoms, positions, charges, grad_out, moments,
+                                    grad_positions, grad_charges, grad_cell));
+}
+
+#define IDX_SWITCH(dtype, idx, FN, ...)                                                   \
+  do {                                                                                    \
+    if ((dtype) == MIPME_F32 && (idx) == MIPME_I64) return FN<float, int64_t>(__VA_ARGS__);  \
+    if ((dtype) == MIPME_F32 && (idx) == MIPME_I32) return FN<float, int32_t>(__VA_ARGS__);  \
+    if ((dtype) == MIPME_F64 && (idx) == MIPME_I64) return FN<double, int64_t>(__VA_ARGS__); \
+    if ((dtype) == MIPME_F64 && (idx) == MIPME_I32) return FN<double, int32_t>(__VA_ARGS__); \
+    set_error("invalid dtype/index dtype %d/%d", int(dtype), int(idx));                   \
+    return MIPME_EINVAL;                                                                  \
+  } while (0)
+
+int mipme_rspace_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
+                         const void* pairs, const void* dist, const void* charges, const void* pair_mask,
+                         int full_list, const mipme_potential_t* pot, int accumulate, void* out_pot) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && n_channels > 0, "invalid sizes passed to mipme_rspace_forward");
+  MIPME_REQUIRE(n_atoms == 0 || out_pot, "out_pot is NULL");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs && dist && charges), "NULL pair buffer passed to mipme_rspace_forward");
+  hipStream_t st = (hipStream_t)stream;
+  IDX_SWITCH(dtype, idx_dtype, rspace_forward_impl, st, n_pairs, n_atoms, n_channels, pairs, dist, charges, pair_mask,
+             full_list, pot, accumulate, out_pot);
+}
+
+int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
+                          const void* pairs, const void* dist, const void* charges, const void* pair_mask,
+                          int full_list, const mipme_potential_t* pot, const void* grad_out, void* grad_dist,
+                          void* grad_charges) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && n_channels > 0, "invalid sizes passed to mipme_rspace_backward");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs && dist && charges && grad_out), "NULL pair buffer passed to mipme_rspace_backward");
+  hipStream_t st = (hipStream_t)stream;
+  IDX_SWITCH(dtype, idx_dtype, rspace_backward_impl, st, n_pairs, n_atoms, n_channels, pairs, dist, charges, pair_mask,
+             full_list, pot, grad_out, grad_dist, grad_charges);
+}
+
+int mipme_pair_distance_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, const void* pairs,
+                                const void* positions, const void* cell, const void* shifts, void* out_dist) {
+  MIPME_REQUIRE(n_pairs >= 0, "invalid n_pairs");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs && positions && out_dist), "NULL buffer passed to mipme_pair_distance_forward");
+  MIPME_REQUIRE((cell == nullptr) == (shifts == nullptr), "`cell` and `shifts` must be given together");
+  hipStream_t st = (hipStream_t)stream;
+  IDX_SWITCH(dtype, idx_dtype, distance_forward_impl, st, n_pairs, pairs, positions, cell, shifts, out_dist);
+}
+
+int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms,
+                                 const void* pairs, const void* positions, const void* cell, const void* shifts,
+                                 const void* grad_dist, void* partials, void* grad_positions, void* grad_cell) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0, "invalid sizes");
+  MIPME_REQUIRE(grad_positions || n_atoms == 0, "grad_positions is NULL");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs && positions && grad_dist), "NULL buffer passed to mipme_pair_distance_backward");
+  MIPME_REQUIRE((cell == nullptr) == (shifts == nullptr), "`cell` and `shifts` must be given together");
+  MIPME_REQUIRE(!grad_cell || cell, "cell gradient requested without a cell");
+  hipStream_t st = (hipStream_t)stream;
+  IDX_SWITCH(dtype, idx_dtype, distance_backward_impl, st, n_pairs, n_atoms, pairs, positions, cell, shifts, grad_dist,
+             partials, grad_positions, grad_cell);
+}
+
+int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// Internal helpers shared by the libmipme translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mipme.h"
+
+namespace mipme {
+
+void set_error(const char* fmt, ...);
+
+#define MIPME_CHECK_HIP(expr)                                                                 \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      mipme::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return MIPME_EHIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define MIPME_REQUIRE(cond, ...)     \
+  do {                               \
+    if (!(cond)) {                   \
+      mipme::set_error(__VA_ARGS__); \
+      return MIPME_EINVAL;           \
+    }                                \
+  } while (0)
+
+#define MIPME_LAUNCH_CHECK() MIPME_CHECK_HIP(hipGetLastError())
+
+// Geometry handed to kernels by value (fits the kernarg segment; no device-side cell read).
+struct Geom {
+  double inv[9];  // inverse cell, row-major: u_d = n_d * sum_c r_c inv[c][d]
+  int nx, ny, nz;
+};
+
+inline Geom make_geom(const mipme_mesh_t* m) {
+  Geom g;
+  for (int i = 0; i < 9; ++i) g.inv[i] = m->inv_cell[i];
+  g.nx = m->nx;
+  g.ny = m->ny;
+  g.nz = m->nz;
+  return g;
+}
+
+inline int validate_mesh(const mipme_mesh_t* m) {
+  MIPME_REQUIRE(m != nullptr, "mesh descriptor is NULL");
+  MIPME_REQUIRE(m->nx > 0 && m->ny > 0 && m->nz > 0, "mesh sizes must be positive, got %d %d %d", m->nx, m->ny, m->nz);
+  MIPME_REQUIRE(m->n_channels > 0, "n_channels must be positive");
+  if (m->scheme == MIPME_LAGRANGE) {
+    MIPME_REQUIRE(m->order >= 3 && m->order <= 7,
+                  "`interpolation_nodes` is %d but only values from 3 to 7 for method 'Lagrange' are allowed", m->order);
+  } else if (m->scheme == MIPME_P3M) {
+    MIPME_REQUIRE(m->order >= 1 && m->order <= 5,
+                  "`interpolation_nodes` is %d but only values from 1 to 5 for method 'P3M' are allowed", m->order);
+  } else {
+    MIPME_REQUIRE(false, "unknown interpolation scheme %d", m->scheme);
+  }
+  return MIPME_OK;
+}
+
+// Hardware float atomics (global_atomic_add_f32 / _f64 on gfx950; memory is coarse-grained hipMalloc).
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ int posmod(int a, int n) {
+  int r = a % n;
+  return r < 0 ? r + n : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-D interpolation weights, generated from their defining rules rather
+// than from expanded polynomial tables (the reference stores those: lib/mesh_interpolator.py:156-301).
+//   P3M      : w_t(x) = M_n(t - (n-1)/2 - x), centred cardinal B-spline of order n.
+//              With f = x + 1/2 and N_k the cardinal B-spline on [0,k]: w_t = N_n(f + n-1-t),
+//              N_k(y) = [y N_{k-1}(y) + (k-y) N_{k-1}(y-1)]/(k-1),  N_n'(y) = N_{n-1}(y) - N_{n-1}(y-1).
+//   Lagrange : nodes xi_t = t - (n-1)/2,  w_t(x) = prod_{s!=t} (x - xi_s)/(xi_t - xi_s).
+// x in [-1/2, 1/2].  `DERIV` also fills dw/dx.
+// ---------------------------------------------------------------------------------------------
+template <int SCHEME, int N, bool DERIV, typename T>
+__device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
+  if constexpr (SCHEME == MIPME_P3M) {
+    if constexpr (N == 1) {
+      w[0] = T(1);
+      dw[0] = T(0);
+    } else {
+      const T f = x + T(0.5);
+      T a[N];
+      T b[N];
+      a[0] = T(1);
+#pragma unroll
+      for (int j = 1; j < N; ++j) a[j] = T(0);
+#pragma unroll
+      for (int k = 2; k <= N; ++k) {
+        if (k == N) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) b[j] = (j < N - 1) ? a[j] : T(0);
+        }
+        const T inv = T(1) / T(k - 1);
+#pragma unroll
+        for (int j = k - 1; j >= 0; --j) {
+          const T lo = (j < k - 1) ? a[j] : T(0);
+          const T hi = (j >= 1) ? a[j - 1] : T(0);
+          a[j] = ((f + T(j)) * lo + (T(k - j) - f) * hi) * inv;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < N; ++t) {
+        w[t] = a[N - 1 - t];
+        if constexpr (DERIV) dw[t] = b[N - 1 - t] - ((N - 2 - t >= 0) ? b[(N - 2 - t >= 0) ? N - 2 - t : 0] : T(0));
+      }
+    }
+  } else {
+    T e[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) e[s] = x - (T(s) - T(0.5) * T(N - 1));
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      // den = prod_{s != t} (t - s) = (-1)^(N-1-t) t! (N-1-t)!
+      double den = 1.0;
+      for (int s = 0; s < N; ++s)
+        if (s != t) den *= double(t - s);
+      T p = T(1), dp = T(0);
+#pragma unroll
+      for (int s = 0; s < N; ++s) {
+        if (s != t) {
+          if constexpr (DERIV) dp = dp * e[s] + p;
+          p = p * e[s];
+        }
+      }
+      const T rden = T(1.0 / den);
+      w[t] = p * rden;
+      if constexpr (DERIV) dw[t] = dp * rden;
+    }
+  }
+}
+
+// Register-array select with a runtime index (keeps the arrays in VGPRs).
+template <int N, typename T>
+__device__ __forceinline__ T pick(const T (&a)[N], int idx) {
+  T r = a[0];
+#pragma unroll
+  for (int t = 1; t < N; ++t) r = (idx == t) ? a[t] : r;
+  return r;
+}
+
+// Fractional mesh coordinate -> base index m and offset x in [-1/2,1/2]
+// (lib/mesh_interpolator.py:326-341: even n -> floor, x = u-(m+1/2); odd n -> round-half-even, x = u-m).
+template <int N>
+__device__ __forceinline__ void split_coordinate(double u, int& m, double& x) {
+  if constexpr (N % 2 == 0) {
+    const double fl = floor(u);
+    m = int(fl);
+    x = u - (fl + 0.5);
+  } else {
+    const double r = rint(u);  // round-half-even
+    m = int(r);
+    x = u - r;
+  }
+}
+
+// first stencil offset: range(1-(n+1)//2, 1+n//2)
+template <int N>
+__device__ __forceinline__ constexpr int stencil_start() {
+  return 1 - (N + 1) / 2;
+}
+
+template <int N>
+struct StencilGroup {
+  // lanes cooperating on one atom: (ty,tz) plane of the stencil, padded to a power of two
+  static constexpr int PLANE = N * N;
+  static constexpr int LANES = PLANE <= 1 ? 1 : PLANE <= 4 ? 4 : PLANE <= 16 ? 16 : PLANE <= 32 ? 32 : 64;
+};
+
+}  // namespace mipme

@@ -1,0 +1,487 @@
+// Reciprocal-space part: G(k) table, hipFFT R2C -> * G -> C2R, and the k-grid reductions of the
+// cell gradient.
+//
+// Replaces generate_kvectors_for_mesh (reference lib/kvectors.py:24-74), KSpaceFilter.update/forward
+// (lib/kspace_filter.py:97-197), P3MKSpaceFilter.update/_compute_influence/_charge_assignment
+// (lib/kspace_filter.py:293-329,349-361) and Potential.lr_from_k_sq (potentials/coulomb.py:122-142,
+// potentials/inversepowerlaw.py:109-141, lib/math.py:85-104).  The reference materialises the
+// (nx,ny,nz/2+1,3) k-vector grid and k^2; here every thread derives its k-vector from its index.
+#include <hipfft/hipfft.h>
+
+#include <cmath>
+#include <new>
+
+#include "common.h"
+
+namespace mipme {
+
+static constexpr double kPi = 3.14159265358979323846;
+
+struct KGeom {
+  double inv[9];  // inverse cell
+  double h[3];    // |a_c| / n_c (P3M charge-assignment spacing, kspace_filter.py:308-311)
+  int nx, ny, nz, nzh;
+  int scheme, order;
+};
+
+struct KPot {
+  int p;          // exponent
+  double c0;      // prefactor * pi^1.5 / Gamma(p/2) * (2 sigma^2)^((3-p)/2)
+  double hs2;     // sigma^2 / 2
+  double a;       // (3-p)/2
+  double k0;      // value at k = 0
+};
+
+static inline KGeom make_kgeom(const mipme_mesh_t* m) {
+  KGeom g;
+  for (int i = 0; i < 9; ++i) g.inv[i] = m->inv_cell[i];
+  const int ns[3] = {m->nx, m->ny, m->nz};
+  for (int c = 0; c < 3; ++c) {
+    const double* a = m->cell + 3 * c;
+    g.h[c] = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) / double(ns[c]);
+  }
+  g.nx = m->nx;
+  g.ny = m->ny;
+  g.nz = m->nz;
+  g.nzh = m->nz / 2 + 1;
+  g.scheme = m->scheme;
+  g.order = m->order;
+  return g;
+}
+
+static inline int make_kpot(const mipme_potential_t* pot, KPot& k) {
+  MIPME_REQUIRE(pot != nullptr, "potential descriptor is NULL");
+  MIPME_REQUIRE(pot->smearing > 0, "`smearing` is %g but must be positive", pot->smearing);
+  k.p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  MIPME_REQUIRE(k.p >= 1 && k.p <= 6, "Unsupported exponent: %d", k.p);
+  k.a = 0.5 * (3 - k.p);
+  const double two_s2 = 2.0 * pot->smearing * pot->smearing;
+  k.c0 = pot->prefactor * std::pow(kPi, 1.5) / std::tgamma(0.5 * k.p) * std::pow(two_s2, k.a);
+  k.hs2 = 0.5 * pot->smearing * pot->smearing;
+  k.k0 = k.p > 3 ? -k.c0 / k.a : 0.0;
+  return MIPME_OK;
+}
+
+// E1(z), z > 0: power series for z <= 1, continued fraction (backward recurrence) above.
+__device__ inline double exp1_dev(double z) {
+  if (z <= 1.0) {
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 40; ++k) {
+      term *= -z * double(k) / (double(k + 1) * double(k + 1));
+      sum += term;
+      if (fabs(term) <= fabs(sum) * 1e-17) break;
+    }
+    return -0.57721566490153286061 - log(z) + z * sum;
+  }
+  const int m = 20 + int(80.0 / z);
+  double t = 0.0;
+  for (int k = m; k >= 1; --k) t = double(k) / (1.0 + double(k) / (z + t));
+  return exp(-z) / (z + t);
+}
+
+// f_p(z) = Gamma(a, z) / z^a with a = (3-p)/2 (closed forms for integer p) and its derivative
+// f_p' = -(exp(-z) + a f_p)/z.
+__device__ inline void lr_kernel_dev(const KPot& kp, double k2, double& v, double& dv_dk2) {
+  if (k2 == 0.0) {
+    v = kp.k0;
+    dv_dk2 = 0.0;
+    return;
+  }
+  const double z = kp.hs2 * k2;
+  const double ez = exp(-z);
+  double f;
+  switch (kp.p) {
+    case 1: f = ez / z; break;
+    case 2: f = sqrt(kPi / z) * erfc(sqrt(z)); break;
+    case 3: f = exp1_dev(z); break;
+    case 4: f = 2.0 * (ez - sqrt(kPi * z) * erfc(sqrt(z))); break;
+    case 5: f = ez - z * exp1_dev(z); break;
+    default: f = ((2.0 - 4.0 * z) * ez + 4.0 * sqrt(kPi * z * z * z) * erfc(sqrt(z))) / 3.0; break;
+  }
+  v = kp.c0 * f;
+  dv_dk2 = kp.c0 * (-(ez + kp.a * f) / z) * kp.hs2;
+}
+
+__device__ inline int fft_freq(int i, int n) { return i < (n + 1) / 2 ? i : i - n; }
+
+struct KPoint {
+  double k[3];
+  int f[3];
+  double G, dGdk[3], dGdh[3];
+};
+
+template <bool DERIV>
+__device__ inline void eval_point(const KGeom& g, const KPot& kp, int ix, int iy, int iz, KPoint& o) {
+  o.f[0] = fft_freq(ix, g.nx);
+  o.f[1] = fft_freq(iy, g.ny);
+  o.f[2] = iz;
+  double k2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o.k[c] = 2.0 * kPi * (o.f[0] * g.inv[3 * c + 0] + o.f[1] * g.inv[3 * c + 1] + o.f[2] * g.inv[3 * c + 2]);
+    k2 += o.k[c] * o.k[c];
+  }
+  double v, dv;
+  lr_kernel_dev(kp, k2, v, dv);
+  if (g.scheme == MIPME_LAGRANGE) {
+    o.G = v;
+    if constexpr (DERIV) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o.dGdk[c] = 2.0 * o.k[c] * dv;
+        o.dGdh[c] = 0.0;
+      }
+    }
+    return;
+  }
+  double s = 1.0, t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    t[c] = 0.5 * o.k[c] * g.h[c];
+    s *= (t[c] == 0.0) ? 1.0 : sin(t[c]) / t[c];
+  }
+  double U2 = 1.0;
+  const double s2 = s * s;
+  for (int i = 0; i < g.order; ++i) U2 *= s2;
+  if (U2 == 0.0) {
+    o.G = 0.0;
+    if constexpr (DERIV) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o.dGdk[c] = o.dGdh[c] = 0.0;
+    }
+    return;
+  }
+  const double inv = 1.0 / U2;
+  o.G = v * inv;
+  if constexpr (DERIV) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double tc = t[c];
+      // d/dt ln(sin t / t) = cot t - 1/t
+      const double L = fabs(tc) < 1e-4 ? (-tc / 3.0 - tc * tc * tc / 45.0) : (cos(tc) / sin(tc) - 1.0 / tc);
+      const double w = o.G * double(2 * g.order) * L;
+      o.dGdk[c] = 2.0 * o.k[c] * dv * inv - w * 0.5 * g.h[c];
+      o.dGdh[c] = -w * 0.5 * o.k[c];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kfilter_kernel(KGeom g, KPot kp, T* __restrict__ G) {
+  const int64_t Mh = int64_t(g.nx) * g.ny * g.nzh;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= Mh) return;
+  const int iz = int(t % g.nzh);
+  const int64_t r = t / g.nzh;
+  const int iy = int(r % g.ny);
+  const int ix = int(r / g.ny);
+  KPoint o;
+  eval_point<false>(g, kp, ix, iy, iz, o);
+  G[t] = T(o.G);
+}
+
+// hat_work = hat * G ; dc[c] = Re hat[c, 0]
+template <typename T>
+__global__ __launch_bounds__(256) void apply_filter_kernel(int64_t Mh, int C, const T* __restrict__ hat,
+                                                          const T* __restrict__ G, T* __restrict__ out,
+                                                          T* __restrict__ dc) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= Mh) return;
+  const T gk = G[t];
+  for (int c = 0; c < C; ++c) {
+    const int64_t o = 2 * (c * Mh + t);
+    const T re = hat[o], im = hat[o + 1];
+    out[o] = re * gk;
+    out[o + 1] = im * gk;
+    if (t == 0 && dc) dc[c] = re;
+  }
+}
+
+// Backward variant: also accumulates, per block, the 12 k-grid sums of the cell gradient
+//   K[c][d] = 2 pi sum_k dL/dG(k) dG/dk_c f_d ,  H[c] = sum_k dL/dG(k) dG/dh_c ,
+//   dL/dG(k) = mu(k) sum_ch Re[rho^_ch(k) conj psi^_ch(k)]          
+template <typename T>
+__global__ __launch_bounds__(256) void apply_filter_cellgrad_kernel(KGeom g, KPot kp, int C,
+                                                                   const T* __restrict__ psi_hat,
+                                                                   const T* __restrict__ rho_hat,
+                                                                   const T* __restrict__ G, T* __restrict__ out,
+                                                                   T* __restrict__ dc, double* __restrict__ partials) {
+  const int64_t Mh = int64_t(g.nx) * g.ny * g.nzh;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+  if (t < Mh) {
+    const int iz = int(t % g.nzh);
+    const int64_t r = t / g.nzh;
+    const int iy = int(r % g.ny);
+    const int ix = int(r / g.ny);
+    const T gk = G[t];
+    double dLdG = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const int64_t o = 2 * (c * Mh + t);
+      const T re = psi_hat[o], im = psi_hat[o + 1];
+      out[o] = re * gk;
+      out[o + 1] = im * gk;
+      if (t == 0 && dc) dc[c] = re;
+      dLdG += double(rho_hat[o]) * double(re) + double(rho_hat[o + 1]) * double(im);
+    }
+    const bool edge = (iz == 0) || ((g.nz % 2 == 0) && (iz == g.nz / 2));
+    dLdG *= edge ? 1.0 : 2.0;
+    KPoint p;
+    eval_point<true>(g, kp, ix, iy, iz, p);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[3 * c + d] = 2.0 * kPi * dLdG * p.dGdk[c] * double(p.f[d]);
+      acc[9 + c] = dLdG * p.dGdh[c];
+    }
+  }
+  __shared__ double red[4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    partials[int64_t(blockIdx.x) * 12 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+// Single-block finalisation of dL/dcell:
+//   D = r^T T + K,  T = grad_pos A^T ;  gA = -Ainv^T D Ainv^T + rows[(H_c/(|a_c| n_c)) a_c] + dL/dV * V * Ainv^T
+//   dL/dV = -(1/V) sum_ic g_ic/2 Phi_ic + (2 bg / V) sum_c Q_c dc(psi_c)
+template <typename T>
+__global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m, double bg, int64_t n_atoms, int nblocks,
+                                                                const double* __restrict__ partials,
+                                                                const T* __restrict__ pos,
+                                                                const T* __restrict__ grad_pos,
+                                                                const T* __restrict__ gout, const T* __restrict__ phi_atoms,
+                                                                const T* __restrict__ rho_dc, const T* __restrict__ psi_dc,
+                                                                T* __restrict__ grad_cell) {
+  constexpr int NV = 22;  // 12 k-grid sums, 9 r^T grad_pos, 1 sum g*Phi/2
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] += partials[int64_t(b) * 12 + i];
+  }
+  const int C = m.n_channels;
+  for (int64_t a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+    const double r[3] = {double(pos[3 * a]), double(pos[3 * a + 1]), double(pos[3 * a + 2])};
+    const double gp[3] = {double(grad_pos[3 * a]), double(grad_pos[3 * a + 1]), double(grad_pos[3 * a + 2])};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) acc[12 + 3 * c + e] += r[c] * gp[e];
+    for (int c = 0; c < C; ++c) acc[21] += 0.5 * double(gout[a * C + c]) * double(phi_atoms[a * C + c]);
+  }
+  __shared__ double red[16][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[NV];
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < NV; ++i) {
+      double v = 0.0;
+      for (int w = 0; w < nw; ++w) v += red[w][i];
+      s[i] = v;
+    }
+    const double* A = m.cell;
+    const double* Ai = m.inv_cell;
+    double D[9];
+    // R = R' A^T : R[c][d] = sum_e R'[c][e] A[d][e]
+    for (int c = 0; c < 3; ++c)
+      for (int d = 0; d < 3; ++d) {
+        double v = 0.0;
+        for (int e = 0; e < 3; ++e) v += s[12 + 3 * c + e] * A[3 * d + e];
+        D[3 * c + d] = v + s[3 * c + d];
+      }
+    double sumQ = 0.0;
+    for (int c = 0; c < C; ++c) sumQ += double(rho_dc[c]) * double(psi_dc[c]);
+    const double dLdV = -s[21] / m.volume + 2.0 * bg / m.volume * sumQ;
+    const int ns[3] = {m.nx, m.ny, m.nz};
+    for (int a = 0; a < 3; ++a) {
+      const double norm = sqrt(A[3 * a] * A[3 * a] + A[3 * a + 1] * A[3 * a + 1] + A[3 * a + 2] * A[3 * a + 2]);
+      for (int b = 0; b < 3; ++b) {
+        double v = 0.0;
+        for (int c = 0; c < 3; ++c)
+          for (int d = 0; d < 3; ++d) v += Ai[3 * c + a] * D[3 * c + d] * Ai[3 * b + d];
+        double out = -v + dLdV * m.volume * Ai[3 * b + a];
+        out += s[9 + a] / (norm * double(ns[a])) * A[3 * a + b];
+        grad_cell[3 * a + b] = T(out);
+      }
+    }
+  }
+}
+
+// ---- hipFFT plans ------------------------------------------------------------------------------
+}  // namespace mipme
+
+struct mipme_fft_plan {
+  hipfftHandle fwd = 0, inv = 0;
+  int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
+};
+
+namespace mipme {
+
+static const char* fft_err(hipfftResult r) {
+  switch (r) {
+    case HIPFFT_SUCCESS: return "HIPFFT_SUCCESS";
+    case HIPFFT_INVALID_PLAN: return "HIPFFT_INVALID_PLAN";
+    case HIPFFT_ALLOC_FAILED: return "HIPFFT_ALLOC_FAILED";
+    case HIPFFT_INVALID_TYPE: return "HIPFFT_INVALID_TYPE";
+    case HIPFFT_INVALID_VALUE: return "HIPFFT_INVALID_VALUE";
+    case HIPFFT_INTERNAL_ERROR: return "HIPFFT_INTERNAL_ERROR";
+    case HIPFFT_EXEC_FAILED: return "HIPFFT_EXEC_FAILED";
+    case HIPFFT_SETUP_FAILED: return "HIPFFT_SETUP_FAILED";
+    case HIPFFT_INVALID_SIZE: return "HIPFFT_INVALID_SIZE";
+    default: return "HIPFFT_<other>";
+  }
+}
+
+#define MIPME_CHECK_FFT(expr)                                                           \
+  do {                                                                                  \
+    hipfftResult _r = (expr);                                                           \
+    if (_r != HIPFFT_SUCCESS) {                                                         \
+      mipme::set_error("%s failed: %s (%s:%d)", #expr, fft_err(_r), __FILE__, __LINE__); \
+      return MIPME_EFFT;                                                                \
+    }                                                                                   \
+  } while (0)
+
+int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {
+  MIPME_REQUIRE(out != nullptr, "plan output pointer is NULL");
+  MIPME_REQUIRE(nx > 0 && ny > 0 && nz > 0 && batch > 0, "invalid FFT dimensions %d %d %d x%d", nx, ny, nz, batch);
+  MIPME_REQUIRE(dtype == MIPME_F32 || dtype == MIPME_F64, "invalid dtype %d", dtype);
+  mipme_fft_plan* p = new (std::nothrow) mipme_fft_plan();
+  MIPME_REQUIRE(p != nullptr, "out of host memory");
+  p->dtype = dtype;
+  p->nx = nx;
+  p->ny = ny;
+  p->nz = nz;
+  p->batch = batch;
+  int n[3] = {nx, ny, nz};
+  int rembed[3] = {nx, ny, nz};
+  int cembed[3] = {nx, ny, nz / 2 + 1};
+  const int rdist = nx * ny * nz, cdist = nx * ny * (nz / 2 + 1);
+  hipfftResult r = hipfftPlanMany(&p->fwd, 3, n, rembed, 1, rdist, cembed, 1, cdist,
+                                  dtype == MIPME_F32 ? HIPFFT_R2C : HIPFFT_D2Z, batch);
+  if (r == HIPFFT_SUCCESS)
+    r = hipfftPlanMany(&p->inv, 3, n, cembed, 1, cdist, rembed, 1, rdist, dtype == MIPME_F32 ? HIPFFT_C2R : HIPFFT_Z2D,
+                       batch);
+  if (r != HIPFFT_SUCCESS) {
+    set_error("hipfftPlanMany(%d,%d,%d x%d) failed: %s", nx, ny, nz, batch, fft_err(r));
+    if (p->fwd) hipfftDestroy(p->fwd);
+    if (p->inv) hipfftDestroy(p->inv);
+    delete p;
+    return MIPME_EFFT;
+  }
+  *out = p;
+  return MIPME_OK;
+}
+
+struct FftDims { int dtype, nx, ny, nz, batch; };
+FftDims fft_plan_dims(const mipme_fft_plan* p) { return FftDims{p->dtype, p->nx, p->ny, p->nz, p->batch}; }
+
+int fft_plan_destroy(mipme_fft_plan* p) {
+  if (!p) return MIPME_OK;
+  if (p->fwd) hipfftDestroy(p->fwd);
+  if (p->inv) hipfftDestroy(p->inv);
+  delete p;
+  return MIPME_OK;
+}
+
+int fft_forward(mipme_fft_plan* p, hipStream_t st, const void* in, void* out) {
+  MIPME_CHECK_FFT(hipfftSetStream(p->fwd, st));
+  if (p->dtype == MIPME_F32)
+    MIPME_CHECK_FFT(hipfftExecR2C(p->fwd, (hipfftReal*)in, (hipfftComplex*)out));
+  else
+    MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd, (hipfftDoubleReal*)in, (hipfftDoubleComplex*)out));
+  return MIPME_OK;
+}
+
+int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out) {
+  MIPME_CHECK_FFT(hipfftSetStream(p->inv, st));
+  if (p->dtype == MIPME_F32)
+    MIPME_CHECK_FFT(hipfftExecC2R(p->inv, (hipfftComplex*)in, (hipfftReal*)out));
+  else
+    MIPME_CHECK_FFT(hipfftExecZ2D(p->inv, (hipfftDoubleComplex*)in, (hipfftDoubleReal*)out));
+  return MIPME_OK;
+}
+
+template <typename T>
+int kfilter_build_impl(hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot, void* G) {
+  KPot kp;
+  int rc = make_kpot(pot, kp);
+  if (rc) return rc;
+  const KGeom g = make_kgeom(m);
+  const int64_t Mh = int64_t(g.nx) * g.ny * g.nzh;
+  kfilter_kernel<T><<<unsigned((Mh + 255) / 256), 256, 0, st>>>(g, kp, (T*)G);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int apply_filter_impl(hipStream_t st, int64_t Mh, int C, const void* hat, const void* G, void* out, void* dc) {
+  apply_filter_kernel<T><<<unsigned((Mh + 255) / 256), 256, 0, st>>>(Mh, C, (const T*)hat, (const T*)G, (T*)out, (T*)dc);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int64_t cellgrad_blocks(const mipme_mesh_t* m) {
+  const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+  return (Mh + 255) / 256;
+}
+
+template <typename T>
+int apply_filter_cellgrad_impl(hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot, const void* psi_hat,
+                               const void* rho_hat, const void* G, void* out, void* dc, void* partials) {
+  KPot kp;
+  int rc = make_kpot(pot, kp);
+  if (rc) return rc;
+  const KGeom g = make_kgeom(m);
+  apply_filter_cellgrad_kernel<T><<<unsigned(cellgrad_blocks(m)), 256, 0, st>>>(
+      g, kp, m->n_channels, (const T*)psi_hat, (const T*)rho_hat, (const T*)G, (T*)out, (T*)dc, (double*)partials);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int64_t n_atoms, const void* partials,
+                           const void* pos, const void* grad_pos, const void* gout, const void* phi_atoms,
+                           const void* rho_dc, const void* psi_dc, void* grad_cell) {
+  cellgrad_finalize_kernel<T><<<1, 1024, 0, st>>>(*m, bg, n_atoms, int(cellgrad_blocks(m)), (const double*)partials,
+                                                 (const T*)pos, (const T*)grad_pos, (const T*)gout,
+                                                 (const T*)phi_atoms, (const T*)rho_dc, (const T*)psi_dc,
+                                                 (T*)grad_cell);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template int kfilter_build_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template int kfilter_build_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template int apply_filter_impl<float>(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
+template int apply_filter_impl<double>(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
+template int apply_filter_cellgrad_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*,
+                                               const void*, const void*, void*, void*, void*);
+template int apply_filter_cellgrad_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*,
+                                                const void*, const void*, const void*, void*, void*, void*);
+template int cellgrad_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*,
+                                           const void*, const void*, const void*, const void*, const void*, void*);
+template int cellgrad_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*,
+                                            const void*, const void*, const void*, const void*, const void*, void*);
+
+}  // namespace mipme

@@ -1,0 +1,388 @@
+// Real-space pair kernels: the short-range pair sum, its adjoint, and the caller-side pair-distance op.
+//
+// Replaces Calculator._compute_rspace (reference calculators/calculator.py:43-87: sr_from_dist ->
+// charges[atom_js] gather -> two index_add_ -> /2, each an ATen op with a P-sized temporary) and the
+// elementwise potential functions of potentials/potential.py:59-138, potentials/coulomb.py:80-120,
+// potentials/inversepowerlaw.py:55-106.  One pass over the pair stream: 2 indices + 1 distance per pair
+// are read once (coalesced, 16-byte index loads), charges are gathered from the L2-resident (N,C) table,
+// and contributions are added with hardware float atomics.
+#include "common.h"
+
+namespace mipme {
+
+static constexpr double kPiR = 3.14159265358979323846;
+
+// Device-side description of v_SR(d)
+struct SRPot {
+  int mode;        // 0: bare v, 1: v - v_LR (range separated), 2: -v_LR * f_cut, 3: v * (1 - f_cut)
+  int p;           // exponent 1..6
+  double pref;
+  double inv_2s2;  // 1/(2 sigma^2)
+  double rx;       // exclusion radius
+  int deg;         // exclusion degree
+};
+
+static inline int make_srpot(const mipme_potential_t* pot, SRPot& s) {
+  MIPME_REQUIRE(pot != nullptr, "potential descriptor is NULL");
+  s.p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  MIPME_REQUIRE(s.p >= 1 && s.p <= 6, "Unsupported exponent: %d", s.p);
+  const bool smeared = pot->smearing > 0;
+  const bool excl = pot->exclusion_radius > 0;
+  s.mode = smeared ? (excl ? 2 : 1) : (excl ? 3 : 0);
+  s.pref = pot->prefactor;
+  s.inv_2s2 = smeared ? 0.5 / (pot->smearing * pot->smearing) : 0.0;
+  s.rx = pot->exclusion_radius;
+  s.deg = pot->exclusion_degree;
+  return MIPME_OK;
+}
+
+__device__ __forceinline__ float fexp(float x) { return expf(x); }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ float ferfc(float x) { return erfcf(x); }
+__device__ __forceinline__ double ferfc(double x) { return erfc(x); }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fsin(float x) { return sinf(x); }
+__device__ __forceinline__ double fsin(double x) { return sin(x); }
+__device__ __forceinline__ float fcos(float x) { return cosf(x); }
+__device__ __forceinline__ double fcos(double x) { return cos(x); }
+
+template <typename T>
+__device__ __forceinline__ T powi(T x, int n) {
+  T r = T(1);
+  for (int i = 0; i < n; ++i) r *= x;
+  return r;
+}
+
+// Q(p/2, x) regularised upper incomplete gamma and x^(p/2-1) e^-x / Gamma(p/2) for integer p in 1..6.
+//   integer a:      Q(a,x) = e^-x sum_{k<a} x^k/k!
+//   half-integer a: Q(1/2,x) = erfc(sqrt x);  Q(a+1,x) = Q(a,x) + x^a e^-x / Gamma(a+1)
+template <typename T>
+__device__ __forceinline__ void upper_gamma(int p, T x, T& Q, T& dens) {
+  const T ex = fexp(-x);
+  if ((p & 1) == 0) {
+    const int a = p / 2;  // 1,2,3
+    T term = T(1), sum = T(1);
+    for (int k = 1; k < a; ++k) {
+      term *= x / T(k);
+      sum += term;
+    }
+    Q = ex * sum;
+    dens = ex * term;  // x^(a-1)/(a-1)!
+  } else {
+    const T sx = fsqrt(x);
+    const T isp = T(0.56418958354775628695);  // 1/sqrt(pi) = 1/Gamma(1/2)
+    Q = ferfc(sx);
+    // term_k = x^(k-1/2) e^-x / Gamma(k+1/2)
+    T term = (x > T(0)) ? ex * isp / sx : T(0);  // k = 0: x^(-1/2)/Gamma(1/2)
+    dens = term;
+    for (int k = 1; k <= (p - 1) / 2; ++k) {
+      term *= x / (T(k) - T(0.5));
+      Q += term;
+      dens = term;
+    }
+  }
+}
+
+// v_SR(d) and dv_SR/dd (see oracle/pme_numpy.py::sr_pair for the derivation).
+template <typename T, bool DERIV>
+__device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
+  const T pref = T(s.pref);
+  const T dc = d > T(1e-15) ? d : T(1e-15);
+  const T inv = T(1) / dc;
+  const T invp = powi(inv, s.p);
+  T fc = T(0), dfc = T(0);
+  if (s.mode >= 2) {
+    const T rx = T(s.rx);
+    if (d < rx) {
+      const T arg = T(kPiR) * d / rx;
+      const T base = T(0.5) * (T(1) - fcos(arg));
+      fc = T(1) - powi(base, s.deg);
+      if constexpr (DERIV) dfc = -T(s.deg) * powi(base, s.deg - 1) * T(0.5) * T(kPiR) / rx * fsin(arg);
+    }
+  }
+  if (s.mode == 0 || s.mode == 3) {
+    const T vb = pref * invp;
+    const T dvb = -T(s.p) * vb * inv;
+    if (s.mode == 0) {
+      v = vb;
+      if constexpr (DERIV) dv = dvb;
+    } else {
+      v = vb * (T(1) - fc);
+      if constexpr (DERIV) dv = dvb * (T(1) - fc) - vb * dfc;
+    }
+    return;
+  }
+  const T x = dc * dc * T(s.inv_2s2);
+  T Q, dens;
+  upper_gamma<T>(s.p, x, Q, dens);
+  const T dxdd = T(2) * dc * T(s.inv_2s2);
+  if (s.mode == 1) {
+    v = pref * Q * invp;
+    if constexpr (DERIV) dv = pref * (-dens * dxdd * invp - T(s.p) * Q * invp * inv);
+  } else {
+    const T P = T(1) - Q;
+    const T vl = pref * P * invp;
+    v = -vl * fc;
+    if constexpr (DERIV) {
+      const T dvl = pref * (dens * dxdd * invp - T(s.p) * P * invp * inv);
+      dv = -(dvl * fc + vl * dfc);
+    }
+  }
+}
+
+template <typename I>
+__device__ __forceinline__ void load_pair(const I* __restrict__ pairs, int64_t p, int64_t& i, int64_t& j) {
+  if constexpr (sizeof(I) == 8) {
+    const longlong2 ij = reinterpret_cast<const longlong2*>(pairs)[p];
+    i = ij.x;
+    j = ij.y;
+  } else {
+    const int2 ij = reinterpret_cast<const int2*>(pairs)[p];
+    i = ij.x;
+    j = ij.y;
+  }
+}
+
+// ---- forward -----------------------------------------------------------------------------------
+template <typename T, typename I, int CT>
+__global__ __launch_bounds__(256) void rspace_forward_kernel(SRPot s, int64_t P, int Cdyn, const I* __restrict__ pairs,
+                                                            const T* __restrict__ dist, const T* __restrict__ q,
+                                                            const uint8_t* __restrict__ mask, bool full,
+                                                            T* __restrict__ out) {
+  const int C = CT > 0 ? CT : Cdyn;
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+    if (mask && !mask[p]) continue;
+    int64_t i, j;
+    load_pair<I>(pairs, p, i, j);
+    T v, dv;
+    sr_eval<T, false>(s, dist[p], v, dv);
+    v *= T(0.5);
+    for (int c = 0; c < C; ++c) {
+      atomic_add(out + i * C + c, q[j * C + c] * v);
+      if (!full) atomic_add(out + j * C + c, q[i * C + c] * v);
+    }
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void rspace_backward_kernel(SRPot s, int64_t P, int C, const I* __restrict__ pairs,
+                                                             const T* __restrict__ dist, const T* __restrict__ q,
+                                                             const uint8_t* __restrict__ mask, bool full,
+                                                             const T* __restrict__ g, T* __restrict__ grad_d,
+                                                             T* __restrict__ grad_q) {
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+    if (mask && !mask[p]) {
+      if (grad_d) grad_d[p] = T(0);
+      continue;
+    }
+    int64_t i, j;
+    load_pair<I>(pairs, p, i, j);
+    T v, dv;
+    sr_eval<T, true>(s, dist[p], v, dv);
+    T acc = T(0);
+    for (int c = 0; c < C; ++c) {
+      const T gi = g[i * C + c], gj = g[j * C + c];
+      acc += gi * q[j * C + c];
+      if (!full) acc += gj * q[i * C + c];
+      if (grad_q) {
+        atomic_add(grad_q + j * C + c, T(0.5) * v * gi);
+        if (!full) atomic_add(grad_q + i * C + c, T(0.5) * v * gj);
+      }
+    }
+    if (grad_d) grad_d[p] = T(0.5) * dv * acc;
+  }
+}
+
+// ---- pair distances (caller side, tests/helpers.py:278-304) ------------------------------------
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void distance_forward_kernel(int64_t P, const I* __restrict__ pairs,
+                                                              const T* __restrict__ pos, const T* __restrict__ cell,
+                                                              const T* __restrict__ shifts, T* __restrict__ out) {
+  T A[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+    int64_t i, j;
+    load_pair<I>(pairs, p, i, j);
+    T vx = pos[3 * j] - pos[3 * i], vy = pos[3 * j + 1] - pos[3 * i + 1], vz = pos[3 * j + 2] - pos[3 * i + 2];
+    if (shifts) {
+      const T sx = shifts[3 * p], sy = shifts[3 * p + 1], sz = shifts[3 * p + 2];
+      vx += sx * A[0] + sy * A[3] + sz * A[6];
+      vy += sx * A[1] + sy * A[4] + sz * A[7];
+      vz += sx * A[2] + sy * A[5] + sz * A[8];
+    }
+    out[p] = fsqrt(vx * vx + vy * vy + vz * vz);
+  }
+}
+
+template <typename T, typename I, bool CELLGRAD>
+__global__ __launch_bounds__(256) void distance_backward_kernel(int64_t P, const I* __restrict__ pairs,
+                                                               const T* __restrict__ pos, const T* __restrict__ cell,
+                                                               const T* __restrict__ shifts,
+                                                               const T* __restrict__ grad_d, T* __restrict__ grad_pos,
+                                                               double* __restrict__ partials) {
+  T A[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+    int64_t i, j;
+    load_pair<I>(pairs, p, i, j);
+    T vx = pos[3 * j] - pos[3 * i], vy = pos[3 * j + 1] - pos[3 * i + 1], vz = pos[3 * j + 2] - pos[3 * i + 2];
+    T sx = T(0), sy = T(0), sz = T(0);
+    if (shifts) {
+      sx = shifts[3 * p], sy = shifts[3 * p + 1], sz = shifts[3 * p + 2];
+      vx += sx * A[0] + sy * A[3] + sz * A[6];
+      vy += sx * A[1] + sy * A[4] + sz * A[7];
+      vz += sx * A[2] + sy * A[5] + sz * A[8];
+    }
+    const T d = fsqrt(vx * vx + vy * vy + vz * vz);
+    const T sc = grad_d[p] / d;
+    const T gx = sc * vx, gy = sc * vy, gz = sc * vz;
+    atomic_add(grad_pos + 3 * j + 0, gx);
+    atomic_add(grad_pos + 3 * j + 1, gy);
+    atomic_add(grad_pos + 3 * j + 2, gz);
+    atomic_add(grad_pos + 3 * i + 0, -gx);
+    atomic_add(grad_pos + 3 * i + 1, -gy);
+    atomic_add(grad_pos + 3 * i + 2, -gz);
+    if constexpr (CELLGRAD) {
+      acc[0] += double(sx * gx); acc[1] += double(sx * gy); acc[2] += double(sx * gz);
+      acc[3] += double(sy * gx); acc[4] += double(sy * gy); acc[5] += double(sy * gz);
+      acc[6] += double(sz * gx); acc[7] += double(sz * gy); acc[8] += double(sz * gz);
+    }
+  }
+  if constexpr (CELLGRAD) {
+    __shared__ double red[4][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+      partials[int64_t(blockIdx.x) * 9 + threadIdx.x] =
+          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+template <typename T>
+__global__ void reduce9_kernel(int nblocks, const double* __restrict__ partials, T* __restrict__ out) {
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] += partials[int64_t(b) * 9 + k];
+  __shared__ double red[4][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) out[threadIdx.x] = T(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------
+static constexpr int kPairGridMax = 256 * 16;  // 256 CUs x 16 blocks of 256 threads; grid-stride beyond
+
+static inline unsigned pair_grid(int64_t P) {
+  const int64_t b = (P + 255) / 256;
+  return unsigned(b < kPairGridMax ? (b > 0 ? b : 1) : kPairGridMax);
+}
+
+int64_t pair_partials_blocks(int64_t P) { return pair_grid(P); }
+
+template <typename T, typename I>
+int rspace_forward_impl(hipStream_t st, int64_t P, int64_t N, int C, const void* pairs, const void* dist, const void* q,
+                        const void* mask, int full, const mipme_potential_t* pot, int accumulate, void* out) {
+  SRPot s;
+  int rc = make_srpot(pot, s);
+  if (rc) return rc;
+  if (!accumulate) MIPME_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * size_t(N) * C, st));
+  if (P == 0) return MIPME_OK;
+  if (C == 1)
+    rspace_forward_kernel<T, I, 1><<<pair_grid(P), 256, 0, st>>>(s, P, C, (const I*)pairs, (const T*)dist, (const T*)q,
+                                                                 (const uint8_t*)mask, full != 0, (T*)out);
+  else
+    rspace_forward_kernel<T, I, 0><<<pair_grid(P), 256, 0, st>>>(s, P, C, (const I*)pairs, (const T*)dist, (const T*)q,
+                                                                 (const uint8_t*)mask, full != 0, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T, typename I>
+int rspace_backward_impl(hipStream_t st, int64_t P, int64_t N, int C, const void* pairs, const void* dist,
+                         const void* q, const void* mask, int full, const mipme_potential_t* pot, const void* g,
+                         void* grad_d, void* grad_q) {
+  SRPot s;
+  int rc = make_srpot(pot, s);
+  if (rc) return rc;
+  if (P == 0) return MIPME_OK;
+  rspace_backward_kernel<T, I><<<pair_grid(P), 256, 0, st>>>(s, P, C, (const I*)pairs, (const T*)dist, (const T*)q,
+                                                             (const uint8_t*)mask, full != 0, (const T*)g, (T*)grad_d,
+                                                             (T*)grad_q);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T, typename I>
+int distance_forward_impl(hipStream_t st, int64_t P, const void* pairs, const void* pos, const void* cell,
+                          const void* shifts, void* out) {
+  if (P == 0) return MIPME_OK;
+  distance_forward_kernel<T, I><<<pair_grid(P), 256, 0, st>>>(P, (const I*)pairs, (const T*)pos, (const T*)cell,
+                                                              (const T*)shifts, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T, typename I>
+int distance_backward_impl(hipStream_t st, int64_t P, int64_t N, const void* pairs, const void* pos, const void* cell,
+                           const void* shifts, const void* grad_d, void* partials, void* grad_pos, void* grad_cell) {
+  MIPME_CHECK_HIP(hipMemsetAsync(grad_pos, 0, sizeof(T) * size_t(N) * 3, st));
+  if (P == 0) {
+    if (grad_cell) MIPME_CHECK_HIP(hipMemsetAsync(grad_cell, 0, sizeof(T) * 9, st));
+    return MIPME_OK;
+  }
+  const unsigned grid = pair_grid(P);
+  if (grad_cell) {
+    MIPME_REQUIRE(partials != nullptr, "partials scratch required for the cell gradient");
+    distance_backward_kernel<T, I, true><<<grid, 256, 0, st>>>(P, (const I*)pairs, (const T*)pos, (const T*)cell,
+                                                               (const T*)shifts, (const T*)grad_d, (T*)grad_pos,
+                                                               (double*)partials);
+    MIPME_LAUNCH_CHECK();
+    reduce9_kernel<T><<<1, 256, 0, st>>>(int(grid), (const double*)partials, (T*)grad_cell);
+  } else {
+    distance_backward_kernel<T, I, false><<<grid, 256, 0, st>>>(P, (const I*)pairs, (const T*)pos, (const T*)cell,
+                                                                (const T*)shifts, (const T*)grad_d, (T*)grad_pos,
+                                                                nullptr);
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+#define MIPME_INST(T, I)                                                                                               \
+  template int rspace_forward_impl<T, I>(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*,    \
+                                         const void*, int, const mipme_potential_t*, int, void*);                     \
+  template int rspace_backward_impl<T, I>(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*,   \
+                                          const void*, int, const mipme_potential_t*, const void*, void*, void*);      \
+  template int distance_forward_impl<T, I>(hipStream_t, int64_t, const void*, const void*, const void*, const void*,   \
+                                           void*);                                                                     \
+  template int distance_backward_impl<T, I>(hipStream_t, int64_t, int64_t, const void*, const void*, const void*,      \
+                                            const void*, const void*, void*, void*, void*);
+MIPME_INST(float, int64_t)
+MIPME_INST(float, int32_t)
+MIPME_INST(double, int64_t)
+MIPME_INST(double, int32_t)
+
+}  // namespace mipme

@@ -1,0 +1,275 @@
+"""Autograd operators of the hot path, each a thin shim over the C-ABI of ``libmipme.so``.
+
+* :class:`MeshGeometry` -- host-side cell-derived quantities (what ``MeshInterpolator.update`` and
+  ``KSpaceFilter._prep_kvectors`` cache in the reference).
+* :func:`pme_potential` -- ``Calculator.forward`` (reference ``calculators/calculator.py:103-189`` with
+  ``calculators/pme.py:88-143``) as ONE autograd node: SR pair sum + mesh LR part, differentiable w.r.t.
+  charges, cell, positions and neighbor_distances (first order).
+* :func:`pair_distances` -- the caller-side distance op (reference ``tests/helpers.py:278-304``),
+  differentiable w.r.t. positions and cell.
+
+PyTorch is used for device memory, streams and the autograd tape only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class MeshGeometry:
+    """Cell-derived host quantities for one (cell, ns_mesh, scheme, order) combination."""
+
+    def __init__(self, cell_host: np.ndarray, ns, scheme: int, order: int):
+        A = np.ascontiguousarray(np.asarray(cell_host, dtype=np.float64).reshape(3, 3))
+        det = float(np.linalg.det(A))
+        if det == 0.0 or not np.isfinite(det):
+            raise ValueError(f"provided `cell` has a determinant of {det}, i.e. it is not a valid unit cell")
+        self.cell = A
+        self.inv_cell = np.linalg.inv(A)
+        self.volume = abs(det)
+        self.ns = tuple(int(n) for n in ns)
+        self.scheme = scheme
+        self.order = order
+
+    def desc(self, n_channels: int) -> _lib.MeshDesc:
+        d = _lib.MeshDesc()
+        d.scheme, d.order = self.scheme, self.order
+        d.nx, d.ny, d.nz = self.ns
+        d.n_channels = n_channels
+        d.cell[:] = self.cell.ravel().tolist()
+        d.inv_cell[:] = self.inv_cell.ravel().tolist()
+        d.volume = self.volume
+        return d
+
+    @property
+    def n_mesh(self) -> int:
+        return self.ns[0] * self.ns[1] * self.ns[2]
+
+    @property
+    def n_half(self) -> int:
+        return self.ns[0] * self.ns[1] * (self.ns[2] // 2 + 1)
+
+
+def ns_mesh_from_cell(cell_host: np.ndarray, mesh_spacing: float):
+    """2^ceil(log2(2 |a_d| / h + 1)) per axis (reference ``lib/kvectors.py:5-21``)."""
+    norms = np.linalg.norm(np.asarray(cell_host, dtype=np.float64).reshape(3, 3), axis=1)
+    return tuple(int(v) for v in 2 ** np.ceil(np.log2(2 * norms / mesh_spacing + 1)).astype(np.int64))
+
+
+def build_filter(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device) -> torch.Tensor:
+    """G(k) on the rfft half grid, computed on the device in fp64 and stored in ``dtype``."""
+    G = torch.empty((geom.ns[0], geom.ns[1], geom.ns[2] // 2 + 1), dtype=dtype, device=device)
+    md = geom.desc(1)
+    with torch.cuda.device(device):
+        _lib.check(
+            _lib.load().mipme_kfilter_build(
+                _lib.current_stream(device), _lib.dtype_code(dtype), C.byref(md), C.byref(pot_desc), G.data_ptr()
+            )
+        )
+    return G
+
+
+def _slab_axis(periodic_host):
+    if periodic_host is None:
+        return None
+    p = [bool(v) for v in periodic_host]
+    if sum(p) != 2:
+        return None
+    return p.index(False)
+
+
+class _PMEFunction(torch.autograd.Function):
+    """SR + LR per-atom potentials as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G, pot_desc,
+                full_list, slab_axis):
+        lib = _lib.load()
+        device, dtype = positions.device, positions.dtype
+        dt = _lib.dtype_code(dtype)
+        N, Cn = charges.shape
+        P = neighbor_indices.shape[0]
+        q = charges.detach().contiguous()
+        pos = positions.detach().contiguous()
+        dist = neighbor_distances.detach().contiguous()
+        pairs = neighbor_indices.contiguous()
+        mask = None if pair_mask is None else pair_mask.contiguous()
+        out = torch.empty((N, Cn), dtype=dtype, device=device)
+        need_cell = ctx.needs_input_grad[1]
+        saved = {}
+        with torch.cuda.device(device):
+            st = _lib.current_stream(device)
+            if geom is not None:
+                md = geom.desc(Cn)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
+                rho_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
+                phi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
+                rho_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                dc = torch.empty((Cn,), dtype=dtype, device=device)
+                phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
+                _lib.check(
+                    lib.mipme_kspace_forward(
+                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                        G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
+                        phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms),
+                    )
+                )
+                if slab_axis is not None:
+                    moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
+                    _lib.check(
+                        lib.mipme_slab_forward(st, dt, slab_axis, C.byref(md), pot_desc.prefactor, N, pos.data_ptr(),
+                                               q.data_ptr(), moments.data_ptr(), out.data_ptr())
+                    )
+                saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms)
+                accumulate = 1
+            else:
+                accumulate = 0
+            _lib.check(
+                lib.mipme_rspace_forward(
+                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                    _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
+                )
+            )
+        ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms")))
+        ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms = ctx.saved_tensors
+        geom, pot_desc = ctx.geom, ctx.pot_desc
+        need_q, need_cell, need_pos, need_dist = ctx.needs_input_grad[:4]
+        device, dtype = pos.device, pos.dtype
+        dt = _lib.dtype_code(dtype)
+        N, Cn = q.shape
+        P = pairs.shape[0]
+        g = grad_out.contiguous()
+        grad_q = grad_pos = grad_cell = grad_dist = None
+        with torch.cuda.device(device):
+            st = _lib.current_stream(device)
+            if geom is not None and (need_q or need_cell or need_pos):
+                md = geom.desc(Cn)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
+                psi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
+                chi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
+                psi_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                dc = torch.empty((Cn,), dtype=dtype, device=device)
+                if need_pos or need_cell:
+                    grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                if need_q:
+                    grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
+                partials = None
+                if need_cell:
+                    grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
+                    partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64, device=device)
+                _lib.check(
+                    lib.mipme_kspace_backward(
+                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
+                        _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
+                        chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
+                        _lib.ptr(grad_cell),
+                    )
+                )
+                if ctx.slab_axis is not None:
+                    moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
+                    _lib.check(
+                        lib.mipme_slab_backward(st, dt, ctx.slab_axis, C.byref(md), pot_desc.prefactor, N, pos.data_ptr(),
+                                                q.data_ptr(), g.data_ptr(), moments.data_ptr(), _lib.ptr(grad_pos),
+                                                _lib.ptr(grad_q), _lib.ptr(grad_cell))
+                    )
+                if not need_pos:
+                    grad_pos = None
+            elif need_q:
+                grad_q = torch.zeros((N, Cn), dtype=dtype, device=device)
+            if need_dist or need_q:
+                if need_dist:
+                    grad_dist = torch.empty((P,), dtype=dtype, device=device)
+                _lib.check(
+                    lib.mipme_rspace_backward(
+                        st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                        _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
+                        _lib.ptr(grad_q) if need_q else None,
+                    )
+                )
+            if geom is None:
+                if need_pos:
+                    grad_pos = torch.zeros((N, 3), dtype=dtype, device=device)
+                if need_cell:
+                    grad_cell = torch.zeros((3, 3), dtype=dtype, device=device)
+        return grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None
+
+
+def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
+                  full_list, slab_axis):
+    return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
+                              pot_desc, full_list, slab_axis)
+
+
+class _PairDistances(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, cell, neighbor_indices, shifts):
+        lib = _lib.load()
+        device, dtype = positions.device, positions.dtype
+        pos = positions.detach().contiguous()
+        pairs = neighbor_indices.contiguous()
+        cl = None if cell is None else cell.detach().contiguous()
+        sh = None if shifts is None else shifts.to(dtype).contiguous()
+        P = pairs.shape[0]
+        out = torch.empty((P,), dtype=dtype, device=device)
+        with torch.cuda.device(device):
+            _lib.check(
+                lib.mipme_pair_distance_forward(
+                    _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P,
+                    pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
+                )
+            )
+        ctx.save_for_backward(pos, cl, pairs, sh)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_d):
+        lib = _lib.load()
+        pos, cl, pairs, sh = ctx.saved_tensors
+        device, dtype = pos.device, pos.dtype
+        N, P = pos.shape[0], pairs.shape[0]
+        need_cell = cl is not None and ctx.needs_input_grad[1]
+        grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+        grad_cell = partials = None
+        if need_cell:
+            grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
+            partials = torch.empty((lib.mipme_pair_partials_size(P),), dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            _lib.check(
+                lib.mipme_pair_distance_backward(
+                    _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P, N,
+                    pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), grad_d.contiguous().data_ptr(),
+                    _lib.ptr(partials), grad_pos.data_ptr(), _lib.ptr(grad_cell),
+                )
+            )
+        return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
+
+
+def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None):
+    """``d[p] = |r_j - r_i + S_p @ cell|``, differentiable w.r.t. ``positions`` and ``cell``.
+
+    Counterpart of the reference's caller-side helper ``compute_distances``
+    (``tests/helpers.py:278-304``, ``examples/02-neighbor-lists-usage.py:141-164``)."""
+    if cell is not None and neighbor_shifts is None:
+        raise ValueError("Provided `cell` but no `neighbor_shifts`.")
+    if cell is None and neighbor_shifts is not None:
+        raise ValueError("Provided `neighbor_shifts` but no `cell`.")
+    _lib.require_device(positions, "positions")
+    return _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts)

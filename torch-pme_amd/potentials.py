@@ -1,0 +1,246 @@
+"""Pair potentials 1/r^p with Gaussian range separation (reference ``potentials/potential.py``,
+``potentials/coulomb.py``, ``potentials/inversepowerlaw.py``).
+
+Same constructor signatures, buffer names (``smearing``, ``prefactor``, ``exponent`` as float64
+buffers; ``exclusion_radius``, ``exclusion_degree`` attributes) and method names as the reference,
+so user code and ``state_dict`` round-trips carry over.  On the hot path the calculators do NOT call
+these Python methods: they hand :meth:`Potential._descriptor` to the fused HIP kernels
+(``csrc/rspace.hip`` evaluates v_SR and its derivative per pair, ``csrc/kfilter.hip`` evaluates the
+Fourier-space kernel per mesh point).  The elementwise methods below exist for inspection and plotting,
+as small closed-form tensor expressions.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+_SQRT_PI = math.sqrt(math.pi)
+
+
+def _reg_upper_gamma(p: int, x: torch.Tensor) -> torch.Tensor:
+    """Q(p/2, x) for integer p: finite sums (integer p/2) or erfc plus a finite sum (half-integer)."""
+    ex = torch.exp(-x)
+    if p % 2 == 0:
+        term = torch.ones_like(x)
+        total = torch.ones_like(x)
+        for k in range(1, p // 2):
+            term = term * x / k
+            total = total + term
+        return ex * total
+    sx = torch.sqrt(x)
+    q = torch.erfc(sx)
+    term = ex / (_SQRT_PI * sx.clamp(min=1e-300))
+    for k in range(1, (p - 1) // 2 + 1):
+        term = term * x / (k - 0.5)
+        q = q + term
+    return q
+
+
+class Potential(torch.nn.Module):
+    """Base interface of a pair potential (reference ``potentials/potential.py:4-212``).
+
+    :param smearing: length scale of the SR/LR split (``None``: no split, real-space only)
+    :param exclusion_radius: radius inside which the potential is smoothly switched off
+    :param exclusion_degree: exponent of the raised-cosine switch
+    :param prefactor: multiplicative prefactor (see :mod:`prefactors`)
+    """
+
+    _kind = None  # set by subclasses the HIP kernels know
+
+    def __init__(
+        self,
+        smearing: float | None = None,
+        exclusion_radius: float | None = None,
+        exclusion_degree: int = 1,
+        prefactor: float = 1.0,
+    ):
+        super().__init__()
+        if smearing is not None:
+            self.register_buffer("smearing", torch.tensor(smearing, dtype=torch.float64))
+        else:
+            self.smearing = None
+        self.exclusion_radius = exclusion_radius
+        self.exclusion_degree = exclusion_degree
+        self.register_buffer("prefactor", torch.tensor(prefactor, dtype=torch.float64))
+        self._host_cache = None
+
+    # ---- host-side view of the parameters (buffers may live on the device) -------------------
+    def _host_params(self):
+        """(smearing|None, prefactor, exponent) as Python floats; one D2H copy, then cached."""
+        key = (
+            None if self.smearing is None else (self.smearing.data_ptr(), self.smearing._version),
+            (self.prefactor.data_ptr(), self.prefactor._version),
+        )
+        if self._host_cache is None or self._host_cache[0] != key:
+            sm = None if self.smearing is None else float(self.smearing)
+            self._host_cache = (key, sm, float(self.prefactor), self._exponent_int())
+        return self._host_cache[1:]
+
+    def _exponent_int(self) -> int:
+        raise NotImplementedError
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._host_cache = None
+        return out
+
+    def _descriptor(self) -> _lib.PotentialDesc:
+        """The plain-C description consumed by libmipme (``mipme_potential_t``)."""
+        if self._kind is None:
+            raise TypeError(
+                f"{self.__class__.__name__} has no HIP kernel: the MI355X-native calculators support "
+                "CoulombPotential and InversePowerLawPotential"
+            )
+        sm, pref, p = self._host_params()
+        return _lib.PotentialDesc(
+            kind=self._kind,
+            exponent=p,
+            smearing=-1.0 if sm is None else sm,
+            prefactor=pref,
+            exclusion_radius=-1.0 if self.exclusion_radius is None else float(self.exclusion_radius),
+            exclusion_degree=int(self.exclusion_degree),
+        )
+
+    # ---- reference method surface ------------------------------------------------------------
+    def f_cutoff(self, dist: torch.Tensor, pair_mask: torch.Tensor | None = None) -> torch.Tensor:
+        """1 - ((1 - cos(pi r / r_excl)) / 2)^n inside the exclusion radius, 0 outside."""
+        if self.exclusion_radius is None:
+            raise ValueError("Cannot compute cutoff function when `exclusion_radius` is not set")
+        rx = self.exclusion_radius
+        inside = dist < rx
+        base = 0.5 * (1 - torch.cos(torch.pi * dist / rx))
+        out = torch.where(inside, 1 - base**self.exclusion_degree, torch.zeros_like(dist))
+        return out if pair_mask is None else out * pair_mask
+
+    def from_dist(self, dist, pair_mask=None):
+        raise NotImplementedError(f"from_dist is not implemented for {self.__class__.__name__}")
+
+    def lr_from_dist(self, dist, pair_mask=None):
+        raise NotImplementedError(f"lr_from_dist is not implemented for {self.__class__.__name__}")
+
+    def sr_from_dist(self, dist: torch.Tensor, pair_mask: torch.Tensor | None = None) -> torch.Tensor:
+        """V_SR = V - V_LR, or -V_LR * f_cut when an exclusion radius is set."""
+        if self.smearing is None:
+            raise ValueError("Cannot compute range-separated potential when `smearing` is not specified.")
+        if self.exclusion_radius is None:
+            return self.from_dist(dist, pair_mask=pair_mask) - self.lr_from_dist(dist, pair_mask=pair_mask)
+        return -self.lr_from_dist(dist, pair_mask=pair_mask) * self.f_cutoff(dist, pair_mask=pair_mask)
+
+    def lr_from_k_sq(self, k_sq):
+        raise NotImplementedError(f"lr_from_k_sq is not implemented for {self.__class__.__name__}")
+
+    def kernel_from_k_sq(self, k_sq: torch.Tensor) -> torch.Tensor:
+        return self.lr_from_k_sq(k_sq)
+
+    def self_contribution(self):
+        raise NotImplementedError(f"self_contribution is not implemented for {self.__class__.__name__}")
+
+    def background_correction(self):
+        raise NotImplementedError(f"background_correction is not implemented for {self.__class__.__name__}")
+
+    def pbc_correction(self, periodic, positions, cell, charges):
+        return self.prefactor * torch.zeros_like(charges)
+
+
+class _PowerLawPotential(Potential):
+    """Shared closed forms for 1/r^p, integer p in 1..6."""
+
+    _p = 1
+
+    def _exponent_int(self) -> int:
+        return self._p
+
+    def from_dist(self, dist: torch.Tensor, pair_mask: torch.Tensor | None = None) -> torch.Tensor:
+        out = dist.clamp(min=1e-15) ** (-self._p)
+        if pair_mask is not None:
+            out = out * pair_mask
+        return self.prefactor * out
+
+    def lr_from_dist(self, dist: torch.Tensor, pair_mask: torch.Tensor | None = None) -> torch.Tensor:
+        if self.smearing is None:
+            raise ValueError("Cannot compute long-range contribution without specifying `smearing`.")
+        d = dist.clamp(min=1e-12)
+        x = 0.5 * d * d / self.smearing**2
+        out = (1 - _reg_upper_gamma(self._p, x)) / d**self._p
+        if pair_mask is not None:
+            out = out * pair_mask
+        return self.prefactor * out
+
+    def lr_from_k_sq(self, k_sq: torch.Tensor) -> torch.Tensor:
+        if self.smearing is None:
+            raise ValueError("Cannot compute long-range kernel without specifying `smearing`.")
+        p = self._p
+        a = 0.5 * (3 - p)
+        c0 = math.pi**1.5 / math.gamma(0.5 * p) * (2 * self.smearing**2) ** a
+        zero = k_sq == 0
+        z = 0.5 * self.smearing**2 * torch.where(zero, torch.ones_like(k_sq), k_sq)
+        ez = torch.exp(-z)
+        if p == 1:
+            f = ez / z
+        elif p == 2:
+            f = torch.sqrt(torch.pi / z) * torch.erfc(torch.sqrt(z))
+        elif p == 4:
+            f = 2 * (ez - torch.sqrt(torch.pi * z) * torch.erfc(torch.sqrt(z)))
+        elif p == 6:
+            f = ((2 - 4 * z) * ez + 4 * torch.sqrt(torch.pi * z**3) * torch.erfc(torch.sqrt(z))) / 3
+        else:
+            raise NotImplementedError(
+                "the Python-side Fourier kernel for p = 3, 5 needs E1(z); it is evaluated in csrc/kfilter.hip "
+                "(use lib.KSpaceFilter to obtain it on the device)"
+            )
+        k0 = -c0 / a if p > 3 else 0.0
+        return self.prefactor * torch.where(zero, k0 * torch.ones_like(k_sq), c0 * f)
+
+    def self_contribution(self) -> torch.Tensor:
+        if self.smearing is None:
+            raise ValueError("Cannot compute self contribution without specifying `smearing`.")
+        ph = 0.5 * self._p
+        return self.prefactor / math.gamma(ph + 1) / (2 * self.smearing**2) ** ph
+
+    def background_correction(self) -> torch.Tensor:
+        if self.smearing is None:
+            raise ValueError("Cannot compute background correction without specifying `smearing`.")
+        p = self._p
+        if p >= 3:
+            return torch.zeros_like(self.smearing)
+        return self.prefactor * math.pi**1.5 * (2 * self.smearing**2) ** (0.5 * (3 - p)) / ((3 - p) * math.gamma(0.5 * p))
+
+
+class InversePowerLawPotential(_PowerLawPotential):
+    """1/r^p potential, p in 1..6 (reference ``potentials/inversepowerlaw.py:9-173``)."""
+
+    _kind = _lib.INVERSE_POWER_LAW
+
+    def __init__(
+        self,
+        exponent: int,
+        smearing: float | None = None,
+        exclusion_radius: float | None = None,
+        exclusion_degree: int = 1,
+        prefactor: float = 1.0,
+    ):
+        super().__init__(smearing, exclusion_radius, exclusion_degree, prefactor)
+        if exponent not in (1, 2, 3, 4, 5, 6):
+            raise ValueError(f"Unsupported exponent: {exponent}")
+        self.register_buffer("exponent", torch.tensor(exponent, dtype=torch.float64))
+        self._p = int(exponent)
+
+
+class CoulombPotential(_PowerLawPotential):
+    """Smoothed electrostatic 1/r potential (reference ``potentials/coulomb.py:43-171``)."""
+
+    _kind = _lib.COULOMB
+    _p = 1
+
+    def __init__(
+        self,
+        smearing: float | None = None,
+        exclusion_radius: float | None = None,
+        exclusion_degree: int = 1,
+        prefactor: float = 1.0,
+    ):
+        super().__init__(smearing, exclusion_radius, exclusion_degree, prefactor)

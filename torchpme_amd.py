@@ -1,0 +1,14 @@
+"""Import shim: the package directory is ``torch-pme_amd/`` (not a valid Python identifier), so this
+module loads it under the importable name ``torchpme_amd``."""
+
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "torch-pme_amd")
+_spec = importlib.util.spec_from_file_location(
+    "torchpme_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["torchpme_amd"] = _mod
+_spec.loader.exec_module(_mod)
