@@ -21,6 +21,25 @@ import torch
 from . import _lib
 
 
+# Optional per-call timing used by bench.py: when PROFILE is a dict, every C-ABI call below is bracketed by
+# HIP events recorded on the launch stream (torch.cuda.Event records on the current stream, which is the
+# stream handed to libmipme).  PROFILE[name] collects (start, end) event pairs.
+PROFILE = None
+
+
+def _call(name, fn, *args):
+    """Invoke a C-ABI entry point, raise on a non-zero status, optionally time it with HIP events."""
+    if PROFILE is None:
+        _lib.check(fn(*args))
+        return
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    _lib.check(fn(*args))
+    end.record()
+    PROFILE.setdefault(name, []).append((start, end))
+
+
 class MeshGeometry:
     """Cell-derived host quantities for one (cell, ns_mesh, scheme, order) combination."""
 
@@ -114,28 +133,26 @@ class _PMEFunction(torch.autograd.Function):
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
-                _lib.check(
-                    lib.mipme_kspace_forward(
+                _call(
+                    "kspace_forward", lib.mipme_kspace_forward,
                         plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                         G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
                         phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms),
-                    )
                 )
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
-                    _lib.check(
-                        lib.mipme_slab_forward(st, dt, slab_axis, C.byref(md), pot_desc.prefactor, N, pos.data_ptr(),
-                                               q.data_ptr(), moments.data_ptr(), out.data_ptr())
+                    _call(
+                        "slab_forward", lib.mipme_slab_forward, st, dt, slab_axis, C.byref(md), pot_desc.prefactor, N,
+                        pos.data_ptr(), q.data_ptr(), moments.data_ptr(), out.data_ptr(),
                     )
                 saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms)
                 accumulate = 1
             else:
                 accumulate = 0
-            _lib.check(
-                lib.mipme_rspace_forward(
-                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                    _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
-                )
+            _call(
+                "rspace_forward", lib.mipme_rspace_forward,
+                st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
             )
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms")))
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
@@ -173,21 +190,20 @@ class _PMEFunction(torch.autograd.Function):
                 if need_cell:
                     grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
                     partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64, device=device)
-                _lib.check(
-                    lib.mipme_kspace_backward(
+                _call(
+                    "kspace_backward", lib.mipme_kspace_backward,
                         plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                         g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
                         _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
                         chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
                         _lib.ptr(grad_cell),
-                    )
                 )
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
-                    _lib.check(
-                        lib.mipme_slab_backward(st, dt, ctx.slab_axis, C.byref(md), pot_desc.prefactor, N, pos.data_ptr(),
-                                                q.data_ptr(), g.data_ptr(), moments.data_ptr(), _lib.ptr(grad_pos),
-                                                _lib.ptr(grad_q), _lib.ptr(grad_cell))
+                    _call(
+                        "slab_backward", lib.mipme_slab_backward, st, dt, ctx.slab_axis, C.byref(md), pot_desc.prefactor,
+                        N, pos.data_ptr(), q.data_ptr(), g.data_ptr(), moments.data_ptr(), _lib.ptr(grad_pos),
+                        _lib.ptr(grad_q), _lib.ptr(grad_cell),
                     )
                 if not need_pos:
                     grad_pos = None
@@ -196,12 +212,11 @@ class _PMEFunction(torch.autograd.Function):
             if need_dist or need_q:
                 if need_dist:
                     grad_dist = torch.empty((P,), dtype=dtype, device=device)
-                _lib.check(
-                    lib.mipme_rspace_backward(
-                        st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                        _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
-                        _lib.ptr(grad_q) if need_q else None,
-                    )
+                _call(
+                    "rspace_backward", lib.mipme_rspace_backward,
+                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                    _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
+                    _lib.ptr(grad_q) if need_q else None,
                 )
             if geom is None:
                 if need_pos:
@@ -229,11 +244,10 @@ class _PairDistances(torch.autograd.Function):
         P = pairs.shape[0]
         out = torch.empty((P,), dtype=dtype, device=device)
         with torch.cuda.device(device):
-            _lib.check(
-                lib.mipme_pair_distance_forward(
+            _call(
+                "pair_distance_forward", lib.mipme_pair_distance_forward,
                     _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P,
                     pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
-                )
             )
         ctx.save_for_backward(pos, cl, pairs, sh)
         return out
@@ -252,12 +266,11 @@ class _PairDistances(torch.autograd.Function):
             grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
             partials = torch.empty((lib.mipme_pair_partials_size(P),), dtype=torch.float64, device=device)
         with torch.cuda.device(device):
-            _lib.check(
-                lib.mipme_pair_distance_backward(
+            _call(
+                "pair_distance_backward", lib.mipme_pair_distance_backward,
                     _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P, N,
                     pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), grad_d.contiguous().data_ptr(),
                     _lib.ptr(partials), grad_pos.data_ptr(), _lib.ptr(grad_cell),
-                )
             )
         return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
 
