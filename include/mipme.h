@@ -164,6 +164,37 @@ int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t
                                  const void* grad_dist, void* partials, void* grad_positions, void* grad_cell);
 int64_t mipme_pair_partials_size(int64_t n_pairs);
 
+/* ---- pair-list topology (build-side helper, no reference counterpart) ---------------------------
+ * Scattered float atomics are the slowest thing an MI355X does (~21 G/s); the reference's index_add_
+ * (calculators/calculator.py:78-84) and the scatter in the distance gradient are therefore restated as
+ * owner-computes row sums over a transposed pair list, built once per neighbour list:
+ *   row_ptr  int32[2N+1]: entries row_ptr[2a]..row_ptr[2a+1] have atom a as FIRST index (role i),
+ *                         row_ptr[2a+1]..row_ptr[2a+2] as SECOND index (role j); pair index ascending.
+ *   entries  int32[2P][2]: { other atom, pair index }.
+ * workspace: >= mipme_topology_workspace_bytes(P) bytes of device scratch. */
+int64_t mipme_topology_workspace_bytes(int64_t n_pairs);
+int mipme_topology_build(void* stream, int idx_dtype, int64_t n_pairs, int64_t n_atoms, const void* pairs,
+                         void* workspace, int64_t workspace_bytes, void* row_ptr, void* entries);
+/* packed[e] = 3 x int8 cell shift of entry e's pair; flag[0] != 0 if some shift is not an integer in [-127,127]. */
+int mipme_topology_pack_shifts(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
+                               void* packed, void* flag);
+
+/* Row form of mipme_rspace_forward (transpose = 0, src = charges) and of the charge-gradient part of
+ * mipme_rspace_backward (transpose = 1, src = upstream gradient):
+ *   out[a,c] (+)= 1/2 sum_{entries of a} src[other,c] v_SR(dist[p]).   accumulate = 0 overwrites. */
+int mipme_rspace_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, const void* row_ptr, const void* entries,
+                      const void* dist, const void* src, const void* pair_mask, int transpose, int full_list,
+                      const mipme_potential_t* pot, int accumulate, void* out_pot);
+
+/* Row form of mipme_pair_distance_backward: grad_positions (N,3) OVERWRITTEN.  packed_shifts (from
+ * mipme_topology_pack_shifts) or shifts (P,3 reals) supply the cell shifts; partials: float64 scratch of
+ * >= mipme_rows_partials_size(N) elements when grad_cell != NULL. */
+int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries,
+                                      const void* packed_shifts, const void* positions, const void* cell,
+                                      const void* shifts, const void* grad_dist, void* partials, void* grad_positions,
+                                      void* grad_cell);
+int64_t mipme_rows_partials_size(int64_t n_atoms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,6 +204,46 @@ def test_direct_molecules(golden_dir, p):
             np.testing.assert_allclose(V.cpu().numpy(), z[f"{nm}/V_excl"], rtol=1e-12, atol=2e-15)
 
 
+@pytest.mark.parametrize("mode", ["atomic", "rows"])
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_pair_modes(mode, full, idx_dtype, monkeypatch):
+    """Both accumulation strategies of the pair kernels (hardware atomics / owner-computes rows), half and full
+    lists, int64 and int32 indices, integer and non-integer shift tensors, with a pair mask: vs the oracle."""
+    from torchpme_amd import ops
+
+    monkeypatch.setattr(ops, "PAIR_MODE", mode)
+    rng = np.random.default_rng(7)
+    cell = np.array([[7.0, 0, 0], [0.7, 6.0, 0], [0.2, -0.5, 8.0]])
+    N = 150
+    pos = rng.uniform(-1, 8, (N, 3))
+    q = rng.normal(size=(N, 3))
+    rc, sm, h = 5.0, 1.1, 0.9  # rc > L/2: several images of the same pair
+    pairs, S, dist = tpa.neighbor_list(pos, cell, rc, full_list=full)
+    mask = rng.uniform(size=len(pairs)) > 0.2
+    spec = O.PotentialSpec("coulomb", 1, sm, 0.7)
+    g = rng.normal(size=(N, 3))
+    Vo, cache = O.forward(spec, "P3M", 3, h, q, cell, pos, pairs, dist, full_list=full, pair_mask=mask, return_cache=True)
+    gr = O.backward(cache, g)
+    gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=sm, prefactor=0.7), mesh_spacing=h, interpolation_nodes=3,
+                             full_neighbor_list=full)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=torch.float64, requires_grad=grad)  # noqa: E731
+    tq, tc, tp = t(q, True), t(cell, True), t(pos, True)
+    ti = torch.tensor(pairs, device=DEV, dtype=idx_dtype)
+    for shifts in (torch.tensor(S, device=DEV), t(S)):  # int64 (converted) and float shifts
+        for x in (tq, tc, tp):
+            x.grad = None
+        d = tpa.pair_distances(tp, ti, tc, shifts)
+        np.testing.assert_allclose(d.detach().cpu().numpy(), dist, rtol=1e-13)
+        V = calc(tq, tc, tp, ti, d, pair_mask=torch.tensor(mask, device=DEV))
+        (V * t(g)).sum().backward()
+        assert rell2(V.detach().cpu(), Vo) < 1e-11
+        assert rell2(tq.grad.cpu(), gr["charges"]) < 1e-11
+        assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+        assert relmax(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+
+
 def test_native_library_loaded():
     """The tests above must have run through libmipme.so (no silent fallback exists)."""
     with open("/proc/self/maps") as f:

@@ -26,7 +26,8 @@ EXPORTS = (
     "mipme_convolve", "mipme_spread", "mipme_gather", "mipme_kspace_forward", "mipme_kspace_backward",
     "mipme_cellgrad_partials_size", "mipme_slab_forward", "mipme_slab_backward", "mipme_rspace_forward",
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
-    "mipme_pair_partials_size",
+    "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
+    "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size",
 )
 
 
@@ -85,6 +86,10 @@ def _declare(lib):
         "mipme_rspace_backward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, vp, vp, vp],
         "mipme_pair_distance_forward": [vp, ci, ci, i64, vp, vp, vp, vp, vp],
         "mipme_pair_distance_backward": [vp, ci, ci, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_topology_build": [vp, ci, i64, i64, vp, vp, i64, vp, vp],
+        "mipme_topology_pack_shifts": [vp, ci, i64, vp, vp, vp, vp],
+        "mipme_rspace_rows": [vp, ci, i64, ci, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp],
+        "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -94,6 +99,10 @@ def _declare(lib):
     lib.mipme_cellgrad_partials_size.argtypes = [MP, i64]
     lib.mipme_pair_partials_size.restype = i64
     lib.mipme_pair_partials_size.argtypes = [i64]
+    lib.mipme_topology_workspace_bytes.restype = i64
+    lib.mipme_topology_workspace_bytes.argtypes = [i64]
+    lib.mipme_rows_partials_size.restype = i64
+    lib.mipme_rows_partials_size.argtypes = [i64]
 
 
 def load():

@@ -1,0 +1,131 @@
+// v_SR(d): the real-space pair kernel and its derivative, shared by the pair kernels.
+// Reference: Potential.sr_from_dist / from_dist / f_cutoff (potentials/potential.py:59-138),
+// CoulombPotential (potentials/coulomb.py:80-120), InversePowerLawPotential (potentials/inversepowerlaw.py:55-106).
+#pragma once
+
+#include "common.h"
+
+namespace mipme {
+
+static constexpr double kPiR = 3.14159265358979323846;
+
+// Device-side description of v_SR(d)
+struct SRPot {
+  int mode;        // 0: bare v, 1: v - v_LR (range separated), 2: -v_LR * f_cut, 3: v * (1 - f_cut)
+  int p;           // exponent 1..6
+  double pref;
+  double inv_2s2;  // 1/(2 sigma^2)
+  double rx;       // exclusion radius
+  int deg;         // exclusion degree
+};
+
+inline int make_srpot(const mipme_potential_t* pot, SRPot& s) {
+  MIPME_REQUIRE(pot != nullptr, "potential descriptor is NULL");
+  s.p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  MIPME_REQUIRE(s.p >= 1 && s.p <= 6, "Unsupported exponent: %d", s.p);
+  const bool smeared = pot->smearing > 0;
+  const bool excl = pot->exclusion_radius > 0;
+  s.mode = smeared ? (excl ? 2 : 1) : (excl ? 3 : 0);
+  s.pref = pot->prefactor;
+  s.inv_2s2 = smeared ? 0.5 / (pot->smearing * pot->smearing) : 0.0;
+  s.rx = pot->exclusion_radius;
+  s.deg = pot->exclusion_degree;
+  return MIPME_OK;
+}
+
+__device__ __forceinline__ float fexp(float x) { return expf(x); }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ float ferfc(float x) { return erfcf(x); }
+__device__ __forceinline__ double ferfc(double x) { return erfc(x); }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fsin(float x) { return sinf(x); }
+__device__ __forceinline__ double fsin(double x) { return sin(x); }
+__device__ __forceinline__ float fcos(float x) { return cosf(x); }
+__device__ __forceinline__ double fcos(double x) { return cos(x); }
+
+template <typename T>
+__device__ __forceinline__ T powi(T x, int n) {
+  T r = T(1);
+  for (int i = 0; i < n; ++i) r *= x;
+  return r;
+}
+
+// Q(p/2, x) regularised upper incomplete gamma and x^(p/2-1) e^-x / Gamma(p/2) for integer p in 1..6.
+//   integer a:      Q(a,x) = e^-x sum_{k<a} x^k/k!
+//   half-integer a: Q(1/2,x) = erfc(sqrt x);  Q(a+1,x) = Q(a,x) + x^a e^-x / Gamma(a+1)
+template <typename T>
+__device__ __forceinline__ void upper_gamma(int p, T x, T& Q, T& dens) {
+  const T ex = fexp(-x);
+  if ((p & 1) == 0) {
+    const int a = p / 2;  // 1,2,3
+    T term = T(1), sum = T(1);
+    for (int k = 1; k < a; ++k) {
+      term *= x / T(k);
+      sum += term;
+    }
+    Q = ex * sum;
+    dens = ex * term;  // x^(a-1)/(a-1)!
+  } else {
+    const T sx = fsqrt(x);
+    const T isp = T(0.56418958354775628695);  // 1/sqrt(pi) = 1/Gamma(1/2)
+    Q = ferfc(sx);
+    // term_k = x^(k-1/2) e^-x / Gamma(k+1/2)
+    T term = (x > T(0)) ? ex * isp / sx : T(0);  // k = 0: x^(-1/2)/Gamma(1/2)
+    dens = term;
+    for (int k = 1; k <= (p - 1) / 2; ++k) {
+      term *= x / (T(k) - T(0.5));
+      Q += term;
+      dens = term;
+    }
+  }
+}
+
+// v_SR(d) and dv_SR/dd (see oracle/pme_numpy.py::sr_pair for the derivation).
+template <typename T, bool DERIV>
+__device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
+  const T pref = T(s.pref);
+  const T dc = d > T(1e-15) ? d : T(1e-15);
+  const T inv = T(1) / dc;
+  const T invp = powi(inv, s.p);
+  T fc = T(0), dfc = T(0);
+  if (s.mode >= 2) {
+    const T rx = T(s.rx);
+    if (d < rx) {
+      const T arg = T(kPiR) * d / rx;
+      const T base = T(0.5) * (T(1) - fcos(arg));
+      fc = T(1) - powi(base, s.deg);
+      if constexpr (DERIV) dfc = -T(s.deg) * powi(base, s.deg - 1) * T(0.5) * T(kPiR) / rx * fsin(arg);
+    }
+  }
+  if (s.mode == 0 || s.mode == 3) {
+    const T vb = pref * invp;
+    const T dvb = -T(s.p) * vb * inv;
+    if (s.mode == 0) {
+      v = vb;
+      if constexpr (DERIV) dv = dvb;
+    } else {
+      v = vb * (T(1) - fc);
+      if constexpr (DERIV) dv = dvb * (T(1) - fc) - vb * dfc;
+    }
+    return;
+  }
+  const T x = dc * dc * T(s.inv_2s2);
+  T Q, dens;
+  upper_gamma<T>(s.p, x, Q, dens);
+  const T dxdd = T(2) * dc * T(s.inv_2s2);
+  if (s.mode == 1) {
+    v = pref * Q * invp;
+    if constexpr (DERIV) dv = pref * (-dens * dxdd * invp - T(s.p) * Q * invp * inv);
+  } else {
+    const T P = T(1) - Q;
+    const T vl = pref * P * invp;
+    v = -vl * fc;
+    if constexpr (DERIV) {
+      const T dvl = pref * (dens * dxdd * invp - T(s.p) * P * invp * inv);
+      dv = -(dvl * fc + vl * dfc);
+    }
+  }
+}
+
+}  // namespace mipme

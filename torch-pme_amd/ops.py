@@ -14,6 +14,9 @@ PyTorch is used for device memory, streams and the autograd tape only.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -93,6 +96,77 @@ def build_filter(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device
     return G
 
 
+# How the pair kernels accumulate per-atom results:
+#   "rows"   (default) owner-computes sums over a transposed pair list (csrc/topology.hip); needs a
+#            one-off build per neighbour-list tensor, no atomics, deterministic.
+#   "atomic" one pass over the list with hardware float atomics (csrc/rspace.hip); no preprocessing.
+PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
+
+
+class PairTopology:
+    """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
+
+    def __init__(self, pairs: torch.Tensor, n_atoms: int):
+        lib = _lib.load()
+        device = pairs.device
+        P = pairs.shape[0]
+        self.n_atoms, self.n_pairs = n_atoms, P
+        self.row_ptr = torch.empty((2 * n_atoms + 1,), dtype=torch.int32, device=device)
+        self.entries = torch.empty((max(2 * P, 1), 2), dtype=torch.int32, device=device)
+        self._packed = None  # (weakref(shifts), version, tensor|None)
+        with torch.cuda.device(device):
+            nbytes = lib.mipme_topology_workspace_bytes(P)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+            _lib.check(
+                lib.mipme_topology_build(
+                    _lib.current_stream(device), _lib.index_code(pairs.dtype), P, n_atoms, pairs.data_ptr(),
+                    ws.data_ptr(), nbytes, self.row_ptr.data_ptr(), self.entries.data_ptr(),
+                )
+            )
+
+    def packed_shifts(self, shifts: torch.Tensor, key: torch.Tensor | None = None):
+        """int32 per entry holding the 3 cell shifts as int8, or None if the shifts are not small integers
+        (the kernel then reads ``shifts[p]`` itself).  Cached per shifts tensor; the integrality flag is the
+        only D2H read, once per (list, shifts) pair."""
+        key = shifts if key is None else key  # cache on the caller's tensor (``shifts`` may be a converted copy)
+        c = self._packed
+        if c is not None and c[0]() is key and c[1] == key._version:
+            return c[2]
+        lib = _lib.load()
+        device = shifts.device
+        packed = torch.empty((max(2 * self.n_pairs, 1),), dtype=torch.int32, device=device)
+        flag = torch.empty((1,), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(
+                lib.mipme_topology_pack_shifts(
+                    _lib.current_stream(device), _lib.dtype_code(shifts.dtype), self.n_pairs, self.entries.data_ptr(),
+                    shifts.data_ptr(), packed.data_ptr(), flag.data_ptr(),
+                )
+            )
+        if int(flag.item()) != 0:
+            packed = None
+        self._packed = (weakref.ref(key), key._version, packed)
+        return packed
+
+
+_TOPOLOGIES: "OrderedDict" = OrderedDict()
+
+
+def get_topology(pairs: torch.Tensor, n_atoms: int) -> PairTopology:
+    """Topology of ``pairs``, cached on the identity and version counter of the tensor object: keep the
+    neighbour-list tensor alive across steps (a Verlet list) and the transposition is paid once."""
+    key = (pairs.data_ptr(), pairs.shape[0], n_atoms, pairs.device.index)
+    hit = _TOPOLOGIES.get(key)
+    if hit is not None and hit[0]() is pairs and hit[1] == pairs._version:
+        _TOPOLOGIES.move_to_end(key)
+        return hit[2]
+    topo = PairTopology(pairs, n_atoms)
+    _TOPOLOGIES[key] = (weakref.ref(pairs), pairs._version, topo)
+    while len(_TOPOLOGIES) > 16:
+        _TOPOLOGIES.popitem(last=False)
+    return topo
+
+
 def _slab_axis(periodic_host):
     if periodic_host is None:
         return None
@@ -149,13 +223,22 @@ class _PMEFunction(torch.autograd.Function):
                 accumulate = 1
             else:
                 accumulate = 0
-            _call(
-                "rspace_forward", lib.mipme_rspace_forward,
-                st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
-            )
+            topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
+            if topo is not None:
+                _call(
+                    "rspace_forward", lib.mipme_rspace_rows,
+                    st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                    _lib.ptr(mask), 0, int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
+                )
+            else:
+                _call(
+                    "rspace_forward", lib.mipme_rspace_forward,
+                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                    _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
+                )
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms")))
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
+        ctx.topo = topo
         return out
 
     @staticmethod
@@ -212,12 +295,21 @@ class _PMEFunction(torch.autograd.Function):
             if need_dist or need_q:
                 if need_dist:
                     grad_dist = torch.empty((P,), dtype=dtype, device=device)
-                _call(
-                    "rspace_backward", lib.mipme_rspace_backward,
-                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                    _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
-                    _lib.ptr(grad_q) if need_q else None,
-                )
+                topo = ctx.topo
+                # grad_dist is a per-pair stream (no scatter); the charge gradient is a per-atom row sum
+                if need_dist or topo is None:
+                    _call(
+                        "rspace_backward", lib.mipme_rspace_backward,
+                        st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
+                        _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
+                        _lib.ptr(grad_q) if (need_q and topo is None) else None,
+                    )
+                if need_q and topo is not None:
+                    _call(
+                        "rspace_backward_charges", lib.mipme_rspace_rows,
+                        st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
+                        _lib.ptr(mask), 1, int(ctx.full_list), C.byref(pot_desc), 1, grad_q.data_ptr(),
+                    )
             if geom is None:
                 if need_pos:
                     grad_pos = torch.zeros((N, 3), dtype=dtype, device=device)
@@ -250,6 +342,8 @@ class _PairDistances(torch.autograd.Function):
                     pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
             )
         ctx.save_for_backward(pos, cl, pairs, sh)
+        ctx.topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+        ctx.shifts_key = shifts
         return out
 
     @staticmethod
@@ -262,9 +356,22 @@ class _PairDistances(torch.autograd.Function):
         need_cell = cl is not None and ctx.needs_input_grad[1]
         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
         grad_cell = partials = None
+        topo = ctx.topo
         if need_cell:
             grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
-            partials = torch.empty((lib.mipme_pair_partials_size(P),), dtype=torch.float64, device=device)
+            n_part = lib.mipme_rows_partials_size(N) if topo is not None else lib.mipme_pair_partials_size(P)
+            partials = torch.empty((n_part,), dtype=torch.float64, device=device)
+        if topo is not None:
+            packed = None if sh is None else topo.packed_shifts(sh, ctx.shifts_key)
+            with torch.cuda.device(device):
+                _call(
+                    "pair_distance_backward", lib.mipme_pair_distance_backward_rows,
+                    _lib.current_stream(device), _lib.dtype_code(dtype), N, topo.row_ptr.data_ptr(),
+                    topo.entries.data_ptr(), _lib.ptr(packed), pos.data_ptr(), _lib.ptr(cl),
+                    None if packed is not None else _lib.ptr(sh), grad_d.contiguous().data_ptr(), _lib.ptr(partials),
+                    grad_pos.data_ptr(), _lib.ptr(grad_cell),
+                )
+            return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
         with torch.cuda.device(device):
             _call(
                 "pair_distance_backward", lib.mipme_pair_distance_backward,
