@@ -1,0 +1,68 @@
+"""Multi-process path (world_size 2, gloo, CPU): frame sharding + the single all-gather of the frame farm.
+The per-frame evaluator here is the NumPy oracle (the HIP path needs a GPU); what is under test is the
+partitioning and the collective."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from torchpme_amd import farm
+
+
+def test_frame_blocks_cover_everything():
+    for n, w in [(64, 8), (10, 4), (3, 8), (0, 2), (7, 1)]:
+        seen = []
+        for r in range(w):
+            seen += list(farm.frame_block(n, r, w))
+        assert seen == list(range(n))
+        sizes = [len(farm.frame_block(n, r, w)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+    assert [farm.frame_owner(f, 64, 8) for f in (0, 7, 8, 63)] == [0, 0, 1, 7]
+    with pytest.raises(ValueError):
+        farm.frame_block(4, 5, 2)
+
+
+def _frame_energy(f: int) -> torch.Tensor:
+    from oracle import pme_numpy as O
+    from torchpme_amd.workloads import ionic_box
+
+    w = ionic_box(n_side=3, n_mesh=8, cutoff=3.0, seed=100 + f)
+    spec = O.PotentialSpec("coulomb", 1, w.smearing, 1.0)
+    dist_, _ = O.pair_distances(w.positions, w.cell, w.pairs, w.shifts)
+    V = O.forward(spec, "P3M", 3, w.mesh_spacing, w.charges, w.cell, w.positions, w.pairs, dist_)
+    return torch.tensor(float((V * w.charges).sum()), dtype=torch.float64)
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def ev(f):
+            calls.append(f)
+            return _frame_energy(f)
+
+        e = farm.farm_energies(n_frames, ev)
+        assert calls == list(farm.frame_block(n_frames, rank, world))
+        np.save(os.path.join(out_dir, f"e{rank}.npy"), e.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [4, 5])
+def test_farm_two_ranks_gloo(tmp_path, n_frames):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = np.load(tmp_path / "e0.npy"), np.load(tmp_path / "e1.npy")
+    serial = farm.farm_energies(n_frames, _frame_energy).numpy()
+    np.testing.assert_array_equal(e0, e1)
+    np.testing.assert_allclose(e0, serial, rtol=0, atol=0)

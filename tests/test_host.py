@@ -1,0 +1,206 @@
+"""CPU tests (no GPU) of the host side: the C-ABI library loads and exports every declared symbol, argument
+validation reproduces the reference's exception types and messages, constructors, prefactors, neighbour list."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import torchpme_amd as tpa
+from torchpme_amd import _lib
+from torchpme_amd.neighbors import neighbor_list, neighbor_list_bruteforce
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mipme.h")).read()
+    declared = sorted(set(re.findall(r"\b(mipme_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"libmipme.so does not export {name}"
+    assert sorted(declared) == sorted(_lib.EXPORTS)
+    assert lib.mipme_version() == 100
+
+
+def test_abi_struct_layout_matches_header():
+    import ctypes as C
+
+    assert C.sizeof(_lib.PotentialDesc) == 40
+    assert C.sizeof(_lib.MeshDesc) == 24 + 19 * 8
+    assert _lib.MeshDesc.cell.offset == 24 and _lib.MeshDesc.volume.offset == 24 + 18 * 8
+
+
+def test_no_cpu_fallback():
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.5)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64)  # noqa: E731
+    with pytest.raises(tpa.MipmeError, match="no CPU fallback"):
+        calc(z(2, 1), torch.eye(3, dtype=torch.float64), z(2, 3), torch.zeros((1, 2), dtype=torch.long), z(1))
+    with pytest.raises(tpa.MipmeError, match="no CPU fallback"):
+        tpa.pair_distances(z(2, 3), torch.zeros((1, 2), dtype=torch.long))
+
+
+def test_abi_argument_errors_without_gpu():
+    """Error paths of the C-ABI that return before touching the device."""
+    import ctypes as C
+
+    lib = _lib.load()
+    md = _lib.MeshDesc(scheme=_lib.P3M, order=9, nx=4, ny=4, nz=4, n_channels=1)
+    pd = _lib.PotentialDesc(kind=_lib.COULOMB, exponent=1, smearing=1.0, prefactor=1.0, exclusion_radius=-1, exclusion_degree=1)
+    rc = lib.mipme_kfilter_build(None, _lib.F32, C.byref(md), C.byref(pd), None)
+    assert rc == -1
+    assert b"only values from 1 to 5 for method 'P3M' are allowed" in lib.mipme_last_error()
+    with pytest.raises(ValueError, match="from 1 to 5"):
+        _lib.check(rc)
+
+
+# ---- constructors (reference tests/calculators/test_workflow.py:77-96, test_calculator.py) ----
+def test_constructor_errors():
+    with pytest.raises(TypeError, match="Potential must be an instance of Potential, got <class 'int'>"):
+        tpa.Calculator(potential=1)
+    with pytest.raises(ValueError, match="Must specify smearing to use a potential with PMECalculator"):
+        tpa.PMECalculator(tpa.CoulombPotential(), mesh_spacing=1.0)
+    with pytest.raises(ValueError, match="`smearing` is -1.0 but must be positive"):
+        tpa.P3MCalculator(tpa.CoulombPotential(smearing=-1.0), mesh_spacing=1.0)
+    with pytest.raises(ValueError, match="`interpolation_nodes` is 8 but only values from 3 to 7 for method 'Lagrange' are allowed"):
+        tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0, interpolation_nodes=8)
+    with pytest.raises(ValueError, match="`interpolation_nodes` is 6 but only values from 1 to 5 for method 'P3M' are allowed"):
+        tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0, interpolation_nodes=6)
+    with pytest.raises(ValueError, match="Unsupported exponent: 7"):
+        tpa.InversePowerLawPotential(exponent=7, smearing=1.0)
+    calc = tpa.P3MCalculator(tpa.InversePowerLawPotential(exponent=6, smearing=1.5), mesh_spacing=0.3, interpolation_nodes=5,
+                             full_neighbor_list=True)
+    assert (calc.mesh_spacing, calc.interpolation_nodes, calc.full_neighbor_list) == (0.3, 5, True)
+    assert isinstance(calc.potential, tpa.Potential)
+
+
+def test_state_dict_buffers():
+    pot = tpa.InversePowerLawPotential(exponent=3, smearing=1.2, prefactor=2.0)
+    sd = pot.state_dict()
+    assert set(sd) == {"smearing", "prefactor", "exponent"} and all(v.dtype == torch.float64 for v in sd.values())
+    assert set(tpa.CoulombPotential(smearing=1.0).state_dict()) == {"smearing", "prefactor"}
+    pot2 = tpa.InversePowerLawPotential(exponent=3, smearing=9.9)
+    pot2.load_state_dict(sd)
+    assert pot2._descriptor().smearing == pytest.approx(1.2)
+    d = tpa.CoulombPotential(smearing=None, exclusion_radius=2.0)._descriptor()
+    assert d.smearing < 0 and d.exclusion_radius == 2.0 and d.kind == _lib.COULOMB
+
+
+def test_potential_closed_forms_match_oracle():
+    """The inspection methods of the potentials agree with the oracle's (scipy) special functions."""
+    from oracle import pme_numpy as O
+
+    d = torch.linspace(0.3, 6.0, 50, dtype=torch.float64)
+    for p in range(1, 7):
+        pot = tpa.InversePowerLawPotential(exponent=p, smearing=0.8, prefactor=1.7)
+        spec = O.PotentialSpec("ipl", p, 0.8, 1.7)
+        np.testing.assert_allclose(pot.lr_from_dist(d).numpy(), O.lr_pair(spec, d.numpy())[0], rtol=1e-11)
+        np.testing.assert_allclose(pot.sr_from_dist(d).numpy(), O.sr_pair(spec, d.numpy())[0], rtol=1e-8, atol=1e-14)
+        assert float(pot.self_contribution()) == pytest.approx(O.self_term(spec), rel=1e-14)
+        assert float(pot.background_correction()) == pytest.approx(O.background_term(spec), rel=1e-14)
+        if p in (1, 2, 4, 6):
+            k2 = torch.tensor([0.0, 0.1, 1.0, 7.0], dtype=torch.float64)
+            np.testing.assert_allclose(pot.lr_from_k_sq(k2).numpy(), O.lr_kernel(spec, k2.numpy())[0], rtol=1e-12)
+    c = tpa.CoulombPotential(smearing=0.8, prefactor=1.7)
+    i = tpa.InversePowerLawPotential(exponent=1, smearing=0.8, prefactor=1.7)
+    np.testing.assert_allclose(c.sr_from_dist(d).numpy(), i.sr_from_dist(d).numpy(), rtol=1e-14)
+
+
+def test_prefactors():
+    assert tpa.prefactors.eV_A == pytest.approx(14.399645478425667, rel=1e-15)
+    assert tpa.prefactors.kcalmol_A == pytest.approx(332.0637132991921, rel=1e-15)
+    assert tpa.prefactors.kJmol == pytest.approx(1389.3545764438197, rel=1e-15)
+    assert tpa.prefactors.SI == pytest.approx(2.3070775523417355e-28, rel=1e-15)
+
+
+# ---- _validate_parameters messages (reference tests/calculators/test_calculator.py:50-243) ----
+def _args(n=4, p=3, dtype=torch.float32):
+    return dict(
+        charges=torch.ones((n, 2), dtype=dtype),
+        cell=torch.eye(3, dtype=dtype),
+        positions=torch.zeros((n, 3), dtype=dtype),
+        neighbor_indices=torch.zeros((p, 2), dtype=torch.long),
+        neighbor_distances=torch.ones(p, dtype=dtype),
+    )
+
+
+VALIDATION_CASES = [
+    (dict(positions=torch.zeros((4, 5))), ValueError,
+     r"`positions` must be a tensor with shape \[n_atoms, 3\], got tensor with shape \[4, 5\]"),
+    (dict(cell=torch.eye(2)), ValueError, r"`cell` must be a tensor with shape \[3, 3\], got tensor with shape \[2, 2\]"),
+    (dict(cell=torch.eye(3, dtype=torch.float64)), TypeError,
+     r"type of `cell` \(torch.float64\) must be same as that of the `positions` class \(torch.float32\)"),
+    (dict(charges=torch.ones(4)), ValueError,
+     r"`charges` must be a 2-dimensional tensor, got tensor with 1 dimension\(s\) and shape \[4\]"),
+    (dict(charges=torch.ones((6, 2))), ValueError,
+     r"`charges` must be a tensor with shape \[n_atoms, n_channels\], with `n_atoms` being the same as the variable "
+     r"`positions`. Got tensor with shape \[6, 2\] where positions contains 4 atoms"),
+    (dict(charges=torch.ones((4, 2), dtype=torch.float64)), TypeError,
+     r"type of `charges` \(torch.float64\) must be same as that of the `positions` class \(torch.float32\)"),
+    (dict(neighbor_indices=torch.zeros((3, 3), dtype=torch.long)), ValueError,
+     r"neighbor_indices is expected to have shape \[num_neighbors, 2\], but got \[3, 3\] for one structure"),
+    (dict(neighbor_distances=torch.ones(5)), ValueError,
+     r"`neighbor_indices` and `neighbor_distances` need to have shapes \[num_neighbors, 2\] and \[num_neighbors\], "
+     r"but got \[3, 2\] and \[5\]"),
+    (dict(neighbor_distances=torch.ones(3, dtype=torch.float64)), TypeError,
+     r"type of `neighbor_distances` \(torch.float64\) must be same as that of the `positions` class \(torch.float32\)"),
+    (dict(periodic=torch.ones(2, dtype=torch.bool)), ValueError,
+     r"`periodic` must be a tensor of shape \(3,\), got tensor with shape \[2\]"),
+    (dict(pair_mask=torch.ones(5, dtype=torch.bool)), ValueError,
+     r"`pair_mask` must have the same shape as the number of neighbors, got tensor with shape \[5\] while the number "
+     r"of neighbors is 3"),
+    (dict(pair_mask=torch.ones(3)), TypeError, r"type of `pair_mask` \(torch.float32\) must be torch.bool"),
+    (dict(node_mask=torch.ones(5, dtype=torch.bool)), ValueError,
+     r"`node_mask` must have shape \[n_atoms\], got tensor with shape \[5\] where n_atoms is 4"),
+    (dict(node_mask=torch.ones(4)), TypeError, r"type of `node_mask` \(torch.float32\) must be torch.bool"),
+    (dict(kvectors=torch.ones((7, 2))), ValueError,
+     r"`kvectors` must be a tensor of shape \[n_kvecs, 3\], got tensor with shape \[7, 2\]"),
+    (dict(kvectors=torch.ones((7, 3), dtype=torch.float64)), TypeError,
+     r"type of `kvectors` \(torch.float64\) must be same as that of the `positions` class \(torch.float32\)"),
+]
+
+
+@pytest.mark.parametrize("override,exc,msg", VALIDATION_CASES)
+def test_validation_messages(override, exc, msg):
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.5)
+    args = _args()
+    args.update(override)
+    with pytest.raises(exc, match=msg):
+        calc(**args)
+
+
+def test_validation_device_message():
+    calc = tpa.Calculator(tpa.CoulombPotential())
+    args = _args()
+    args["cell"] = torch.eye(3, device="meta")
+    with pytest.raises(ValueError, match=r"device of `cell` \(meta\) must be same as that of the `positions` class \(cpu\)"):
+        calc(**args)
+
+
+# ---- neighbour list (reference tests/helpers.py:240-275, third-party vesin there) ----
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("cutoff", [1.5, 3.2])
+def test_neighbor_list_vs_bruteforce(full, cutoff):
+    rng = np.random.default_rng(11)
+    cell = np.array([[3.0, 0, 0], [0.6, 2.5, 0], [-0.4, 0.3, 2.8]])
+    pos = rng.uniform(-2, 5, (9, 3))  # some atoms outside the cell; cutoff > L/2 -> several images
+    a = neighbor_list(pos, cell, cutoff, full_list=full)
+    b = neighbor_list_bruteforce(pos, cell, cutoff, full_list=full)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-13)
+    if not full:
+        f = neighbor_list(pos, cell, cutoff, full_list=True)
+        assert len(f[0]) == 2 * len(a[0])
+
+
+def test_workload_shapes():
+    from torchpme_amd import ops, workloads
+
+    w = workloads.ionic_box(n_side=6, n_mesh=16, cutoff=5.0)
+    assert w.n_atoms == 216 and w.pairs.shape == (w.n_pairs, 2) and w.shifts.shape == (w.n_pairs, 3)
+    assert ops.ns_mesh_from_cell(w.cell, w.mesh_spacing) == (16, 16, 16)
+    assert abs(w.charges.sum()) < 1e-9

@@ -10,7 +10,8 @@ carries its own builder.  It returns exactly what the calculators consume:
 
 Half list: every unordered interaction once (``i < j`` for any shift; ``i == j`` only for the
 lexicographically positive half of the shifts).  Full list: both directions.  The cutoff may
-exceed half the box (several periodic images), and cells may be triclinic.
+exceed half the box (several periodic images), and cells may be triclinic.  Pairs at exactly the cutoff
+are excluded (``d < cutoff``).
 """
 
 from __future__ import annotations
@@ -86,7 +87,8 @@ def neighbor_list(positions, cell, cutoff: float, full_list: bool = False, perio
     i, j, S = i[order], j[order], S[order]
     vec = pos[j] - pos[i] + S @ A
     dist = np.sqrt(np.sum(vec * vec, axis=1))
-    return np.stack([i, j], axis=1), S, dist
+    inside = dist < cutoff  # strictly inside, like the list the reference tests use (58 half pairs for CsCl, rc = 2)
+    return np.stack([i, j], axis=1)[inside], S[inside], dist[inside]
 
 
 def neighbor_list_bruteforce(positions, cell, cutoff: float, full_list: bool = False, periodic=(True, True, True)):
@@ -106,7 +108,7 @@ def neighbor_list_bruteforce(positions, cell, cutoff: float, full_list: bool = F
                 S = np.array([sx, sy, sz])
                 vec = pos[None, :, :] - pos[:, None, :] + S @ A
                 d = np.sqrt(np.sum(vec * vec, axis=2))
-                ii, jj = np.nonzero(d <= cutoff)
+                ii, jj = np.nonzero(d < cutoff)
                 for a, b in zip(ii, jj):
                     if a == b and not S.any():
                         continue
