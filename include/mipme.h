@@ -111,7 +111,7 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi);
+                         void* out_lr, void* out_phi, void* atom_bins);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
  * (In the reference this is PyTorch autograd through the ATen chain)
@@ -124,8 +124,20 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell);
+                          void* grad_cell, void* atom_bins);
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
+
+/* atom_bins (nullable): device scratch of mipme_atom_bins_bytes() bytes.  When given, the atoms are counting-sorted
+ * by 8x8x8 mesh brick in the forward call and the particle<->mesh stages run as brick kernels (owner-computes spread
+ * into an LDS tile: no global atomics, no mesh memset; LDS-tiled gathers).  The SAME buffer must be handed to the
+ * backward call (it reuses the bins).  mipme_atom_bins_bytes returns 0 when the mesh is too small for bricks
+ * (< 17 points on an axis, or a last brick narrower than 4 points): pass NULL then (atomic-scatter kernels). */
+int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
+
+/* Per-stage timing for benchmarks: HIP events on the launch stream around every stage of the composite calls.
+ * mipme_profile_report writes "stage calls total_ms" lines into buf and returns the byte count needed. */
+int mipme_profile_enable(int on);
+int64_t mipme_profile_report(char* buf, int64_t buflen);
 
 /* 2-D slab correction, potentials/coulomb.py:6-40 (active when exactly two axes are periodic).
  * forward: pot[i,c] += 1/2 * prefactor * E_slab[i,c].  moments: float64 scratch of 6*C elements.

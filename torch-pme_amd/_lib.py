@@ -27,7 +27,8 @@ EXPORTS = (
     "mipme_cellgrad_partials_size", "mipme_slab_forward", "mipme_slab_backward", "mipme_rspace_forward",
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
-    "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size",
+    "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
+    "mipme_profile_enable", "mipme_profile_report",
 )
 
 
@@ -78,8 +79,8 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 10,
-        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 17,
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 11,
+        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 18,
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
         "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
@@ -103,6 +104,12 @@ def _declare(lib):
     lib.mipme_topology_workspace_bytes.argtypes = [i64]
     lib.mipme_rows_partials_size.restype = i64
     lib.mipme_rows_partials_size.argtypes = [i64]
+    lib.mipme_atom_bins_bytes.restype = i64
+    lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
+    lib.mipme_profile_enable.restype = ci
+    lib.mipme_profile_enable.argtypes = [ci]
+    lib.mipme_profile_report.restype = i64
+    lib.mipme_profile_report.argtypes = [C.c_char_p, i64]
 
 
 def load():
@@ -193,3 +200,20 @@ def get_plan(device, dtype, ns, batch) -> FFTPlan:
         plan = FFTPlan(device, dtype, ns, batch)
         _PLANS[key] = plan
     return plan
+
+
+def profile_enable(on: bool):
+    check(load().mipme_profile_enable(1 if on else 0))
+
+
+def profile_report() -> dict:
+    """{stage: (calls, total_ms)} recorded by the library since ``profile_enable(True)``."""
+    lib = load()
+    n = lib.mipme_profile_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    lib.mipme_profile_report(buf, n + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split()
+        out[name] = (int(calls), float(ms))
+    return out

@@ -2,6 +2,9 @@
 // k-space forward / backward sequences (reference calculators/pme.py:88-143 and its autograd).
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -38,6 +41,46 @@ int64_t pair_partials_blocks(int64_t);
 
 struct FftDims { int dtype, nx, ny, nz, batch; };
 FftDims fft_plan_dims(const mipme_fft_plan*);
+// bricks.hip
+bool bricks_supported(const mipme_mesh_t*, int dtype);
+int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
+template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
+template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
+
+// ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
+struct ProfEntry {
+  const char* name;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  ProfEntry e;
+  bool on;
+  ProfScope(hipStream_t s, const char* name) : st(s), on(g_prof_on) {
+    if (!on) return;
+    e.name = name;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(e.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e.b, st);
+    g_prof.push_back(e);
+  }
+};
+#define STAGE(st, name, call)        \
+  do {                               \
+    ProfScope _ps(st, name);         \
+    if ((rc = (call))) return rc;    \
+  } while (0)
 
 // self / background corrections: potentials/coulomb.py:144-158, potentials/inversepowerlaw.py:143-166
 static void correction_terms(const mipme_potential_t* pot, double& self_c, double& bg_c) {
@@ -62,16 +105,25 @@ static int check_plan(const mipme_fft_plan* plan, int dtype, const mipme_mesh_t*
 template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
-                            void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi) {
+                            void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins) {
   int rc;
-  if ((rc = spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh))) return rc;
-  if ((rc = fft_forward(plan, st, rho_mesh, rho_hat))) return rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
-  if ((rc = apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc))) return rc;
-  if ((rc = fft_inverse(plan, st, hat_work, phi_mesh))) return rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
-  return gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi);
+  if (bins) {
+    STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh));
+  } else {
+    STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
+  }
+  STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
+  STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
+  STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, phi_mesh));
+  if (bins)
+    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi));
+  else
+    STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi));
+  return MIPME_OK;
 }
 
 template <typename T>
@@ -79,26 +131,32 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
                              int64_t N, const void* pos, const void* q, const void* gout, const void* G,
                              const void* phi_mesh, const void* rho_hat, const void* rho_dc, const void* phi_atoms,
                              void* psi_mesh, void* psi_hat, void* hat_work, void* chi_mesh, void* dc, void* partials,
-                             void* grad_pos, void* grad_q, void* grad_cell) {
+                             void* grad_pos, void* grad_q, void* grad_cell, void* bins) {
   int rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
   // psi = spread(g / 2V); chi = F psi
-  if ((rc = spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh))) return rc;
-  if ((rc = fft_forward(plan, st, psi_mesh, psi_hat))) return rc;
+  if (bins)
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh));
+  else
+    STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
+  STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   if (grad_cell) {
     MIPME_REQUIRE(rho_hat && rho_dc && phi_atoms && partials && grad_pos,
                   "cell gradient needs rho_hat, rho_dc, phi_atoms, partials and grad_positions buffers");
-    if ((rc = apply_filter_cellgrad_impl<T>(st, m, pot, psi_hat, rho_hat, G, hat_work, dc, partials))) return rc;
+    STAGE(st, "apply_filter_cellgrad", apply_filter_cellgrad_impl<T>(st, m, pot, psi_hat, rho_hat, G, hat_work, dc, partials));
   } else {
-    if ((rc = apply_filter_impl<T>(st, Mh, m->n_channels, psi_hat, G, hat_work, dc))) return rc;
+    STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, psi_hat, G, hat_work, dc));
   }
-  if ((rc = fft_inverse(plan, st, hat_work, chi_mesh))) return rc;
-  if ((rc = gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q)))
-    return rc;
+  STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, chi_mesh));
+  if (bins)
+    STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q));
+  else
+    STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q));
   if (grad_cell)
-    return cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, grad_cell);
+    STAGE(st, "cellgrad_finalize",
+          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, grad_cell));
   return MIPME_OK;
 }
 
@@ -302,19 +360,20 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi) {
+                         void* out_lr, void* out_phi, void* bins) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
   MIPME_REQUIRE(G && rho_mesh && rho_hat && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi),
+                                    phi_mesh, dc, out_lr, out_phi, bins),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi));
+                                     phi_mesh, dc, out_lr, out_phi, bins));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
@@ -322,7 +381,7 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell) {
+                          void* grad_cell, void* bins) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -330,14 +389,56 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
   MIPME_REQUIRE(G && phi_mesh && psi_mesh && psi_hat && hat_work && chi_mesh && dc,
                 "NULL work buffer passed to mipme_kspace_backward");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && grad_out), "NULL atom buffer passed to mipme_kspace_backward");
+  MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_backward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                      rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                     grad_positions, grad_charges, grad_cell),
+                                     grad_positions, grad_charges, grad_cell, bins),
             kspace_backward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                       rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                      grad_positions, grad_charges, grad_cell));
+                                      grad_positions, grad_charges, grad_cell, bins));
+}
+
+int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
+  if (!mesh || n_atoms < 0) return 0;
+  return bins_bytes(mesh, n_atoms, dtype);
+}
+
+int mipme_profile_enable(int on) {
+  for (auto& e : g_prof) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return MIPME_OK;
+}
+
+/* Writes "name calls total_ms\n" lines (NUL terminated) for the stages recorded since mipme_profile_enable(1);
+ * synchronises on the recorded events.  Returns the number of bytes needed (excluding the NUL). */
+int64_t mipme_profile_report(char* buf, int64_t buflen) {
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& e : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      auto& a = agg[e.name];
+      a.first += 1;
+      a.second += ms;
+    }
+  }
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && buflen > 0) {
+    const size_t n = out.size() < size_t(buflen - 1) ? out.size() : size_t(buflen - 1);
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return int64_t(out.size());
 }
 
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms) {

@@ -1,0 +1,558 @@
+// Brick-binned particle <-> mesh kernels (the fast path of csrc/mesh.hip).
+//
+// The mesh is cut into bricks of 8x8x8 points and the atoms are counting-sorted by the brick that
+// holds their stencil base point (three tiny kernels per forward; the backward reuses the bins).
+//   spread : one workgroup per brick OWNS its 512 mesh points.  It scans the atoms of the 27 surrounding
+//            bricks, keeps those whose n^3 stencil overlaps the brick, accumulates them into an LDS tile
+//            with ds_add_f32 and writes the tile with plain coalesced stores: no global atomics (the
+//            slowest operation on MI355X, ~21 G/s), no mesh memset, each mesh point written exactly once.
+//   gather : one workgroup per brick stages the (8+n-1)^3 mesh tile of its own atoms into LDS with
+//            coalesced loads; the n^3 stencil reads of every atom then hit LDS instead of L2.
+// Replaces, like mesh.hip, MeshInterpolator.compute_weights / points_to_mesh / mesh_to_points
+// (reference lib/mesh_interpolator.py:303-457).
+#include "common.h"
+
+namespace mipme {
+
+static constexpr int BRICK = 8;
+static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
+
+struct BrickGeom {
+  int nbx, nby, nbz, nb;
+};
+
+static inline BrickGeom make_brick_geom(const mipme_mesh_t* m) {
+  BrickGeom b;
+  b.nbx = (m->nx + BRICK - 1) / BRICK;
+  b.nby = (m->ny + BRICK - 1) / BRICK;
+  b.nbz = (m->nz + BRICK - 1) / BRICK;
+  b.nb = b.nbx * b.nby * b.nbz;
+  return b;
+}
+
+// Brick path preconditions: >= 3 bricks per axis (the 27 neighbours are distinct bricks) and enough LDS.
+bool bricks_supported(const mipme_mesh_t* m, int dtype) {
+  const size_t s = dtype == MIPME_F32 ? 4 : 8;
+  const int ns[3] = {m->nx, m->ny, m->nz};
+  for (int d = 0; d < 3; ++d) {
+    if (ns[d] <= 2 * BRICK) return false;               // need >= 3 distinct bricks per axis
+    const int rem = ns[d] % BRICK;
+    if (rem != 0 && rem < 4) return false;              // a narrow last brick would be skipped over by a stencil
+  }
+  const size_t tile = BRICK + m->order - 1;
+  if (2 * size_t(m->n_channels) * tile * tile * tile * s > 60 * 1024) return false;  // gather_grad: phi+chi per channel
+  if (size_t(m->n_channels) * BRICK_PTS * s > 48 * 1024) return false;               // spread: one tile per channel
+  return true;
+}
+
+struct BinsLayout {
+  size_t count, start, slot, brick, rec, frac, total;
+};
+
+static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
+  const BrickGeom b = make_brick_geom(m);
+  const size_t s = dtype == MIPME_F32 ? 4 : 8;
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  BinsLayout l;
+  size_t off = 0;
+  l.count = off; off += al(sizeof(int) * size_t(b.nb + 1));
+  l.start = off; off += al(sizeof(int) * size_t(b.nb + 1));
+  l.slot = off;  off += al(sizeof(int) * size_t(N));
+  l.brick = off; off += al(sizeof(int) * size_t(N));
+  l.rec = off;   off += al(sizeof(int4) * size_t(N));
+  l.frac = off;  off += al(4 * s * size_t(N));
+  l.total = off;
+  return l;
+}
+
+int64_t bins_bytes(const mipme_mesh_t* m, int64_t N, int dtype) {
+  if (!bricks_supported(m, dtype)) return 0;
+  return int64_t(bins_layout(m, N, dtype).total);
+}
+
+__device__ __forceinline__ void split_runtime(double u, bool even, int& m, double& x) {
+  if (even) {
+    const double fl = floor(u);
+    m = int(fl);
+    x = u - (fl + 0.5);
+  } else {
+    const double r = rint(u);
+    m = int(r);
+    x = u - r;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void atom_mesh_coords(const Geom& g, bool even, const T* __restrict__ pos, int64_t i,
+                                                 int (&m)[3], double (&x)[3]) {
+  const double rx = double(pos[3 * i + 0]), ry = double(pos[3 * i + 1]), rz = double(pos[3 * i + 2]);
+  const double u[3] = {double(g.nx) * (rx * g.inv[0] + ry * g.inv[3] + rz * g.inv[6]),
+                       double(g.ny) * (rx * g.inv[1] + ry * g.inv[4] + rz * g.inv[7]),
+                       double(g.nz) * (rx * g.inv[2] + ry * g.inv[5] + rz * g.inv[8])};
+  const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int mm;
+    split_runtime(u[d], even, mm, x[d]);
+    m[d] = posmod(mm, n[d]);
+  }
+}
+
+// ---- binning -----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bool even, int64_t N,
+                                                       const T* __restrict__ pos, int* __restrict__ count,
+                                                       int* __restrict__ slot, int* __restrict__ brick) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int m[3];
+  double x[3];
+  atom_mesh_coords<T>(g, even, pos, i, m, x);
+  const int b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
+  brick[i] = b;
+  slot[i] = atomicAdd(&count[b], 1);
+}
+
+// exclusive scan of count[0..nb) into start[0..nb]; single block
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __restrict__ count, int* __restrict__ start) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int lo = t * per, hi = min(lo + per, nb);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += count[k];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int k = lo; k < hi; ++k) {
+    start[k] = run;
+    run += count[k];
+  }
+  if (t == 1023) start[nb] = part[1023];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, bool even, int64_t N, const T* __restrict__ pos,
+                                                      const int* __restrict__ start, const int* __restrict__ slot,
+                                                      const int* __restrict__ brick, int4* __restrict__ rec,
+                                                      T* __restrict__ frac) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int m[3];
+  double x[3];
+  atom_mesh_coords<T>(g, even, pos, i, m, x);
+  const int64_t dst = int64_t(start[brick[i]]) + slot[i];
+  rec[dst] = make_int4(m[0], m[1], m[2], int(i));
+  frac[4 * dst + 0] = T(x[0]);
+  frac[4 * dst + 1] = T(x[1]);
+  frac[4 * dst + 2] = T(x[2]);
+  frac[4 * dst + 3] = T(0);
+}
+
+// ---- shared device helpers ---------------------------------------------------------------------
+template <int LANES, typename T>
+__device__ __forceinline__ T group_sum_b(T v) {
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LANES);
+  return v;
+}
+
+__device__ __forceinline__ void brick_coords(const BrickGeom& bg, int b, int& bx, int& by, int& bz) {
+  bz = b % bg.nbz;
+  const int r = b / bg.nbz;
+  by = r % bg.nby;
+  bx = r / bg.nby;
+}
+
+// offset of stencil start relative to a brick origin, mapped into [-(n-1), n_mesh - n]; overlap iff <= BRICK-1
+__device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, int order) {
+  int r = posmod(m + s0 - origin, nmesh);
+  if (r > nmesh - order) r -= nmesh;
+  return r;
+}
+
+// ---- spread: owner-computes per brick ------------------------------------------------------------
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg, int C, const int* __restrict__ start,
+                                                          const int4* __restrict__ rec, const T* __restrict__ frac,
+                                                          const T* __restrict__ val, T scale, T* __restrict__ mesh) {
+  constexpr int LANES = StencilGroup<N>::LANES;
+  constexpr int GROUPS = 256 / LANES;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);                          // [C][512]
+  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [256][3]: packed rel, sorted index, atom
+  int* rstart = surv + 3 * 256;                                      // [28]
+  int* rbase = rstart + 28;                                          // [28]
+  int& nsurv = rbase[28];
+  int bx, by, bz;
+  brick_coords(bg, blockIdx.x, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < C * BRICK_PTS; k += 256) tile[k] = T(0);
+  if (tid < 27) {
+    const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
+    const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
+    rstart[tid] = start[nbr];
+    rbase[tid] = start[nbr + 1] - start[nbr];  // length for now
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < 27; ++k) {
+      const int len = rbase[k];
+      rbase[k] = run;
+      run += len;
+    }
+    rbase[27] = run;
+  }
+  __syncthreads();
+  const int total = rbase[27];
+  constexpr int s0 = stencil_start<N>();
+  const int l = tid % LANES, grp = tid / LANES;
+  const int ty = l / N, tz = l - ty * N;
+  const bool lane_active = l < N * N;
+  for (int round = 0; round < total; round += 256) {
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+    // phase A: one candidate per thread
+    const int k = round + tid;
+    if (k < total) {
+      int r = 0;
+#pragma unroll
+      for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
+      const int idx = rstart[r] + (k - rbase[r]);
+      const int4 a = rec[idx];
+      const int rx = rel_start(a.x, s0, ox, g.nx, N);
+      const int ry = rel_start(a.y, s0, oy, g.ny, N);
+      const int rz = rel_start(a.z, s0, oz, g.nz, N);
+      if (rx < BRICK && ry < BRICK && rz < BRICK) {
+        const int dst = atomicAdd(&nsurv, 1);
+        surv[3 * dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
+        surv[3 * dst + 1] = idx;
+        surv[3 * dst + 2] = a.w;
+      }
+    }
+    __syncthreads();
+    // phase B: one stencil group per surviving atom
+    const int ns = nsurv;
+    for (int sidx = grp; sidx < ns; sidx += GROUPS) {
+      const int packed = surv[3 * sidx];
+      const int idx = surv[3 * sidx + 1];
+      const int orig = surv[3 * sidx + 2];
+      const int rx = (packed << 24) >> 24, ry = (packed << 16) >> 24, rz = (packed << 8) >> 24;
+      T wx[N], wy[N], wz[N], dummy[N];
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 0], wx, dummy);
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 1], wy, dummy);
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 2], wz, dummy);
+      const int py = ry + ty, pz = rz + tz;
+      const bool in_yz = lane_active && py >= 0 && py < BRICK && pz >= 0 && pz < BRICK;
+      if (in_yz) {
+        const T wyz = pick<N, T>(wy, ty) * pick<N, T>(wz, tz) * scale;
+        for (int c = 0; c < C; ++c) {
+          const T qv = val[int64_t(orig) * C + c] * wyz;
+          T* tc = tile + c * BRICK_PTS + py * BRICK + pz;
+#pragma unroll
+          for (int tx = 0; tx < N; ++tx) {
+            const int px = rx + tx;
+            if (px >= 0 && px < BRICK) atomicAdd(tc + px * BRICK * BRICK, qv * wx[tx]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // write the owned points (coalesced along z)
+  const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
+  for (int k = tid; k < C * BRICK_PTS; k += 256) {
+    const int c = k / BRICK_PTS, p = k - c * BRICK_PTS;
+    const int px = p / (BRICK * BRICK), py = (p / BRICK) % BRICK, pz = p % BRICK;
+    const int gx = ox + px, gy = oy + py, gz = oz + pz;
+    if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = tile[k];
+  }
+}
+
+// ---- gather with an LDS halo tile ----------------------------------------------------------------
+// NT = number of meshes staged (1: potential gather, 2: phi and chi for the gradient gather)
+template <int N, int NT, typename T>
+__device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz, const T* __restrict__ m0,
+                                           const T* __restrict__ m1, T* tile) {
+  constexpr int TL = BRICK + N - 1;
+  constexpr int s0 = stencil_start<N>();
+  const int64_t plane = int64_t(g.ny) * g.nz;
+  for (int k = threadIdx.x; k < TL * TL * TL; k += 256) {
+    const int tx = k / (TL * TL), ty = (k / TL) % TL, tz = k % TL;
+    const int gx = posmod(ox + s0 + tx, g.nx), gy = posmod(oy + s0 + ty, g.ny), gz = posmod(oz + s0 + tz, g.nz);
+    const int64_t gi = gx * plane + int64_t(gy) * g.nz + gz;
+    tile[k] = m0[gi];
+    if constexpr (NT == 2) tile[TL * TL * TL + k] = m1[gi];
+  }
+}
+
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void gather_brick_kernel(Geom g, BrickGeom bg, int C, const int* __restrict__ start,
+                                                          const int4* __restrict__ rec, const T* __restrict__ frac,
+                                                          const T* __restrict__ mesh, const T* __restrict__ q,
+                                                          const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
+                                                          T* __restrict__ out, T* __restrict__ raw) {
+  constexpr int LANES = StencilGroup<N>::LANES;
+  constexpr int GROUPS = 256 / LANES;
+  constexpr int TL = BRICK + N - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  int bx, by, bz;
+  brick_coords(bg, blockIdx.x, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
+  if (beg == end) return;
+  const int64_t M = int64_t(g.nx) * g.ny * g.nz;
+  const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  const int ty = l / N, tz = l - ty * N;
+  const bool lane_active = l < N * N;
+  for (int c = 0; c < C; ++c) {
+    if (c > 0) __syncthreads();
+    load_tiles<N, 1, T>(g, ox, oy, oz, mesh + c * M, nullptr, tile);
+    __syncthreads();
+    for (int base = beg; base < end; base += GROUPS) {
+      const int idx = base + grp;
+      const bool valid = idx < end;
+      const int4 a = rec[valid ? idx : beg];
+      const int id = valid ? idx : beg;
+      T wx[N], wy[N], wz[N], dummy[N];
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 0], wx, dummy);
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 1], wy, dummy);
+      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 2], wz, dummy);
+      const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
+      T acc = T(0);
+      if (lane_active) {
+        const T* tp = tile + (ry + ty) * TL + (rz + tz);
+#pragma unroll
+        for (int tx = 0; tx < N; ++tx) acc += tp[(rx + tx) * TL * TL] * wx[tx];
+        acc *= pick<N, T>(wy, ty) * pick<N, T>(wz, tz);
+      }
+      acc = group_sum_b<LANES, T>(acc);
+      if (l == 0 && valid) {
+        const int64_t o = int64_t(a.w) * C + c;
+        if (q) {
+          const T phi = acc * inv_vol;
+          out[o] = T(0.5) * (phi - self_c * q[o] - T(2) * bg_c * inv_vol * qsum[c]);
+          if (raw) raw[o] = phi;
+        } else {
+          out[o] = acc;
+        }
+      }
+    }
+  }
+}
+
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void gather_grad_brick_kernel(Geom g, BrickGeom bg, int C,
+                                                               const int* __restrict__ start,
+                                                               const int4* __restrict__ rec, const T* __restrict__ frac,
+                                                               const T* __restrict__ q, const T* __restrict__ gout,
+                                                               const T* __restrict__ phi, const T* __restrict__ chi,
+                                                               const T* __restrict__ psi_dc, T half_inv_vol, T self_c,
+                                                               T bg_c, T* __restrict__ grad_pos, T* __restrict__ grad_q) {
+  constexpr int LANES = StencilGroup<N>::LANES;
+  constexpr int GROUPS = 256 / LANES;
+  constexpr int TL = BRICK + N - 1;
+  constexpr int TV = TL * TL * TL;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);  // [C][2][TV]: phi, chi
+  int bx, by, bz;
+  brick_coords(bg, blockIdx.x, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
+  if (beg == end) return;
+  const int64_t M = int64_t(g.nx) * g.ny * g.nz;
+  const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  const int ty = l / N, tz = l - ty * N;
+  const bool lane_active = l < N * N;
+  // stage phi and chi of every channel once: tile[(2c + {0: phi, 1: chi}) * TV + k]
+  for (int c = 0; c < C; ++c) load_tiles<N, 2, T>(g, ox, oy, oz, phi + c * M, chi + c * M, tile + 2 * c * TV);
+  __syncthreads();
+  for (int base = beg; base < end; base += GROUPS) {
+    const int idx = base + grp;
+    const bool valid = idx < end;
+    const int id = valid ? idx : beg;
+    const int4 a = rec[id];
+    T wx[N], wy[N], wz[N], dwx[N], dwy[N], dwz[N];
+    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 0], wx, dwx);
+    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 1], wy, dwy);
+    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 2], wz, dwz);
+    const T wyv = pick<N, T>(wy, ty), wzv = pick<N, T>(wz, tz);
+    const T dwyv = pick<N, T>(dwy, ty), dwzv = pick<N, T>(dwz, tz);
+    const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
+    T sx = T(0), sdx = T(0);
+    for (int c = 0; c < C; ++c) {
+      const int64_t o = int64_t(a.w) * C + c;
+      const T hc = gout[o] * half_inv_vol;
+      const T qc = q[o];
+      T schi = T(0);
+      if (lane_active) {
+        const T* tp = tile + 2 * c * TV + (ry + ty) * TL + (rz + tz);
+#pragma unroll
+        for (int tx = 0; tx < N; ++tx) {
+          const T vphi = tp[(rx + tx) * TL * TL];
+          const T vchi = tp[TV + (rx + tx) * TL * TL];
+          const T v = hc * vphi + qc * vchi;
+          sx += v * wx[tx];
+          sdx += v * dwx[tx];
+          schi += vchi * wx[tx];
+        }
+      }
+      if (grad_q) {
+        schi = group_sum_b<LANES, T>(lane_active ? schi * wyv * wzv : T(0));
+        if (l == 0 && valid) grad_q[o] = schi - T(0.5) * self_c * gout[o] - T(2) * bg_c * psi_dc[c];
+      }
+    }
+    if (grad_pos) {
+      const T act = lane_active ? T(1) : T(0);
+      const T ax = group_sum_b<LANES, T>(sdx * wyv * wzv * act) * T(g.nx);
+      const T ay = group_sum_b<LANES, T>(sx * dwyv * wzv * act) * T(g.ny);
+      const T az = group_sum_b<LANES, T>(sx * wyv * dwzv * act) * T(g.nz);
+      if (l == 0 && valid) {
+        const int64_t o = int64_t(a.w);
+        grad_pos[3 * o + 0] = T(g.inv[0]) * ax + T(g.inv[1]) * ay + T(g.inv[2]) * az;
+        grad_pos[3 * o + 1] = T(g.inv[3]) * ax + T(g.inv[4]) * ay + T(g.inv[5]) * az;
+        grad_pos[3 * o + 2] = T(g.inv[6]) * ax + T(g.inv[7]) * ay + T(g.inv[8]) * az;
+      }
+    }
+  }
+}
+
+// ---- host wrappers -----------------------------------------------------------------------------
+#define MIPME_DISPATCH_STENCIL_B(SCHEME_V, ORDER_V, BODY)                                 \
+  do {                                                                                    \
+    bool _done = true;                                                                    \
+    if ((SCHEME_V) == MIPME_P3M) {                                                        \
+      switch (ORDER_V) {                                                                  \
+        case 1: { constexpr int S = MIPME_P3M, N = 1; BODY; } break;                      \
+        case 2: { constexpr int S = MIPME_P3M, N = 2; BODY; } break;                      \
+        case 3: { constexpr int S = MIPME_P3M, N = 3; BODY; } break;                      \
+        case 4: { constexpr int S = MIPME_P3M, N = 4; BODY; } break;                      \
+        case 5: { constexpr int S = MIPME_P3M, N = 5; BODY; } break;                      \
+        default: _done = false;                                                           \
+      }                                                                                   \
+    } else {                                                                              \
+      switch (ORDER_V) {                                                                  \
+        case 3: { constexpr int S = MIPME_LAGRANGE, N = 3; BODY; } break;                 \
+        case 4: { constexpr int S = MIPME_LAGRANGE, N = 4; BODY; } break;                 \
+        case 5: { constexpr int S = MIPME_LAGRANGE, N = 5; BODY; } break;                 \
+        case 6: { constexpr int S = MIPME_LAGRANGE, N = 6; BODY; } break;                 \
+        case 7: { constexpr int S = MIPME_LAGRANGE, N = 7; BODY; } break;                 \
+        default: _done = false;                                                           \
+      }                                                                                   \
+    }                                                                                     \
+    if (!_done) {                                                                         \
+      set_error("unsupported scheme/order %d/%d", int(SCHEME_V), int(ORDER_V));           \
+      return MIPME_EINVAL;                                                                \
+    }                                                                                     \
+  } while (0)
+
+struct BinsView {
+  int *count, *start, *slot, *brick;
+  int4* rec;
+  void* frac;
+};
+
+static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
+  const BinsLayout l = bins_layout(m, N, dtype);
+  char* b = (char*)bins;
+  return BinsView{(int*)(b + l.count), (int*)(b + l.start), (int*)(b + l.slot), (int*)(b + l.brick), (int4*)(b + l.rec),
+                  (void*)(b + l.frac)};
+}
+
+template <typename T>
+int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* pos, void* bins) {
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  const bool even = (m->order % 2) == 0;
+  MIPME_CHECK_HIP(hipMemsetAsync(v.count, 0, sizeof(int) * size_t(bg.nb + 1), st));
+  const unsigned blocks = unsigned((N + 255) / 256);
+  if (N > 0) {
+    bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, N, (const T*)pos, v.count, v.slot, v.brick);
+    MIPME_LAUNCH_CHECK();
+  }
+  bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
+  MIPME_LAUNCH_CHECK();
+  if (N > 0) {
+    bin_fill_kernel<T><<<blocks, 256, 0, st>>>(g, even, N, (const T*)pos, v.start, v.slot, v.brick, v.rec, (T*)v.frac);
+    MIPME_LAUNCH_CHECK();
+  }
+  return MIPME_OK;
+}
+
+template <typename T>
+int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh) {
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * 256 + 28 + 29);
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                           (spread_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)val, T(scale), (T*)mesh)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
+                  const void* qsum, double self_c, double bg_c, void* out, void* raw) {
+  if (N == 0) return MIPME_OK;
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  const int tl = BRICK + m->order - 1;
+  const size_t lds = sizeof(T) * size_t(tl) * tl * tl;
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                           (gather_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)mesh, (const T*)q,
+                               (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* q, const void* gout,
+                       const void* phi, const void* chi, const void* psi_dc, double self_c, double bg_c, void* grad_pos,
+                       void* grad_q) {
+  if (N == 0) return MIPME_OK;
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  const int tl = BRICK + m->order - 1;
+  const size_t lds = 2 * sizeof(T) * size_t(m->n_channels) * tl * tl * tl;
+  MIPME_DISPATCH_STENCIL_B(
+      m->scheme, m->order,
+      (gather_grad_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
+          g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)q, (const T*)gout, (const T*)phi,
+          (const T*)chi, (const T*)psi_dc, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos, (T*)grad_q)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
+template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
+template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
+template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
+template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
+                                  double, double, void*, void*);
+template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
+                                   double, double, void*, void*);
+template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
+                                       const void*, const void*, const void*, double, double, void*, void*);
+template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
+                                        const void*, const void*, const void*, double, double, void*, void*);
+
+}  // namespace mipme

@@ -119,7 +119,6 @@ __global__ void topo_pack_shifts_kernel(int64_t E, const int2* __restrict__ entr
 }
 
 // ---- owner-computes pair kernels ---------------------------------------------------------------
-static constexpr int kRowLanes = 64;  // one wavefront per atom
 static constexpr int kRowsPerBlock = 4;
 
 template <typename T>

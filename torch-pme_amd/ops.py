@@ -102,6 +102,11 @@ def build_filter(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device
 #   "atomic" one pass over the list with hardware float atomics (csrc/rspace.hip); no preprocessing.
 PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
 
+# How atoms meet the mesh: "bricks" (default; atoms binned by 8^3 mesh brick, owner-computes LDS-tile spread,
+# LDS-tiled gathers -- csrc/bricks.hip) or "atomic" (global float atomics -- csrc/mesh.hip).  Meshes too small
+# for bricks always take the atomic kernels.
+MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
+
 
 class PairTopology:
     """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
@@ -207,11 +212,16 @@ class _PMEFunction(torch.autograd.Function):
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
+                bins = None
+                if MESH_MODE == "bricks":
+                    nbytes = lib.mipme_atom_bins_bytes(C.byref(md), N, dt)
+                    if nbytes > 0:
+                        bins = torch.empty((nbytes,), dtype=torch.uint8, device=device)
                 _call(
                     "kspace_forward", lib.mipme_kspace_forward,
-                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                        G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
-                        phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms),
+                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                    G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
+                    phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
                 )
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
@@ -219,7 +229,8 @@ class _PMEFunction(torch.autograd.Function):
                         "slab_forward", lib.mipme_slab_forward, st, dt, slab_axis, C.byref(md), pot_desc.prefactor, N,
                         pos.data_ptr(), q.data_ptr(), moments.data_ptr(), out.data_ptr(),
                     )
-                saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms)
+                saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
+                             bins=bins)
                 accumulate = 1
             else:
                 accumulate = 0
@@ -236,7 +247,7 @@ class _PMEFunction(torch.autograd.Function):
                     st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
                     _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
                 )
-        ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms")))
+        ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")))
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
         return out
@@ -245,7 +256,7 @@ class _PMEFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.load()
-        q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms = ctx.saved_tensors
+        q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins = ctx.saved_tensors
         geom, pot_desc = ctx.geom, ctx.pot_desc
         need_q, need_cell, need_pos, need_dist = ctx.needs_input_grad[:4]
         device, dtype = pos.device, pos.dtype
@@ -279,7 +290,7 @@ class _PMEFunction(torch.autograd.Function):
                         g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
                         _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
                         chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
-                        _lib.ptr(grad_cell),
+                        _lib.ptr(grad_cell), _lib.ptr(bins),
                 )
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
