@@ -46,7 +46,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 }
 
 struct BinsLayout {
-  size_t count, start, slot, brick, rec, frac, total;
+  size_t count, start, slot, brick, rec, wts, total;
 };
 
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
@@ -60,7 +60,7 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.slot = off;  off += al(sizeof(int) * size_t(N));
   l.brick = off; off += al(sizeof(int) * size_t(N));
   l.rec = off;   off += al(sizeof(int4) * size_t(N));
-  l.frac = off;  off += al(4 * s * size_t(N));
+  l.wts = off;   off += al(6 * size_t(m->order) * s * size_t(N));  // per atom: wx, wy, wz, dwx, dwy, dwz (n each)
   l.total = off;
   return l;
 }
@@ -137,22 +137,31 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __res
   if (t == 1023) start[nb] = part[1023];
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, bool even, int64_t N, const T* __restrict__ pos,
+// Scatter the atoms into brick order and evaluate their 1-D weights (and derivatives) ONCE: the four
+// particle<->mesh kernels of a step (spread, gather, spread of the gradient, gradient gather) only load them.
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int64_t Natoms, const T* __restrict__ pos,
                                                       const int* __restrict__ start, const int* __restrict__ slot,
                                                       const int* __restrict__ brick, int4* __restrict__ rec,
-                                                      T* __restrict__ frac) {
+                                                      T* __restrict__ wts) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  if (i >= Natoms) return;
   int m[3];
   double x[3];
-  atom_mesh_coords<T>(g, even, pos, i, m, x);
+  atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
   const int64_t dst = int64_t(start[brick[i]]) + slot[i];
   rec[dst] = make_int4(m[0], m[1], m[2], int(i));
-  frac[4 * dst + 0] = T(x[0]);
-  frac[4 * dst + 1] = T(x[1]);
-  frac[4 * dst + 2] = T(x[2]);
-  frac[4 * dst + 3] = T(0);
+  T* wr = wts + dst * (6 * N);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    T w[N], dw[N];
+    weights_1d<SCHEME, N, true, T>(T(x[d]), w, dw);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      wr[d * N + t] = w[t];
+      wr[(3 + d) * N + t] = dw[t];
+    }
+  }
 }
 
 // ---- shared device helpers ---------------------------------------------------------------------
@@ -178,23 +187,28 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
 }
 
 // ---- spread: owner-computes per brick ------------------------------------------------------------
-template <int SCHEME, int N, typename T>
-__global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg, int C, const int* __restrict__ start,
-                                                          const int4* __restrict__ rec, const T* __restrict__ frac,
-                                                          const T* __restrict__ val, T scale, T* __restrict__ mesh) {
+static constexpr int SPREAD_THREADS = 1024;
+
+template <int N, typename T>
+__global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, BrickGeom bg, int C,
+                                                                     const int* __restrict__ start,
+                                                                     const int4* __restrict__ rec,
+                                                                     const T* __restrict__ wts,
+                                                                     const T* __restrict__ val, T scale,
+                                                                     T* __restrict__ mesh) {
   constexpr int LANES = StencilGroup<N>::LANES;
-  constexpr int GROUPS = 256 / LANES;
+  constexpr int GROUPS = SPREAD_THREADS / LANES;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);                          // [C][512]
-  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [256][3]: packed rel, sorted index, atom
-  int* rstart = surv + 3 * 256;                                      // [28]
+  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [SPREAD_THREADS][3]: packed rel, sorted idx, atom
+  int* rstart = surv + 3 * SPREAD_THREADS;                           // [28]
   int* rbase = rstart + 28;                                          // [28]
   int& nsurv = rbase[28];
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int tid = threadIdx.x;
-  for (int k = tid; k < C * BRICK_PTS; k += 256) tile[k] = T(0);
+  for (int k = tid; k < C * BRICK_PTS; k += SPREAD_THREADS) tile[k] = T(0);
   if (tid < 27) {
     const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
     const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
@@ -217,10 +231,10 @@ __global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg,
   const int l = tid % LANES, grp = tid / LANES;
   const int ty = l / N, tz = l - ty * N;
   const bool lane_active = l < N * N;
-  for (int round = 0; round < total; round += 256) {
+  for (int round = 0; round < total; round += SPREAD_THREADS) {
     if (tid == 0) nsurv = 0;
     __syncthreads();
-    // phase A: one candidate per thread
+    // phase A: one candidate atom per thread -- does its stencil touch this brick?
     const int k = round + tid;
     if (k < total) {
       int r = 0;
@@ -239,21 +253,20 @@ __global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg,
       }
     }
     __syncthreads();
-    // phase B: one stencil group per surviving atom
+    // phase B: one stencil group per surviving atom, LDS float atomics into the brick tile
     const int ns = nsurv;
     for (int sidx = grp; sidx < ns; sidx += GROUPS) {
       const int packed = surv[3 * sidx];
       const int idx = surv[3 * sidx + 1];
       const int orig = surv[3 * sidx + 2];
       const int rx = (packed << 24) >> 24, ry = (packed << 16) >> 24, rz = (packed << 8) >> 24;
-      T wx[N], wy[N], wz[N], dummy[N];
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 0], wx, dummy);
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 1], wy, dummy);
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(idx) + 2], wz, dummy);
       const int py = ry + ty, pz = rz + tz;
-      const bool in_yz = lane_active && py >= 0 && py < BRICK && pz >= 0 && pz < BRICK;
-      if (in_yz) {
-        const T wyz = pick<N, T>(wy, ty) * pick<N, T>(wz, tz) * scale;
+      if (lane_active && py >= 0 && py < BRICK && pz >= 0 && pz < BRICK) {
+        const T* wr = wts + int64_t(idx) * (6 * N);
+        const T wyz = wr[N + ty] * wr[2 * N + tz] * scale;
+        T wx[N];
+#pragma unroll
+        for (int tx = 0; tx < N; ++tx) wx[tx] = wr[tx];
         for (int c = 0; c < C; ++c) {
           const T qv = val[int64_t(orig) * C + c] * wyz;
           T* tc = tile + c * BRICK_PTS + py * BRICK + pz;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg,
   }
   // write the owned points (coalesced along z)
   const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
-  for (int k = tid; k < C * BRICK_PTS; k += 256) {
+  for (int k = tid; k < C * BRICK_PTS; k += SPREAD_THREADS) {
     const int c = k / BRICK_PTS, p = k - c * BRICK_PTS;
     const int px = p / (BRICK * BRICK), py = (p / BRICK) % BRICK, pz = p % BRICK;
     const int gx = ox + px, gy = oy + py, gz = oz + pz;
@@ -279,13 +292,15 @@ __global__ __launch_bounds__(256) void spread_brick_kernel(Geom g, BrickGeom bg,
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
 // NT = number of meshes staged (1: potential gather, 2: phi and chi for the gradient gather)
+static constexpr int GATHER_THREADS = 512;
+
 template <int N, int NT, typename T>
 __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz, const T* __restrict__ m0,
                                            const T* __restrict__ m1, T* tile) {
   constexpr int TL = BRICK + N - 1;
   constexpr int s0 = stencil_start<N>();
   const int64_t plane = int64_t(g.ny) * g.nz;
-  for (int k = threadIdx.x; k < TL * TL * TL; k += 256) {
+  for (int k = threadIdx.x; k < TL * TL * TL; k += GATHER_THREADS) {
     const int tx = k / (TL * TL), ty = (k / TL) % TL, tz = k % TL;
     const int gx = posmod(ox + s0 + tx, g.nx), gy = posmod(oy + s0 + ty, g.ny), gz = posmod(oz + s0 + tz, g.nz);
     const int64_t gi = gx * plane + int64_t(gy) * g.nz + gz;
@@ -294,14 +309,16 @@ __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz
   }
 }
 
-template <int SCHEME, int N, typename T>
-__global__ __launch_bounds__(256) void gather_brick_kernel(Geom g, BrickGeom bg, int C, const int* __restrict__ start,
-                                                          const int4* __restrict__ rec, const T* __restrict__ frac,
-                                                          const T* __restrict__ mesh, const T* __restrict__ q,
-                                                          const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
-                                                          T* __restrict__ out, T* __restrict__ raw) {
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C,
+                                                                     const int* __restrict__ start,
+                                                                     const int4* __restrict__ rec,
+                                                                     const T* __restrict__ wts,
+                                                                     const T* __restrict__ mesh, const T* __restrict__ q,
+                                                                     const T* __restrict__ qsum, T inv_vol, T self_c,
+                                                                     T bg_c, T* __restrict__ out, T* __restrict__ raw) {
   constexpr int LANES = StencilGroup<N>::LANES;
-  constexpr int GROUPS = 256 / LANES;
+  constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
@@ -321,19 +338,16 @@ __global__ __launch_bounds__(256) void gather_brick_kernel(Geom g, BrickGeom bg,
     for (int base = beg; base < end; base += GROUPS) {
       const int idx = base + grp;
       const bool valid = idx < end;
-      const int4 a = rec[valid ? idx : beg];
       const int id = valid ? idx : beg;
-      T wx[N], wy[N], wz[N], dummy[N];
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 0], wx, dummy);
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 1], wy, dummy);
-      weights_1d<SCHEME, N, false, T>(frac[4 * int64_t(id) + 2], wz, dummy);
+      const int4 a = rec[id];
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       T acc = T(0);
       if (lane_active) {
+        const T* wr = wts + int64_t(id) * (6 * N);
         const T* tp = tile + (ry + ty) * TL + (rz + tz);
 #pragma unroll
-        for (int tx = 0; tx < N; ++tx) acc += tp[(rx + tx) * TL * TL] * wx[tx];
-        acc *= pick<N, T>(wy, ty) * pick<N, T>(wz, tz);
+        for (int tx = 0; tx < N; ++tx) acc += tp[(rx + tx) * TL * TL] * wr[tx];
+        acc *= wr[N + ty] * wr[2 * N + tz];
       }
       acc = group_sum_b<LANES, T>(acc);
       if (l == 0 && valid) {
@@ -350,16 +364,13 @@ __global__ __launch_bounds__(256) void gather_brick_kernel(Geom g, BrickGeom bg,
   }
 }
 
-template <int SCHEME, int N, typename T>
-__global__ __launch_bounds__(256) void gather_grad_brick_kernel(Geom g, BrickGeom bg, int C,
-                                                               const int* __restrict__ start,
-                                                               const int4* __restrict__ rec, const T* __restrict__ frac,
-                                                               const T* __restrict__ q, const T* __restrict__ gout,
-                                                               const T* __restrict__ phi, const T* __restrict__ chi,
-                                                               const T* __restrict__ psi_dc, T half_inv_vol, T self_c,
-                                                               T bg_c, T* __restrict__ grad_pos, T* __restrict__ grad_q) {
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
+    Geom g, BrickGeom bg, int C, const int* __restrict__ start, const int4* __restrict__ rec, const T* __restrict__ wts,
+    const T* __restrict__ q, const T* __restrict__ gout, const T* __restrict__ phi, const T* __restrict__ chi,
+    const T* __restrict__ psi_dc, T half_inv_vol, T self_c, T bg_c, T* __restrict__ grad_pos, T* __restrict__ grad_q) {
   constexpr int LANES = StencilGroup<N>::LANES;
-  constexpr int GROUPS = 256 / LANES;
+  constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   constexpr int TV = TL * TL * TL;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -381,12 +392,10 @@ __global__ __launch_bounds__(256) void gather_grad_brick_kernel(Geom g, BrickGeo
     const bool valid = idx < end;
     const int id = valid ? idx : beg;
     const int4 a = rec[id];
-    T wx[N], wy[N], wz[N], dwx[N], dwy[N], dwz[N];
-    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 0], wx, dwx);
-    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 1], wy, dwy);
-    weights_1d<SCHEME, N, true, T>(frac[4 * int64_t(id) + 2], wz, dwz);
-    const T wyv = pick<N, T>(wy, ty), wzv = pick<N, T>(wz, tz);
-    const T dwyv = pick<N, T>(dwy, ty), dwzv = pick<N, T>(dwz, tz);
+    const T* wr = wts + int64_t(id) * (6 * N);
+    const int tyc = lane_active ? ty : 0, tzc = lane_active ? tz : 0;
+    const T wyv = wr[N + tyc], wzv = wr[2 * N + tzc];
+    const T dwyv = wr[4 * N + tyc], dwzv = wr[5 * N + tzc];
     const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
     T sx = T(0), sdx = T(0);
     for (int c = 0; c < C; ++c) {
@@ -401,9 +410,10 @@ __global__ __launch_bounds__(256) void gather_grad_brick_kernel(Geom g, BrickGeo
           const T vphi = tp[(rx + tx) * TL * TL];
           const T vchi = tp[TV + (rx + tx) * TL * TL];
           const T v = hc * vphi + qc * vchi;
-          sx += v * wx[tx];
-          sdx += v * dwx[tx];
-          schi += vchi * wx[tx];
+          const T wxv = wr[tx];
+          sx += v * wxv;
+          sdx += v * wr[3 * N + tx];
+          schi += vchi * wxv;
         }
       }
       if (grad_q) {
@@ -458,14 +468,14 @@ __global__ __launch_bounds__(256) void gather_grad_brick_kernel(Geom g, BrickGeo
 struct BinsView {
   int *count, *start, *slot, *brick;
   int4* rec;
-  void* frac;
+  void* wts;
 };
 
 static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
   const BinsLayout l = bins_layout(m, N, dtype);
   char* b = (char*)bins;
   return BinsView{(int*)(b + l.count), (int*)(b + l.start), (int*)(b + l.slot), (int*)(b + l.brick), (int4*)(b + l.rec),
-                  (void*)(b + l.frac)};
+                  (void*)(b + l.wts)};
 }
 
 template <typename T>
@@ -484,7 +494,9 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* pos
   bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
   MIPME_LAUNCH_CHECK();
   if (N > 0) {
-    bin_fill_kernel<T><<<blocks, 256, 0, st>>>(g, even, N, (const T*)pos, v.start, v.slot, v.brick, v.rec, (T*)v.frac);
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             (bin_fill_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, N, (const T*)pos, v.start, v.slot,
+                                                                              v.brick, v.rec, (T*)v.wts)));
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;
@@ -496,10 +508,10 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * 256 + 28 + 29);
+  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * SPREAD_THREADS + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           (spread_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)val, T(scale), (T*)mesh)));
+                           ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -515,8 +527,8 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const int tl = BRICK + m->order - 1;
   const size_t lds = sizeof(T) * size_t(tl) * tl * tl;
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           (gather_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)mesh, (const T*)q,
+                           ((void)S, gather_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
@@ -535,8 +547,8 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
   const size_t lds = 2 * sizeof(T) * size_t(m->n_channels) * tl * tl * tl;
   MIPME_DISPATCH_STENCIL_B(
       m->scheme, m->order,
-      (gather_grad_brick_kernel<S, N, T><<<unsigned(bg.nb), 256, lds, st>>>(
-          g, bg, m->n_channels, v.start, v.rec, (const T*)v.frac, (const T*)q, (const T*)gout, (const T*)phi,
+      ((void)S, gather_grad_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
+          g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)q, (const T*)gout, (const T*)phi,
           (const T*)chi, (const T*)psi_dc, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos, (T*)grad_q)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;

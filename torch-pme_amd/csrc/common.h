@@ -80,6 +80,31 @@ __device__ __forceinline__ int posmod(int a, int n) {
 //   Lagrange : nodes xi_t = t - (n-1)/2,  w_t(x) = prod_{s!=t} (x - xi_s)/(xi_t - xi_s).
 // x in [-1/2, 1/2].  `DERIV` also fills dw/dx.
 // ---------------------------------------------------------------------------------------------
+// One Cox-de Boor step a[j] = N_K(f + j) from a[j] = N_{K-1}(f + j); K is a compile-time constant so that every
+// array index is static and the arrays live in VGPRs (a runtime-bounded loop nest sent them to scratch memory).
+template <int K, int N, typename T>
+__device__ __forceinline__ void bspline_step(T f, T (&a)[N]) {
+  constexpr T inv = T(1) / T(K - 1);
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    const T lo = (j < K - 1) ? a[j] : T(0);
+    const T hi = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : T(0);
+    a[j] = ((f + T(j)) * lo + (T(K - j) - f) * hi) * inv;
+  }
+}
+
+template <int K, int N, typename T>
+__device__ __forceinline__ void bspline_raise(T f, T (&a)[N], T (&b)[N]) {
+  if constexpr (K <= N) {
+    if constexpr (K == N) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) b[j] = (j < N - 1) ? a[j] : T(0);
+    }
+    bspline_step<K, N, T>(f, a);
+    bspline_raise<K + 1, N, T>(f, a, b);
+  }
+}
+
 template <int SCHEME, int N, bool DERIV, typename T>
 __device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
   if constexpr (SCHEME == MIPME_P3M) {
@@ -94,19 +119,8 @@ __device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
 #pragma unroll
       for (int j = 1; j < N; ++j) a[j] = T(0);
 #pragma unroll
-      for (int k = 2; k <= N; ++k) {
-        if (k == N) {
-#pragma unroll
-          for (int j = 0; j < N; ++j) b[j] = (j < N - 1) ? a[j] : T(0);
-        }
-        const T inv = T(1) / T(k - 1);
-#pragma unroll
-        for (int j = k - 1; j >= 0; --j) {
-          const T lo = (j < k - 1) ? a[j] : T(0);
-          const T hi = (j >= 1) ? a[j - 1] : T(0);
-          a[j] = ((f + T(j)) * lo + (T(k - j) - f) * hi) * inv;
-        }
-      }
+      for (int j = 0; j < N; ++j) b[j] = T(0);
+      bspline_raise<2, N, T>(f, a, b);
 #pragma unroll
       for (int t = 0; t < N; ++t) {
         w[t] = a[N - 1 - t];
@@ -121,6 +135,7 @@ __device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
     for (int t = 0; t < N; ++t) {
       // den = prod_{s != t} (t - s) = (-1)^(N-1-t) t! (N-1-t)!
       double den = 1.0;
+#pragma unroll
       for (int s = 0; s < N; ++s)
         if (s != t) den *= double(t - s);
       T p = T(1), dp = T(0);
