@@ -107,11 +107,15 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 
 /* out_lr[i,c] = 1/2 [ gather(convolve(spread(q)))/V - q*self - 2*bg*Q_c/V ]      (no slab term)
  * Work buffers (caller allocated): rho_mesh, phi_mesh (C,nx,ny,nz); rho_hat, hat_work complex half grids;
- * dc (C).  phi_mesh, rho_hat, dc and out_phi (N,C, nullable: the raw gather/V) are what the backward needs. */
+ * dc (C).  phi_mesh, rho_hat, dc and out_phi (N,C, nullable: the raw gather/V) are what the backward needs.
+ * gather_wait_event (hipEvent_t as void*, nullable) + accumulate_out = 1: the final gather first waits for the event
+ * and then ADDS the long-range part to out_lr -- the short-range pair sum can then run concurrently on a second
+ * stream, writing out_lr with accumulate = 0 and recording that event (bandwidth-bound pair kernels hide under the
+ * latency-bound mesh kernels). */
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* atom_bins);
+                         void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
  * (In the reference this is PyTorch autograd through the ATen chain)

@@ -281,6 +281,30 @@ def test_mesh_modes(mode, dtype, scheme, order, monkeypatch):
     assert relmax(tc.grad.cpu(), gr["cell"]) < tol * 50
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_stream_overlap_matches_serial(golden_dir, overlap, monkeypatch):
+    """Pair kernels on the side stream (default) or serialised on the caller's stream: same numbers, repeatedly."""
+    from torchpme_amd import ops
+
+    monkeypatch.setattr(ops, "OVERLAP", overlap)
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])),
+                             mesh_spacing=float(z["p3m5/mesh_spacing"]), interpolation_nodes=5)
+    pos = torch.tensor(z["positions"], device=DEV, requires_grad=True)
+    cell = torch.tensor(z["cell"], device=DEV)
+    q = torch.tensor(z["charges"], device=DEV, requires_grad=True)
+    pairs = torch.tensor(z["pairs"], device=DEV)
+    S = torch.tensor(z["shifts"], device=DEV, dtype=torch.float64)
+    for _ in range(5):
+        pos.grad = q.grad = None
+        d = tpa.pair_distances(pos, pairs, cell, S)
+        V = calc(q, cell, pos, pairs, d)
+        (V * q).sum().backward()
+        assert rell2(V.detach().cpu(), z["p3m5/f64/V"]) < 1e-10
+        assert rell2(pos.grad.cpu(), z["p3m5/f64/grad_positions"]) < 1e-10
+        assert rell2(q.grad.cpu(), z["p3m5/f64/grad_charges"]) < 1e-10
+
+
 def test_native_library_loaded():
     """The tests above must have run through libmipme.so (no silent fallback exists)."""
     with open("/proc/self/maps") as f:

@@ -79,7 +79,7 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 11,
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci],
         "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 18,
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],

@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 // implemented in mesh.hip / kfilter.hip / rspace.hip
 template <typename T> int spread_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, double, void*);
 template <typename T> int gather_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
-template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*, int);
 template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
@@ -46,7 +46,7 @@ bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
-template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
@@ -105,7 +105,8 @@ static int check_plan(const mipme_fft_plan* plan, int dtype, const mipme_mesh_t*
 template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
-                            void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins) {
+                            void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
+                            void* wait_event, int accumulate) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -119,10 +120,12 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
   STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
   STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, phi_mesh));
+  // the short-range sum may be running on another stream into out_lr: join it before the gather adds to it
+  if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
-    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi));
+    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
   else
-    STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi));
+    STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
   return MIPME_OK;
 }
 
@@ -360,7 +363,7 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* bins) {
+                         void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -371,9 +374,9 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins),
+                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins));
+                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,

@@ -316,7 +316,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ mesh, const T* __restrict__ q,
                                                                      const T* __restrict__ qsum, T inv_vol, T self_c,
-                                                                     T bg_c, T* __restrict__ out, T* __restrict__ raw) {
+                                                                     T bg_c, bool accumulate, T* __restrict__ out,
+                                                                     T* __restrict__ raw) {
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
         const int64_t o = int64_t(a.w) * C + c;
         if (q) {
           const T phi = acc * inv_vol;
-          out[o] = T(0.5) * (phi - self_c * q[o] - T(2) * bg_c * inv_vol * qsum[c]);
+          const T lr = T(0.5) * (phi - self_c * q[o] - T(2) * bg_c * inv_vol * qsum[c]);
+          out[o] = accumulate ? out[o] + lr : lr;
           if (raw) raw[o] = phi;
         } else {
           out[o] = acc;
@@ -479,23 +481,23 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
 }
 
 template <typename T>
-int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* pos, void* bins) {
+int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
-  const BinsView v = bins_view(m, N, dtype, bins);
+  const BinsView v = bins_view(m, n_atoms, dtype, bins);
   const bool even = (m->order % 2) == 0;
   MIPME_CHECK_HIP(hipMemsetAsync(v.count, 0, sizeof(int) * size_t(bg.nb + 1), st));
-  const unsigned blocks = unsigned((N + 255) / 256);
-  if (N > 0) {
-    bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, N, (const T*)pos, v.count, v.slot, v.brick);
+  const unsigned blocks = unsigned((n_atoms + 255) / 256);
+  if (n_atoms > 0) {
+    bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, n_atoms, (const T*)pos, v.count, v.slot, v.brick);
     MIPME_LAUNCH_CHECK();
   }
   bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
   MIPME_LAUNCH_CHECK();
-  if (N > 0) {
+  if (n_atoms > 0) {
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             (bin_fill_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, N, (const T*)pos, v.start, v.slot,
+                             (bin_fill_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, n_atoms, (const T*)pos, v.start, v.slot,
                                                                               v.brick, v.rec, (T*)v.wts)));
     MIPME_LAUNCH_CHECK();
   }
@@ -518,7 +520,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
 
 template <typename T>
 int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
-                  const void* qsum, double self_c, double bg_c, void* out, void* raw) {
+                  const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
@@ -529,7 +531,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, gather_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
                                g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
-                               (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw)));
+                               (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out, (T*)raw)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -559,9 +561,9 @@ template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                  double, double, void*, void*);
+                                  double, double, void*, void*, int);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                   double, double, void*, void*);
+                                   double, double, void*, void*, int);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
                                        const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,

@@ -108,6 +108,23 @@ PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
 MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 
 
+# The bandwidth-bound pair kernels and the latency-bound mesh kernels of one evaluation are independent until
+# the final sum, so they run concurrently: pair work on a per-device side stream, mesh work on the caller's stream,
+# joined with HIP events (SURVEY.md 7 "hard part 2": at 32k atoms the step is launch/latency limited).
+OVERLAP = os.environ.get("MIPME_OVERLAP", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    """(side stream, fork event, join event) of ``device``; events are re-recorded every call."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    entry = _SIDE.get(key)
+    if entry is None:
+        entry = (torch.cuda.Stream(device), torch.cuda.Event(), torch.cuda.Event())
+        _SIDE[key] = entry
+    return entry
+
+
 class PairTopology:
     """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
 
@@ -202,6 +219,23 @@ class _PMEFunction(torch.autograd.Function):
         saved = {}
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
+            topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
+
+            def run_rspace(accumulate):
+                stream = _lib.current_stream(device)
+                if topo is not None:
+                    _call(
+                        "rspace_forward", lib.mipme_rspace_rows,
+                        stream, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(),
+                        q.data_ptr(), _lib.ptr(mask), 0, int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
+                    )
+                else:
+                    _call(
+                        "rspace_forward", lib.mipme_rspace_forward,
+                        stream, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(),
+                        q.data_ptr(), _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
+                    )
+
             if geom is not None:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn)
@@ -217,11 +251,23 @@ class _PMEFunction(torch.autograd.Function):
                     nbytes = lib.mipme_atom_bins_bytes(C.byref(md), N, dt)
                     if nbytes > 0:
                         bins = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+                overlap = OVERLAP and topo is not None
+                join = None
+                if overlap:
+                    # short-range sum on the side stream (writes `out`); the gather at the end of the mesh
+                    # pipeline waits for it and adds the long-range part
+                    side, fork, join = _side_stream(device)
+                    fork.record()
+                    side.wait_event(fork)
+                    with torch.cuda.stream(side):
+                        run_rspace(0)
+                        join.record()
                 _call(
                     "kspace_forward", lib.mipme_kspace_forward,
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                     G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
+                    join.cuda_event if overlap else None, 1 if overlap else 0,
                 )
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
@@ -231,22 +277,10 @@ class _PMEFunction(torch.autograd.Function):
                     )
                 saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
                              bins=bins)
-                accumulate = 1
+                if not overlap:
+                    run_rspace(1)
             else:
-                accumulate = 0
-            topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
-            if topo is not None:
-                _call(
-                    "rspace_forward", lib.mipme_rspace_rows,
-                    st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                    _lib.ptr(mask), 0, int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
-                )
-            else:
-                _call(
-                    "rspace_forward", lib.mipme_rspace_forward,
-                    st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                    _lib.ptr(mask), int(full_list), C.byref(pot_desc), accumulate, out.data_ptr(),
-                )
+                run_rspace(0)
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")))
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
@@ -267,7 +301,29 @@ class _PMEFunction(torch.autograd.Function):
         grad_q = grad_pos = grad_cell = grad_dist = None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
-            if geom is not None and (need_q or need_cell or need_pos):
+            topo = ctx.topo
+            do_kspace = geom is not None and (need_q or need_cell or need_pos)
+            if need_dist:
+                grad_dist = torch.empty((P,), dtype=dtype, device=device)
+
+            def run_grad_dist(with_charges):
+                # grad_dist is a per-pair stream (no scatter); in "atomic" mode the same kernel also scatters grad_q
+                _call(
+                    "rspace_backward", lib.mipme_rspace_backward,
+                    _lib.current_stream(device), dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(),
+                    dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(),
+                    _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
+                )
+
+            overlap = OVERLAP and topo is not None and do_kspace and need_dist
+            if overlap:
+                side, fork, join = _side_stream(device)
+                fork.record()
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    run_grad_dist(False)
+                    join.record()
+            if do_kspace:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn)
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
@@ -286,11 +342,11 @@ class _PMEFunction(torch.autograd.Function):
                     partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64, device=device)
                 _call(
                     "kspace_backward", lib.mipme_kspace_backward,
-                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
-                        _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
-                        chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
-                        _lib.ptr(grad_cell), _lib.ptr(bins),
+                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                    g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
+                    _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
+                    chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
+                    _lib.ptr(grad_cell), _lib.ptr(bins),
                 )
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
@@ -303,24 +359,16 @@ class _PMEFunction(torch.autograd.Function):
                     grad_pos = None
             elif need_q:
                 grad_q = torch.zeros((N, Cn), dtype=dtype, device=device)
-            if need_dist or need_q:
-                if need_dist:
-                    grad_dist = torch.empty((P,), dtype=dtype, device=device)
-                topo = ctx.topo
-                # grad_dist is a per-pair stream (no scatter); the charge gradient is a per-atom row sum
-                if need_dist or topo is None:
-                    _call(
-                        "rspace_backward", lib.mipme_rspace_backward,
-                        st, dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                        _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(), _lib.ptr(grad_dist),
-                        _lib.ptr(grad_q) if (need_q and topo is None) else None,
-                    )
-                if need_q and topo is not None:
-                    _call(
-                        "rspace_backward_charges", lib.mipme_rspace_rows,
-                        st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
-                        _lib.ptr(mask), 1, int(ctx.full_list), C.byref(pot_desc), 1, grad_q.data_ptr(),
-                    )
+            if overlap:
+                torch.cuda.current_stream(device).wait_event(join)
+            elif need_dist or (need_q and topo is None):
+                run_grad_dist(need_q and topo is None)
+            if need_q and topo is not None:
+                _call(
+                    "rspace_backward_charges", lib.mipme_rspace_rows,
+                    st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
+                    _lib.ptr(mask), 1, int(ctx.full_list), C.byref(pot_desc), 1, grad_q.data_ptr(),
+                )
             if geom is None:
                 if need_pos:
                     grad_pos = torch.zeros((N, 3), dtype=dtype, device=device)
