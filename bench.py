@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,8 +152,20 @@ def main():
     s = 4 if w.dtype == "f32" else 8
     energies = torch.zeros(world, dtype=frame.dtype, device=device)
 
+    launch = args.launch
+    graphed = None
+    if launch == "graph":
+        try:
+            graphed = tpa.GraphedEnergyForces(frame.calc, frame.q, frame.cell, frame.pos, frame.pairs, frame.shifts)
+        except Exception as exc:  # capture not possible on this stack: fall back to eager launches, and say so
+            print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
+            launch = "eager"
+
     def one_step():
-        E, F = frame.step()
+        if graphed is not None:
+            E, F = graphed()
+        else:
+            E, F = frame.step()
         if distributed:
             dist.all_gather_into_tensor(energies, E.reshape(1))
         return E
@@ -217,6 +231,7 @@ def main():
                             f"{w.scheme} order {w.order}, {w.n_mesh}^3 mesh, "
                             f"{'Coulomb' if w.exponent == 1 else '1/r^%d' % w.exponent}, {w.dtype}, energy+forces via autograd",
                 "frames_per_gpu": 1,
+                "launch": "HIP graph replay of the captured step" if launch == "graph" else "eager kernel launches",
                 "parallelism": f"{world} independent frame(s), one per GPU",
             },
             "roofline": {

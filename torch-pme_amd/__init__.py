@@ -9,6 +9,7 @@ repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI 
 from . import lib, prefactors  # noqa: F401
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, P3MCalculator, PMECalculator
+from .graphed import GraphedEnergyForces
 from .neighbors import neighbor_list
 from .ops import pair_distances
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
@@ -23,5 +24,6 @@ __all__ = [
     "InversePowerLawPotential",
     "Potential",
     "pair_distances",
+    "GraphedEnergyForces",
     "neighbor_list",
 ]

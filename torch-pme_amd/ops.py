@@ -111,7 +111,7 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 # The bandwidth-bound pair kernels and the latency-bound mesh kernels of one evaluation are independent until
 # the final sum, so they run concurrently: pair work on a per-device side stream, mesh work on the caller's stream,
 # joined with HIP events (SURVEY.md 7 "hard part 2": at 32k atoms the step is launch/latency limited).
-OVERLAP = os.environ.get("MIPME_OVERLAP", "1") != "0"
+OVERLAP = os.environ.get("MIPME_OVERLAP", "0") != "0"  # measured: cross-stream event joins cost more than they hide in eager mode
 _SIDE = {}
 
 
