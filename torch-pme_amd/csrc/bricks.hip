@@ -99,18 +99,38 @@ __device__ __forceinline__ void atom_mesh_coords(const Geom& g, bool even, const
 }
 
 // ---- binning -----------------------------------------------------------------------------------
+// Lanes of a wavefront that fall into the same brick share ONE returning atomic (atoms are usually stored in a
+// spatially coherent order, so a wave touches only a handful of bricks): leader election over the ballot mask.
 template <typename T>
 __global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bool even, int64_t N,
                                                        const T* __restrict__ pos, int* __restrict__ count,
                                                        int* __restrict__ slot, int* __restrict__ brick) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int m[3];
-  double x[3];
-  atom_mesh_coords<T>(g, even, pos, i, m, x);
-  const int b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
-  brick[i] = b;
-  slot[i] = atomicAdd(&count[b], 1);
+  const bool valid = i < N;
+  const int lane = threadIdx.x & 63;
+  int b = -1;
+  if (valid) {
+    int m[3];
+    double x[3];
+    atom_mesh_coords<T>(g, even, pos, i, m, x);
+    b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
+  }
+  unsigned long long remaining = __ballot(valid);
+  int myslot = 0;
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int b0 = __shfl(b, leader, 64);
+    const unsigned long long peers = __ballot(valid && b == b0);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&count[b0], __popcll(peers));
+    base = __shfl(base, leader, 64);
+    if (valid && b == b0) myslot = base + __popcll(peers & ((1ull << lane) - 1ull));
+    remaining &= ~peers;
+  }
+  if (valid) {
+    brick[i] = b;
+    slot[i] = myslot;
+  }
 }
 
 // exclusive scan of count[0..nb) into start[0..nb]; single block
@@ -188,6 +208,7 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
 
 // ---- spread: owner-computes per brick ------------------------------------------------------------
 static constexpr int SPREAD_THREADS = 1024;
+static constexpr int SPREAD_CAND_PER_THREAD = 2;
 
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, BrickGeom bg, int C,
@@ -200,8 +221,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
   constexpr int GROUPS = SPREAD_THREADS / LANES;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);                          // [C][512]
-  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [SPREAD_THREADS][3]: packed rel, sorted idx, atom
-  int* rstart = surv + 3 * SPREAD_THREADS;                           // [28]
+  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [CPT*SPREAD_THREADS][3]: packed rel, sorted idx, atom
+  int* rstart = surv + 3 * SPREAD_CAND_PER_THREAD * SPREAD_THREADS;  // [28]
   int* rbase = rstart + 28;                                          // [28]
   int& nsurv = rbase[28];
   int bx, by, bz;
@@ -228,52 +249,82 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
   __syncthreads();
   const int total = rbase[27];
   constexpr int s0 = stencil_start<N>();
+  constexpr int CPT = SPREAD_CAND_PER_THREAD;  // candidates per thread and round
+  constexpr int UB = 4;                        // survivors whose loads are in flight together in phase B
   const int l = tid % LANES, grp = tid / LANES;
   const int ty = l / N, tz = l - ty * N;
   const bool lane_active = l < N * N;
-  for (int round = 0; round < total; round += SPREAD_THREADS) {
+  for (int round = 0; round < total; round += CPT * SPREAD_THREADS) {
     if (tid == 0) nsurv = 0;
     __syncthreads();
-    // phase A: one candidate atom per thread -- does its stencil touch this brick?
-    const int k = round + tid;
-    if (k < total) {
-      int r = 0;
+    // phase A: candidate atoms of the 27 surrounding bricks -- does the stencil touch this brick?
+    int cidx[CPT];
+    int4 crec[CPT];
 #pragma unroll
-      for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
-      const int idx = rstart[r] + (k - rbase[r]);
-      const int4 a = rec[idx];
-      const int rx = rel_start(a.x, s0, ox, g.nx, N);
-      const int ry = rel_start(a.y, s0, oy, g.ny, N);
-      const int rz = rel_start(a.z, s0, oz, g.nz, N);
-      if (rx < BRICK && ry < BRICK && rz < BRICK) {
-        const int dst = atomicAdd(&nsurv, 1);
-        surv[3 * dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
-        surv[3 * dst + 1] = idx;
-        surv[3 * dst + 2] = a.w;
+    for (int u = 0; u < CPT; ++u) {
+      const int k = round + u * SPREAD_THREADS + tid;
+      cidx[u] = -1;
+      if (k < total) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
+        cidx[u] = rstart[r] + (k - rbase[r]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      if (cidx[u] >= 0) {
+        const int rx = rel_start(crec[u].x, s0, ox, g.nx, N);
+        const int ry = rel_start(crec[u].y, s0, oy, g.ny, N);
+        const int rz = rel_start(crec[u].z, s0, oz, g.nz, N);
+        if (rx < BRICK && ry < BRICK && rz < BRICK) {
+          const int dst = atomicAdd(&nsurv, 1);
+          surv[3 * dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
+          surv[3 * dst + 1] = cidx[u];
+          surv[3 * dst + 2] = crec[u].w;
+        }
       }
     }
     __syncthreads();
     // phase B: one stencil group per surviving atom, LDS float atomics into the brick tile
     const int ns = nsurv;
-    for (int sidx = grp; sidx < ns; sidx += GROUPS) {
-      const int packed = surv[3 * sidx];
-      const int idx = surv[3 * sidx + 1];
-      const int orig = surv[3 * sidx + 2];
-      const int rx = (packed << 24) >> 24, ry = (packed << 16) >> 24, rz = (packed << 8) >> 24;
-      const int py = ry + ty, pz = rz + tz;
-      if (lane_active && py >= 0 && py < BRICK && pz >= 0 && pz < BRICK) {
+    for (int sbase = grp; sbase < ns; sbase += GROUPS * UB) {
+      int rxs[UB], orig[UB];
+      bool on[UB];
+      T wyz[UB], wx[UB][N], qv0[UB];
+      int py[UB], pz[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int sidx = sbase + u * GROUPS;
+        on[u] = sidx < ns;
+        const int sc = on[u] ? sidx : sbase;
+        const int packed = surv[3 * sc];
+        const int idx = surv[3 * sc + 1];
+        orig[u] = surv[3 * sc + 2];
+        rxs[u] = (packed << 24) >> 24;
+        py[u] = ((packed << 16) >> 24) + ty;
+        pz[u] = ((packed << 8) >> 24) + tz;
+        on[u] = on[u] && lane_active && py[u] >= 0 && py[u] < BRICK && pz[u] >= 0 && pz[u] < BRICK;
         const T* wr = wts + int64_t(idx) * (6 * N);
-        const T wyz = wr[N + ty] * wr[2 * N + tz] * scale;
-        T wx[N];
+        const int tyc = lane_active ? ty : 0, tzc = lane_active ? tz : 0;
+        wyz[u] = wr[N + tyc] * wr[2 * N + tzc] * scale;
 #pragma unroll
-        for (int tx = 0; tx < N; ++tx) wx[tx] = wr[tx];
-        for (int c = 0; c < C; ++c) {
-          const T qv = val[int64_t(orig) * C + c] * wyz;
-          T* tc = tile + c * BRICK_PTS + py * BRICK + pz;
+        for (int tx = 0; tx < N; ++tx) wx[u][tx] = wr[tx];
+        qv0[u] = val[int64_t(orig[u]) * C];
+      }
 #pragma unroll
-          for (int tx = 0; tx < N; ++tx) {
-            const int px = rx + tx;
-            if (px >= 0 && px < BRICK) atomicAdd(tc + px * BRICK * BRICK, qv * wx[tx]);
+      for (int u = 0; u < UB; ++u) {
+        if (on[u]) {
+          for (int c = 0; c < C; ++c) {
+            const T qv = (c == 0 ? qv0[u] : val[int64_t(orig[u]) * C + c]) * wyz[u];
+            T* tc = tile + c * BRICK_PTS + py[u] * BRICK + pz[u];
+#pragma unroll
+            for (int tx = 0; tx < N; ++tx) {
+              const int px = rxs[u] + tx;
+              if (px >= 0 && px < BRICK) atomicAdd(tc + px * BRICK * BRICK, qv * wx[u][tx]);
+            }
           }
         }
       }
@@ -510,7 +561,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * SPREAD_THREADS + 28 + 29);
+  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * SPREAD_CAND_PER_THREAD * SPREAD_THREADS + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
                                g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));

@@ -131,12 +131,17 @@ __device__ __forceinline__ T wave_sum(T v) {
 // out[a,c] (+)= 1/2 sum_{entries of a} src[other,c] * v_SR(dist[p])
 //   roles: forward uses role i (+ role j for a half list) with src = charges;
 //          the charge gradient uses role j (+ role i for a half list) with src = upstream gradient.
+// Entries are processed U at a time per lane: all entry loads are issued first, then all dependent gathers
+// (dist[p], src[other]), then the arithmetic -- one memory round trip per 64*U entries instead of per 64.
+static constexpr int kRowUnroll = 4;
+
 template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, int C, const int* __restrict__ row_ptr,
                                                          const int2* __restrict__ entries, const T* __restrict__ dist,
                                                          const T* __restrict__ src, const uint8_t* __restrict__ mask,
                                                          int role_lo, int role_hi, bool accumulate,
                                                          T* __restrict__ out) {
+  constexpr int U = kRowUnroll;
   const int lane = threadIdx.x & 63;
   const int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + (threadIdx.x >> 6);
   if (a >= N) return;
@@ -145,14 +150,31 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
     T acc[CMAX];
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) acc[k] = T(0);
-    for (int e = beg + lane; e < end; e += 64) {
-      const int2 en = entries[e];
-      if (mask && !mask[en.y]) continue;
-      T v, dv;
-      sr_eval<T, false>(s, dist[en.y], v, dv);
+    for (int base = beg; base < end; base += 64 * U) {
+      int2 en[U];
+      bool ok[U];
 #pragma unroll
-      for (int k = 0; k < CMAX; ++k)
-        if (c0 + k < C) acc[k] += src[int64_t(en.x) * C + c0 + k] * v;
+      for (int u = 0; u < U; ++u) {
+        const int e = base + u * 64 + lane;
+        ok[u] = e < end;
+        en[u] = entries[ok[u] ? e : beg];
+      }
+      T d[U], sv[U][CMAX];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (mask) ok[u] = ok[u] && mask[en[u].y];
+        d[u] = dist[en[u].y];
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) sv[u][k] = (c0 + k < C) ? src[int64_t(en[u].x) * C + c0 + k] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        T v, dv;
+        sr_eval<T, false>(s, d[u], v, dv);
+        v = ok[u] ? v : T(0);
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) acc[k] += sv[u][k] * v;
+      }
     }
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) {
@@ -192,36 +214,59 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
   if (a < N) {
     const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
     const int beg = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = row_ptr[2 * a + 2];
-    for (int e = beg + lane; e < end; e += 64) {
-      const int2 en = entries[e];
-      const T sign = e < mid ? T(-1) : T(1);  // role i: a is the tail of vec (gradient -gvec); role j: +gvec
-      T sx = T(0), sy = T(0), sz = T(0);
-      if (packed) {
-        const int w = packed[e];
-        sx = T(unpack8(w, 0));
-        sy = T(unpack8(w, 1));
-        sz = T(unpack8(w, 2));
-      } else if (shifts) {
-        sx = shifts[3 * int64_t(en.y)];
-        sy = shifts[3 * int64_t(en.y) + 1];
-        sz = shifts[3 * int64_t(en.y) + 2];
+    constexpr int U = kRowUnroll;
+    for (int base = beg; base < end; base += 64 * U) {
+      int2 en[U];
+      int pk[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = base + u * 64 + lane;
+        ok[u] = e < end;
+        const int ec = ok[u] ? e : beg;
+        en[u] = entries[ec];
+        pk[u] = packed ? packed[ec] : 0;
       }
-      // vec = r_j - r_i + S A ; with o = other atom: role i -> r_o - r_a + S A ; role j -> r_a - r_o + S A
-      const T ox = pos[3 * int64_t(en.x)], oy = pos[3 * int64_t(en.x) + 1], oz = pos[3 * int64_t(en.x) + 2];
-      const T vx = -sign * (ox - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
-      const T vy = -sign * (oy - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
-      const T vz = -sign * (oz - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
-      const T d = fsqrt(vx * vx + vy * vy + vz * vz);
-      const T sc = grad_d[en.y] / d;
-      gx += sign * sc * vx;
-      gy += sign * sc * vy;
-      gz += sign * sc * vz;
-      if constexpr (CELLGRAD) {
-        if (e < mid) {
-          const double px = double(sc * vx), py = double(sc * vy), pz = double(sc * vz);
-          cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
-          cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
-          cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
+      T gd[U], ox[U], oy[U], oz[U], shx[U], shy[U], shz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        gd[u] = grad_d[en[u].y];
+        ox[u] = pos[3 * int64_t(en[u].x)];
+        oy[u] = pos[3 * int64_t(en[u].x) + 1];
+        oz[u] = pos[3 * int64_t(en[u].x) + 2];
+        if (packed) {
+          shx[u] = T(unpack8(pk[u], 0));
+          shy[u] = T(unpack8(pk[u], 1));
+          shz[u] = T(unpack8(pk[u], 2));
+        } else if (shifts) {
+          shx[u] = shifts[3 * int64_t(en[u].y)];
+          shy[u] = shifts[3 * int64_t(en[u].y) + 1];
+          shz[u] = shifts[3 * int64_t(en[u].y) + 2];
+        } else {
+          shx[u] = shy[u] = shz[u] = T(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = base + u * 64 + lane;
+        const T sign = e < mid ? T(-1) : T(1);  // role i: a is the tail of vec (gradient -gvec); role j: +gvec
+        const T sx = shx[u], sy = shy[u], sz = shz[u];
+        // vec = r_j - r_i + S A ; with o = other atom: role i -> r_o - r_a + S A ; role j -> r_a - r_o + S A
+        const T vx = -sign * (ox[u] - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
+        const T vy = -sign * (oy[u] - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
+        const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
+        const T d2 = vx * vx + vy * vy + vz * vz;
+        const T sc = ok[u] ? gd[u] / fsqrt(d2) : T(0);
+        gx += sign * sc * vx;
+        gy += sign * sc * vy;
+        gz += sign * sc * vz;
+        if constexpr (CELLGRAD) {
+          if (ok[u] && e < mid) {
+            const double px = double(sc * vx), py = double(sc * vy), pz = double(sc * vz);
+            cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
+            cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
+            cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
+          }
         }
       }
     }
