@@ -10,12 +10,15 @@
 //            coalesced loads; the n^3 stencil reads of every atom then hit LDS instead of L2.
 // Replaces, like mesh.hip, MeshInterpolator.compute_weights / points_to_mesh / mesh_to_points
 // (reference lib/mesh_interpolator.py:303-457).
+#include <algorithm>
+
 #include "common.h"
 
 namespace mipme {
 
 static constexpr int BRICK = 8;
 static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
+static constexpr int SPREAD_STAGE_HOST = 256;
 
 struct BrickGeom {
   int nbx, nby, nbz, nb;
@@ -41,7 +44,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   }
   const size_t tile = BRICK + m->order - 1;
   if (2 * size_t(m->n_channels) * tile * tile * tile * s > 60 * 1024) return false;  // gather_grad: phi+chi per channel
-  if (size_t(m->n_channels) * BRICK_PTS * s > 48 * 1024) return false;               // spread: one tile per channel
+  if (s * std::max<size_t>(4 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * (3 * m->order + m->n_channels)) > 46 * 1024) return false;  // spread staging
   return true;
 }
 
@@ -206,9 +209,18 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
   return r;
 }
 
-// ---- spread: owner-computes per brick ------------------------------------------------------------
-static constexpr int SPREAD_THREADS = 1024;
-static constexpr int SPREAD_CAND_PER_THREAD = 2;
+// ---- spread: owner-computes per brick, no atomics of any kind ------------------------------------------
+// (LDS float atomics turned out to be the limiter of the first brick version: ~30 us for 4 M ds_add_f32.)
+//   A1  every thread tests candidates of the 27 surrounding bricks (independent 16-byte loads) and appends the
+//       atoms whose stencil overlaps the brick to an LDS index list;
+//   A2  survivors are staged 256 at a time: thread t copies the 3n weights and the C values of survivor t to LDS;
+//   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+4, ...:
+//       two lane-dependent LDS reads (wx, wy) and n broadcast reads (wz) per survivor, no atomics;
+//   R   the four waves' partial bricks are summed through LDS and written with coalesced stores.
+static constexpr int SPREAD_THREADS = 256;
+static constexpr int SPREAD_CPT = 8;                              // candidates per thread and round
+static constexpr int SPREAD_ROUND = SPREAD_THREADS * SPREAD_CPT;  // 2048
+static constexpr int SPREAD_STAGE = 256;                          // survivors staged together
 
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, BrickGeom bg, int C,
@@ -217,19 +229,20 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ val, T scale,
                                                                      T* __restrict__ mesh) {
-  constexpr int LANES = StencilGroup<N>::LANES;
-  constexpr int GROUPS = SPREAD_THREADS / LANES;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);                          // [C][512]
-  int* surv = reinterpret_cast<int*>(tile + size_t(C) * BRICK_PTS);  // [CPT*SPREAD_THREADS][3]: packed rel, sorted idx, atom
-  int* rstart = surv + 3 * SPREAD_CAND_PER_THREAD * SPREAD_THREADS;  // [28]
-  int* rbase = rstart + 28;                                          // [28]
+  const int SW = 3 * N + C;                                 // staged reals per survivor
+  const int region = max(4 * BRICK_PTS, SPREAD_STAGE * SW);
+  T* stage = reinterpret_cast<T*>(smem_raw);                // [SPREAD_STAGE][SW] staged weights + value
+  T* part = stage;                                          // [4 waves][512] partial bricks (aliases the stage, phase R)
+  int* srel = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND] packed rel
+  int* sidx = srel + SPREAD_ROUND;                          // [SPREAD_ROUND] sorted atom index
+  int* rstart = sidx + SPREAD_ROUND;                        // [28]
+  int* rbase = rstart + 28;                                 // [28]
   int& nsurv = rbase[28];
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
-  const int tid = threadIdx.x;
-  for (int k = tid; k < C * BRICK_PTS; k += SPREAD_THREADS) tile[k] = T(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 27) {
     const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
     const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
@@ -249,95 +262,88 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
   __syncthreads();
   const int total = rbase[27];
   constexpr int s0 = stencil_start<N>();
-  constexpr int CPT = SPREAD_CAND_PER_THREAD;  // candidates per thread and round
-  constexpr int UB = 4;                        // survivors whose loads are in flight together in phase B
-  const int l = tid % LANES, grp = tid / LANES;
-  const int ty = l / N, tz = l - ty * N;
-  const bool lane_active = l < N * N;
-  for (int round = 0; round < total; round += CPT * SPREAD_THREADS) {
-    if (tid == 0) nsurv = 0;
-    __syncthreads();
-    // phase A: candidate atoms of the 27 surrounding bricks -- does the stencil touch this brick?
-    int cidx[CPT];
-    int4 crec[CPT];
+  const int px = lane >> 3, py = lane & 7;  // this lane's (x,y) column of the brick
+  const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
+  for (int c = 0; c < C; ++c) {
+    T acc[BRICK];
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      const int k = round + u * SPREAD_THREADS + tid;
-      cidx[u] = -1;
-      if (k < total) {
-        int r = 0;
+    for (int k = 0; k < BRICK; ++k) acc[k] = T(0);
+    for (int round = 0; round < total; round += SPREAD_ROUND) {
+      if (tid == 0) nsurv = 0;
+      __syncthreads();
+      // A1: which candidate stencils overlap this brick?
+      int cidx[SPREAD_CPT];
+      int4 crec[SPREAD_CPT];
 #pragma unroll
-        for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
-        cidx[u] = rstart[r] + (k - rbase[r]);
-      }
-    }
+      for (int u = 0; u < SPREAD_CPT; ++u) {
+        const int k = round + u * SPREAD_THREADS + tid;
+        cidx[u] = -1;
+        if (k < total) {
+          int r = 0;
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      if (cidx[u] >= 0) {
-        const int rx = rel_start(crec[u].x, s0, ox, g.nx, N);
-        const int ry = rel_start(crec[u].y, s0, oy, g.ny, N);
-        const int rz = rel_start(crec[u].z, s0, oz, g.nz, N);
-        if (rx < BRICK && ry < BRICK && rz < BRICK) {
-          const int dst = atomicAdd(&nsurv, 1);
-          surv[3 * dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
-          surv[3 * dst + 1] = cidx[u];
-          surv[3 * dst + 2] = crec[u].w;
+          for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
+          cidx[u] = rstart[r] + (k - rbase[r]);
         }
       }
-    }
-    __syncthreads();
-    // phase B: one stencil group per surviving atom, LDS float atomics into the brick tile
-    const int ns = nsurv;
-    for (int sbase = grp; sbase < ns; sbase += GROUPS * UB) {
-      int rxs[UB], orig[UB];
-      bool on[UB];
-      T wyz[UB], wx[UB][N], qv0[UB];
-      int py[UB], pz[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int sidx = sbase + u * GROUPS;
-        on[u] = sidx < ns;
-        const int sc = on[u] ? sidx : sbase;
-        const int packed = surv[3 * sc];
-        const int idx = surv[3 * sc + 1];
-        orig[u] = surv[3 * sc + 2];
-        rxs[u] = (packed << 24) >> 24;
-        py[u] = ((packed << 16) >> 24) + ty;
-        pz[u] = ((packed << 8) >> 24) + tz;
-        on[u] = on[u] && lane_active && py[u] >= 0 && py[u] < BRICK && pz[u] >= 0 && pz[u] < BRICK;
-        const T* wr = wts + int64_t(idx) * (6 * N);
-        const int tyc = lane_active ? ty : 0, tzc = lane_active ? tz : 0;
-        wyz[u] = wr[N + tyc] * wr[2 * N + tzc] * scale;
+      for (int u = 0; u < SPREAD_CPT; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
 #pragma unroll
-        for (int tx = 0; tx < N; ++tx) wx[u][tx] = wr[tx];
-        qv0[u] = val[int64_t(orig[u]) * C];
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        if (on[u]) {
-          for (int c = 0; c < C; ++c) {
-            const T qv = (c == 0 ? qv0[u] : val[int64_t(orig[u]) * C + c]) * wyz[u];
-            T* tc = tile + c * BRICK_PTS + py[u] * BRICK + pz[u];
-#pragma unroll
-            for (int tx = 0; tx < N; ++tx) {
-              const int px = rxs[u] + tx;
-              if (px >= 0 && px < BRICK) atomicAdd(tc + px * BRICK * BRICK, qv * wx[u][tx]);
-            }
+      for (int u = 0; u < SPREAD_CPT; ++u) {
+        if (cidx[u] >= 0) {
+          const int rx = rel_start(crec[u].x, s0, ox, g.nx, N);
+          const int ry = rel_start(crec[u].y, s0, oy, g.ny, N);
+          const int rz = rel_start(crec[u].z, s0, oz, g.nz, N);
+          if (rx < BRICK && ry < BRICK && rz < BRICK) {
+            const int dst = atomicAdd(&nsurv, 1);
+            srel[dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
+            sidx[dst] = cidx[u];
           }
         }
       }
+      __syncthreads();
+      const int ns = nsurv;
+      for (int chunk = 0; chunk < ns; chunk += SPREAD_STAGE) {
+        const int nst = min(SPREAD_STAGE, ns - chunk);
+        // A2: stage weights and the value of this channel
+        if (tid < nst) {
+          const int si = sidx[chunk + tid];
+          const int orig = rec[si].w;
+          const T* wr = wts + int64_t(si) * (6 * N);
+          T* dst = stage + tid * SW;
+#pragma unroll
+          for (int k = 0; k < 3 * N; ++k) dst[k] = wr[k];
+          dst[3 * N] = val[int64_t(orig) * C + c] * scale;
+        }
+        __syncthreads();
+        // C: register accumulation, wave w takes survivors w, w+4, ...
+        for (int sv = wave; sv < nst; sv += 4) {
+          const int packed = srel[chunk + sv];
+          const int rx = (packed << 24) >> 24, ry = (packed << 16) >> 24, rz = (packed << 8) >> 24;
+          const int tx = px - rx, ty = py - ry;
+          if (tx >= 0 && tx < N && ty >= 0 && ty < N) {
+            const T* sw = stage + sv * SW;
+            const T wxy = sw[tx] * sw[N + ty] * sw[3 * N];
+#pragma unroll
+            for (int pz = 0; pz < BRICK; ++pz) {
+              const int tz = pz - rz;
+              if (tz >= 0 && tz < N) acc[pz] += wxy * sw[2 * N + tz];
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // R: sum the four waves' partial bricks and write the owned points (the stage is free again: last sync above)
+#pragma unroll
+    for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
+    __syncthreads();
+    for (int k = tid; k < BRICK_PTS; k += SPREAD_THREADS) {
+      const T v = part[k] + part[BRICK_PTS + k] + part[2 * BRICK_PTS + k] + part[3 * BRICK_PTS + k];
+      const int qx = k / (BRICK * BRICK), qy = (k / BRICK) % BRICK, qz = k % BRICK;
+      const int gx = ox + qx, gy = oy + qy, gz = oz + qz;
+      if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = v;
     }
     __syncthreads();
-  }
-  // write the owned points (coalesced along z)
-  const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
-  for (int k = tid; k < C * BRICK_PTS; k += SPREAD_THREADS) {
-    const int c = k / BRICK_PTS, p = k - c * BRICK_PTS;
-    const int px = p / (BRICK * BRICK), py = (p / BRICK) % BRICK, pz = p % BRICK;
-    const int gx = ox + px, gy = oy + py, gz = oz + pz;
-    if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = tile[k];
   }
 }
 
@@ -561,7 +567,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t lds = sizeof(T) * size_t(m->n_channels) * BRICK_PTS + sizeof(int) * (3 * SPREAD_CAND_PER_THREAD * SPREAD_THREADS + 28 + 29);
+  const size_t region = std::max<size_t>(4 * BRICK_PTS, size_t(SPREAD_STAGE) * (3 * m->order + m->n_channels));
+  const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
                                g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));
