@@ -11,6 +11,7 @@
 // Replaces, like mesh.hip, MeshInterpolator.compute_weights / points_to_mesh / mesh_to_points
 // (reference lib/mesh_interpolator.py:303-457).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -44,7 +45,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   }
   const size_t tile = BRICK + m->order - 1;
   if (2 * size_t(m->n_channels) * tile * tile * tile * s > 60 * 1024) return false;  // gather_grad: phi+chi per channel
-  if (s * std::max<size_t>(4 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * (3 * m->order + m->n_channels)) > 46 * 1024) return false;  // spread staging
+  if (s * std::max<size_t>(8 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * (3 * m->order + m->n_channels)) > 46 * 1024) return false;  // spread staging
   return true;
 }
 
@@ -217,8 +218,41 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
 //   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+4, ...:
 //       two lane-dependent LDS reads (wx, wy) and n broadcast reads (wz) per survivor, no atomics;
 //   R   the four waves' partial bricks are summed through LDS and written with coalesced stores.
-static constexpr int SPREAD_THREADS = 256;
-static constexpr int SPREAD_CPT = 8;                              // candidates per thread and round
+// acc[RZ + t] += wxy * wz[t] for the stencil points that fall inside the brick; RZ (first z point relative to the
+// brick) is a template parameter so that every accumulator index is static (registers, no selects).
+template <int N, int RZ, typename T>
+__device__ __forceinline__ void add_column(T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    constexpr int lo = RZ;
+    if (lo + t >= 0 && lo + t < BRICK) acc[(lo + t >= 0 && lo + t < BRICK) ? lo + t : 0] += wxy * wz[t];
+  }
+}
+
+template <int N, typename T>
+__device__ __forceinline__ void add_column_dispatch(int rz, T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
+  switch (rz) {  // rz is wave-uniform (one survivor per wave iteration): a scalar branch
+    case -6: add_column<N, -6, T>(acc, wxy, wz); break;
+    case -5: add_column<N, -5, T>(acc, wxy, wz); break;
+    case -4: add_column<N, -4, T>(acc, wxy, wz); break;
+    case -3: add_column<N, -3, T>(acc, wxy, wz); break;
+    case -2: add_column<N, -2, T>(acc, wxy, wz); break;
+    case -1: add_column<N, -1, T>(acc, wxy, wz); break;
+    case 0: add_column<N, 0, T>(acc, wxy, wz); break;
+    case 1: add_column<N, 1, T>(acc, wxy, wz); break;
+    case 2: add_column<N, 2, T>(acc, wxy, wz); break;
+    case 3: add_column<N, 3, T>(acc, wxy, wz); break;
+    case 4: add_column<N, 4, T>(acc, wxy, wz); break;
+    case 5: add_column<N, 5, T>(acc, wxy, wz); break;
+    case 6: add_column<N, 6, T>(acc, wxy, wz); break;
+    case 7: add_column<N, 7, T>(acc, wxy, wz); break;
+    default: break;
+  }
+}
+
+static constexpr int SPREAD_THREADS = 512;
+static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
+static constexpr int SPREAD_CPT = 4;                              // candidates per thread and round
 static constexpr int SPREAD_ROUND = SPREAD_THREADS * SPREAD_CPT;  // 2048
 static constexpr int SPREAD_STAGE = 256;                          // survivors staged together
 
@@ -228,12 +262,12 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      const int4* __restrict__ rec,
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ val, T scale,
-                                                                     T* __restrict__ mesh) {
+                                                                     T* __restrict__ mesh, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int SW = 3 * N + C;                                 // staged reals per survivor
-  const int region = max(4 * BRICK_PTS, SPREAD_STAGE * SW);
+  const int region = max(SPREAD_WAVES * BRICK_PTS, SPREAD_STAGE * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [SPREAD_STAGE][SW] staged weights + value
-  T* part = stage;                                          // [4 waves][512] partial bricks (aliases the stage, phase R)
+  T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
   int* srel = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND] packed rel
   int* sidx = srel + SPREAD_ROUND;                          // [SPREAD_ROUND] sorted atom index
   int* rstart = sidx + SPREAD_ROUND;                        // [28]
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
     rbase[27] = run;
   }
   __syncthreads();
-  const int total = rbase[27];
+  const int total = (dbg & 1) ? 0 : rbase[27];
   constexpr int s0 = stencil_start<N>();
   const int px = lane >> 3, py = lane & 7;  // this lane's (x,y) column of the brick
   const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
@@ -301,7 +335,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
         }
       }
       __syncthreads();
-      const int ns = nsurv;
+      const int ns = (dbg & 2) ? 0 : nsurv;
       for (int chunk = 0; chunk < ns; chunk += SPREAD_STAGE) {
         const int nst = min(SPREAD_STAGE, ns - chunk);
         // A2: stage weights and the value of this channel
@@ -315,20 +349,36 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
           dst[3 * N] = val[int64_t(orig) * C + c] * scale;
         }
         __syncthreads();
-        // C: register accumulation, wave w takes survivors w, w+4, ...
-        for (int sv = wave; sv < nst; sv += 4) {
-          const int packed = srel[chunk + sv];
-          const int rx = (packed << 24) >> 24, ry = (packed << 16) >> 24, rz = (packed << 8) >> 24;
-          const int tx = px - rx, ty = py - ry;
-          if (tx >= 0 && tx < N && ty >= 0 && ty < N) {
-            const T* sw = stage + sv * SW;
-            const T wxy = sw[tx] * sw[N + ty] * sw[3 * N];
+        // C: register accumulation; wave w takes survivors w, w+W, ...; four survivors per iteration so that
+        // their LDS reads overlap (the loop is a chain of dependent LDS reads otherwise)
+        constexpr int UC = 4;
+        const int nstc = (dbg & 4) ? 0 : nst;
+        for (int sv0 = wave; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
+          int pk[UC];
+          bool live[UC];
 #pragma unroll
-            for (int pz = 0; pz < BRICK; ++pz) {
-              const int tz = pz - rz;
-              if (tz >= 0 && tz < N) acc[pz] += wxy * sw[2 * N + tz];
-            }
+          for (int u = 0; u < UC; ++u) {
+            const int sv = sv0 + u * SPREAD_WAVES;
+            live[u] = sv < nstc;
+            pk[u] = srel[chunk + (live[u] ? sv : sv0)];
           }
+          T wxy[UC], wz[UC][N];
+          int rzs[UC];
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            const int sv = live[u] ? sv0 + u * SPREAD_WAVES : sv0;
+            const int rx = (pk[u] << 24) >> 24, ry = (pk[u] << 16) >> 24;
+            rzs[u] = (pk[u] << 8) >> 24;
+            const int tx = px - rx, ty = py - ry;
+            const bool in = live[u] && tx >= 0 && tx < N && ty >= 0 && ty < N;
+            const T* sw = stage + sv * SW;
+            wxy[u] = in ? sw[in ? tx : 0] * sw[N + (in ? ty : 0)] * sw[3 * N] : T(0);
+#pragma unroll
+            for (int t = 0; t < N; ++t) wz[u][t] = sw[2 * N + t];  // wave-uniform address: LDS broadcast
+          }
+#pragma unroll
+          for (int u = 0; u < UC; ++u)
+            add_column_dispatch<N, T>(__builtin_amdgcn_readfirstlane(rzs[u]), acc, wxy[u], wz[u]);
         }
         __syncthreads();
       }
@@ -338,7 +388,9 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
     for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
     __syncthreads();
     for (int k = tid; k < BRICK_PTS; k += SPREAD_THREADS) {
-      const T v = part[k] + part[BRICK_PTS + k] + part[2 * BRICK_PTS + k] + part[3 * BRICK_PTS + k];
+      T v = T(0);
+#pragma unroll
+      for (int w = 0; w < SPREAD_WAVES; ++w) v += part[w * BRICK_PTS + k];
       const int qx = k / (BRICK * BRICK), qy = (k / BRICK) % BRICK, qz = k % BRICK;
       const int gx = ox + qx, gy = oy + qy, gz = oz + qz;
       if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = v;
@@ -567,11 +619,12 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t region = std::max<size_t>(4 * BRICK_PTS, size_t(SPREAD_STAGE) * (3 * m->order + m->n_channels));
+  static const int dbg = getenv("MIPME_SPREAD_DBG") ? atoi(getenv("MIPME_SPREAD_DBG")) : 0;
+  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(SPREAD_STAGE) * (3 * m->order + m->n_channels));
   const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh, dbg)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
