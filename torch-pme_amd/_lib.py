@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipme.so")
+LIB_PATH = os.environ.get("MIPME_LIB", os.path.join(_HERE, "libmipme.so"))  # MIPME_LIB: alternative build (experiments)
 
 F32, F64 = 0, 1
 I64, I32 = 0, 1

@@ -14,6 +14,8 @@
 // deterministic summation order (stable radix sort).
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "srpot.h"
 
@@ -119,7 +121,9 @@ __global__ void topo_pack_shifts_kernel(int64_t E, const int2* __restrict__ entr
 }
 
 // ---- owner-computes pair kernels ---------------------------------------------------------------
-static constexpr int kRowsPerBlock = 4;
+#ifndef MIPME_ROW_UNROLL
+#define MIPME_ROW_UNROLL 4
+#endif
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -131,9 +135,19 @@ __device__ __forceinline__ T wave_sum(T v) {
 // out[a,c] (+)= 1/2 sum_{entries of a} src[other,c] * v_SR(dist[p])
 //   roles: forward uses role i (+ role j for a half list) with src = charges;
 //          the charge gradient uses role j (+ role i for a half list) with src = upstream gradient.
-// Entries are processed U at a time per lane: all entry loads are issued first, then all dependent gathers
-// (dist[p], src[other]), then the arithmetic -- one memory round trip per 64*U entries instead of per 64.
-static constexpr int kRowUnroll = 4;
+// Row kernels: kRowLanes lanes own one atom's row (4 atoms per wavefront -- a wavefront per atom was limited by the
+// fixed per-wave latency: row_ptr fetch, reduction, store), and every lane keeps kRowUnroll entries in flight:
+// all entry loads are issued first, then the dependent gathers (dist[p], src[other]), then the arithmetic.
+static constexpr int kRowUnroll = MIPME_ROW_UNROLL;
+static constexpr int kRowLanes = 16;
+static constexpr int kRowsPerBlock = 256 / kRowLanes;
+
+template <typename T>
+__device__ __forceinline__ T row_sum(T v) {
+#pragma unroll
+  for (int off = kRowLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kRowLanes);
+  return v;
+}
 
 template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, int C, const int* __restrict__ row_ptr,
@@ -142,20 +156,21 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
                                                          int role_lo, int role_hi, bool accumulate,
                                                          T* __restrict__ out) {
   constexpr int U = kRowUnroll;
-  const int lane = threadIdx.x & 63;
-  const int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + (threadIdx.x >> 6);
-  if (a >= N) return;
-  const int beg = row_ptr[2 * a + role_lo], end = row_ptr[2 * a + role_hi + 1];
+  const int sub = threadIdx.x % kRowLanes;
+  int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;  // keep the lanes alive for the shuffles; nothing is written
+  const int beg = row_ptr[2 * a + role_lo], end = valid ? row_ptr[2 * a + role_hi + 1] : beg;
   for (int c0 = 0; c0 < C; c0 += CMAX) {
     T acc[CMAX];
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) acc[k] = T(0);
-    for (int base = beg; base < end; base += 64 * U) {
+    for (int base = beg; base < end; base += kRowLanes * U) {
       int2 en[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = base + u * 64 + lane;
+        const int e = base + u * kRowLanes + sub;
         ok[u] = e < end;
         en[u] = entries[ok[u] ? e : beg];
       }
@@ -178,8 +193,8 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
     }
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) {
-      const T tot = wave_sum(acc[k]);
-      if (lane == 0 && c0 + k < C) {
+      const T tot = row_sum(acc[k]);
+      if (sub == 0 && valid && c0 + k < C) {
         T* o = out + a * C + c0 + k;
         *o = (accumulate ? *o : T(0)) + T(0.5) * tot;
       }
@@ -200,96 +215,97 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
                                                                     const T* __restrict__ grad_d,
                                                                     T* __restrict__ grad_pos,
                                                                     double* __restrict__ partials) {
+  constexpr int U = kRowUnroll;
   T A[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
-  const int lane = threadIdx.x & 63;
-  const int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + (threadIdx.x >> 6);
+  const int sub = threadIdx.x % kRowLanes;
+  int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;
   T gx = T(0), gy = T(0), gz = T(0);
   double cg[9];
   if constexpr (CELLGRAD) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) cg[k] = 0.0;
   }
-  if (a < N) {
-    const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
-    const int beg = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = row_ptr[2 * a + 2];
-    constexpr int U = kRowUnroll;
-    for (int base = beg; base < end; base += 64 * U) {
-      int2 en[U];
-      int pk[U];
-      bool ok[U];
+  const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+  const int beg = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = valid ? row_ptr[2 * a + 2] : beg;
+  for (int base = beg; base < end; base += kRowLanes * U) {
+    int2 en[U];
+    int pk[U];
+    bool ok[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = base + u * 64 + lane;
-        ok[u] = e < end;
-        const int ec = ok[u] ? e : beg;
-        en[u] = entries[ec];
-        pk[u] = packed ? packed[ec] : 0;
-      }
-      T gd[U], ox[U], oy[U], oz[U], shx[U], shy[U], shz[U];
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * kRowLanes + sub;
+      ok[u] = e < end;
+      const int ec = ok[u] ? e : beg;
+      en[u] = entries[ec];
+      pk[u] = packed ? packed[ec] : 0;
+    }
+    T gd[U], ox[U], oy[U], oz[U], shx[U], shy[U], shz[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        gd[u] = grad_d[en[u].y];
-        ox[u] = pos[3 * int64_t(en[u].x)];
-        oy[u] = pos[3 * int64_t(en[u].x) + 1];
-        oz[u] = pos[3 * int64_t(en[u].x) + 2];
-        if (packed) {
-          shx[u] = T(unpack8(pk[u], 0));
-          shy[u] = T(unpack8(pk[u], 1));
-          shz[u] = T(unpack8(pk[u], 2));
-        } else if (shifts) {
-          shx[u] = shifts[3 * int64_t(en[u].y)];
-          shy[u] = shifts[3 * int64_t(en[u].y) + 1];
-          shz[u] = shifts[3 * int64_t(en[u].y) + 2];
-        } else {
-          shx[u] = shy[u] = shz[u] = T(0);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = base + u * 64 + lane;
-        const T sign = e < mid ? T(-1) : T(1);  // role i: a is the tail of vec (gradient -gvec); role j: +gvec
-        const T sx = shx[u], sy = shy[u], sz = shz[u];
-        // vec = r_j - r_i + S A ; with o = other atom: role i -> r_o - r_a + S A ; role j -> r_a - r_o + S A
-        const T vx = -sign * (ox[u] - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
-        const T vy = -sign * (oy[u] - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
-        const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
-        const T d2 = vx * vx + vy * vy + vz * vz;
-        const T sc = ok[u] ? gd[u] / fsqrt(d2) : T(0);
-        gx += sign * sc * vx;
-        gy += sign * sc * vy;
-        gz += sign * sc * vz;
-        if constexpr (CELLGRAD) {
-          if (ok[u] && e < mid) {
-            const double px = double(sc * vx), py = double(sc * vy), pz = double(sc * vz);
-            cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
-            cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
-            cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
-          }
-        }
+    for (int u = 0; u < U; ++u) {
+      gd[u] = grad_d[en[u].y];
+      ox[u] = pos[3 * int64_t(en[u].x)];
+      oy[u] = pos[3 * int64_t(en[u].x) + 1];
+      oz[u] = pos[3 * int64_t(en[u].x) + 2];
+      if (packed) {
+        shx[u] = T(unpack8(pk[u], 0));
+        shy[u] = T(unpack8(pk[u], 1));
+        shz[u] = T(unpack8(pk[u], 2));
+      } else if (shifts) {
+        shx[u] = shifts[3 * int64_t(en[u].y)];
+        shy[u] = shifts[3 * int64_t(en[u].y) + 1];
+        shz[u] = shifts[3 * int64_t(en[u].y) + 2];
+      } else {
+        shx[u] = shy[u] = shz[u] = T(0);
       }
     }
-    gx = wave_sum(gx);
-    gy = wave_sum(gy);
-    gz = wave_sum(gz);
-    if (lane == 0) {
-      grad_pos[3 * a] = gx;
-      grad_pos[3 * a + 1] = gy;
-      grad_pos[3 * a + 2] = gz;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * kRowLanes + sub;
+      const T sign = e < mid ? T(-1) : T(1);  // role i: a is the tail of vec (gradient -gvec); role j: +gvec
+      const T sx = shx[u], sy = shy[u], sz = shz[u];
+      // vec = r_j - r_i + S A ; with o = other atom: role i -> r_o - r_a + S A ; role j -> r_a - r_o + S A
+      const T vx = -sign * (ox[u] - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
+      const T vy = -sign * (oy[u] - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
+      const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
+      const T d2 = vx * vx + vy * vy + vz * vz;
+      const T sc = ok[u] ? gd[u] / fsqrt(d2) : T(0);
+      gx += sign * sc * vx;
+      gy += sign * sc * vy;
+      gz += sign * sc * vz;
+      if constexpr (CELLGRAD) {
+        if (ok[u] && e < mid) {
+          const double px = double(sc * vx), py = double(sc * vy), pz = double(sc * vz);
+          cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
+          cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
+          cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
+        }
+      }
     }
   }
+  gx = row_sum(gx);
+  gy = row_sum(gy);
+  gz = row_sum(gz);
+  if (sub == 0 && valid) {
+    grad_pos[3 * a] = gx;
+    grad_pos[3 * a + 1] = gy;
+    grad_pos[3 * a + 2] = gz;
+  }
   if constexpr (CELLGRAD) {
-    __shared__ double red[kRowsPerBlock][9];
+    __shared__ double red[4][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const double v = wave_sum(cg[k]);
-      if (lane == 0) red[threadIdx.x >> 6][k] = v;
+      if (lane == 0) red[wave][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < 9) {
       double v = 0.0;
-      for (int w = 0; w < kRowsPerBlock; ++w) v += red[w][threadIdx.x];
+      for (int w = 0; w < 4; ++w) v += red[w][threadIdx.x];
       partials[int64_t(blockIdx.x) * 9 + threadIdx.x] = v;
     }
   }
