@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload water|ionic|dispersion]
 
 One *step* = one energy + forces evaluation of one frame per GPU, the reference's protocol
-(BASELINE.md section 2): ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = (q*V).sum()`` ->
+(BASELINE.md section 2): ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = sum(q*V)`` ->
 ``E.backward()`` (forces = -dE/dpositions).  Inputs are resident in HBM before the timed region.  With N > 1
 every rank owns an independent frame (weak scaling, no intra-cell decomposition) and the per-frame energies
 are exchanged with one RCCL all_gather per step.
@@ -64,7 +64,7 @@ class Frame:
         self.pos.grad = None
         d = tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
         V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
-        E = (V * self.q).sum()
+        E = tpa.weighted_sum(V, self.q)
         E.backward()
         return E.detach(), self.pos.grad
 

@@ -168,6 +168,12 @@ int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pair
                           int full_list, const mipme_potential_t* pot, const void* grad_out, void* grad_dist,
                           void* grad_charges);
 
+/* ---- caller side: the energy reduction E = sum_ic q_ic V_ic (README.rst:112-114, tests/calculators/test_values_ewald.py:306)
+ * as one kernel, and its adjoint grad_a = g*b, grad_b = g*a (g: device scalar; grad_a / grad_b nullable). ---- */
+int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* out);
+int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
+                       void* grad_b);
+
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 
 /* d[p] = | r[j] - r[i] + shifts[p] @ cell |.  cell: DEVICE (9 reals); shifts (P,3) reals (nullable = 0). */

@@ -305,6 +305,19 @@ def test_stream_overlap_matches_serial(golden_dir, overlap, monkeypatch):
         assert rell2(q.grad.cpu(), z["p3m5/f64/grad_charges"]) < 1e-10
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_weighted_sum(dtype):
+    torch.manual_seed(0)
+    a = torch.randn(1000, 3, device=DEV, dtype=dtype, requires_grad=True)
+    b = torch.randn(1000, 3, device=DEV, dtype=dtype, requires_grad=True)
+    E = tpa.weighted_sum(a, b)
+    (2.5 * E).backward()
+    ref = (a.detach().double() * b.detach().double()).sum()
+    assert abs(E.item() - ref.item()) < (1e-12 if dtype == torch.float64 else 1e-4) * max(1.0, abs(ref.item()))
+    torch.testing.assert_close(a.grad, 2.5 * b.detach())
+    torch.testing.assert_close(b.grad, 2.5 * a.detach())
+
+
 def test_native_library_loaded():
     """The tests above must have run through libmipme.so (no silent fallback exists)."""
     with open("/proc/self/maps") as f:

@@ -11,7 +11,7 @@ from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces
 from .neighbors import neighbor_list
-from .ops import pair_distances
+from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
 
 __version__ = "0.1.0"
@@ -24,6 +24,7 @@ __all__ = [
     "InversePowerLawPotential",
     "Potential",
     "pair_distances",
+    "weighted_sum",
     "GraphedEnergyForces",
     "neighbor_list",
 ]

@@ -28,7 +28,7 @@ EXPORTS = (
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
     "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
-    "mipme_profile_enable", "mipme_profile_report",
+    "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
 )
 
 
@@ -91,6 +91,8 @@ def _declare(lib):
         "mipme_topology_pack_shifts": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_rspace_rows": [vp, ci, i64, ci, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp],
         "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_dot_forward": [vp, ci, i64, vp, vp, vp],
+        "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

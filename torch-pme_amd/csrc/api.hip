@@ -253,6 +253,37 @@ __global__ void slab_cell_kernel(int axis, int C, mipme_mesh_t m, double c0, dou
     }
 }
 
+// ---- E = sum_i a_i b_i (the caller's energy reduction, README.rst:112-114) and its adjoint ---------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                  T* __restrict__ out) {
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += double(a[i]) * double(b[i]);
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) v += red[w];
+    out[0] = T(v);
+  }
+}
+
+// out_a[i] = g * b[i], out_b[i] = g * a[i]  (g: device scalar)
+template <typename T>
+__global__ __launch_bounds__(256) void dot_backward_kernel(int64_t n, const T* __restrict__ g, const T* __restrict__ a,
+                                                          const T* __restrict__ b, T* __restrict__ out_a,
+                                                          T* __restrict__ out_b) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T gv = g[0];
+  if (out_a) out_a[i] = gv * b[i];
+  if (out_b) out_b[i] = gv * a[i];
+}
+
 static double axis_length(const mipme_mesh_t* m, int axis) {
   const double* a = m->cell + 3 * axis;
   return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -522,6 +553,41 @@ int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t
   hipStream_t st = (hipStream_t)stream;
   IDX_SWITCH(dtype, idx_dtype, distance_backward_impl, st, n_pairs, n_atoms, pairs, positions, cell, shifts, grad_dist,
              partials, grad_positions, grad_cell);
+}
+
+int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* out) {
+  MIPME_REQUIRE(n >= 0 && out && (n == 0 || (a && b)), "invalid arguments to mipme_dot_forward");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    dot_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)a, (const float*)b, (float*)out);
+  else if (dtype == MIPME_F64)
+    dot_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)a, (const double*)b, (double*)out);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
+                       void* grad_b) {
+  MIPME_REQUIRE(n >= 0 && grad && (n == 0 || (a && b)), "invalid arguments to mipme_dot_backward");
+  if (n == 0 || (!grad_a && !grad_b)) return MIPME_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = unsigned((n + 255) / 256);
+  if (dtype == MIPME_F32)
+    dot_backward_kernel<float><<<blocks, 256, 0, st>>>(n, (const float*)grad, (const float*)a, (const float*)b,
+                                                       (float*)grad_a, (float*)grad_b);
+  else if (dtype == MIPME_F64)
+    dot_backward_kernel<double><<<blocks, 256, 0, st>>>(n, (const double*)grad, (const double*)a, (const double*)b,
+                                                        (double*)grad_a, (double*)grad_b);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
 }
 
 int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }

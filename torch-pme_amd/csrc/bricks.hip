@@ -119,18 +119,25 @@ __global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bo
     atom_mesh_coords<T>(g, even, pos, i, m, x);
     b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
   }
+  // pass 1 (no memory traffic): group the lanes by brick; every lane learns its leader lane and its rank
   unsigned long long remaining = __ballot(valid);
-  int myslot = 0;
+  int my_leader = lane, my_rank = 0, my_count = 0;
   while (remaining) {
     const int leader = __ffsll((long long)remaining) - 1;
     const int b0 = __shfl(b, leader, 64);
     const unsigned long long peers = __ballot(valid && b == b0);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&count[b0], __popcll(peers));
-    base = __shfl(base, leader, 64);
-    if (valid && b == b0) myslot = base + __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && b == b0) {
+      my_leader = leader;
+      my_rank = __popcll(peers & ((1ull << lane) - 1ull));
+      my_count = __popcll(peers);
+    }
     remaining &= ~peers;
   }
+  // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
+  int base = 0;
+  if (valid && my_leader == lane) base = atomicAdd(&count[b], my_count);
+  base = __shfl(base, my_leader, 64);
+  const int myslot = base + my_rank;
   if (valid) {
     brick[i] = b;
     slot[i] = myslot;

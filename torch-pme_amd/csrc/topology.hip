@@ -139,7 +139,10 @@ __device__ __forceinline__ T wave_sum(T v) {
 // fixed per-wave latency: row_ptr fetch, reduction, store), and every lane keeps kRowUnroll entries in flight:
 // all entry loads are issued first, then the dependent gathers (dist[p], src[other]), then the arithmetic.
 static constexpr int kRowUnroll = MIPME_ROW_UNROLL;
-static constexpr int kRowLanes = 16;
+#ifndef MIPME_ROW_LANES
+#define MIPME_ROW_LANES 16
+#endif
+static constexpr int kRowLanes = MIPME_ROW_LANES;
 static constexpr int kRowsPerBlock = 256 / kRowLanes;
 
 template <typename T>

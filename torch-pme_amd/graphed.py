@@ -48,7 +48,7 @@ class GraphedEnergyForces:
     def _eval(self):
         d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
         V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
-        E = (V * self.q).sum()
+        E = ops.weighted_sum(V, self.q)
         E.backward()
         return E.detach()
 

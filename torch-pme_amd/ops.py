@@ -136,6 +136,8 @@ class PairTopology:
         self.row_ptr = torch.empty((2 * n_atoms + 1,), dtype=torch.int32, device=device)
         self.entries = torch.empty((max(2 * P, 1), 2), dtype=torch.int32, device=device)
         self._packed = None  # (weakref(shifts), version, tensor|None)
+        # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
+        self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
         with torch.cuda.device(device):
             nbytes = lib.mipme_topology_workspace_bytes(P)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
@@ -308,9 +310,10 @@ class _PMEFunction(torch.autograd.Function):
 
             def run_grad_dist(with_charges):
                 # grad_dist is a per-pair stream (no scatter); in "atomic" mode the same kernel also scatters grad_q
+                pl = pairs if topo is None else topo.pairs32
                 _call(
                     "rspace_backward", lib.mipme_rspace_backward,
-                    _lib.current_stream(device), dt, _lib.index_code(pairs.dtype), P, N, Cn, pairs.data_ptr(),
+                    _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
                     dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(),
                     _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
                 )
@@ -394,14 +397,16 @@ class _PairDistances(torch.autograd.Function):
         sh = None if shifts is None else shifts.to(dtype).contiguous()
         P = pairs.shape[0]
         out = torch.empty((P,), dtype=dtype, device=device)
+        topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+        pl = pairs if topo is None else topo.pairs32
         with torch.cuda.device(device):
             _call(
                 "pair_distance_forward", lib.mipme_pair_distance_forward,
-                    _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P,
-                    pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
+                _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pl.dtype), P,
+                pl.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
             )
         ctx.save_for_backward(pos, cl, pairs, sh)
-        ctx.topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+        ctx.topo = topo
         ctx.shifts_key = shifts
         return out
 
@@ -452,3 +457,37 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None)
         raise ValueError("Provided `neighbor_shifts` but no `cell`.")
     _lib.require_device(positions, "positions")
     return _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts)
+
+
+class _WeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        a_c, b_c = a.detach().contiguous(), b.detach().contiguous()
+        out = torch.empty((), dtype=a.dtype, device=a.device)
+        with torch.cuda.device(a.device):
+            _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
+                  a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(a_c, b_c)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(a.device):
+            _call("energy_sum_backward", lib.mipme_dot_backward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
+                  a.numel(), g.contiguous().data_ptr(), a.data_ptr(), b.data_ptr(), _lib.ptr(ga), _lib.ptr(gb))
+        return ga, gb
+
+
+def weighted_sum(potentials: torch.Tensor, charges: torch.Tensor) -> torch.Tensor:
+    """``(charges * potentials).sum()`` -- the energy reduction every caller of the reference performs
+    (``README.rst:112-114``) -- as one kernel forward and one backward instead of five ATen launches."""
+    if potentials.shape != charges.shape or potentials.dtype != charges.dtype:
+        raise ValueError("`potentials` and `charges` must have the same shape and dtype")
+    _lib.require_device(potentials, "potentials")
+    return _WeightedSum.apply(potentials, charges)
