@@ -55,6 +55,7 @@ class Frame:
         self.cell = torch.tensor(w.cell, dtype=dt, device=device)
         self.pairs = torch.tensor(w.pairs, dtype=torch.int64, device=device)
         self.shifts = torch.tensor(w.shifts, dtype=dt, device=device)
+        self.minus_one = torch.tensor(-1.0, dtype=dt, device=device)  # backward seed: pos.grad = -dE/dr = forces
         pot = (tpa.CoulombPotential(smearing=w.smearing) if w.exponent == 1
                else tpa.InversePowerLawPotential(exponent=w.exponent, smearing=w.smearing))
         Calc = tpa.P3MCalculator if w.scheme == "P3M" else tpa.PMECalculator
@@ -65,7 +66,7 @@ class Frame:
         d = tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
         V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
         E = tpa.weighted_sum(V, self.q)
-        E.backward()
+        E.backward(self.minus_one)
         return E.detach(), self.pos.grad
 
 

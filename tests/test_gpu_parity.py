@@ -322,3 +322,21 @@ def test_native_library_loaded():
     """The tests above must have run through libmipme.so (no silent fallback exists)."""
     with open("/proc/self/maps") as f:
         assert "libmipme.so" in f.read()
+
+
+def test_graphed_energy_forces(golden_dir):
+    """HIP-graph replay of distances -> forward -> backward reproduces the reference energy and forces, also after
+    the positions are updated in place."""
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])),
+                             mesh_spacing=float(z["p3m5/mesh_spacing"]), interpolation_nodes=5)
+    t = lambda a, dt=torch.float64: torch.tensor(a, device=DEV, dtype=dt)  # noqa: E731
+    pos, cell, q = t(z["positions"]), t(z["cell"]), t(z["charges"])
+    pairs, S = torch.tensor(z["pairs"], device=DEV), t(z["shifts"])
+    step = tpa.GraphedEnergyForces(calc, q, cell, pos + 0.01, pairs, S)
+    E, F = step(pos)
+    assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())
+    assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
+    E2, F2 = step(pos + 0.01)
+    E3, F3 = step(pos)
+    assert abs(E2.item() - E.item()) > 1e-6 and abs(E3.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())

@@ -258,7 +258,18 @@ template <typename T>
 __global__ __launch_bounds__(1024) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
                                                   T* __restrict__ out) {
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += double(a[i]) * double(b[i]);
+  constexpr int U = 8;  // independent loads in flight per thread (a single block must hide its own latency)
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += int64_t(blockDim.x) * U) {
+    T av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + int64_t(u) * blockDim.x;
+      av[u] = i < n ? a[i] : T(0);
+      bv[u] = i < n ? b[i] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += double(av[u]) * double(bv[u]);
+  }
   __shared__ double red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll

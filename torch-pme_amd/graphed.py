@@ -31,6 +31,8 @@ class GraphedEnergyForces:
         self.shifts = neighbor_shifts.to(positions.dtype).contiguous()
         self.pos = positions.detach().clone().requires_grad_(True)
         device = positions.device
+        # seeding the backward pass with -1 makes ``pos.grad`` the forces directly (no fill and no negation kernel)
+        self._minus_one = torch.tensor(-1.0, dtype=positions.dtype, device=device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):  # warm-up off the default stream: plans, topology, filter caches get built
@@ -43,13 +45,13 @@ class GraphedEnergyForces:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
-            self.forces = self.pos.grad.neg()
+            self.forces = self.pos.grad
 
     def _eval(self):
         d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
         V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
         E = ops.weighted_sum(V, self.q)
-        E.backward()
+        E.backward(self._minus_one)
         return E.detach()
 
     def __call__(self, positions: torch.Tensor | None = None):
