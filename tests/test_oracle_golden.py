@@ -160,3 +160,26 @@ def test_mesh_sum_rules():
             mesh = rng.normal(size=rho.shape)
             gat = O.gather(mesh, idx, w[:, :, 0], w[:, :, 1], w[:, :, 2])
             assert abs((gat * q).sum() - (mesh * rho).sum()) < 1e-11  # <gather(m), q> = <m, spread(q)>
+
+
+@pytest.mark.parametrize("name,scheme", [("p3m5", "P3M"), ("pme4", "Lagrange")])
+def test_torch_cpu_oracle(golden_dir, name, scheme):
+    """oracle/pme_torch.py (the multi-threaded CPU baseline of bench.py) against the reference goldens and the
+    NumPy oracle: potentials, energy, forces and the cell gradient through autograd."""
+    import torch
+
+    from oracle import pme_torch as OT
+
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    spec = O.PotentialSpec("coulomb", 1, float(z["smearing"]), 1.0)
+    t = lambda a: torch.tensor(a, dtype=torch.float64)  # noqa: E731
+    pos, cell, q = t(z["positions"]).requires_grad_(True), t(z["cell"]).requires_grad_(True), t(z["charges"])
+    pairs, S = torch.tensor(z["pairs"]), torch.tensor(z["shifts"])
+    d = OT.pair_distances(pos, cell, pairs, S)
+    V = OT.forward(spec, scheme, int(z[f"{name}/order"]), float(z[f"{name}/mesh_spacing"]), q, cell, pos, pairs, d)
+    E = (V * q).sum()
+    E.backward()
+    assert relmax(V.detach().numpy(), z[f"{name}/f64/V"]) < 1e-12
+    assert abs(E.item() / float(z[f"{name}/f64/energy"]) - 1) < 1e-12
+    assert relmax(pos.grad.numpy(), z[f"{name}/f64/grad_positions"]) < 1e-10
+    assert relmax(cell.grad.numpy(), z[f"{name}/f64/grad_cell"]) < 1e-10
