@@ -249,6 +249,12 @@ def main():
         # table below lists every kernel with its launches per step
         dom = max(pair_kernels, key=pair_kernels.get)
         achieved = per_kernel[dom] / (pair_kernels[dom] * 1e-3) / 1e9
+        # HBM bytes per launch from the rocprofv3 PMC passes of the same command (tools/profile_gpu.sh ->
+        # tools/pmc_to_json.py, committed under profiles/); bench.py cannot run the profiler on itself
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if args.workload == "water" and os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         table = {
             k: {"ms_per_launch": round(v, 5), "launches_per_step": stage_calls.get(k, 1.0),
                 "algorithmic_MB": round(per_kernel[k] / 1e6, 3), "GBps": round(per_kernel[k] / (v * 1e-3) / 1e9, 1)}
@@ -282,7 +288,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_kernel[dom],
                 "kernel_ms": pair_kernels[dom],
             },

@@ -122,13 +122,16 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
  * grad_positions (N,3), grad_charges (N,C), grad_cell (9) are OVERWRITTEN; each may be NULL.
  * Work: psi_mesh, chi_mesh (C,nx,ny,nz); psi_hat, hat_work complex half grids; dc (C);
  * partials: float64 scratch of >= mipme_cellgrad_partials_size() elements (only used when grad_cell != NULL,
- * which also requires rho_hat, rho_dc, phi_atoms and grad_positions). */
+ * which also requires rho_hat, rho_dc, phi_atoms and grad_positions).
+ * grad_scale (device scalar, nullable): "energy mode" -- promises grad_out == grad_scale[0] * charges (the gradient of
+ * E = sum q V).  Then chi = (grad_scale/2V) phi, so the second spread, both FFTs and the filter are skipped and only the
+ * gradient gather runs (needs phi_mesh and rho_dc; the work meshes may be NULL; grad_cell must be NULL). */
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                           const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* atom_bins);
+                          void* grad_cell, void* atom_bins, const void* grad_scale);
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
 
 /* atom_bins (nullable): device scratch of mipme_atom_bins_bytes() bytes.  When given, the atoms are counting-sorted
@@ -170,7 +173,8 @@ int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pair
 
 /* ---- caller side: the energy reduction E = sum_ic q_ic V_ic (README.rst:112-114, tests/calculators/test_values_ewald.py:306)
  * as one kernel, and its adjoint grad_a = g*b, grad_b = g*a (g: device scalar; grad_a / grad_b nullable). ---- */
-int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* out);
+int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* scratch /* 64 float64 */,
+                      void* out);
 int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
                        void* grad_b);
 

@@ -342,3 +342,31 @@ def test_graphed_energy_forces(golden_dir):
     e2 = step(pos + 0.01)[0].item()
     e3 = step(pos)[0].item()
     assert abs(e2 - e1) > 1e-6 and abs(e3 - eref) < 1e-10 * abs(eref)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("mesh_mode", ["bricks", "atomic"])
+@pytest.mark.parametrize("name", ["p3m5", "pme4"])
+def test_energy_fast_path(golden_dir, fast, mesh_mode, name, monkeypatch):
+    """E = weighted_sum(V, q): the backward recognises grad = gE * charges and reuses the forward mesh (no second
+    spread / FFT); forces and charge gradients must equal the general path and the reference, also for gE != 1."""
+    from torchpme_amd import ops
+
+    monkeypatch.setattr(ops, "ENERGY_FAST_PATH", fast)
+    monkeypatch.setattr(ops, "MESH_MODE", mesh_mode)
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    Calc = tpa.P3MCalculator if name == "p3m5" else tpa.PMECalculator
+    calc = Calc(tpa.CoulombPotential(smearing=float(z["smearing"])), mesh_spacing=float(z[f"{name}/mesh_spacing"]),
+                interpolation_nodes=int(z[f"{name}/order"]))
+    pos = torch.tensor(z["positions"], device=DEV, requires_grad=True)
+    cell = torch.tensor(z["cell"], device=DEV)
+    q = torch.tensor(z["charges"], device=DEV, requires_grad=True)
+    pairs = torch.tensor(z["pairs"], device=DEV)
+    S = torch.tensor(z["shifts"], device=DEV, dtype=torch.float64)
+    d = tpa.pair_distances(pos, pairs, cell, S)
+    V = calc(q, cell, pos, pairs, d)
+    E = tpa.weighted_sum(V, q)
+    (-1.7 * E).backward()
+    assert abs(E.item() - float(z[f"{name}/f64/energy"])) < 1e-11 * abs(E.item())
+    assert rell2(pos.grad.cpu(), -1.7 * z[f"{name}/f64/grad_positions"]) < 1e-10
+    assert rell2(q.grad.cpu(), -1.7 * z[f"{name}/f64/grad_charges"]) < 1e-10

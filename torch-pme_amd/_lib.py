@@ -80,7 +80,7 @@ def _declare(lib):
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci],
-        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 18,
+        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19,
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
         "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
@@ -91,7 +91,7 @@ def _declare(lib):
         "mipme_topology_pack_shifts": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_rspace_rows": [vp, ci, i64, ci, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp],
         "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-        "mipme_dot_forward": [vp, ci, i64, vp, vp, vp],
+        "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():

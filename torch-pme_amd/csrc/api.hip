@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 template <typename T> int spread_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, double, void*);
 template <typename T> int gather_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
 template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*, int);
-template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
 template <typename T> int apply_filter_cellgrad_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*, const void*, const void*, void*, void*, void*);
@@ -47,7 +47,7 @@ int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int);
-template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
+template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
 struct ProfEntry {
@@ -134,10 +134,20 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
                              int64_t N, const void* pos, const void* q, const void* gout, const void* G,
                              const void* phi_mesh, const void* rho_hat, const void* rho_dc, const void* phi_atoms,
                              void* psi_mesh, void* psi_hat, void* hat_work, void* chi_mesh, void* dc, void* partials,
-                             void* grad_pos, void* grad_q, void* grad_cell, void* bins) {
+                             void* grad_pos, void* grad_q, void* grad_cell, void* bins, const void* grad_scale) {
   int rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
+  if (grad_scale) {
+    // energy mode: grad_out = grad_scale * charges  =>  psi = (grad_scale/2V) rho, chi = (grad_scale/2V) phi:
+    // no second spread / FFT / filter / inverse FFT (special case L = sum q V)
+    MIPME_REQUIRE(!grad_cell && rho_dc, "energy-mode backward needs rho_dc and does not produce the cell gradient");
+    if (bins)
+      STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+    else
+      STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+    return MIPME_OK;
+  }
   // psi = spread(g / 2V); chi = F psi
   if (bins)
     STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh));
@@ -154,9 +164,9 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   }
   STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, chi_mesh));
   if (bins)
-    STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q));
+    STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
   else
-    STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, self_c, bg_c, grad_pos, grad_q));
+    STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
   if (grad_cell)
     STAGE(st, "cellgrad_finalize",
           cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, grad_cell));
@@ -254,33 +264,30 @@ __global__ void slab_cell_kernel(int axis, int C, mipme_mesh_t m, double c0, dou
 }
 
 // ---- E = sum_i a_i b_i (the caller's energy reduction, README.rst:112-114) and its adjoint ---------------------
+// two stages, both deterministic: kDotBlocks block partials (double), then one wave sums them
+static constexpr int kDotBlocks = 64;
+
 template <typename T>
-__global__ __launch_bounds__(1024) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
-                                                  T* __restrict__ out) {
+__global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                         double* __restrict__ partials) {
   double acc = 0.0;
-  constexpr int U = 8;  // independent loads in flight per thread (a single block must hide its own latency)
-  for (int64_t i0 = threadIdx.x; i0 < n; i0 += int64_t(blockDim.x) * U) {
-    T av[U], bv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + int64_t(u) * blockDim.x;
-      av[u] = i < n ? a[i] : T(0);
-      bv[u] = i < n ? b[i] : T(0);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc += double(av[u]) * double(bv[u]);
-  }
-  __shared__ double red[16];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    acc += double(a[i]) * double(b[i]);
+  __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) red[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double v = 0.0;
-    for (int w = 0; w < int(blockDim.x >> 6); ++w) v += red[w];
-    out[0] = T(v);
-  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void dot_final_kernel(int nblocks, const double* __restrict__ partials, T* __restrict__ out) {
+  double acc = int(threadIdx.x) < nblocks ? partials[threadIdx.x] : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (threadIdx.x == 0) out[0] = T(acc);
 }
 
 // out_a[i] = g * b[i], out_b[i] = g * a[i]  (g: device scalar)
@@ -426,12 +433,12 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* bins) {
+                          void* grad_cell, void* bins, const void* grad_scale) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
-  MIPME_REQUIRE(G && phi_mesh && psi_mesh && psi_hat && hat_work && chi_mesh && dc,
+  MIPME_REQUIRE(G && phi_mesh && (grad_scale || (psi_mesh && psi_hat && hat_work && chi_mesh && dc)),
                 "NULL work buffer passed to mipme_kspace_backward");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && grad_out), "NULL atom buffer passed to mipme_kspace_backward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
@@ -439,10 +446,10 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
   DT_SWITCH(dtype,
             kspace_backward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                      rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                     grad_positions, grad_charges, grad_cell, bins),
+                                     grad_positions, grad_charges, grad_cell, bins, grad_scale),
             kspace_backward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                       rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                      grad_positions, grad_charges, grad_cell, bins));
+                                      grad_positions, grad_charges, grad_cell, bins, grad_scale));
 }
 
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
@@ -566,14 +573,17 @@ int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t
              partials, grad_positions, grad_cell);
 }
 
-int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* out) {
-  MIPME_REQUIRE(n >= 0 && out && (n == 0 || (a && b)), "invalid arguments to mipme_dot_forward");
+int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* scratch, void* out) {
+  MIPME_REQUIRE(n >= 0 && out && scratch && (n == 0 || (a && b)), "invalid arguments to mipme_dot_forward");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIPME_F32)
-    dot_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)a, (const float*)b, (float*)out);
-  else if (dtype == MIPME_F64)
-    dot_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)a, (const double*)b, (double*)out);
-  else {
+  double* partials = (double*)scratch;
+  if (dtype == MIPME_F32) {
+    dot_partial_kernel<float><<<kDotBlocks, 256, 0, st>>>(n, (const float*)a, (const float*)b, partials);
+    dot_final_kernel<float><<<1, 64, 0, st>>>(kDotBlocks, partials, (float*)out);
+  } else if (dtype == MIPME_F64) {
+    dot_partial_kernel<double><<<kDotBlocks, 256, 0, st>>>(n, (const double*)a, (const double*)b, partials);
+    dot_final_kernel<double><<<1, 64, 0, st>>>(kDotBlocks, partials, (double*)out);
+  } else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;
   }

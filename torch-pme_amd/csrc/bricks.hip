@@ -486,11 +486,15 @@ template <int N, typename T>
 __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
     Geom g, BrickGeom bg, int C, const int* __restrict__ start, const int4* __restrict__ rec, const T* __restrict__ wts,
     const T* __restrict__ q, const T* __restrict__ gout, const T* __restrict__ phi, const T* __restrict__ chi,
-    const T* __restrict__ psi_dc, T half_inv_vol, T self_c, T bg_c, T* __restrict__ grad_pos, T* __restrict__ grad_q) {
+    const T* __restrict__ psi_dc, const T* __restrict__ gscale, T half_inv_vol, T self_c, T bg_c,
+    T* __restrict__ grad_pos, T* __restrict__ grad_q) {
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   constexpr int TV = TL * TL * TL;
+  // energy mode (gscale != NULL): the upstream gradient is gscale * charges, hence chi = (gscale / 2V) * phi and
+  // dc(psi) = (gscale / 2V) * dc(rho): `chi` / `psi_dc` then alias phi / dc(rho) and are scaled on the fly
+  const T cs = gscale ? gscale[0] * half_inv_vol : T(1);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);  // [C][2][TV]: phi, chi
   int bx, by, bz;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
 #pragma unroll
         for (int tx = 0; tx < N; ++tx) {
           const T vphi = tp[(rx + tx) * TL * TL];
-          const T vchi = tp[TV + (rx + tx) * TL * TL];
+          const T vchi = tp[TV + (rx + tx) * TL * TL] * cs;
           const T v = hc * vphi + qc * vchi;
           const T wxv = wr[tx];
           sx += v * wxv;
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
       }
       if (grad_q) {
         schi = group_sum_b<LANES, T>(lane_active ? schi * wyv * wzv : T(0));
-        if (l == 0 && valid) grad_q[o] = schi - T(0.5) * self_c * gout[o] - T(2) * bg_c * psi_dc[c];
+        if (l == 0 && valid) grad_q[o] = schi - T(0.5) * self_c * gout[o] - T(2) * bg_c * psi_dc[c] * cs;
       }
     }
     if (grad_pos) {
@@ -656,8 +660,8 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
 
 template <typename T>
 int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* q, const void* gout,
-                       const void* phi, const void* chi, const void* psi_dc, double self_c, double bg_c, void* grad_pos,
-                       void* grad_q) {
+                       const void* phi, const void* chi, const void* psi_dc, const void* gscale, double self_c,
+                       double bg_c, void* grad_pos, void* grad_q) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
@@ -669,7 +673,8 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
       m->scheme, m->order,
       ((void)S, gather_grad_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
           g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)q, (const T*)gout, (const T*)phi,
-          (const T*)chi, (const T*)psi_dc, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos, (T*)grad_q)));
+          (const T*)chi, (const T*)psi_dc, (const T*)gscale, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos,
+          (T*)grad_q)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -683,8 +688,8 @@ template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, voi
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                    double, double, void*, void*, int);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
-                                       const void*, const void*, const void*, double, double, void*, void*);
+                                       const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
-                                        const void*, const void*, const void*, double, double, void*, void*);
+                                        const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 }  // namespace mipme

@@ -137,11 +137,12 @@ template <int SCHEME, int N, typename T>
 __global__ __launch_bounds__(256) void gather_grad_kernel(Geom g, int64_t n_atoms, int C, const T* __restrict__ pos,
                                                          const T* __restrict__ q, const T* __restrict__ gout,
                                                          const T* __restrict__ phi, const T* __restrict__ chi,
-                                                         const T* __restrict__ psi_dc, T half_inv_vol,
-                                                         T self_c, T bg_c, T* __restrict__ grad_pos,
+                                                         const T* __restrict__ psi_dc, const T* __restrict__ gscale,
+                                                         T half_inv_vol, T self_c, T bg_c, T* __restrict__ grad_pos,
                                                          T* __restrict__ grad_q) {
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int APB = 256 / LANES;
+  const T cs = gscale ? gscale[0] * half_inv_vol : T(1);  // energy mode: chi = cs * phi (see bricks.hip)
   const int l = threadIdx.x % LANES;
   int64_t atom = int64_t(blockIdx.x) * APB + threadIdx.x / LANES;
   const bool valid = atom < n_atoms;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gather_grad_kernel(Geom g, int64_t n_atom
     int ix = s.bx;
 #pragma unroll
     for (int tx = 0; tx < N; ++tx) {
-      const T vchi = cc[ix * plane];
+      const T vchi = cc[ix * plane] * cs;
       const T v = hc * pc[ix * plane] + qc * vchi;
       sx += v * s.wx[tx];
       sdx += v * s.dwx[tx];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void gather_grad_kernel(Geom g, int64_t n_atom
       schi = group_sum<LANES, T>(schi * s.wy * s.wz * act);
       if (l == 0 && valid) {
         // (bg/V) sum_j g_jc = 2 bg * dc(psi_c), psi = spread(g/2V)
-        grad_q[atom * C + c] = schi - T(0.5) * self_c * gout[atom * C + c] - T(2) * bg_c * psi_dc[c];
+        grad_q[atom * C + c] = schi - T(0.5) * self_c * gout[atom * C + c] - T(2) * bg_c * psi_dc[c] * cs;
       }
     }
   }
@@ -265,15 +266,15 @@ int gather_epilogue_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms,
 
 template <typename T>
 int gather_grad_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, const void* q,
-                     const void* gout, const void* phi, const void* chi, const void* gsum_dc, double self_c,
-                     double bg_c, void* grad_pos, void* grad_q) {
+                     const void* gout, const void* phi, const void* chi, const void* gsum_dc, const void* gscale,
+                     double self_c, double bg_c, void* grad_pos, void* grad_q) {
   if (n_atoms == 0) return MIPME_OK;
   const Geom g = make_geom(m);
   MIPME_DISPATCH_STENCIL(
       m->scheme, m->order,
       (gather_grad_kernel<S, N, T><<<blocks_for<N>(n_atoms), 256, 0, st>>>(
           g, n_atoms, m->n_channels, (const T*)pos, (const T*)q, (const T*)gout, (const T*)phi, (const T*)chi,
-          (const T*)gsum_dc, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos, (T*)grad_q)));
+          (const T*)gsum_dc, (const T*)gscale, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos, (T*)grad_q)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -288,8 +289,8 @@ template int gather_epilogue_impl<float>(hipStream_t, const mipme_mesh_t*, int64
 template int gather_epilogue_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*,
                                           const void*, const void*, double, double, void*, void*, int);
 template int gather_grad_impl<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*,
-                                     const void*, const void*, const void*, double, double, void*, void*);
+                                     const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*,
-                                      const void*, const void*, const void*, double, double, void*, void*);
+                                      const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 }  // namespace mipme

@@ -107,6 +107,11 @@ PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
 # for bricks always take the atomic kernels.
 MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 
+# When the gradient arriving at the calculator's backward was produced by ``weighted_sum(V, charges)`` (E = sum q V, the
+# reduction every energy/force evaluation performs) it equals gE * charges and the adjoint mesh is a multiple of the
+# forward mesh: the backward then skips the second spread + FFT pair.  Any other upstream gradient takes the general path.
+ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
+
 
 # The bandwidth-bound pair kernels and the latency-bound mesh kernels of one evaluation are independent until
 # the final sum, so they run concurrently: pair work on a per-device side stream, mesh work on the caller's stream,
@@ -326,7 +331,27 @@ class _PMEFunction(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     run_grad_dist(False)
                     join.record()
-            if do_kspace:
+            # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
+            # exactly gE * charges, and the adjoint mesh is a multiple of the forward one (no second spread / FFT).
+            tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
+            gscale = None
+            if (tag is not None and do_kspace and not need_cell and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape)
+                    and tag[2] == q._version and ctx.slab_axis is None):
+                gscale = tag[3]
+            if do_kspace and gscale is not None:
+                md = geom.desc(Cn)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                if need_pos:
+                    grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                if need_q:
+                    grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
+                _call(
+                    "kspace_backward", lib.mipme_kspace_backward,
+                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                    g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), None, _lib.ptr(rho_dc), None, None, None, None,
+                    None, None, None, _lib.ptr(grad_pos), _lib.ptr(grad_q), None, _lib.ptr(bins), gscale.data_ptr(),
+                )
+            elif do_kspace:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn)
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
@@ -349,7 +374,7 @@ class _PMEFunction(torch.autograd.Function):
                     g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
                     _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
                     chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
-                    _lib.ptr(grad_cell), _lib.ptr(bins),
+                    _lib.ptr(grad_cell), _lib.ptr(bins), None,
                 )
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
@@ -465,9 +490,10 @@ class _WeightedSum(torch.autograd.Function):
         lib = _lib.load()
         a_c, b_c = a.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((), dtype=a.dtype, device=a.device)
+        scratch = torch.empty((64,), dtype=torch.float64, device=a.device)
         with torch.cuda.device(a.device):
             _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
-                  a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), out.data_ptr())
+                  a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
         ctx.save_for_backward(a_c, b_c)
         return out
 
@@ -478,9 +504,13 @@ class _WeightedSum(torch.autograd.Function):
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        g = g.contiguous()
         with torch.cuda.device(a.device):
             _call("energy_sum_backward", lib.mipme_dot_backward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
-                  a.numel(), g.contiguous().data_ptr(), a.data_ptr(), b.data_ptr(), _lib.ptr(ga), _lib.ptr(gb))
+                  a.numel(), g.data_ptr(), a.data_ptr(), b.data_ptr(), _lib.ptr(ga), _lib.ptr(gb))
+        if ga is not None:
+            # ga == g * b exactly: let a calculator backward that receives THIS tensor recognise it (see ENERGY_FAST_PATH)
+            ga._mipme_scaled = (b.data_ptr(), tuple(b.shape), b._version, g)
         return ga, gb
 
 
