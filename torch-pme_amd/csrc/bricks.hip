@@ -170,17 +170,55 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __res
 
 // Scatter the atoms into brick order and evaluate their 1-D weights (and derivatives) ONCE: the four
 // particle<->mesh kernels of a step (spread, gather, spread of the gradient, gradient gather) only load them.
-template <int SCHEME, int N, typename T>
-__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int64_t Natoms, const T* __restrict__ pos,
-                                                      const int* __restrict__ start, const int* __restrict__ slot,
-                                                      const int* __restrict__ brick, int4* __restrict__ rec,
-                                                      T* __restrict__ wts) {
+// FUSED_SCAN: every block first rebuilds the exclusive scan of the (<= 1024) brick counts in LDS -- cheaper than a
+// separate single-block scan kernel plus its launch boundary; block 0 also publishes it as `start`.
+static constexpr int kFusedScanMax = 1024;
+
+template <int SCHEME, int N, bool FUSED_SCAN, typename T>
+__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t Natoms, const T* __restrict__ pos,
+                                                      const int* __restrict__ count, int* __restrict__ start,
+                                                      const int* __restrict__ slot, const int* __restrict__ brick,
+                                                      int4* __restrict__ rec, T* __restrict__ wts) {
+  __shared__ int sstart[FUSED_SCAN ? kFusedScanMax + 1 : 1];
+  __shared__ int wsum[4];
+  if constexpr (FUSED_SCAN) {
+    // 4 consecutive counts per thread, wave scan, then wave offsets
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int c[4], run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = 4 * t + k;
+      c[k] = idx < nb ? count[idx] : 0;
+      run += c[k];
+    }
+    int incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = 4 * t + k;
+      if (idx <= nb) sstart[idx] = base;
+      base += c[k];
+    }
+    if (t == 255 && nb == kFusedScanMax) sstart[nb] = base;
+    __syncthreads();
+    if (blockIdx.x == 0)
+      for (int idx = t; idx <= nb; idx += 256) start[idx] = sstart[idx];
+  }
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= Natoms) return;
   int m[3];
   double x[3];
   atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
-  const int64_t dst = int64_t(start[brick[i]]) + slot[i];
+  const int b = brick[i];
+  const int64_t dst = int64_t(FUSED_SCAN ? sstart[b] : start[b]) + slot[i];
   rec[dst] = make_int4(m[0], m[1], m[2], int(i));
   T* wr = wts + dst * (6 * N);
 #pragma unroll
@@ -613,12 +651,23 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
     bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, n_atoms, (const T*)pos, v.count, v.slot, v.brick);
     MIPME_LAUNCH_CHECK();
   }
-  bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
-  MIPME_LAUNCH_CHECK();
+  const bool fused = bg.nb <= kFusedScanMax;
+  if (!fused) {
+    bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
+    MIPME_LAUNCH_CHECK();
+  }
   if (n_atoms > 0) {
-    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             (bin_fill_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, n_atoms, (const T*)pos, v.start, v.slot,
-                                                                              v.brick, v.rec, (T*)v.wts)));
+    if (fused)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               (bin_fill_kernel<S, N, true, T><<<blocks, 256, 0, st>>>(
+                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts)));
+    else
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               (bin_fill_kernel<S, N, false, T><<<blocks, 256, 0, st>>>(
+                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts)));
+    MIPME_LAUNCH_CHECK();
+  } else if (fused) {
+    bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;

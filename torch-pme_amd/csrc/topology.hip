@@ -168,14 +168,20 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
     T acc[CMAX];
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) acc[k] = T(0);
+    // software pipeline: the entries of macro-iteration k+1 are requested before the gathers of iteration k are used
+    int2 en_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = beg + u * kRowLanes + sub;
+      en_next[u] = entries[e < end ? e : beg];
+    }
     for (int base = beg; base < end; base += kRowLanes * U) {
       int2 en[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = base + u * kRowLanes + sub;
-        ok[u] = e < end;
-        en[u] = entries[ok[u] ? e : beg];
+        ok[u] = base + u * kRowLanes + sub < end;
+        en[u] = en_next[u];
       }
       T d[U], sv[U][CMAX];
 #pragma unroll
@@ -184,6 +190,11 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
         d[u] = dist[en[u].y];
 #pragma unroll
         for (int k = 0; k < CMAX; ++k) sv[u][k] = (c0 + k < C) ? src[int64_t(en[u].x) * C + c0 + k] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = base + kRowLanes * U + u * kRowLanes + sub;
+        en_next[u] = entries[e < end ? e : beg];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -234,17 +245,24 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
   }
   const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
   const int beg = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = valid ? row_ptr[2 * a + 2] : beg;
+  int2 en_next[U];
+  int pk_next[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = beg + u * kRowLanes + sub;
+    const int ec = e < end ? e : beg;
+    en_next[u] = entries[ec];
+    pk_next[u] = packed ? packed[ec] : 0;
+  }
   for (int base = beg; base < end; base += kRowLanes * U) {
     int2 en[U];
     int pk[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = base + u * kRowLanes + sub;
-      ok[u] = e < end;
-      const int ec = ok[u] ? e : beg;
-      en[u] = entries[ec];
-      pk[u] = packed ? packed[ec] : 0;
+      ok[u] = base + u * kRowLanes + sub < end;
+      en[u] = en_next[u];
+      pk[u] = pk_next[u];
     }
     T gd[U], ox[U], oy[U], oz[U], shx[U], shy[U], shz[U];
 #pragma unroll
@@ -264,6 +282,13 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
       } else {
         shx[u] = shy[u] = shz[u] = T(0);
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + kRowLanes * U + u * kRowLanes + sub;
+      const int ec = e < end ? e : beg;
+      en_next[u] = entries[ec];
+      pk_next[u] = packed ? packed[ec] : 0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
