@@ -241,6 +241,23 @@ def main():
     _lib.profile_enable(False)
     ops.PROFILE = None
 
+    # ---- accuracy of the timed dtype against the same path in fp64 (itself pinned to the reference at 1e-13) ----
+    accuracy = None
+    if rank == 0 and w.dtype == "f32":
+        import copy
+
+        w64 = copy.copy(w)
+        w64.dtype = "f64"
+        f64 = Frame(w64, device)
+        E64, F64 = f64.step()
+        E32, F32 = frame.step()
+        accuracy = {
+            "reference": "same HIP path in fp64 (parity with torch-pme fp64 <= 1e-12, tests/test_gpu_parity.py)",
+            "rel_energy_error": abs(float(E32) - float(E64)) / abs(float(E64)),
+            "force_rel_l2_error": float((F32.double() - F64).norm() / F64.norm()),
+        }
+        del f64
+
     if rank == 0:
         step_bytes, per_kernel = algorithmic_bytes(w, s)
         pair_kernels = {k: v for k, v in prof.items() if k in per_kernel}
@@ -297,6 +314,7 @@ def main():
             "kernels": table,
             "abi_call_ms": prof,
             "energy": float(E.item()),
+            "accuracy": accuracy,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)

@@ -11,7 +11,6 @@
 // Replaces, like mesh.hip, MeshInterpolator.compute_weights / points_to_mesh / mesh_to_points
 // (reference lib/mesh_interpolator.py:303-457).
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.h"
 
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      const int4* __restrict__ rec,
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ val, T scale,
-                                                                     T* __restrict__ mesh, int dbg) {
+                                                                     T* __restrict__ mesh) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int SW = 3 * N + C;                                 // staged reals per survivor
   const int region = max(SPREAD_WAVES * BRICK_PTS, SPREAD_STAGE * SW);
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
     rbase[27] = run;
   }
   __syncthreads();
-  const int total = (dbg & 1) ? 0 : rbase[27];
+  const int total = rbase[27];
   constexpr int s0 = stencil_start<N>();
   const int px = lane >> 3, py = lane & 7;  // this lane's (x,y) column of the brick
   const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
         }
       }
       __syncthreads();
-      const int ns = (dbg & 2) ? 0 : nsurv;
+      const int ns = nsurv;
       for (int chunk = 0; chunk < ns; chunk += SPREAD_STAGE) {
         const int nst = min(SPREAD_STAGE, ns - chunk);
         // A2: stage weights and the value of this channel
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
         // C: register accumulation; wave w takes survivors w, w+W, ...; four survivors per iteration so that
         // their LDS reads overlap (the loop is a chain of dependent LDS reads otherwise)
         constexpr int UC = 4;
-        const int nstc = (dbg & 4) ? 0 : nst;
+        const int nstc = nst;
         for (int sv0 = wave; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
           int pk[UC];
           bool live[UC];
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
         __syncthreads();
       }
     }
-    // R: sum the four waves' partial bricks and write the owned points (the stage is free again: last sync above)
+    // R: sum the waves' partial bricks and write the owned points (the stage is free again: last sync above)
 #pragma unroll
     for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
     __syncthreads();
@@ -679,12 +678,11 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  static const int dbg = getenv("MIPME_SPREAD_DBG") ? atoi(getenv("MIPME_SPREAD_DBG")) : 0;
   const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(SPREAD_STAGE) * (3 * m->order + m->n_channels));
   const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh, dbg)));
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }

@@ -14,8 +14,6 @@
 // deterministic summation order (stable radix sort).
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include <cstdlib>
-
 #include "common.h"
 #include "srpot.h"
 
