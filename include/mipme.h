@@ -165,11 +165,13 @@ int mipme_rspace_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs
                          int full_list, const mipme_potential_t* pot, int accumulate, void* out_pot);
 
 /* grad_dist[p] = 1/2 v_SR'(d_p) sum_c (g[i,c] q[j,c] + g[j,c] q[i,c])   (overwritten, nullable)
- * grad_charges (N,C): ACCUMULATED atomically (nullable). */
+ * grad_charges (N,C): ACCUMULATED atomically (nullable).
+ * grad_scale (device scalar, nullable): energy mode, grad_out == grad_scale[0] * charges (see mipme_kspace_backward);
+ * the kernel then needs no gathers of grad_out. */
 int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
                           const void* pairs, const void* dist, const void* charges, const void* pair_mask,
-                          int full_list, const mipme_potential_t* pot, const void* grad_out, void* grad_dist,
-                          void* grad_charges);
+                          int full_list, const mipme_potential_t* pot, const void* grad_out, const void* grad_scale,
+                          void* grad_dist, void* grad_charges);
 
 /* ---- caller side: the energy reduction E = sum_ic q_ic V_ic (README.rst:112-114, tests/calculators/test_values_ewald.py:306)
  * as one kernel, and its adjoint grad_a = g*b, grad_b = g*a (g: device scalar; grad_a / grad_b nullable). ---- */

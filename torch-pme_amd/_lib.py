@@ -84,7 +84,7 @@ def _declare(lib):
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
         "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
-        "mipme_rspace_backward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, vp, vp, vp],
+        "mipme_rspace_backward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, vp, vp, vp, vp],
         "mipme_pair_distance_forward": [vp, ci, ci, i64, vp, vp, vp, vp, vp],
         "mipme_pair_distance_backward": [vp, ci, ci, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_topology_build": [vp, ci, i64, i64, vp, vp, i64, vp, vp],

@@ -34,7 +34,7 @@ int fft_plan_destroy(mipme_fft_plan*);
 int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
-template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, void*, void*);
+template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
 template <typename T, typename I> int distance_backward_impl(hipStream_t, int64_t, int64_t, const void*, const void*, const void*, const void*, const void*, void*, void*, void*);
 int64_t pair_partials_blocks(int64_t);
@@ -542,13 +542,13 @@ int mipme_rspace_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs
 
 int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels,
                           const void* pairs, const void* dist, const void* charges, const void* pair_mask,
-                          int full_list, const mipme_potential_t* pot, const void* grad_out, void* grad_dist,
-                          void* grad_charges) {
+                          int full_list, const mipme_potential_t* pot, const void* grad_out, const void* grad_scale,
+                          void* grad_dist, void* grad_charges) {
   MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && n_channels > 0, "invalid sizes passed to mipme_rspace_backward");
   MIPME_REQUIRE(n_pairs == 0 || (pairs && dist && charges && grad_out), "NULL pair buffer passed to mipme_rspace_backward");
   hipStream_t st = (hipStream_t)stream;
   IDX_SWITCH(dtype, idx_dtype, rspace_backward_impl, st, n_pairs, n_atoms, n_channels, pairs, dist, charges, pair_mask,
-             full_list, pot, grad_out, grad_dist, grad_charges);
+             full_list, pot, grad_out, grad_scale, grad_dist, grad_charges);
 }
 
 int mipme_pair_distance_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, const void* pairs,

@@ -46,12 +46,15 @@ __global__ __launch_bounds__(256) void rspace_forward_kernel(SRPot s, int64_t P,
 }
 
 // ---- backward ----------------------------------------------------------------------------------
+// gscale != NULL ("energy mode"): the upstream gradient is g = gscale * charges, so
+// g_i q_j + g_j q_i = 2 gscale q_i q_j and the two gathers of g are not needed.
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void rspace_backward_kernel(SRPot s, int64_t P, int C, const I* __restrict__ pairs,
                                                              const T* __restrict__ dist, const T* __restrict__ q,
                                                              const uint8_t* __restrict__ mask, bool full,
-                                                             const T* __restrict__ g, T* __restrict__ grad_d,
-                                                             T* __restrict__ grad_q) {
+                                                             const T* __restrict__ g, const T* __restrict__ gscale,
+                                                             T* __restrict__ grad_d, T* __restrict__ grad_q) {
+  const T gs = gscale ? gscale[0] : T(0);
   for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
     if (mask && !mask[p]) {
       if (grad_d) grad_d[p] = T(0);
@@ -62,13 +65,18 @@ __global__ __launch_bounds__(256) void rspace_backward_kernel(SRPot s, int64_t P
     T v, dv;
     sr_eval<T, true>(s, dist[p], v, dv);
     T acc = T(0);
-    for (int c = 0; c < C; ++c) {
-      const T gi = g[i * C + c], gj = g[j * C + c];
-      acc += gi * q[j * C + c];
-      if (!full) acc += gj * q[i * C + c];
-      if (grad_q) {
-        atomic_add(grad_q + j * C + c, T(0.5) * v * gi);
-        if (!full) atomic_add(grad_q + i * C + c, T(0.5) * v * gj);
+    if (gscale && !grad_q) {
+      for (int c = 0; c < C; ++c) acc += q[i * C + c] * q[j * C + c];
+      acc *= gs * (full ? T(1) : T(2));
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const T gi = g[i * C + c], gj = g[j * C + c];
+        acc += gi * q[j * C + c];
+        if (!full) acc += gj * q[i * C + c];
+        if (grad_q) {
+          atomic_add(grad_q + j * C + c, T(0.5) * v * gi);
+          if (!full) atomic_add(grad_q + i * C + c, T(0.5) * v * gj);
+        }
       }
     }
     if (grad_d) grad_d[p] = T(0.5) * dv * acc;
@@ -204,14 +212,14 @@ int rspace_forward_impl(hipStream_t st, int64_t P, int64_t N, int C, const void*
 template <typename T, typename I>
 int rspace_backward_impl(hipStream_t st, int64_t P, int64_t N, int C, const void* pairs, const void* dist,
                          const void* q, const void* mask, int full, const mipme_potential_t* pot, const void* g,
-                         void* grad_d, void* grad_q) {
+                         const void* gscale, void* grad_d, void* grad_q) {
   SRPot s;
   int rc = make_srpot(pot, s);
   if (rc) return rc;
   if (P == 0) return MIPME_OK;
   rspace_backward_kernel<T, I><<<pair_grid(P), 256, 0, st>>>(s, P, C, (const I*)pairs, (const T*)dist, (const T*)q,
-                                                             (const uint8_t*)mask, full != 0, (const T*)g, (T*)grad_d,
-                                                             (T*)grad_q);
+                                                             (const uint8_t*)mask, full != 0, (const T*)g,
+                                                             (const T*)gscale, (T*)grad_d, (T*)grad_q);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -255,7 +263,8 @@ int distance_backward_impl(hipStream_t st, int64_t P, int64_t N, const void* pai
   template int rspace_forward_impl<T, I>(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*,    \
                                          const void*, int, const mipme_potential_t*, int, void*);                     \
   template int rspace_backward_impl<T, I>(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*,   \
-                                          const void*, int, const mipme_potential_t*, const void*, void*, void*);      \
+                                          const void*, int, const mipme_potential_t*, const void*, const void*, void*, \
+                                          void*);                                                                      \
   template int distance_forward_impl<T, I>(hipStream_t, int64_t, const void*, const void*, const void*, const void*,   \
                                            void*);                                                                     \
   template int distance_backward_impl<T, I>(hipStream_t, int64_t, int64_t, const void*, const void*, const void*,      \

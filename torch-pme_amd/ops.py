@@ -310,6 +310,13 @@ class _PMEFunction(torch.autograd.Function):
             st = _lib.current_stream(device)
             topo = ctx.topo
             do_kspace = geom is not None and (need_q or need_cell or need_pos)
+            # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
+            # exactly gE * charges, and the adjoint mesh is a multiple of the forward one (no second spread / FFT).
+            tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
+            gscale = None
+            if (tag is not None and not need_cell and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape)
+                    and tag[2] == q._version and ctx.slab_axis is None):
+                gscale = tag[3]
             if need_dist:
                 grad_dist = torch.empty((P,), dtype=dtype, device=device)
 
@@ -320,7 +327,7 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward", lib.mipme_rspace_backward,
                     _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
                     dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(),
-                    _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
+                    _lib.ptr(gscale), _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
                 )
 
             overlap = OVERLAP and topo is not None and do_kspace and need_dist
@@ -331,13 +338,6 @@ class _PMEFunction(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     run_grad_dist(False)
                     join.record()
-            # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
-            # exactly gE * charges, and the adjoint mesh is a multiple of the forward one (no second spread / FFT).
-            tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
-            gscale = None
-            if (tag is not None and do_kspace and not need_cell and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape)
-                    and tag[2] == q._version and ctx.slab_axis is None):
-                gscale = tag[3]
             if do_kspace and gscale is not None:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn)
