@@ -223,6 +223,30 @@ int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, 
                                       void* grad_cell);
 int64_t mipme_rows_partials_size(int64_t n_atoms);
 
+/* ---- device neighbour list (the reference uses third-party vesin on the host,
+ * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------
+ * Scope: fully periodic cells with >= 3 cells of perpendicular width >= cutoff per axis (n_cells[d] = floor(width_d /
+ * cutoff) >= 3); other cases use the host builder.  Protocol: mipme_nl_bin -> mipme_nl_count -> (caller: exclusive
+ * scan of counts into int64 offsets[N+1], allocate P = offsets[N]) -> mipme_nl_fill. */
+typedef struct {
+  double cell[9];      /* row-major, rows = lattice vectors */
+  double inv_cell[9];
+  int32_t n_cells[3];
+  int32_t periodic[3];
+  double cutoff;
+  int32_t full_list;
+  int32_t _pad;
+} mipme_nl_t;
+int64_t mipme_nl_scratch_ints(const mipme_nl_t* nl, int64_t n_atoms);
+/* cell_of int32[N], wrap int32[N][3], cell_start int32[ncells+1], cell_atoms int32[N], scratch int32[mipme_nl_scratch_ints] */
+int mipme_nl_bin(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, void* cell_of,
+                 void* wrap, void* cell_start, void* cell_atoms, void* scratch);
+int mipme_nl_count(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, const void* wrap,
+                   const void* cell_start, const void* cell_atoms, void* counts /* int32[N] */);
+int mipme_nl_fill(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, const void* wrap,
+                  const void* cell_start, const void* cell_atoms, const void* offsets /* int64[N+1] */, void* pairs,
+                  void* shifts, void* dist /* nullable */);
+
 #ifdef __cplusplus
 }
 #endif

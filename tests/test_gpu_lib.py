@@ -218,3 +218,56 @@ def test_filter_all_exponents(golden_dir, p):
     f = P3MKSpaceFilter(torch.tensor(z["cell"], device=DEV), torch.tensor(z["ns"], device=DEV), 4, pot, "backward", "forward", 0, 2)
     ref = z[f"G_ipl{p}"]
     np.testing.assert_allclose(f._kfilter.cpu().numpy(), ref, rtol=1e-10, atol=1e-13 * np.abs(ref).max())
+
+
+def _canon(pairs, shifts, dist):
+    pairs, shifts, dist = np.asarray(pairs), np.asarray(shifts).round().astype(np.int64), np.asarray(dist)
+    order = np.lexsort((shifts[:, 2], shifts[:, 1], shifts[:, 0], pairs[:, 1], pairs[:, 0]))
+    return pairs[order], shifts[order], dist[order]
+
+
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("triclinic", [False, True])
+def test_device_neighbor_list_matches_host(full, triclinic):
+    """GPU cell-list builder == host builder (same pairs, shifts, distances), atoms outside the cell included."""
+    rng = np.random.default_rng(5)
+    cell = np.array([[13.0, 0, 0], [0, 14.0, 0], [0, 0, 12.5]]) if not triclinic else np.array(
+        [[13.0, 0, 0], [2.0, 14.0, 0], [1.0, -1.5, 12.5]])
+    N = 700
+    pos = rng.uniform(-6, 20, (N, 3))
+    rc = 3.7
+    hp, hS, hd = tpa.neighbor_list(pos, cell, rc, full_list=full)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    gp, gS, gd = tpa.neighbor_list_device(t(pos), t(cell), rc, full_list=full)
+    assert gp.dtype == torch.int64 and gS.dtype == torch.float64 and len(gp) == len(hp)
+    a = _canon(hp, hS, hd)
+    b = _canon(gp.cpu().numpy(), gS.cpu().numpy(), gd.cpu().numpy())
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-13)
+    assert (np.diff(gp[:, 0].cpu().numpy()) >= 0).all()  # rows ordered by the first index
+    # deterministic output order
+    gp2, gS2, _ = tpa.neighbor_list_device(t(pos), t(cell), rc, full_list=full)
+    assert torch.equal(gp, gp2) and torch.equal(gS, gS2)
+
+
+def test_device_neighbor_list_feeds_the_calculator(golden_dir):
+    """End to end with a list built on the GPU: same energy / forces as the reference golden (fp64)."""
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    pos, cell, q = t(z["positions"]).requires_grad_(True), t(z["cell"]), t(z["charges"])
+    pairs, S, _ = tpa.neighbor_list_device(pos.detach(), cell, float(z["cutoff"]))
+    assert len(pairs) == len(z["pairs"])
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])),
+                             mesh_spacing=float(z["p3m5/mesh_spacing"]), interpolation_nodes=5)
+    d = tpa.pair_distances(pos, pairs, cell, S)
+    E = tpa.weighted_sum(calc(q, cell, pos, pairs, d), q)
+    E.backward()
+    assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-11 * abs(E.item())
+    assert np.linalg.norm(pos.grad.cpu().numpy() - z["p3m5/f64/grad_positions"]) < 1e-10 * np.linalg.norm(z["p3m5/f64/grad_positions"])
+
+
+def test_device_neighbor_list_scope():
+    with pytest.raises(ValueError, match="device neighbour list needs >= 3 cells"):
+        tpa.neighbor_list_device(torch.zeros((2, 3), device=DEV, dtype=torch.float64),
+                                 torch.eye(3, device=DEV, dtype=torch.float64), 2.0)

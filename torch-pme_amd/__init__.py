@@ -10,7 +10,7 @@ from . import lib, prefactors  # noqa: F401
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces
-from .neighbors import neighbor_list
+from .neighbors import neighbor_list, neighbor_list_device
 from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
 
@@ -27,4 +27,5 @@ __all__ = [
     "weighted_sum",
     "GraphedEnergyForces",
     "neighbor_list",
+    "neighbor_list_device",
 ]

@@ -29,6 +29,7 @@ EXPORTS = (
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
     "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
+    "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
 )
 
 
@@ -55,6 +56,18 @@ class MeshDesc(C.Structure):
         ("cell", C.c_double * 9),
         ("inv_cell", C.c_double * 9),
         ("volume", C.c_double),
+    ]
+
+
+class NlDesc(C.Structure):
+    _fields_ = [
+        ("cell", C.c_double * 9),
+        ("inv_cell", C.c_double * 9),
+        ("n_cells", C.c_int32 * 3),
+        ("periodic", C.c_int32 * 3),
+        ("cutoff", C.c_double),
+        ("full_list", C.c_int32),
+        ("_pad", C.c_int32),
     ]
 
 
@@ -93,6 +106,9 @@ def _declare(lib):
         "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
+        "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],
+        "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
+        "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -108,6 +124,8 @@ def _declare(lib):
     lib.mipme_rows_partials_size.argtypes = [i64]
     lib.mipme_atom_bins_bytes.restype = i64
     lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
+    lib.mipme_nl_scratch_ints.restype = i64
+    lib.mipme_nl_scratch_ints.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_profile_enable.restype = ci
     lib.mipme_profile_enable.argtypes = [ci]
     lib.mipme_profile_report.restype = i64

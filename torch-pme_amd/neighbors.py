@@ -126,3 +126,66 @@ def neighbor_list_bruteforce(positions, cell, cutoff: float, full_list: bool = F
     i, j, S = i[order], j[order], S[order]
     vec = pos[j] - pos[i] + S @ A
     return np.stack([i, j], axis=1), S, np.sqrt(np.sum(vec * vec, axis=1))
+
+
+def neighbor_list_device(positions, cell, cutoff: float, full_list: bool = False):
+    """Neighbour list built ON THE GPU (``csrc/neighbors.hip``): ``positions`` (N,3) and ``cell`` (3,3) are device
+    tensors; returns device tensors ``pairs`` (P,2) int64, ``shifts`` (P,3) and ``dist`` (P,) in the dtype of
+    ``positions`` -- the same pair set as :func:`neighbor_list` (rows ordered by the first index; the order inside a
+    row is the cell-traversal order).  Fully periodic cells with at least 3 cutoff-wide cells per axis; raises
+    ``ValueError`` otherwise (use the host builder then)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    _lib.require_device(positions, "positions")
+    lib = _lib.load()
+    device, dtype = positions.device, positions.dtype
+    A = cell.detach().to("cpu", torch.float64).numpy()
+    vol = abs(np.linalg.det(A))
+    nc = []
+    for d in range(3):
+        width = vol / np.linalg.norm(np.cross(A[(d + 1) % 3], A[(d + 2) % 3]))
+        nc.append(int(np.floor(width / cutoff)))
+    if min(nc) < 3:
+        raise ValueError(
+            f"device neighbour list needs >= 3 cells of width >= cutoff per axis, got {nc}; use neighbor_list() (host)"
+        )
+    nc = [min(n, 256) for n in nc]
+    desc = _lib.NlDesc()
+    desc.cell[:] = A.ravel().tolist()
+    desc.inv_cell[:] = np.linalg.inv(A).ravel().tolist()
+    desc.n_cells[:] = nc
+    desc.periodic[:] = [1, 1, 1]
+    desc.cutoff = float(cutoff)
+    desc.full_list = int(bool(full_list))
+    pos = positions.detach().contiguous()
+    N = pos.shape[0]
+    ncells = nc[0] * nc[1] * nc[2]
+    i32 = dict(dtype=torch.int32, device=device)
+    cell_of = torch.empty((max(N, 1),), **i32)
+    wrap = torch.empty((max(N, 1), 3), **i32)
+    cell_start = torch.empty((ncells + 1,), **i32)
+    cell_atoms = torch.empty((max(N, 1),), **i32)
+    scratch = torch.empty((lib.mipme_nl_scratch_ints(C.byref(desc), N),), **i32)
+    counts = torch.zeros((N,), **i32)
+    dt = _lib.dtype_code(dtype)
+    with torch.cuda.device(device):
+        st = _lib.current_stream(device)
+        _lib.check(lib.mipme_nl_bin(st, dt, C.byref(desc), N, pos.data_ptr(), cell_of.data_ptr(), wrap.data_ptr(),
+                                    cell_start.data_ptr(), cell_atoms.data_ptr(), scratch.data_ptr()))
+        _lib.check(lib.mipme_nl_count(st, dt, C.byref(desc), N, pos.data_ptr(), wrap.data_ptr(), cell_start.data_ptr(),
+                                      cell_atoms.data_ptr(), counts.data_ptr()))
+        offsets = torch.zeros((N + 1,), dtype=torch.int64, device=device)
+        torch.cumsum(counts, dim=0, out=offsets[1:])
+        P = int(offsets[-1].item())  # the one host synchronisation: the size of the list
+        pairs = torch.empty((P, 2), dtype=torch.int64, device=device)
+        shifts = torch.empty((P, 3), dtype=dtype, device=device)
+        dist = torch.empty((P,), dtype=dtype, device=device)
+        if P > 0:
+            _lib.check(lib.mipme_nl_fill(st, dt, C.byref(desc), N, pos.data_ptr(), wrap.data_ptr(), cell_start.data_ptr(),
+                                         cell_atoms.data_ptr(), offsets.data_ptr(), pairs.data_ptr(), shifts.data_ptr(),
+                                         dist.data_ptr()))
+    return pairs, shifts, dist
