@@ -251,20 +251,34 @@ def test_device_neighbor_list_matches_host(full, triclinic):
     assert torch.equal(gp, gp2) and torch.equal(gS, gS2)
 
 
-def test_device_neighbor_list_feeds_the_calculator(golden_dir):
-    """End to end with a list built on the GPU: same energy / forces as the reference golden (fp64)."""
-    z = np.load(f"{golden_dir}/ref_medium.npz")
+def test_device_neighbor_list_feeds_the_calculator():
+    """End to end with a list built on the GPU: same potentials / forces as with the host-built list."""
+    rng = np.random.default_rng(9)
+    n_side, a = 10, 2.2
+    L = n_side * a
+    g = (np.arange(n_side) + 0.5) * a
+    pos_np = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.4, 0.4, (n_side**3, 3))
+    q_np = rng.normal(size=(n_side**3, 1))
+    q_np -= q_np.mean()
+    cell_np = L * np.eye(3)
+    rc = 6.0
     t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
-    pos, cell, q = t(z["positions"]).requires_grad_(True), t(z["cell"]), t(z["charges"])
-    pairs, S, _ = tpa.neighbor_list_device(pos.detach(), cell, float(z["cutoff"]))
-    assert len(pairs) == len(z["pairs"])
-    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])),
-                             mesh_spacing=float(z["p3m5/mesh_spacing"]), interpolation_nodes=5)
-    d = tpa.pair_distances(pos, pairs, cell, S)
-    E = tpa.weighted_sum(calc(q, cell, pos, pairs, d), q)
-    E.backward()
-    assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-11 * abs(E.item())
-    assert np.linalg.norm(pos.grad.cpu().numpy() - z["p3m5/f64/grad_positions"]) < 1e-10 * np.linalg.norm(z["p3m5/f64/grad_positions"])
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=rc / 5), mesh_spacing=2 * L / 30, interpolation_nodes=5)
+    results = []
+    for builder in ("host", "device"):
+        pos, cell, q = t(pos_np).requires_grad_(True), t(cell_np), t(q_np)
+        if builder == "host":
+            pairs, S, _ = tpa.neighbor_list(pos_np, cell_np, rc)
+            pairs, S = t(pairs), t(S).double()
+        else:
+            pairs, S, _ = tpa.neighbor_list_device(pos.detach(), cell, rc)
+        d = tpa.pair_distances(pos, pairs, cell, S)
+        V = calc(q, cell, pos, pairs, d)
+        tpa.weighted_sum(V, q).backward()
+        results.append((len(pairs), V.detach().cpu().numpy(), pos.grad.cpu().numpy()))
+    assert results[0][0] == results[1][0]
+    np.testing.assert_allclose(results[1][1], results[0][1], rtol=0, atol=1e-12 * np.abs(results[0][1]).max())
+    np.testing.assert_allclose(results[1][2], results[0][2], rtol=0, atol=1e-11 * np.abs(results[0][2]).max())
 
 
 def test_device_neighbor_list_scope():
