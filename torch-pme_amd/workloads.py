@@ -12,7 +12,22 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .neighbors import neighbor_list
+from .neighbors import neighbor_list, neighbor_list_device
+
+
+def _build_list(pos: np.ndarray, cell: np.ndarray, cutoff: float):
+    """Half neighbour list of a synthetic box: built on the GPU when one is present (milliseconds instead of ~15 s
+    for 32k atoms with the host k-d tree), on the host otherwise; both give the same pair set."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            p, s, _ = neighbor_list_device(torch.tensor(pos, device="cuda"), torch.tensor(cell, device="cuda"), cutoff)
+            return p.cpu().numpy(), s.cpu().numpy().round().astype(np.int64)
+    except ValueError:
+        pass  # box too small for the device cell list
+    p, s, _ = neighbor_list(pos, cell, cutoff)
+    return p, s
 
 
 @dataclass
@@ -77,7 +92,7 @@ def water_box(n_side: int = 22, n_mesh: int = 64, order: int = 5, cutoff: float 
     pos = np.concatenate([oxy[:, None, :], h], axis=1).reshape(-1, 3)
     q = np.tile(np.array([-0.834, 0.417, 0.417]), n_mol).reshape(-1, 1)
     cell = L * np.eye(3)
-    pairs, shifts, _ = neighbor_list(pos, cell, cutoff)
+    pairs, shifts = _build_list(pos, cell, cutoff)
     return Workload(f"water_{3 * n_mol}", pos, q, cell, pairs, shifts, cutoff, cutoff / 5, 2 * L / (n_mesh - 2), n_mesh,
                     "P3M", order, 1, dtype)
 
@@ -92,7 +107,7 @@ def ionic_box(n_side: int = 20, n_mesh: int = 32, order: int = 4, cutoff: float 
     q = rng.normal(size=(n, 1))
     q -= q.mean()
     cell = L * np.eye(3)
-    pairs, shifts, _ = neighbor_list(pos, cell, cutoff)
+    pairs, shifts = _build_list(pos, cell, cutoff)
     return Workload(f"ionic_{n}", pos, q, cell, pairs, shifts, cutoff, cutoff / 5, 2 * L / (n_mesh - 2), n_mesh, "P3M",
                     order, 1, dtype)
 
@@ -106,6 +121,6 @@ def dispersion_box(n_side: int = 64, n_mesh: int = 128, order: int = 5, cutoff: 
     pos = _lattice(n_side, L / n_side, 0.4, rng)
     q = rng.uniform(0.5, 1.5, size=(n, 1))
     cell = L * np.eye(3)
-    pairs, shifts, _ = neighbor_list(pos, cell, cutoff)
+    pairs, shifts = _build_list(pos, cell, cutoff)
     return Workload(f"dispersion_{n}", pos, q, cell, pairs, shifts, cutoff, cutoff / 5, 2 * L / (n_mesh - 2), n_mesh,
                     "P3M", order, 6, dtype)
