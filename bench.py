@@ -173,7 +173,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("MIPME_FORCE_DIST") == "1"  # the latter: 1-rank smoke test of this path
     if distributed:
         import torch.distributed as dist
 
@@ -186,7 +186,13 @@ def main():
     w = make_workload(args.workload, rank)
     frame = Frame(w, device)
     s = 4 if w.dtype == "f32" else 8
-    energies = torch.zeros(world, dtype=frame.dtype, device=device)
+    # per-frame energies of all ranks: the farm's only exchange (8 bytes x frames).  Double-buffered and asynchronous:
+    # the all-gather of step k runs on RCCL's stream while step k+1 computes; it is waited for one step later, and
+    # the last one before the closing barrier, so the timed region contains every collective.
+    energies = [torch.zeros(world, dtype=frame.dtype, device=device) for _ in range(2)]
+    send = [torch.zeros(1, dtype=frame.dtype, device=device) for _ in range(2)]
+    pending = [None]
+    counter = [0]
 
     launch = args.launch
     graphed = None
@@ -203,11 +209,22 @@ def main():
         else:
             E, F = frame.step()
         if distributed:
-            dist.all_gather_into_tensor(energies, E.reshape(1))
+            k = counter[0] & 1
+            counter[0] += 1
+            if pending[0] is not None:
+                pending[0].wait()
+            send[k].copy_(E.reshape(1))
+            pending[0] = dist.all_gather_into_tensor(energies[k], send[k], async_op=True)
         return E
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -215,6 +232,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         E = one_step()
+    drain()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
