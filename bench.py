@@ -5,8 +5,8 @@
 One *step* = one energy + forces evaluation of one frame per GPU, the reference's protocol
 (BASELINE.md section 2): ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = sum(q*V)`` ->
 ``E.backward()`` (forces = -dE/dpositions).  Inputs are resident in HBM before the timed region.  With N > 1
-every rank owns an independent frame (weak scaling, no intra-cell decomposition) and the per-frame energies
-are exchanged with one RCCL all_gather per step.
+every rank owns an independent frame (weak scaling, no intra-cell decomposition); the per-frame energies are
+logged on the device and exchanged with ONE RCCL all_gather after the last step (inside the timed region).
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
@@ -180,18 +180,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("MIPME_DIST_EARLY_BARRIER", "1") == "1":
+            # run one collective NOW: RCCL finishes its lazy set-up (channels, buffers) before any HIP graph is
+            # captured -- a first collective issued after the capture made later replays fault on this stack
+            dist.barrier()
+            torch.cuda.synchronize()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
     w = make_workload(args.workload, rank)
     frame = Frame(w, device)
     s = 4 if w.dtype == "f32" else 8
-    # per-frame energies of all ranks: the farm's only exchange (8 bytes x frames).  Double-buffered and asynchronous:
-    # the all-gather of step k runs on RCCL's stream while step k+1 computes; it is waited for one step later, and
-    # the last one before the closing barrier, so the timed region contains every collective.
-    energies = [torch.zeros(world, dtype=frame.dtype, device=device) for _ in range(2)]
-    send = [torch.zeros(1, dtype=frame.dtype, device=device) for _ in range(2)]
-    pending = [None]
+    # per-frame energies: every rank logs the energy of each of its frame evaluations on the device and the farm's ONE
+    # exchange -- an all-gather of the logs over RCCL (8 B x steps per rank) -- runs after the last
+    # step, inside the timed region.
+    n_log = max(args.steps, args.warmup, 1)
+    energy_log = torch.zeros(n_log, dtype=frame.dtype, device=device)
+    all_logs = torch.zeros(world * n_log, dtype=frame.dtype, device=device)
     counter = [0]
 
     launch = args.launch
@@ -208,36 +213,34 @@ def main():
             E, F = graphed()
         else:
             E, F = frame.step()
-        if distributed:
-            k = counter[0] & 1
-            counter[0] += 1
-            if pending[0] is not None:
-                pending[0].wait()
-            send[k].copy_(E.reshape(1))
-            pending[0] = dist.all_gather_into_tensor(energies[k], send[k], async_op=True)
+        energy_log[counter[0] % n_log].copy_(E)
+        counter[0] += 1
         return E
 
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+    def exchange():
+        if distributed:
+            dist.all_gather_into_tensor(all_logs, energy_log)
 
+    dbg("graph captured" if graphed is not None else "eager mode")
     for _ in range(args.warmup):
         one_step()
-    drain()
+    exchange()
+    dbg("warm-up done")
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    counter[0] = 0
     for _ in range(args.steps):
         E = one_step()
-    drain()
+    exchange()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dbg("timed loop done")
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

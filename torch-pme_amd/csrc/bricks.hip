@@ -474,8 +474,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);
+  // static LDS on purpose: HIP-graph replays of kernels with a *dynamic* LDS segment faulted on this stack once an
+  // RCCL collective had run after the capture (tools/dist_probe.py); statically sized tiles are unaffected
+  __shared__ T tile[TL * TL * TL];
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
@@ -644,7 +645,7 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, n_atoms, dtype, bins);
   const bool even = (m->order % 2) == 0;
-  MIPME_CHECK_HIP(hipMemsetAsync(v.count, 0, sizeof(int) * size_t(bg.nb + 1), st));
+  MIPME_CHECK_HIP(zero_async(v.count, sizeof(int) * size_t(bg.nb + 1), st));
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
   if (n_atoms > 0) {
     bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, n_atoms, (const T*)pos, v.count, v.slot, v.brick);
@@ -672,6 +673,21 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   return MIPME_OK;
 }
 
+// debug probe: a 512-thread kernel that only reads the bins (rec) and writes one word back
+__global__ __launch_bounds__(512) void bins_touch_kernel(const int* __restrict__ start, const int4* __restrict__ rec, int* __restrict__ slot) {
+  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
+  int acc = 0;
+  for (int k = beg + threadIdx.x; k < end; k += 512) acc += rec[k].w;
+  if (acc == -12345) slot[0] = acc;
+}
+int bins_touch(hipStream_t st, const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  bins_touch_kernel<<<unsigned(bg.nb), 512, 0, st>>>(v.start, v.rec, v.slot);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
@@ -695,10 +711,8 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const int tl = BRICK + m->order - 1;
-  const size_t lds = sizeof(T) * size_t(tl) * tl * tl;
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           ((void)S, gather_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
+                           ((void)S, gather_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out, (T*)raw)));
   MIPME_LAUNCH_CHECK();

@@ -62,6 +62,24 @@ inline int validate_mesh(const mipme_mesh_t* m) {
   return MIPME_OK;
 }
 
+// Zero-fill with our own kernel instead of hipMemsetAsync: a memset NODE captured into a HIP graph stopped zeroing
+// its buffer once an RCCL collective had run after the capture (ROCm 7.0 runtime under PyTorch; found with
+// tools/dist_probe.py -- the stale brick counters then sent the binning kernels out of bounds).  A kernel node is
+// immune, and the fill is as fast (the buffers are <= a few MB).
+static __global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n_words) {
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_words; i += size_t(gridDim.x) * blockDim.x) p[i] = 0u;
+}
+
+inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  // every buffer zeroed by the library is 4-byte aligned and a multiple of 4 bytes long
+  const size_t n_words = bytes / 4;
+  size_t blocks = (n_words + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  zero_words_kernel<<<unsigned(blocks), 256, 0, st>>>(static_cast<uint32_t*>(ptr), n_words);
+  return hipGetLastError();
+}
+
 // Hardware float atomics (global_atomic_add_f32 / _f64 on gfx950; memory is coarse-grained hipMalloc).
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }

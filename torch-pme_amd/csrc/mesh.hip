@@ -230,7 +230,7 @@ int spread_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const vo
                 void* mesh) {
   const Geom g = make_geom(m);
   const size_t bytes = sizeof(T) * size_t(m->n_channels) * m->nx * m->ny * m->nz;
-  MIPME_CHECK_HIP(hipMemsetAsync(mesh, 0, bytes, st));
+  MIPME_CHECK_HIP(zero_async(mesh, bytes, st));
   if (n_atoms == 0) return MIPME_OK;
   MIPME_DISPATCH_STENCIL(m->scheme, m->order, (spread_kernel<S, N, T><<<blocks_for<N>(n_atoms), 256, 0, st>>>(
                                                   g, n_atoms, m->n_channels, (const T*)pos, (const T*)val, T(scale), (T*)mesh)));

@@ -219,9 +219,9 @@ static int nl_bin_impl(hipStream_t st, const mipme_nl_t* d, int64_t N, const voi
   int* count = (int*)scratch;               // [ncells + 1]
   int* cursor = count + (ncells + 1);       // [ncells + 1]
   int* tmp_atoms = cursor + (ncells + 1);   // [N]
-  MIPME_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(int) * size_t(2 * (ncells + 1)), st));
+  MIPME_CHECK_HIP(zero_async(scratch, sizeof(int) * size_t(2 * (ncells + 1)), st));
   if (N == 0) {
-    MIPME_CHECK_HIP(hipMemsetAsync(cell_start, 0, sizeof(int) * size_t(ncells + 1), st));
+    MIPME_CHECK_HIP(zero_async(cell_start, sizeof(int) * size_t(ncells + 1), st));
     return MIPME_OK;
   }
   const unsigned blocks = unsigned((N + 255) / 256);

@@ -197,7 +197,7 @@ int rspace_forward_impl(hipStream_t st, int64_t P, int64_t N, int C, const void*
   SRPot s;
   int rc = make_srpot(pot, s);
   if (rc) return rc;
-  if (!accumulate) MIPME_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * size_t(N) * C, st));
+  if (!accumulate) MIPME_CHECK_HIP(zero_async(out, sizeof(T) * size_t(N) * C, st));
   if (P == 0) return MIPME_OK;
   if (C == 1)
     rspace_forward_kernel<T, I, 1><<<pair_grid(P), 256, 0, st>>>(s, P, C, (const I*)pairs, (const T*)dist, (const T*)q,
@@ -237,9 +237,9 @@ int distance_forward_impl(hipStream_t st, int64_t P, const void* pairs, const vo
 template <typename T, typename I>
 int distance_backward_impl(hipStream_t st, int64_t P, int64_t N, const void* pairs, const void* pos, const void* cell,
                            const void* shifts, const void* grad_d, void* partials, void* grad_pos, void* grad_cell) {
-  MIPME_CHECK_HIP(hipMemsetAsync(grad_pos, 0, sizeof(T) * size_t(N) * 3, st));
+  MIPME_CHECK_HIP(zero_async(grad_pos, sizeof(T) * size_t(N) * 3, st));
   if (P == 0) {
-    if (grad_cell) MIPME_CHECK_HIP(hipMemsetAsync(grad_cell, 0, sizeof(T) * 9, st));
+    if (grad_cell) MIPME_CHECK_HIP(zero_async(grad_cell, sizeof(T) * 9, st));
     return MIPME_OK;
   }
   const unsigned grid = pair_grid(P);

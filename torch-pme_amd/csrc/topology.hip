@@ -75,7 +75,7 @@ static int topology_build_impl(hipStream_t st, int64_t P, int64_t N, const void*
   const int64_t E = 2 * P;
   MIPME_REQUIRE(N < (int64_t(1) << 30) && P < (int64_t(1) << 30), "pair list too large for 32-bit topology");
   if (P == 0) {
-    MIPME_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int) * size_t(2 * N + 1), st));
+    MIPME_CHECK_HIP(zero_async(row_ptr, sizeof(int) * size_t(2 * N + 1), st));
     return MIPME_OK;
   }
   const TopoWorkspace w = topo_layout(P);
@@ -387,7 +387,7 @@ static int distance_backward_rows_impl(hipStream_t st, int64_t N, const void* ro
                                        const void* packed, const void* pos, const void* cell, const void* shifts,
                                        const void* grad_d, void* partials, void* grad_pos, void* grad_cell) {
   if (N == 0) {
-    if (grad_cell) MIPME_CHECK_HIP(hipMemsetAsync(grad_cell, 0, sizeof(T) * 9, st));
+    if (grad_cell) MIPME_CHECK_HIP(zero_async(grad_cell, sizeof(T) * 9, st));
     return MIPME_OK;
   }
   if (grad_cell) {
@@ -431,7 +431,7 @@ int mipme_topology_pack_shifts(void* stream, int dtype, int64_t n_pairs, const v
                                void* packed, void* flag) {
   MIPME_REQUIRE(n_pairs >= 0 && flag, "invalid arguments to mipme_topology_pack_shifts");
   hipStream_t st = (hipStream_t)stream;
-  MIPME_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+  MIPME_CHECK_HIP(zero_async(flag, sizeof(int), st));
   const int64_t E = 2 * n_pairs;
   if (E == 0) return MIPME_OK;
   MIPME_REQUIRE(entries && shifts && packed, "NULL buffer passed to mipme_topology_pack_shifts");
