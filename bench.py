@@ -199,6 +199,11 @@ def main():
     all_logs = torch.zeros(world * n_log, dtype=frame.dtype, device=device)
     counter = [0]
 
+    def dbg(msg):
+        if os.environ.get("MIPME_BENCH_DEBUG") == "1":
+            torch.cuda.synchronize()
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     launch = args.launch
     graphed = None
     if launch == "graph":
