@@ -180,11 +180,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        if os.environ.get("MIPME_DIST_EARLY_BARRIER", "1") == "1":
-            # run one collective NOW: RCCL finishes its lazy set-up (channels, buffers) before any HIP graph is
-            # captured -- a first collective issued after the capture made later replays fault on this stack
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()  # one collective up front: RCCL completes its lazy set-up before anything is timed or captured
+        torch.cuda.synchronize()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 

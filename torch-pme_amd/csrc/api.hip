@@ -1,7 +1,6 @@
 // extern "C" entry points of libmipme.so (declared in include/mipme.h) and the composite
 // k-space forward / backward sequences (reference calculators/pme.py:88-143 and its autograd).
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -46,7 +45,6 @@ FftDims fft_plan_dims(const mipme_fft_plan*);
 bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
-int bins_touch(hipStream_t, const mipme_mesh_t*, int64_t, int, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
@@ -113,14 +111,9 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
-  static const int bmask = getenv("MIPME_BRICK_MASK") ? atoi(getenv("MIPME_BRICK_MASK")) : 7;
   if (bins) {
     STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins));
-    if (bmask & 8) STAGE(st, "bins_touch", bins_touch(st, m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins));
-    if (bmask & 1)
-      STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh));
-    else
-      STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh));
   } else {
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
   }
@@ -129,7 +122,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, phi_mesh));
   // the short-range sum may be running on another stream into out_lr: join it before the gather adds to it
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
-  if (bins && (bmask & 2))
+  if (bins)
     STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
   else
     STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
@@ -149,8 +142,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
     // energy mode: grad_out = grad_scale * charges  =>  psi = (grad_scale/2V) rho, chi = (grad_scale/2V) phi:
     // no second spread / FFT / filter / inverse FFT (special case L = sum q V)
     MIPME_REQUIRE(!grad_cell && rho_dc, "energy-mode backward needs rho_dc and does not produce the cell gradient");
-    static const int bmask = getenv("MIPME_BRICK_MASK") ? atoi(getenv("MIPME_BRICK_MASK")) : 7;
-    if (bins && (bmask & 4))
+    if (bins)
       STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
     else
       STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));

@@ -474,8 +474,6 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
-  // static LDS on purpose: HIP-graph replays of kernels with a *dynamic* LDS segment faulted on this stack once an
-  // RCCL collective had run after the capture (tools/dist_probe.py); statically sized tiles are unaffected
   __shared__ T tile[TL * TL * TL];
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
@@ -670,21 +668,6 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
     bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
     MIPME_LAUNCH_CHECK();
   }
-  return MIPME_OK;
-}
-
-// debug probe: a 512-thread kernel that only reads the bins (rec) and writes one word back
-__global__ __launch_bounds__(512) void bins_touch_kernel(const int* __restrict__ start, const int4* __restrict__ rec, int* __restrict__ slot) {
-  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
-  int acc = 0;
-  for (int k = beg + threadIdx.x; k < end; k += 512) acc += rec[k].w;
-  if (acc == -12345) slot[0] = acc;
-}
-int bins_touch(hipStream_t st, const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
-  const BrickGeom bg = make_brick_geom(m);
-  const BinsView v = bins_view(m, N, dtype, bins);
-  bins_touch_kernel<<<unsigned(bg.nb), 512, 0, st>>>(v.start, v.rec, v.slot);
-  MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
 
