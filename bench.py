@@ -179,9 +179,19 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()  # one collective up front: RCCL completes its lazy set-up before anything is timed or captured
-        torch.cuda.synchronize()
+        # RCCL prints a version banner on the C-level stdout when the communicator comes up; keep stdout for the one JSON
+        # line by pointing fd 1 at stderr while the process group initialises and runs its first collective
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()  # RCCL completes its lazy set-up before anything is timed or captured
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
