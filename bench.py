@@ -5,8 +5,8 @@
 One *step* = one energy + forces evaluation of one frame per GPU, the reference's protocol
 (BASELINE.md section 2): ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = sum(q*V)`` ->
 ``E.backward()`` (forces = -dE/dpositions).  Inputs are resident in HBM before the timed region.  With N > 1
-every rank owns an independent frame (weak scaling, no intra-cell decomposition); the per-frame energies are
-logged on the device and exchanged with ONE RCCL all_gather after the last step (inside the timed region).
+every rank owns an independent frame (weak scaling, no intra-cell decomposition); the frame energies are exchanged
+with ONE RCCL all_gather after the last step (inside the timed region).
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
@@ -198,13 +198,10 @@ def main():
     w = make_workload(args.workload, rank)
     frame = Frame(w, device)
     s = 4 if w.dtype == "f32" else 8
-    # per-frame energies: every rank logs the energy of each of its frame evaluations on the device and the farm's ONE
-    # exchange -- an all-gather of the logs over RCCL (8 B x steps per rank) -- runs after the last
-    # step, inside the timed region.
-    n_log = max(args.steps, args.warmup, 1)
-    energy_log = torch.zeros(n_log, dtype=frame.dtype, device=device)
-    all_logs = torch.zeros(world * n_log, dtype=frame.dtype, device=device)
-    counter = [0]
+    # the farm's ONE exchange: after its last frame evaluation every rank contributes its frame energy
+    # to an all-gather over RCCL (8 B per frame), inside the timed region
+    my_energy = torch.zeros(1, dtype=frame.dtype, device=device)
+    all_energies = torch.zeros(world, dtype=frame.dtype, device=device)
 
     def dbg(msg):
         if os.environ.get("MIPME_BENCH_DEBUG") == "1":
@@ -225,28 +222,26 @@ def main():
             E, F = graphed()
         else:
             E, F = frame.step()
-        energy_log[counter[0] % n_log].copy_(E)
-        counter[0] += 1
         return E
 
-    def exchange():
+    def exchange(E):
         if distributed:
-            dist.all_gather_into_tensor(all_logs, energy_log)
+            my_energy.copy_(E.reshape(1))
+            dist.all_gather_into_tensor(all_energies, my_energy)
 
     dbg("graph captured" if graphed is not None else "eager mode")
     for _ in range(args.warmup):
-        one_step()
-    exchange()
+        E = one_step()
+    exchange(E)
     dbg("warm-up done")
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    counter[0] = 0
     for _ in range(args.steps):
         E = one_step()
-    exchange()
+    exchange(E)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
