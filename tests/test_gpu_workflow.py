@@ -1,0 +1,148 @@
+"""GPU workflow / API tests modelled on the reference's ``tests/calculators/test_workflow.py`` and
+``tests/calculators/test_calculator.py`` (CsCl two-atom system, every calculator on the path, both dtypes)."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import torchpme_amd as tpa  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.float64]
+
+
+def cscl_system(dtype, device=DEV):
+    positions = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.5]], dtype=dtype, device=device)
+    charges = torch.tensor([1.0, -1.0], dtype=dtype, device=device).reshape(-1, 1)
+    cell = torch.eye(3, dtype=dtype, device=device)
+    pairs = torch.tensor([[0, 1]], dtype=torch.int64, device=device)
+    dist = torch.tensor([0.8660254], dtype=dtype, device=device)
+    return charges, cell, positions, pairs, dist
+
+
+CALCULATORS = [
+    (tpa.Calculator, dict(potential=tpa.CoulombPotential(smearing=None))),
+    (tpa.PMECalculator, dict(potential=tpa.CoulombPotential(smearing=0.1), mesh_spacing=0.1)),
+    (tpa.P3MCalculator, dict(potential=tpa.CoulombPotential(smearing=0.1), mesh_spacing=0.1)),
+    (tpa.P3MCalculator, dict(potential=tpa.InversePowerLawPotential(exponent=3, smearing=0.1), mesh_spacing=0.1,
+                             interpolation_nodes=3)),
+]
+
+
+@pytest.mark.parametrize("CalculatorClass,params", CALCULATORS)
+@pytest.mark.parametrize("dtype", DTYPES)
+class TestWorkflow:
+    def test_dtype_device(self, CalculatorClass, params, dtype):
+        """Output dtype and device are those of the input (reference test_workflow.py:112-123)."""
+        calculator = CalculatorClass(**params)
+        calculator.to(device=DEV, dtype=dtype)
+        potential = calculator(*cscl_system(dtype))
+        assert type(potential) is torch.Tensor
+        assert potential.dtype == dtype and potential.device.type == "cuda" and potential.shape == (2, 1)
+
+    def test_not_nan(self, CalculatorClass, params, dtype):
+        """Gradients w.r.t. charges, cell, positions, neighbor distances exist and are finite (:164-192)."""
+        calculator = CalculatorClass(**params)
+        system = list(cscl_system(dtype))
+        for k in (0, 1, 2, 4):
+            system[k].requires_grad = True
+        energy = calculator.forward(*system).sum()
+        for k in (0, 4):
+            g = torch.autograd.grad(energy, system[k], retain_graph=True)[0]
+            assert torch.isfinite(g).all() and g.abs().sum() > 0
+        if CalculatorClass is not tpa.Calculator:
+            for k in (1, 2):
+                g = torch.autograd.grad(energy, system[k], retain_graph=True)[0]
+                assert torch.isfinite(g).all()
+
+    def test_repeated_backward_and_module_call(self, CalculatorClass, params, dtype):
+        calculator = CalculatorClass(**params)
+        system = list(cscl_system(dtype))
+        system[2].requires_grad = True
+        v1 = calculator(*system)
+        v2 = calculator.forward(*system)
+        torch.testing.assert_close(v1, v2)
+        (v1.sum() + 2 * v2.sum()).backward()
+        assert torch.isfinite(system[2].grad).all()
+
+
+def test_batching_not_implemented():
+    calc = tpa.PMECalculator(tpa.CoulombPotential(smearing=0.1), mesh_spacing=0.1)
+    sys_ = cscl_system(torch.float32)
+    with pytest.raises(NotImplementedError, match="Batching not implemented for mesh-based calculators"):
+        calc(*sys_, node_mask=torch.ones(2, dtype=torch.bool, device=DEV))
+    with pytest.raises(NotImplementedError, match="Batching not implemented for mesh-based calculators"):
+        calc(*sys_, kvectors=torch.ones((4, 3), device=DEV))
+
+
+def test_nan_guard_is_opt_in():
+    """The reference raises on NaNs in the k-space result (test_workflow.py:252-288).  Here the filter is built in fp64 and
+    the guard is opt-in (``check_nan``): the reference's problem case gives finite numbers, NaN inputs trip the guard."""
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0, exclusion_radius=4.5), interpolation_nodes=5,
+                             full_neighbor_list=True, mesh_spacing=0.5)
+    charges = torch.ones((4, 1), device=DEV)
+    positions = torch.arange(12, device=DEV).reshape(4, 3).to(torch.float32)
+    cell = torch.tensor([[-2.2958, -0.5882, -0.0797], [1.3575, -0.2575, -1.9272], [1.9694, -5.7254, 2.1524]], device=DEV)
+    pairs = torch.zeros((0, 2), dtype=torch.int64, device=DEV)
+    dist = torch.zeros((0,), device=DEV)
+    calc.check_nan = True
+    out = calc(charges, cell, positions, pairs, dist)
+    assert torch.isfinite(out).all()
+    bad = charges.clone()
+    bad[0, 0] = float("nan")
+    with pytest.raises(ValueError, match=r"NaNs detected in the k-space filter result.*shape: \[1, 16, 16, 32\]"):
+        calc(bad, cell, positions, pairs, dist)
+
+
+def test_exclusion_radius():
+    """Reference test_calculator.py:246-289: with an exclusion radius the direct potential is scaled by (1 - f_cut)."""
+    rx, deg = 4.0, 8
+    d0 = 1.3
+    charges = torch.tensor([[1.0], [-0.4]], dtype=torch.float64, device=DEV)
+    positions = torch.tensor([[0.0, 0, 0], [0, 0, d0]], dtype=torch.float64, device=DEV)
+    cell = torch.eye(3, dtype=torch.float64, device=DEV) * 20
+    pairs = torch.tensor([[0, 1]], device=DEV)
+    dist = torch.tensor([d0], dtype=torch.float64, device=DEV)
+    p1 = tpa.Calculator(tpa.CoulombPotential())(charges, cell, positions, pairs, dist)
+    p2 = tpa.Calculator(tpa.CoulombPotential(exclusion_radius=rx, exclusion_degree=deg))(charges, cell, positions, pairs, dist)
+    fcut = 1 - ((1 - np.cos(np.pi * d0 / rx)) * 0.5) ** deg
+    torch.testing.assert_close(p1 * (1 - fcut), p2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_edge_cases(dtype):
+    """Empty pair list, int32 indices, non-contiguous inputs, atoms far outside the cell, a charged cell."""
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=0.5), mesh_spacing=0.25, interpolation_nodes=4)
+    charges, cell, positions, pairs, dist = cscl_system(dtype)
+    base = calc(charges, cell, positions, pairs, dist)
+    # int32 indices
+    torch.testing.assert_close(calc(charges, cell, positions, pairs.to(torch.int32), dist), base)
+    # non-contiguous positions / charges views
+    big = torch.zeros((2, 6), dtype=dtype, device=DEV)
+    big[:, ::2] = positions
+    torch.testing.assert_close(calc(charges, cell, big[:, ::2], pairs, dist), base)
+    # periodic images of the atoms give the same potentials
+    shifted = positions + torch.tensor([[3.0, -2.0, 5.0], [-4.0, 1.0, 0.0]], dtype=dtype, device=DEV)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    torch.testing.assert_close(calc(charges, cell, shifted, pairs, dist), base, **tol)
+    # no neighbours at all, and a net charge (background term)
+    none = torch.zeros((0, 2), dtype=torch.int64, device=DEV)
+    out = calc(torch.ones_like(charges), cell, positions, none, torch.zeros((0,), dtype=dtype, device=DEV))
+    assert torch.isfinite(out).all()
+    # all three periodic: the slab term is inactive, same result as periodic=None
+    per = torch.tensor([True, True, True], device=DEV)
+    torch.testing.assert_close(calc(charges, cell, positions, pairs, dist, periodic=per), base)
+
+
+def test_module_to_and_state_dict():
+    calc = tpa.P3MCalculator(tpa.InversePowerLawPotential(exponent=2, smearing=0.3, prefactor=2.0), mesh_spacing=0.2)
+    calc.to(device=DEV, dtype=torch.float32)
+    assert calc.potential.smearing.device.type == "cuda" and calc.potential.smearing.dtype == torch.float32
+    sd = calc.state_dict()
+    assert set(sd) == {"potential.smearing", "potential.prefactor", "potential.exponent"}
+    out = calc(*cscl_system(torch.float32))
+    assert torch.isfinite(out).all()
+    d = calc.potential._descriptor()
+    assert d.smearing == pytest.approx(0.3, rel=1e-6) and d.prefactor == 2.0 and d.exponent == 2

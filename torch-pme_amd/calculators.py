@@ -31,6 +31,9 @@ class Calculator(torch.nn.Module):
             raise TypeError(f"Potential must be an instance of Potential, got {type(potential)}")
         self.potential = potential
         self.full_neighbor_list = full_neighbor_list
+        #: opt-in NaN guard of the reference (``lib/kspace_filter.py:189-195``).  Off by default: it costs a device
+        #: synchronisation per call, which the reference pays unconditionally.
+        self.check_nan = False
 
     # mesh calculators override this to return (MeshGeometry, G); the base class has no k-space part
     def _kspace_setup(self, cell, dtype, device):
@@ -70,14 +73,21 @@ class Calculator(torch.nn.Module):
             raise NotImplementedError("Batching not implemented for mesh-based calculators")
         geom, G = self._kspace_setup(cell, positions.dtype, positions.device)
         slab_axis = None
-        if has_kspace and periodic is not None and pot_desc.kind == _lib.COULOMB or (
-            has_kspace and periodic is not None and pot_desc.exponent == 1
-        ):
+        is_coulombic = pot_desc.kind == _lib.COULOMB or pot_desc.exponent == 1  # the slab term exists for 1/r only
+        if has_kspace and periodic is not None and is_coulombic:
             slab_axis = ops._slab_axis(periodic.tolist())
-        return ops.pme_potential(
+        out = ops.pme_potential(
             charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
             bool(self.full_neighbor_list), slab_axis,
         )
+        if self.check_nan and geom is not None and bool(torch.isnan(out).any()):
+            raise ValueError(
+                "NaNs detected in the k-space filter result. This are probably caused "
+                "by an unsuitable `mesh_spacing`, resulting in a problematic grid of "
+                f"shape: {[charges.shape[1], *geom.ns]}. Try adjsuting the grid by using a "
+                "different `mesh_spacing` value."
+            )
+        return out
 
 
 class PMECalculator(Calculator):
