@@ -223,6 +223,33 @@ int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, 
                                       void* grad_cell);
 int64_t mipme_rows_partials_size(int64_t n_atoms);
 
+/* ---- fused distance + pair-sum row kernels (single channel) --------------------------------------
+ * For callers whose distances come from mipme_pair_distance_forward(positions, cell, shifts): the row kernels recompute
+ * d_e = |r_other - r_a + S A| from the L2-resident positions instead of gathering dist[p] / grad_dist[p] from P-sized
+ * arrays, and apply the chain rule through d in the same pass.  Fuses Calculator._compute_rspace
+ * (calculators/calculator.py:43-87) with the caller's compute_distances (tests/helpers.py:278-304) and their adjoints.
+ *   entries_shift int32[2P][2] = { other atom, 3 x int8 cell shift } from mipme_topology_pack_entries
+ *                 (shifts == NULL -> zero shifts; flag[0] != 0 -> some shift is not an integer in [-127,127]: unusable).
+ *   out   (N) nullable: out[a] (+)= 1/2 sum_{potential roles} src[o] v_SR(d_e)          (transpose as mipme_rspace_rows)
+ *   force (N,3) nullable, OVERWRITTEN: sum_e sign_e w_e v_SR'(d_e) vec_e / d_e with
+ *         w_e = charges[o] when grad_out == NULL (finish with mipme_sr_rows_finalize: energy mode, g = gE * charges),
+ *         otherwise the general weights 1/2 (g[a] q[o] + g[o] q[a]) (half list) -- force is then d L / d positions.
+ *   records: device scratch of 4 * N reals (16-byte aligned); holds (x, y, z, src) per atom so that one gather per entry
+ *         fetches the partner atom.
+ *   partials nullable: float64[mipme_rows_partials_size(N)] per-block sums of the cell gradient; with grad_out != NULL
+ *         and grad_cell != NULL they are reduced into grad_cell (3,3). */
+int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
+                                void* entries_shift, void* flag);
+int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
+                        const void* entries, const void* pair_mask, const void* positions, const void* cell,
+                        const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
+                        const mipme_potential_t* pot, int accumulate, void* records, void* out, void* force,
+                        void* partials, void* grad_cell);
+/* grad_positions[a] = f gE charges[a] force[a]; grad_cell = f gE sum(partials); f = 1/2 for a full list, gE = grad_scale[0]. */
+int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* charges,
+                           const void* grad_scale, int full_list, const void* partials, void* grad_positions,
+                           void* grad_cell);
+
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
  * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------
  * Scope: fully periodic cells with >= 3 cells of perpendicular width >= cutoff per axis (n_cells[d] = floor(width_d /

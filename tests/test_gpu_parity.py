@@ -370,3 +370,91 @@ def test_energy_fast_path(golden_dir, fast, mesh_mode, name, monkeypatch):
     assert abs(E.item() - float(z[f"{name}/f64/energy"])) < 1e-11 * abs(E.item())
     assert rell2(pos.grad.cpu(), -1.7 * z[f"{name}/f64/grad_positions"]) < 1e-10
     assert rell2(q.grad.cpu(), -1.7 * z[f"{name}/f64/grad_charges"]) < 1e-10
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("energy", [True, False])
+@pytest.mark.parametrize("potential", ["coulomb", "excl", "p6"])
+def test_fused_distances(fuse, full, energy, potential, monkeypatch):
+    """Distances from ``pair_distances`` let the calculator recompute d in its row kernels and differentiate straight
+    through to positions / cell (ops.FUSE_DISTANCES): same potentials and gradients as the unfused path and the
+    oracle -- half and full lists, pair mask, triclinic cell with several images per pair, energy mode (speculative
+    force sums finished by the finalize kernel) and an arbitrary upstream gradient, Coulomb / exclusion / 1/r^6."""
+    from torchpme_amd import ops
+
+    monkeypatch.setattr(ops, "FUSE_DISTANCES", fuse)
+    rng = np.random.default_rng(11)
+    cell = np.array([[7.0, 0, 0], [0.7, 6.0, 0], [0.2, -0.5, 8.0]])
+    N = 170
+    pos = rng.uniform(-1, 8, (N, 3))
+    q = rng.normal(size=(N, 1))
+    rc, sm, h = 5.0, 1.1, 0.9
+    pairs, S, dist = tpa.neighbor_list(pos, cell, rc, full_list=full)
+    mask = rng.uniform(size=len(pairs)) > 0.2
+    if potential == "coulomb":
+        spec, pot = O.PotentialSpec("coulomb", 1, sm, 0.7), tpa.CoulombPotential(smearing=sm, prefactor=0.7)
+    elif potential == "excl":
+        spec = O.PotentialSpec("coulomb", 1, sm, 1.0, exclusion_radius=2.5, exclusion_degree=2)
+        pot = tpa.CoulombPotential(smearing=sm, exclusion_radius=2.5, exclusion_degree=2)
+    else:
+        spec, pot = O.PotentialSpec("ipl", 6, sm, 1.0), tpa.InversePowerLawPotential(exponent=6, smearing=sm)
+    gE = -1.3
+    g = gE * q if energy else rng.normal(size=(N, 1))
+    Vo, cache = O.forward(spec, "P3M", 4, h, q, cell, pos, pairs, dist, full_list=full, pair_mask=mask, return_cache=True)
+    gr = O.backward(cache, g)
+    gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    calc = tpa.P3MCalculator(pot, mesh_spacing=h, interpolation_nodes=4, full_neighbor_list=full)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=torch.float64, requires_grad=grad)  # noqa: E731
+    tq, tc, tp = t(q, not energy), t(cell, True), t(pos, True)
+    ti = torch.tensor(pairs, device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, torch.tensor(S, device=DEV))
+    calls = {}
+    monkeypatch.setattr(ops, "PROFILE", calls)
+    V = calc(tq, tc, tp, ti, d, pair_mask=torch.tensor(mask, device=DEV))
+    if energy:
+        (gE * tpa.weighted_sum(V, tq)).backward()
+    else:
+        (V * t(g)).sum().backward()
+    monkeypatch.setattr(ops, "PROFILE", None)
+    assert ("pair_distance_backward" in calls) == (not fuse)  # the fused path never touches dL/dd
+    assert rell2(V.detach().cpu(), Vo) < 1e-11
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    assert relmax(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+    if not energy:
+        assert rell2(tq.grad.cpu(), gr["charges"]) < 1e-11
+
+
+def test_fused_distances_guards():
+    """The fused path is taken only while the distance tensor is the untouched output of pair_distances for the same
+    pair list; anything else (modified d, other list, leaf d, non-integer shifts, several channels) falls back."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(3)
+    cell = np.eye(3) * 6.0
+    pos = rng.uniform(0, 6, (60, 3))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 2.9)
+    tp = torch.tensor(pos, device=DEV, requires_grad=True)
+    tc = torch.tensor(cell, device=DEV)
+    ti = torch.tensor(pairs, device=DEV)
+    tS = torch.tensor(S, device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    src = d._mipme_src
+    assert src.usable_for(d, ti, 1) and not src.usable_for(d, ti, 2) and not src.usable_for(d, ti.clone(), 1)
+    assert not src.usable_for(d.detach(), ti, 1)
+    d2 = tpa.pair_distances(tp, ti, tc, tS)
+    d2.mul_(1.0)  # in-place edit bumps the version: provenance void
+    assert not d2._mipme_src.usable_for(d2, ti, 1)
+    # non-integer shifts cannot be packed: silently unfused, same numbers
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.8)
+    q = torch.tensor(rng.normal(size=(60, 1)), device=DEV)
+    Sf = tS.to(torch.float64) + 0.25
+    outs = []
+    for fuse in (True, False):
+        ops.FUSE_DISTANCES = fuse
+        try:
+            dd = tpa.pair_distances(tp, ti, tc, Sf)
+            outs.append(calc(q, tc, tp, ti, dd))
+        finally:
+            ops.FUSE_DISTANCES = True
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-12, atol=1e-12)

@@ -30,6 +30,7 @@ EXPORTS = (
     "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
     "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
+    "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
 )
 
 
@@ -104,6 +105,9 @@ def _declare(lib):
         "mipme_topology_pack_shifts": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_rspace_rows": [vp, ci, i64, ci, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp],
         "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_topology_pack_entries": [vp, ci, i64, vp, vp, vp, vp],
+        "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp, vp, vp, vp, vp],
+        "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, ci, vp, vp, vp],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],

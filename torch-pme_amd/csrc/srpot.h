@@ -61,6 +61,20 @@ __device__ __forceinline__ float erfc_from_exp(float y, float e) {
   return e * t * p;
 }
 __device__ __forceinline__ double erfc_from_exp(double y, double) { return erfc(y); }
+// same fit with the hardware reciprocal (1 ulp) for t
+__device__ __forceinline__ float erfc_from_exp_fast(float y, float e) {
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.4f * y);
+  float p = 2.646481385e-02f;
+  p = p * t + -6.557867191e-02f;
+  p = p * t + -7.738398321e-02f;
+  p = p * t + 2.820383187e-01f;
+  p = p * t + -6.220284696e-02f;
+  p = p * t + 2.579626189e-01f;
+  p = p * t + 1.840778096e-01f;
+  p = p * t + 2.291638826e-01f;
+  p = p * t + 2.254580744e-01f;
+  return e * t * p;
+}
 
 template <typename T>
 __device__ __forceinline__ T powi(T x, int n) {
@@ -144,6 +158,45 @@ __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
       dv = -(dvl * fc + vl * dfc);
     }
   }
+}
+
+// Fast path of the fused row kernels for the smeared Coulomb potential without exclusion (mode 1, p = 1):
+//   v = pref erfc(y)/d,  (dv/dd) / d = -pref (erfc(y) + c2 d e^{-y^2}) / d^3,   y = c1 d, c1 = 1/(sigma sqrt 2), c2 = 2 c1/sqrt(pi)
+// from d^2.  The float version uses the hardware rsq / rcp / exp2 (1 ulp each) instead of IEEE division sequences and
+// libm range reduction: the generic sr_eval costs ~190 VALU slots per pair, which made the fused kernels VALU-bound.
+struct CoulombFast {
+  double c1, c2, pref;
+};
+inline CoulombFast make_coulomb_fast(const SRPot& s) {
+  CoulombFast c;
+  c.c1 = sqrt(s.inv_2s2);
+  c.c2 = 2.0 * c.c1 / sqrt(kPiR);
+  c.pref = s.pref;
+  return c;
+}
+inline bool is_coulomb_fast(const SRPot& s) { return s.mode == 1 && s.p == 1; }
+
+template <bool DERIV>
+__device__ __forceinline__ void coulomb_fast_eval(float c1, float c2, float pref, float d2, float& v, float& sc) {
+  d2 = fmaxf(d2, 1e-30f);
+  const float inv = __builtin_amdgcn_rsqf(d2);
+  const float d = d2 * inv;
+  const float y = c1 * d;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (y * y));
+  const float er = erfc_from_exp_fast(y, e);
+  const float pi = pref * inv;
+  v = pi * er;
+  if constexpr (DERIV) sc = -(pi * inv * inv) * (er + c2 * d * e);
+}
+template <bool DERIV>
+__device__ __forceinline__ void coulomb_fast_eval(double c1, double c2, double pref, double d2, double& v, double& sc) {
+  d2 = fmax(d2, 1e-30);
+  const double d = sqrt(d2);
+  const double inv = 1.0 / d;
+  const double y = c1 * d;
+  const double er = erfc(y);
+  v = pref * er * inv;
+  if constexpr (DERIV) sc = -(pref * inv * inv * inv) * (er + c2 * d * exp(-y * y));
 }
 
 }  // namespace mipme

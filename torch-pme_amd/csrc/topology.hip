@@ -118,6 +118,29 @@ __global__ void topo_pack_shifts_kernel(int64_t E, const int2* __restrict__ entr
   if (bad) atomicOr(flag, 1);
 }
 
+
+// Entry stream of the fused kernels: int2 {other atom, 3 x int8 cell shift} per entry (shifts == NULL -> zero shifts).
+template <typename T>
+__global__ void topo_pack_entries_kernel(int64_t E, const int2* __restrict__ entries, const T* __restrict__ shifts,
+                                         int2* __restrict__ ent_sh, int* __restrict__ flag) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int2 en = entries[e];
+  int word = 0;
+  bool bad = false;
+  if (shifts) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const T sh = shifts[3 * int64_t(en.y) + k];
+      const T r = rint(sh);
+      bad |= (r != sh) || (r > T(127)) || (r < T(-127));
+      word |= (int(r) & 0xff) << (8 * k);
+    }
+  }
+  ent_sh[e] = make_int2(en.x, word);
+  if (bad) atomicOr(flag, 1);
+}
+
 // ---- owner-computes pair kernels ---------------------------------------------------------------
 #ifndef MIPME_ROW_UNROLL
 #define MIPME_ROW_UNROLL 4
@@ -337,6 +360,232 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
   }
 }
 
+
+// ---- fused distance + pair-sum row kernels ------------------------------------------------------------------------
+// When the distances handed to the calculator were produced by mipme_pair_distance_forward from (positions, cell,
+// shifts), the row kernels can recompute d_e = |r_o - r_a + S A| from the L2-resident positions (one gather per entry)
+// instead of gathering d[p] (and, backward, grad_d[p] and the shifts) at random from P-sized arrays, and the chain rule
+// through d is applied in the same kernel:
+//   POT    out[a] (+)= 1/2 sum_{e in potential roles} src[o] v_SR(d_e)
+//   FORCE  F[a]    = sum_{all e} sign_e w_e v_SR'(d_e) vec_e / d_e        (sign: -1 role i, +1 role j)
+//          w_e = q[o]                                   if g == NULL  (caller multiplies by gE q[a] f: energy mode)
+//              = 1/2 (g[a] q[o] + g[o] q[a])            half list
+//              = 1/2 g[a] q[o] (role i), 1/2 g[o] q[a] (role j)   full list
+//   CELLGRAD partial sums of sum_{role-i e} (q[a] if g == NULL) w_e v' / d  S_e^T vec_e  per block (fp64)
+// (x, y, z, w) per atom, 16-byte aligned: one gather per entry fetches the partner's position and charge (or source value)
+template <typename T>
+struct alignas(4 * sizeof(T)) AtomRecord {
+  T x, y, z, w;
+};
+
+template <typename T>
+__global__ void pack_atom_records_kernel(int64_t N, const T* __restrict__ pos, const T* __restrict__ w,
+                                         AtomRecord<T>* __restrict__ rec) {
+  const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  AtomRecord<T> r;
+  r.x = pos[3 * a];
+  r.y = pos[3 * a + 1];
+  r.z = pos[3 * a + 2];
+  r.w = w[a];
+  rec[a] = r;
+}
+
+enum FusedMode {
+  kPot = 0,       // potentials from src
+  kPotForce = 1,  // potentials from charges + speculative force sums (w_e = q[o])
+  kForceQ = 2,    // force sums with w_e = q[o] (energy mode, finished by the finalize kernel)
+  kForceG = 3,    // force sums with the general weights built from g and q
+};
+
+template <typename T, int MODE, bool CELLGRAD, bool CFAST, bool MASK>
+__global__ __launch_bounds__(256) void sr_fused_rows_kernel(
+    SRPot s, CoulombFast cf, int64_t N, const int* __restrict__ row_ptr, const int2* __restrict__ ent_sh,
+    const int2* __restrict__ entries, const uint8_t* __restrict__ mask, const T* __restrict__ pos,
+    const AtomRecord<T>* __restrict__ rec, const T* __restrict__ cell, const T* __restrict__ q,
+    const T* __restrict__ g, int pot_lo, int pot_hi, bool full, bool accumulate, T* __restrict__ out,
+    T* __restrict__ force, double* __restrict__ partials) {
+  // rec[o] = (position of o, src[o]) with src = charges except in the transposed potential pass
+  constexpr int U = kRowUnroll;
+  constexpr bool POT = MODE == kPot || MODE == kPotForce;
+  constexpr bool FORCE = MODE != kPot;
+  T A[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
+  const T c1 = T(cf.c1), c2 = T(cf.c2), cpref = T(cf.pref);
+  const int sub = threadIdx.x % kRowLanes;
+  unsigned a = blockIdx.x * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = unsigned(N - 1);
+  const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
+  const int pbeg = pot_lo == 0 ? r0 : mid, pend = pot_hi == 0 ? mid : r2;  // entries that feed the potential
+  const int beg = FORCE ? r0 : pbeg;
+  const int end = valid ? (FORCE ? r2 : pend) : beg;
+  const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+  T qa = T(0), ga = T(0);
+  if constexpr (FORCE) qa = q[a];
+  if constexpr (MODE == kForceG) ga = g[a];
+  // general weights: half list 1/2 (g_a q_o + g_o q_a); full list keeps the first term for role i, the second for role j
+  const T keep_i = T(0.5), keep_j_of_i = full ? T(0) : T(0.5);
+  T pot = T(0), fx = T(0), fy = T(0), fz = T(0);
+  double cg[9];
+  if constexpr (CELLGRAD) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cg[k] = 0.0;
+  }
+  int2 en_next[U];
+  int pm_next[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = beg + u * kRowLanes + sub;
+    const int ec = e < end ? e : beg;
+    en_next[u] = ent_sh[ec];
+    if constexpr (MASK) pm_next[u] = entries[ec].y;
+  }
+  for (int base = beg; base < end; base += kRowLanes * U) {
+    int2 en[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = base + u * kRowLanes + sub < end;
+      en[u] = en_next[u];
+    }
+    T ox[U], oy[U], oz[U], so[U], go[U];
+    uint8_t mk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = en[u].x;
+      const AtomRecord<T> r = rec[o];
+      ox[u] = r.x;
+      oy[u] = r.y;
+      oz[u] = r.z;
+      so[u] = r.w;
+      if constexpr (MODE == kForceG) go[u] = g[o];
+      if constexpr (MASK) mk[u] = mask[pm_next[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + kRowLanes * U + u * kRowLanes + sub;
+      const int ec = e < end ? e : beg;
+      en_next[u] = ent_sh[ec];
+      if constexpr (MASK) pm_next[u] = entries[ec].y;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * kRowLanes + sub;
+      const bool role_i = e < mid;
+      bool use = ok[u];
+      if constexpr (MASK) use = use && mk[u] != 0;
+      const T sign = role_i ? T(-1) : T(1);
+      const T sx = T(unpack8(en[u].y, 0)), sy = T(unpack8(en[u].y, 1)), sz = T(unpack8(en[u].y, 2));
+      // vec = r_j - r_i + S A: role i -> (r_o - r_a) + S A ; role j -> (r_a - r_o) + S A
+      const T vx = -sign * (ox[u] - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
+      const T vy = -sign * (oy[u] - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
+      const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
+      const T d2 = vx * vx + vy * vy + vz * vz;
+      T v, dvd;  // v_SR(d) and v_SR'(d) / d
+      if constexpr (CFAST) {
+        coulomb_fast_eval<FORCE>(c1, c2, cpref, d2, v, dvd);
+      } else {
+        const T d = fsqrt(d2);
+        T dv;
+        sr_eval<T, FORCE>(s, d, v, dv);
+        dvd = dv / d;
+      }
+      const T sv = use ? so[u] : T(0);  // masked / padding entries carry zero weight
+      if constexpr (POT) {
+        const bool in_pot = MODE == kPot || (e >= pbeg && e < pend);
+        pot += (in_pot ? sv : T(0)) * v;
+      }
+      if constexpr (FORCE) {
+        T w;
+        if constexpr (MODE == kForceG) {
+          const T gq = role_i ? keep_i * ga * sv + keep_j_of_i * go[u] * qa : keep_j_of_i * ga * sv + keep_i * go[u] * qa;
+          w = use ? gq : T(0);
+        } else {
+          w = sv;
+        }
+        const T sc = w * dvd;
+        fx += sign * sc * vx;
+        fy += sign * sc * vy;
+        fz += sign * sc * vz;
+        if constexpr (CELLGRAD) {
+          if (role_i) {
+            const double wq = MODE == kForceG ? 1.0 : double(qa);
+            const double px = wq * double(sc * vx), py = wq * double(sc * vy), pz = wq * double(sc * vz);
+            cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
+            cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
+            cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (POT) {
+    pot = row_sum(pot);
+    if (sub == 0 && valid) out[a] = (accumulate ? out[a] : T(0)) + T(0.5) * pot;
+  }
+  if constexpr (FORCE) {
+    fx = row_sum(fx);
+    fy = row_sum(fy);
+    fz = row_sum(fz);
+    if (sub == 0 && valid) {
+      force[3 * a] = fx;
+      force[3 * a + 1] = fy;
+      force[3 * a + 2] = fz;
+    }
+  }
+  if constexpr (CELLGRAD) {
+    __shared__ double red[4][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double v = wave_sum(cg[k]);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += red[w][threadIdx.x];
+      partials[int64_t(blockIdx.x) * 9 + threadIdx.x] = v;
+    }
+  }
+}
+
+// energy mode: grad_pos[a] = f gE q[a] F[a], grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list)
+template <typename T>
+__global__ void sr_fused_finalize_kernel(int64_t N, const T* __restrict__ force, const T* __restrict__ q,
+                                         const T* __restrict__ gscale, T f, int64_t nblocks,
+                                         const double* __restrict__ partials, T* __restrict__ grad_pos,
+                                         T* __restrict__ grad_cell) {
+  const T sc = f * gscale[0];
+  if (grad_pos) {
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < 3 * N; t += int64_t(gridDim.x) * blockDim.x)
+      grad_pos[t] = sc * q[t / 3] * force[t];
+  }
+  if (grad_cell && blockIdx.x == 0) {
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[k] += partials[b * 9 + k];
+    __shared__ double red[4][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double v = wave_sum(acc[k]);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+      double v = 0.0;
+      for (int w = 0; w < int(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];
+      grad_cell[threadIdx.x] = T(double(sc) * v);
+    }
+  }
+}
+
 template <typename T>
 __global__ void reduce9_rows_kernel(int64_t nblocks, const double* __restrict__ partials, T* __restrict__ out) {
   double acc[9];
@@ -402,6 +651,100 @@ static int distance_backward_rows_impl(hipStream_t st, int64_t N, const void* ro
         N, (const int*)row_ptr, (const int2*)entries, (const int*)packed, (const T*)pos, (const T*)cell,
         (const T*)shifts, (const T*)grad_d, (T*)grad_pos, nullptr);
   }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+
+template <typename T>
+static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, const void* ent_sh, const void* entries,
+                              const void* mask, const void* pos, const void* cell, const void* q, const void* src,
+                              const void* g, int transpose, int full_list, const mipme_potential_t* pot, int accumulate,
+                              void* records, void* out, void* force, void* partials, void* grad_cell) {
+  SRPot s;
+  int rc = make_srpot(pot, s);
+  if (rc) return rc;
+  if (N == 0) {
+    if (grad_cell) MIPME_CHECK_HIP(zero_async(grad_cell, sizeof(T) * 9, st));
+    return MIPME_OK;
+  }
+  int lo = 0, hi = 1;
+  if (full_list) lo = hi = transpose ? 1 : 0;
+  const unsigned grid = row_blocks(N);
+  const CoulombFast cf = make_coulomb_fast(s);
+  const bool cfast = is_coulomb_fast(s);
+  pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
+      N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
+  MIPME_LAUNCH_CHECK();
+  const bool want_pot = out != nullptr, want_force = force != nullptr, want_cg = partials != nullptr;
+  int mode;
+  if (want_pot && !want_force)
+    mode = kPot;
+  else if (want_pot && want_force) {
+    MIPME_REQUIRE(src == q && !g, "potential + force sums are computed together only for src == charges, grad_out == NULL");
+    mode = kPotForce;
+  } else if (want_force)
+    mode = g ? kForceG : kForceQ;
+  else {
+    set_error("mipme_sr_rows_fused: nothing to compute");
+    return MIPME_EINVAL;
+  }
+#define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK)                                                                         \
+  sr_fused_rows_kernel<T, MODE, CG, CF, MK><<<grid, 256, 0, st>>>(                                                    \
+      s, cf, N, (const int*)row_ptr, (const int2*)ent_sh, (const int2*)entries, (const uint8_t*)mask, (const T*)pos,  \
+      (const AtomRecord<T>*)records, (const T*)cell, (const T*)q, (const T*)g, lo, hi, full_list != 0,                \
+      accumulate != 0, (T*)out, (T*)force, (double*)partials)
+#define MIPME_FUSED_MK(MODE, CG, CF)                                                                                  \
+  do {                                                                                                                \
+    if (mask)                                                                                                         \
+      MIPME_FUSED_LAUNCH_(MODE, CG, CF, true);                                                                        \
+    else                                                                                                              \
+      MIPME_FUSED_LAUNCH_(MODE, CG, CF, false);                                                                       \
+  } while (0)
+#define MIPME_FUSED_CF(MODE, CG)                                                                                      \
+  do {                                                                                                                \
+    if (cfast)                                                                                                        \
+      MIPME_FUSED_MK(MODE, CG, true);                                                                                 \
+    else                                                                                                              \
+      MIPME_FUSED_MK(MODE, CG, false);                                                                                \
+  } while (0)
+#define MIPME_FUSED_CG(MODE)                                                                                          \
+  do {                                                                                                                \
+    if (want_cg)                                                                                                      \
+      MIPME_FUSED_CF(MODE, true);                                                                                     \
+    else                                                                                                              \
+      MIPME_FUSED_CF(MODE, false);                                                                                    \
+  } while (0)
+  switch (mode) {
+    case kPot: MIPME_FUSED_CF(kPot, false); break;
+    case kPotForce: MIPME_FUSED_CG(kPotForce); break;
+    case kForceQ: MIPME_FUSED_CG(kForceQ); break;
+    default: MIPME_FUSED_CG(kForceG); break;
+  }
+#undef MIPME_FUSED_CG
+#undef MIPME_FUSED_CF
+#undef MIPME_FUSED_MK
+#undef MIPME_FUSED_LAUNCH_
+  MIPME_LAUNCH_CHECK();
+  if (grad_cell) {
+    reduce9_rows_kernel<T><<<1, 1024, 0, st>>>(int64_t(grid), (const double*)partials, (T*)grad_cell);
+    MIPME_LAUNCH_CHECK();
+  }
+  return MIPME_OK;
+}
+
+template <typename T>
+static int sr_fused_finalize_impl(hipStream_t st, int64_t N, const void* force, const void* q, const void* gscale,
+                                  int full_list, const void* partials, void* grad_pos, void* grad_cell) {
+  if (N == 0) {
+    if (grad_cell) MIPME_CHECK_HIP(zero_async(grad_cell, sizeof(T) * 9, st));
+    return MIPME_OK;
+  }
+  const int64_t want = (3 * N + 255) / 256;
+  const unsigned grid = unsigned(want < 2048 ? want : 2048);
+  sr_fused_finalize_kernel<T><<<grid, 256, 0, st>>>(N, (const T*)force, (const T*)q, (const T*)gscale,
+                                                    full_list ? T(0.5) : T(1), int64_t(row_blocks(N)),
+                                                    (const double*)partials, (T*)grad_pos, (T*)grad_cell);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -486,6 +829,66 @@ int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, 
   if (dtype == MIPME_F64)
     return distance_backward_rows_impl<double>(st, n_atoms, row_ptr, entries, packed_shifts, positions, cell, shifts,
                                                grad_dist, partials, grad_positions, grad_cell);
+  set_error("invalid dtype %d", dtype);
+  return MIPME_EINVAL;
+}
+
+int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
+                                void* entries_shift, void* flag) {
+  MIPME_REQUIRE(n_pairs >= 0 && flag, "invalid arguments to mipme_topology_pack_entries");
+  hipStream_t st = (hipStream_t)stream;
+  MIPME_CHECK_HIP(zero_async(flag, sizeof(int), st));
+  const int64_t E = 2 * n_pairs;
+  if (E == 0) return MIPME_OK;
+  MIPME_REQUIRE(entries && entries_shift, "NULL buffer passed to mipme_topology_pack_entries");
+  const unsigned grid = unsigned((E + 255) / 256);
+  if (dtype == MIPME_F32)
+    topo_pack_entries_kernel<float><<<grid, 256, 0, st>>>(E, (const int2*)entries, (const float*)shifts,
+                                                          (int2*)entries_shift, (int*)flag);
+  else if (dtype == MIPME_F64)
+    topo_pack_entries_kernel<double><<<grid, 256, 0, st>>>(E, (const int2*)entries, (const double*)shifts,
+                                                           (int2*)entries_shift, (int*)flag);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
+                        const void* entries, const void* pair_mask, const void* positions, const void* cell,
+                        const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
+                        const mipme_potential_t* pot, int accumulate, void* records, void* out, void* force,
+                        void* partials, void* grad_cell) {
+  MIPME_REQUIRE(n_atoms >= 0 && row_ptr, "invalid arguments to mipme_sr_rows_fused");
+  MIPME_REQUIRE(n_atoms == 0 || (entries_shift && positions && charges && records), "NULL buffer passed to mipme_sr_rows_fused");
+  MIPME_REQUIRE(!pair_mask || entries, "`pair_mask` needs the (other, pair) entry table");
+  MIPME_REQUIRE(!out || src, "`src` is required for the potential sum");
+  MIPME_REQUIRE(!partials || force, "cell partial sums are produced together with the force sums");
+  MIPME_REQUIRE(!grad_cell || (partials && grad_out), "grad_cell needs partials and an explicit upstream gradient");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    return sr_fused_rows_impl<float>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
+                                     src, grad_out, transpose, full_list, pot, accumulate, records, out, force, partials, grad_cell);
+  if (dtype == MIPME_F64)
+    return sr_fused_rows_impl<double>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
+                                      src, grad_out, transpose, full_list, pot, accumulate, records, out, force, partials, grad_cell);
+  set_error("invalid dtype %d", dtype);
+  return MIPME_EINVAL;
+}
+
+int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* charges,
+                           const void* grad_scale, int full_list, const void* partials, void* grad_positions,
+                           void* grad_cell) {
+  MIPME_REQUIRE(n_atoms >= 0 && grad_scale, "invalid arguments to mipme_sr_rows_finalize");
+  MIPME_REQUIRE(n_atoms == 0 || !grad_positions || (force && charges), "NULL buffer passed to mipme_sr_rows_finalize");
+  MIPME_REQUIRE(!grad_cell || partials, "grad_cell needs the partial sums of mipme_sr_rows_fused");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    return sr_fused_finalize_impl<float>(st, n_atoms, force, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
+  if (dtype == MIPME_F64)
+    return sr_fused_finalize_impl<double>(st, n_atoms, force, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
 }

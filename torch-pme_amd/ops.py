@@ -113,6 +113,14 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
 
 
+# When ``neighbor_distances`` is the untouched output of :func:`pair_distances`, the calculator differentiates straight through
+# to the positions / cell the distances were built from: the row kernels recompute d from the L2-resident positions (one
+# gather per entry instead of random reads of P-sized arrays) and neither ``d`` nor ``dL/dd`` is read or written by the
+# calculator.  The gradient then reaches ``positions`` directly, NOT via ``neighbor_distances`` -- set to 0 if you need
+# ``torch.autograd.grad(E, neighbor_distances)`` for such a tensor (a leaf ``neighbor_distances`` is never fused).
+FUSE_DISTANCES = os.environ.get("MIPME_FUSE_DISTANCES", "1") != "0"
+
+
 # The bandwidth-bound pair kernels and the latency-bound mesh kernels of one evaluation are independent until
 # the final sum, so they run concurrently: pair work on a per-device side stream, mesh work on the caller's stream,
 # joined with HIP events (SURVEY.md 7 "hard part 2": at 32k atoms the step is launch/latency limited).
@@ -141,6 +149,7 @@ class PairTopology:
         self.row_ptr = torch.empty((2 * n_atoms + 1,), dtype=torch.int32, device=device)
         self.entries = torch.empty((max(2 * P, 1), 2), dtype=torch.int32, device=device)
         self._packed = None  # (weakref(shifts), version, tensor|None)
+        self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
         with torch.cuda.device(device):
@@ -178,6 +187,51 @@ class PairTopology:
         return packed
 
 
+    def entries_with_shifts(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None):
+        """int32 (2P, 2) table {other atom, 3 x int8 cell shift} for the fused kernels, or None if the shifts are not small
+        integers.  Cached per shifts tensor like :meth:`packed_shifts`."""
+        key = shifts if key is None else key
+        c = self._ent_sh
+        if c is not None and ((key is None and c[0] is None) or (key is not None and c[0] is not None and c[0]() is key
+                                                                   and c[1] == key._version)):
+            return c[2]
+        lib = _lib.load()
+        device = self.entries.device
+        ent_sh = torch.empty((max(2 * self.n_pairs, 1), 2), dtype=torch.int32, device=device)
+        flag = torch.empty((1,), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(
+                lib.mipme_topology_pack_entries(
+                    _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
+                    self.n_pairs, self.entries.data_ptr(), _lib.ptr(shifts), ent_sh.data_ptr(), flag.data_ptr(),
+                )
+            )
+        if shifts is not None and int(flag.item()) != 0:
+            ent_sh = None
+        self._ent_sh = (None if key is None else weakref.ref(key), 0 if key is None else key._version, ent_sh)
+        return ent_sh
+
+
+class DistanceSource:
+    """Provenance of a distance tensor made by :func:`pair_distances` (attached to it as ``_mipme_src``)."""
+
+    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref")
+
+    def __init__(self, positions, cell, pairs, shifts, shifts_key, dist):
+        self.positions, self.cell, self.pairs, self.shifts, self.shifts_key = positions, cell, pairs, shifts, shifts_key
+        self.versions = (positions._version, None if cell is None else cell._version, pairs._version, dist._version)
+        self.dist_ref = weakref.ref(dist)
+
+    def usable_for(self, dist, pairs, n_channels) -> bool:
+        """True if ``dist`` still equals ``|r_j - r_i + S cell|`` of the recorded tensors and ``pairs`` is the same list."""
+        if not FUSE_DISTANCES or PAIR_MODE != "rows" or n_channels != 1:
+            return False
+        if self.dist_ref() is not dist or pairs is not self.pairs or dist.retains_grad:
+            return False
+        now = (self.positions._version, None if self.cell is None else self.cell._version, pairs._version, dist._version)
+        return now == self.versions and dist.dtype == self.positions.dtype and dist.device == self.positions.device
+
+
 _TOPOLOGIES: "OrderedDict" = OrderedDict()
 
 
@@ -210,7 +264,7 @@ class _PMEFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G, pot_desc,
-                full_list, slab_axis):
+                full_list, slab_axis, src_positions=None, src_cell=None, src=None):
         lib = _lib.load()
         device, dtype = positions.device, positions.dtype
         dt = _lib.dtype_code(dtype)
@@ -227,10 +281,33 @@ class _PMEFunction(torch.autograd.Function):
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
             topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
+            fused = None
+            if src is not None:
+                ent_sh = topo.entries_with_shifts(src.shifts, src.shifts_key)
+                if ent_sh is not None:
+                    fused = dict(
+                        ent_sh=ent_sh, pos=src_positions.detach().contiguous(),
+                        cell=None if src_cell is None else src_cell.detach().contiguous(), force=None, partials=None,
+                        records=torch.empty((N, 4), dtype=dtype, device=device),
+                    )
+                    # speculative force sums: if the backward turns out to be in energy mode they ARE the SR forces
+                    if ENERGY_FAST_PATH and ctx.needs_input_grad[11]:
+                        fused["force"] = torch.empty((N, 3), dtype=dtype, device=device)
+                        if src_cell is not None and ctx.needs_input_grad[12]:
+                            fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64,
+                                                            device=device)
 
             def run_rspace(accumulate):
                 stream = _lib.current_stream(device)
-                if topo is not None:
+                if fused is not None:
+                    _call(
+                        "rspace_forward", lib.mipme_sr_rows_fused,
+                        stream, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
+                        _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), q.data_ptr(), None,
+                        0, int(full_list), C.byref(pot_desc), accumulate, fused["records"].data_ptr(), out.data_ptr(),
+                        _lib.ptr(fused["force"]), _lib.ptr(fused["partials"]), None,
+                    )
+                elif topo is not None:
                     _call(
                         "rspace_forward", lib.mipme_rspace_rows,
                         stream, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(),
@@ -291,6 +368,7 @@ class _PMEFunction(torch.autograd.Function):
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")))
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
+        ctx.fused = fused  # plain tensors made here, none of them an input or output of this node
         return out
 
     @staticmethod
@@ -300,6 +378,10 @@ class _PMEFunction(torch.autograd.Function):
         q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins = ctx.saved_tensors
         geom, pot_desc = ctx.geom, ctx.pot_desc
         need_q, need_cell, need_pos, need_dist = ctx.needs_input_grad[:4]
+        fused = ctx.fused
+        need_src_pos = fused is not None and ctx.needs_input_grad[11]
+        need_src_cell = fused is not None and fused["cell"] is not None and ctx.needs_input_grad[12]
+        grad_src_pos = grad_src_cell = None
         device, dtype = pos.device, pos.dtype
         dt = _lib.dtype_code(dtype)
         N, Cn = q.shape
@@ -313,10 +395,11 @@ class _PMEFunction(torch.autograd.Function):
             # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
             # exactly gE * charges, and the adjoint mesh is a multiple of the forward one (no second spread / FFT).
             tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
-            gscale = None
-            if (tag is not None and not need_cell and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape)
-                    and tag[2] == q._version and ctx.slab_axis is None):
-                gscale = tag[3]
+            gscale = sr_scale = None
+            if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
+                sr_scale = tag[3]  # g == gE * charges: enough for the pair part
+                if not need_cell and ctx.slab_axis is None:
+                    gscale = tag[3]
             if need_dist:
                 grad_dist = torch.empty((P,), dtype=dtype, device=device)
 
@@ -327,7 +410,7 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward", lib.mipme_rspace_backward,
                     _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
                     dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(),
-                    _lib.ptr(gscale), _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
+                    _lib.ptr(sr_scale), _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
                 )
 
             overlap = OVERLAP and topo is not None and do_kspace and need_dist
@@ -391,7 +474,40 @@ class _PMEFunction(torch.autograd.Function):
                 torch.cuda.current_stream(device).wait_event(join)
             elif need_dist or (need_q and topo is None):
                 run_grad_dist(need_q and topo is None)
-            if need_q and topo is not None:
+            if need_src_pos or need_src_cell:
+                grad_src_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                if need_src_cell:
+                    grad_src_cell = torch.empty((3, 3), dtype=dtype, device=device)
+                have_cell_sums = fused["partials"] is not None or not need_src_cell
+                if sr_scale is not None and fused["force"] is not None and have_cell_sums:
+                    # energy mode: the forward pass already holds sum_e sign q_o v' vec/d per atom
+                    _call(
+                        "rspace_backward", lib.mipme_sr_rows_finalize,
+                        st, dt, N, fused["force"].data_ptr(), q.data_ptr(), sr_scale.data_ptr(), int(ctx.full_list),
+                        _lib.ptr(fused["partials"]), grad_src_pos.data_ptr(), _lib.ptr(grad_src_cell),
+                    )
+                else:
+                    partials = None
+                    if need_src_cell:
+                        partials = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
+                    _call(
+                        "rspace_backward", lib.mipme_sr_rows_fused,
+                        st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
+                        _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
+                        0, int(ctx.full_list), C.byref(pot_desc), 0, fused["records"].data_ptr(), None,
+                        grad_src_pos.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_src_cell),
+                    )
+                if not need_src_pos:
+                    grad_src_pos = None
+            if need_q and fused is not None:
+                _call(
+                    "rspace_backward_charges", lib.mipme_sr_rows_fused,
+                    st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
+                    _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), g.data_ptr(), None,
+                    1, int(ctx.full_list), C.byref(pot_desc), 1, fused["records"].data_ptr(), grad_q.data_ptr(), None, None,
+                    None,
+                )
+            elif need_q and topo is not None:
                 _call(
                     "rspace_backward_charges", lib.mipme_rspace_rows,
                     st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
@@ -402,13 +518,19 @@ class _PMEFunction(torch.autograd.Function):
                     grad_pos = torch.zeros((N, 3), dtype=dtype, device=device)
                 if need_cell:
                     grad_cell = torch.zeros((3, 3), dtype=dtype, device=device)
-        return grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None
+        return (grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None, grad_src_pos,
+                grad_src_cell, None)
 
 
 def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
                   full_list, slab_axis):
+    src = getattr(neighbor_distances, "_mipme_src", None)
+    if src is not None and src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1]):
+        # differentiate straight through to the tensors the distances were built from (see FUSE_DISTANCES)
+        return _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
+                                  G, pot_desc, full_list, slab_axis, src.positions, src.cell, src)
     return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
-                              pot_desc, full_list, slab_axis)
+                              pot_desc, full_list, slab_axis, None, None, None)
 
 
 class _PairDistances(torch.autograd.Function):
@@ -481,7 +603,13 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None)
     if cell is None and neighbor_shifts is not None:
         raise ValueError("Provided `neighbor_shifts` but no `cell`.")
     _lib.require_device(positions, "positions")
-    return _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts)
+    dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts)
+    if neighbor_shifts is None or neighbor_shifts.dtype == positions.dtype:
+        shifts_c = neighbor_shifts
+    else:
+        shifts_c = neighbor_shifts.to(positions.dtype)
+    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist)
+    return dist
 
 
 class _WeightedSum(torch.autograd.Function):
