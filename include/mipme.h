@@ -111,11 +111,15 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * gather_wait_event (hipEvent_t as void*, nullable) + accumulate_out = 1: the final gather first waits for the event
  * and then ADDS the long-range part to out_lr -- the short-range pair sum can then run concurrently on a second
  * stream, writing out_lr with accumulate = 0 and recording that event (bandwidth-bound pair kernels hide under the
- * latency-bound mesh kernels). */
+ * latency-bound mesh kernels).
+ * out_field (N,3), nullable, needs atom_bins and C == 1: field[a] = (1/V) sum_g phi(g) grad W_a(g), written by the same
+ * gather.  If the backward pass is in energy mode (g = gE * charges) the mesh force is gE q_a field[a]
+ * (mipme_sr_rows_finalize) and mipme_kspace_backward is not needed. */
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out);
+                         void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
+                         void* out_field);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
  * (In the reference this is PyTorch autograd through the ATen chain)
@@ -185,6 +189,12 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
 /* d[p] = | r[j] - r[i] + shifts[p] @ cell |.  cell: DEVICE (9 reals); shifts (P,3) reals (nullable = 0). */
 int mipme_pair_distance_forward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, const void* pairs,
                                 const void* positions, const void* cell, const void* shifts, void* out_dist);
+/* Compressed pair stream for the same op (16 instead of 28 bytes per pair in fp32): pairs32 int32 (P,2), packed_shifts
+ * int32 (P) = 3 x int8 from mipme_pack_pair_shifts (flag[0] != 0 -> some shift is not an integer in [-127,127]). */
+int mipme_pack_pair_shifts(void* stream, int dtype, int64_t n_pairs, const void* shifts, void* packed, void* flag);
+int mipme_pair_distance_forward_packed(void* stream, int dtype, int64_t n_pairs, const void* pairs32,
+                                       const void* packed_shifts, const void* positions, const void* cell,
+                                       void* out_dist);
 /* grad_positions (N,3): zeroed then accumulated.  grad_cell (9, nullable): overwritten; partials: float64 scratch
  * of >= mipme_pair_partials_size(n_pairs) elements, required when grad_cell != NULL. */
 int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms,
@@ -245,10 +255,11 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
                         const mipme_potential_t* pot, int accumulate, void* records, void* out, void* force,
                         void* partials, void* grad_cell);
-/* grad_positions[a] = f gE charges[a] force[a]; grad_cell = f gE sum(partials); f = 1/2 for a full list, gE = grad_scale[0]. */
-int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* charges,
-                           const void* grad_scale, int full_list, const void* partials, void* grad_positions,
-                           void* grad_cell);
+/* grad_positions[a] = gE charges[a] (f force[a] + field[a]); grad_cell = f gE sum(partials); f = 1/2 for a full list,
+ * gE = grad_scale[0].  force: from mipme_sr_rows_fused (nullable); field: out_field of mipme_kspace_forward (nullable). */
+int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* field,
+                           const void* charges, const void* grad_scale, int full_list, const void* partials,
+                           void* grad_positions, void* grad_cell);
 
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
  * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------

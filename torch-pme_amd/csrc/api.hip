@@ -36,6 +36,8 @@ int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
+template <typename T> int pack_pair_shifts_impl(hipStream_t, int64_t, const void*, void*, void*);
+template <typename T> int distance_forward_packed_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
 template <typename T, typename I> int distance_backward_impl(hipStream_t, int64_t, int64_t, const void*, const void*, const void*, const void*, const void*, void*, void*, void*);
 int64_t pair_partials_blocks(int64_t);
 
@@ -46,7 +48,7 @@ bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
-template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
@@ -106,7 +108,7 @@ template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
-                            void* wait_event, int accumulate) {
+                            void* wait_event, int accumulate, void* out_field) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -123,7 +125,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   // the short-range sum may be running on another stream into out_lr: join it before the gather adds to it
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
-    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
+    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field));
   else
     STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
   return MIPME_OK;
@@ -412,7 +414,8 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out) {
+                         void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out,
+                         void* out_field) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -420,12 +423,13 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   MIPME_REQUIRE(G && rho_mesh && rho_hat && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
+  MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out),
+                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out));
+                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
@@ -558,6 +562,28 @@ int mipme_pair_distance_forward(void* stream, int dtype, int idx_dtype, int64_t 
   MIPME_REQUIRE((cell == nullptr) == (shifts == nullptr), "`cell` and `shifts` must be given together");
   hipStream_t st = (hipStream_t)stream;
   IDX_SWITCH(dtype, idx_dtype, distance_forward_impl, st, n_pairs, pairs, positions, cell, shifts, out_dist);
+}
+
+int mipme_pack_pair_shifts(void* stream, int dtype, int64_t n_pairs, const void* shifts, void* packed, void* flag) {
+  MIPME_REQUIRE(n_pairs >= 0 && flag && (n_pairs == 0 || (shifts && packed)), "invalid arguments to mipme_pack_pair_shifts");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32) return pack_pair_shifts_impl<float>(st, n_pairs, shifts, packed, flag);
+  if (dtype == MIPME_F64) return pack_pair_shifts_impl<double>(st, n_pairs, shifts, packed, flag);
+  set_error("invalid dtype %d", dtype);
+  return MIPME_EINVAL;
+}
+
+int mipme_pair_distance_forward_packed(void* stream, int dtype, int64_t n_pairs, const void* pairs32,
+                                       const void* packed_shifts, const void* positions, const void* cell,
+                                       void* out_dist) {
+  MIPME_REQUIRE(n_pairs >= 0, "invalid n_pairs");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs32 && packed_shifts && positions && cell && out_dist),
+                "NULL buffer passed to mipme_pair_distance_forward_packed");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32) return distance_forward_packed_impl<float>(st, n_pairs, pairs32, packed_shifts, positions, cell, out_dist);
+  if (dtype == MIPME_F64) return distance_forward_packed_impl<double>(st, n_pairs, pairs32, packed_shifts, positions, cell, out_dist);
+  set_error("invalid dtype %d", dtype);
+  return MIPME_EINVAL;
 }
 
 int mipme_pair_distance_backward(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms,

@@ -462,7 +462,9 @@ __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz
   }
 }
 
-template <int N, typename T>
+// FIELD: also write field[a] = (1/V) sum_g mesh(g) grad W_a(g) (Cartesian), single channel.  When the backward pass turns out
+// to be in energy mode (g = gE * charges) the mesh force is gE q_a field[a] and no gradient gather is needed at all.
+template <int N, bool FIELD, typename T>
 __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C,
                                                                      const int* __restrict__ start,
                                                                      const int4* __restrict__ rec,
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      const T* __restrict__ mesh, const T* __restrict__ q,
                                                                      const T* __restrict__ qsum, T inv_vol, T self_c,
                                                                      T bg_c, bool accumulate, T* __restrict__ out,
-                                                                     T* __restrict__ raw) {
+                                                                     T* __restrict__ raw, T* __restrict__ field) {
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
@@ -495,7 +497,30 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
       const int4 a = rec[id];
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       T acc = T(0);
-      if (lane_active) {
+      if constexpr (FIELD) {
+        const T* wr = wts + int64_t(id) * (6 * N);
+        const int tyc = lane_active ? ty : 0, tzc = lane_active ? tz : 0;
+        const T wyv = lane_active ? wr[N + tyc] : T(0), wzv = wr[2 * N + tzc];
+        const T dwyv = lane_active ? wr[4 * N + tyc] : T(0), dwzv = wr[5 * N + tzc];
+        const T* tp = tile + (ry + tyc) * TL + (rz + tzc);
+        T sx = T(0), sdx = T(0);
+#pragma unroll
+        for (int tx = 0; tx < N; ++tx) {
+          const T v = tp[(rx + tx) * TL * TL];
+          sx += v * wr[tx];
+          sdx += v * wr[3 * N + tx];
+        }
+        acc = sx * wyv * wzv;
+        const T fx = group_sum_b<LANES, T>(sdx * wyv * wzv) * T(g.nx) * inv_vol;
+        const T fy = group_sum_b<LANES, T>(sx * dwyv * wzv) * T(g.ny) * inv_vol;
+        const T fz = group_sum_b<LANES, T>(sx * wyv * dwzv) * T(g.nz) * inv_vol;
+        if (l == 0 && valid) {
+          const int64_t o = int64_t(a.w);
+          field[3 * o + 0] = T(g.inv[0]) * fx + T(g.inv[1]) * fy + T(g.inv[2]) * fz;
+          field[3 * o + 1] = T(g.inv[3]) * fx + T(g.inv[4]) * fy + T(g.inv[5]) * fz;
+          field[3 * o + 2] = T(g.inv[6]) * fx + T(g.inv[7]) * fy + T(g.inv[8]) * fz;
+        }
+      } else if (lane_active) {
         const T* wr = wts + int64_t(id) * (6 * N);
         const T* tp = tile + (ry + ty) * TL + (rz + tz);
 #pragma unroll
@@ -688,16 +713,25 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
 
 template <typename T>
 int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
-                  const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate) {
+                  const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate, void* field) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           ((void)S, gather_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
-                               (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out, (T*)raw)));
+  MIPME_REQUIRE(!field || m->n_channels == 1, "the field output of the gather is single-channel");
+  if (field)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, gather_brick_kernel<N, true, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                                 g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
+                                 (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
+                                 (T*)raw, (T*)field)));
+  else
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, gather_brick_kernel<N, false, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                                 g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
+                                 (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
+                                 (T*)raw, nullptr)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -728,9 +762,9 @@ template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                  double, double, void*, void*, int);
+                                  double, double, void*, void*, int, void*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                   double, double, void*, void*, int);
+                                   double, double, void*, void*, int, void*);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
                                        const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,

@@ -105,6 +105,47 @@ __global__ __launch_bounds__(256) void distance_forward_kernel(int64_t P, const 
   }
 }
 
+
+// Same op with the pair stream compressed to 16 bytes per pair: (i, j) as int32 and the three integer cell shifts as
+// int8 in one word (the float (P,3) shift tensor alone is 12 of the 28 bytes the generic kernel moves per pair).
+template <typename T>
+__global__ void pack_pair_shifts_kernel(int64_t P, const T* __restrict__ shifts, int* __restrict__ packed,
+                                        int* __restrict__ flag) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int word = 0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const T sh = shifts[3 * p + k];
+    const T r = rint(sh);
+    bad |= (r != sh) || (r > T(127)) || (r < T(-127));
+    word |= (int(r) & 0xff) << (8 * k);
+  }
+  packed[p] = word;
+  if (bad) atomicOr(flag, 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void distance_forward_packed_kernel(int64_t P, const int2* __restrict__ pairs,
+                                                                     const int* __restrict__ packed,
+                                                                     const T* __restrict__ pos, const T* __restrict__ cell,
+                                                                     T* __restrict__ out) {
+  T A[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = cell[k];
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+    const int2 ij = pairs[p];
+    const int w = packed[p];
+    const int64_t i = ij.x, j = ij.y;
+    const T sx = T((w << 24) >> 24), sy = T((w << 16) >> 24), sz = T((w << 8) >> 24);
+    const T vx = pos[3 * j] - pos[3 * i] + (sx * A[0] + sy * A[3] + sz * A[6]);
+    const T vy = pos[3 * j + 1] - pos[3 * i + 1] + (sx * A[1] + sy * A[4] + sz * A[7]);
+    const T vz = pos[3 * j + 2] - pos[3 * i + 2] + (sx * A[2] + sy * A[5] + sz * A[8]);
+    out[p] = fsqrt(vx * vx + vy * vy + vz * vz);
+  }
+}
+
 template <typename T, typename I, bool CELLGRAD>
 __global__ __launch_bounds__(256) void distance_backward_kernel(int64_t P, const I* __restrict__ pairs,
                                                                const T* __restrict__ pos, const T* __restrict__ cell,
@@ -258,6 +299,30 @@ int distance_backward_impl(hipStream_t st, int64_t P, int64_t N, const void* pai
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
+
+
+template <typename T>
+int pack_pair_shifts_impl(hipStream_t st, int64_t P, const void* shifts, void* packed, void* flag) {
+  MIPME_CHECK_HIP(zero_async(flag, sizeof(int), st));
+  if (P == 0) return MIPME_OK;
+  pack_pair_shifts_kernel<T><<<unsigned((P + 255) / 256), 256, 0, st>>>(P, (const T*)shifts, (int*)packed, (int*)flag);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int distance_forward_packed_impl(hipStream_t st, int64_t P, const void* pairs, const void* packed, const void* pos,
+                                 const void* cell, void* out) {
+  if (P == 0) return MIPME_OK;
+  distance_forward_packed_kernel<T><<<pair_grid(P), 256, 0, st>>>(P, (const int2*)pairs, (const int*)packed,
+                                                                  (const T*)pos, (const T*)cell, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+template int pack_pair_shifts_impl<float>(hipStream_t, int64_t, const void*, void*, void*);
+template int pack_pair_shifts_impl<double>(hipStream_t, int64_t, const void*, void*, void*);
+template int distance_forward_packed_impl<float>(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
+template int distance_forward_packed_impl<double>(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
 
 #define MIPME_INST(T, I)                                                                                               \
   template int rspace_forward_impl<T, I>(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*,    \

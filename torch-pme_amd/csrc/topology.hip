@@ -552,16 +552,20 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
   }
 }
 
-// energy mode: grad_pos[a] = f gE q[a] F[a], grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list)
+// energy mode: grad_pos[a] = gE q[a] (f F[a] + field[a]), grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list;
+// field = the mesh part from the forward gather, nullable, as is force)
 template <typename T>
-__global__ void sr_fused_finalize_kernel(int64_t N, const T* __restrict__ force, const T* __restrict__ q,
-                                         const T* __restrict__ gscale, T f, int64_t nblocks,
+__global__ void sr_fused_finalize_kernel(int64_t N, const T* __restrict__ force, const T* __restrict__ field,
+                                         const T* __restrict__ q, const T* __restrict__ gscale, T f, int64_t nblocks,
                                          const double* __restrict__ partials, T* __restrict__ grad_pos,
                                          T* __restrict__ grad_cell) {
-  const T sc = f * gscale[0];
+  const T ge = gscale[0];
+  const T sc = f * ge;
   if (grad_pos) {
-    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < 3 * N; t += int64_t(gridDim.x) * blockDim.x)
-      grad_pos[t] = sc * q[t / 3] * force[t];
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < 3 * N; t += int64_t(gridDim.x) * blockDim.x) {
+      const T sr = force ? f * force[t] : T(0), lr = field ? field[t] : T(0);
+      grad_pos[t] = ge * q[t / 3] * (sr + lr);
+    }
   }
   if (grad_cell && blockIdx.x == 0) {
     double acc[9];
@@ -734,15 +738,16 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
 }
 
 template <typename T>
-static int sr_fused_finalize_impl(hipStream_t st, int64_t N, const void* force, const void* q, const void* gscale,
-                                  int full_list, const void* partials, void* grad_pos, void* grad_cell) {
+static int sr_fused_finalize_impl(hipStream_t st, int64_t N, const void* force, const void* field, const void* q,
+                                  const void* gscale, int full_list, const void* partials, void* grad_pos,
+                                  void* grad_cell) {
   if (N == 0) {
     if (grad_cell) MIPME_CHECK_HIP(zero_async(grad_cell, sizeof(T) * 9, st));
     return MIPME_OK;
   }
   const int64_t want = (3 * N + 255) / 256;
   const unsigned grid = unsigned(want < 2048 ? want : 2048);
-  sr_fused_finalize_kernel<T><<<grid, 256, 0, st>>>(N, (const T*)force, (const T*)q, (const T*)gscale,
+  sr_fused_finalize_kernel<T><<<grid, 256, 0, st>>>(N, (const T*)force, (const T*)field, (const T*)q, (const T*)gscale,
                                                     full_list ? T(0.5) : T(1), int64_t(row_blocks(N)),
                                                     (const double*)partials, (T*)grad_pos, (T*)grad_cell);
   MIPME_LAUNCH_CHECK();
@@ -878,17 +883,17 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
   return MIPME_EINVAL;
 }
 
-int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* charges,
-                           const void* grad_scale, int full_list, const void* partials, void* grad_positions,
-                           void* grad_cell) {
+int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* field,
+                           const void* charges, const void* grad_scale, int full_list, const void* partials,
+                           void* grad_positions, void* grad_cell) {
   MIPME_REQUIRE(n_atoms >= 0 && grad_scale, "invalid arguments to mipme_sr_rows_finalize");
-  MIPME_REQUIRE(n_atoms == 0 || !grad_positions || (force && charges), "NULL buffer passed to mipme_sr_rows_finalize");
+  MIPME_REQUIRE(n_atoms == 0 || !grad_positions || ((force || field) && charges), "NULL buffer passed to mipme_sr_rows_finalize");
   MIPME_REQUIRE(!grad_cell || partials, "grad_cell needs the partial sums of mipme_sr_rows_fused");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIPME_F32)
-    return sr_fused_finalize_impl<float>(st, n_atoms, force, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
+    return sr_fused_finalize_impl<float>(st, n_atoms, force, field, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
   if (dtype == MIPME_F64)
-    return sr_fused_finalize_impl<double>(st, n_atoms, force, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
+    return sr_fused_finalize_impl<double>(st, n_atoms, force, field, charges, grad_scale, full_list, partials, grad_positions, grad_cell);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
 }

@@ -150,6 +150,7 @@ class PairTopology:
         self.entries = torch.empty((max(2 * P, 1), 2), dtype=torch.int32, device=device)
         self._packed = None  # (weakref(shifts), version, tensor|None)
         self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
+        self._pair_sh = None  # (weakref(shifts), version, tensor|None)
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
         with torch.cuda.device(device):
@@ -186,6 +187,24 @@ class PairTopology:
         self._packed = (weakref.ref(key), key._version, packed)
         return packed
 
+
+    def pair_packed_shifts(self, shifts: torch.Tensor, key: torch.Tensor | None = None):
+        """int32 (P,) with the 3 cell shifts of every pair as int8 (list order), or None if they are not small integers."""
+        key = shifts if key is None else key
+        c = self._pair_sh
+        if c is not None and c[0]() is key and c[1] == key._version:
+            return c[2]
+        lib = _lib.load()
+        device = shifts.device
+        packed = torch.empty((max(self.n_pairs, 1),), dtype=torch.int32, device=device)
+        flag = torch.empty((1,), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.mipme_pack_pair_shifts(_lib.current_stream(device), _lib.dtype_code(shifts.dtype), self.n_pairs,
+                                                  shifts.data_ptr(), packed.data_ptr(), flag.data_ptr()))
+        if int(flag.item()) != 0:
+            packed = None
+        self._pair_sh = (weakref.ref(key), key._version, packed)
+        return packed
 
     def entries_with_shifts(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None):
         """int32 (2P, 2) table {other atom, 3 x int8 cell shift} for the fused kernels, or None if the shifts are not small
@@ -278,6 +297,7 @@ class _PMEFunction(torch.autograd.Function):
         out = torch.empty((N, Cn), dtype=dtype, device=device)
         need_cell = ctx.needs_input_grad[1]
         saved = {}
+        field = None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
             topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
@@ -335,6 +355,9 @@ class _PMEFunction(torch.autograd.Function):
                     nbytes = lib.mipme_atom_bins_bytes(C.byref(md), N, dt)
                     if nbytes > 0:
                         bins = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+                # speculative: the mesh force per unit gE q_a, formed by the same gather (see the backward's energy mode)
+                if ENERGY_FAST_PATH and bins is not None and Cn == 1 and ctx.needs_input_grad[2] and slab_axis is None:
+                    field = torch.empty((N, 3), dtype=dtype, device=device)
                 overlap = OVERLAP and topo is not None
                 join = None
                 if overlap:
@@ -351,7 +374,7 @@ class _PMEFunction(torch.autograd.Function):
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                     G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
-                    join.cuda_event if overlap else None, 1 if overlap else 0,
+                    join.cuda_event if overlap else None, 1 if overlap else 0, _lib.ptr(field),
                 )
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
@@ -365,7 +388,9 @@ class _PMEFunction(torch.autograd.Function):
                     run_rspace(1)
             else:
                 run_rspace(0)
-        ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")))
+        ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")), out)
+        ctx.field = field
+        ctx.same_positions = src_positions is positions
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
         ctx.fused = fused  # plain tensors made here, none of them an input or output of this node
@@ -375,31 +400,33 @@ class _PMEFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.load()
-        q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins = ctx.saved_tensors
-        geom, pot_desc = ctx.geom, ctx.pot_desc
+        q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins, out = ctx.saved_tensors
+        geom, pot_desc, fused, topo = ctx.geom, ctx.pot_desc, ctx.fused, ctx.topo
         need_q, need_cell, need_pos, need_dist = ctx.needs_input_grad[:4]
-        fused = ctx.fused
         need_src_pos = fused is not None and ctx.needs_input_grad[11]
         need_src_cell = fused is not None and fused["cell"] is not None and ctx.needs_input_grad[12]
-        grad_src_pos = grad_src_cell = None
         device, dtype = pos.device, pos.dtype
         dt = _lib.dtype_code(dtype)
         N, Cn = q.shape
         P = pairs.shape[0]
+        full = int(ctx.full_list)
         g = grad_out.contiguous()
-        grad_q = grad_pos = grad_cell = grad_dist = None
+        grad_q = grad_pos = grad_cell = grad_dist = grad_src_pos = grad_src_cell = None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
-            topo = ctx.topo
             do_kspace = geom is not None and (need_q or need_cell or need_pos)
             # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
-            # exactly gE * charges, and the adjoint mesh is a multiple of the forward one (no second spread / FFT).
+            # exactly gE * charges.  Then (a) the adjoint mesh is a multiple of the forward one (no second spread / FFT),
+            # (b) the forces are gE q_a times the per-atom sums the forward pass already formed (``field`` from the gather,
+            # ``force`` from the fused pair kernel), (c) for a half list dL/dq = gE * V (V is a symmetric bilinear form).
             tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
             gscale = sr_scale = None
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
-                sr_scale = tag[3]  # g == gE * charges: enough for the pair part
+                sr_scale = tag[3]  # enough for the pair part
                 if not need_cell and ctx.slab_axis is None:
                     gscale = tag[3]
+            field = ctx.field if gscale is not None else None
+            energy_q = need_q and gscale is not None and not ctx.full_list
             if need_dist:
                 grad_dist = torch.empty((P,), dtype=dtype, device=device)
 
@@ -409,7 +436,7 @@ class _PMEFunction(torch.autograd.Function):
                 _call(
                     "rspace_backward", lib.mipme_rspace_backward,
                     _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
-                    dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), int(ctx.full_list), C.byref(pot_desc), g.data_ptr(),
+                    dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), full, C.byref(pot_desc), g.data_ptr(),
                     _lib.ptr(sr_scale), _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
                 )
 
@@ -422,18 +449,21 @@ class _PMEFunction(torch.autograd.Function):
                     run_grad_dist(False)
                     join.record()
             if do_kspace and gscale is not None:
-                md = geom.desc(Cn)
-                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
-                if need_pos:
-                    grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
-                if need_q:
-                    grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
-                _call(
-                    "kspace_backward", lib.mipme_kspace_backward,
-                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                    g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), None, _lib.ptr(rho_dc), None, None, None, None,
-                    None, None, None, _lib.ptr(grad_pos), _lib.ptr(grad_q), None, _lib.ptr(bins), gscale.data_ptr(),
-                )
+                kb_pos = need_pos and field is None
+                kb_q = need_q and not energy_q
+                if kb_pos or kb_q:
+                    md = geom.desc(Cn)
+                    plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                    if kb_pos:
+                        grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                    if kb_q:
+                        grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
+                    _call(
+                        "kspace_backward", lib.mipme_kspace_backward,
+                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
+                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), None, _lib.ptr(rho_dc), None, None, None, None,
+                        None, None, None, _lib.ptr(grad_pos), _lib.ptr(grad_q), None, _lib.ptr(bins), gscale.data_ptr(),
+                    )
             elif do_kspace:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn)
@@ -468,50 +498,71 @@ class _PMEFunction(torch.autograd.Function):
                     )
                 if not need_pos:
                     grad_pos = None
-            elif need_q:
+            elif need_q and not energy_q:
                 grad_q = torch.zeros((N, Cn), dtype=dtype, device=device)
+            atomic_q = need_q and topo is None and not energy_q
             if overlap:
                 torch.cuda.current_stream(device).wait_event(join)
-            elif need_dist or (need_q and topo is None):
-                run_grad_dist(need_q and topo is None)
-            if need_src_pos or need_src_cell:
+            elif need_dist or atomic_q:
+                run_grad_dist(atomic_q)
+
+            # ---- gradients that end in per-atom sums formed by the forward pass (energy mode) ----
+            sr_done = (need_src_pos or need_src_cell) and sr_scale is not None and fused["force"] is not None and (
+                fused["partials"] is not None or not need_src_cell)
+            mesh_done = need_pos and field is not None
+
+            def finalize(force_t, field_t, partials_t, out_pos, out_cell):
+                _call(
+                    "forces_finalize", lib.mipme_sr_rows_finalize,
+                    st, dt, N, _lib.ptr(force_t), _lib.ptr(field_t), q.data_ptr(), sr_scale.data_ptr(), full,
+                    _lib.ptr(partials_t), _lib.ptr(out_pos), _lib.ptr(out_cell),
+                )
+
+            if sr_done and need_src_cell:
+                grad_src_cell = torch.empty((3, 3), dtype=dtype, device=device)
+            if sr_done and mesh_done and ctx.same_positions and need_src_pos:
+                # both parts differentiate the same ``positions`` tensor: one kernel, one gradient
+                grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                finalize(fused["force"], field, fused["partials"], grad_pos, grad_src_cell)
+            else:
+                if mesh_done:
+                    grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                    finalize(None, field, None, grad_pos, None)
+                if sr_done:
+                    if need_src_pos:
+                        grad_src_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                    finalize(fused["force"], None, fused["partials"], grad_src_pos, grad_src_cell)
+            if (need_src_pos or need_src_cell) and not sr_done:
                 grad_src_pos = torch.empty((N, 3), dtype=dtype, device=device)
+                partials = None
                 if need_src_cell:
                     grad_src_cell = torch.empty((3, 3), dtype=dtype, device=device)
-                have_cell_sums = fused["partials"] is not None or not need_src_cell
-                if sr_scale is not None and fused["force"] is not None and have_cell_sums:
-                    # energy mode: the forward pass already holds sum_e sign q_o v' vec/d per atom
-                    _call(
-                        "rspace_backward", lib.mipme_sr_rows_finalize,
-                        st, dt, N, fused["force"].data_ptr(), q.data_ptr(), sr_scale.data_ptr(), int(ctx.full_list),
-                        _lib.ptr(fused["partials"]), grad_src_pos.data_ptr(), _lib.ptr(grad_src_cell),
-                    )
-                else:
-                    partials = None
-                    if need_src_cell:
-                        partials = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
-                    _call(
-                        "rspace_backward", lib.mipme_sr_rows_fused,
-                        st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
-                        _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
-                        0, int(ctx.full_list), C.byref(pot_desc), 0, fused["records"].data_ptr(), None,
-                        grad_src_pos.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_src_cell),
-                    )
+                    partials = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
+                _call(
+                    "rspace_backward", lib.mipme_sr_rows_fused,
+                    st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
+                    _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
+                    0, full, C.byref(pot_desc), 0, fused["records"].data_ptr(), None, grad_src_pos.data_ptr(),
+                    _lib.ptr(partials), _lib.ptr(grad_src_cell),
+                )
                 if not need_src_pos:
                     grad_src_pos = None
-            if need_q and fused is not None:
+
+            # ---- charge gradient of the pair part ----
+            if energy_q:
+                grad_q = out * sr_scale
+            elif need_q and fused is not None:
                 _call(
                     "rspace_backward_charges", lib.mipme_sr_rows_fused,
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), g.data_ptr(), None,
-                    1, int(ctx.full_list), C.byref(pot_desc), 1, fused["records"].data_ptr(), grad_q.data_ptr(), None, None,
-                    None,
+                    1, full, C.byref(pot_desc), 1, fused["records"].data_ptr(), grad_q.data_ptr(), None, None, None,
                 )
             elif need_q and topo is not None:
                 _call(
                     "rspace_backward_charges", lib.mipme_rspace_rows,
                     st, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
-                    _lib.ptr(mask), 1, int(ctx.full_list), C.byref(pot_desc), 1, grad_q.data_ptr(),
+                    _lib.ptr(mask), 1, full, C.byref(pot_desc), 1, grad_q.data_ptr(),
                 )
             if geom is None:
                 if need_pos:
@@ -546,12 +597,20 @@ class _PairDistances(torch.autograd.Function):
         out = torch.empty((P,), dtype=dtype, device=device)
         topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
         pl = pairs if topo is None else topo.pairs32
+        packed = topo.pair_packed_shifts(sh, shifts) if (topo is not None and sh is not None) else None
         with torch.cuda.device(device):
-            _call(
-                "pair_distance_forward", lib.mipme_pair_distance_forward,
-                _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pl.dtype), P,
-                pl.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
-            )
+            if packed is not None:
+                _call(
+                    "pair_distance_forward", lib.mipme_pair_distance_forward_packed,
+                    _lib.current_stream(device), _lib.dtype_code(dtype), P, pl.data_ptr(), packed.data_ptr(),
+                    pos.data_ptr(), cl.data_ptr(), out.data_ptr(),
+                )
+            else:
+                _call(
+                    "pair_distance_forward", lib.mipme_pair_distance_forward,
+                    _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pl.dtype), P,
+                    pl.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
+                )
         ctx.save_for_backward(pos, cl, pairs, sh)
         ctx.topo = topo
         ctx.shifts_key = shifts
