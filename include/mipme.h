@@ -114,12 +114,15 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * latency-bound mesh kernels).
  * out_field (N,3), nullable, needs atom_bins and C == 1: field[a] = (1/V) sum_g phi(g) grad W_a(g), written by the same
  * gather.  If the backward pass is in energy mode (g = gE * charges) the mesh force is gE q_a field[a]
- * (mipme_sr_rows_finalize) and mipme_kspace_backward is not needed. */
+ * (mipme_sr_rows_finalize) and mipme_kspace_backward is not needed.
+ * out_records (4N reals, 16-byte aligned), nullable, same conditions: (x, y, z, q) per atom for mipme_sr_rows_fused
+ * (records_ready = 1), written by the binning pass while the positions are in registers.
+ * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time. */
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field);
+                         void* out_field, void* out_records);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
  * (In the reference this is PyTorch autograd through the ATen chain)
@@ -178,8 +181,11 @@ int mipme_rspace_backward(void* stream, int dtype, int idx_dtype, int64_t n_pair
                           void* grad_dist, void* grad_charges);
 
 /* ---- caller side: the energy reduction E = sum_ic q_ic V_ic (README.rst:112-114, tests/calculators/test_values_ewald.py:306)
- * as one kernel, and its adjoint grad_a = g*b, grad_b = g*a (g: device scalar; grad_a / grad_b nullable). ---- */
-int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* scratch /* 64 float64 */,
+ * as one kernel, and its adjoint grad_a = g*b, grad_b = g*a (g: device scalar; grad_a / grad_b nullable).
+ * scratch: 65 float64 of PERSISTENT device memory, zero-initialised once by the caller and used by one stream at a time:
+ * 64 block sums + a ticket counter that the kernel leaves at zero (the block drawing the last ticket adds the block sums
+ * in index order, so the result is deterministic). ---- */
+int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const void* b, void* scratch /* 65 float64 */,
                       void* out);
 int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
                        void* grad_b);
@@ -245,7 +251,8 @@ int64_t mipme_rows_partials_size(int64_t n_atoms);
  *         w_e = charges[o] when grad_out == NULL (finish with mipme_sr_rows_finalize: energy mode, g = gE * charges),
  *         otherwise the general weights 1/2 (g[a] q[o] + g[o] q[a]) (half list) -- force is then d L / d positions.
  *   records: device scratch of 4 * N reals (16-byte aligned); holds (x, y, z, src) per atom so that one gather per entry
- *         fetches the partner atom.
+ *         fetches the partner atom; records_ready != 0: already filled with (positions, src) -- e.g. by
+ *         mipme_kspace_forward(out_records) -- and not repacked.
  *   partials nullable: float64[mipme_rows_partials_size(N)] per-block sums of the cell gradient; with grad_out != NULL
  *         and grad_cell != NULL they are reduced into grad_cell (3,3). */
 int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
@@ -253,8 +260,8 @@ int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const 
 int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
-                        const mipme_potential_t* pot, int accumulate, void* records, void* out, void* force,
-                        void* partials, void* grad_cell);
+                        const mipme_potential_t* pot, int accumulate, void* records, int records_ready, void* out,
+                        void* force, void* partials, void* grad_cell);
 /* grad_positions[a] = gE charges[a] (f force[a] + field[a]); grad_cell = f gE sum(partials); f = 1/2 for a full list,
  * gE = grad_scale[0].  force: from mipme_sr_rows_fused (nullable); field: out_field of mipme_kspace_forward (nullable). */
 int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* field,

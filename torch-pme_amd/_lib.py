@@ -94,7 +94,7 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp],
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp],
         "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19,
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
@@ -109,7 +109,7 @@ def _declare(lib):
         "mipme_topology_pack_entries": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_pack_pair_shifts": [vp, ci, i64, vp, vp, vp],
         "mipme_pair_distance_forward_packed": [vp, ci, i64, vp, vp, vp, vp, vp],
-        "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp, vp, vp, vp, vp],
+        "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp, ci, vp, vp, vp, vp],
         "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],

@@ -46,8 +46,9 @@ FftDims fft_plan_dims(const mipme_fft_plan*);
 // bricks.hip
 bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
-template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
-template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
+template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
+template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
+int* fft_plan_brick_count(const mipme_fft_plan*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
@@ -108,14 +109,23 @@ template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
-                            void* wait_event, int accumulate, void* out_field) {
+                            void* wait_event, int accumulate, void* out_field, void* out_records) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
   if (bins) {
-    STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins));
-    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh));
+    // the plan's counters are zero here and the spread clears them again (no memset launch); if the spread cannot be
+    // launched they are cleared explicitly so that a failed call does not poison the next one
+    int* counters = fft_plan_brick_count(plan);
+    STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins, counters, q, out_records));
+    {
+      ProfScope _ps(st, "spread");
+      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters))) {
+        (void)hipMemsetAsync(counters, 0, sizeof(int) * (size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1), st);
+        return rc;
+      }
+    }
   } else {
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
   }
@@ -152,7 +162,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   }
   // psi = spread(g / 2V); chi = F psi
   if (bins)
-    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr));
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
   STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
@@ -269,27 +279,37 @@ __global__ void slab_cell_kernel(int axis, int C, mipme_mesh_t m, double c0, dou
 // two stages, both deterministic: kDotBlocks block partials (double), then one wave sums them
 static constexpr int kDotBlocks = 64;
 
+// One kernel: per-block partial sums, then the block that draws the last ticket adds them in index order (deterministic)
+// and resets the ticket counter.  scratch: kDotBlocks doubles + one int counter that is zero between calls.
 template <typename T>
-__global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
-                                                         double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                 double* partials, int* counter, T* __restrict__ out) {
   double acc = 0.0;
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
     acc += double(a[i]) * double(b[i]);
   __shared__ double red[4];
+  __shared__ bool last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) red[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void dot_final_kernel(int nblocks, const double* __restrict__ partials, T* __restrict__ out) {
-  double acc = int(threadIdx.x) < nblocks ? partials[threadIdx.x] : 0.0;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = ticket == int(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!last || wave != 0) return;
+  double tot = int(threadIdx.x) < int(gridDim.x)
+                   ? __hip_atomic_load(&partials[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (threadIdx.x == 0) out[0] = T(acc);
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+  if (threadIdx.x == 0) {
+    out[0] = T(tot);
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // out_a[i] = g * b[i], out_b[i] = g * a[i]  (g: device scalar)
@@ -415,7 +435,7 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field) {
+                         void* out_field, void* out_records) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -424,12 +444,13 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
+  MIPME_REQUIRE(!out_records || (bins && mesh->n_channels == 1), "out_records needs atom bins and a single channel");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field),
+                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field));
+                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
@@ -603,12 +624,11 @@ int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const v
   MIPME_REQUIRE(n >= 0 && out && scratch && (n == 0 || (a && b)), "invalid arguments to mipme_dot_forward");
   hipStream_t st = (hipStream_t)stream;
   double* partials = (double*)scratch;
+  int* counter = (int*)(partials + kDotBlocks);
   if (dtype == MIPME_F32) {
-    dot_partial_kernel<float><<<kDotBlocks, 256, 0, st>>>(n, (const float*)a, (const float*)b, partials);
-    dot_final_kernel<float><<<1, 64, 0, st>>>(kDotBlocks, partials, (float*)out);
+    dot_kernel<float><<<kDotBlocks, 256, 0, st>>>(n, (const float*)a, (const float*)b, partials, counter, (float*)out);
   } else if (dtype == MIPME_F64) {
-    dot_partial_kernel<double><<<kDotBlocks, 256, 0, st>>>(n, (const double*)a, (const double*)b, partials);
-    dot_final_kernel<double><<<1, 64, 0, st>>>(kDotBlocks, partials, (double*)out);
+    dot_kernel<double><<<kDotBlocks, 256, 0, st>>>(n, (const double*)a, (const double*)b, partials, counter, (double*)out);
   } else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;

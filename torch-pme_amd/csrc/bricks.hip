@@ -177,7 +177,8 @@ template <int SCHEME, int N, bool FUSED_SCAN, typename T>
 __global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t Natoms, const T* __restrict__ pos,
                                                       const int* __restrict__ count, int* __restrict__ start,
                                                       const int* __restrict__ slot, const int* __restrict__ brick,
-                                                      int4* __restrict__ rec, T* __restrict__ wts) {
+                                                      int4* __restrict__ rec, T* __restrict__ wts,
+                                                      const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
   __shared__ int sstart[FUSED_SCAN ? kFusedScanMax + 1 : 1];
   __shared__ int wsum[4];
   if constexpr (FUSED_SCAN) {
@@ -216,6 +217,14 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t N
   int m[3];
   double x[3];
   atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
+  if (atom_rec) {  // (position, charge) records for the fused pair kernels, while the position is in registers anyway
+    AtomRecord<T> r;
+    r.x = pos[3 * i];
+    r.y = pos[3 * i + 1];
+    r.z = pos[3 * i + 2];
+    r.w = q[i];
+    atom_rec[i] = r;
+  }
   const int b = brick[i];
   const int64_t dst = int64_t(FUSED_SCAN ? sstart[b] : start[b]) + slot[i];
   rec[dst] = make_int4(m[0], m[1], m[2], int(i));
@@ -306,8 +315,9 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      const int4* __restrict__ rec,
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ val, T scale,
-                                                                     T* __restrict__ mesh) {
+                                                                     T* __restrict__ mesh, int* __restrict__ clear_count) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (clear_count && threadIdx.x == 0) clear_count[blockIdx.x] = 0;  // leave the plan's brick counters clean (bins_build)
   const int SW = 3 * N + C;                                 // staged reals per survivor
   const int region = max(SPREAD_WAVES * BRICK_PTS, SPREAD_STAGE * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [SPREAD_STAGE][SW] staged weights + value
@@ -661,14 +671,20 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
                   (void*)(b + l.wts)};
 }
 
+// clean_count (nullable): brick counters that are zero on entry (plan-owned; spread_bricks clears them again); otherwise the
+// counters inside `bins` are zeroed here.  q + atom_rec (nullable, single channel): also emit the (position, charge) records.
 template <typename T>
-int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins) {
+int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins, int* clean_count,
+               const void* q, void* atom_rec) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
-  const BinsView v = bins_view(m, n_atoms, dtype, bins);
+  BinsView v = bins_view(m, n_atoms, dtype, bins);
   const bool even = (m->order % 2) == 0;
-  MIPME_CHECK_HIP(zero_async(v.count, sizeof(int) * size_t(bg.nb + 1), st));
+  if (clean_count)
+    v.count = clean_count;
+  else
+    MIPME_CHECK_HIP(zero_async(v.count, sizeof(int) * size_t(bg.nb + 1), st));
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
   if (n_atoms > 0) {
     bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, n_atoms, (const T*)pos, v.count, v.slot, v.brick);
@@ -683,11 +699,13 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
     if (fused)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_fill_kernel<S, N, true, T><<<blocks, 256, 0, st>>>(
-                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts)));
+                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts,
+                                   (const T*)q, (AtomRecord<T>*)atom_rec)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_fill_kernel<S, N, false, T><<<blocks, 256, 0, st>>>(
-                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts)));
+                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts,
+                                   (const T*)q, (AtomRecord<T>*)atom_rec)));
     MIPME_LAUNCH_CHECK();
   } else if (fused) {
     bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
@@ -697,7 +715,8 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
 }
 
 template <typename T>
-int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh) {
+int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
+                  int* clear_count) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
@@ -706,7 +725,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh)));
+                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh,
+                               clear_count)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -757,10 +777,10 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
   return MIPME_OK;
 }
 
-template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
-template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*);
-template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
-template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*);
+template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
+template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
+template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
+template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                   double, double, void*, void*, int, void*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,

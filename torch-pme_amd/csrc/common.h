@@ -208,4 +208,11 @@ struct StencilGroup {
   static constexpr int LANES = PLANE <= 1 ? 1 : PLANE <= 4 ? 4 : PLANE <= 16 ? 16 : PLANE <= 32 ? 32 : 64;
 };
 
+// (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position
+// and charge (or source value).  Written by pack_atom_records_kernel (topology.hip) or by the binning pass (bricks.hip).
+template <typename T>
+struct alignas(4 * sizeof(T)) AtomRecord {
+  T x, y, z, w;
+};
+
 }  // namespace mipme

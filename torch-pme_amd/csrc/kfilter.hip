@@ -334,6 +334,9 @@ __global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m,
 struct mipme_fft_plan {
   hipfftHandle fwd = 0, inv = 0;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
+  // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
+  // the bins clears them again, which saves a memset launch per evaluation
+  int* brick_count = nullptr;
 };
 
 namespace mipme {
@@ -389,17 +392,30 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     delete p;
     return MIPME_EFFT;
   }
+  const size_t n_count = size_t((nx + 7) / 8) * size_t((ny + 7) / 8) * size_t((nz + 7) / 8) + 1;
+  if (hipMalloc((void**)&p->brick_count, n_count * sizeof(int)) != hipSuccess ||
+      hipMemset(p->brick_count, 0, n_count * sizeof(int)) != hipSuccess) {
+    set_error("could not allocate the brick counters of the plan (plans cannot be created during stream capture)");
+    (void)hipGetLastError();
+    if (p->brick_count) (void)hipFree(p->brick_count);
+    hipfftDestroy(p->fwd);
+    hipfftDestroy(p->inv);
+    delete p;
+    return MIPME_EHIP;
+  }
   *out = p;
   return MIPME_OK;
 }
 
 struct FftDims { int dtype, nx, ny, nz, batch; };
 FftDims fft_plan_dims(const mipme_fft_plan* p) { return FftDims{p->dtype, p->nx, p->ny, p->nz, p->batch}; }
+int* fft_plan_brick_count(const mipme_fft_plan* p) { return p->brick_count; }
 
 int fft_plan_destroy(mipme_fft_plan* p) {
   if (!p) return MIPME_OK;
   if (p->fwd) hipfftDestroy(p->fwd);
   if (p->inv) hipfftDestroy(p->inv);
+  if (p->brick_count) (void)hipFree(p->brick_count);
   delete p;
   return MIPME_OK;
 }

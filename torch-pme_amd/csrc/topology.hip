@@ -372,11 +372,6 @@ __global__ __launch_bounds__(256) void distance_backward_rows_kernel(int64_t N, 
 //              = 1/2 (g[a] q[o] + g[o] q[a])            half list
 //              = 1/2 g[a] q[o] (role i), 1/2 g[o] q[a] (role j)   full list
 //   CELLGRAD partial sums of sum_{role-i e} (q[a] if g == NULL) w_e v' / d  S_e^T vec_e  per block (fp64)
-// (x, y, z, w) per atom, 16-byte aligned: one gather per entry fetches the partner's position and charge (or source value)
-template <typename T>
-struct alignas(4 * sizeof(T)) AtomRecord {
-  T x, y, z, w;
-};
 
 template <typename T>
 __global__ void pack_atom_records_kernel(int64_t N, const T* __restrict__ pos, const T* __restrict__ w,
@@ -664,7 +659,8 @@ template <typename T>
 static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, const void* ent_sh, const void* entries,
                               const void* mask, const void* pos, const void* cell, const void* q, const void* src,
                               const void* g, int transpose, int full_list, const mipme_potential_t* pot, int accumulate,
-                              void* records, void* out, void* force, void* partials, void* grad_cell) {
+                              void* records, int records_ready, void* out, void* force, void* partials,
+                              void* grad_cell) {
   SRPot s;
   int rc = make_srpot(pot, s);
   if (rc) return rc;
@@ -677,9 +673,11 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   const unsigned grid = row_blocks(N);
   const CoulombFast cf = make_coulomb_fast(s);
   const bool cfast = is_coulomb_fast(s);
-  pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
-      N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
-  MIPME_LAUNCH_CHECK();
+  if (!records_ready) {
+    pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
+        N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
+    MIPME_LAUNCH_CHECK();
+  }
   const bool want_pot = out != nullptr, want_force = force != nullptr, want_cg = partials != nullptr;
   int mode;
   if (want_pot && !want_force)
@@ -864,8 +862,8 @@ int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const 
 int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
-                        const mipme_potential_t* pot, int accumulate, void* records, void* out, void* force,
-                        void* partials, void* grad_cell) {
+                        const mipme_potential_t* pot, int accumulate, void* records, int records_ready, void* out,
+                        void* force, void* partials, void* grad_cell) {
   MIPME_REQUIRE(n_atoms >= 0 && row_ptr, "invalid arguments to mipme_sr_rows_fused");
   MIPME_REQUIRE(n_atoms == 0 || (entries_shift && positions && charges && records), "NULL buffer passed to mipme_sr_rows_fused");
   MIPME_REQUIRE(!pair_mask || entries, "`pair_mask` needs the (other, pair) entry table");
@@ -875,10 +873,10 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIPME_F32)
     return sr_fused_rows_impl<float>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
-                                     src, grad_out, transpose, full_list, pot, accumulate, records, out, force, partials, grad_cell);
+                                     src, grad_out, transpose, full_list, pot, accumulate, records, records_ready, out, force, partials, grad_cell);
   if (dtype == MIPME_F64)
     return sr_fused_rows_impl<double>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
-                                      src, grad_out, transpose, full_list, pot, accumulate, records, out, force, partials, grad_cell);
+                                      src, grad_out, transpose, full_list, pot, accumulate, records, records_ready, out, force, partials, grad_cell);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
 }

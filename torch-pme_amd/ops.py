@@ -324,8 +324,9 @@ class _PMEFunction(torch.autograd.Function):
                         "rspace_forward", lib.mipme_sr_rows_fused,
                         stream, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                         _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), q.data_ptr(), None,
-                        0, int(full_list), C.byref(pot_desc), accumulate, fused["records"].data_ptr(), out.data_ptr(),
-                        _lib.ptr(fused["force"]), _lib.ptr(fused["partials"]), None,
+                        0, int(full_list), C.byref(pot_desc), accumulate, fused["records"].data_ptr(),
+                        int(fused.get("records_ready", False)), out.data_ptr(), _lib.ptr(fused["force"]),
+                        _lib.ptr(fused["partials"]), None,
                     )
                 elif topo is not None:
                     _call(
@@ -360,6 +361,10 @@ class _PMEFunction(torch.autograd.Function):
                     field = torch.empty((N, 3), dtype=dtype, device=device)
                 overlap = OVERLAP and topo is not None
                 join = None
+                # the binning pass can emit the (position, charge) records of the fused pair kernel for free
+                records_out = None
+                if fused is not None and bins is not None and Cn == 1 and src_positions is positions and not overlap:
+                    records_out = fused["records"]
                 if overlap:
                     # short-range sum on the side stream (writes `out`); the gather at the end of the mesh
                     # pipeline waits for it and adds the long-range part
@@ -374,8 +379,10 @@ class _PMEFunction(torch.autograd.Function):
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                     G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
-                    join.cuda_event if overlap else None, 1 if overlap else 0, _lib.ptr(field),
+                    join.cuda_event if overlap else None, 1 if overlap else 0, _lib.ptr(field), _lib.ptr(records_out),
                 )
+                if records_out is not None:
+                    fused["records_ready"] = True
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
                     _call(
@@ -542,7 +549,7 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward", lib.mipme_sr_rows_fused,
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
-                    0, full, C.byref(pot_desc), 0, fused["records"].data_ptr(), None, grad_src_pos.data_ptr(),
+                    0, full, C.byref(pot_desc), 0, fused["records"].data_ptr(), 0, None, grad_src_pos.data_ptr(),
                     _lib.ptr(partials), _lib.ptr(grad_src_cell),
                 )
                 if not need_src_pos:
@@ -556,7 +563,7 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward_charges", lib.mipme_sr_rows_fused,
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), g.data_ptr(), None,
-                    1, full, C.byref(pot_desc), 1, fused["records"].data_ptr(), grad_q.data_ptr(), None, None, None,
+                    1, full, C.byref(pot_desc), 1, fused["records"].data_ptr(), 0, grad_q.data_ptr(), None, None, None,
                 )
             elif need_q and topo is not None:
                 _call(
@@ -671,13 +678,27 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None)
     return dist
 
 
+_DOT_SCRATCH = {}
+
+
+def _dot_scratch(device):
+    """Persistent, zero-initialised scratch of ``mipme_dot_forward``, one per device (``weighted_sum`` calls on one device
+    must not run concurrently on several streams).  Not keyed on the stream: a CUDA-graph capture stream differs from the
+    warm-up stream, and a buffer created during capture would bake its zero fill into every replay."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _DOT_SCRATCH.get(key)
+    if buf is None:
+        buf = _DOT_SCRATCH[key] = torch.zeros((65,), dtype=torch.float64, device=device)
+    return buf
+
+
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         lib = _lib.load()
         a_c, b_c = a.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((), dtype=a.dtype, device=a.device)
-        scratch = torch.empty((64,), dtype=torch.float64, device=a.device)
+        scratch = _dot_scratch(a.device)
         with torch.cuda.device(a.device):
             _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
                   a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
