@@ -117,12 +117,16 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * (mipme_sr_rows_finalize) and mipme_kspace_backward is not needed.
  * out_records (4N reals, 16-byte aligned), nullable, same conditions: (x, y, z, q) per atom for mipme_sr_rows_fused
  * (records_ready = 1), written by the binning pass while the positions are in registers.
- * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time. */
+ * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time.
+ * rho_hat == NULL (allowed when mipme_fft_plan_xfused(plan) != 0, i.e. nx is a power of two): rfftn(rho) is not kept and
+ * the convolution runs as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT. */
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
                          void* out_field, void* out_records);
+
+int mipme_fft_plan_xfused(const mipme_fft_plan* plan);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).
  * (In the reference this is PyTorch autograd through the ATen chain)
@@ -132,7 +136,8 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
  * which also requires rho_hat, rho_dc, phi_atoms and grad_positions).
  * grad_scale (device scalar, nullable): "energy mode" -- promises grad_out == grad_scale[0] * charges (the gradient of
  * E = sum q V).  Then chi = (grad_scale/2V) phi, so the second spread, both FFTs and the filter are skipped and only the
- * gradient gather runs (needs phi_mesh and rho_dc; the work meshes may be NULL; grad_cell must be NULL). */
+ * gradient gather runs (needs phi_mesh and rho_dc; the work meshes may be NULL; grad_cell must be NULL).
+ * psi_hat == NULL (only without grad_cell, plans with mipme_fft_plan_xfused): fused convolution as in the forward. */
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                           const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,

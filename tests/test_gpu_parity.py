@@ -458,3 +458,34 @@ def test_fused_distances_guards():
         finally:
             ops.FUSE_DISTANCES = True
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("cell_diag,h", [((5.0, 9.0, 17.0), 1.1), ((3.0, 3.0, 3.0), 2.9), ((30.0, 7.0, 7.0), 0.6)])
+def test_fused_convolution(dtype, cell_diag, h, monkeypatch):
+    """(y,z) hipFFT planes + one x-FFT * G * inverse-x-FFT kernel (ops.XFUSED) against the 3-D hipFFT plans + filter
+    kernel, forward and general backward, several channels, unequal mesh sizes (nx from 4 to 128)."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(5)
+    N = 90
+    cell = torch.tensor(np.diag(cell_diag) + rng.normal(scale=0.1, size=(3, 3)), device=DEV, dtype=dtype)
+    pos = torch.tensor(rng.uniform(0, 1, (N, 3)) * np.array(cell_diag), device=DEV, dtype=dtype)
+    q = torch.tensor(rng.normal(size=(N, 2)), device=DEV, dtype=dtype)
+    g = torch.tensor(rng.normal(size=(N, 2)), device=DEV, dtype=dtype)
+    none = torch.zeros((0, 2), dtype=torch.int64, device=DEV)
+    nod = torch.zeros((0,), dtype=dtype, device=DEV)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "XFUSED", fused)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=h, interpolation_nodes=3)
+        p, c = pos.clone().requires_grad_(True), q.clone().requires_grad_(True)
+        calls = {}
+        monkeypatch.setattr(ops, "PROFILE", calls)
+        V = calc(c, cell, p, none, nod)
+        (V * g).sum().backward()
+        monkeypatch.setattr(ops, "PROFILE", None)
+        res.append((V.detach(), p.grad, c.grad))
+    tol = 1e-11 if dtype == torch.float64 else 2e-4
+    for a, b in zip(*res):
+        assert rell2(a.cpu(), b.cpu().numpy()) < tol

@@ -31,7 +31,7 @@ EXPORTS = (
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
     "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
-    "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed",
+    "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused",
 )
 
 
@@ -133,6 +133,8 @@ def _declare(lib):
     lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
     lib.mipme_nl_scratch_ints.restype = i64
     lib.mipme_nl_scratch_ints.argtypes = [C.POINTER(NlDesc), i64]
+    lib.mipme_fft_plan_xfused.restype = ci
+    lib.mipme_fft_plan_xfused.argtypes = [vp]
     lib.mipme_profile_enable.restype = ci
     lib.mipme_profile_enable.argtypes = [ci]
     lib.mipme_profile_report.restype = i64
@@ -206,6 +208,8 @@ class FFTPlan:
         with torch.cuda.device(device):
             check(load().mipme_fft_plan_create(dtype_code(dtype), int(ns[0]), int(ns[1]), int(ns[2]), int(batch), C.byref(handle)))
         self.handle = handle
+        #: the plan can run the convolution as (y,z) hipFFT planes + one fused x kernel (power-of-two nx)
+        self.xfused = bool(load().mipme_fft_plan_xfused(handle))
 
     def __del__(self):
         try:

@@ -33,6 +33,8 @@ int fft_plan_create(int, int, int, int, int, mipme_fft_plan**);
 int fft_plan_destroy(mipme_fft_plan*);
 int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
+bool fft_plan_xfused(const mipme_fft_plan*);
+int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
@@ -129,9 +131,14 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   } else {
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
   }
-  STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
-  STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
-  STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, phi_mesh));
+  if (!rho_hat) {
+    // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc));
+  } else {
+    STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
+    STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
+    STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, phi_mesh));
+  }
   // the short-range sum may be running on another stream into out_lr: join it before the gather adds to it
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
@@ -165,16 +172,22 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
     STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr));
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
-  STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
-  if (grad_cell) {
+  const bool xfused = !grad_cell && !psi_hat;
+  if (xfused) {
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc));
+  } else {
+    STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
+  }
+  if (xfused) {
+  } else if (grad_cell) {
     MIPME_REQUIRE(rho_hat && rho_dc && phi_atoms && partials && grad_pos,
                   "cell gradient needs rho_hat, rho_dc, phi_atoms, partials and grad_positions buffers");
     STAGE(st, "apply_filter_cellgrad", apply_filter_cellgrad_impl<T>(st, m, pot, psi_hat, rho_hat, G, hat_work, dc, partials));
   } else {
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, psi_hat, G, hat_work, dc));
   }
-  STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, chi_mesh));
+  if (!xfused) STAGE(st, "fft_c2r", fft_inverse(plan, st, hat_work, chi_mesh));
   if (bins)
     STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
   else
@@ -440,7 +453,8 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
-  MIPME_REQUIRE(G && rho_mesh && rho_hat && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(G && rho_mesh && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(rho_hat || fft_plan_xfused(plan), "rho_hat may only be NULL for plans with a power-of-two nx");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
@@ -463,8 +477,10 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
-  MIPME_REQUIRE(G && phi_mesh && (grad_scale || (psi_mesh && psi_hat && hat_work && chi_mesh && dc)),
+  MIPME_REQUIRE(G && phi_mesh && (grad_scale || (psi_mesh && hat_work && chi_mesh && dc)),
                 "NULL work buffer passed to mipme_kspace_backward");
+  MIPME_REQUIRE(grad_scale || psi_hat || (!grad_cell && fft_plan_xfused(plan)),
+                "psi_hat may only be NULL without a cell gradient and for plans with a power-of-two nx");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && grad_out), "NULL atom buffer passed to mipme_kspace_backward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   hipStream_t st = (hipStream_t)stream;
@@ -476,6 +492,8 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                                       rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
                                       grad_positions, grad_charges, grad_cell, bins, grad_scale));
 }
+
+int mipme_fft_plan_xfused(const mipme_fft_plan* plan) { return plan && fft_plan_xfused(plan) ? 1 : 0; }
 
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
   if (!mesh || n_atoms < 0) return 0;

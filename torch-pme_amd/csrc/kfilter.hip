@@ -333,6 +333,8 @@ __global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m,
 
 struct mipme_fft_plan {
   hipfftHandle fwd = 0, inv = 0;
+  // (y, z) plane transforms for the fused convolution (convolve_xfused): the x direction is done by xconv_kernel
+  hipfftHandle fwd2d = 0, inv2d = 0;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
@@ -365,6 +367,185 @@ static const char* fft_err(hipfftResult r) {
     }                                                                                   \
   } while (0)
 
+// ---- fused reciprocal-space convolution ------------------------------------------------------------------------
+// irfftn(rfftn(rho) * G) with hipFFT doing the (y, z) plane transforms and ONE kernel doing everything along x:
+// forward FFT over x, multiplication by G, inverse FFT over x -- per (ky, kz) column these three steps are independent
+// of every other column, so they need no pass through memory in between (the 3-D hipFFT plans spend a kernel on each
+// and the filter a third).  Decimation-in-frequency forward (natural -> bit-reversed order), pointwise product in
+// bit-reversed order, decimation-in-time inverse (bit-reversed -> natural): no reordering pass.  nx = 2^k (the mesh
+// sizes of get_ns_mesh are always powers of two, lib/kvectors.py:17-21); other sizes use the 3-D plans.
+static bool xfused_dims_ok(int nx) { return nx >= 2 && nx <= 2048 && (nx & (nx - 1)) == 0; }
+
+template <typename T>
+struct Cplx {
+  T re, im;
+};
+
+__device__ __forceinline__ void unit_root(int j, int n, float& re, float& im) { sincospif(-2.0f * float(j) / float(n), &im, &re); }
+__device__ __forceinline__ void unit_root(int j, int n, double& re, double& im) { sincospi(-2.0 * double(j) / double(n), &im, &re); }
+
+template <typename T>
+__device__ __forceinline__ Cplx<T> cmul(Cplx<T> a, Cplx<T> w) { return Cplx<T>{a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re}; }
+template <typename T>
+__device__ __forceinline__ Cplx<T> cmulc(Cplx<T> a, Cplx<T> w) { return Cplx<T>{a.re * w.re + a.im * w.im, a.im * w.re - a.re * w.im}; }
+template <typename T>
+__device__ __forceinline__ Cplx<T> cadd(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a.re + b.re, a.im + b.im}; }
+template <typename T>
+__device__ __forceinline__ Cplx<T> csub(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a.re - b.re, a.im - b.im}; }
+
+// One block: the columns (ky, kz0 .. kz0 + KZ) of channel c, all nx points of each, in LDS as tile[x][z] (KZ = 2^kzs
+// columns, padded ones compute on zeros).  Two radix-2 stages are done per pass by the thread that owns the four points
+// they couple, which halves the LDS round trips and barriers of the textbook radix-2 schedule without changing its
+// (bit-reversed) data order.
+template <typename T>
+__global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
+                                                   Cplx<T>* __restrict__ hat, const T* __restrict__ G,
+                                                   T* __restrict__ dc) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  const int KZ = 1 << kzs;
+  Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
+  Cplx<T>* tw = tile + size_t(nx) * KZ;                 // [nx/2]: exp(-2 pi i j / nx)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int chunk = blockIdx.x % nchunk;
+  const int ky = (blockIdx.x / nchunk) % ny;
+  const int c = blockIdx.x / (nchunk * ny);
+  const int kz0 = chunk << kzs;
+  const int kzn = min(KZ, nzh - kz0);
+  const int half_n = nx >> 1;
+  for (int j = tid; j < half_n; j += nthr) unit_root(j, nx, tw[j].re, tw[j].im);
+  Cplx<T>* col = hat + (int64_t(c) * nx * ny + ky) * nzh + kz0;  // element (x, z): col[x * ny * nzh + z]
+  const int64_t xs = int64_t(ny) * nzh;
+  const int n_el = nx << kzs;
+  for (int idx = tid; idx < n_el; idx += nthr) {
+    const int x = idx >> kzs, z = idx & (KZ - 1);
+    tile[idx] = z < kzn ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+  }
+  __syncthreads();
+  const int quarter = (nx >> 2) << kzs;  // 4-point groups per double stage
+  // ---- forward, decimation in frequency: stages m = nx, nx/2, ..., 2 (two per pass) ----
+  int s = log2nx;  // current sub-transform length m = 2^s
+  for (; s >= 2; s -= 2) {
+    const int q = 1 << (s - 2);  // m/4
+    const int f = nx >> s;       // nx/m
+    for (int b = tid; b < quarter; b += nthr) {
+      const int z = b & (KZ - 1), t = b >> kzs;
+      const int j = t & (q - 1);
+      const int i = ((t >> (s - 2)) << s) + j;
+      Cplx<T>* p = tile + (i << kzs) + z;
+      const int st = q << kzs;
+      const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+      const Cplx<T> u0 = cadd(x0, x2), u2 = cmul(csub(x0, x2), tw[j * f]);
+      const Cplx<T> u1 = cadd(x1, x3), u3 = cmul(csub(x1, x3), tw[(j + q) * f]);
+      const Cplx<T> w2 = tw[j * 2 * f];
+      p[0] = cadd(u0, u1);
+      p[st] = cmul(csub(u0, u1), w2);
+      p[2 * st] = cadd(u2, u3);
+      p[3 * st] = cmul(csub(u2, u3), w2);
+    }
+    __syncthreads();
+  }
+  if (s == 1) {  // last radix-2 stage (m = 2, twiddle 1)
+    for (int b = tid; b < (half_n << kzs); b += nthr) {
+      const int z = b & (KZ - 1), t = b >> kzs;
+      Cplx<T>* p = tile + ((2 * t) << kzs) + z;
+      const Cplx<T> a = p[0], bb = p[KZ];
+      p[0] = cadd(a, bb);
+      p[KZ] = csub(a, bb);
+    }
+    __syncthreads();
+  }
+  if (dc && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
+  // ---- product with G: position x holds kx = bitrev(x) ----
+  for (int idx = tid; idx < n_el; idx += nthr) {
+    const int x = idx >> kzs, z = idx & (KZ - 1);
+    if (z < kzn) {
+      const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+      const T gk = G[(int64_t(kx) * ny + ky) * nzh + kz0 + z];
+      Cplx<T> v = tile[idx];
+      v.re *= gk;
+      v.im *= gk;
+      tile[idx] = v;
+    }
+  }
+  __syncthreads();
+  // ---- inverse, decimation in time: stages m = 2, 4, ..., nx; conjugate twiddles, no normalisation
+  //      (kspace_filter.py:169-187: norm="backward" forward, norm="forward" inverse) ----
+  s = 0;  // next stage has half-length h = 2^s
+  if (log2nx & 1) {
+    for (int b = tid; b < (half_n << kzs); b += nthr) {
+      const int z = b & (KZ - 1), t = b >> kzs;
+      Cplx<T>* p = tile + ((2 * t) << kzs) + z;
+      const Cplx<T> a = p[0], bb = p[KZ];
+      p[0] = cadd(a, bb);
+      p[KZ] = csub(a, bb);
+    }
+    __syncthreads();
+    s = 1;
+  }
+  for (; s + 1 < log2nx + 1 && s + 2 <= log2nx; s += 2) {
+    const int h = 1 << s;              // stage lengths 2h then 4h
+    const int f2 = nx >> (s + 1);      // nx / 2h
+    const int f4 = nx >> (s + 2);      // nx / 4h
+    for (int b = tid; b < quarter; b += nthr) {
+      const int z = b & (KZ - 1), t = b >> kzs;
+      const int j = t & (h - 1);
+      const int i = ((t >> s) << (s + 2)) + j;
+      Cplx<T>* p = tile + (i << kzs) + z;
+      const int st = h << kzs;
+      const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+      const Cplx<T> w = tw[j * f2];
+      const Cplx<T> b1 = cmulc(x1, w), b3 = cmulc(x3, w);
+      const Cplx<T> u0 = cadd(x0, b1), u1 = csub(x0, b1), u2 = cadd(x2, b3), u3 = csub(x2, b3);
+      const Cplx<T> c2 = cmulc(u2, tw[j * f4]), c3 = cmulc(u3, tw[(j + h) * f4]);
+      p[0] = cadd(u0, c2);
+      p[2 * st] = csub(u0, c2);
+      p[st] = cadd(u1, c3);
+      p[3 * st] = csub(u1, c3);
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n_el; idx += nthr) {
+    const int x = idx >> kzs, z = idx & (KZ - 1);
+    if (z < kzn) col[x * xs + z] = tile[idx];
+  }
+}
+
+bool fft_plan_xfused(const mipme_fft_plan* p) { return p->fwd2d != 0 && p->inv2d != 0; }
+
+// mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
+int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
+                    void* dc) {
+  MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
+  MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
+  const int nzh = p->nz / 2 + 1;
+  int log2nx = 0;
+  while ((1 << log2nx) < p->nx) ++log2nx;
+  const size_t cs = p->dtype == MIPME_F32 ? 8 : 16;
+  // columns per block: a power of two giving >= 64-byte segments (8 complex floats / 4 complex doubles), tile <= 32 KiB
+  int kzs = p->dtype == MIPME_F32 ? 3 : 2;
+  while (kzs > 0 && cs * (size_t(p->nx) << kzs) > 32768) --kzs;
+  const int KZ = 1 << kzs;
+  const int nchunk = (nzh + KZ - 1) / KZ;
+  const unsigned grid = unsigned(nchunk) * unsigned(p->ny) * unsigned(p->batch);
+  const size_t lds = cs * ((size_t(p->nx) << kzs) + size_t(p->nx / 2));
+  int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  if (p->dtype == MIPME_F32) {
+    MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
+    xconv_kernel<float><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat, (const float*)G,
+                                                (float*)dc);
+    MIPME_LAUNCH_CHECK();
+    MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
+  } else {
+    MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
+    xconv_kernel<double><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
+                                                 (const double*)G, (double*)dc);
+    MIPME_LAUNCH_CHECK();
+    MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
+  }
+  return MIPME_OK;
+}
+
 int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {
   MIPME_REQUIRE(out != nullptr, "plan output pointer is NULL");
   MIPME_REQUIRE(nx > 0 && ny > 0 && nz > 0 && batch > 0, "invalid FFT dimensions %d %d %d x%d", nx, ny, nz, batch);
@@ -385,10 +566,22 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
   if (r == HIPFFT_SUCCESS)
     r = hipfftPlanMany(&p->inv, 3, n, cembed, 1, cdist, rembed, 1, rdist, dtype == MIPME_F32 ? HIPFFT_C2R : HIPFFT_Z2D,
                        batch);
+  if (r == HIPFFT_SUCCESS && xfused_dims_ok(nx)) {
+    int n2[2] = {ny, nz};
+    int rembed2[2] = {ny, nz};
+    int cembed2[2] = {ny, nz / 2 + 1};
+    r = hipfftPlanMany(&p->fwd2d, 2, n2, rembed2, 1, ny * nz, cembed2, 1, ny * (nz / 2 + 1),
+                       dtype == MIPME_F32 ? HIPFFT_R2C : HIPFFT_D2Z, nx * batch);
+    if (r == HIPFFT_SUCCESS)
+      r = hipfftPlanMany(&p->inv2d, 2, n2, cembed2, 1, ny * (nz / 2 + 1), rembed2, 1, ny * nz,
+                         dtype == MIPME_F32 ? HIPFFT_C2R : HIPFFT_Z2D, nx * batch);
+  }
   if (r != HIPFFT_SUCCESS) {
     set_error("hipfftPlanMany(%d,%d,%d x%d) failed: %s", nx, ny, nz, batch, fft_err(r));
     if (p->fwd) hipfftDestroy(p->fwd);
     if (p->inv) hipfftDestroy(p->inv);
+    if (p->fwd2d) hipfftDestroy(p->fwd2d);
+    if (p->inv2d) hipfftDestroy(p->inv2d);
     delete p;
     return MIPME_EFFT;
   }
@@ -400,6 +593,8 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     if (p->brick_count) (void)hipFree(p->brick_count);
     hipfftDestroy(p->fwd);
     hipfftDestroy(p->inv);
+    if (p->fwd2d) hipfftDestroy(p->fwd2d);
+    if (p->inv2d) hipfftDestroy(p->inv2d);
     delete p;
     return MIPME_EHIP;
   }
@@ -415,6 +610,8 @@ int fft_plan_destroy(mipme_fft_plan* p) {
   if (!p) return MIPME_OK;
   if (p->fwd) hipfftDestroy(p->fwd);
   if (p->inv) hipfftDestroy(p->inv);
+  if (p->fwd2d) hipfftDestroy(p->fwd2d);
+  if (p->inv2d) hipfftDestroy(p->inv2d);
   if (p->brick_count) (void)hipFree(p->brick_count);
   delete p;
   return MIPME_OK;

@@ -160,43 +160,62 @@ __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
   }
 }
 
-// Fast path of the fused row kernels for the smeared Coulomb potential without exclusion (mode 1, p = 1):
-//   v = pref erfc(y)/d,  (dv/dd) / d = -pref (erfc(y) + c2 d e^{-y^2}) / d^3,   y = c1 d, c1 = 1/(sigma sqrt 2), c2 = 2 c1/sqrt(pi)
-// from d^2.  The float version uses the hardware rsq / rcp / exp2 (1 ulp each) instead of IEEE division sequences and
-// libm range reduction: the generic sr_eval costs ~190 VALU slots per pair, which made the fused kernels VALU-bound.
-struct CoulombFast {
-  double c1, c2, pref;
+// Fast path of the fused row kernels for range-separated potentials without exclusion (mode 1) and a compile-time
+// exponent P:   v = pref Q(P/2, x) / d^P,   (dv/dd) / d = -pref (2 x dens + P Q) / d^(P+2),   x = d^2 / (2 sigma^2),
+// dens = x^(P/2-1) e^-x / Gamma(P/2), evaluated from d^2.  The float version uses the hardware rsq / rcp / exp2 (1 ulp
+// each) instead of IEEE division sequences and libm range reduction: the generic sr_eval costs ~190 VALU slots per pair,
+// which made the fused kernels VALU-bound.  P = 1 is the Coulomb potential.
+struct FastRS {
+  double inv_2s2, c1, pref;  // c1 = 1/(sigma sqrt 2)
 };
-inline CoulombFast make_coulomb_fast(const SRPot& s) {
-  CoulombFast c;
-  c.c1 = sqrt(s.inv_2s2);
-  c.c2 = 2.0 * c.c1 / sqrt(kPiR);
-  c.pref = s.pref;
-  return c;
-}
-inline bool is_coulomb_fast(const SRPot& s) { return s.mode == 1 && s.p == 1; }
+inline FastRS make_fast_rs(const SRPot& s) { return FastRS{s.inv_2s2, sqrt(s.inv_2s2), s.pref}; }
+// exponents with a dedicated instantiation (others take the generic sr_eval): Coulomb and dispersion
+inline int fast_rs_exponent(const SRPot& s) { return (s.mode == 1 && (s.p == 1 || s.p == 6)) ? s.p : 0; }
 
-template <bool DERIV>
-__device__ __forceinline__ void coulomb_fast_eval(float c1, float c2, float pref, float d2, float& v, float& sc) {
-  d2 = fmaxf(d2, 1e-30f);
-  const float inv = __builtin_amdgcn_rsqf(d2);
-  const float d = d2 * inv;
-  const float y = c1 * d;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (y * y));
-  const float er = erfc_from_exp_fast(y, e);
-  const float pi = pref * inv;
-  v = pi * er;
-  if constexpr (DERIV) sc = -(pi * inv * inv) * (er + c2 * d * e);
-}
-template <bool DERIV>
-__device__ __forceinline__ void coulomb_fast_eval(double c1, double c2, double pref, double d2, double& v, double& sc) {
-  d2 = fmax(d2, 1e-30);
-  const double d = sqrt(d2);
-  const double inv = 1.0 / d;
-  const double y = c1 * d;
-  const double er = erfc(y);
-  v = pref * er * inv;
-  if constexpr (DERIV) sc = -(pref * inv * inv * inv) * (er + c2 * d * exp(-y * y));
+__device__ __forceinline__ float rs_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double rs_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float rs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rs_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float rs_exp_neg(float x) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * x); }
+__device__ __forceinline__ double rs_exp_neg(double x) { return exp(-x); }
+__device__ __forceinline__ float rs_erfc(float y, float e) { return erfc_from_exp_fast(y, e); }
+__device__ __forceinline__ double rs_erfc(double y, double) { return erfc(y); }
+
+template <int P, bool DERIV, typename T>
+__device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v, T& dvd) {
+  d2 = d2 > T(1e-30) ? d2 : T(1e-30);
+  const T inv = rs_rsqrt(d2);
+  const T inv2 = inv * inv;
+  const T x = d2 * inv_2s2;
+  const T e = rs_exp_neg(x);
+  T Q, dens;
+  if constexpr (P % 2 == 0) {
+    T term = T(1), sum = T(1);
+#pragma unroll
+    for (int k = 1; k < P / 2; ++k) {
+      term *= x * T(1.0 / k);
+      sum += term;
+    }
+    Q = e * sum;
+    dens = e * term;
+  } else {
+    const T y = c1 * (d2 * inv);
+    Q = rs_erfc(y, e);
+    T term = e * T(0.56418958354775628695) * rs_rcp(y);
+    dens = term;
+#pragma unroll
+    for (int k = 1; k <= (P - 1) / 2; ++k) {
+      term *= x * T(1.0 / (k - 0.5));
+      Q += term;
+      dens = term;
+    }
+  }
+  T invp = inv;
+#pragma unroll
+  for (int k = 1; k < P; ++k) invp *= inv;
+  const T pi = pref * invp;
+  v = pi * Q;
+  if constexpr (DERIV) dvd = -(pi * inv2) * (T(2) * x * dens + T(P) * Q);
 }
 
 }  // namespace mipme

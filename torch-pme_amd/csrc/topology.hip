@@ -393,9 +393,9 @@ enum FusedMode {
   kForceG = 3,    // force sums with the general weights built from g and q
 };
 
-template <typename T, int MODE, bool CELLGRAD, bool CFAST, bool MASK>
+template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK>
 __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
-    SRPot s, CoulombFast cf, int64_t N, const int* __restrict__ row_ptr, const int2* __restrict__ ent_sh,
+    SRPot s, FastRS cf, int64_t N, const int* __restrict__ row_ptr, const int2* __restrict__ ent_sh,
     const int2* __restrict__ entries, const uint8_t* __restrict__ mask, const T* __restrict__ pos,
     const AtomRecord<T>* __restrict__ rec, const T* __restrict__ cell, const T* __restrict__ q,
     const T* __restrict__ g, int pot_lo, int pot_hi, bool full, bool accumulate, T* __restrict__ out,
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
   T A[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
-  const T c1 = T(cf.c1), c2 = T(cf.c2), cpref = T(cf.pref);
+  const T c_inv2s2 = T(cf.inv_2s2), c1 = T(cf.c1), cpref = T(cf.pref);
   const int sub = threadIdx.x % kRowLanes;
   unsigned a = blockIdx.x * kRowsPerBlock + threadIdx.x / kRowLanes;
   const bool valid = a < N;
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
       const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
       const T d2 = vx * vx + vy * vy + vz * vz;
       T v, dvd;  // v_SR(d) and v_SR'(d) / d
-      if constexpr (CFAST) {
-        coulomb_fast_eval<FORCE>(c1, c2, cpref, d2, v, dvd);
+      if constexpr (PFAST > 0) {
+        fast_rs_eval<PFAST, FORCE, T>(c_inv2s2, c1, cpref, d2, v, dvd);
       } else {
         const T d = fsqrt(d2);
         T dv;
@@ -671,8 +671,8 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   int lo = 0, hi = 1;
   if (full_list) lo = hi = transpose ? 1 : 0;
   const unsigned grid = row_blocks(N);
-  const CoulombFast cf = make_coulomb_fast(s);
-  const bool cfast = is_coulomb_fast(s);
+  const FastRS cf = make_fast_rs(s);
+  const int pfast = fast_rs_exponent(s);
   if (!records_ready) {
     pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
         N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
@@ -705,10 +705,12 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   } while (0)
 #define MIPME_FUSED_CF(MODE, CG)                                                                                      \
   do {                                                                                                                \
-    if (cfast)                                                                                                        \
-      MIPME_FUSED_MK(MODE, CG, true);                                                                                 \
+    if (pfast == 1)                                                                                                   \
+      MIPME_FUSED_MK(MODE, CG, 1);                                                                                    \
+    else if (pfast == 6)                                                                                              \
+      MIPME_FUSED_MK(MODE, CG, 6);                                                                                    \
     else                                                                                                              \
-      MIPME_FUSED_MK(MODE, CG, false);                                                                                \
+      MIPME_FUSED_MK(MODE, CG, 0);                                                                                    \
   } while (0)
 #define MIPME_FUSED_CG(MODE)                                                                                          \
   do {                                                                                                                \

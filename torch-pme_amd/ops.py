@@ -112,6 +112,10 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 # forward mesh: the backward then skips the second spread + FFT pair.  Any other upstream gradient takes the general path.
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
 
+# Reciprocal-space convolution as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two nx,
+# whenever rfftn(rho) itself is not needed, i.e. no cell gradient); "0" keeps the 3-D hipFFT plans + filter kernel.
+XFUSED = os.environ.get("MIPME_XFUSED", "1") != "0"
+
 
 # When ``neighbor_distances`` is the untouched output of :func:`pair_distances`, the calculator differentiates straight through
 # to the positions / cell the distances were built from: the row kernels recompute d from the L2-resident positions (one
@@ -347,7 +351,10 @@ class _PMEFunction(torch.autograd.Function):
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 rho_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 phi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
-                rho_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                # rfftn(rho) itself is only needed by the cell gradient; without it the convolution runs fused (see mipme.h)
+                rho_hat = None
+                if need_cell or not plan.xfused or not XFUSED:
+                    rho_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
@@ -377,7 +384,7 @@ class _PMEFunction(torch.autograd.Function):
                 _call(
                     "kspace_forward", lib.mipme_kspace_forward,
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                    G.data_ptr(), rho_mesh.data_ptr(), rho_hat.data_ptr(), hat_work.data_ptr(),
+                    G.data_ptr(), rho_mesh.data_ptr(), _lib.ptr(rho_hat), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
                     join.cuda_event if overlap else None, 1 if overlap else 0, _lib.ptr(field), _lib.ptr(records_out),
                 )
@@ -477,7 +484,9 @@ class _PMEFunction(torch.autograd.Function):
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 psi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 chi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
-                psi_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                psi_hat = None
+                if need_cell or not plan.xfused or not XFUSED:
+                    psi_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 if need_pos or need_cell:
@@ -492,7 +501,7 @@ class _PMEFunction(torch.autograd.Function):
                     "kspace_backward", lib.mipme_kspace_backward,
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                     g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
-                    _lib.ptr(phi_atoms), psi_mesh.data_ptr(), psi_hat.data_ptr(), hat_work.data_ptr(),
+                    _lib.ptr(phi_atoms), psi_mesh.data_ptr(), _lib.ptr(psi_hat), hat_work.data_ptr(),
                     chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
                     _lib.ptr(grad_cell), _lib.ptr(bins), None,
                 )
