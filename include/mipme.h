@@ -249,8 +249,11 @@ int64_t mipme_rows_partials_size(int64_t n_atoms);
  * d_e = |r_other - r_a + S A| from the L2-resident positions instead of gathering dist[p] / grad_dist[p] from P-sized
  * arrays, and apply the chain rule through d in the same pass.  Fuses Calculator._compute_rspace
  * (calculators/calculator.py:43-87) with the caller's compute_distances (tests/helpers.py:278-304) and their adjoints.
- *   entries_shift int32[2P][2] = { other atom, 3 x int8 cell shift } from mipme_topology_pack_entries
- *                 (shifts == NULL -> zero shifts; flag[0] != 0 -> some shift is not an integer in [-127,127]: unusable).
+ *   entries_shift int32[2P][2] = { other atom, cell-shift code } from mipme_topology_pack_entries (shifts == NULL -> zero
+ *                 shifts).  The shift is stored role-adjusted (S for role i, -S for role j).  shift_format 0: 3 x int8;
+ *                 1: index into a 7^3 table of Cartesian shift vectors kept in LDS (needs |s| <= 3, no pair mask).
+ *                 flag[0] bit 0: some shift is not an integer in [-127,127] (unusable); bit 1: some |s| > 3 (format 1
+ *                 unusable).
  *   out   (N) nullable: out[a] (+)= 1/2 sum_{potential roles} src[o] v_SR(d_e)          (transpose as mipme_rspace_rows)
  *   force (N,3) nullable, OVERWRITTEN: sum_e sign_e w_e v_SR'(d_e) vec_e / d_e with
  *         w_e = charges[o] when grad_out == NULL (finish with mipme_sr_rows_finalize: energy mode, g = gE * charges),
@@ -260,13 +263,14 @@ int64_t mipme_rows_partials_size(int64_t n_atoms);
  *         mipme_kspace_forward(out_records) -- and not repacked.
  *   partials nullable: float64[mipme_rows_partials_size(N)] per-block sums of the cell gradient; with grad_out != NULL
  *         and grad_cell != NULL they are reduced into grad_cell (3,3). */
-int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
-                                void* entries_shift, void* flag);
+int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, int64_t n_atoms, const void* row_ptr,
+                                const void* entries, const void* shifts, int shift_format, void* entries_shift,
+                                void* flag);
 int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
-                        const mipme_potential_t* pot, int accumulate, void* records, int records_ready, void* out,
-                        void* force, void* partials, void* grad_cell);
+                        const mipme_potential_t* pot, int accumulate, int shift_format, void* records,
+                        int records_ready, void* out, void* force, void* partials, void* grad_cell);
 /* grad_positions[a] = gE charges[a] (f force[a] + field[a]); grad_cell = f gE sum(partials); f = 1/2 for a full list,
  * gE = grad_scale[0].  force: from mipme_sr_rows_fused (nullable); field: out_field of mipme_kspace_forward (nullable). */
 int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* field,

@@ -489,3 +489,34 @@ def test_fused_convolution(dtype, cell_diag, h, monkeypatch):
     tol = 1e-11 if dtype == torch.float64 else 2e-4
     for a, b in zip(*res):
         assert rell2(a.cpu(), b.cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_fused_distances_large_shifts(with_mask, monkeypatch):
+    """Cutoff of several cell lengths: cell shifts beyond the +-3 range of the LDS shift table make the fused kernels fall
+    back to the 3 x int8 code; same numbers as the unfused path (also with a pair mask, which always takes that code)."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(2)
+    cell = np.array([[2.1, 0, 0], [0.3, 1.9, 0], [0.0, 0.2, 2.3]])
+    pos = rng.uniform(0, 2, (6, 3))
+    q = rng.normal(size=(6, 1))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 9.5)
+    assert np.abs(S).max() > 3
+    mask = torch.tensor(rng.uniform(size=len(pairs)) > 0.3, device=DEV) if with_mask else None
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "FUSE_DISTANCES", fuse)
+        tp = torch.tensor(pos, device=DEV, requires_grad=True)
+        tc = torch.tensor(cell, device=DEV, requires_grad=True)
+        tq = torch.tensor(q, device=DEV)
+        ti = torch.tensor(pairs, device=DEV)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.5), mesh_spacing=0.4, interpolation_nodes=4)
+        d = tpa.pair_distances(tp, ti, tc, torch.tensor(S, device=DEV))
+        V = calc(tq, tc, tp, ti, d, pair_mask=mask)
+        tpa.weighted_sum(V, tq).backward()
+        res.append((V.detach().cpu(), tp.grad.cpu(), tc.grad.cpu()))
+    topo = ops.get_topology(ti, 6)
+    assert topo.entries_with_shifts(torch.tensor(S, device=DEV, dtype=torch.float64))[1] == 0  # 3 x int8 code
+    for a, b in zip(*res):
+        assert rell2(a, b.numpy()) < 1e-10

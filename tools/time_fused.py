@@ -20,7 +20,7 @@ pairs = torch.tensor(w.pairs, device=dev)
 S = torch.tensor(w.shifts, dtype=f32, device=dev)
 N = pos.shape[0]
 topo = ops.get_topology(pairs, N)
-ent_sh = topo.entries_with_shifts(S)
+ent_sh, fmt = topo.entries_with_shifts(S)
 dist = tpa.pair_distances(pos, pairs, cell, S)
 pot = tpa.CoulombPotential(smearing=w.smearing)._descriptor()
 lib = _lib.load()
@@ -49,7 +49,7 @@ def fused(want_pot, want_force, grad):
     _lib.check(lib.mipme_sr_rows_fused(
         st, F32, N, topo.row_ptr.data_ptr(), ent_sh.data_ptr(), topo.entries.data_ptr(), None, pos.data_ptr(),
         cell.data_ptr(), q.data_ptr(), q.data_ptr() if want_pot else None, g.data_ptr() if grad else None, 0, 0,
-        C.byref(pot), 0, rec.data_ptr(), 0, out.data_ptr() if want_pot else None, force.data_ptr() if want_force else None, None, None))
+        C.byref(pot), 0, fmt, rec.data_ptr(), 0, out.data_ptr() if want_pot else None, force.data_ptr() if want_force else None, None, None))
 
 
 def unfused():

@@ -119,26 +119,52 @@ __global__ void topo_pack_shifts_kernel(int64_t E, const int2* __restrict__ entr
 }
 
 
-// Entry stream of the fused kernels: int2 {other atom, 3 x int8 cell shift} per entry (shifts == NULL -> zero shifts).
+// Entry stream of the fused kernels: int2 {other atom, cell-shift code} per entry (shifts == NULL -> zero shifts).
+// The shift is stored ROLE-ADJUSTED: S for a role-i entry, -S for a role-j entry, so that for both roles
+//   u_e = r_other - r_a + S'_e A   has |u_e| = d_p and  d d_p / d r_a = -u_e / d_p   (no per-entry sign in the kernels).
+// Code formats: kShiftPacked = 3 x int8 (little end first); kShiftTable = index (sx+3) + 7 (sy+3) + 49 (sz+3) into the
+// 343-entry table of Cartesian shift vectors the kernel keeps in LDS (needs |s| <= 3).
+// flag bits: 1 = some shift is not an integer in [-127,127]; 2 = some |shift| > 3 (table format unusable).
+enum ShiftFormat { kShiftPacked = 0, kShiftTable = 1 };
+static constexpr int kShiftTableRange = 3, kShiftTableBase = 2 * kShiftTableRange + 1;
+static constexpr int kShiftTableSize = kShiftTableBase * kShiftTableBase * kShiftTableBase;
+
 template <typename T>
-__global__ void topo_pack_entries_kernel(int64_t E, const int2* __restrict__ entries, const T* __restrict__ shifts,
+__global__ void topo_pack_entries_kernel(int64_t E, int64_t n_rows, const int* __restrict__ row_ptr,
+                                         const int2* __restrict__ entries, const T* __restrict__ shifts, int format,
                                          int2* __restrict__ ent_sh, int* __restrict__ flag) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int2 en = entries[e];
-  int word = 0;
-  bool bad = false;
+  // role of the entry: the half-row r (largest r with row_ptr[r] <= e) is odd for role j
+  int64_t lo = 0, hi = n_rows;
+  while (lo < hi) {
+    const int64_t m = (lo + hi + 1) >> 1;
+    if (row_ptr[m] <= e)
+      lo = m;
+    else
+      hi = m - 1;
+  }
+  const int sgn = (lo & 1) ? -1 : 1;
+  int sh[3] = {0, 0, 0};
+  int bits = 0;
   if (shifts) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const T sh = shifts[3 * int64_t(en.y) + k];
-      const T r = rint(sh);
-      bad |= (r != sh) || (r > T(127)) || (r < T(-127));
-      word |= (int(r) & 0xff) << (8 * k);
+      const T v = shifts[3 * int64_t(en.y) + k];
+      const T r = rint(v);
+      if ((r != v) || (r > T(127)) || (r < T(-127))) bits |= 1;
+      sh[k] = sgn * int(r);
+      if (sh[k] > kShiftTableRange || sh[k] < -kShiftTableRange) bits |= 2;
     }
   }
+  int word;
+  if (format == kShiftTable)
+    word = (sh[0] + kShiftTableRange) + kShiftTableBase * ((sh[1] + kShiftTableRange) + kShiftTableBase * (sh[2] + kShiftTableRange));
+  else
+    word = (sh[0] & 0xff) | ((sh[1] & 0xff) << 8) | ((sh[2] & 0xff) << 16);
   ent_sh[e] = make_int2(en.x, word);
-  if (bad) atomicOr(flag, 1);
+  if (bits) atomicOr(flag, bits);
 }
 
 // ---- owner-computes pair kernels ---------------------------------------------------------------
@@ -393,7 +419,7 @@ enum FusedMode {
   kForceG = 3,    // force sums with the general weights built from g and q
 };
 
-template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK>
+template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE>
 __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
     SRPot s, FastRS cf, int64_t N, const int* __restrict__ row_ptr, const int2* __restrict__ ent_sh,
     const int2* __restrict__ entries, const uint8_t* __restrict__ mask, const T* __restrict__ pos,
@@ -408,12 +434,24 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
 #pragma unroll
   for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
   const T c_inv2s2 = T(cf.inv_2s2), c1 = T(cf.c1), cpref = T(cf.pref);
+  __shared__ AtomRecord<T> shift_tab[TABLE ? kShiftTableSize : 1];  // Cartesian shift vector of every table code
+  if constexpr (TABLE) {
+    for (int k = threadIdx.x; k < kShiftTableSize; k += 256) {
+      const T sx = T(k % kShiftTableBase - kShiftTableRange), sy = T((k / kShiftTableBase) % kShiftTableBase - kShiftTableRange),
+              sz = T(k / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
+      shift_tab[k] = AtomRecord<T>{sx * A[0] + sy * A[3] + sz * A[6], sx * A[1] + sy * A[4] + sz * A[7],
+                                   sx * A[2] + sy * A[5] + sz * A[8], T(0)};
+    }
+    __syncthreads();
+  }
   const int sub = threadIdx.x % kRowLanes;
   unsigned a = blockIdx.x * kRowsPerBlock + threadIdx.x / kRowLanes;
   const bool valid = a < N;
   if (!valid) a = unsigned(N - 1);
   const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
   const int pbeg = pot_lo == 0 ? r0 : mid, pend = pot_hi == 0 ? mid : r2;  // entries that feed the potential
+  // in the potential + force pass (roles i and j both visited) a full list feeds the potential from role i only
+  const int pot_end = (MODE == kPotForce && full) ? mid : 0x7fffffff;
   const int beg = FORCE ? r0 : pbeg;
   const int end = valid ? (FORCE ? r2 : pend) : beg;
   const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
@@ -471,12 +509,20 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
       const bool role_i = e < mid;
       bool use = ok[u];
       if constexpr (MASK) use = use && mk[u] != 0;
-      const T sign = role_i ? T(-1) : T(1);
-      const T sx = T(unpack8(en[u].y, 0)), sy = T(unpack8(en[u].y, 1)), sz = T(unpack8(en[u].y, 2));
-      // vec = r_j - r_i + S A: role i -> (r_o - r_a) + S A ; role j -> (r_a - r_o) + S A
-      const T vx = -sign * (ox[u] - ax) + (sx * A[0] + sy * A[3] + sz * A[6]);
-      const T vy = -sign * (oy[u] - ay) + (sx * A[1] + sy * A[4] + sz * A[7]);
-      const T vz = -sign * (oz[u] - az) + (sx * A[2] + sy * A[5] + sz * A[8]);
+      // u = r_o - r_a + S' A with the role-adjusted shift S' (see topo_pack_entries_kernel): |u| = d, d d / d r_a = -u / d
+      T shx, shy, shz;
+      if constexpr (TABLE) {
+        const AtomRecord<T> sh = shift_tab[en[u].y];
+        shx = sh.x;
+        shy = sh.y;
+        shz = sh.z;
+      } else {
+        const T sx = T(unpack8(en[u].y, 0)), sy = T(unpack8(en[u].y, 1)), sz = T(unpack8(en[u].y, 2));
+        shx = sx * A[0] + sy * A[3] + sz * A[6];
+        shy = sx * A[1] + sy * A[4] + sz * A[7];
+        shz = sx * A[2] + sy * A[5] + sz * A[8];
+      }
+      const T vx = (ox[u] - ax) + shx, vy = (oy[u] - ay) + shy, vz = (oz[u] - az) + shz;
       const T d2 = vx * vx + vy * vy + vz * vz;
       T v, dvd;  // v_SR(d) and v_SR'(d) / d
       if constexpr (PFAST > 0) {
@@ -489,7 +535,7 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
       }
       const T sv = use ? so[u] : T(0);  // masked / padding entries carry zero weight
       if constexpr (POT) {
-        const bool in_pot = MODE == kPot || (e >= pbeg && e < pend);
+        const bool in_pot = MODE == kPot || e < pot_end;
         pot += (in_pot ? sv : T(0)) * v;
       }
       if constexpr (FORCE) {
@@ -501,11 +547,22 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
           w = sv;
         }
         const T sc = w * dvd;
-        fx += sign * sc * vx;
-        fy += sign * sc * vy;
-        fz += sign * sc * vz;
+        fx -= sc * vx;
+        fy -= sc * vy;
+        fz -= sc * vz;
         if constexpr (CELLGRAD) {
-          if (role_i) {
+          if (role_i) {  // role i: S' = S and u is the pair vector itself
+            T sx, sy, sz;
+            if constexpr (TABLE) {
+              const int code = en[u].y;
+              sx = T(code % kShiftTableBase - kShiftTableRange);
+              sy = T((code / kShiftTableBase) % kShiftTableBase - kShiftTableRange);
+              sz = T(code / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
+            } else {
+              sx = T(unpack8(en[u].y, 0));
+              sy = T(unpack8(en[u].y, 1));
+              sz = T(unpack8(en[u].y, 2));
+            }
             const double wq = MODE == kForceG ? 1.0 : double(qa);
             const double px = wq * double(sc * vx), py = wq * double(sc * vy), pz = wq * double(sc * vz);
             cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
@@ -659,8 +716,8 @@ template <typename T>
 static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, const void* ent_sh, const void* entries,
                               const void* mask, const void* pos, const void* cell, const void* q, const void* src,
                               const void* g, int transpose, int full_list, const mipme_potential_t* pot, int accumulate,
-                              void* records, int records_ready, void* out, void* force, void* partials,
-                              void* grad_cell) {
+                              int shift_format, void* records, int records_ready, void* out, void* force,
+                              void* partials, void* grad_cell) {
   SRPot s;
   int rc = make_srpot(pot, s);
   if (rc) return rc;
@@ -673,6 +730,8 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   const unsigned grid = row_blocks(N);
   const FastRS cf = make_fast_rs(s);
   const int pfast = fast_rs_exponent(s);
+  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable, "invalid shift format %d", shift_format);
+  MIPME_REQUIRE(!(mask && shift_format == kShiftTable), "a pair mask needs entries packed in the int8 shift format");
   if (!records_ready) {
     pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
         N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
@@ -691,17 +750,19 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
     set_error("mipme_sr_rows_fused: nothing to compute");
     return MIPME_EINVAL;
   }
-#define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK)                                                                         \
-  sr_fused_rows_kernel<T, MODE, CG, CF, MK><<<grid, 256, 0, st>>>(                                                    \
+#define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK, TB)                                                                     \
+  sr_fused_rows_kernel<T, MODE, CG, CF, MK, TB><<<grid, 256, 0, st>>>(                                                    \
       s, cf, N, (const int*)row_ptr, (const int2*)ent_sh, (const int2*)entries, (const uint8_t*)mask, (const T*)pos,  \
       (const AtomRecord<T>*)records, (const T*)cell, (const T*)q, (const T*)g, lo, hi, full_list != 0,                \
       accumulate != 0, (T*)out, (T*)force, (double*)partials)
 #define MIPME_FUSED_MK(MODE, CG, CF)                                                                                  \
   do {                                                                                                                \
     if (mask)                                                                                                         \
-      MIPME_FUSED_LAUNCH_(MODE, CG, CF, true);                                                                        \
+      MIPME_FUSED_LAUNCH_(MODE, CG, CF, true, false);                                                                 \
+    else if (shift_format == kShiftTable)                                                                             \
+      MIPME_FUSED_LAUNCH_(MODE, CG, CF, false, true);                                                                 \
     else                                                                                                              \
-      MIPME_FUSED_LAUNCH_(MODE, CG, CF, false);                                                                       \
+      MIPME_FUSED_LAUNCH_(MODE, CG, CF, false, false);                                                                \
   } while (0)
 #define MIPME_FUSED_CF(MODE, CG)                                                                                      \
   do {                                                                                                                \
@@ -838,9 +899,11 @@ int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, 
   return MIPME_EINVAL;
 }
 
-int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const void* entries, const void* shifts,
-                                void* entries_shift, void* flag) {
-  MIPME_REQUIRE(n_pairs >= 0 && flag, "invalid arguments to mipme_topology_pack_entries");
+int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, int64_t n_atoms, const void* row_ptr,
+                                const void* entries, const void* shifts, int shift_format, void* entries_shift,
+                                void* flag) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && flag && row_ptr, "invalid arguments to mipme_topology_pack_entries");
+  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable, "invalid shift format %d", shift_format);
   hipStream_t st = (hipStream_t)stream;
   MIPME_CHECK_HIP(zero_async(flag, sizeof(int), st));
   const int64_t E = 2 * n_pairs;
@@ -848,11 +911,13 @@ int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const 
   MIPME_REQUIRE(entries && entries_shift, "NULL buffer passed to mipme_topology_pack_entries");
   const unsigned grid = unsigned((E + 255) / 256);
   if (dtype == MIPME_F32)
-    topo_pack_entries_kernel<float><<<grid, 256, 0, st>>>(E, (const int2*)entries, (const float*)shifts,
-                                                          (int2*)entries_shift, (int*)flag);
+    topo_pack_entries_kernel<float><<<grid, 256, 0, st>>>(E, 2 * n_atoms, (const int*)row_ptr, (const int2*)entries,
+                                                          (const float*)shifts, shift_format, (int2*)entries_shift,
+                                                          (int*)flag);
   else if (dtype == MIPME_F64)
-    topo_pack_entries_kernel<double><<<grid, 256, 0, st>>>(E, (const int2*)entries, (const double*)shifts,
-                                                           (int2*)entries_shift, (int*)flag);
+    topo_pack_entries_kernel<double><<<grid, 256, 0, st>>>(E, 2 * n_atoms, (const int*)row_ptr, (const int2*)entries,
+                                                           (const double*)shifts, shift_format, (int2*)entries_shift,
+                                                           (int*)flag);
   else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;
@@ -864,8 +929,8 @@ int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, const 
 int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries_shift,
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
-                        const mipme_potential_t* pot, int accumulate, void* records, int records_ready, void* out,
-                        void* force, void* partials, void* grad_cell) {
+                        const mipme_potential_t* pot, int accumulate, int shift_format, void* records,
+                        int records_ready, void* out, void* force, void* partials, void* grad_cell) {
   MIPME_REQUIRE(n_atoms >= 0 && row_ptr, "invalid arguments to mipme_sr_rows_fused");
   MIPME_REQUIRE(n_atoms == 0 || (entries_shift && positions && charges && records), "NULL buffer passed to mipme_sr_rows_fused");
   MIPME_REQUIRE(!pair_mask || entries, "`pair_mask` needs the (other, pair) entry table");
@@ -875,10 +940,12 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIPME_F32)
     return sr_fused_rows_impl<float>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
-                                     src, grad_out, transpose, full_list, pot, accumulate, records, records_ready, out, force, partials, grad_cell);
+                                     src, grad_out, transpose, full_list, pot, accumulate, shift_format, records, records_ready, out, force, partials,
+                                     grad_cell);
   if (dtype == MIPME_F64)
     return sr_fused_rows_impl<double>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
-                                      src, grad_out, transpose, full_list, pot, accumulate, records, records_ready, out, force, partials, grad_cell);
+                                      src, grad_out, transpose, full_list, pot, accumulate, shift_format, records, records_ready, out, force, partials,
+                                     grad_cell);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
 }

@@ -210,29 +210,40 @@ class PairTopology:
         self._pair_sh = (weakref.ref(key), key._version, packed)
         return packed
 
-    def entries_with_shifts(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None):
-        """int32 (2P, 2) table {other atom, 3 x int8 cell shift} for the fused kernels, or None if the shifts are not small
-        integers.  Cached per shifts tensor like :meth:`packed_shifts`."""
+    def entries_with_shifts(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None, table: bool = True):
+        """``(ent_sh, shift_format)``: the int32 (2P, 2) stream {other atom, role-adjusted cell-shift code} of the fused
+        kernels, or ``(None, 0)`` if the shifts are not small integers.  ``table`` asks for the LDS-table code (format 1,
+        |s| <= 3), falling back to 3 x int8 (format 0).  Cached per (shifts tensor, requested format)."""
         key = shifts if key is None else key
-        c = self._ent_sh
+        c = self._ent_sh.get(bool(table)) if isinstance(self._ent_sh, dict) else None
         if c is not None and ((key is None and c[0] is None) or (key is not None and c[0] is not None and c[0]() is key
                                                                    and c[1] == key._version)):
-            return c[2]
+            return c[2], c[3]
         lib = _lib.load()
         device = self.entries.device
         ent_sh = torch.empty((max(2 * self.n_pairs, 1), 2), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):
-            _lib.check(
-                lib.mipme_topology_pack_entries(
-                    _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
-                    self.n_pairs, self.entries.data_ptr(), _lib.ptr(shifts), ent_sh.data_ptr(), flag.data_ptr(),
+        fmt = 1 if table else 0
+        while True:
+            with torch.cuda.device(device):
+                _lib.check(
+                    lib.mipme_topology_pack_entries(
+                        _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
+                        self.n_pairs, self.n_atoms, self.row_ptr.data_ptr(), self.entries.data_ptr(), _lib.ptr(shifts),
+                        fmt, ent_sh.data_ptr(), flag.data_ptr(),
+                    )
                 )
-            )
-        if shifts is not None and int(flag.item()) != 0:
-            ent_sh = None
-        self._ent_sh = (None if key is None else weakref.ref(key), 0 if key is None else key._version, ent_sh)
-        return ent_sh
+            bits = int(flag.item()) if shifts is not None else 0
+            if bits & 1:
+                ent_sh = None
+            elif fmt == 1 and bits & 2:
+                fmt = 0  # shifts beyond the table range: repack as 3 x int8
+                continue
+            break
+        if not isinstance(self._ent_sh, dict):
+            self._ent_sh = {}
+        self._ent_sh[bool(table)] = (None if key is None else weakref.ref(key), 0 if key is None else key._version, ent_sh, fmt)
+        return ent_sh, fmt
 
 
 class DistanceSource:
@@ -307,10 +318,10 @@ class _PMEFunction(torch.autograd.Function):
             topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
             fused = None
             if src is not None:
-                ent_sh = topo.entries_with_shifts(src.shifts, src.shifts_key)
+                ent_sh, shift_fmt = topo.entries_with_shifts(src.shifts, src.shifts_key, table=mask is None)
                 if ent_sh is not None:
                     fused = dict(
-                        ent_sh=ent_sh, pos=src_positions.detach().contiguous(),
+                        ent_sh=ent_sh, fmt=shift_fmt, pos=src_positions.detach().contiguous(),
                         cell=None if src_cell is None else src_cell.detach().contiguous(), force=None, partials=None,
                         records=torch.empty((N, 4), dtype=dtype, device=device),
                     )
@@ -328,7 +339,7 @@ class _PMEFunction(torch.autograd.Function):
                         "rspace_forward", lib.mipme_sr_rows_fused,
                         stream, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                         _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), q.data_ptr(), None,
-                        0, int(full_list), C.byref(pot_desc), accumulate, fused["records"].data_ptr(),
+                        0, int(full_list), C.byref(pot_desc), accumulate, fused["fmt"], fused["records"].data_ptr(),
                         int(fused.get("records_ready", False)), out.data_ptr(), _lib.ptr(fused["force"]),
                         _lib.ptr(fused["partials"]), None,
                     )
@@ -558,7 +569,7 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward", lib.mipme_sr_rows_fused,
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
-                    0, full, C.byref(pot_desc), 0, fused["records"].data_ptr(), 0, None, grad_src_pos.data_ptr(),
+                    0, full, C.byref(pot_desc), 0, fused["fmt"], fused["records"].data_ptr(), 0, None, grad_src_pos.data_ptr(),
                     _lib.ptr(partials), _lib.ptr(grad_src_cell),
                 )
                 if not need_src_pos:
@@ -572,7 +583,8 @@ class _PMEFunction(torch.autograd.Function):
                     "rspace_backward_charges", lib.mipme_sr_rows_fused,
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), g.data_ptr(), None,
-                    1, full, C.byref(pot_desc), 1, fused["records"].data_ptr(), 0, grad_q.data_ptr(), None, None, None,
+                    1, full, C.byref(pot_desc), 1, fused["fmt"], fused["records"].data_ptr(), 0, grad_q.data_ptr(), None, None,
+                    None,
                 )
             elif need_q and topo is not None:
                 _call(
