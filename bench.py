@@ -71,13 +71,18 @@ class Frame:
         return E.detach(), self.pos.grad
 
 
-def algorithmic_bytes(w, s: int):
-    """minimum HBM bytes per energy+forces step and per pair kernel."""
+def algorithmic_bytes(w, s: int, fused: bool = True):
+    """Minimum HBM bytes per energy+forces step (reference data formats) and per kernel launch.
+
+    Per kernel the figure is what the launch must move IN THE FORMAT IT READS, never more than SURVEY's figure for the
+    reference formats: the distance kernel streams int32 pairs + one packed shift word + writes d (8 + 4 + s bytes per
+    pair instead of 16 + 3s + s), and the fused pair kernel streams two 8-byte entries per pair and reads neither d nor
+    dL/dd (16 bytes per pair; SURVEY's three kernels it replaces add up to 48 + 7s).  DESIGN.md section 2 lists both."""
     P, N, M = w.n_pairs, w.n_atoms, w.n_mesh**3
     per_kernel = {
-        "pair_distance_forward": P * (16 + 3 * s + s) + N * 3 * s,
+        "pair_distance_forward": (P * (8 + 4 + s) if fused else P * (16 + 3 * s + s)) + N * 3 * s,
         "pair_distance_backward": P * (16 + 3 * s + s) + N * 6 * s,
-        "rspace_forward": P * (16 + s) + N * 2 * s,
+        "rspace_forward": (2 * P * 8 + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
         "rspace_backward": P * (16 + 2 * s) + N * 3 * s,
         # mesh stages (the meshes themselves are L2 / Infinity-Cache resident at these sizes)
         "spread": N * 4 * s + 2 * M * s,
@@ -86,7 +91,13 @@ def algorithmic_bytes(w, s: int):
         "fft_r2c": 2 * M * s,
         "fft_c2r": 2 * M * s,
         "apply_filter": int(2.5 * M * s),
+        # (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT: the three stages above in one composite
+        "convolve_xfused": int(6.5 * M * s),
         "bin_atoms": N * (3 * s + 8 + 16 + 4 * s),
+        # energy reduction E = sum q V, its adjoint, and the energy-mode force assembly gE q_a (f F_a + field_a)
+        "energy_sum": N * 2 * s,
+        "energy_sum_backward": N * 3 * s,
+        "forces_finalize": N * 10 * s,
     }
     step = P * (32 + 3 * s) + P * (32 + 8 * s) + N * 25 * s + 19 * M * s
     return step, per_kernel
@@ -287,7 +298,7 @@ def main():
         del f64
 
     if rank == 0:
-        step_bytes, per_kernel = algorithmic_bytes(w, s)
+        step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES)
         pair_kernels = {k: v for k, v in prof.items() if k in per_kernel}
         pair_kernels.update({k: v for k, v in stages.items() if k in per_kernel})
         # dominant kernel = the longest single launch (an HBM-streaming pair kernel at these sizes); the per-kernel
