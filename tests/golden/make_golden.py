@@ -16,6 +16,8 @@ Fixtures written:
                      reference potentials, energies and forces
   conventions.npz    stencil / weight / k-grid / filter known answers
   direct.npz         exact direct-sum molecules (tests/calculators/test_values_direct.py)
+  tuning.npz         a-priori error estimates (tuning/p3m.py, tuning/pme.py) and smearing estimates (tuning/tuner.py)
+                     on two structures for a grid of (smearing, mesh_spacing, cutoff, nodes)
 """
 
 import math
@@ -286,8 +288,39 @@ def make_direct():
     np.savez(os.path.join(HERE, "direct.npz"), **out)
 
 
+def make_tuning():
+    from torchpme.tuning.p3m import P3MErrorBounds
+    from torchpme.tuning.pme import PMEErrorBounds
+    from torchpme.tuning.tuner import TunerBase
+
+    rng = np.random.default_rng(42)
+    structures = {
+        "pair": (np.array([[1.0], [-1.0]]), np.eye(3), np.array([[0.0, 0.0, 0.0], [0.4, 0.4, 0.4]])),
+        "tri": (rng.normal(size=(11, 1)), np.array([[6.0, 0, 0], [0.8, 7.0, 0], [-0.4, 0.5, 9.0]]),
+                rng.uniform(0, 6, (11, 3))),
+    }
+    out = {}
+    for name, (q, cell, pos) in structures.items():
+        out[f"{name}/charges"], out[f"{name}/cell"], out[f"{name}/positions"] = q, cell, pos
+        tq, tc, tp = t(q), t(cell), t(pos)
+        rows = []
+        for smearing, h, rc in ((1.0, 0.5, 4.4), (0.7, 0.3, 3.0), (1.6, 0.9, 6.5)):
+            for nodes in range(1, 8):
+                p3m = float(P3MErrorBounds(tq, tc, tp)(smearing=smearing, mesh_spacing=h, cutoff=rc, interpolation_nodes=nodes)) if nodes <= 7 else np.nan
+                pme = float(PMEErrorBounds(tq, tc, tp)(smearing=smearing, mesh_spacing=h, cutoff=rc, interpolation_nodes=nodes)) if nodes >= 3 else np.nan
+                rows.append((smearing, h, rc, nodes, p3m, pme))
+        out[f"{name}/bounds"] = np.array(rows)  # smearing, mesh_spacing, cutoff, nodes, P3M estimate, PME estimate
+        out[f"{name}/smearing"] = np.array([[rc, acc, TunerBase(tq, tc, tp, rc, None).estimate_smearing(acc)]
+                                             for rc in (3.0, 4.4, 6.0) for acc in (1e-1, 1e-3, 1e-6)])
+    np.savez(os.path.join(HERE, "tuning.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "tuning":
+        make_tuning()
+        sys.exit(0)
+    make_tuning()
     make_crystals()
     make_gromacs()
     make_ref_small()

@@ -146,3 +146,44 @@ def test_module_to_and_state_dict():
     assert torch.isfinite(out).all()
     d = calc.potential._descriptor()
     assert d.smearing == pytest.approx(0.3, rel=1e-6) and d.prefactor == 2.0 and d.exponent == 2
+
+
+@pytest.mark.parametrize("tune,Calc,nodes_hi", [(tpa.tune_p3m, tpa.P3MCalculator, 5), (tpa.tune_pme, tpa.PMECalculator, 7)])
+@pytest.mark.parametrize("accuracy", [1e-1, 1e-3, 1e-5])
+@pytest.mark.parametrize("full", [False, True])
+def test_tuned_parameters_reach_accuracy(tune, Calc, nodes_hi, accuracy, full):
+    """Reference tests/tuning/test_tuning.py:47-107: the tuned (smearing, nodes, mesh_spacing) reproduce the Madelung
+    constant of CsCl within the requested accuracy; here the candidates are timed on the GPU."""
+    dtype = torch.float64
+    positions = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.5]], dtype=dtype, device=DEV)
+    charges = torch.tensor([[-1.0], [1.0]], dtype=dtype, device=DEV)
+    cell = torch.eye(3, dtype=dtype, device=DEV)
+    madelung_ref = 2.035361
+    cutoff = 4.4
+    pairs, _, dist = tpa.neighbor_list(positions.cpu().numpy(), cell.cpu().numpy(), cutoff, full_list=full)
+    pairs, dist = torch.tensor(pairs, device=DEV), torch.tensor(dist, device=DEV)
+    smearing, params, timing = tune(charges, cell, positions, cutoff, neighbor_indices=pairs, neighbor_distances=dist,
+                                    full_neighbor_list=full, accuracy=accuracy)
+    assert set(params) == {"interpolation_nodes", "mesh_spacing"} and 0 < timing < 1.0
+    assert params["interpolation_nodes"] <= nodes_hi
+    calc = Calc(potential=tpa.CoulombPotential(smearing=smearing), full_neighbor_list=full, **params)
+    calc.to(device=DEV, dtype=dtype)
+    potentials = calc.forward(positions=positions, charges=charges, cell=cell, neighbor_indices=pairs,
+                              neighbor_distances=dist)
+    madelung = -float(torch.sum(potentials * charges))
+    assert madelung == pytest.approx(madelung_ref, rel=accuracy)
+
+
+def test_tuning_timer():
+    """Reference tests/tuning/test_timer.py: positive, and the total grows with the number of repeats."""
+    from torchpme_amd.tuning import TuningTimings
+
+    w = tpa.workloads.ionic_box(n_side=8, n_mesh=16, cutoff=4.4)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)  # noqa: E731
+    pos, cell, q = t(w.positions), t(w.cell), t(w.charges)
+    pairs = torch.tensor(w.pairs, device=DEV)
+    dist = tpa.pair_distances(pos, pairs, cell, t(w.shifts)).detach()
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=w.mesh_spacing)
+    t1 = TuningTimings(q, cell, pos, pairs, dist, n_repeat=4)(calc)
+    t2 = TuningTimings(q, cell, pos, pairs, dist, n_repeat=16, run_backward=False)(calc)
+    assert 0 < t2 < t1 < 0.1

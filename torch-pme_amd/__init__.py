@@ -6,13 +6,14 @@ The directory is named ``torch-pme_amd``; import it as ``torchpme_amd`` (see ``t
 repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI in ``include/mipme.h``).
 """
 
-from . import lib, prefactors  # noqa: F401
+from . import lib, prefactors, tuning, workloads  # noqa: F401
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces
 from .neighbors import neighbor_list, neighbor_list_device
 from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
+from .tuning import tune_p3m, tune_pme
 
 __version__ = "0.1.0"
 
@@ -28,4 +29,6 @@ __all__ = [
     "GraphedEnergyForces",
     "neighbor_list",
     "neighbor_list_device",
+    "tune_p3m",
+    "tune_pme",
 ]
