@@ -277,6 +277,28 @@ int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void*
                            const void* charges, const void* grad_scale, int full_list, const void* partials,
                            void* grad_positions, void* grad_cell);
 
+/* ---- explicit Ewald sum: EwaldCalculator._compute_kspace, calculators/ewald.py:76-142 -------
+ * k-vectors (K,3) are caller supplied (lib/kvectors.py:105-166 builds them from the cell; the host layer does that with
+ * differentiable tensor ops so that the cell gradient flows through them).  The (K,N) phase tables of the reference are
+ * never materialised.  All arrays in `dtype`; s_* / t_* are (K,C), G / dG (K).
+ *   mipme_ewald_filter     G[k] = v_LR^(|k|^2), dG[k] = dG/d(|k|^2) (nullable)         (Potential.lr_from_k_sq)
+ *   mipme_ewald_structure  out_cos[k,c] = sum_i w[i,c] cos(k r_i), out_sin likewise    (w = charges, or the upstream gradient)
+ *   mipme_ewald_potential  out[i,c] = sum_k G[k] (cos(k r_i) s_cos[k,c] + sin(k r_i) s_sin[k,c])   (no 1/V; OVERWRITES)
+ *   mipme_ewald_backward   with S = structure(charges), T = structure(grad_out):
+ *        grad_positions[i] = sum_k G[k] k B(i,k),  grad_kvectors[k] = G[k] sum_i r_i B(i,k) + 2 dG[k] k sum_c (T.S),
+ *        B(i,k) = sum_c [ g_ic (cos S_sin - sin S_cos) + q_ic (cos T_sin - sin T_cos) ]   (either output nullable)
+ *   (the charge gradient is mipme_ewald_potential with T in place of S) */
+int mipme_ewald_filter(void* stream, int dtype, const mipme_potential_t* pot, int64_t n_k, const void* kvectors, void* G,
+                       void* dG);
+int mipme_ewald_structure(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
+                          const void* weights, const void* kvectors, void* out_cos, void* out_sin);
+int mipme_ewald_potential(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
+                          const void* kvectors, const void* G, const void* s_cos, const void* s_sin, void* out);
+int mipme_ewald_backward(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
+                         const void* charges, const void* grad_out, const void* kvectors, const void* G, const void* dG,
+                         const void* s_cos, const void* s_sin, const void* t_cos, const void* t_sin,
+                         void* grad_positions, void* grad_kvectors);
+
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
  * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------
  * Scope: fully periodic cells with >= 3 cells of perpendicular width >= cutoff per axis (n_cells[d] = floor(width_d /

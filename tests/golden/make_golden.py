@@ -16,6 +16,8 @@ Fixtures written:
                      reference potentials, energies and forces
   conventions.npz    stencil / weight / k-grid / filter known answers
   direct.npz         exact direct-sum molecules (tests/calculators/test_values_direct.py)
+  ref_ewald.npz      EwaldCalculator potentials + autograd gradients (7-atom triclinic cell): Coulomb and 1/r^p, several
+                     channels, 2-D periodic slab, user-supplied k-vectors, node mask, full list
   tuning.npz         a-priori error estimates (tuning/p3m.py, tuning/pme.py) and smearing estimates (tuning/tuner.py)
                      on two structures for a grid of (smearing, mesh_spacing, cutoff, nodes)
 """
@@ -288,6 +290,66 @@ def make_direct():
     np.savez(os.path.join(HERE, "direct.npz"), **out)
 
 
+def make_ref_ewald():
+    from torchpme.lib import generate_kvectors_for_ewald
+
+    rng = np.random.default_rng(77)
+    cell = np.array([[4, 0, 0], [0.5, 5, 0], [0.3, -0.4, 6]], dtype=np.float64)
+    N, P = 7, 14
+    out = {"cell": cell}
+    #        kind       p  C  periodic             full   lr_wl  own_k  node_mask
+    cases = [("coulomb", 1, 1, None, False, 1.3, False, False),
+             ("coulomb", 1, 2, None, True, 0.9, False, False),
+             ("coulomb", 1, 1, [True, True, False], False, 1.1, False, False),
+             ("coulomb", 1, 1, [False, True, True], False, 1.1, False, True),
+             ("coulomb", 1, 1, None, False, 1.0, True, False),
+             ("ipl", 1, 1, None, False, 1.2, False, False),
+             ("ipl", 2, 1, None, False, 1.2, False, False),
+             ("ipl", 3, 2, None, False, 1.2, False, False),
+             ("ipl", 4, 1, None, False, 1.2, False, False),
+             ("ipl", 5, 1, None, False, 1.2, False, False),
+             ("ipl", 6, 1, None, True, 1.2, False, True)]
+    names = []
+    for ci, (kind, p, C, periodic, full, wl, own_k, use_mask) in enumerate(cases):
+        pos = rng.uniform(-2, 7, (N, 3))
+        q = rng.normal(size=(N, C))
+        pairs = rng.integers(0, N, (P, 2))
+        pairs[:, 1] = (pairs[:, 0] + 1 + rng.integers(0, N - 1, P)) % N
+        dist = rng.uniform(0.8, 3.0, P)
+        g = rng.normal(size=(N, C))
+        sm, pref = 0.9, 1.3
+        pot = (torchpme.CoulombPotential(smearing=sm, prefactor=pref) if kind == "coulomb"
+               else torchpme.InversePowerLawPotential(exponent=p, smearing=sm, prefactor=pref))
+        calc = torchpme.EwaldCalculator(pot, lr_wavelength=wl, full_neighbor_list=full)
+        tq, tc, tp, td = t(q, grad=True), t(cell, grad=True), t(pos, grad=True), t(dist, grad=True)
+        per = None if periodic is None else torch.tensor(periodic)
+        kv = None
+        if own_k:  # a caller-supplied set: the vectors of a coarser grid, zero padded (lib/kvectors.py:139-166)
+            kv0 = generate_kvectors_for_ewald(ns=torch.tensor([3, 4, 5]), cell=t(cell))
+            kv = torch.cat([kv0, torch.zeros((5, 3), dtype=torch.float64)])
+            out[f"e{ci:02d}/kvectors"] = kv.numpy()
+        mask = None
+        if use_mask:
+            mask = torch.tensor(rng.uniform(size=N) > 0.3)
+            out[f"e{ci:02d}/node_mask"] = mask.numpy()
+        V = calc(tq, tc, tp, torch.tensor(pairs), td, periodic=per, kvectors=kv, node_mask=mask)
+        (V * t(g)).sum().backward()
+        nm = f"e{ci:02d}"
+        names.append(nm)
+        meta = dict(kind=kind, exponent=p, smearing=sm, prefactor=pref, lr_wavelength=wl, periodic=periodic,
+                    full_list=full, own_kvectors=own_k, node_mask=use_mask)
+        out[f"{nm}/meta"] = np.array(repr(meta))
+        for key, val in dict(positions=pos, charges=q, pairs=pairs, dist=dist, g=g, V=V.detach().numpy(),
+                             grad_charges=tq.grad.numpy(), grad_positions=tp.grad.numpy(),
+                             grad_cell=None if own_k else tc.grad.numpy(), grad_dist=td.grad.numpy()).items():
+            if val is not None:
+                out[f"{nm}/{key}"] = val
+        if own_k:  # with caller-supplied k-vectors the cell only enters through the volume
+            out[f"{nm}/grad_cell"] = tc.grad.numpy()
+    out["names"] = np.array(names)
+    np.savez(os.path.join(HERE, "ref_ewald.npz"), **out)
+
+
 def make_tuning():
     from torchpme.tuning.p3m import P3MErrorBounds
     from torchpme.tuning.pme import PMEErrorBounds
@@ -317,10 +379,11 @@ def make_tuning():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "tuning":
-        make_tuning()
+    if len(sys.argv) > 1 and sys.argv[1] in ("tuning", "ewald"):
+        {"tuning": make_tuning, "ewald": make_ref_ewald}[sys.argv[1]]()
         sys.exit(0)
     make_tuning()
+    make_ref_ewald()
     make_crystals()
     make_gromacs()
     make_ref_small()

@@ -520,3 +520,58 @@ def test_fused_distances_large_shifts(with_mask, monkeypatch):
     assert topo.entries_with_shifts(torch.tensor(S, device=DEV, dtype=torch.float64))[1] == 0  # 3 x int8 code
     for a, b in zip(*res):
         assert rell2(a, b.numpy()) < 1e-10
+
+
+def test_ref_ewald_all_cases(golden_dir):
+    """EwaldCalculator: V and the gradients w.r.t. charges, positions, cell and distances against the
+    reference's autograd for every golden case (Coulomb / 1/r^p, channels, slab, own k-vectors, node mask, full list)."""
+    z = np.load(f"{golden_dir}/ref_ewald.npz")
+    for nm in [str(n) for n in z["names"]]:
+        meta = ast.literal_eval(str(z[f"{nm}/meta"]))
+        pot = (tpa.CoulombPotential(smearing=meta["smearing"], prefactor=meta["prefactor"]) if meta["kind"] == "coulomb"
+               else tpa.InversePowerLawPotential(exponent=meta["exponent"], smearing=meta["smearing"],
+                                                 prefactor=meta["prefactor"]))
+        calc = tpa.EwaldCalculator(pot, lr_wavelength=meta["lr_wavelength"], full_neighbor_list=meta["full_list"])
+        t = lambda k, grad=False: torch.tensor(z[f"{nm}/{k}"], device=DEV, requires_grad=grad)  # noqa: E731
+        q, pos, d = t("charges", True), t("positions", True), t("dist", True)
+        cell = torch.tensor(z["cell"], device=DEV, requires_grad=True)
+        per = None if meta["periodic"] is None else torch.tensor(meta["periodic"], device=DEV)
+        kv = t("kvectors") if meta["own_kvectors"] else None
+        mask = t("node_mask") if meta["node_mask"] else None
+        V = calc(q, cell, pos, t("pairs"), d, periodic=per, kvectors=kv, node_mask=mask)
+        (V * t("g")).sum().backward()
+        errs = dict(V=relmax(V.detach().cpu(), z[f"{nm}/V"]), q=relmax(q.grad.cpu(), z[f"{nm}/grad_charges"]),
+                    pos=relmax(pos.grad.cpu(), z[f"{nm}/grad_positions"]), cell=relmax(cell.grad.cpu(), z[f"{nm}/grad_cell"]),
+                    d=relmax(d.grad.cpu(), z[f"{nm}/grad_dist"]))
+        for k, v in errs.items():
+            assert v < 1e-9, (nm, meta, k, v)
+        # fp32 evaluation of the same case
+        V32 = calc(q.detach().float(), cell.detach().float(), pos.detach().float(), t("pairs"), d.detach().float(),
+                   periodic=per, kvectors=None if kv is None else kv.float(), node_mask=mask)
+        assert V32.dtype == torch.float32 and relmax(V32.cpu().double(), z[f"{nm}/V"]) < 2e-4, (nm, meta)
+
+
+@pytest.mark.parametrize("crystal", CRYSTALS)
+def test_madelung_ewald(golden_dir, crystal):
+    """Literature Madelung constants with the Ewald sum (reference tests/calculators/test_values_ewald.py:65-152,
+    lr_wavelength = smearing / 2)."""
+    z = np.load(f"{golden_dir}/crystals.npz")
+    pos_np, cell_np, q_np = z[f"{crystal}/positions"], z[f"{crystal}/cell"], z[f"{crystal}/charges"]
+    rc = 2.0
+    sm = rc / 5.0
+    calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=sm), lr_wavelength=0.5 * sm)
+    pairs, S, dist = tpa.neighbor_list(pos_np, cell_np, rc)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    V = calc(t(q_np), t(cell_np), t(pos_np), t(pairs), t(dist))
+    energy = float((V.cpu().numpy() * q_np).sum())
+    madelung = float(z[f"{crystal}/madelung"])
+    assert abs(-energy / int(z[f"{crystal}/n_formula"]) - madelung) / madelung < 9e-4
+
+
+def test_ewald_constructor_errors():
+    with pytest.raises(ValueError, match="Must specify range radius to use a potential with EwaldCalculator"):
+        tpa.EwaldCalculator(tpa.CoulombPotential(smearing=None), lr_wavelength=1.0)
+    with pytest.raises(ValueError, match="`smearing` is -1.0 but must be positive"):
+        tpa.EwaldCalculator(tpa.CoulombPotential(smearing=-1.0), lr_wavelength=1.0)
+    with pytest.raises(ValueError, match="`lr_wavelength` is -0.5 but must be positive"):
+        tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=-0.5)

@@ -28,6 +28,7 @@ CALCULATORS = [
     (tpa.P3MCalculator, dict(potential=tpa.CoulombPotential(smearing=0.1), mesh_spacing=0.1)),
     (tpa.P3MCalculator, dict(potential=tpa.InversePowerLawPotential(exponent=3, smearing=0.1), mesh_spacing=0.1,
                              interpolation_nodes=3)),
+    (tpa.EwaldCalculator, dict(potential=tpa.CoulombPotential(smearing=0.1), lr_wavelength=0.1)),
 ]
 
 
@@ -148,7 +149,8 @@ def test_module_to_and_state_dict():
     assert d.smearing == pytest.approx(0.3, rel=1e-6) and d.prefactor == 2.0 and d.exponent == 2
 
 
-@pytest.mark.parametrize("tune,Calc,nodes_hi", [(tpa.tune_p3m, tpa.P3MCalculator, 5), (tpa.tune_pme, tpa.PMECalculator, 7)])
+@pytest.mark.parametrize("tune,Calc,nodes_hi", [(tpa.tune_p3m, tpa.P3MCalculator, 5), (tpa.tune_pme, tpa.PMECalculator, 7),
+                                                (tpa.tune_ewald, tpa.EwaldCalculator, None)])
 @pytest.mark.parametrize("accuracy", [1e-1, 1e-3, 1e-5])
 @pytest.mark.parametrize("full", [False, True])
 def test_tuned_parameters_reach_accuracy(tune, Calc, nodes_hi, accuracy, full):
@@ -164,8 +166,11 @@ def test_tuned_parameters_reach_accuracy(tune, Calc, nodes_hi, accuracy, full):
     pairs, dist = torch.tensor(pairs, device=DEV), torch.tensor(dist, device=DEV)
     smearing, params, timing = tune(charges, cell, positions, cutoff, neighbor_indices=pairs, neighbor_distances=dist,
                                     full_neighbor_list=full, accuracy=accuracy)
-    assert set(params) == {"interpolation_nodes", "mesh_spacing"} and 0 < timing < 1.0
-    assert params["interpolation_nodes"] <= nodes_hi
+    assert 0 < timing < 1.0
+    if nodes_hi is None:
+        assert set(params) == {"lr_wavelength"}
+    else:
+        assert set(params) == {"interpolation_nodes", "mesh_spacing"} and params["interpolation_nodes"] <= nodes_hi
     calc = Calc(potential=tpa.CoulombPotential(smearing=smearing), full_neighbor_list=full, **params)
     calc.to(device=DEV, dtype=dtype)
     potentials = calc.forward(positions=positions, charges=charges, cell=cell, neighbor_indices=pairs,

@@ -183,3 +183,17 @@ def test_torch_cpu_oracle(golden_dir, name, scheme):
     assert abs(E.item() / float(z[f"{name}/f64/energy"]) - 1) < 1e-12
     assert relmax(pos.grad.numpy(), z[f"{name}/f64/grad_positions"]) < 1e-10
     assert relmax(cell.grad.numpy(), z[f"{name}/f64/grad_cell"]) < 1e-10
+
+
+def test_ref_ewald_oracle(golden_dir):
+    """oracle.ewald_forward against the reference's EwaldCalculator: Coulomb and 1/r^p, channels, slab, caller-supplied
+    k-vectors, node mask, full list."""
+    z = np.load(f"{golden_dir}/ref_ewald.npz")
+    for nm in [str(n) for n in z["names"]]:
+        meta = ast.literal_eval(str(z[f"{nm}/meta"]))
+        spec = O.PotentialSpec(meta["kind"], meta["exponent"], meta["smearing"], meta["prefactor"])
+        kv = z[f"{nm}/kvectors"] if meta["own_kvectors"] else None
+        mask = z[f"{nm}/node_mask"] if meta["node_mask"] else None
+        V = O.ewald_forward(spec, meta["lr_wavelength"], z[f"{nm}/charges"], z["cell"], z[f"{nm}/positions"],
+                            z[f"{nm}/pairs"], z[f"{nm}/dist"], meta["full_list"], meta["periodic"], None, kv, mask)
+        assert relmax(V, z[f"{nm}/V"]) < 1e-12, (nm, meta)

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 import torchpme_amd as tpa
-from torchpme_amd.tuning import GridSearchTuner, P3MErrorBounds, PMEErrorBounds, TunerBase, tune_p3m, tune_pme
+from torchpme_amd.tuning import (EwaldErrorBounds, GridSearchTuner, P3MErrorBounds, PMEErrorBounds, TunerBase, tune_ewald,
+                                 tune_p3m, tune_pme)
 
 
 @pytest.mark.parametrize("name", ["pair", "tri"])
@@ -35,6 +36,8 @@ def test_error_bounds_known_values():
     out = PMEErrorBounds(charges, cell, positions)(**kw)
     assert isinstance(out, torch.Tensor) and out.dtype == torch.float32
     torch.testing.assert_close(out, torch.tensor(0.0011180))
+    torch.testing.assert_close(EwaldErrorBounds(charges, cell, positions)(smearing=1.0, lr_wavelength=0.5, cutoff=4.4),
+                               torch.tensor(8.4304e-05))  # tests/tuning/test_error_bounds.py:12-16
     assert float(P3MErrorBounds(charges, cell, positions)(**kw)) == pytest.approx(4.5968e-4, rel=1e-4)
     assert TunerBase(charges, cell, positions, 4.4, None).estimate_smearing(1e-3) == pytest.approx(1.1069526756106463)
     # the real-space part is shared and the total is the root of the sum of squares
@@ -46,7 +49,7 @@ def system():
     return torch.ones((4, 1)), torch.eye(3), 0.3 * torch.arange(12, dtype=torch.float32).reshape((4, 3))
 
 
-@pytest.mark.parametrize("tune", [tune_pme, tune_p3m])
+@pytest.mark.parametrize("tune", [tune_ewald, tune_pme, tune_p3m])
 def test_tuner_argument_errors(tune):
     charges, cell, positions = system()
     pairs, dist = torch.tensor([[0, 1]]), torch.tensor([0.5])

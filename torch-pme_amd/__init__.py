@@ -8,17 +8,18 @@ repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI 
 
 from . import lib, prefactors, tuning, workloads  # noqa: F401
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
-from .calculators import Calculator, P3MCalculator, PMECalculator
+from .calculators import Calculator, EwaldCalculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces
 from .neighbors import neighbor_list, neighbor_list_device
 from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
-from .tuning import tune_p3m, tune_pme
+from .tuning import tune_ewald, tune_p3m, tune_pme
 
 __version__ = "0.1.0"
 
 __all__ = [
     "Calculator",
+    "EwaldCalculator",
     "P3MCalculator",
     "PMECalculator",
     "CoulombPotential",
@@ -29,6 +30,7 @@ __all__ = [
     "GraphedEnergyForces",
     "neighbor_list",
     "neighbor_list_device",
+    "tune_ewald",
     "tune_p3m",
     "tune_pme",
 ]

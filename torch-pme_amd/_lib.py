@@ -32,6 +32,7 @@ EXPORTS = (
     "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused",
+    "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
 )
 
 
@@ -111,6 +112,10 @@ def _declare(lib):
         "mipme_pair_distance_forward_packed": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, ci, vp, ci, vp, vp, vp, vp],
         "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
+        "mipme_ewald_filter": [vp, ci, PP, i64, vp, vp, vp],
+        "mipme_ewald_structure": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp],
+        "mipme_ewald_potential": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp, vp],
+        "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12,
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],

@@ -9,8 +9,10 @@ to ``charges``, ``cell``, ``positions`` and ``neighbor_distances``.
 
 from __future__ import annotations
 
+import math
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -157,3 +159,80 @@ class P3MCalculator(PMECalculator):
     _scheme = _lib.P3M
     _orders = (1, 2, 3, 4, 5)
     _scheme_name = "P3M"
+
+
+class EwaldCalculator(Calculator):
+    r"""Ewald summation: real-space pair sum + explicit reciprocal-space sum over all k-vectors with wavelength
+    ``>= lr_wavelength`` (reference ``calculators/ewald.py:8-142``).  O(N K); meant for small cells.
+
+    The (K, N) phase sums run in ``csrc/ewald.hip``; k-vector generation (``lib/kvectors.py:24-74,105-136``: integer
+    frequencies times the reciprocal cell), the 1/V factor and the self / background / slab terms are a handful of small
+    tensor ops here, so that the cell gradient is autograd's.  ``kvectors`` may be supplied by the caller; ``node_mask``
+    masks atoms of the result.  Batched (3-D, ``torch.vmap``) inputs are not supported.
+
+    :param potential: potential with a positive ``smearing``
+    :param lr_wavelength: spatial resolution of the reciprocal-space part
+    :param full_neighbor_list: see :class:`Calculator`
+    """
+
+    def __init__(self, potential: Potential, lr_wavelength: float, full_neighbor_list: bool = False):
+        super().__init__(potential=potential, full_neighbor_list=full_neighbor_list)
+        if potential.smearing is None:
+            raise ValueError("Must specify range radius to use a potential with EwaldCalculator")
+        if potential.smearing <= 0:
+            raise ValueError(f"`smearing` is {potential.smearing} but must be positive")
+        if lr_wavelength <= 0:
+            raise ValueError(f"`lr_wavelength` is {lr_wavelength} but must be positive")
+        self.lr_wavelength: float = lr_wavelength
+        self._freq_cache = None  # (weakref(cell), version, device) -> integer frequency table (K, 3)
+
+    def _frequencies(self, cell: torch.Tensor) -> torch.Tensor:
+        """Integer frequencies (K,3) of all k-vectors: ``fftfreq(ns_d) * ns_d`` per axis, ``ns_d = ceil(|a_d| /
+        lr_wavelength)``, x-major order, the zero vector first.  The mesh size needs the cell on the host (as in the
+        reference, ``ewald.py:88-93``); cached per cell tensor."""
+        c = self._freq_cache
+        if c is not None and c[0]() is cell and c[1] == cell._version and c[2] == cell.device and c[3] == self.lr_wavelength:
+            return c[4]
+        norms = np.linalg.norm(cell.detach().to("cpu", torch.float64).numpy(), axis=1)
+        ns = np.ceil(norms / self.lr_wavelength).astype(np.int64)
+        f = [np.fft.fftfreq(int(n)) * int(n) for n in ns]
+        F = np.stack(np.meshgrid(*f, indexing="ij"), axis=-1).reshape(-1, 3)
+        freq = torch.tensor(F, dtype=cell.dtype, device=cell.device)
+        self._freq_cache = (weakref.ref(cell), cell._version, cell.device, self.lr_wavelength, freq)
+        return freq
+
+    def forward(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
+                pair_mask=None, kvectors=None):
+        _validate_parameters(
+            charges=charges, cell=cell, positions=positions, neighbor_indices=neighbor_indices,
+            neighbor_distances=neighbor_distances, periodic=periodic, pair_mask=pair_mask, node_mask=node_mask,
+            kvectors=kvectors,
+        )
+        _lib.require_device(positions, "positions")
+        if charges.dim() != 2:
+            raise NotImplementedError("EwaldCalculator: batched (padded) inputs are not supported by this build")
+        pot_desc = self.potential._descriptor()
+        sr = ops.pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, None, None,
+                               pot_desc, bool(self.full_neighbor_list), None)
+        if kvectors is None:
+            # k = 2 pi F A^-T (kvectors.py:47-74); differentiable w.r.t. the cell
+            kvectors = (2 * math.pi) * self._frequencies(cell) @ torch.linalg.inv(cell).T
+        volume = torch.abs(torch.det(cell))
+        lr = ops.ewald_kspace(charges, positions, kvectors, pot_desc) / volume
+        p = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+        two_s2 = 2.0 * pot_desc.smearing**2
+        self_c = pot_desc.prefactor / math.gamma(0.5 * p + 1.0) / two_s2 ** (0.5 * p)
+        lr = lr - charges * self_c
+        if p < 3:
+            bg = pot_desc.prefactor * math.pi**1.5 * two_s2 ** (0.5 * (3 - p)) / ((3 - p) * math.gamma(0.5 * p))
+            lr = lr - (2.0 * bg) * charges.sum(dim=0) / volume
+        if periodic is not None and p == 1:
+            axis = ops._slab_axis(periodic.tolist())
+            if axis is not None:  # 2-D periodic slab, potentials/coulomb.py:6-40
+                z = positions[:, axis : axis + 1]
+                Lz = torch.linalg.norm(cell[axis])
+                Q, M, M2 = charges.sum(dim=0), (charges * z).sum(dim=0), (charges * z * z).sum(dim=0)
+                lr = lr + pot_desc.prefactor * (4 * math.pi / volume) * (z * M - 0.5 * (M2 + Q * z * z) - Q / 12.0 * Lz * Lz)
+        if node_mask is not None:
+            lr = lr * node_mask.unsqueeze(-1)
+        return sr + lr / 2

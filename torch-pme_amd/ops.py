@@ -750,3 +750,66 @@ def weighted_sum(potentials: torch.Tensor, charges: torch.Tensor) -> torch.Tenso
         raise ValueError("`potentials` and `charges` must have the same shape and dtype")
     _lib.require_device(potentials, "potentials")
     return _WeightedSum.apply(potentials, charges)
+
+
+class _EwaldKSpace(torch.autograd.Function):
+    """``core[i,c] = sum_k G(k) [cos(k r_i) S_c(k,c) + sin(k r_i) S_s(k,c)]`` with S the structure factors of the charges:
+    the reciprocal-space sum of ``EwaldCalculator`` (reference ``calculators/ewald.py:97-113``) without the 1/V factor.
+    Differentiable w.r.t. charges, positions and the k-vectors (through which the cell gradient flows)."""
+
+    @staticmethod
+    def forward(ctx, charges, positions, kvectors, pot_desc):
+        lib = _lib.load()
+        device, dtype = positions.device, positions.dtype
+        dt = _lib.dtype_code(dtype)
+        q, pos, kv = charges.detach().contiguous(), positions.detach().contiguous(), kvectors.detach().contiguous()
+        N, Cn = q.shape
+        K = kv.shape[0]
+        G = torch.empty((K,), dtype=dtype, device=device)
+        dG = torch.empty((K,), dtype=dtype, device=device)
+        Sc = torch.empty((K, Cn), dtype=dtype, device=device)
+        Ss = torch.empty((K, Cn), dtype=dtype, device=device)
+        out = torch.empty((N, Cn), dtype=dtype, device=device)
+        with torch.cuda.device(device):
+            st = _lib.current_stream(device)
+            _call("ewald_filter", lib.mipme_ewald_filter, st, dt, C.byref(pot_desc), K, kv.data_ptr(), G.data_ptr(),
+                  dG.data_ptr())
+            _call("ewald_structure", lib.mipme_ewald_structure, st, dt, N, Cn, K, pos.data_ptr(), q.data_ptr(),
+                  kv.data_ptr(), Sc.data_ptr(), Ss.data_ptr())
+            _call("ewald_potential", lib.mipme_ewald_potential, st, dt, N, Cn, K, pos.data_ptr(), kv.data_ptr(),
+                  G.data_ptr(), Sc.data_ptr(), Ss.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(q, pos, kv, G, dG, Sc, Ss)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        q, pos, kv, G, dG, Sc, Ss = ctx.saved_tensors
+        need_q, need_pos, need_k = ctx.needs_input_grad[:3]
+        device, dtype = pos.device, pos.dtype
+        dt = _lib.dtype_code(dtype)
+        N, Cn = q.shape
+        K = kv.shape[0]
+        g = grad_out.contiguous()
+        Tc = torch.empty((K, Cn), dtype=dtype, device=device)
+        Ts = torch.empty((K, Cn), dtype=dtype, device=device)
+        grad_q = torch.empty((N, Cn), dtype=dtype, device=device) if need_q else None
+        grad_pos = torch.empty((N, 3), dtype=dtype, device=device) if need_pos else None
+        grad_k = torch.empty((K, 3), dtype=dtype, device=device) if need_k else None
+        with torch.cuda.device(device):
+            st = _lib.current_stream(device)
+            _call("ewald_structure", lib.mipme_ewald_structure, st, dt, N, Cn, K, pos.data_ptr(), g.data_ptr(),
+                  kv.data_ptr(), Tc.data_ptr(), Ts.data_ptr())
+            if need_q:  # the sum is symmetric in (q, g): same kernel with the structure factors of g
+                _call("ewald_potential", lib.mipme_ewald_potential, st, dt, N, Cn, K, pos.data_ptr(), kv.data_ptr(),
+                      G.data_ptr(), Tc.data_ptr(), Ts.data_ptr(), grad_q.data_ptr())
+            if need_pos or need_k:
+                _call("ewald_backward", lib.mipme_ewald_backward, st, dt, N, Cn, K, pos.data_ptr(), q.data_ptr(),
+                      g.data_ptr(), kv.data_ptr(), G.data_ptr(), dG.data_ptr(), Sc.data_ptr(), Ss.data_ptr(),
+                      Tc.data_ptr(), Ts.data_ptr(), _lib.ptr(grad_pos), _lib.ptr(grad_k))
+        return grad_q, grad_pos, grad_k, None
+
+
+def ewald_kspace(charges, positions, kvectors, pot_desc):
+    return _EwaldKSpace.apply(charges, positions, kvectors, pot_desc)

@@ -25,7 +25,7 @@ from warnings import warn
 import torch
 
 from ._utils import _validate_parameters
-from .calculators import P3MCalculator, PMECalculator
+from .calculators import EwaldCalculator, P3MCalculator, PMECalculator
 from .potentials import CoulombPotential
 
 # a_m^(P) of Deserno & Holm, Table II: P = charge assignment order (interpolation nodes), m = 0 .. P-1
@@ -111,6 +111,19 @@ class PMEErrorBounds(TuningErrorBounds):
 
     def error(self, cutoff: float, smearing: float, mesh_spacing: float, interpolation_nodes: float) -> torch.Tensor:
         return self._combine(smearing, mesh_spacing, cutoff, interpolation_nodes)
+
+
+class EwaldErrorBounds(TuningErrorBounds):
+    """A-priori RMS force error of :class:`EwaldCalculator` (reference ``tuning/ewald.py:126-211``)."""
+
+    def err_kspace(self, smearing, lr_wavelength):
+        smearing, lr_wavelength = float(smearing), float(lr_wavelength)
+        return (math.sqrt(self.prefac) / smearing / math.pi / math.sqrt(self.volume / lr_wavelength)
+                * math.exp(-2.0 * (math.pi * smearing / lr_wavelength) ** 2))
+
+    def error(self, smearing: float, lr_wavelength: float, cutoff: float) -> torch.Tensor:
+        k, r = self.err_kspace(smearing, lr_wavelength), self.err_rspace(smearing, cutoff)
+        return torch.tensor(math.sqrt(k * k + r * r), dtype=self._positions.dtype)
 
 
 class TunerBase:
@@ -216,8 +229,7 @@ class GridSearchTuner(TunerBase):
         return self.time_func(calculator)
 
 
-def _tune_mesh(calculator, bounds_cls, charges, cell, positions, cutoff, neighbor_indices, neighbor_distances,
-               full_neighbor_list, prefactor, exponent, nodes_lo, nodes_hi, mesh_lo, mesh_hi, accuracy):
+def _validated_min_dimension(charges, cell, positions, exponent) -> float:
     # validation first (the reference's tuners validate in TunerBase.__init__, before touching the cell)
     if exponent != 1:
         raise NotImplementedError(f"Only exponent = 1 is supported but got {exponent}.")
@@ -226,11 +238,22 @@ def _tune_mesh(calculator, bounds_cls, charges, cell, positions, cutoff, neighbo
         neighbor_indices=torch.tensor([[0, 1]], device=positions.device),
         neighbor_distances=torch.tensor([1.0], device=positions.device, dtype=positions.dtype),
     )
-    min_dimension = float(torch.min(torch.linalg.norm(cell, dim=1)))
+    return float(torch.min(torch.linalg.norm(cell, dim=1)))
+
+
+def _tune_mesh(calculator, bounds_cls, charges, cell, positions, cutoff, neighbor_indices, neighbor_distances,
+               full_neighbor_list, prefactor, exponent, nodes_lo, nodes_hi, mesh_lo, mesh_hi, accuracy):
+    min_dimension = _validated_min_dimension(charges, cell, positions, exponent)
     params = [
         {"interpolation_nodes": nodes, "mesh_spacing": 2 * min_dimension / (2**ns - 1)}
         for nodes, ns in product(range(nodes_lo, nodes_hi + 1), range(mesh_lo, mesh_hi + 1))
     ]
+    return _grid_search(calculator, bounds_cls, params, charges, cell, positions, cutoff, neighbor_indices,
+                        neighbor_distances, full_neighbor_list, prefactor, exponent, accuracy)
+
+
+def _grid_search(calculator, bounds_cls, params, charges, cell, positions, cutoff, neighbor_indices, neighbor_distances,
+                 full_neighbor_list, prefactor, exponent, accuracy):
     tuner = GridSearchTuner(
         charges=charges, cell=cell, positions=positions, cutoff=cutoff, exponent=exponent,
         neighbor_indices=neighbor_indices, neighbor_distances=neighbor_distances,
@@ -271,3 +294,14 @@ def tune_pme(charges, cell, positions, cutoff: float, neighbor_indices, neighbor
     return _tune_mesh(PMECalculator, PMEErrorBounds, charges, cell, positions, cutoff, neighbor_indices,
                       neighbor_distances, full_neighbor_list, prefactor, exponent, nodes_lo, nodes_hi, mesh_lo, mesh_hi,
                       accuracy)
+
+
+def tune_ewald(charges, cell, positions, cutoff: float, neighbor_indices, neighbor_distances,
+               full_neighbor_list: bool = False, prefactor: float = 1.0, exponent: int = 1, ns_lo: int = 1,
+               ns_hi: int = 14, accuracy: float = 1e-3) -> tuple[float, dict[str, Any], float]:
+    """Fastest ``lr_wavelength = min|a_d| / ns`` (``ns_lo <= ns <= ns_hi``) of :class:`EwaldCalculator` whose estimated
+    error is below ``accuracy``; returns ``(smearing, {"lr_wavelength"}, seconds)`` (reference ``tuning/ewald.py:11-123``)."""
+    min_dimension = _validated_min_dimension(charges, cell, positions, exponent)
+    params = [{"lr_wavelength": min_dimension / ns} for ns in range(ns_lo, ns_hi + 1)]
+    return _grid_search(EwaldCalculator, EwaldErrorBounds, params, charges, cell, positions, cutoff, neighbor_indices,
+                        neighbor_distances, full_neighbor_list, prefactor, exponent, accuracy)
