@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
+    ap.add_argument("--frames-per-gpu", type=int, default=1,
+                    help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --workload ionic "
+                         "--frames-per-gpu 8 on 8 GPUs = 64 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
@@ -206,13 +209,14 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    w = make_workload(args.workload, rank)
-    frame = Frame(w, device)
+    n_frames = max(1, args.frames_per_gpu)
+    frames = [Frame(make_workload(args.workload, rank * n_frames + f), device) for f in range(n_frames)]
+    frame, w = frames[0], frames[0].w
     s = 4 if w.dtype == "f32" else 8
     # the farm's ONE exchange: after its last frame evaluation every rank contributes its frame energy
     # to an all-gather over RCCL (8 B per frame), inside the timed region
-    my_energy = torch.zeros(1, dtype=frame.dtype, device=device)
-    all_energies = torch.zeros(world, dtype=frame.dtype, device=device)
+    my_energy = torch.zeros(n_frames, dtype=frame.dtype, device=device)
+    all_energies = torch.zeros(world * n_frames, dtype=frame.dtype, device=device)
 
     def dbg(msg):
         if os.environ.get("MIPME_BENCH_DEBUG") == "1":
@@ -223,21 +227,21 @@ def main():
     graphed = None
     if launch == "graph":
         try:
-            graphed = tpa.GraphedEnergyForces(frame.calc, frame.q, frame.cell, frame.pos, frame.pairs, frame.shifts)
+            graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames]
         except Exception as exc:  # capture not possible on this stack: fall back to eager launches, and say so
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
-            launch = "eager"
+            launch, graphed = "eager", None
 
     def one_step():
+        """One pass of the hot path over this rank's batch of frames; returns the frame energies (device tensors)."""
         if graphed is not None:
-            E, F = graphed()
-        else:
-            E, F = frame.step()
-        return E
+            return [g()[0] for g in graphed]
+        return [f.step()[0] for f in frames]
 
-    def exchange(E):
+    def exchange(energies):
         if distributed:
-            my_energy.copy_(E.reshape(1))
+            for k, E in enumerate(energies):
+                my_energy[k] = E.reshape(())
             dist.all_gather_into_tensor(all_energies, my_energy)
 
     dbg("graph captured" if graphed is not None else "eager mode")
@@ -264,7 +268,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * w.n_atoms * args.steps / elapsed
+    value = world * n_frames * w.n_atoms * args.steps / elapsed
 
     # ---- instrumented pass: per-call HIP-event timings on the launch stream (does not affect `value`) ----
     from torchpme_amd import _lib
@@ -333,9 +337,9 @@ def main():
                 "workload": f"{w.name}: {w.n_atoms} atoms, {w.n_pairs} half pairs (rc={w.cutoff} A), "
                             f"{w.scheme} order {w.order}, {w.n_mesh}^3 mesh, "
                             f"{'Coulomb' if w.exponent == 1 else '1/r^%d' % w.exponent}, {w.dtype}, energy+forces via autograd",
-                "frames_per_gpu": 1,
+                "frames_per_gpu": n_frames,
                 "launch": "HIP graph replay of the captured step" if launch == "graph" else "eager kernel launches",
-                "parallelism": f"{world} independent frame(s), one per GPU",
+                "parallelism": f"{world * n_frames} independent frame(s), {n_frames} per GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -352,7 +356,7 @@ def main():
             "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "kernels": table,
             "abi_call_ms": prof,
-            "energy": float(E.item()),
+            "energy": float(E[0].item()),
             "accuracy": accuracy,
         }
         if world == 1 and not args.no_cpu_baseline:
