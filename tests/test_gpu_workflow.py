@@ -192,3 +192,32 @@ def test_tuning_timer():
     t1 = TuningTimings(q, cell, pos, pairs, dist, n_repeat=4)(calc)
     t2 = TuningTimings(q, cell, pos, pairs, dist, n_repeat=16, run_backward=False)(calc)
     assert 0 < t2 < t1 < 0.1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_path_degenerate_lists(dtype):
+    """pair_distances -> calculator (the fused path) with an empty pair list and with a single atom / single pair."""
+    cell = torch.eye(3, dtype=dtype, device=DEV) * 5
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0)
+    pos = torch.tensor([[0.5, 0.5, 0.5], [2.0, 2.5, 3.0]], dtype=dtype, device=DEV, requires_grad=True)
+    q = torch.tensor([[1.0], [-1.0]], dtype=dtype, device=DEV)
+    none = torch.zeros((0, 2), dtype=torch.int64, device=DEV)
+    d0 = tpa.pair_distances(pos, none, cell, torch.zeros((0, 3), dtype=dtype, device=DEV))
+    assert d0.shape == (0,)
+    V0 = calc(q, cell, pos, none, d0)
+    tpa.weighted_sum(V0, q).backward()
+    g0 = pos.grad.clone()
+    ref = calc(q, cell, pos.detach(), none, torch.zeros((0,), dtype=dtype, device=DEV))
+    torch.testing.assert_close(V0.detach(), ref)
+    assert torch.isfinite(g0).all()
+    # one pair, one of the atoms its own periodic image partner as well
+    pairs = torch.tensor([[0, 1], [0, 0]], device=DEV)
+    shifts = torch.tensor([[0, 0, 0], [1, 0, 0]], dtype=dtype, device=DEV)
+    pos.grad = None
+    d = tpa.pair_distances(pos, pairs, cell, shifts)
+    torch.testing.assert_close(d.detach(), torch.stack([(pos[1] - pos[0]).norm(), cell[0].norm()]).detach())
+    V = calc(q, cell, pos, pairs, d)
+    tpa.weighted_sum(V, q).backward()
+    Vu = calc(q, cell, pos.detach(), pairs, d.detach().clone())  # leaf distances: unfused kernels
+    torch.testing.assert_close(V.detach(), Vu)
+    assert torch.isfinite(pos.grad).all() and (pos.grad - g0).abs().sum() > 0
