@@ -221,3 +221,24 @@ def test_fused_path_degenerate_lists(dtype):
     Vu = calc(q, cell, pos.detach(), pairs, d.detach().clone())  # leaf distances: unfused kernels
     torch.testing.assert_close(V.detach(), Vu)
     assert torch.isfinite(pos.grad).all() and (pos.grad - g0).abs().sum() > 0
+
+
+def test_inside_torch_compile():
+    """A torch.compile'd model may contain a calculator: it runs as an opaque eager call (SURVEY 8f rank 4 is only
+    covered to this extent -- no torch.library registration, no TorchScript)."""
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=0.2), mesh_spacing=0.1)
+    charges, cell, positions, pairs, dist = cscl_system(torch.float32)
+
+    def model(pos, scale):
+        d = tpa.pair_distances(pos * scale, pairs, cell * scale, torch.zeros((1, 3), device=DEV))
+        V = calc(charges, cell * scale, pos * scale, pairs, d)
+        return tpa.weighted_sum(V, charges) * 2.0 + scale.sum()
+
+    pos = positions.clone().requires_grad_(True)
+    scale = torch.tensor(1.5, device=DEV)
+    eager = model(pos, scale)
+    (g_eager,) = torch.autograd.grad(eager, pos)
+    compiled = torch.compile(model)(pos, scale)
+    (g_comp,) = torch.autograd.grad(compiled, pos)
+    torch.testing.assert_close(compiled, eager)
+    torch.testing.assert_close(g_comp, g_eager)

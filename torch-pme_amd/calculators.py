@@ -43,6 +43,7 @@ class Calculator(torch.nn.Module):
             raise NotImplementedError(f"`compute_kspace` not implemented for {self.__class__.__name__}")
         return None, None
 
+    @torch.compiler.disable  # an opaque eager call inside torch.compile'd models (ctypes + HIP launches are not traceable)
     def forward(
         self,
         charges: torch.Tensor,
@@ -201,6 +202,7 @@ class EwaldCalculator(Calculator):
         self._freq_cache = (weakref.ref(cell), cell._version, cell.device, self.lr_wavelength, freq)
         return freq
 
+    @torch.compiler.disable
     def forward(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
                 pair_mask=None, kvectors=None):
         _validate_parameters(

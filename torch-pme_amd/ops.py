@@ -680,6 +680,7 @@ class _PairDistances(torch.autograd.Function):
         return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
 
 
+@torch.compiler.disable
 def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None):
     """``d[p] = |r_j - r_i + S_p @ cell|``, differentiable w.r.t. ``positions`` and ``cell``.
 
@@ -743,6 +744,7 @@ class _WeightedSum(torch.autograd.Function):
         return ga, gb
 
 
+@torch.compiler.disable
 def weighted_sum(potentials: torch.Tensor, charges: torch.Tensor) -> torch.Tensor:
     """``(charges * potentials).sum()`` -- the energy reduction every caller of the reference performs
     (``README.rst:112-114``) -- as one kernel forward and one backward instead of five ATen launches."""
