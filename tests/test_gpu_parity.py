@@ -575,3 +575,30 @@ def test_ewald_constructor_errors():
         tpa.EwaldCalculator(tpa.CoulombPotential(smearing=-1.0), lr_wavelength=1.0)
     with pytest.raises(ValueError, match="`lr_wavelength` is -0.5 but must be positive"):
         tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=-0.5)
+
+
+def test_concurrent_frames_on_streams():
+    """Independent frames replayed concurrently on separate streams (bench.py --frames-per-gpu): every calculator owns its
+    FFT plan / brick counters and every charges tensor its reduction scratch, so the results equal the sequential ones."""
+    from torchpme_amd import workloads
+
+    frames = []
+    for f in range(4):
+        w = workloads.ionic_box(n_side=10, n_mesh=16, cutoff=6.0, seed=50 + f)
+        t = lambda a: torch.tensor(a, dtype=torch.float64, device=DEV)  # noqa: E731
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=w.smearing), mesh_spacing=w.mesh_spacing, interpolation_nodes=4)
+        frames.append(tpa.GraphedEnergyForces(calc, t(w.charges), t(w.cell), t(w.positions),
+                                              torch.tensor(w.pairs, device=DEV), t(w.shifts)))
+    ref = []
+    for g in frames:
+        E, F = g()
+        ref.append((E.clone(), F.clone()))
+    streams = [torch.cuda.Stream(DEV) for _ in frames]
+    for _ in range(20):
+        for g, st in zip(frames, streams):
+            with torch.cuda.stream(st):
+                g.graph.replay()
+    torch.cuda.synchronize()
+    for g, (E, F) in zip(frames, ref):
+        torch.testing.assert_close(g.energy, E, rtol=1e-12, atol=0)
+        torch.testing.assert_close(g.forces, F, rtol=1e-10, atol=1e-12)

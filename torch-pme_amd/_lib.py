@@ -227,11 +227,14 @@ class FFTPlan:
 _PLANS: dict = {}
 
 
-def get_plan(device, dtype, ns, batch) -> FFTPlan:
-    key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch))
+def get_plan(device, dtype, ns, batch, owner=None) -> FFTPlan:
+    """Plan of (device, dtype, mesh, batch) for ``owner`` (any hashable; the calculators pass their mesh geometry object).
+    A plan owns device state that is live between its kernels (the brick counters of the binning pass), so evaluations
+    that may run concurrently on different streams must not share one: one plan per owner."""
+    key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch), owner)
     plan = _PLANS.get(key)
     if plan is None:
-        if len(_PLANS) >= 32:
+        if len(_PLANS) >= 64:
             _PLANS.pop(next(iter(_PLANS)))
         plan = FFTPlan(device, dtype, ns, batch)
         _PLANS[key] = plan

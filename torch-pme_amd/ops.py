@@ -358,7 +358,7 @@ class _PMEFunction(torch.autograd.Function):
 
             if geom is not None:
                 md = geom.desc(Cn)
-                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn, id(geom))
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 rho_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 phi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
@@ -478,7 +478,7 @@ class _PMEFunction(torch.autograd.Function):
                 kb_q = need_q and not energy_q
                 if kb_pos or kb_q:
                     md = geom.desc(Cn)
-                    plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                    plan = _lib.get_plan(device, dtype, geom.ns, Cn, id(geom))
                     if kb_pos:
                         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
                     if kb_q:
@@ -491,7 +491,7 @@ class _PMEFunction(torch.autograd.Function):
                     )
             elif do_kspace:
                 md = geom.desc(Cn)
-                plan = _lib.get_plan(device, dtype, geom.ns, Cn)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn, id(geom))
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 psi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 chi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
@@ -703,13 +703,16 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None)
 _DOT_SCRATCH = {}
 
 
-def _dot_scratch(device):
-    """Persistent, zero-initialised scratch of ``mipme_dot_forward``, one per device (``weighted_sum`` calls on one device
-    must not run concurrently on several streams).  Not keyed on the stream: a CUDA-graph capture stream differs from the
-    warm-up stream, and a buffer created during capture would bake its zero fill into every replay."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def _dot_scratch(device, owner):
+    """Persistent, zero-initialised scratch of ``mipme_dot_forward`` per (device, owner): the owner is the storage address
+    of the charges tensor, so reductions of different frames (which may run concurrently on different streams) never share
+    a ticket counter.  Not keyed on the stream: a CUDA-graph capture stream differs from the warm-up stream, and a buffer
+    created during capture would bake its zero fill into every replay."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), owner)
     buf = _DOT_SCRATCH.get(key)
     if buf is None:
+        while len(_DOT_SCRATCH) >= 256:
+            _DOT_SCRATCH.pop(next(iter(_DOT_SCRATCH)))
         buf = _DOT_SCRATCH[key] = torch.zeros((65,), dtype=torch.float64, device=device)
     return buf
 
@@ -720,7 +723,7 @@ class _WeightedSum(torch.autograd.Function):
         lib = _lib.load()
         a_c, b_c = a.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((), dtype=a.dtype, device=a.device)
-        scratch = _dot_scratch(a.device)
+        scratch = _dot_scratch(a.device, b.data_ptr())
         with torch.cuda.device(a.device):
             _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
                   a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
