@@ -60,7 +60,44 @@ __device__ __forceinline__ float erfc_from_exp(float y, float e) {
   p = p * t + 2.254580744e-01f;
   return e * t * p;
 }
-__device__ __forceinline__ double erfc_from_exp(double y, double) { return erfc(y); }
+// double: erfc(y) = e * t * C20(t) with the same substitution, C20 a degree-20 Chebyshev series of erfcx(y)/t on
+// t in [1/(1+0.4*27), 1] (interpolation at Chebyshev nodes; max relative error 4e-15 for 0 <= y <= 27, beyond which
+// e = exp(-y^2) underflows anyway), evaluated with Clenshaw's recurrence: ~45 flops instead of libm erfc's ~150.
+__device__ __forceinline__ double erfc_from_exp(double y, double e) {
+  constexpr double c[21] = {
+    0.5360362114901628,
+    0.36394201332405524,
+    0.08650903632395776,
+    0.013008876153714528,
+    0.0006814592277430882,
+    -0.00015462371847884464,
+    -2.5921853049941386e-05,
+    2.306253180458029e-06,
+    7.220220663501949e-07,
+    -6.169012444769808e-08,
+    -2.0618514118898877e-08,
+    2.6589056503780845e-09,
+    5.618178359727535e-10,
+    -1.305151311061305e-10,
+    -1.0535414781885487e-11,
+    5.9990625120232684e-12,
+    -2.000942951395261e-13,
+    -2.2583487398503573e-13,
+    3.6983871068685136e-14,
+    5.0608677594587146e-15,
+    -2.7192201719058864e-15};
+  constexpr double tlo = 0.0847457627118644;
+  const double t = 1.0 / (1.0 + 0.4 * y);
+  const double x = (2.0 * t - (1.0 + tlo)) / (1.0 - tlo);
+  double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+  for (int k = 20; k >= 1; --k) {
+    const double b0 = c[k] + 2.0 * x * b1 - b2;
+    b2 = b1;
+    b1 = b0;
+  }
+  return e * t * (c[0] + x * b1 - b2);
+}
 // same fit with the hardware reciprocal (1 ulp) for t
 __device__ __forceinline__ float erfc_from_exp_fast(float y, float e) {
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.4f * y);
@@ -179,7 +216,7 @@ __device__ __forceinline__ double rs_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float rs_exp_neg(float x) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * x); }
 __device__ __forceinline__ double rs_exp_neg(double x) { return exp(-x); }
 __device__ __forceinline__ float rs_erfc(float y, float e) { return erfc_from_exp_fast(y, e); }
-__device__ __forceinline__ double rs_erfc(double y, double) { return erfc(y); }
+__device__ __forceinline__ double rs_erfc(double y, double e) { return erfc_from_exp(y, e); }
 
 template <int P, bool DERIV, typename T>
 __device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v, T& dvd) {
