@@ -55,6 +55,24 @@ def test_abi_argument_errors_without_gpu():
     assert b"only values from 1 to 5 for method 'P3M' are allowed" in lib.mipme_last_error()
     with pytest.raises(ValueError, match="from 1 to 5"):
         _lib.check(rc)
+    # argument checks of the entry points added for the fused / Ewald / tuning rows (all return MIPME_EINVAL = -1 before
+    # any launch; messages via mipme_last_error)
+    assert lib.mipme_sr_rows_fused(None, _lib.F32, 4, None, None, None, None, None, None, None, None, None, 0, 0,
+                                   C.byref(pd), 0, 0, None, 0, None, None, None, None) == -1
+    assert b"mipme_sr_rows_fused" in lib.mipme_last_error()
+    assert lib.mipme_sr_rows_finalize(None, _lib.F32, 4, None, None, None, None, 0, None, None, None) == -1
+    assert lib.mipme_topology_pack_entries(None, _lib.F32, 4, 2, None, None, None, 0, None, None) == -1
+    assert lib.mipme_pair_distance_forward_packed(None, _lib.F32, 4, None, None, None, None, None) == -1
+    assert b"mipme_pair_distance_forward_packed" in lib.mipme_last_error()
+    assert lib.mipme_ewald_structure(None, _lib.F32, 4, 0, 8, None, None, None, None, None) == -1
+    assert b"invalid sizes" in lib.mipme_last_error()
+    assert lib.mipme_ewald_backward(None, 99, 0, 1, 0, *([None] * 12)) == -1
+    assert b"invalid dtype 99" in lib.mipme_last_error()
+    bad = _lib.PotentialDesc(kind=_lib.INVERSE_POWER_LAW, exponent=9, smearing=1.0, prefactor=1.0, exclusion_radius=-1,
+                             exclusion_degree=1)
+    assert lib.mipme_ewald_filter(None, _lib.F64, C.byref(bad), 0, None, None, None) == -1
+    assert b"Unsupported exponent: 9" in lib.mipme_last_error()
+    assert lib.mipme_fft_plan_xfused(None) == 0
 
 
 # ---- constructors (reference tests/calculators/test_workflow.py:77-96, test_calculator.py) ----
