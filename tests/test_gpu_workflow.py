@@ -242,3 +242,46 @@ def test_inside_torch_compile():
     (g_comp,) = torch.autograd.grad(compiled, pos)
     torch.testing.assert_close(compiled, eager)
     torch.testing.assert_close(g_comp, g_eager)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_padded_batch_through_vmap(dtype):
+    """Reference tests/calculators/test_padding.py: ``torch.vmap(EwaldCalculator.forward)`` on zero-padded structures with
+    node_mask / pair_mask / batched k-vectors equals the loop over the unpadded structures."""
+    from torch.nn.utils.rnn import pad_sequence
+
+    rng = np.random.default_rng(4)
+    calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0, prefactor=1.0), full_neighbor_list=True, lr_wavelength=2.0)
+    sizes = [5, 9, 7]
+    systems = []
+    for n in sizes:
+        cell = np.diag(rng.uniform(5.0, 7.0, 3)) + rng.normal(scale=0.2, size=(3, 3))
+        pos = rng.uniform(0, 5, (n, 3))
+        q = rng.normal(size=(n, 1)) + 1.0
+        pairs, _, dist = tpa.neighbor_list(pos, cell, 4.0, full_list=True)
+        systems.append(tuple(torch.tensor(a, device=DEV, dtype=dtype if a.dtype.kind == "f" else None)
+                             for a in (q, cell, pos, pairs, dist)))
+    periodic = torch.tensor([[True, True, True], [True, True, False], [True, True, True]], device=DEV)
+    loop = [calc.forward(q, cell, pos, pairs, dist, periodic[k]) for k, (q, cell, pos, pairs, dist) in enumerate(systems)]
+    q_b = pad_sequence([s[0] for s in systems], batch_first=True)
+    pos_b = pad_sequence([s[2] for s in systems], batch_first=True)
+    pairs_b = pad_sequence([s[3] for s in systems], batch_first=True, padding_value=0)
+    dist_b = pad_sequence([s[4] for s in systems], batch_first=True, padding_value=0.0)
+    cell_b = torch.stack([s[1] for s in systems])
+    node_mask = torch.arange(max(sizes), device=DEV)[None, :] < torch.tensor(sizes, device=DEV)[:, None]
+    pair_mask = (torch.arange(pairs_b.shape[1], device=DEV)[None, :]
+                 < torch.tensor([len(s[3]) for s in systems], device=DEV)[:, None])
+    kvectors = tpa.lib.compute_batched_kvectors(lr_wavelength=2.0, cells=cell_b)
+    batched = torch.vmap(calc.forward)(q_b, cell_b, pos_b, pairs_b, dist_b, periodic, node_mask, pair_mask, kvectors)
+    assert batched.shape == (3, max(sizes), 1)
+    expect = pad_sequence(loop, batch_first=True)
+    torch.testing.assert_close(batched, expect, rtol=1e-5 if dtype == torch.float32 else 1e-11, atol=1e-6 if dtype == torch.float32 else 1e-12)
+    # the samples are ordinary autograd graphs inside the vmap rule: gradients flow through the stack / select ops
+    pos_g = pos_b.clone().requires_grad_(True)
+    out = torch.vmap(calc.forward)(q_b, cell_b, pos_g, pairs_b, dist_b, periodic, node_mask, pair_mask, kvectors)
+    (out * q_b).sum().backward()
+    for k, (q, cell, pos, pairs, dist) in enumerate(systems):
+        p = pos.clone().requires_grad_(True)
+        (calc.forward(q, cell, p, pairs, dist, periodic[k]) * q).sum().backward()
+        torch.testing.assert_close(pos_g.grad[k, : sizes[k]], p.grad, rtol=1e-4 if dtype == torch.float32 else 1e-10,
+                                   atol=1e-5 if dtype == torch.float32 else 1e-11)

@@ -57,7 +57,15 @@ class Calculator(torch.nn.Module):
         kvectors: torch.Tensor | None = None,
     ):
         """Per-atom potentials ``(n_atoms, n_channels)``; see the reference docstring
-        (``calculators/calculator.py:115-156``) for the meaning of every argument."""
+        (``calculators/calculator.py:115-156``) for the meaning of every argument.  Under ``torch.vmap`` (padded batches
+        with ``node_mask`` / ``pair_mask`` / ``kvectors``) the structures are evaluated one after the other."""
+        args = (charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask, pair_mask, kvectors)
+        if ops.inside_vmap(*args):
+            return ops.vmap_bridge(self._forward_impl, *args)
+        return self._forward_impl(*args)
+
+    def _forward_impl(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
+                      pair_mask=None, kvectors=None):
         _validate_parameters(
             charges=charges,
             cell=cell,
@@ -169,7 +177,8 @@ class EwaldCalculator(Calculator):
     The (K, N) phase sums run in ``csrc/ewald.hip``; k-vector generation (``lib/kvectors.py:24-74,105-136``: integer
     frequencies times the reciprocal cell), the 1/V factor and the self / background / slab terms are a handful of small
     tensor ops here, so that the cell gradient is autograd's.  ``kvectors`` may be supplied by the caller; ``node_mask``
-    masks atoms of the result.  Batched (3-D, ``torch.vmap``) inputs are not supported.
+    masks atoms of the result.  Padded batches go through ``torch.vmap(calculator.forward)`` as in the reference
+    (``tests/calculators/test_padding.py``): the structures are evaluated one after the other.
 
     :param potential: potential with a positive ``smearing``
     :param lr_wavelength: spatial resolution of the reciprocal-space part
@@ -202,9 +211,8 @@ class EwaldCalculator(Calculator):
         self._freq_cache = (weakref.ref(cell), cell._version, cell.device, self.lr_wavelength, freq)
         return freq
 
-    @torch.compiler.disable
-    def forward(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
-                pair_mask=None, kvectors=None):
+    def _forward_impl(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
+                      pair_mask=None, kvectors=None):
         _validate_parameters(
             charges=charges, cell=cell, positions=positions, neighbor_indices=neighbor_indices,
             neighbor_distances=neighbor_distances, periodic=periodic, pair_mask=pair_mask, node_mask=node_mask,

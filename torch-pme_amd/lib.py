@@ -218,3 +218,26 @@ class P3MKSpaceFilter(KSpaceFilter):
         self.mode = mode
         self.differential_order = differential_order
         super().__init__(cell, ns_mesh, kernel, fft_norm, ifft_norm)
+
+
+def generate_kvectors_for_ewald(cell: torch.Tensor, ns) -> torch.Tensor:
+    """All reciprocal-space vectors ``2 pi (f_x, f_y, f_z) A^-T`` with integer frequencies ``f_d = fftfreq(ns_d) ns_d``,
+    shape ``(nx ny nz, 3)``, the zero vector first (reference ``lib/kvectors.py:105-136``).  Differentiable w.r.t. ``cell``."""
+    if cell.shape != (3, 3):
+        raise ValueError(f"cell of shape {list(cell.shape)} should be of shape (3, 3)")
+    ns = _ns_tuple(ns)
+    if len(ns) != 3:
+        raise ValueError(f"ns of shape {[len(ns)]} should be of shape (3, )")
+    freqs = [torch.fft.fftfreq(n, device=cell.device, dtype=cell.dtype) * n for n in ns]
+    F = torch.stack(torch.meshgrid(*freqs, indexing="ij"), dim=-1).reshape(-1, 3)
+    return (2 * torch.pi) * F @ torch.linalg.inv(cell).T
+
+
+def compute_batched_kvectors(lr_wavelength: float, cells: torch.Tensor) -> torch.Tensor:
+    """Zero-padded k-vector sets ``(B, K_max, 3)`` of a batch of cells for ``torch.vmap(EwaldCalculator.forward)``
+    (reference ``lib/kvectors.py:139-166``; the padding relies on G(k = 0) = 0)."""
+    sets = []
+    for cell in cells:
+        ns = torch.ceil(torch.linalg.norm(cell, dim=1) / lr_wavelength).long()
+        sets.append(generate_kvectors_for_ewald(cell, ns))
+    return torch.nn.utils.rnn.pad_sequence(sets, batch_first=True)

@@ -818,3 +818,40 @@ class _EwaldKSpace(torch.autograd.Function):
 
 def ewald_kspace(charges, positions, kvectors, pot_desc):
     return _EwaldKSpace.apply(charges, positions, kvectors, pot_desc)
+
+
+# ---- torch.vmap bridge (padded batches, reference tests/calculators/test_padding.py) ------------------------------------
+def inside_vmap(*tensors) -> bool:
+    """True if any argument is a functorch BatchedTensor, i.e. the caller is being traced by ``torch.vmap``."""
+    check = getattr(torch._C._functorch, "is_batchedtensor", None)
+    return check is not None and any(isinstance(t, torch.Tensor) and check(t) for t in tensors)
+
+
+class _SampleLoop(torch.autograd.Function):
+    """``torch.vmap(calculator.forward)(padded batch)``: the HIP kernels take one structure at a time, so the vmap rule runs
+    the samples one after the other on their slices of the padded batch and stacks the results.  Each sample is an ordinary
+    autograd graph, so gradients flow back through the stack / select ops."""
+
+    @staticmethod
+    def forward(fn, *args):
+        return fn(*args)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        pass
+
+    @staticmethod
+    def backward(ctx, *grads):  # only reached when the bridge is applied outside vmap, which the calculators never do
+        raise NotImplementedError("_SampleLoop is a torch.vmap bridge; call the calculator directly")
+
+    @staticmethod
+    def vmap(info, in_dims, fn, *args):
+        outs = []
+        for b in range(info.batch_size):
+            sample = [a if d is None else a.select(d, b) for a, d in zip(args, in_dims[1:])]
+            outs.append(fn(*sample))
+        return torch.stack(outs), 0
+
+
+def vmap_bridge(fn, *args):
+    return _SampleLoop.apply(fn, *args)
