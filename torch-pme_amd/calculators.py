@@ -156,6 +156,7 @@ class PMECalculator(Calculator):
         cell_host = cell.detach().to("cpu", torch.float64).numpy()
         ns = ops.ns_mesh_from_cell(cell_host, self.mesh_spacing)
         geom = ops.MeshGeometry(cell_host, ns, self._scheme, self.interpolation_nodes)
+        geom.owner = id(self)
         G = ops.build_filter(geom, pot_desc, dtype, device)
         self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, self.mesh_spacing, geom, G)
         return geom, G
