@@ -27,7 +27,8 @@ template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
 template <typename T> int apply_filter_cellgrad_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*, const void*, const void*, void*, void*, void*);
-template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
+template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
+int64_t cellgrad_scratch_doubles();
 int64_t cellgrad_blocks(const mipme_mesh_t*);
 int fft_plan_create(int, int, int, int, int, mipme_fft_plan**);
 int fft_plan_destroy(mipme_fft_plan*);
@@ -539,7 +540,7 @@ int64_t mipme_profile_report(char* buf, int64_t buflen) {
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms) {
   (void)n_atoms;
   if (!mesh) return 0;
-  return 12 * cellgrad_blocks(mesh);
+  return 12 * cellgrad_blocks(mesh) + cellgrad_scratch_doubles();
 }
 
 int mipme_slab_forward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void apply_filter_kernel(int64_t Mh, int C, co
   }
 }
 
+static constexpr int kFinalizeBlocksDecl = 64, kFinalizeNVDecl = 22;  // layout of the finalisation scratch, see below
+
 // Backward variant: also accumulates, per block, the 12 k-grid sums of the cell gradient
 //   K[c][d] = 2 pi sum_k dL/dG(k) dG/dk_c f_d ,  H[c] = sum_k dL/dG(k) dG/dh_c ,
 //   dL/dG(k) = mu(k) sum_ch Re[rho^_ch(k) conj psi^_ch(k)]          
@@ -190,29 +192,41 @@ __global__ __launch_bounds__(256) void apply_filter_cellgrad_kernel(KGeom g, KPo
     partials[int64_t(blockIdx.x) * 12 + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   }
+  // clear the ticket counter of cellgrad_finalize_kernel (stored behind its block sums, after the k-grid partials)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    *reinterpret_cast<int*>(partials + int64_t(gridDim.x) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl) = 0;
 }
 
 // Single-block finalisation of dL/dcell:
 //   D = r^T T + K,  T = grad_pos A^T ;  gA = -Ainv^T D Ainv^T + rows[(H_c/(|a_c| n_c)) a_c] + dL/dV * V * Ainv^T
 //   dL/dV = -(1/V) sum_ic g_ic/2 Phi_ic + (2 bg / V) sum_c Q_c dc(psi_c)
+static constexpr int kFinalizeBlocks = kFinalizeBlocksDecl;  // partial-sum blocks of the finalisation (+ a ticket counter after them)
+static constexpr int kFinalizeNV = kFinalizeNVDecl;          // 12 k-grid sums, 9 r^T grad_pos, 1 sum g*Phi/2
+
+// Multi-block: every block sums its share of the k-grid partials and of the atoms into scratch[b][22]; the block that draws
+// the last ticket adds the block sums in index order (deterministic) and does the 3x3 algebra.  `scratch` = the tail of the
+// partials buffer: kFinalizeBlocks * 22 doubles + one int ticket counter that is zero on entry (cleared by
+// apply_filter_cellgrad_kernel) and is left at zero.
 template <typename T>
-__global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m, double bg, int64_t n_atoms, int nblocks,
-                                                                const double* __restrict__ partials,
-                                                                const T* __restrict__ pos,
-                                                                const T* __restrict__ grad_pos,
-                                                                const T* __restrict__ gout, const T* __restrict__ phi_atoms,
-                                                                const T* __restrict__ rho_dc, const T* __restrict__ psi_dc,
-                                                                T* __restrict__ grad_cell) {
-  constexpr int NV = 22;  // 12 k-grid sums, 9 r^T grad_pos, 1 sum g*Phi/2
+__global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, double bg, int64_t n_atoms, int nblocks,
+                                                               const double* __restrict__ partials, double* scratch,
+                                                               const T* __restrict__ pos,
+                                                               const T* __restrict__ grad_pos,
+                                                               const T* __restrict__ gout, const T* __restrict__ phi_atoms,
+                                                               const T* __restrict__ rho_dc, const T* __restrict__ psi_dc,
+                                                               T* __restrict__ grad_cell) {
+  constexpr int NV = kFinalizeNV;
   double acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  const int64_t t0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t b = t0; b < nblocks; b += stride) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] += partials[int64_t(b) * 12 + i];
+    for (int i = 0; i < 12; ++i) acc[i] += partials[b * 12 + i];
   }
   const int C = m.n_channels;
-  for (int64_t a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+  for (int64_t a = t0; a < n_atoms; a += stride) {
     const double r[3] = {double(pos[3 * a]), double(pos[3 * a + 1]), double(pos[3 * a + 2])};
     const double gp[3] = {double(grad_pos[3 * a]), double(grad_pos[3 * a + 1]), double(grad_pos[3 * a + 2])};
 #pragma unroll
@@ -221,7 +235,8 @@ __global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m,
       for (int e = 0; e < 3; ++e) acc[12 + 3 * c + e] += r[c] * gp[e];
     for (int c = 0; c < C; ++c) acc[21] += 0.5 * double(gout[a * C + c]) * double(phi_atoms[a * C + c]);
   }
-  __shared__ double red[16][NV];
+  __shared__ double red[4][NV];
+  __shared__ bool last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -231,14 +246,31 @@ __global__ __launch_bounds__(1024) void cellgrad_finalize_kernel(mipme_mesh_t m,
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
+  int* counter = reinterpret_cast<int*>(scratch + size_t(kFinalizeBlocks) * NV);
+  if (threadIdx.x < NV)
+    __hip_atomic_store(&scratch[size_t(blockIdx.x) * NV + threadIdx.x],
+                       red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double s[NV];
-    const int nw = blockDim.x >> 6;
-    for (int i = 0; i < NV; ++i) {
-      double v = 0.0;
-      for (int w = 0; w < nw; ++w) v += red[w][i];
-      s[i] = v;
-    }
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = ticket == int(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __shared__ double s[NV];
+  __shared__ double all[kFinalizeBlocks * NV];  // independent loads first (a dependent chain of 64 L2 round trips took 20 us)
+  for (int k = threadIdx.x; k < int(gridDim.x) * NV; k += blockDim.x)
+    all[k] = __hip_atomic_load(&scratch[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double v = 0.0;
+    for (int b = 0; b < int(gridDim.x); ++b) v += all[b * NV + threadIdx.x];
+    s[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double* A = m.cell;
     const double* Ai = m.inv_cell;
     double D[9];
@@ -611,11 +643,15 @@ int apply_filter_cellgrad_impl(hipStream_t st, const mipme_mesh_t* m, const mipm
   return MIPME_OK;
 }
 
+int64_t cellgrad_scratch_doubles() { return int64_t(kFinalizeBlocks) * kFinalizeNV + 1; }
+
 template <typename T>
-int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int64_t n_atoms, const void* partials,
+int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int64_t n_atoms, void* partials,
                            const void* pos, const void* grad_pos, const void* gout, const void* phi_atoms,
                            const void* rho_dc, const void* psi_dc, void* grad_cell) {
-  cellgrad_finalize_kernel<T><<<1, 1024, 0, st>>>(*m, bg, n_atoms, int(cellgrad_blocks(m)), (const double*)partials,
+  double* scratch = (double*)partials + 12 * cellgrad_blocks(m);
+  cellgrad_finalize_kernel<T><<<kFinalizeBlocks, 256, 0, st>>>(*m, bg, n_atoms, int(cellgrad_blocks(m)),
+                                                 (const double*)partials, scratch,
                                                  (const T*)pos, (const T*)grad_pos, (const T*)gout,
                                                  (const T*)phi_atoms, (const T*)rho_dc, (const T*)psi_dc,
                                                  (T*)grad_cell);
@@ -631,9 +667,9 @@ template int apply_filter_cellgrad_impl<float>(hipStream_t, const mipme_mesh_t*,
                                                const void*, const void*, void*, void*, void*);
 template int apply_filter_cellgrad_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*,
                                                 const void*, const void*, const void*, void*, void*, void*);
-template int cellgrad_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*,
+template int cellgrad_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
                                            const void*, const void*, const void*, const void*, const void*, void*);
-template int cellgrad_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, int64_t, const void*, const void*,
+template int cellgrad_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
                                             const void*, const void*, const void*, const void*, const void*, void*);
 
 }  // namespace mipme
