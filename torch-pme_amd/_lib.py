@@ -227,17 +227,19 @@ class FFTPlan:
 _PLANS: dict = {}
 
 
-def get_plan(device, dtype, ns, batch, owner=None) -> FFTPlan:
-    """Plan of (device, dtype, mesh, batch) for ``owner`` (any hashable; the calculators pass their mesh geometry object).
-    A plan owns device state that is live between its kernels (the brick counters of the binning pass), so evaluations
-    that may run concurrently on different streams must not share one: one plan per owner."""
-    key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch), owner)
-    plan = _PLANS.get(key)
+def get_plan(device, dtype, ns, batch, store: dict | None = None) -> FFTPlan:
+    """Plan of (device, dtype, mesh, batch).  A plan owns device state that is live between its kernels (the brick counters
+    of the binning pass), so evaluations that may run concurrently on different streams must not share one, and a plan must
+    outlive every captured HIP graph that launches its kernels: the calculators therefore pass their own ``store`` dict
+    (one plan per calculator and mesh, freed with the calculator).  Without a store a small global cache is used."""
+    key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch))
+    cache = _PLANS if store is None else store
+    plan = cache.get(key)
     if plan is None:
-        if len(_PLANS) >= 64:
+        if store is None and len(_PLANS) >= 32:
             _PLANS.pop(next(iter(_PLANS)))
         plan = FFTPlan(device, dtype, ns, batch)
-        _PLANS[key] = plan
+        cache[key] = plan
     return plan
 
 

@@ -135,6 +135,7 @@ class PMECalculator(Calculator):
         self.mesh_spacing: float = mesh_spacing
         self.interpolation_nodes: int = interpolation_nodes
         self._cache = None  # (weakref(cell), version, dtype, device, pot key) -> (geom, G)
+        self._plan_store = {}  # FFT plans of this calculator (see _lib.get_plan)
 
     def _kspace_setup(self, cell, dtype, device):
         """Mesh geometry and G(k) for this cell.  Both depend only on (cell, potential); they are cached on
@@ -156,7 +157,7 @@ class PMECalculator(Calculator):
         cell_host = cell.detach().to("cpu", torch.float64).numpy()
         ns = ops.ns_mesh_from_cell(cell_host, self.mesh_spacing)
         geom = ops.MeshGeometry(cell_host, ns, self._scheme, self.interpolation_nodes)
-        geom.owner = id(self)
+        geom.plan_store = self._plan_store
         G = ops.build_filter(geom, pot_desc, dtype, device)
         self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, self.mesh_spacing, geom, G)
         return geom, G

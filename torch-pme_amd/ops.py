@@ -57,9 +57,10 @@ class MeshGeometry:
         self.ns = tuple(int(n) for n in ns)
         self.scheme = scheme
         self.order = order
-        #: key of the FFT plan (and its brick counters) this geometry uses: the calculators set it to their own identity,
-        #: so that a calculator keeps ONE plan across cells while concurrently running calculators never share one
-        self.owner = None
+        #: where the FFT plans (with their brick counters) of this geometry live: the calculators point it at their own dict,
+        #: so that a calculator keeps ONE plan per mesh across cells, concurrently running calculators never share one, and
+        #: the plan lives as long as the calculator (captured graphs hold raw pointers into it)
+        self.plan_store = None
 
     def desc(self, n_channels: int) -> _lib.MeshDesc:
         d = _lib.MeshDesc()
@@ -361,7 +362,7 @@ class _PMEFunction(torch.autograd.Function):
 
             if geom is not None:
                 md = geom.desc(Cn)
-                plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.owner)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 rho_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 phi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
@@ -481,7 +482,7 @@ class _PMEFunction(torch.autograd.Function):
                 kb_q = need_q and not energy_q
                 if kb_pos or kb_q:
                     md = geom.desc(Cn)
-                    plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.owner)
+                    plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
                     if kb_pos:
                         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
                     if kb_q:
@@ -494,7 +495,7 @@ class _PMEFunction(torch.autograd.Function):
                     )
             elif do_kspace:
                 md = geom.desc(Cn)
-                plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.owner)
+                plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
                 cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
                 psi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 chi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
