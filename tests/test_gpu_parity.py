@@ -602,3 +602,34 @@ def test_concurrent_frames_on_streams():
     for g, (E, F) in zip(frames, ref):
         torch.testing.assert_close(g.energy, E, rtol=1e-12, atol=0)
         torch.testing.assert_close(g.forces, F, rtol=1e-10, atol=1e-12)
+
+
+def test_graph_survives_cache_eviction(golden_dir):
+    """A captured step keeps its cached inputs alive: after the topology / filter caches have been flushed by other work
+    the replay still reproduces the reference."""
+    import gc
+
+    from torchpme_amd import ops
+
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    t = lambda k: torch.tensor(z[k], device=DEV)  # noqa: E731
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])), mesh_spacing=float(z["p3m5/mesh_spacing"]),
+                             interpolation_nodes=5)
+    pos = t("positions")
+    step = tpa.GraphedEnergyForces(calc, t("charges"), t("cell"), pos, t("pairs"), t("shifts").double())
+    e_ref = float(z["p3m5/f64/energy"])
+    # flush: many other pair lists through the topology cache, another cell through the calculator, lots of allocations
+    rng = np.random.default_rng(0)
+    for k in range(20):
+        pr = torch.tensor(rng.integers(0, 50, (200, 2)), device=DEV)
+        ops.get_topology(pr, 64)
+    other_cell = t("cell") * 1.01
+    calc(t("charges"), other_cell, pos, t("pairs"), tpa.pair_distances(pos, t("pairs"), other_cell, t("shifts").double()))
+    ops._TOPOLOGIES.clear()
+    ops._DOT_SCRATCH.clear()
+    gc.collect()
+    junk = [torch.full((1 << 20,), float(k), device=DEV) for k in range(64)]  # would overwrite freed blocks
+    del junk
+    E, F = step(pos)
+    assert abs(E.item() - e_ref) < 1e-10 * abs(e_ref)
+    assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10

@@ -42,6 +42,14 @@ class GraphedEnergyForces:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.pos.grad = None
+        # The captured graph holds raw pointers into buffers that were built during the warm-up and live in caches: the
+        # transposed pair list (+ packed shifts), the calculator's filter table, the reduction scratch.  Keep them alive
+        # for the lifetime of the graph, whatever the caches evict later.
+        self._keepalive = [
+            ops.get_topology(self.pairs, self.pos.shape[0]) if ops.PAIR_MODE == "rows" else None,
+            getattr(calculator, "_cache", None),
+            ops._dot_scratch(device, self.q.data_ptr()),
+        ]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
