@@ -136,7 +136,9 @@ int mipme_fft_plan_xfused(const mipme_fft_plan* plan);
  * which also requires rho_hat, rho_dc, phi_atoms and grad_positions).
  * grad_scale (device scalar, nullable): "energy mode" -- promises grad_out == grad_scale[0] * charges (the gradient of
  * E = sum q V).  Then chi = (grad_scale/2V) phi, so the second spread, both FFTs and the filter are skipped and only the
- * gradient gather runs (needs phi_mesh and rho_dc; the work meshes may be NULL; grad_cell must be NULL).
+ * gradient gather runs (needs phi_mesh and rho_dc; the work meshes may be NULL).  With grad_cell != NULL the k-grid sums of
+ * the cell gradient are formed from the saved rho_hat alone (dL/dG = (gE/2V) mu |rho^|^2): needs rho_hat, phi_atoms,
+ * partials and grad_positions, as in the general case.
  * psi_hat == NULL (only without grad_cell, plans with mipme_fft_plan_xfused): fused convolution as in the forward. */
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                           const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,

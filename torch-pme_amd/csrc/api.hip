@@ -27,7 +27,7 @@ template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
 template <typename T> int apply_filter_cellgrad_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*, const void*, const void*, void*, void*, void*);
-template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
+template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
 int64_t cellgrad_scratch_doubles();
 int64_t cellgrad_blocks(const mipme_mesh_t*);
 int fft_plan_create(int, int, int, int, int, mipme_fft_plan**);
@@ -161,11 +161,19 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   if (grad_scale) {
     // energy mode: grad_out = grad_scale * charges  =>  psi = (grad_scale/2V) rho, chi = (grad_scale/2V) phi:
     // no second spread / FFT / filter / inverse FFT (special case L = sum q V)
-    MIPME_REQUIRE(!grad_cell && rho_dc, "energy-mode backward needs rho_dc and does not produce the cell gradient");
+    MIPME_REQUIRE(rho_dc, "energy-mode backward needs rho_dc");
     if (bins)
       STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
     else
       STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+    if (grad_cell) {
+      // dL/dG(k) = (gE / 2V) mu(k) |rho^(k)|^2: the 12 k-grid sums from the saved rho^ alone, scaled in the finalisation
+      MIPME_REQUIRE(rho_hat && phi_atoms && partials && grad_pos,
+                    "cell gradient needs rho_hat, phi_atoms, partials and grad_positions buffers");
+      STAGE(st, "apply_filter_cellgrad", apply_filter_cellgrad_impl<T>(st, m, pot, rho_hat, rho_hat, G, nullptr, nullptr, partials));
+      STAGE(st, "cellgrad_finalize",
+            cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, rho_dc, grad_scale, grad_cell));
+    }
     return MIPME_OK;
   }
   // psi = spread(g / 2V); chi = F psi
@@ -195,7 +203,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
     STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
   if (grad_cell)
     STAGE(st, "cellgrad_finalize",
-          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, grad_cell));
+          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, nullptr, grad_cell));
   return MIPME_OK;
 }
 

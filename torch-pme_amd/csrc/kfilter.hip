@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) void apply_filter_cellgrad_kernel(KGeom g, KPo
     for (int c = 0; c < C; ++c) {
       const int64_t o = 2 * (c * Mh + t);
       const T re = psi_hat[o], im = psi_hat[o + 1];
-      out[o] = re * gk;
-      out[o + 1] = im * gk;
+      if (out) {  // energy mode passes psi_hat = rho_hat and needs only the sums
+        out[o] = re * gk;
+        out[o + 1] = im * gk;
+      }
       if (t == 0 && dc) dc[c] = re;
       dLdG += double(rho_hat[o]) * double(re) + double(rho_hat[o + 1]) * double(im);
     }
@@ -214,7 +216,10 @@ __global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, 
                                                                const T* __restrict__ grad_pos,
                                                                const T* __restrict__ gout, const T* __restrict__ phi_atoms,
                                                                const T* __restrict__ rho_dc, const T* __restrict__ psi_dc,
+                                                               const T* __restrict__ energy_scale,
                                                                T* __restrict__ grad_cell) {
+  // energy_scale != NULL (energy mode, g = gE * charges): the k-grid partials were formed with psi^ = rho^ and psi_dc is
+  // rho_dc; both are multiplied by gE / 2V here
   constexpr int NV = kFinalizeNV;
   double acc[NV];
 #pragma unroll
@@ -271,6 +276,8 @@ __global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, 
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double es = energy_scale ? double(energy_scale[0]) * 0.5 / m.volume : 1.0;
+    for (int i = 0; i < 12; ++i) s[i] *= es;
     const double* A = m.cell;
     const double* Ai = m.inv_cell;
     double D[9];
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, 
         D[3 * c + d] = v + s[3 * c + d];
       }
     double sumQ = 0.0;
-    for (int c = 0; c < C; ++c) sumQ += double(rho_dc[c]) * double(psi_dc[c]);
+    for (int c = 0; c < C; ++c) sumQ += double(rho_dc[c]) * double(psi_dc[c]) * es;
     const double dLdV = -s[21] / m.volume + 2.0 * bg / m.volume * sumQ;
     const int ns[3] = {m.nx, m.ny, m.nz};
     for (int a = 0; a < 3; ++a) {
@@ -648,13 +655,13 @@ int64_t cellgrad_scratch_doubles() { return int64_t(kFinalizeBlocks) * kFinalize
 template <typename T>
 int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int64_t n_atoms, void* partials,
                            const void* pos, const void* grad_pos, const void* gout, const void* phi_atoms,
-                           const void* rho_dc, const void* psi_dc, void* grad_cell) {
+                           const void* rho_dc, const void* psi_dc, const void* energy_scale, void* grad_cell) {
   double* scratch = (double*)partials + 12 * cellgrad_blocks(m);
   cellgrad_finalize_kernel<T><<<kFinalizeBlocks, 256, 0, st>>>(*m, bg, n_atoms, int(cellgrad_blocks(m)),
                                                  (const double*)partials, scratch,
                                                  (const T*)pos, (const T*)grad_pos, (const T*)gout,
                                                  (const T*)phi_atoms, (const T*)rho_dc, (const T*)psi_dc,
-                                                 (T*)grad_cell);
+                                                 (const T*)energy_scale, (T*)grad_cell);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -668,8 +675,10 @@ template int apply_filter_cellgrad_impl<float>(hipStream_t, const mipme_mesh_t*,
 template int apply_filter_cellgrad_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*,
                                                 const void*, const void*, const void*, void*, void*, void*);
 template int cellgrad_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
-                                           const void*, const void*, const void*, const void*, const void*, void*);
+                                           const void*, const void*, const void*, const void*, const void*, const void*,
+                                           void*);
 template int cellgrad_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
-                                            const void*, const void*, const void*, const void*, const void*, void*);
+                                            const void*, const void*, const void*, const void*, const void*, const void*,
+                                            void*);
 
 }  // namespace mipme

@@ -452,9 +452,10 @@ class _PMEFunction(torch.autograd.Function):
             gscale = sr_scale = None
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
                 sr_scale = tag[3]  # enough for the pair part
-                if not need_cell and ctx.slab_axis is None:
+                if ctx.slab_axis is None:
                     gscale = tag[3]
-            field = ctx.field if gscale is not None else None
+            # with a cell gradient the mesh forces are needed as a tensor by its finalisation: take them from the gather
+            field = ctx.field if (gscale is not None and not need_cell) else None
             energy_q = need_q and gscale is not None and not ctx.full_list
             if need_dist:
                 grad_dist = torch.empty((P,), dtype=dtype, device=device)
@@ -478,7 +479,7 @@ class _PMEFunction(torch.autograd.Function):
                     run_grad_dist(False)
                     join.record()
             if do_kspace and gscale is not None:
-                kb_pos = need_pos and field is None
+                kb_pos = (need_pos and field is None) or need_cell
                 kb_q = need_q and not energy_q
                 if kb_pos or kb_q:
                     md = geom.desc(Cn)
@@ -487,12 +488,21 @@ class _PMEFunction(torch.autograd.Function):
                         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
                     if kb_q:
                         grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
+                    partials = None
+                    if need_cell:  # energy mode: the k-grid sums come from the saved rho^ alone (no second spread / FFTs)
+                        grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
+                        partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
+                                               device=device)
                     _call(
                         "kspace_backward", lib.mipme_kspace_backward,
                         plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), None, _lib.ptr(rho_dc), None, None, None, None,
-                        None, None, None, _lib.ptr(grad_pos), _lib.ptr(grad_q), None, _lib.ptr(bins), gscale.data_ptr(),
+                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat) if need_cell else None,
+                        _lib.ptr(rho_dc), _lib.ptr(phi_atoms) if need_cell else None, None, None, None,
+                        None, None, _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q), _lib.ptr(grad_cell),
+                        _lib.ptr(bins), gscale.data_ptr(),
                     )
+                    if not need_pos:
+                        grad_pos = None
             elif do_kspace:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
