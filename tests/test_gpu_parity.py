@@ -633,3 +633,19 @@ def test_graph_survives_cache_eviction(golden_dir):
     E, F = step(pos)
     assert abs(E.item() - e_ref) < 1e-10 * abs(e_ref)
     assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
+
+
+def test_graphed_cell_gradient(golden_dir):
+    """GraphedEnergyForces(cell_gradient=True): energy, forces and dE/dcell (stress) of the replayed step equal the
+    reference's autograd results."""
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])), mesh_spacing=float(z["p3m5/mesh_spacing"]),
+                             interpolation_nodes=5)
+    t = lambda k: torch.tensor(z[k], device=DEV)  # noqa: E731
+    step = tpa.GraphedEnergyForces(calc, t("charges"), t("cell"), t("positions"), t("pairs"), t("shifts").double(),
+                                   cell_gradient=True)
+    for _ in range(2):
+        E, F, dEdcell = step(t("positions"))
+        assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())
+        assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
+        assert relmax(dEdcell.cpu(), z["p3m5/f64/grad_cell"]) < 1e-9

@@ -21,12 +21,16 @@ class GraphedEnergyForces:
     :param calculator: a :class:`PMECalculator` / :class:`P3MCalculator`
     :param charges, cell, positions, neighbor_indices, neighbor_shifts: tensors on the GPU; ``positions`` only
         provides the shape/dtype and the values for the warm-up.
+    :param cell_gradient: also return ``dE/dcell`` (stress) from every call
     """
 
-    def __init__(self, calculator, charges, cell, positions, neighbor_indices, neighbor_shifts, warmup: int = 3):
+    def __init__(self, calculator, charges, cell, positions, neighbor_indices, neighbor_shifts, warmup: int = 3,
+                 cell_gradient: bool = False):
         self.calc = calculator
         self.q = charges.detach()
-        self.cell = cell.detach()
+        #: with ``cell_gradient=True`` every call also returns dE/dcell (3,3) -- the virial is ``-cell.T @ dE/dcell``
+        self.cell_gradient = cell_gradient
+        self.cell = cell.detach().clone().requires_grad_(True) if cell_gradient else cell.detach()
         self.pairs = neighbor_indices
         self.shifts = neighbor_shifts.to(positions.dtype).contiguous()
         self.pos = positions.detach().clone().requires_grad_(True)
@@ -38,10 +42,12 @@ class GraphedEnergyForces:
         with torch.cuda.stream(side):  # warm-up off the default stream: plans, topology, filter caches get built
             for _ in range(max(1, warmup)):
                 self.pos.grad = None
+                self.cell.grad = None
                 self._eval()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.pos.grad = None
+        self.cell.grad = None
         # The captured graph holds raw pointers into buffers that were built during the warm-up and live in caches: the
         # transposed pair list (+ packed shifts), the calculator's filter table, the reduction scratch.  Keep them alive
         # for the lifetime of the graph, whatever the caches evict later.
@@ -54,6 +60,8 @@ class GraphedEnergyForces:
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
             self.forces = self.pos.grad
+            # the backward pass is seeded with -1 (so that pos.grad is the force): undo the sign for the cell
+            self.cell_grad = -self.cell.grad if cell_gradient else None
 
     def _eval(self):
         d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
@@ -67,4 +75,6 @@ class GraphedEnergyForces:
             with torch.no_grad():
                 self.pos.copy_(positions)
         self.graph.replay()
+        if self.cell_gradient:
+            return self.energy, self.forces, self.cell_grad
         return self.energy, self.forces
