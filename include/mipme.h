@@ -303,8 +303,10 @@ int mipme_ewald_backward(void* stream, int dtype, int64_t n_atoms, int n_channel
 
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
  * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------
- * Scope: fully periodic cells with >= 3 cells of perpendicular width >= cutoff per axis (n_cells[d] = floor(width_d /
- * cutoff) >= 3); other cases use the host builder.  Protocol: mipme_nl_bin -> mipme_nl_count -> (caller: exclusive
+ * Scope: >= 3 cells of perpendicular width >= cutoff along every PERIODIC axis (n_cells[d] = floor(width_d / cutoff) >= 3);
+ * a non-periodic axis (periodic[d] = 0: no images, shift 0) may have any n_cells[d] >= 1 and bins the fractional coordinate
+ * (f_d - frac_offset[d]) * frac_scale[d], which the caller chooses so that all atoms fall in [0, 1) and a cell is at least
+ * cutoff wide.  Other cases use the host builder.  Protocol: mipme_nl_bin -> mipme_nl_count -> (caller: exclusive
  * scan of counts into int64 offsets[N+1], allocate P = offsets[N]) -> mipme_nl_fill. */
 typedef struct {
   double cell[9];      /* row-major, rows = lattice vectors */
@@ -314,6 +316,8 @@ typedef struct {
   double cutoff;
   int32_t full_list;
   int32_t _pad;
+  double frac_offset[3]; /* non-periodic axes only; 0 / 1 for periodic axes */
+  double frac_scale[3];
 } mipme_nl_t;
 int64_t mipme_nl_scratch_ints(const mipme_nl_t* nl, int64_t n_atoms);
 /* cell_of int32[N], wrap int32[N][3], cell_start int32[ncells+1], cell_atoms int32[N], scratch int32[mipme_nl_scratch_ints] */

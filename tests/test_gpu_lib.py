@@ -285,3 +285,26 @@ def test_device_neighbor_list_scope():
     with pytest.raises(ValueError, match="device neighbour list needs >= 3 cells"):
         tpa.neighbor_list_device(torch.zeros((2, 3), device=DEV, dtype=torch.float64),
                                  torch.eye(3, device=DEV, dtype=torch.float64), 2.0)
+
+
+@pytest.mark.parametrize("periodic", [(True, True, False), (False, True, True), (False, False, False), (True, False, False)])
+@pytest.mark.parametrize("full", [False, True])
+def test_device_neighbor_list_nonperiodic_axes(periodic, full):
+    """Slabs, wires and clusters: along a non-periodic axis there are no images and the atoms may lie far outside the cell
+    (the cell grid spans their extent); same pair set as the host builder."""
+    rng = np.random.default_rng(13)
+    cell = np.array([[13.0, 0, 0], [2.0, 14.0, 0], [1.0, -1.5, 12.5]])
+    pos = rng.uniform(-9, 30, (600, 3))
+    rc = 3.9
+    hp, hS, hd = tpa.neighbor_list(pos, cell, rc, full_list=full, periodic=periodic)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    gp, gS, gd = tpa.neighbor_list_device(t(pos), t(cell), rc, full_list=full, periodic=periodic)
+    assert len(gp) == len(hp) and len(hp) > 50
+    a = _canon(hp, hS, hd)
+    b = _canon(gp.cpu().numpy(), gS.cpu().numpy(), gd.cpu().numpy())
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-13)
+    for d in range(3):
+        if not periodic[d]:
+            assert (gS[:, d] == 0).all()

@@ -32,6 +32,7 @@ def test_abi_struct_layout_matches_header():
     assert C.sizeof(_lib.PotentialDesc) == 40
     assert C.sizeof(_lib.MeshDesc) == 24 + 19 * 8
     assert _lib.MeshDesc.cell.offset == 24 and _lib.MeshDesc.volume.offset == 24 + 18 * 8
+    assert C.sizeof(_lib.NlDesc) == 18 * 8 + 6 * 4 + 8 + 8 + 6 * 8 and _lib.NlDesc.frac_offset.offset == 18 * 8 + 24 + 16
 
 
 def test_no_cpu_fallback():
@@ -201,17 +202,18 @@ def test_validation_device_message():
 # ---- neighbour list (reference tests/helpers.py:240-275, third-party vesin there) ----
 @pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("cutoff", [1.5, 3.2])
-def test_neighbor_list_vs_bruteforce(full, cutoff):
+@pytest.mark.parametrize("periodic", [(True, True, True), (True, True, False), (False, True, False), (False, False, False)])
+def test_neighbor_list_vs_bruteforce(full, cutoff, periodic):
     rng = np.random.default_rng(11)
     cell = np.array([[3.0, 0, 0], [0.6, 2.5, 0], [-0.4, 0.3, 2.8]])
     pos = rng.uniform(-2, 5, (9, 3))  # some atoms outside the cell; cutoff > L/2 -> several images
-    a = neighbor_list(pos, cell, cutoff, full_list=full)
-    b = neighbor_list_bruteforce(pos, cell, cutoff, full_list=full)
+    a = neighbor_list(pos, cell, cutoff, full_list=full, periodic=periodic)
+    b = neighbor_list_bruteforce(pos, cell, cutoff, full_list=full, periodic=periodic)
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
     np.testing.assert_allclose(a[2], b[2], rtol=1e-13)
     if not full:
-        f = neighbor_list(pos, cell, cutoff, full_list=True)
+        f = neighbor_list(pos, cell, cutoff, full_list=True, periodic=periodic)
         assert len(f[0]) == 2 * len(a[0])
 
 

@@ -71,6 +71,8 @@ class NlDesc(C.Structure):
         ("cutoff", C.c_double),
         ("full_list", C.c_int32),
         ("_pad", C.c_int32),
+        ("frac_offset", C.c_double * 3),
+        ("frac_scale", C.c_double * 3),
     ]
 
 

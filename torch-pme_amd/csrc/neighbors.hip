@@ -21,6 +21,7 @@ struct NlGeom {
   int periodic[3];
   double cutoff2;
   int full_list;
+  double foff[3], fscale[3];  // binning map of the non-periodic axes
 };
 
 static inline NlGeom make_nl(const mipme_nl_t* d) {
@@ -32,6 +33,8 @@ static inline NlGeom make_nl(const mipme_nl_t* d) {
   for (int k = 0; k < 3; ++k) {
     g.nc[k] = d->n_cells[k];
     g.periodic[k] = d->periodic[k];
+    g.foff[k] = d->periodic[k] ? 0.0 : d->frac_offset[k];
+    g.fscale[k] = d->periodic[k] ? 1.0 : d->frac_scale[k];
   }
   g.cutoff2 = d->cutoff * d->cutoff;
   g.full_list = d->full_list;
@@ -50,7 +53,7 @@ __device__ __forceinline__ void atom_cell(const NlGeom& g, const T* __restrict__
     const double fl = g.periodic[d] ? floor(f[d]) : 0.0;
     w[d] = int(fl);
     f[d] -= fl;
-    int cd = int(f[d] * g.nc[d]);
+    int cd = int((f[d] - g.foff[d]) * g.fscale[d] * g.nc[d]);
     cd = cd < 0 ? 0 : (cd >= g.nc[d] ? g.nc[d] - 1 : cd);
     c[d] = cd;
   }
@@ -241,6 +244,8 @@ static int validate_nl(const mipme_nl_t* d) {
   MIPME_REQUIRE(d->cutoff > 0, "cutoff must be positive");
   for (int k = 0; k < 3; ++k) {
     MIPME_REQUIRE(d->n_cells[k] >= 1, "invalid cell grid");
+    MIPME_REQUIRE(d->periodic[k] || (d->n_cells[k] >= 1 && d->frac_scale[k] > 0.0),
+                  "a non-periodic axis needs n_cells >= 1 and a positive frac_scale");
     MIPME_REQUIRE(!d->periodic[k] || d->n_cells[k] >= 3,
                   "the device neighbour list needs >= 3 cells of width >= cutoff along every periodic axis");
   }

@@ -58,7 +58,8 @@ def neighbor_list(positions, cell, cutoff: float, full_list: bool = False, perio
             for sz in rng[2]:
                 s = np.array([sx, sy, sz])
                 f = fw + s
-                keep = np.all((f >= -skin) & (f <= 1.0 + skin), axis=1)
+                # (along a non-periodic axis there are no images and atoms may lie anywhere: no filter there)
+                keep = np.all(((f >= -skin) & (f <= 1.0 + skin)) | ~periodic, axis=1)
                 if not keep.any():
                     continue
                 ids = np.nonzero(keep)[0]
@@ -128,12 +129,13 @@ def neighbor_list_bruteforce(positions, cell, cutoff: float, full_list: bool = F
     return np.stack([i, j], axis=1), S, np.sqrt(np.sum(vec * vec, axis=1))
 
 
-def neighbor_list_device(positions, cell, cutoff: float, full_list: bool = False):
+def neighbor_list_device(positions, cell, cutoff: float, full_list: bool = False, periodic=(True, True, True)):
     """Neighbour list built ON THE GPU (``csrc/neighbors.hip``): ``positions`` (N,3) and ``cell`` (3,3) are device
     tensors; returns device tensors ``pairs`` (P,2) int64, ``shifts`` (P,3) and ``dist`` (P,) in the dtype of
     ``positions`` -- the same pair set as :func:`neighbor_list` (rows ordered by the first index; the order inside a
-    row is the cell-traversal order).  Fully periodic cells with at least 3 cutoff-wide cells per axis; raises
-    ``ValueError`` otherwise (use the host builder then)."""
+    row is the cell-traversal order).  Every periodic axis needs at least 3 cutoff-wide cells (raises ``ValueError``
+    otherwise: use the host builder then); along a non-periodic axis (no images) the atoms may lie anywhere -- the cell grid
+    then spans their extent, which costs one more small device-to-host copy."""
     import ctypes as C
 
     import torch
@@ -145,20 +147,33 @@ def neighbor_list_device(positions, cell, cutoff: float, full_list: bool = False
     device, dtype = positions.device, positions.dtype
     A = cell.detach().to("cpu", torch.float64).numpy()
     vol = abs(np.linalg.det(A))
+    periodic = [bool(p) for p in periodic]
+    frac_off, frac_scale = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    if not all(periodic) and positions.shape[0] > 0:
+        frac = positions.detach().to(torch.float64) @ torch.tensor(np.linalg.inv(A), device=positions.device)
+        lo, hi = frac.min(dim=0).values.cpu().numpy(), frac.max(dim=0).values.cpu().numpy()
     nc = []
     for d in range(3):
         width = vol / np.linalg.norm(np.cross(A[(d + 1) % 3], A[(d + 2) % 3]))
-        nc.append(int(np.floor(width / cutoff)))
-    if min(nc) < 3:
+        if periodic[d]:
+            nc.append(int(np.floor(width / cutoff)))
+        else:  # the grid spans the atoms' extent along this axis (slightly enlarged so that the last atom is inside)
+            span = (float(hi[d] - lo[d]) if positions.shape[0] > 0 else 0.0) * (1.0 + 1e-9) + 1e-9
+            frac_off[d] = float(lo[d]) if positions.shape[0] > 0 else 0.0
+            frac_scale[d] = 1.0 / span
+            nc.append(max(1, int(np.floor(width * span / cutoff))))
+    if any(p and n < 3 for n, p in zip(nc, periodic)):
         raise ValueError(
-            f"device neighbour list needs >= 3 cells of width >= cutoff per axis, got {nc}; use neighbor_list() (host)"
+            f"device neighbour list needs >= 3 cells of width >= cutoff per periodic axis, got {nc}; use neighbor_list() (host)"
         )
     nc = [min(n, 256) for n in nc]
     desc = _lib.NlDesc()
     desc.cell[:] = A.ravel().tolist()
     desc.inv_cell[:] = np.linalg.inv(A).ravel().tolist()
     desc.n_cells[:] = nc
-    desc.periodic[:] = [1, 1, 1]
+    desc.periodic[:] = [int(p) for p in periodic]
+    desc.frac_offset[:] = frac_off
+    desc.frac_scale[:] = frac_scale
     desc.cutoff = float(cutoff)
     desc.full_list = int(bool(full_list))
     pos = positions.detach().contiguous()
