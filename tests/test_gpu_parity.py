@@ -649,3 +649,35 @@ def test_graphed_cell_gradient(golden_dir):
         assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())
         assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
         assert relmax(dEdcell.cpu(), z["p3m5/f64/grad_cell"]) < 1e-9
+
+
+@pytest.mark.parametrize("energy", [True, False])
+def test_fused_path_with_slab_correction(energy):
+    """2-D periodic slab (periodic = [T, T, F]) through pair_distances -> calculator: the slab term keeps the mesh part on
+    the general backward while the pair part may still take its energy-mode shortcut; compare with the oracle."""
+    rng = np.random.default_rng(21)
+    cell = np.array([[8.0, 0, 0], [0.5, 7.0, 0], [0, 0, 30.0]])
+    N = 120
+    pos = np.column_stack([rng.uniform(0, 8, N), rng.uniform(0, 7, N), rng.uniform(10, 18, N)])
+    q = rng.normal(size=(N, 1))
+    q -= q.mean()
+    periodic = (True, True, False)
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 5.0, periodic=periodic)
+    spec = O.PotentialSpec("coulomb", 1, 1.0, 1.0)
+    g = -0.7 * q if energy else rng.normal(size=(N, 1))
+    Vo, cache = O.forward(spec, "P3M", 5, 0.8, q, cell, pos, pairs, dist, periodic=periodic, return_cache=True)
+    gr = O.backward(cache, g)
+    gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.8, interpolation_nodes=5)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=torch.float64, requires_grad=grad)  # noqa: E731
+    tq, tc, tp = t(q), t(cell, True), t(pos, True)
+    ti = torch.tensor(pairs, device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, torch.tensor(S, device=DEV))
+    V = calc(tq, tc, tp, ti, d, periodic=torch.tensor(periodic, device=DEV))
+    if energy:
+        (-0.7 * tpa.weighted_sum(V, tq)).backward()
+    else:
+        (V * t(g)).sum().backward()
+    assert rell2(V.detach().cpu(), Vo) < 1e-11
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    assert relmax(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
