@@ -681,3 +681,24 @@ def test_fused_path_with_slab_correction(energy):
     assert rell2(V.detach().cpu(), Vo) < 1e-11
     assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
     assert relmax(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+
+
+def test_graphed_recapture(golden_dir):
+    """GraphedEnergyForces.recapture with a new neighbour list (different pair order and a larger cutoff list of the same
+    pairs): the replayed step follows the new list."""
+    z = np.load(f"{golden_dir}/ref_medium.npz")
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=float(z["smearing"])), mesh_spacing=float(z["p3m5/mesh_spacing"]),
+                             interpolation_nodes=5)
+    t = lambda k: torch.tensor(z[k], device=DEV)  # noqa: E731
+    pairs, shifts = t("pairs"), t("shifts").double()
+    half = len(pairs) // 2
+    step = tpa.GraphedEnergyForces(calc, t("charges"), t("cell"), t("positions"), pairs[:half].contiguous(),
+                                   shifts[:half].contiguous())
+    E_half, _ = step()
+    e_half = E_half.item()
+    perm = torch.randperm(len(pairs), device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    step.recapture(pairs[perm].contiguous(), shifts[perm].contiguous())
+    E, F = step(t("positions"))
+    assert abs(e_half - float(z["p3m5/f64/energy"])) > 1e-3 * abs(e_half)
+    assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())
+    assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10

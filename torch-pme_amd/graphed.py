@@ -30,12 +30,25 @@ class GraphedEnergyForces:
         #: with ``cell_gradient=True`` every call also returns dE/dcell (3,3) -- the virial is ``-cell.T @ dE/dcell``
         self.cell_gradient = cell_gradient
         self.cell = cell.detach().clone().requires_grad_(True) if cell_gradient else cell.detach()
-        self.pairs = neighbor_indices
-        self.shifts = neighbor_shifts.to(positions.dtype).contiguous()
         self.pos = positions.detach().clone().requires_grad_(True)
         device = positions.device
         # seeding the backward pass with -1 makes ``pos.grad`` the forces directly (no fill and no negation kernel)
         self._minus_one = torch.tensor(-1.0, dtype=positions.dtype, device=device)
+        self._warmup = max(1, warmup)
+        self._capture(neighbor_indices, neighbor_shifts)
+
+    def recapture(self, neighbor_indices, neighbor_shifts, positions: torch.Tensor | None = None) -> None:
+        """New neighbour list (e.g. after the atoms moved by more than the skin): rebuild the pair topology and capture the
+        step again; positions, cell and charges buffers are kept."""
+        if positions is not None:
+            with torch.no_grad():
+                self.pos.copy_(positions)
+        self._capture(neighbor_indices, neighbor_shifts)
+
+    def _capture(self, neighbor_indices, neighbor_shifts):
+        calculator, cell_gradient, device, warmup = self.calc, self.cell_gradient, self.pos.device, self._warmup
+        self.pairs = neighbor_indices
+        self.shifts = neighbor_shifts.to(self.pos.dtype).contiguous()
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):  # warm-up off the default stream: plans, topology, filter caches get built
