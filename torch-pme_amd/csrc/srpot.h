@@ -225,7 +225,7 @@ __device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v
   const T inv2 = inv * inv;
   const T x = d2 * inv_2s2;
   const T e = rs_exp_neg(x);
-  T Q, dens;
+  T Q, two_x_dens;  // Q(P/2, x) and 2 x dens(x)
   if constexpr (P % 2 == 0) {
     T term = T(1), sum = T(1);
 #pragma unroll
@@ -234,25 +234,27 @@ __device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v
       sum += term;
     }
     Q = e * sum;
-    dens = e * term;
+    two_x_dens = T(2) * x * e * term;
   } else {
+    // half-integer a = m + 1/2: term_k = x^(k-1/2) e^-x / Gamma(k+1/2); term_1 = 2 y e / sqrt(pi) with y = sqrt(x), so no
+    // division by y is needed: Q = erfc(y) + sum_{k=1..m} term_k and 2 x dens = 2 x term_m = (2m+1) term_{m+1}
+    constexpr int m = (P - 1) / 2;
     const T y = c1 * (d2 * inv);
     Q = rs_erfc(y, e);
-    T term = e * T(0.56418958354775628695) * rs_rcp(y);
-    dens = term;
+    T term = T(2.0 * 0.56418958354775628695) * y * e;  // term_1
 #pragma unroll
-    for (int k = 1; k <= (P - 1) / 2; ++k) {
-      term *= x * T(1.0 / (k - 0.5));
+    for (int k = 1; k <= m; ++k) {
       Q += term;
-      dens = term;
+      term *= x * T(1.0 / (k + 0.5));  // -> term_{k+1}
     }
+    two_x_dens = T(2 * m + 1) * term;
   }
   T invp = inv;
 #pragma unroll
   for (int k = 1; k < P; ++k) invp *= inv;
   const T pi = pref * invp;
   v = pi * Q;
-  if constexpr (DERIV) dvd = -(pi * inv2) * (T(2) * x * dens + T(P) * Q);
+  if constexpr (DERIV) dvd = -(pi * inv2) * (two_x_dens + T(P) * Q);
 }
 
 }  // namespace mipme
