@@ -221,7 +221,9 @@ int64_t mipme_pair_partials_size(int64_t n_pairs);
  * owner-computes row sums over a transposed pair list, built once per neighbour list:
  *   row_ptr  int32[2N+1]: entries row_ptr[2a]..row_ptr[2a+1] have atom a as FIRST index (role i),
  *                         row_ptr[2a+1]..row_ptr[2a+2] as SECOND index (role j); pair index ascending.
- *   entries  int32[2P][2]: { other atom, pair index }.
+ *   entries  int32[2P][2]: { other atom, pair index }.  Allocate the entry tables (entries, packed shifts, entries_shift)
+ *                         with ONE extra element: the row kernels prefetch the first entry of a row before testing
+ *                         whether the row is empty, which for an empty last row is index 2P (the value is never used).
  * workspace: >= mipme_topology_workspace_bytes(P) bytes of device scratch. */
 int64_t mipme_topology_workspace_bytes(int64_t n_pairs);
 int mipme_topology_build(void* stream, int idx_dtype, int64_t n_pairs, int64_t n_atoms, const void* pairs,

@@ -155,7 +155,8 @@ class PairTopology:
         P = pairs.shape[0]
         self.n_atoms, self.n_pairs = n_atoms, P
         self.row_ptr = torch.empty((2 * n_atoms + 1,), dtype=torch.int32, device=device)
-        self.entries = torch.empty((max(2 * P, 1), 2), dtype=torch.int32, device=device)
+        # one slot more than 2P: the row kernels prefetch entry `row begin` even for an empty last row (index 2P), never used
+        self.entries = torch.zeros((2 * P + 1, 2), dtype=torch.int32, device=device)
         self._packed = None  # (weakref(shifts), version, tensor|None)
         self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
         self._pair_sh = None  # (weakref(shifts), version, tensor|None)
@@ -181,7 +182,7 @@ class PairTopology:
             return c[2]
         lib = _lib.load()
         device = shifts.device
-        packed = torch.empty((max(2 * self.n_pairs, 1),), dtype=torch.int32, device=device)
+        packed = torch.zeros((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
         with torch.cuda.device(device):
             _lib.check(
@@ -225,7 +226,7 @@ class PairTopology:
             return c[2], c[3]
         lib = _lib.load()
         device = self.entries.device
-        ent_sh = torch.empty((max(2 * self.n_pairs, 1), 2), dtype=torch.int32, device=device)
+        ent_sh = torch.zeros((2 * self.n_pairs + 1, 2), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
         fmt = 1 if table else 0
         while True:
