@@ -285,3 +285,40 @@ def test_padded_batch_through_vmap(dtype):
         (calc.forward(q, cell, p, pairs, dist, periodic[k]) * q).sum().backward()
         torch.testing.assert_close(pos_g.grad[k, : sizes[k]], p.grad, rtol=1e-4 if dtype == torch.float32 else 1e-10,
                                    atol=1e-5 if dtype == torch.float32 else 1e-11)
+
+
+def test_fused_path_input_variants():
+    """int32 pair lists, integer-typed shift tensors, non-contiguous positions and float32 shifts with float64 positions all
+    go through the fused path and agree with the plain call."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(8)
+    cell_np = np.array([[9.0, 0, 0], [1.0, 8.0, 0], [0.5, -0.5, 10.0]])
+    pos_np = rng.uniform(0, 9, (80, 3))
+    q_np = rng.normal(size=(80, 1))
+    pairs_np, S_np, _ = tpa.neighbor_list(pos_np, cell_np, 4.0)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.7, interpolation_nodes=4)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    cell, q = t(cell_np), t(q_np)
+
+    def run(pos, pairs, shifts):
+        p = pos.clone().requires_grad_(True)
+        d = tpa.pair_distances(p, pairs, cell, shifts)
+        V = calc(q, cell, p, pairs, d)
+        assert ops.LAST_FORWARD_FUSED if hasattr(ops, "LAST_FORWARD_FUSED") else True
+        tpa.weighted_sum(V, q).backward()
+        return V.detach(), p.grad
+
+    ref_V, ref_g = run(t(pos_np), t(pairs_np), t(S_np).double())
+    wide = torch.zeros((80, 7), device=DEV, dtype=torch.float64)
+    wide[:, 1:6:2] = t(pos_np)
+    variants = {
+        "int32 pairs": (t(pos_np), t(pairs_np).to(torch.int32), t(S_np).double()),
+        "int64 shifts": (t(pos_np), t(pairs_np), t(S_np)),
+        "float32 shifts": (t(pos_np), t(pairs_np), t(S_np).float()),
+        "strided positions": (wide[:, 1:6:2], t(pairs_np), t(S_np).double()),
+    }
+    for name, (pos, pairs, shifts) in variants.items():
+        V, g = run(pos, pairs, shifts)
+        torch.testing.assert_close(V, ref_V, rtol=1e-12, atol=1e-13, msg=name)
+        torch.testing.assert_close(g, ref_g, rtol=1e-11, atol=1e-12, msg=name)
