@@ -572,13 +572,15 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
   }
 }
 
+// Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
 template <int N, typename T>
 __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
     Geom g, BrickGeom bg, int C, const int* __restrict__ start, const int4* __restrict__ rec, const T* __restrict__ wts,
     const T* __restrict__ q, const T* __restrict__ gout, const T* __restrict__ phi, const T* __restrict__ chi,
     const T* __restrict__ psi_dc, const T* __restrict__ gscale, T half_inv_vol, T self_c, T bg_c,
     T* __restrict__ grad_pos, T* __restrict__ grad_q) {
-  constexpr int LANES = StencilGroup<N>::LANES;
+  static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
+  constexpr int LANES = kGatherLanes;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   constexpr int TV = TL * TL * TL;
@@ -594,8 +596,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
   if (beg == end) return;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
-  const int ty = l / N, tz = l - ty * N;
-  const bool lane_active = l < N * N;
+  const bool lane_active = l < N;
+  const int tz = lane_active ? l : 0;
   // stage phi and chi of every channel once: tile[(2c + {0: phi, 1: chi}) * TV + k]
   for (int c = 0; c < C; ++c) load_tiles<N, 2, T>(g, ox, oy, oz, phi + c * M, chi + c * M, tile + 2 * c * TV);
   __syncthreads();
@@ -605,39 +607,50 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
     const int id = valid ? idx : beg;
     const int4 a = rec[id];
     const T* wr = wts + int64_t(id) * (6 * N);
-    const int tyc = lane_active ? ty : 0, tzc = lane_active ? tz : 0;
-    const T wyv = wr[N + tyc], wzv = wr[2 * N + tzc];
-    const T dwyv = wr[4 * N + tyc], dwzv = wr[5 * N + tzc];
+    T wx[N], wy[N], dwx[N], dwy[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      wx[t] = wr[t];
+      wy[t] = wr[N + t];
+      dwx[t] = wr[3 * N + t];
+      dwy[t] = wr[4 * N + t];
+    }
+    const T wzv = lane_active ? wr[2 * N + tz] : T(0), dwzv = lane_active ? wr[5 * N + tz] : T(0);
     const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
-    T sx = T(0), sdx = T(0);
+    T sA = T(0), sB = T(0), sC = T(0);  // over (t_x, t_y), summed over channels: wx wy v, dwx wy v, wx dwy v
     for (int c = 0; c < C; ++c) {
       const int64_t o = int64_t(a.w) * C + c;
       const T hc = gout[o] * half_inv_vol;
       const T qc = q[o];
+      const T* tp = tile + 2 * c * TV + ry * TL + (rz + tz);
       T schi = T(0);
-      if (lane_active) {
-        const T* tp = tile + 2 * c * TV + (ry + ty) * TL + (rz + tz);
+#pragma unroll
+      for (int ty = 0; ty < N; ++ty) {
+        T sx = T(0), sdx = T(0), sch = T(0);
 #pragma unroll
         for (int tx = 0; tx < N; ++tx) {
-          const T vphi = tp[(rx + tx) * TL * TL];
-          const T vchi = tp[TV + (rx + tx) * TL * TL] * cs;
+          const int off = (rx + tx) * TL * TL + ty * TL;
+          const T vphi = tp[off];
+          const T vchi = tp[TV + off] * cs;
           const T v = hc * vphi + qc * vchi;
-          const T wxv = wr[tx];
-          sx += v * wxv;
-          sdx += v * wr[3 * N + tx];
-          schi += vchi * wxv;
+          sx += v * wx[tx];
+          sdx += v * dwx[tx];
+          sch += vchi * wx[tx];
         }
+        sA += sx * wy[ty];
+        sB += sdx * wy[ty];
+        sC += sx * dwy[ty];
+        schi += sch * wy[ty];
       }
       if (grad_q) {
-        schi = group_sum_b<LANES, T>(lane_active ? schi * wyv * wzv : T(0));
+        schi = group_sum_b<LANES, T>(schi * wzv);
         if (l == 0 && valid) grad_q[o] = schi - T(0.5) * self_c * gout[o] - T(2) * bg_c * psi_dc[c] * cs;
       }
     }
     if (grad_pos) {
-      const T act = lane_active ? T(1) : T(0);
-      const T ax = group_sum_b<LANES, T>(sdx * wyv * wzv * act) * T(g.nx);
-      const T ay = group_sum_b<LANES, T>(sx * dwyv * wzv * act) * T(g.ny);
-      const T az = group_sum_b<LANES, T>(sx * wyv * dwzv * act) * T(g.nz);
+      const T ax = group_sum_b<LANES, T>(sB * wzv) * T(g.nx);
+      const T ay = group_sum_b<LANES, T>(sC * wzv) * T(g.ny);
+      const T az = group_sum_b<LANES, T>(sA * dwzv) * T(g.nz);
       if (l == 0 && valid) {
         const int64_t o = int64_t(a.w);
         grad_pos[3 * o + 0] = T(g.inv[0]) * ax + T(g.inv[1]) * ay + T(g.inv[2]) * az;
