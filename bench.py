@@ -173,8 +173,8 @@ def cpu_baseline_numpy(w, budget_s: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
     ap.add_argument("--frames-per-gpu", type=int, default=1,
                     help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --workload ionic "
@@ -291,12 +291,13 @@ def main():
 
     ops.PROFILE = {}
     _lib.profile_enable(True)
-    for _ in range(args.steps):
+    n_instr = min(args.steps, 50)
+    for _ in range(n_instr):
         frame.step()
     torch.cuda.synchronize()
     prof = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ops.PROFILE.items()}  # ms per call
     stages = {k: ms / calls for k, (calls, ms) in _lib.profile_report().items()}  # ms per launch, inside composites
-    stage_calls = {k: calls / args.steps for k, (calls, ms) in _lib.profile_report().items()}
+    stage_calls = {k: calls / n_instr for k, (calls, ms) in _lib.profile_report().items()}
     _lib.profile_enable(False)
     ops.PROFILE = None
 
