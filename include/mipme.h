@@ -266,7 +266,12 @@ int64_t mipme_rows_partials_size(int64_t n_atoms);
  *         fetches the partner atom; records_ready != 0: already filled with (positions, src) -- e.g. by
  *         mipme_kspace_forward(out_records) -- and not repacked.
  *   partials nullable: float64[mipme_rows_partials_size(N)] per-block sums of the cell gradient; with grad_out != NULL
- *         and grad_cell != NULL they are reduced into grad_cell (3,3). */
+ *         and grad_cell != NULL they are reduced into grad_cell (3,3).
+ *   dist_out (P) nullable, potential passes only (out != NULL, no pair mask, transpose == 0): the pair distances d_p,
+ *         written as a by-product by the row that owns the pair's FIRST atom -- the tensor the caller's compute_distances
+ *         (tests/helpers.py:278-304) would have produced, without a separate pass over the list.  Requires a pair list
+ *         ordered by its first index (pairs[p][0] non-decreasing), as neighbour-list builders emit it: the role-i entries
+ *         of a row are then consecutive pairs. */
 int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, int64_t n_atoms, const void* row_ptr,
                                 const void* entries, const void* shifts, int shift_format, void* entries_shift,
                                 void* flag);
@@ -274,7 +279,7 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
                         const mipme_potential_t* pot, int accumulate, int shift_format, void* records,
-                        int records_ready, void* out, void* force, void* partials, void* grad_cell);
+                        int records_ready, void* out, void* force, void* partials, void* grad_cell, void* dist_out);
 /* grad_positions[a] = gE charges[a] (f force[a] + field[a]); grad_cell = f gE sum(partials); f = 1/2 for a full list,
  * gE = grad_scale[0].  force: from mipme_sr_rows_fused (nullable); field: out_field of mipme_kspace_forward (nullable). */
 int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void* force, const void* field,

@@ -339,9 +339,13 @@ def test_graphed_energy_forces(golden_dir):
     e1 = E.item()
     assert abs(e1 - eref) < 1e-10 * abs(eref)
     assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
+    # the distances of the step (written by the pair kernel, see pair_distances(deferred=True)) follow the positions
+    d_ref = np.linalg.norm(z["positions"][z["pairs"][:, 1]] - z["positions"][z["pairs"][:, 0]] + z["shifts"] @ z["cell"], axis=1)
+    assert relmax(step.distances.cpu(), d_ref) < 1e-14
     e2 = step(pos + 0.01)[0].item()
     e3 = step(pos)[0].item()
     assert abs(e2 - e1) > 1e-6 and abs(e3 - eref) < 1e-10 * abs(eref)
+    assert relmax(step.distances.cpu(), d_ref) < 1e-14
 
 
 @pytest.mark.parametrize("fast", [True, False])
@@ -458,6 +462,82 @@ def test_fused_distances_guards():
         finally:
             ops.FUSE_DISTANCES = True
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("variant", ["fused", "mask", "unsorted", "nograd", "p6", "ewald"])
+def test_deferred_distances(dtype, full, variant, monkeypatch):
+    """``pair_distances(..., deferred=True)``: the distance tensor is filled by the calculator's fused pair kernel (the row
+    of a pair's first atom stores d[p]); with a pair mask / a list not ordered by its first index / a calculator without
+    the fused path the stand-alone kernel runs first.  Same distances (vs the oracle), potentials and gradients as the
+    eager distance kernel in every case, and the stand-alone kernel is launched exactly when expected."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(21)
+    cell = np.array([[7.0, 0, 0], [0.7, 6.0, 0], [0.2, -0.5, 8.0]])
+    N = 150
+    pos = rng.uniform(-1, 8, (N, 3))
+    q = rng.normal(size=(N, 1))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 5.0, full_list=full)
+    if variant == "unsorted":
+        perm = rng.permutation(len(pairs))
+        pairs, S, dist = pairs[perm], S[perm], dist[perm]
+    mask = torch.tensor(rng.uniform(size=len(pairs)) > 0.2, device=DEV) if variant == "mask" else None
+    pot = tpa.InversePowerLawPotential(exponent=6, smearing=1.1) if variant == "p6" else tpa.CoulombPotential(smearing=1.1)
+    if variant == "ewald":
+        calc = tpa.EwaldCalculator(pot, lr_wavelength=2.0, full_neighbor_list=full)
+    else:
+        calc = tpa.P3MCalculator(pot, mesh_spacing=0.9, interpolation_nodes=4, full_neighbor_list=full)
+    calc = calc.to(dtype)
+    grad = variant != "nograd"
+    ti, tS = torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV)
+    res = []
+    for deferred in (False, True):
+        tq = torch.tensor(q, device=DEV, dtype=dtype)
+        tc = torch.tensor(cell, device=DEV, dtype=dtype, requires_grad=grad)
+        tp = torch.tensor(pos, device=DEV, dtype=dtype, requires_grad=grad)
+        calls = {}
+        monkeypatch.setattr(ops, "PROFILE", calls)
+        d = tpa.pair_distances(tp, ti, tc, tS, deferred=deferred)
+        assert d._mipme_src.pending == deferred
+        V = calc(tq, tc, tp, ti, d, pair_mask=mask)
+        assert not d._mipme_src.pending
+        if grad:
+            tpa.weighted_sum(V, tq).backward()
+        monkeypatch.setattr(ops, "PROFILE", None)
+        by_product = deferred and variant not in ("mask", "unsorted")
+        assert ("pair_distance_forward" in calls) == (not by_product), calls.keys()
+        res.append((d.detach().cpu(), V.detach().cpu(), tp.grad.cpu() if grad else None, tc.grad.cpu() if grad else None))
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    assert relmax(res[1][0], dist) < (1e-14 if dtype == torch.float64 else 5e-7)  # the by-product distances vs the list builder's
+    assert relmax(res[0][0], dist) < (1e-14 if dtype == torch.float64 else 5e-7)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        if a is not None:
+            assert rell2(b, a.numpy()) < tol
+
+
+def test_deferred_distances_other_consumers():
+    """A deferred tensor that reaches a consumer without the fused path (several charge channels; a second calculator call
+    after the first one filled it) is materialised / reused correctly."""
+    rng = np.random.default_rng(4)
+    cell = np.eye(3) * 6.0
+    pos = rng.uniform(0, 6, (80, 3))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 2.9)
+    tp = torch.tensor(pos, device=DEV, requires_grad=True)
+    tc, ti, tS = torch.tensor(cell, device=DEV), torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV)
+    calc = tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.8)
+    q2 = torch.tensor(rng.normal(size=(80, 2)), device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, tS, deferred=True)
+    V2 = calc(q2, tc, tp, ti, d)  # two channels: unfused pair kernels read d
+    assert relmax(d.detach().cpu(), dist) < 1e-14
+    V2_ref = calc(q2, tc, tp, ti, tpa.pair_distances(tp, ti, tc, tS))
+    torch.testing.assert_close(V2, V2_ref, rtol=1e-13, atol=1e-13)
+    d1 = tpa.pair_distances(tp, ti, tc, tS, deferred=True)
+    Va = calc(q2[:, :1].contiguous(), tc, tp, ti, d1)  # fills d1
+    Vb = calc(q2[:, :1].contiguous(), tc, tp, ti, d1)  # reads the provenance again: nothing pending
+    torch.testing.assert_close(Va, Vb, rtol=1e-13, atol=1e-13)
+    assert relmax(d1.detach().cpu(), dist) < 1e-14
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

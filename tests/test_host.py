@@ -59,7 +59,7 @@ def test_abi_argument_errors_without_gpu():
     # argument checks of the entry points added for the fused / Ewald / tuning rows (all return MIPME_EINVAL = -1 before
     # any launch; messages via mipme_last_error)
     assert lib.mipme_sr_rows_fused(None, _lib.F32, 4, None, None, None, None, None, None, None, None, None, 0, 0,
-                                   C.byref(pd), 0, 0, None, 0, None, None, None, None) == -1
+                                   C.byref(pd), 0, 0, None, 0, None, None, None, None, None) == -1
     assert b"mipme_sr_rows_fused" in lib.mipme_last_error()
     assert lib.mipme_sr_rows_finalize(None, _lib.F32, 4, None, None, None, None, 0, None, None, None) == -1
     assert lib.mipme_topology_pack_entries(None, _lib.F32, 4, 2, None, None, None, 0, None, None) == -1

@@ -49,7 +49,7 @@ def fused(want_pot, want_force, grad):
     _lib.check(lib.mipme_sr_rows_fused(
         st, F32, N, topo.row_ptr.data_ptr(), ent_sh.data_ptr(), topo.entries.data_ptr(), None, pos.data_ptr(),
         cell.data_ptr(), q.data_ptr(), q.data_ptr() if want_pot else None, g.data_ptr() if grad else None, 0, 0,
-        C.byref(pot), 0, fmt, rec.data_ptr(), 0, out.data_ptr() if want_pot else None, force.data_ptr() if want_force else None, None, None))
+        C.byref(pot), 0, fmt, rec.data_ptr(), 0, out.data_ptr() if want_pot else None, force.data_ptr() if want_force else None, None, None, None))
 
 
 def unfused():

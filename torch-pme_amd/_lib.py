@@ -112,7 +112,7 @@ def _declare(lib):
         "mipme_topology_pack_entries": [vp, ci, i64, i64, vp, vp, vp, ci, vp, vp],
         "mipme_pack_pair_shifts": [vp, ci, i64, vp, vp, vp],
         "mipme_pair_distance_forward_packed": [vp, ci, i64, vp, vp, vp, vp, vp],
-        "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, ci, vp, ci, vp, vp, vp, vp],
+        "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, ci, vp, ci, vp, vp, vp, vp, vp],
         "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
         "mipme_ewald_filter": [vp, ci, PP, i64, vp, vp, vp],
         "mipme_ewald_structure": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp],

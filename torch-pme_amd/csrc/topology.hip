@@ -425,8 +425,10 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
     const int2* __restrict__ entries, const uint8_t* __restrict__ mask, const T* __restrict__ pos,
     const AtomRecord<T>* __restrict__ rec, const T* __restrict__ cell, const T* __restrict__ q,
     const T* __restrict__ g, int pot_lo, int pot_hi, bool full, bool accumulate, T* __restrict__ out,
-    T* __restrict__ force, double* __restrict__ partials) {
+    T* __restrict__ force, double* __restrict__ partials, T* __restrict__ dist_out) {
   // rec[o] = (position of o, src[o]) with src = charges except in the transposed potential pass
+  // dist_out (potential passes without a mask, pair list ordered by its first index): the role-i entries of a row are the
+  // consecutive pairs starting at the pair of its first entry, and their distances are written as a by-product
   constexpr int U = kRowUnroll;
   constexpr bool POT = MODE == kPot || MODE == kPotForce;
   constexpr bool FORCE = MODE != kPot;
@@ -455,6 +457,11 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
   const int beg = FORCE ? r0 : pbeg;
   const int end = valid ? (FORCE ? r2 : pend) : beg;
   const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+  constexpr bool CAN_WRITE_D = POT && !MASK;
+  int64_t pair_base = 0;  // pair index of entry r0 minus r0
+  if constexpr (CAN_WRITE_D) {
+    if (dist_out) pair_base = int64_t(entries[r0].y) - r0;
+  }
   T qa = T(0), ga = T(0);
   if constexpr (FORCE) qa = q[a];
   if constexpr (MODE == kForceG) ga = g[a];
@@ -532,6 +539,12 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(
         T dv;
         sr_eval<T, FORCE>(s, d, v, dv);
         dvd = dv / d;
+      }
+      if constexpr (CAN_WRITE_D) {
+        if (dist_out && role_i && ok[u]) {
+          const T d2c = d2 > T(1e-30) ? d2 : T(1e-30);
+          dist_out[pair_base + e] = PFAST > 0 ? d2c * rs_rsqrt(d2c) : fsqrt(d2);
+        }
       }
       const T sv = use ? so[u] : T(0);  // masked / padding entries carry zero weight
       if constexpr (POT) {
@@ -717,7 +730,7 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
                               const void* mask, const void* pos, const void* cell, const void* q, const void* src,
                               const void* g, int transpose, int full_list, const mipme_potential_t* pot, int accumulate,
                               int shift_format, void* records, int records_ready, void* out, void* force,
-                              void* partials, void* grad_cell) {
+                              void* partials, void* grad_cell, void* dist_out) {
   SRPot s;
   int rc = make_srpot(pot, s);
   if (rc) return rc;
@@ -754,7 +767,7 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   sr_fused_rows_kernel<T, MODE, CG, CF, MK, TB><<<grid, 256, 0, st>>>(                                                    \
       s, cf, N, (const int*)row_ptr, (const int2*)ent_sh, (const int2*)entries, (const uint8_t*)mask, (const T*)pos,  \
       (const AtomRecord<T>*)records, (const T*)cell, (const T*)q, (const T*)g, lo, hi, full_list != 0,                \
-      accumulate != 0, (T*)out, (T*)force, (double*)partials)
+      accumulate != 0, (T*)out, (T*)force, (double*)partials, (T*)dist_out)
 #define MIPME_FUSED_MK(MODE, CG, CF)                                                                                  \
   do {                                                                                                                \
     if (mask)                                                                                                         \
@@ -930,8 +943,10 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
                         const void* entries, const void* pair_mask, const void* positions, const void* cell,
                         const void* charges, const void* src, const void* grad_out, int transpose, int full_list,
                         const mipme_potential_t* pot, int accumulate, int shift_format, void* records,
-                        int records_ready, void* out, void* force, void* partials, void* grad_cell) {
+                        int records_ready, void* out, void* force, void* partials, void* grad_cell, void* dist_out) {
   MIPME_REQUIRE(n_atoms >= 0 && row_ptr, "invalid arguments to mipme_sr_rows_fused");
+  MIPME_REQUIRE(!dist_out || (out && !pair_mask && !transpose && entries),
+                "`dist_out` is written by the potential pass only (no pair mask, not transposed) and needs the entry table");
   MIPME_REQUIRE(n_atoms == 0 || (entries_shift && positions && charges && records), "NULL buffer passed to mipme_sr_rows_fused");
   MIPME_REQUIRE(!pair_mask || entries, "`pair_mask` needs the (other, pair) entry table");
   MIPME_REQUIRE(!out || src, "`src` is required for the potential sum");
@@ -941,11 +956,11 @@ int mipme_sr_rows_fused(void* stream, int dtype, int64_t n_atoms, const void* ro
   if (dtype == MIPME_F32)
     return sr_fused_rows_impl<float>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
                                      src, grad_out, transpose, full_list, pot, accumulate, shift_format, records, records_ready, out, force, partials,
-                                     grad_cell);
+                                     grad_cell, dist_out);
   if (dtype == MIPME_F64)
     return sr_fused_rows_impl<double>(st, n_atoms, row_ptr, entries_shift, entries, pair_mask, positions, cell, charges,
                                       src, grad_out, transpose, full_list, pot, accumulate, shift_format, records, records_ready, out, force, partials,
-                                     grad_cell);
+                                     grad_cell, dist_out);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
 }

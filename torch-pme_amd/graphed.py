@@ -76,7 +76,10 @@ class GraphedEnergyForces:
             self.cell_grad = -self.cell.grad if cell_gradient else None
 
     def _eval(self):
-        d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
+        # deferred: the pair kernel of the calculator writes the distances as a by-product (no separate pass over the list)
+        d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts, deferred=True)
+        #: the pair distances of the last evaluation (P,)
+        self.distances = d.detach()
         V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
         E = ops.weighted_sum(V, self.q)
         E.backward(self._minus_one)

@@ -160,6 +160,7 @@ class PairTopology:
         self._packed = None  # (weakref(shifts), version, tensor|None)
         self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
         self._pair_sh = None  # (weakref(shifts), version, tensor|None)
+        self._sorted = None
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
         with torch.cuda.device(device):
@@ -171,6 +172,15 @@ class PairTopology:
                     ws.data_ptr(), nbytes, self.row_ptr.data_ptr(), self.entries.data_ptr(),
                 )
             )
+
+    @property
+    def sorted_by_first(self) -> bool:
+        """True if ``pairs[:, 0]`` is non-decreasing (neighbour-list builders emit it so): the role-i entries of a row are
+        then consecutive pairs.  One device reduction + D2H read per list, cached."""
+        if self._sorted is None:
+            first = self.pairs32[:, 0]
+            self._sorted = bool((first[1:] >= first[:-1]).all().item()) if self.n_pairs > 1 else True
+        return self._sorted
 
     def packed_shifts(self, shifts: torch.Tensor, key: torch.Tensor | None = None):
         """int32 per entry holding the 3 cell shifts as int8, or None if the shifts are not small integers
@@ -254,12 +264,25 @@ class PairTopology:
 class DistanceSource:
     """Provenance of a distance tensor made by :func:`pair_distances` (attached to it as ``_mipme_src``)."""
 
-    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref")
+    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref", "pending")
 
-    def __init__(self, positions, cell, pairs, shifts, shifts_key, dist):
+    def __init__(self, positions, cell, pairs, shifts, shifts_key, dist, pending=False):
         self.positions, self.cell, self.pairs, self.shifts, self.shifts_key = positions, cell, pairs, shifts, shifts_key
         self.versions = (positions._version, None if cell is None else cell._version, pairs._version, dist._version)
         self.dist_ref = weakref.ref(dist)
+        #: True while the values of a ``deferred=True`` tensor have not been written yet
+        self.pending = pending
+
+    def materialize(self) -> None:
+        """Write the values of a deferred distance tensor with the stand-alone distance kernel (for consumers other than
+        the fused pair kernel, which produces them as a by-product)."""
+        dist = self.dist_ref()
+        if self.pending and dist is not None:
+            sh = self.shifts
+            _launch_pair_distances(self.positions.detach().contiguous(), None if self.cell is None else
+                                   self.cell.detach().contiguous(), self.pairs.contiguous(),
+                                   None if sh is None else sh.contiguous(), self.shifts_key, dist.detach())
+        self.pending = False
 
     def usable_for(self, dist, pairs, n_channels) -> bool:
         """True if ``dist`` still equals ``|r_j - r_i + S cell|`` of the recorded tensors and ``pairs`` is the same list."""
@@ -336,6 +359,12 @@ class _PMEFunction(torch.autograd.Function):
                         if src_cell is not None and ctx.needs_input_grad[12]:
                             fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64,
                                                             device=device)
+            # deferred distances (``pair_distances(..., deferred=True)``): the fused kernel writes them as a by-product
+            write_dist = False
+            if src is not None and src.pending:
+                write_dist = fused is not None and mask is None and P > 0 and topo.sorted_by_first
+                if not write_dist:
+                    src.materialize()
 
             def run_rspace(accumulate):
                 stream = _lib.current_stream(device)
@@ -346,8 +375,10 @@ class _PMEFunction(torch.autograd.Function):
                         _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), q.data_ptr(), None,
                         0, int(full_list), C.byref(pot_desc), accumulate, fused["fmt"], fused["records"].data_ptr(),
                         int(fused.get("records_ready", False)), out.data_ptr(), _lib.ptr(fused["force"]),
-                        _lib.ptr(fused["partials"]), None,
+                        _lib.ptr(fused["partials"]), None, dist.data_ptr() if write_dist else None,
                     )
+                    if write_dist:
+                        src.pending = False
                 elif topo is not None:
                     _call(
                         "rspace_forward", lib.mipme_rspace_rows,
@@ -585,7 +616,7 @@ class _PMEFunction(torch.autograd.Function):
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), None, g.data_ptr(),
                     0, full, C.byref(pot_desc), 0, fused["fmt"], fused["records"].data_ptr(), 0, None, grad_src_pos.data_ptr(),
-                    _lib.ptr(partials), _lib.ptr(grad_src_cell),
+                    _lib.ptr(partials), _lib.ptr(grad_src_cell), None,
                 )
                 if not need_src_pos:
                     grad_src_pos = None
@@ -599,7 +630,7 @@ class _PMEFunction(torch.autograd.Function):
                     st, dt, N, topo.row_ptr.data_ptr(), fused["ent_sh"].data_ptr(), topo.entries.data_ptr(),
                     _lib.ptr(mask), fused["pos"].data_ptr(), _lib.ptr(fused["cell"]), q.data_ptr(), g.data_ptr(), None,
                     1, full, C.byref(pot_desc), 1, fused["fmt"], fused["records"].data_ptr(), 0, grad_q.data_ptr(), None, None,
-                    None,
+                    None, None,
                 )
             elif need_q and topo is not None:
                 _call(
@@ -623,14 +654,39 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
         # differentiate straight through to the tensors the distances were built from (see FUSE_DISTANCES)
         return _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
                                   G, pot_desc, full_list, slab_axis, src.positions, src.cell, src)
+    if src is not None and src.pending:
+        src.materialize()
     return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
                               pot_desc, full_list, slab_axis, None, None, None)
 
 
+def _launch_pair_distances(pos, cl, pairs, sh, shifts_key, out):
+    """out[p] = |r_j - r_i + S_p cell| (contiguous, detached tensors; ``sh`` already in the dtype of ``pos``)."""
+    lib = _lib.load()
+    device, dtype = pos.device, pos.dtype
+    P = pairs.shape[0]
+    topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+    pl = pairs if topo is None else topo.pairs32
+    packed = topo.pair_packed_shifts(sh, shifts_key) if (topo is not None and sh is not None) else None
+    with torch.cuda.device(device):
+        if packed is not None:
+            _call(
+                "pair_distance_forward", lib.mipme_pair_distance_forward_packed,
+                _lib.current_stream(device), _lib.dtype_code(dtype), P, pl.data_ptr(), packed.data_ptr(),
+                pos.data_ptr(), cl.data_ptr(), out.data_ptr(),
+            )
+        else:
+            _call(
+                "pair_distance_forward", lib.mipme_pair_distance_forward,
+                _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pl.dtype), P,
+                pl.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
+            )
+    return topo
+
+
 class _PairDistances(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, positions, cell, neighbor_indices, shifts):
-        lib = _lib.load()
+    def forward(ctx, positions, cell, neighbor_indices, shifts, deferred=False):
         device, dtype = positions.device, positions.dtype
         pos = positions.detach().contiguous()
         pairs = neighbor_indices.contiguous()
@@ -638,22 +694,10 @@ class _PairDistances(torch.autograd.Function):
         sh = None if shifts is None else shifts.to(dtype).contiguous()
         P = pairs.shape[0]
         out = torch.empty((P,), dtype=dtype, device=device)
-        topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
-        pl = pairs if topo is None else topo.pairs32
-        packed = topo.pair_packed_shifts(sh, shifts) if (topo is not None and sh is not None) else None
-        with torch.cuda.device(device):
-            if packed is not None:
-                _call(
-                    "pair_distance_forward", lib.mipme_pair_distance_forward_packed,
-                    _lib.current_stream(device), _lib.dtype_code(dtype), P, pl.data_ptr(), packed.data_ptr(),
-                    pos.data_ptr(), cl.data_ptr(), out.data_ptr(),
-                )
-            else:
-                _call(
-                    "pair_distance_forward", lib.mipme_pair_distance_forward,
-                    _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pl.dtype), P,
-                    pl.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), out.data_ptr(),
-                )
+        if deferred:  # values written later: by the fused pair kernel, or by DistanceSource.materialize()
+            topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+        else:
+            topo = _launch_pair_distances(pos, cl, pairs, sh, shifts, out)
         ctx.save_for_backward(pos, cl, pairs, sh)
         ctx.topo = topo
         ctx.shifts_key = shifts
@@ -684,7 +728,7 @@ class _PairDistances(torch.autograd.Function):
                     None if packed is not None else _lib.ptr(sh), grad_d.contiguous().data_ptr(), _lib.ptr(partials),
                     grad_pos.data_ptr(), _lib.ptr(grad_cell),
                 )
-            return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
+            return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None, None
         with torch.cuda.device(device):
             _call(
                 "pair_distance_backward", lib.mipme_pair_distance_backward,
@@ -692,26 +736,32 @@ class _PairDistances(torch.autograd.Function):
                     pairs.data_ptr(), pos.data_ptr(), _lib.ptr(cl), _lib.ptr(sh), grad_d.contiguous().data_ptr(),
                     _lib.ptr(partials), grad_pos.data_ptr(), _lib.ptr(grad_cell),
             )
-        return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None
+        return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None, None
 
 
 @torch.compiler.disable
-def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None):
+def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None, deferred: bool = False):
     """``d[p] = |r_j - r_i + S_p @ cell|``, differentiable w.r.t. ``positions`` and ``cell``.
 
     Counterpart of the reference's caller-side helper ``compute_distances``
-    (``tests/helpers.py:278-304``, ``examples/02-neighbor-lists-usage.py:141-164``)."""
+    (``tests/helpers.py:278-304``, ``examples/02-neighbor-lists-usage.py:141-164``).
+
+    ``deferred=True`` is a promise that the returned tensor goes to a calculator of this package before anything reads
+    it: its values are then written by the calculator's fused distance + pair kernel (the row that owns a pair's first
+    atom stores ``d[p]``) instead of by a separate pass over the list; a calculator call that cannot do so (pair mask,
+    non-integer shifts, list not ordered by its first index, ...) runs the stand-alone kernel first.  The values, the
+    autograd graph and the result of the calculator are the same either way."""
     if cell is not None and neighbor_shifts is None:
         raise ValueError("Provided `cell` but no `neighbor_shifts`.")
     if cell is None and neighbor_shifts is not None:
         raise ValueError("Provided `neighbor_shifts` but no `cell`.")
     _lib.require_device(positions, "positions")
-    dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts)
+    dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts, bool(deferred))
     if neighbor_shifts is None or neighbor_shifts.dtype == positions.dtype:
         shifts_c = neighbor_shifts
     else:
         shifts_c = neighbor_shifts.to(positions.dtype)
-    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist)
+    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, bool(deferred))
     return dist
 
 
