@@ -348,6 +348,49 @@ def test_graphed_energy_forces(golden_dir):
     assert relmax(step.distances.cpu(), d_ref) < 1e-14
 
 
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("kind", ["p3m", "direct"])
+def test_energy_direct_gradient(golden_dir, full, kind, monkeypatch):
+    """``weighted_sum`` of potentials that come straight from a calculator (fused distances, constant charges and cell):
+    the position gradient is formed by one kernel from the per-atom sums of the forward pass -- neither the adjoint of the
+    reduction nor the calculator's backward node runs.  Same numbers as the general path, also when the potentials feed
+    a second loss term (that one goes through their own node; the contributions add) and for a scaled energy."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(8)
+    cell = np.array([[7.0, 0, 0], [0.7, 6.0, 0], [0.2, -0.5, 8.0]])
+    N = 140
+    pos, q, w = rng.uniform(-1, 8, (N, 3)), rng.normal(size=(N, 1)), rng.normal(size=(N, 1))
+    pairs, S, _ = tpa.neighbor_list(pos, cell, 4.5, full_list=full)
+    if kind == "p3m":
+        # mesh (64, 32, 64): more than 16 points per axis, so that the brick kernels (which form the mesh field) are used
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.1), mesh_spacing=0.4, full_neighbor_list=full)
+    else:
+        calc = tpa.Calculator(tpa.CoulombPotential(), full_neighbor_list=full)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    tq, tc, ti, tS, tw = t(q), t(cell), t(pairs), t(S), t(w)
+    res = {}
+    for fast in (True, False):
+        monkeypatch.setattr(ops, "ENERGY_FAST_PATH", fast)
+        for second in (False, True):
+            tp = t(pos).requires_grad_(True)
+            calls = {}
+            monkeypatch.setattr(ops, "PROFILE", calls)
+            V = calc(tq, tc, tp, ti, tpa.pair_distances(tp, ti, tc, tS))
+            L = -1.7 * tpa.weighted_sum(V, tq)
+            if second:
+                L = L + (V * tw).sum()
+            L.backward()
+            monkeypatch.setattr(ops, "PROFILE", None)
+            if fast and not second:  # direct: dot + finalize only
+                assert "energy_sum_backward" not in calls and "rspace_backward" not in calls and "kspace_backward" not in calls
+                assert calls.keys() >= {"energy_sum", "forces_finalize"}
+            res[fast, second] = (L.item(), tp.grad.cpu().numpy())
+    for second in (False, True):
+        assert abs(res[True, second][0] - res[False, second][0]) < 1e-12 * abs(res[False, second][0])
+        assert rell2(res[True, second][1], res[False, second][1]) < 1e-12
+
+
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("mesh_mode", ["bricks", "atomic"])
 @pytest.mark.parametrize("name", ["p3m5", "pme4"])

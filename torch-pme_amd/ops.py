@@ -455,6 +455,13 @@ class _PMEFunction(torch.autograd.Function):
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
         ctx.fused = fused  # plain tensors made here, none of them an input or output of this node
+        # E = weighted_sum(out, charges) can be differentiated without this node (see _EnergyDirectSum) when its gradient is
+        # gE q_a (f F_a + field_a) with both per-atom sums already formed above and nothing else asks for a gradient
+        ni = ctx.needs_input_grad
+        ctx.energy_direct = bool(
+            ENERGY_FAST_PATH and Cn == 1 and fused is not None and fused["force"] is not None and src_positions is positions
+            and not (ni[0] or ni[1] or ni[3] or ni[12]) and slab_axis is None and (geom is None or field is not None)
+        )
         return out
 
     @staticmethod
@@ -652,8 +659,12 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
     src = getattr(neighbor_distances, "_mipme_src", None)
     if src is not None and src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1]):
         # differentiate straight through to the tensors the distances were built from (see FUSE_DISTANCES)
-        return _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
-                                  G, pot_desc, full_list, slab_axis, src.positions, src.cell, src)
+        out = _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
+                                 G, pot_desc, full_list, slab_axis, src.positions, src.cell, src)
+        node = out.grad_fn
+        if node is not None and getattr(node, "energy_direct", False):
+            out._mipme_energy = (node, positions, charges, charges._version)
+        return out
     if src is not None and src.pending:
         src.materialize()
     return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
@@ -819,7 +830,46 @@ def weighted_sum(potentials: torch.Tensor, charges: torch.Tensor) -> torch.Tenso
     if potentials.shape != charges.shape or potentials.dtype != charges.dtype:
         raise ValueError("`potentials` and `charges` must have the same shape and dtype")
     _lib.require_device(potentials, "potentials")
+    hook = getattr(potentials, "_mipme_energy", None)
+    if (hook is not None and ENERGY_FAST_PATH and torch.is_grad_enabled() and potentials.grad_fn is hook[0]
+            and charges is hook[2] and charges._version == hook[3] and not charges.requires_grad):
+        return _EnergyDirectSum.apply(potentials.detach(), charges, hook[1], hook[0])
     return _WeightedSum.apply(potentials, charges)
+
+
+class _EnergyDirectSum(torch.autograd.Function):
+    """``E = sum_a q_a V_a`` of potentials that come straight from a calculator, differentiated w.r.t. the positions in one
+    step.  The gradient that would reach the potentials is ``gE * q`` (the charges are constants here), and for exactly
+    that upstream gradient the calculator's backward is ``dE/dr_a = gE q_a (f F_a + field_a)`` with per-atom sums its
+    FORWARD kernels already formed (``F``: speculative pair-force sums of the fused row kernel; ``field``: mesh field from
+    the gather; f = 1/2 for a full list).  This node evaluates that expression directly (``forces_finalize``): neither
+    the adjoint of the reduction (the tensor ``gE * q``) nor the potentials' own autograd node runs.  Any other consumer
+    of the potentials still differentiates through their node as usual -- the contributions add."""
+
+    @staticmethod
+    def forward(ctx, V, q, positions, node):
+        lib = _lib.load()
+        V_c, q_c = V.contiguous(), q.detach().contiguous()
+        out = torch.empty((), dtype=V.dtype, device=V.device)
+        scratch = _dot_scratch(V.device, q.data_ptr())
+        with torch.cuda.device(V.device):
+            _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(V.device), _lib.dtype_code(V.dtype),
+                  V_c.numel(), V_c.data_ptr(), q_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
+        ctx.q, ctx.force, ctx.field, ctx.full = q_c, node.fused["force"], node.field, int(node.full_list)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        q = ctx.q
+        grad_pos = torch.empty((q.shape[0], 3), dtype=q.dtype, device=q.device)
+        g = g.contiguous()
+        with torch.cuda.device(q.device):
+            _call("forces_finalize", lib.mipme_sr_rows_finalize, _lib.current_stream(q.device), _lib.dtype_code(q.dtype),
+                  q.shape[0], _lib.ptr(ctx.force), _lib.ptr(ctx.field), q.data_ptr(), g.data_ptr(), ctx.full, None,
+                  grad_pos.data_ptr(), None)
+        return None, None, grad_pos, None
 
 
 class _EwaldKSpace(torch.autograd.Function):
