@@ -19,6 +19,12 @@ namespace mipme {
 static constexpr int BRICK = 8;
 static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
 static constexpr int SPREAD_STAGE_HOST = 256;
+// reals staged per survivor by the spread: [wz shifted to the brick's 8 z points | value | wx (n) | wy (n)], rows 16-byte
+// aligned in fp32 (vector LDS reads of the z weights)
+static inline size_t spread_row_reals(int order, size_t real_bytes) {
+  const size_t w = BRICK + 1 + 2 * size_t(order);
+  return real_bytes == 4 ? ((w + 3) & ~size_t(3)) : w;
+}
 
 struct BrickGeom {
   int nbx, nby, nbz, nb;
@@ -44,7 +50,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   }
   const size_t tile = BRICK + m->order - 1;
   if (2 * size_t(m->n_channels) * tile * tile * tile * s > 60 * 1024) return false;  // gather_grad: phi+chi per channel
-  if (s * std::max<size_t>(8 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * (3 * m->order + m->n_channels)) > 46 * 1024) return false;  // spread staging
+  if (s * std::max<size_t>(8 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * spread_row_reals(m->order, s)) > 46 * 1024) return false;  // spread staging
   return true;
 }
 
@@ -282,6 +288,19 @@ __device__ __forceinline__ void add_column(T (&acc)[BRICK], T wxy, const T (&wz)
   }
 }
 
+// eight consecutive reals of a 16-byte aligned (fp32) LDS row
+template <typename T>
+__device__ __forceinline__ void load_row8(const T* __restrict__ row, T (&out)[BRICK]) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 4);
+    out[0] = lo.x; out[1] = lo.y; out[2] = lo.z; out[3] = lo.w;
+    out[4] = hi.x; out[5] = hi.y; out[6] = hi.z; out[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < BRICK; ++k) out[k] = row[k];
+  }
+}
+
 template <int N, typename T>
 __device__ __forceinline__ void add_column_dispatch(int rz, T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
   switch (rz) {  // rz is wave-uniform (one survivor per wave iteration): a scalar branch
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      T* __restrict__ mesh, int* __restrict__ clear_count) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (clear_count && threadIdx.x == 0) clear_count[blockIdx.x] = 0;  // leave the plan's brick counters clean (bins_build)
-  const int SW = 3 * N + C;                                 // staged reals per survivor
+  constexpr int SW = sizeof(T) == 4 ? ((BRICK + 1 + 2 * N + 3) & ~3) : BRICK + 1 + 2 * N;  // staged reals per survivor (spread_row_reals)
   const int region = max(SPREAD_WAVES * BRICK_PTS, SPREAD_STAGE * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [SPREAD_STAGE][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
@@ -398,41 +417,63 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
           const int orig = rec[si].w;
           const T* wr = wts + int64_t(si) * (6 * N);
           T* dst = stage + tid * SW;
+          // row: [wz placed on the brick's 8 z points (zero outside the stencil) | value | wx | wy] -- with the z weights
+          // already shifted, the accumulation below is 8 FMAs per survivor with no dispatch on the z offset
+          const int rz = (srel[chunk + tid] << 8) >> 24;
+          T wzr[N];
 #pragma unroll
-          for (int k = 0; k < 3 * N; ++k) dst[k] = wr[k];
-          dst[3 * N] = val[int64_t(orig) * C + c] * scale;
+          for (int t = 0; t < N; ++t) wzr[t] = wr[2 * N + t];
+#pragma unroll
+          for (int k = 0; k < BRICK; ++k) {
+            T w = T(0);
+#pragma unroll
+            for (int t = 0; t < N; ++t) w = (k - rz == t) ? wzr[t] : w;
+            dst[k] = w;
+          }
+          dst[BRICK] = val[int64_t(orig) * C + c] * scale;
+#pragma unroll
+          for (int k = 0; k < 2 * N; ++k) dst[BRICK + 1 + k] = wr[k];
         }
         __syncthreads();
         // C: register accumulation; wave w takes survivors w, w+W, ...; four survivors per iteration so that
         // their LDS reads overlap (the loop is a chain of dependent LDS reads otherwise)
+        // Everything about a survivor except the lane's own (t_x, t_y) is wave-uniform: keep it in scalar registers
+        // (readfirstlane) so that the loop -- VALU-issue bound, four waves per SIMD -- spends its vector instructions on
+        // the column update only.
         constexpr int UC = 4;
-        const int nstc = nst;
-        for (int sv0 = wave; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
+        const int nstc = __builtin_amdgcn_readfirstlane(nst);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        for (int sv0 = wave_u; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
           int pk[UC];
           bool live[UC];
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
             const int sv = sv0 + u * SPREAD_WAVES;
             live[u] = sv < nstc;
-            pk[u] = srel[chunk + (live[u] ? sv : sv0)];
+            pk[u] = __builtin_amdgcn_readfirstlane(srel[chunk + (live[u] ? sv : sv0)]);
           }
-          T wxy[UC], wz[UC][N];
-          int rzs[UC];
+          T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC], fv[UC];
+          bool in[UC];
+          // all LDS reads of the four survivors are unconditional (clamped addresses) and issued together: a read under
+          // `if (in)` becomes an exec-masked branch with its own wait, i.e. one LDS round trip per survivor in series
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
             const int sv = live[u] ? sv0 + u * SPREAD_WAVES : sv0;
             const int rx = (pk[u] << 24) >> 24, ry = (pk[u] << 16) >> 24;
-            rzs[u] = (pk[u] << 8) >> 24;
-            const int tx = px - rx, ty = py - ry;
-            const bool in = live[u] && tx >= 0 && tx < N && ty >= 0 && ty < N;
+            const unsigned tx = unsigned(px - rx), ty = unsigned(py - ry);
+            in[u] = live[u] && tx < unsigned(N) && ty < unsigned(N);
             const T* sw = stage + sv * SW;
-            wxy[u] = in ? sw[in ? tx : 0] * sw[N + (in ? ty : 0)] * sw[3 * N] : T(0);
-#pragma unroll
-            for (int t = 0; t < N; ++t) wz[u][t] = sw[2 * N + t];  // wave-uniform address: LDS broadcast
+            fx[u] = sw[BRICK + 1 + min(tx, unsigned(N - 1))];
+            fy[u] = sw[BRICK + 1 + N + min(ty, unsigned(N - 1))];
+            fv[u] = sw[BRICK];
+            load_row8<T>(sw, wz[u]);  // wave-uniform address: LDS broadcast
           }
 #pragma unroll
-          for (int u = 0; u < UC; ++u)
-            add_column_dispatch<N, T>(__builtin_amdgcn_readfirstlane(rzs[u]), acc, wxy[u], wz[u]);
+          for (int u = 0; u < UC; ++u) {
+            wxy[u] = in[u] ? fx[u] * fy[u] * fv[u] : T(0);
+#pragma unroll
+            for (int k = 0; k < BRICK; ++k) acc[k] += wxy[u] * wz[u][k];
+          }
         }
         __syncthreads();
       }
@@ -753,7 +794,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(SPREAD_STAGE) * (3 * m->order + m->n_channels));
+  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(SPREAD_STAGE) * spread_row_reals(m->order, sizeof(T)));
   const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
