@@ -18,7 +18,8 @@ namespace mipme {
 
 static constexpr int BRICK = 8;
 static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
-static constexpr int SPREAD_STAGE_HOST = 256;
+// spread: survivors staged together (rows of spread_row_reals reals); 128 when 256 rows would not fit next to the lists
+static inline int spread_stage_rows(int order, size_t real_bytes);
 // reals staged per survivor by the spread: [wz shifted to the brick's 8 z points | value | wx (n) | wy (n)], rows 16-byte
 // aligned in fp32 (vector LDS reads of the z weights)
 static inline size_t spread_row_reals(int order, size_t real_bytes) {
@@ -50,7 +51,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   }
   const size_t tile = BRICK + m->order - 1;
   if (2 * size_t(m->n_channels) * tile * tile * tile * s > 60 * 1024) return false;  // gather_grad: phi+chi per channel
-  if (s * std::max<size_t>(8 * BRICK_PTS, size_t(SPREAD_STAGE_HOST) * spread_row_reals(m->order, s)) > 46 * 1024) return false;  // spread staging
+  if (spread_stage_rows(m->order, s) == 0) return false;  // spread staging
   return true;
 }
 
@@ -264,7 +265,10 @@ __device__ __forceinline__ void brick_coords(const BrickGeom& bg, int b, int& bx
 
 // offset of stencil start relative to a brick origin, mapped into [-(n-1), n_mesh - n]; overlap iff <= BRICK-1
 __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, int order) {
-  int r = posmod(m + s0 - origin, nmesh);
+  // m in [0, nmesh), -order < s0 <= 0, 0 <= origin <= nmesh - 4 (bricks_supported): m + s0 - origin lies in (-nmesh, nmesh),
+  // so the non-negative residue needs one conditional add (no integer division)
+  int r = m + s0 - origin;
+  r = r < 0 ? r + nmesh : r;
   if (r > nmesh - order) r -= nmesh;
   return r;
 }
@@ -324,9 +328,20 @@ __device__ __forceinline__ void add_column_dispatch(int rz, T (&acc)[BRICK], T w
 
 static constexpr int SPREAD_THREADS = 512;
 static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
-static constexpr int SPREAD_CPT = 4;                              // candidates per thread and round
-static constexpr int SPREAD_ROUND = SPREAD_THREADS * SPREAD_CPT;  // 2048
-static constexpr int SPREAD_STAGE = 256;                          // survivors staged together
+static constexpr int SPREAD_GROUP = 16;                           // threads per neighbouring brick in the candidate scan
+static constexpr int SPREAD_CPT = 6;                              // candidates per thread and round (96 per brick and round)
+static constexpr int SPREAD_ROUND = 27 * SPREAD_GROUP * SPREAD_CPT;  // candidates per round = capacity of the survivor lists
+static constexpr size_t SPREAD_LDS_MAX = 64 * 1024;
+
+static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows) {
+  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
+  return real_bytes * region + sizeof(int) * (2 * SPREAD_ROUND + 2);
+}
+static inline int spread_stage_rows(int order, size_t real_bytes) {
+  for (int rows : {256, 128})
+    if (spread_lds_bytes(order, real_bytes, rows) <= SPREAD_LDS_MAX) return rows;
+  return 0;
+}
 
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, BrickGeom bg, int C,
@@ -334,40 +349,37 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
                                                                      const int4* __restrict__ rec,
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ val, T scale,
-                                                                     T* __restrict__ mesh, int* __restrict__ clear_count) {
+                                                                     T* __restrict__ mesh, int* __restrict__ clear_count,
+                                                                     int stage_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (clear_count && threadIdx.x == 0) clear_count[blockIdx.x] = 0;  // leave the plan's brick counters clean (bins_build)
   constexpr int SW = sizeof(T) == 4 ? ((BRICK + 1 + 2 * N + 3) & ~3) : BRICK + 1 + 2 * N;  // staged reals per survivor (spread_row_reals)
-  const int region = max(SPREAD_WAVES * BRICK_PTS, SPREAD_STAGE * SW);
-  T* stage = reinterpret_cast<T*>(smem_raw);                // [SPREAD_STAGE][SW] staged weights + value
+  const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
+  T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
   int* srel = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND] packed rel
   int* sidx = srel + SPREAD_ROUND;                          // [SPREAD_ROUND] sorted atom index
-  int* rstart = sidx + SPREAD_ROUND;                        // [28]
-  int* rbase = rstart + 28;                                 // [28]
-  int& nsurv = rbase[28];
+  int& nsurv = sidx[SPREAD_ROUND];
+  int& maxlen = sidx[SPREAD_ROUND + 1];
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 27) {
-    const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
+  // candidate scan: 16 threads per neighbouring brick (27 x 16 = 432 of the 512 threads) walk that brick's atom records
+  // in rounds of 64 -- the thread -> (brick, atom) mapping needs no search and the 16-byte record loads stay coalesced
+  const int grp = tid / SPREAD_GROUP, sub = tid % SPREAD_GROUP;
+  int gstart = 0, glen = 0;
+  if (grp < 27) {
+    const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
     const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
-    rstart[tid] = start[nbr];
-    rbase[tid] = start[nbr + 1] - start[nbr];  // length for now
+    gstart = start[nbr];
+    glen = start[nbr + 1] - gstart;
   }
+  if (tid == 0) maxlen = 0;
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int k = 0; k < 27; ++k) {
-      const int len = rbase[k];
-      rbase[k] = run;
-      run += len;
-    }
-    rbase[27] = run;
-  }
+  if (grp < 27 && sub == 0) atomicMax(&maxlen, glen);
   __syncthreads();
-  const int total = rbase[27];
+  const int total = maxlen;  // longest of the 27 candidate lists
   constexpr int s0 = stencil_start<N>();
   const int px = lane >> 3, py = lane & 7;  // this lane's (x,y) column of the brick
   const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
@@ -375,22 +387,16 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
     T acc[BRICK];
 #pragma unroll
     for (int k = 0; k < BRICK; ++k) acc[k] = T(0);
-    for (int round = 0; round < total; round += SPREAD_ROUND) {
+    for (int round = 0; round < total; round += SPREAD_GROUP * SPREAD_CPT) {
       if (tid == 0) nsurv = 0;
       __syncthreads();
-      // A1: which candidate stencils overlap this brick?
+      // A1: which candidate stencils overlap this brick?  (SPREAD_ROUND candidates per round = list slots)
       int cidx[SPREAD_CPT];
       int4 crec[SPREAD_CPT];
 #pragma unroll
       for (int u = 0; u < SPREAD_CPT; ++u) {
-        const int k = round + u * SPREAD_THREADS + tid;
-        cidx[u] = -1;
-        if (k < total) {
-          int r = 0;
-#pragma unroll
-          for (int q = 1; q < 27; ++q) r = (k >= rbase[q]) ? q : r;
-          cidx[u] = rstart[r] + (k - rbase[r]);
-        }
+        const int k = round + u * SPREAD_GROUP + sub;
+        cidx[u] = k < glen ? gstart + k : -1;
       }
 #pragma unroll
       for (int u = 0; u < SPREAD_CPT; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
@@ -409,8 +415,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
       }
       __syncthreads();
       const int ns = nsurv;
-      for (int chunk = 0; chunk < ns; chunk += SPREAD_STAGE) {
-        const int nst = min(SPREAD_STAGE, ns - chunk);
+      for (int chunk = 0; chunk < ns; chunk += stage_rows) {
+        const int nst = min(stage_rows, ns - chunk);
         // A2: stage weights and the value of this channel
         if (tid < nst) {
           const int si = sidx[chunk + tid];
@@ -794,12 +800,12 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(SPREAD_STAGE) * spread_row_reals(m->order, sizeof(T)));
-  const size_t lds = sizeof(T) * region + sizeof(int) * (2 * SPREAD_ROUND + 28 + 29);
+  const int stage_rows = spread_stage_rows(m->order, sizeof(T));
+  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
                                g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh,
-                               clear_count)));
+                               clear_count, stage_rows)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
