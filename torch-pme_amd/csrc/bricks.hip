@@ -305,6 +305,25 @@ __device__ __forceinline__ void load_row8(const T* __restrict__ row, T (&out)[BR
   }
 }
 
+// acc[k] += w * row[k], k < 8: four packed FMAs in fp32 (v_pk_fma_f32)
+template <typename T>
+__device__ __forceinline__ void fma_row8(T (&acc)[BRICK], T w, const T (&row)[BRICK]) {
+  if constexpr (sizeof(T) == 4) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f w2 = {w, w};
+#pragma unroll
+    for (int k = 0; k < BRICK; k += 2) {
+      const v2f r = {row[k], row[k + 1]}, a = {acc[k], acc[k + 1]};
+      const v2f o = __builtin_elementwise_fma(w2, r, a);
+      acc[k] = o.x;
+      acc[k + 1] = o.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < BRICK; ++k) acc[k] += w * row[k];
+  }
+}
+
 template <int N, typename T>
 __device__ __forceinline__ void add_column_dispatch(int rz, T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
   switch (rz) {  // rz is wave-uniform (one survivor per wave iteration): a scalar branch
@@ -477,8 +496,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
             wxy[u] = in[u] ? fx[u] * fy[u] * fv[u] : T(0);
-#pragma unroll
-            for (int k = 0; k < BRICK; ++k) acc[k] += wxy[u] * wz[u][k];
+            fma_row8<T>(acc, wxy[u], wz[u]);
           }
         }
         __syncthreads();
