@@ -89,6 +89,8 @@ def algorithmic_bytes(w, s: int, fused: bool = True):
         "rspace_backward": P * (16 + 2 * s) + N * 3 * s,
         # mesh stages (the meshes themselves are L2 / Infinity-Cache resident at these sizes)
         "spread": N * 4 * s + 2 * M * s,
+        # the spread and the fused distance + pair kernel co-scheduled in one launch (mipme_sr_job_t): both byte counts
+        "spread+rspace_forward": (2 * P * 8 + P * s + N * 8 * s) + N * 4 * s + 2 * M * s,
         "gather": N * 5 * s + M * s,
         "gather_grad": N * 8 * s + 2 * M * s,
         "fft_r2c": 2 * M * s,

@@ -119,12 +119,35 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * (records_ready = 1), written by the binning pass while the positions are in registers.
  * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time.
  * rho_hat == NULL (allowed when mipme_fft_plan_xfused(plan) != 0, i.e. nx is a power of two): rfftn(rho) is not kept and
- * the convolution runs as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT. */
+ * the convolution runs as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT.
+ * sr_job (nullable; needs atom_bins, out_records, a single channel, job->records == out_records, job->out == out_lr and
+ * accumulate_out = 1): the short-range pair sum of the same call -- mipme_sr_rows_fused in its potential + force-sum mode
+ * (src = charges, no pair mask, no cell partials; the fields mean what the arguments of that function mean) -- run
+ * CO-SCHEDULED with the spread in one launch: the workgroups of the spread (a chain of dependent phases that leaves the
+ * vector units mostly idle) and of the VALU-bound pair sum share the CUs.  The pair sum overwrites job->out, the gather
+ * then adds the mesh part.  Without a co-scheduled kernel for the request (anything but 1/r or 1/r^6 with the
+ * table shift format and force sums) the two kernels run one after the other -- same results. */
+typedef struct mipme_sr_job {
+  int64_t n_atoms;
+  const void* row_ptr;        /* int32[2N+1]     (mipme_topology_build) */
+  const void* entries_shift;  /* int32[2P+1][2]  (mipme_topology_pack_entries) */
+  const void* entries;        /* int32[2P+1][2]  (mipme_topology_build) */
+  const void* positions;      /* (N,3) reals the pair distances are computed from */
+  const void* cell;           /* (3,3) */
+  const void* charges;        /* (N) */
+  const mipme_potential_t* pot;
+  int32_t full_list;
+  int32_t shift_format;
+  void* records;              /* 4N reals: out_records of the same call */
+  void* out;                  /* (N)   potentials, overwritten (= out_lr of the same call) */
+  void* force;                /* (N,3) speculative force sums, nullable */
+  void* dist_out;             /* (P)   pair distances, nullable (see mipme_sr_rows_fused) */
+} mipme_sr_job_t;
 int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records);
+                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job);
 
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan);
 

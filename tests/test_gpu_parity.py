@@ -348,6 +348,57 @@ def test_graphed_energy_forces(golden_dir):
     assert relmax(step.distances.cpu(), d_ref) < 1e-14
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("variant", ["coulomb-p3m5", "p6-p3m3", "excl-pme4", "coulomb-pme7", "general-grad"])
+def test_coscheduled_pair_sum(dtype, full, variant, monkeypatch):
+    """The pair sum co-scheduled with the spread in one launch (``mipme_sr_job_t``; row workgroups of the fused distance +
+    pair kernel behind the brick workgroups of the spread) against the two separate launches: potentials, deferred
+    distances, energy-mode and general gradients; 1/r and 1/r^6 (co-scheduled kernels), a potential with an exclusion
+    radius (sequential fallback inside the same C call), interpolation orders 3 to 7."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(17)
+    cell = np.array([[9.0, 0, 0], [0.9, 8.0, 0], [0.3, -0.6, 10.0]])
+    N = 260
+    pos, q, w = rng.uniform(-1, 10, (N, 3)), rng.normal(size=(N, 1)), rng.normal(size=(N, 1))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 4.0, full_list=full)
+    pot = {"coulomb": tpa.CoulombPotential(smearing=1.0), "p6": tpa.InversePowerLawPotential(exponent=6, smearing=1.0),
+           "excl": tpa.CoulombPotential(smearing=1.0, exclusion_radius=2.0), "general": tpa.CoulombPotential(smearing=1.0),
+           }[variant.split("-")[0]]
+    mesh = variant.split("-")[1]
+    h = 0.45  # meshes of 64 x 64 x 64: brick kernels
+    if mesh.startswith("pme"):
+        calc = tpa.PMECalculator(pot, mesh_spacing=h, interpolation_nodes=int(mesh[3:]), full_neighbor_list=full)
+    elif mesh.startswith("p3m"):
+        calc = tpa.P3MCalculator(pot, mesh_spacing=h, interpolation_nodes=int(mesh[3:]), full_neighbor_list=full)
+    else:
+        calc = tpa.P3MCalculator(pot, mesh_spacing=h, full_neighbor_list=full)
+    calc = calc.to(dtype)
+    t = lambda a, dt=dtype: torch.tensor(a, device=DEV, dtype=dt)  # noqa: E731
+    tq, tc, ti, tS, tw = t(q), t(cell), torch.tensor(pairs, device=DEV), t(S), t(w)
+    res = {}
+    for co in (True, False):
+        monkeypatch.setattr(ops, "COSCHEDULE", co)
+        tp = t(pos).requires_grad_(True)
+        stages = {}
+        from torchpme_amd import _lib
+        _lib.profile_enable(True)
+        d = tpa.pair_distances(tp, ti, tc, tS, deferred=True)
+        V = calc(tq, tc, tp, ti, d)
+        L = (V * tw).sum() if variant == "general-grad" else -0.7 * tpa.weighted_sum(V, tq)
+        L.backward()
+        stages = _lib.profile_report()
+        _lib.profile_enable(False)
+        expect_fused_launch = co and not variant.startswith("excl")
+        assert ("spread+rspace_forward" in stages) == expect_fused_launch, stages.keys()
+        res[co] = (d.detach().cpu().double().numpy(), V.detach().cpu().double().numpy(), tp.grad.cpu().double().numpy())
+    tol = 1e-12 if dtype == torch.float64 else 5e-6
+    assert relmax(res[True][0], dist) < (1e-14 if dtype == torch.float64 else 1e-6)
+    for a, b in zip(res[True], res[False]):
+        assert rell2(a, b) < tol
+
+
 @pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("kind", ["p3m", "direct"])
 def test_energy_direct_gradient(golden_dir, full, kind, monkeypatch):

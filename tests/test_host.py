@@ -61,6 +61,7 @@ def test_abi_argument_errors_without_gpu():
     assert lib.mipme_sr_rows_fused(None, _lib.F32, 4, None, None, None, None, None, None, None, None, None, 0, 0,
                                    C.byref(pd), 0, 0, None, 0, None, None, None, None, None) == -1
     assert b"mipme_sr_rows_fused" in lib.mipme_last_error()
+    assert C.sizeof(_lib.SrJob) == 104  # mipme_sr_job_t: int64 + 7 pointers + 2 x int32 + 4 pointers
     assert lib.mipme_sr_rows_finalize(None, _lib.F32, 4, None, None, None, None, 0, None, None, None) == -1
     assert lib.mipme_topology_pack_entries(None, _lib.F32, 4, 2, None, None, None, 0, None, None) == -1
     assert lib.mipme_pair_distance_forward_packed(None, _lib.F32, 4, None, None, None, None, None) == -1

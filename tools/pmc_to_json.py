@@ -18,6 +18,8 @@ NAMES = {
     # 8-byte entries read by 16-lane row groups = 128-byte coalesced requests, tallied at 64 B like the wide streams
     # (raw 43.9 MB against a 76.5 MB entry stream that is read exactly once)
     "sr_fused_rows_kernel": ("rspace_forward", 2.0),
+    # spread + pair sum in one launch: the pair-entry stream dominates the traffic (same correction)
+    "spread_rows_kernel": ("spread+rspace_forward", 2.0),
     "xconv_kernel": ("convolve_xfused_x_stage", 1.0),
     "sr_fused_finalize_kernel": ("forces_finalize", 1.0),
     "distance_forward_kernel": ("pair_distance_forward", 2.0),

@@ -62,6 +62,27 @@ class MeshDesc(C.Structure):
     ]
 
 
+class SrJob(C.Structure):
+    """``mipme_sr_job_t``: the short-range pair sum co-scheduled with the spread by ``mipme_kspace_forward``."""
+
+    _fields_ = [
+        ("n_atoms", C.c_int64),
+        ("row_ptr", C.c_void_p),
+        ("entries_shift", C.c_void_p),
+        ("entries", C.c_void_p),
+        ("positions", C.c_void_p),
+        ("cell", C.c_void_p),
+        ("charges", C.c_void_p),
+        ("pot", C.POINTER(PotentialDesc)),
+        ("full_list", C.c_int32),
+        ("shift_format", C.c_int32),
+        ("records", C.c_void_p),
+        ("out", C.c_void_p),
+        ("force", C.c_void_p),
+        ("dist_out", C.c_void_p),
+    ]
+
+
 class NlDesc(C.Structure):
     _fields_ = [
         ("cell", C.c_double * 9),
@@ -97,7 +118,7 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp],
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp, C.POINTER(SrJob)],
         "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19,
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],

@@ -50,7 +50,9 @@ FftDims fft_plan_dims(const mipme_fft_plan*);
 bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
-template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
+template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
+                                        const mipme_sr_job_t*);
+bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
@@ -112,7 +114,8 @@ template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
-                            void* wait_event, int accumulate, void* out_field, void* out_records) {
+                            void* wait_event, int accumulate, void* out_field, void* out_records,
+                            const mipme_sr_job_t* job) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -123,12 +126,19 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     int* counters = fft_plan_brick_count(plan);
     STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins, counters, q, out_records));
     {
-      ProfScope _ps(st, "spread");
-      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters))) {
+      const bool co = job && sr_job_fusable(job);
+      ProfScope _ps(st, co ? "spread+rspace_forward" : "spread");
+      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr))) {
         (void)hipMemsetAsync(counters, 0, sizeof(int) * (size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1), st);
         return rc;
       }
     }
+    if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
+      STAGE(st, "rspace_forward",
+            mipme_sr_rows_fused(st, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, job->n_atoms, job->row_ptr, job->entries_shift,
+                                job->entries, nullptr, job->positions, job->cell, job->charges, job->charges, nullptr, 0,
+                                job->full_list, job->pot, 0, job->shift_format, job->records, 1, job->out, job->force,
+                                nullptr, nullptr, job->dist_out));
   } else {
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, q, 1.0, rho_mesh));
   }
@@ -178,7 +188,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   }
   // psi = spread(g / 2V); chi = F psi
   if (bins)
-    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr, nullptr));
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
@@ -457,7 +467,7 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records) {
+                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -468,12 +478,20 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
   MIPME_REQUIRE(!out_records || (bins && mesh->n_channels == 1), "out_records needs atom bins and a single channel");
+  if (sr_job) {
+    MIPME_REQUIRE(bins && out_records && mesh->n_channels == 1 && accumulate_out && !gather_wait_event,
+                  "sr_job needs atom bins, out_records, a single channel and accumulate_out = 1 without a wait event");
+    MIPME_REQUIRE(sr_job->n_atoms == n_atoms && sr_job->records == out_records && sr_job->out == out_lr,
+                  "sr_job must describe the atoms, records and output of the same call");
+    MIPME_REQUIRE(sr_job->row_ptr && sr_job->entries_shift && sr_job->entries && sr_job->positions && sr_job->charges &&
+                      sr_job->pot, "NULL buffer in sr_job");
+  }
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records),
+                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records));
+                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,

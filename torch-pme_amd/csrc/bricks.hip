@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "rows_body.h"
 
 namespace mipme {
 
@@ -362,16 +363,37 @@ static inline int spread_stage_rows(int order, size_t real_bytes) {
   return 0;
 }
 
+template <typename T>
+struct SpreadArgs {
+  Geom g;
+  BrickGeom bg;
+  int C;
+  const int* start;
+  const int4* rec;
+  const T* wts;
+  const T* val;
+  T scale;
+  T* mesh;
+  int* clear_count;
+  int stage_rows;
+};
+
+// block = index of the brick (workgroup index among the spread workgroups of the launch)
 template <int N, typename T>
-__global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, BrickGeom bg, int C,
-                                                                     const int* __restrict__ start,
-                                                                     const int4* __restrict__ rec,
-                                                                     const T* __restrict__ wts,
-                                                                     const T* __restrict__ val, T scale,
-                                                                     T* __restrict__ mesh, int* __restrict__ clear_count,
-                                                                     int stage_rows) {
+__device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, unsigned block) {
+  const Geom& g = args.g;
+  const BrickGeom& bg = args.bg;
+  const int C = args.C;
+  const int* __restrict__ start = args.start;
+  const int4* __restrict__ rec = args.rec;
+  const T* __restrict__ wts = args.wts;
+  const T* __restrict__ val = args.val;
+  const T scale = args.scale;
+  T* __restrict__ mesh = args.mesh;
+  int* __restrict__ clear_count = args.clear_count;
+  const int stage_rows = args.stage_rows;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (clear_count && threadIdx.x == 0) clear_count[blockIdx.x] = 0;  // leave the plan's brick counters clean (bins_build)
+  if (clear_count && threadIdx.x == 0) clear_count[block] = 0;  // leave the plan's brick counters clean (bins_build)
   constexpr int SW = sizeof(T) == 4 ? ((BRICK + 1 + 2 * N + 3) & ~3) : BRICK + 1 + 2 * N;  // staged reals per survivor (spread_row_reals)
   const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
@@ -381,7 +403,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
   int& nsurv = sidx[SPREAD_ROUND];
   int& maxlen = sidx[SPREAD_ROUND + 1];
   int bx, by, bz;
-  brick_coords(bg, blockIdx.x, bx, by, bz);
+  brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // candidate scan: 16 threads per neighbouring brick (27 x 16 = 432 of the 512 threads) walk that brick's atom records
@@ -516,6 +538,24 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(Geom g, Br
     }
     __syncthreads();
   }
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs<T> a) {
+  spread_brick_body<N, T>(a, blockIdx.x);
+}
+
+// Horizontal fusion of the spread with the fused distance + pair-sum row kernel (rows_body.h): the first `n_spread`
+// workgroups are bricks of the spread -- a chain of dependent phases that leaves the vector units idle most of the time --
+// and the remaining ones are row workgroups of the VALU-bound pair sum, which fill those issue slots.  The two parts are
+// independent (the pair sum reads the atom records that the binning pass emitted, not the mesh); the gather adds the mesh
+// part to the potentials the pair sum wrote.
+template <int N, typename T, int PFAST>
+__global__ __launch_bounds__(SPREAD_THREADS) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread) {
+  if (blockIdx.x < n_spread)
+    spread_brick_body<N, T>(sa, blockIdx.x);
+  else
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS>(ra, blockIdx.x - n_spread);
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -813,19 +853,61 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
 
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
-                  int* clear_count) {
+                  int* clear_count, const mipme_sr_job_t* job) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
-  const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
   const int stage_rows = spread_stage_rows(m->order, sizeof(T));
   const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
+  SpreadArgs<T> sa;
+  sa.g = make_geom(m);
+  sa.bg = bg;
+  sa.C = m->n_channels;
+  sa.start = v.start;
+  sa.rec = v.rec;
+  sa.wts = (const T*)v.wts;
+  sa.val = (const T*)val;
+  sa.scale = T(scale);
+  sa.mesh = (T*)mesh;
+  sa.clear_count = clear_count;
+  sa.stage_rows = stage_rows;
+  if (job) {
+    // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
+    SRPot s;
+    int rc = make_srpot(job->pot, s);
+    if (rc) return rc;
+    const FastRS cf = make_fast_rs(s);
+    const int pfast = fast_rs_exponent(s);
+    const int lo = 0, hi = job->full_list ? 0 : 1;  // roles that feed the potential (as mipme_sr_rows_fused, transpose = 0)
+    const FusedRowsArgs<T> ra = make_fused_rows_args<T>(
+        s, cf, job->n_atoms, job->row_ptr, job->entries_shift, job->entries, nullptr, job->positions, job->records,
+        job->cell, job->charges, nullptr, lo, hi, job->full_list, 0, job->out, job->force, nullptr, job->dist_out);
+    const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
+    const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
+    const unsigned grid = unsigned(bg.nb) + n_rows_blocks;
+    if (pfast == 1)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, unsigned(bg.nb))));
+    else
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, unsigned(bg.nb))));
+    MIPME_LAUNCH_CHECK();
+    return MIPME_OK;
+  }
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(
-                               g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)val, T(scale), (T*)mesh,
-                               clear_count, stage_rows)));
+                           ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(sa)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
+}
+
+// the co-scheduled launch exists for the potential + force-sum mode of the fast range-separated potentials (1/r, 1/r^6)
+// with table shift codes
+bool sr_job_fusable(const mipme_sr_job_t* job) {
+  if (!job || !job->pot || !job->force || job->shift_format != kShiftTable || job->n_atoms <= 0) return false;
+  SRPot s;
+  if (make_srpot(job->pot, s)) return false;
+  const int pfast = fast_rs_exponent(s);
+  return pfast == 1 || pfast == 6;
 }
 
 template <typename T>
@@ -876,8 +958,10 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
 
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
-template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
-template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*);
+template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
+                                  const mipme_sr_job_t*);
+template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
+                                   const mipme_sr_job_t*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                   double, double, void*, void*, int, void*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,

@@ -15,6 +15,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "rows_body.h"
 #include "srpot.h"
 
 namespace mipme {
@@ -119,15 +120,7 @@ __global__ void topo_pack_shifts_kernel(int64_t E, const int2* __restrict__ entr
 }
 
 
-// Entry stream of the fused kernels: int2 {other atom, cell-shift code} per entry (shifts == NULL -> zero shifts).
-// The shift is stored ROLE-ADJUSTED: S for a role-i entry, -S for a role-j entry, so that for both roles
-//   u_e = r_other - r_a + S'_e A   has |u_e| = d_p and  d d_p / d r_a = -u_e / d_p   (no per-entry sign in the kernels).
-// Code formats: kShiftPacked = 3 x int8 (little end first); kShiftTable = index (sx+3) + 7 (sy+3) + 49 (sz+3) into the
-// 343-entry table of Cartesian shift vectors the kernel keeps in LDS (needs |s| <= 3).
-// flag bits: 1 = some shift is not an integer in [-127,127]; 2 = some |shift| > 3 (table format unusable).
-enum ShiftFormat { kShiftPacked = 0, kShiftTable = 1 };
-static constexpr int kShiftTableRange = 3, kShiftTableBase = 2 * kShiftTableRange + 1;
-static constexpr int kShiftTableSize = kShiftTableBase * kShiftTableBase * kShiftTableBase;
+// (the shift-code formats of the fused kernels, ShiftFormat, are defined in rows_body.h)
 
 template <typename T>
 __global__ void topo_pack_entries_kernel(int64_t E, int64_t n_rows, const int* __restrict__ row_ptr,
@@ -167,37 +160,6 @@ __global__ void topo_pack_entries_kernel(int64_t E, int64_t n_rows, const int* _
   if (bits) atomicOr(flag, bits);
 }
 
-// ---- owner-computes pair kernels ---------------------------------------------------------------
-#ifndef MIPME_ROW_UNROLL
-#define MIPME_ROW_UNROLL 4
-#endif
-
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// out[a,c] (+)= 1/2 sum_{entries of a} src[other,c] * v_SR(dist[p])
-//   roles: forward uses role i (+ role j for a half list) with src = charges;
-//          the charge gradient uses role j (+ role i for a half list) with src = upstream gradient.
-// Row kernels: kRowLanes lanes own one atom's row (4 atoms per wavefront -- a wavefront per atom was limited by the
-// fixed per-wave latency: row_ptr fetch, reduction, store), and every lane keeps kRowUnroll entries in flight:
-// all entry loads are issued first, then the dependent gathers (dist[p], src[other]), then the arithmetic.
-static constexpr int kRowUnroll = MIPME_ROW_UNROLL;
-#ifndef MIPME_ROW_LANES
-#define MIPME_ROW_LANES 16
-#endif
-static constexpr int kRowLanes = MIPME_ROW_LANES;
-static constexpr int kRowsPerBlock = 256 / kRowLanes;
-
-template <typename T>
-__device__ __forceinline__ T row_sum(T v) {
-#pragma unroll
-  for (int off = kRowLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kRowLanes);
-  return v;
-}
 
 template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, int C, const int* __restrict__ row_ptr,
@@ -263,7 +225,6 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
   }
 }
 
-__device__ __forceinline__ int unpack8(int word, int k) { return (word << (24 - 8 * k)) >> 24; }
 
 // grad_pos[a] = sum_{role i} -(g_p/d_p) vec_p + sum_{role j} +(g_p/d_p) vec_p ,  vec_p = r_j - r_i + S_p A
 // grad_cell = sum_p S_p^T (g_p/d_p) vec_p, accumulated from the role-i entries (each pair once).
@@ -412,209 +373,10 @@ __global__ void pack_atom_records_kernel(int64_t N, const T* __restrict__ pos, c
   rec[a] = r;
 }
 
-enum FusedMode {
-  kPot = 0,       // potentials from src
-  kPotForce = 1,  // potentials from charges + speculative force sums (w_e = q[o])
-  kForceQ = 2,    // force sums with w_e = q[o] (energy mode, finished by the finalize kernel)
-  kForceG = 3,    // force sums with the general weights built from g and q
-};
 
 template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE>
-__global__ __launch_bounds__(256) void sr_fused_rows_kernel(
-    SRPot s, FastRS cf, int64_t N, const int* __restrict__ row_ptr, const int2* __restrict__ ent_sh,
-    const int2* __restrict__ entries, const uint8_t* __restrict__ mask, const T* __restrict__ pos,
-    const AtomRecord<T>* __restrict__ rec, const T* __restrict__ cell, const T* __restrict__ q,
-    const T* __restrict__ g, int pot_lo, int pot_hi, bool full, bool accumulate, T* __restrict__ out,
-    T* __restrict__ force, double* __restrict__ partials, T* __restrict__ dist_out) {
-  // rec[o] = (position of o, src[o]) with src = charges except in the transposed potential pass
-  // dist_out (potential passes without a mask, pair list ordered by its first index): the role-i entries of a row are the
-  // consecutive pairs starting at the pair of its first entry, and their distances are written as a by-product
-  constexpr int U = kRowUnroll;
-  constexpr bool POT = MODE == kPot || MODE == kPotForce;
-  constexpr bool FORCE = MODE != kPot;
-  T A[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
-  const T c_inv2s2 = T(cf.inv_2s2), c1 = T(cf.c1), cpref = T(cf.pref);
-  __shared__ AtomRecord<T> shift_tab[TABLE ? kShiftTableSize : 1];  // Cartesian shift vector of every table code
-  if constexpr (TABLE) {
-    for (int k = threadIdx.x; k < kShiftTableSize; k += 256) {
-      const T sx = T(k % kShiftTableBase - kShiftTableRange), sy = T((k / kShiftTableBase) % kShiftTableBase - kShiftTableRange),
-              sz = T(k / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
-      shift_tab[k] = AtomRecord<T>{sx * A[0] + sy * A[3] + sz * A[6], sx * A[1] + sy * A[4] + sz * A[7],
-                                   sx * A[2] + sy * A[5] + sz * A[8], T(0)};
-    }
-    __syncthreads();
-  }
-  const int sub = threadIdx.x % kRowLanes;
-  unsigned a = blockIdx.x * kRowsPerBlock + threadIdx.x / kRowLanes;
-  const bool valid = a < N;
-  if (!valid) a = unsigned(N - 1);
-  const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
-  const int pbeg = pot_lo == 0 ? r0 : mid, pend = pot_hi == 0 ? mid : r2;  // entries that feed the potential
-  // in the potential + force pass (roles i and j both visited) a full list feeds the potential from role i only
-  const int pot_end = (MODE == kPotForce && full) ? mid : 0x7fffffff;
-  const int beg = FORCE ? r0 : pbeg;
-  const int end = valid ? (FORCE ? r2 : pend) : beg;
-  const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
-  constexpr bool CAN_WRITE_D = POT && !MASK;
-  int64_t pair_base = 0;  // pair index of entry r0 minus r0
-  if constexpr (CAN_WRITE_D) {
-    if (dist_out) pair_base = int64_t(entries[r0].y) - r0;
-  }
-  T qa = T(0), ga = T(0);
-  if constexpr (FORCE) qa = q[a];
-  if constexpr (MODE == kForceG) ga = g[a];
-  // general weights: half list 1/2 (g_a q_o + g_o q_a); full list keeps the first term for role i, the second for role j
-  const T keep_i = T(0.5), keep_j_of_i = full ? T(0) : T(0.5);
-  T pot = T(0), fx = T(0), fy = T(0), fz = T(0);
-  double cg[9];
-  if constexpr (CELLGRAD) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) cg[k] = 0.0;
-  }
-  int2 en_next[U];
-  int pm_next[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = beg + u * kRowLanes + sub;
-    const int ec = e < end ? e : beg;
-    en_next[u] = ent_sh[ec];
-    if constexpr (MASK) pm_next[u] = entries[ec].y;
-  }
-  for (int base = beg; base < end; base += kRowLanes * U) {
-    int2 en[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ok[u] = base + u * kRowLanes + sub < end;
-      en[u] = en_next[u];
-    }
-    T ox[U], oy[U], oz[U], so[U], go[U];
-    uint8_t mk[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t o = en[u].x;
-      const AtomRecord<T> r = rec[o];
-      ox[u] = r.x;
-      oy[u] = r.y;
-      oz[u] = r.z;
-      so[u] = r.w;
-      if constexpr (MODE == kForceG) go[u] = g[o];
-      if constexpr (MASK) mk[u] = mask[pm_next[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = base + kRowLanes * U + u * kRowLanes + sub;
-      const int ec = e < end ? e : beg;
-      en_next[u] = ent_sh[ec];
-      if constexpr (MASK) pm_next[u] = entries[ec].y;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = base + u * kRowLanes + sub;
-      const bool role_i = e < mid;
-      bool use = ok[u];
-      if constexpr (MASK) use = use && mk[u] != 0;
-      // u = r_o - r_a + S' A with the role-adjusted shift S' (see topo_pack_entries_kernel): |u| = d, d d / d r_a = -u / d
-      T shx, shy, shz;
-      if constexpr (TABLE) {
-        const AtomRecord<T> sh = shift_tab[en[u].y];
-        shx = sh.x;
-        shy = sh.y;
-        shz = sh.z;
-      } else {
-        const T sx = T(unpack8(en[u].y, 0)), sy = T(unpack8(en[u].y, 1)), sz = T(unpack8(en[u].y, 2));
-        shx = sx * A[0] + sy * A[3] + sz * A[6];
-        shy = sx * A[1] + sy * A[4] + sz * A[7];
-        shz = sx * A[2] + sy * A[5] + sz * A[8];
-      }
-      const T vx = (ox[u] - ax) + shx, vy = (oy[u] - ay) + shy, vz = (oz[u] - az) + shz;
-      const T d2 = vx * vx + vy * vy + vz * vz;
-      T v, dvd;  // v_SR(d) and v_SR'(d) / d
-      if constexpr (PFAST > 0) {
-        fast_rs_eval<PFAST, FORCE, T>(c_inv2s2, c1, cpref, d2, v, dvd);
-      } else {
-        const T d = fsqrt(d2);
-        T dv;
-        sr_eval<T, FORCE>(s, d, v, dv);
-        dvd = dv / d;
-      }
-      if constexpr (CAN_WRITE_D) {
-        if (dist_out && role_i && ok[u]) {
-          const T d2c = d2 > T(1e-30) ? d2 : T(1e-30);
-          dist_out[pair_base + e] = PFAST > 0 ? d2c * rs_rsqrt(d2c) : fsqrt(d2);
-        }
-      }
-      const T sv = use ? so[u] : T(0);  // masked / padding entries carry zero weight
-      if constexpr (POT) {
-        const bool in_pot = MODE == kPot || e < pot_end;
-        pot += (in_pot ? sv : T(0)) * v;
-      }
-      if constexpr (FORCE) {
-        T w;
-        if constexpr (MODE == kForceG) {
-          const T gq = role_i ? keep_i * ga * sv + keep_j_of_i * go[u] * qa : keep_j_of_i * ga * sv + keep_i * go[u] * qa;
-          w = use ? gq : T(0);
-        } else {
-          w = sv;
-        }
-        const T sc = w * dvd;
-        fx -= sc * vx;
-        fy -= sc * vy;
-        fz -= sc * vz;
-        if constexpr (CELLGRAD) {
-          if (role_i) {  // role i: S' = S and u is the pair vector itself
-            T sx, sy, sz;
-            if constexpr (TABLE) {
-              const int code = en[u].y;
-              sx = T(code % kShiftTableBase - kShiftTableRange);
-              sy = T((code / kShiftTableBase) % kShiftTableBase - kShiftTableRange);
-              sz = T(code / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
-            } else {
-              sx = T(unpack8(en[u].y, 0));
-              sy = T(unpack8(en[u].y, 1));
-              sz = T(unpack8(en[u].y, 2));
-            }
-            const double wq = MODE == kForceG ? 1.0 : double(qa);
-            const double px = wq * double(sc * vx), py = wq * double(sc * vy), pz = wq * double(sc * vz);
-            cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
-            cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
-            cg[6] += double(sz) * px; cg[7] += double(sz) * py; cg[8] += double(sz) * pz;
-          }
-        }
-      }
-    }
-  }
-  if constexpr (POT) {
-    pot = row_sum(pot);
-    if (sub == 0 && valid) out[a] = (accumulate ? out[a] : T(0)) + T(0.5) * pot;
-  }
-  if constexpr (FORCE) {
-    fx = row_sum(fx);
-    fy = row_sum(fy);
-    fz = row_sum(fz);
-    if (sub == 0 && valid) {
-      force[3 * a] = fx;
-      force[3 * a + 1] = fy;
-      force[3 * a + 2] = fz;
-    }
-  }
-  if constexpr (CELLGRAD) {
-    __shared__ double red[4][9];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double v = wave_sum(cg[k]);
-      if (lane == 0) red[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) {
-      double v = 0.0;
-      for (int w = 0; w < 4; ++w) v += red[w][threadIdx.x];
-      partials[int64_t(blockIdx.x) * 9 + threadIdx.x] = v;
-    }
-  }
+__global__ __launch_bounds__(256) void sr_fused_rows_kernel(FusedRowsArgs<T> a) {
+  sr_fused_rows_body<T, MODE, CELLGRAD, PFAST, MASK, TABLE, 256>(a, blockIdx.x);
 }
 
 // energy mode: grad_pos[a] = gE q[a] (f F[a] + field[a]), grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list;
@@ -763,11 +525,9 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
     set_error("mipme_sr_rows_fused: nothing to compute");
     return MIPME_EINVAL;
   }
-#define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK, TB)                                                                     \
-  sr_fused_rows_kernel<T, MODE, CG, CF, MK, TB><<<grid, 256, 0, st>>>(                                                    \
-      s, cf, N, (const int*)row_ptr, (const int2*)ent_sh, (const int2*)entries, (const uint8_t*)mask, (const T*)pos,  \
-      (const AtomRecord<T>*)records, (const T*)cell, (const T*)q, (const T*)g, lo, hi, full_list != 0,                \
-      accumulate != 0, (T*)out, (T*)force, (double*)partials, (T*)dist_out)
+  const FusedRowsArgs<T> args = make_fused_rows_args<T>(s, cf, N, row_ptr, ent_sh, entries, mask, pos, records, cell, q, g, lo, hi,
+                                                        full_list, accumulate, out, force, partials, dist_out);
+#define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK, TB) sr_fused_rows_kernel<T, MODE, CG, CF, MK, TB><<<grid, 256, 0, st>>>(args)
 #define MIPME_FUSED_MK(MODE, CG, CF)                                                                                  \
   do {                                                                                                                \
     if (mask)                                                                                                         \

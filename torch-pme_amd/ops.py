@@ -114,6 +114,8 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 # When the gradient arriving at the calculator's backward was produced by ``weighted_sum(V, charges)`` (E = sum q V, the
 # reduction every energy/force evaluation performs) it equals gE * charges and the adjoint mesh is a multiple of the
 # forward mesh: the backward then skips the second spread + FFT pair.  Any other upstream gradient takes the general path.
+#: run the short-range pair sum inside the spread launch of the mesh part (see mipme_sr_job_t in include/mipme.h)
+COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
 
 # Reciprocal-space convolution as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two nx,
@@ -419,6 +421,18 @@ class _PMEFunction(torch.autograd.Function):
                 records_out = None
                 if fused is not None and bins is not None and Cn == 1 and src_positions is positions and not overlap:
                     records_out = fused["records"]
+                # co-scheduled pair sum: the spread launch also carries the row workgroups of the fused distance + pair kernel
+                # (mipme_sr_job_t); the gather then adds the mesh part to the potentials the pair sum wrote
+                job = None
+                if (COSCHEDULE and records_out is not None and mask is None and fused["fmt"] == 1
+                        and fused["partials"] is None and N > 0):
+                    job = _lib.SrJob(
+                        n_atoms=N, row_ptr=topo.row_ptr.data_ptr(), entries_shift=fused["ent_sh"].data_ptr(),
+                        entries=topo.entries.data_ptr(), positions=fused["pos"].data_ptr(), cell=_lib.ptr(fused["cell"]),
+                        charges=q.data_ptr(), pot=C.pointer(pot_desc), full_list=int(full_list), shift_format=fused["fmt"],
+                        records=records_out.data_ptr(), out=out.data_ptr(), force=_lib.ptr(fused["force"]),
+                        dist_out=dist.data_ptr() if write_dist else None,
+                    )
                 if overlap:
                     # short-range sum on the side stream (writes `out`); the gather at the end of the mesh
                     # pipeline waits for it and adds the long-range part
@@ -433,10 +447,13 @@ class _PMEFunction(torch.autograd.Function):
                     plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                     G.data_ptr(), rho_mesh.data_ptr(), _lib.ptr(rho_hat), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
-                    join.cuda_event if overlap else None, 1 if overlap else 0, _lib.ptr(field), _lib.ptr(records_out),
+                    join.cuda_event if overlap else None, 1 if (overlap or job is not None) else 0, _lib.ptr(field),
+                    _lib.ptr(records_out), C.byref(job) if job is not None else None,
                 )
                 if records_out is not None:
                     fused["records_ready"] = True
+                if job is not None and write_dist:
+                    src.pending = False
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
                     _call(
@@ -445,7 +462,7 @@ class _PMEFunction(torch.autograd.Function):
                     )
                 saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
                              bins=bins)
-                if not overlap:
+                if not overlap and job is None:
                     run_rspace(1)
             else:
                 run_rspace(0)
