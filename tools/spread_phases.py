@@ -1,3 +1,6 @@
+"""Per-phase timing of the spread kernel from clock stamps written by every workgroup (variant library: see
+tools/build_spread_timing.py).  Prints, for the cfg3 water box, when each phase of a workgroup ends relative to the first
+workgroup's start and the mean / max duration of every phase."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
