@@ -223,25 +223,68 @@ def test_fused_path_degenerate_lists(dtype):
     assert torch.isfinite(pos.grad).all() and (pos.grad - g0).abs().sum() > 0
 
 
-def test_inside_torch_compile():
-    """A torch.compile'd model may contain a calculator: it runs as an opaque eager call (SURVEY 8f rank 4 is only
-    covered to this extent -- no torch.library registration, no TorchScript)."""
+@pytest.mark.parametrize("fullgraph", [True, False])
+def test_inside_torch_compile(fullgraph):
+    """A torch.compile'd model that contains ``pair_distances`` and a calculator stays ONE graph (``fullgraph=True``): both
+    run as dispatcher ops (``torch.ops.mipme.*``, library.py) with a fake implementation and an autograd formula
+    (SURVEY 8f rank 4); same energy and forces as eager."""
     calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=0.2), mesh_spacing=0.1)
     charges, cell, positions, pairs, dist = cscl_system(torch.float32)
+    shifts = torch.zeros((1, 3), device=DEV)
 
     def model(pos, scale):
-        d = tpa.pair_distances(pos * scale, pairs, cell * scale, torch.zeros((1, 3), device=DEV))
+        d = tpa.pair_distances(pos * scale, pairs, cell * scale, shifts)
         V = calc(charges, cell * scale, pos * scale, pairs, d)
-        return tpa.weighted_sum(V, charges) * 2.0 + scale.sum()
+        return (V * charges).sum() * 2.0 + scale.sum()
 
     pos = positions.clone().requires_grad_(True)
-    scale = torch.tensor(1.5, device=DEV)
+    scale = torch.tensor(1.5, device=DEV, requires_grad=True)
     eager = model(pos, scale)
-    (g_eager,) = torch.autograd.grad(eager, pos)
-    compiled = torch.compile(model)(pos, scale)
-    (g_comp,) = torch.autograd.grad(compiled, pos)
+    g_eager = torch.autograd.grad(eager, (pos, scale))
+    compiled = torch.compile(model, fullgraph=fullgraph)(pos, scale)
+    g_comp = torch.autograd.grad(compiled, (pos, scale))
     torch.testing.assert_close(compiled, eager)
-    torch.testing.assert_close(g_comp, g_eager)
+    for a, b in zip(g_comp, g_eager):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["p3m", "pme", "ewald", "direct"])
+def test_torchscript_and_opcheck(name, tmp_path):
+    """``torch.jit.script(calculator.scriptable())`` (reference ``tests/calculators/test_workflow.py:136-162`` scripts the
+    calculator itself): same potentials and gradients as the eager calculator, also after save / load; the dispatcher
+    ops pass ``torch.library.opcheck`` (schema, fake tensors, autograd registration, AOT dispatch)."""
+    pot = tpa.CoulombPotential(smearing=None if name == "direct" else 1.0, exclusion_radius=2.0 if name == "pme" else None)
+    calc = {"p3m": lambda: tpa.P3MCalculator(pot, mesh_spacing=0.8, interpolation_nodes=3),
+            "pme": lambda: tpa.PMECalculator(pot, mesh_spacing=0.8, full_neighbor_list=True),
+            "ewald": lambda: tpa.EwaldCalculator(pot, lr_wavelength=2.0),
+            "direct": lambda: tpa.Calculator(pot)}[name]().to(torch.float64)
+    rng = np.random.default_rng(6)
+    cell = np.array([[6.0, 0, 0], [0.5, 5.5, 0], [0, -0.3, 6.5]])
+    pos = rng.uniform(0, 6, (40, 3))
+    pairs, S, _ = tpa.neighbor_list(pos, cell, 3.0, full_list=(name == "pme"))
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    q, tc, ti, tS = t(rng.normal(size=(40, 2))), t(cell), t(pairs), t(S).double()
+    scripted = torch.jit.script(calc.scriptable())
+    path = str(tmp_path / "calc.pt")
+    scripted.save(path)
+    loaded = torch.jit.load(path)
+    res = []
+    for module in (calc, scripted, loaded):
+        tp = t(pos).requires_grad_(True)
+        tq = q.clone().requires_grad_(True)
+        d = tpa.pair_distances(tp, ti, tc, tS)
+        V = module(tq, tc, tp, ti, d)
+        (V * V).sum().backward()
+        res.append((V.detach(), tp.grad, tq.grad))
+    for other in res[1:]:
+        for a, b in zip(other, res[0]):
+            torch.testing.assert_close(a, b, rtol=1e-11, atol=1e-11)
+    tp = t(pos).requires_grad_(True)
+    d = tpa.pair_distances(tp, ti, tc, tS).detach().requires_grad_(True)
+    torch.library.opcheck(torch.ops.mipme.potentials.default,
+                          (q.clone().requires_grad_(True), tc.clone().requires_grad_(True), tp, ti, d, None, None, None, None,
+                           calc._spec_str))
+    torch.library.opcheck(torch.ops.mipme.pair_distances.default, (tp, ti, tc.clone().requires_grad_(True), tS))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

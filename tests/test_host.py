@@ -225,3 +225,45 @@ def test_workload_shapes():
     assert w.n_atoms == 216 and w.pairs.shape == (w.n_pairs, 2) and w.shifts.shape == (w.n_pairs, 3)
     assert ops.ns_mesh_from_cell(w.cell, w.mesh_spacing) == (16, 16, 16)
     assert abs(w.charges.sum()) < 1e-9
+
+
+def test_dispatcher_ops_and_specs(tmp_path):
+    """SURVEY 8f rank 4 on the host: the calculators describe themselves as JSON specs that rebuild them, the TorchScript
+    front end scripts / saves / loads, and the dispatcher ops propagate shapes on fake tensors (no kernel runs here)."""
+    import json
+
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    import torchpme_amd as tpa
+    from torchpme_amd import library
+
+    calcs = [
+        tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.2, prefactor=14.4), mesh_spacing=0.7, interpolation_nodes=5),
+        tpa.PMECalculator(tpa.InversePowerLawPotential(exponent=6, smearing=0.9, exclusion_radius=3.0, exclusion_degree=2),
+                          mesh_spacing=0.5, interpolation_nodes=7, full_neighbor_list=True),
+        tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=2.5),
+        tpa.Calculator(tpa.CoulombPotential()),
+    ]
+    for calc in calcs:
+        spec = calc._spec_str
+        d = json.loads(spec)
+        assert d["class"] == type(calc).__name__
+        twin = library.calculator_from_spec(spec, torch.float64, torch.device("cpu"))
+        assert type(twin) is type(calc) and library.calculator_spec(twin) == spec
+        assert library.calculator_from_spec(spec, torch.float64, torch.device("cpu")) is twin  # cached
+        scripted = torch.jit.script(calc.scriptable())
+        scripted.save(str(tmp_path / "c.pt"))
+        assert torch.jit.load(str(tmp_path / "c.pt")).spec == spec
+    with FakeTensorMode():
+        q, cell, pos = torch.empty((7, 2), device="cuda"), torch.empty((3, 3), device="cuda"), torch.empty((7, 3), device="cuda")
+        pairs, shifts = torch.empty((11, 2), dtype=torch.int64, device="cuda"), torch.empty((11, 3), device="cuda")
+        d = torch.ops.mipme.pair_distances(pos, pairs, cell, shifts)
+        assert d.shape == (11,) and d.dtype == pos.dtype
+        V = torch.ops.mipme.potentials(q, cell, pos, pairs, d, None, None, None, None, calcs[0]._spec_str)
+        assert V.shape == (7, 2)
+
+    class Custom(tpa.Potential):
+        pass
+
+    assert tpa.Calculator(Custom())._spec_str is None  # no dispatcher op for potentials the library cannot rebuild

@@ -36,6 +36,9 @@ class Calculator(torch.nn.Module):
         #: opt-in NaN guard of the reference (``lib/kspace_filter.py:189-195``).  Off by default: it costs a device
         #: synchronisation per call, which the reference pays unconditionally.
         self.check_nan = False
+        self._spec_str = None
+        if type(self) is Calculator:
+            self._spec()
 
     # mesh calculators override this to return (MeshGeometry, G); the base class has no k-space part
     def _kspace_setup(self, cell, dtype, device):
@@ -43,7 +46,28 @@ class Calculator(torch.nn.Module):
             raise NotImplementedError(f"`compute_kspace` not implemented for {self.__class__.__name__}")
         return None, None
 
-    @torch.compiler.disable  # an opaque eager call inside torch.compile'd models (ctypes + HIP launches are not traceable)
+    def _spec(self):
+        """JSON description of this calculator for the dispatcher op (``library.calculator_spec``).  Recorded at the end of
+        the constructors -- ``torch.compile`` needs it as a constant while tracing -- and refreshed by ``scriptable()``;
+        ``None`` for calculators the op cannot rebuild (custom ``Potential`` subclasses)."""
+        from . import library
+
+        try:
+            self._spec_str = library.calculator_spec(self)
+        except TypeError:
+            self._spec_str = None
+        return self._spec_str
+
+    def scriptable(self):
+        """A TorchScript-compatible module with the same ``forward`` (``torch.jit.script(calculator.scriptable())``): the
+        counterpart of the reference's ``torch.jit.script(calculator)`` (``tests/calculators/test_workflow.py:136-162``)."""
+        from . import library
+
+        spec = self._spec()
+        if spec is None:
+            raise TypeError(f"{type(self).__name__} with a {type(self.potential).__name__} has no dispatcher op")
+        return library.ScriptableCalculator(spec)
+
     def forward(
         self,
         charges: torch.Tensor,
@@ -59,7 +83,16 @@ class Calculator(torch.nn.Module):
         """Per-atom potentials ``(n_atoms, n_channels)``; see the reference docstring
         (``calculators/calculator.py:115-156``) for the meaning of every argument.  Under ``torch.vmap`` (padded batches
         with ``node_mask`` / ``pair_mask`` / ``kvectors``) the structures are evaluated one after the other."""
-        args = (charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask, pair_mask, kvectors)
+        if torch.compiler.is_compiling() and self._spec_str is not None:
+            # inside torch.compile: one dispatcher op (fake implementation + autograd formula in library.py) instead of
+            # ctypes + HIP launches, which cannot be traced -- the model stays a single graph
+            return torch.ops.mipme.potentials(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask,
+                                              periodic, node_mask, kvectors, self._spec_str)
+        return self._eager_forward(charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask,
+                                   pair_mask, kvectors)
+
+    @torch.compiler.disable
+    def _eager_forward(self, *args):
         if ops.inside_vmap(*args):
             return ops.vmap_bridge(self._forward_impl, *args)
         return self._forward_impl(*args)
@@ -136,6 +169,7 @@ class PMECalculator(Calculator):
         self.interpolation_nodes: int = interpolation_nodes
         self._cache = None  # (weakref(cell), version, dtype, device, pot key) -> (geom, G)
         self._plan_store = {}  # FFT plans of this calculator (see _lib.get_plan)
+        self._spec()
 
     def _kspace_setup(self, cell, dtype, device):
         """Mesh geometry and G(k) for this cell.  Both depend only on (cell, potential); they are cached on
@@ -197,6 +231,7 @@ class EwaldCalculator(Calculator):
             raise ValueError(f"`lr_wavelength` is {lr_wavelength} but must be positive")
         self.lr_wavelength: float = lr_wavelength
         self._freq_cache = None  # (weakref(cell), version, device) -> integer frequency table (K, 3)
+        self._spec()
 
     def _frequencies(self, cell: torch.Tensor) -> torch.Tensor:
         """Integer frequencies (K,3) of all k-vectors: ``fftfreq(ns_d) * ns_d`` per axis, ``ns_d = ceil(|a_d| /

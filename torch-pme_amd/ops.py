@@ -767,7 +767,6 @@ class _PairDistances(torch.autograd.Function):
         return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None, None
 
 
-@torch.compiler.disable
 def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None, deferred: bool = False):
     """``d[p] = |r_j - r_i + S_p @ cell|``, differentiable w.r.t. ``positions`` and ``cell``.
 
@@ -779,6 +778,13 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None,
     atom stores ``d[p]``) instead of by a separate pass over the list; a calculator call that cannot do so (pair mask,
     non-integer shifts, list not ordered by its first index, ...) runs the stand-alone kernel first.  The values, the
     autograd graph and the result of the calculator are the same either way."""
+    if torch.compiler.is_compiling():  # one dispatcher op inside torch.compile (library.py); nothing to defer there
+        return torch.ops.mipme.pair_distances(positions, neighbor_indices, cell, neighbor_shifts)
+    return _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, deferred)
+
+
+@torch.compiler.disable
+def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, deferred):
     if cell is not None and neighbor_shifts is None:
         raise ValueError("Provided `cell` but no `neighbor_shifts`.")
     if cell is None and neighbor_shifts is not None:
