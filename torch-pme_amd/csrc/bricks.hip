@@ -611,8 +611,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
   const int tz = lane_active ? l : 0;
   for (int c = 0; c < C; ++c) {
     if (c > 0) __syncthreads();
-    load_tiles<N, 1, T>(g, ox, oy, oz, mesh + c * M, nullptr, tile);
-    __syncthreads();
+    // The loads of a pass are issued in the order of their dependencies and BEFORE the tile is staged, so that the kernel is
+    // three dependent memory round trips (brick range; record + weights + tile; charge + potential of the atom) of which
+    // the third overlaps the stencil arithmetic -- not five in series (each is a trip to the Infinity Cache: the inputs
+    // were written by other XCDs in the previous kernels).
+    bool staged = false;
     for (int base = beg; base < end; base += GROUPS) {
       const int idx = base + grp;
       const bool valid = idx < end;
@@ -631,6 +634,18 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
       }
       const T wzv = lane_active ? wr[2 * N + tz] : T(0);
       const T dwzv = (FIELD && lane_active) ? wr[5 * N + tz] : T(0);
+      if (!staged) {
+        load_tiles<N, 1, T>(g, ox, oy, oz, mesh + c * M, nullptr, tile);
+        staged = true;
+      }
+      // the atom's charge and (accumulate) its potential so far: needed only at the end of the pass
+      const int64_t o_early = int64_t(a.w) * C + c;
+      T q_early = T(0), out_early = T(0);
+      if (q) {
+        q_early = q[o_early];
+        if (accumulate) out_early = out[o_early];
+      }
+      if (base == beg) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       const T* tp = tile + ry * TL + (rz + tz);
       T sA = T(0), sB = T(0), sC = T(0);  // sum wx wy M,  sum dwx wy M,  sum wx dwy M   over (t_x, t_y) of this z column
@@ -666,8 +681,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
         const int64_t o = int64_t(a.w) * C + c;
         if (q) {
           const T phi = acc * inv_vol;
-          const T lr = T(0.5) * (phi - self_c * q[o] - T(2) * bg_c * inv_vol * qsum[c]);
-          out[o] = accumulate ? out[o] + lr : lr;
+          const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[c]);
+          out[o] = accumulate ? out_early + lr : lr;
           if (raw) raw[o] = phi;
         } else {
           out[o] = acc;
