@@ -276,22 +276,15 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
 
 // ---- spread: owner-computes per brick, no atomics of any kind ------------------------------------------
 // (LDS float atomics turned out to be the limiter of the first brick version: ~30 us for 4 M ds_add_f32.)
-//   A1  every thread tests candidates of the 27 surrounding bricks (independent 16-byte loads) and appends the
-//       atoms whose stencil overlaps the brick to an LDS index list;
-//   A2  survivors are staged 256 at a time: thread t copies the 3n weights and the C values of survivor t to LDS;
-//   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+4, ...:
-//       two lane-dependent LDS reads (wx, wy) and n broadcast reads (wz) per survivor, no atomics;
-//   R   the four waves' partial bricks are summed through LDS and written with coalesced stores.
-// acc[RZ + t] += wxy * wz[t] for the stencil points that fall inside the brick; RZ (first z point relative to the
-// brick) is a template parameter so that every accumulator index is static (registers, no selects).
-template <int N, int RZ, typename T>
-__device__ __forceinline__ void add_column(T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
-#pragma unroll
-  for (int t = 0; t < N; ++t) {
-    constexpr int lo = RZ;
-    if (lo + t >= 0 && lo + t < BRICK) acc[(lo + t >= 0 && lo + t < BRICK) ? lo + t : 0] += wxy * wz[t];
-  }
-}
+//   A1  16 threads per neighbouring brick walk its atom records (independent, coalesced 16-byte loads) and append the
+//       atoms whose stencil overlaps this brick to an LDS list ("survivors");
+//   A2  survivors are staged up to 256 at a time: thread t copies the x / y weights, the value and the z weights --
+//       already shifted onto the brick's 8 z points, zero outside the stencil -- of survivor t to LDS;
+//   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+8, ..., four per
+//       iteration: two lane-dependent LDS reads (wx, wy) and one broadcast row (value + 8 z weights) per survivor, then
+//       8 FMAs -- no atomics, no dispatch on the z offset, no conditional reads;
+//   R   the eight waves' partial bricks are summed through LDS and written with coalesced stores.
+// Per-phase clock stamps: tools/spread_phases.py (profiles/r01_j_spread_phases.txt).
 
 // eight consecutive reals of a 16-byte aligned (fp32) LDS row
 template <typename T>
@@ -322,27 +315,6 @@ __device__ __forceinline__ void fma_row8(T (&acc)[BRICK], T w, const T (&row)[BR
   } else {
 #pragma unroll
     for (int k = 0; k < BRICK; ++k) acc[k] += w * row[k];
-  }
-}
-
-template <int N, typename T>
-__device__ __forceinline__ void add_column_dispatch(int rz, T (&acc)[BRICK], T wxy, const T (&wz)[N]) {
-  switch (rz) {  // rz is wave-uniform (one survivor per wave iteration): a scalar branch
-    case -6: add_column<N, -6, T>(acc, wxy, wz); break;
-    case -5: add_column<N, -5, T>(acc, wxy, wz); break;
-    case -4: add_column<N, -4, T>(acc, wxy, wz); break;
-    case -3: add_column<N, -3, T>(acc, wxy, wz); break;
-    case -2: add_column<N, -2, T>(acc, wxy, wz); break;
-    case -1: add_column<N, -1, T>(acc, wxy, wz); break;
-    case 0: add_column<N, 0, T>(acc, wxy, wz); break;
-    case 1: add_column<N, 1, T>(acc, wxy, wz); break;
-    case 2: add_column<N, 2, T>(acc, wxy, wz); break;
-    case 3: add_column<N, 3, T>(acc, wxy, wz); break;
-    case 4: add_column<N, 4, T>(acc, wxy, wz); break;
-    case 5: add_column<N, 5, T>(acc, wxy, wz); break;
-    case 6: add_column<N, 6, T>(acc, wxy, wz); break;
-    case 7: add_column<N, 7, T>(acc, wxy, wz); break;
-    default: break;
   }
 }
 
