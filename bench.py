@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
+    ap.add_argument("--frame-batch", default="one-launch", choices=["one-launch", "streams"],
+                    help="with several frames per GPU: every kernel of the pipeline launched once for all frames "
+                         "(GraphedFrameBatch), or one HIP graph per frame replayed on its own stream")
     ap.add_argument("--frames-per-gpu", type=int, default=1,
                     help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --workload ionic "
                          "--frames-per-gpu 8 on 8 GPUs = 64 frames)")
@@ -240,9 +243,15 @@ def main():
     # several frames per rank: every frame replays its graph on its own stream, so the (latency-bound, small) kernels of
     # independent frames overlap on the GPU; each stream orders the successive steps of its frame
     streams = [torch.cuda.Stream(device) for _ in frames] if (graphed is not None and n_frames > 1) else None
+    batch = None
+    if streams is not None and args.frame_batch == "one-launch":
+        # all frames of this rank with one launch per kernel (blockIdx.y = frame) from one HIP graph
+        batch = tpa.GraphedFrameBatch(frames[0].calc, [(f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames])
 
     def one_step():
         """One pass of the hot path over this rank's batch of frames; returns the frame energies (device tensors)."""
+        if batch is not None:
+            return list(batch()[0].unbind(0))
         if streams is not None:
             for g, st in zip(graphed, streams):
                 with torch.cuda.stream(st):
@@ -253,7 +262,7 @@ def main():
         return [f.step()[0] for f in frames]
 
     def join_streams():
-        if streams is not None:
+        if streams is not None and batch is None:
             for st in streams:
                 torch.cuda.current_stream(device).wait_stream(st)
 
@@ -364,7 +373,9 @@ def main():
                             f"{w.scheme} order {w.order}, {w.n_mesh}^3 mesh, "
                             f"{'Coulomb' if w.exponent == 1 else '1/r^%d' % w.exponent}, {w.dtype}, energy+forces via autograd",
                 "frames_per_gpu": n_frames,
-                "launch": ("HIP graph replay of the captured step" + (", one stream per frame" if streams is not None else ""))
+                "launch": ("HIP graph replay of the captured step"
+                           + (", all frames in one launch per kernel (GraphedFrameBatch)" if batch is not None
+                              else ", one stream per frame" if streams is not None else ""))
                           if launch == "graph" else "eager kernel launches",
                 "parallelism": f"{world * n_frames} independent frame(s), {n_frames} per GPU",
             },

@@ -149,6 +149,52 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
                          void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
                          void* out_field, void* out_records, const mipme_sr_job_t* sr_job);
 
+/* ---- independent frames in one launch (the frames a rank owns) -----------------------------------------
+ * Energy + forces of n_frames independent frames (own atoms, cell, pair list; same mesh
+ * dimensions, interpolation scheme / order, potential and dtype; single channel) with ONE launch per kernel of the
+ * pipeline: blockIdx.y = frame.  The per-frame kernel arguments live in a device-resident table built once per batch
+ * (mipme_frames_table_build fills a HOST buffer of mipme_frames_table_bytes bytes; the caller copies it to the device);
+ * every pointer in it must stay valid while the table is used.
+ *   forward : binning -> spread co-scheduled with the fused distance + pair kernel (potentials, speculative force sums,
+ *             distances) -> batched (y,z) hipFFT planes + x stage (plan: batch = n_frames; G: n_frames filter tables,
+ *             G_stride reals apart, 0 = shared) -> gather (+ mesh force field) -> energy[f] = sum_a q_a V_a
+ *   backward: grad_positions[f] = grad_scale[f] q_a (c force_a + field_a)   (c = 1/2 for a full list)
+ * Requirements (checked; MIPME_EINVAL otherwise): brick kernels support the mesh, <= 1024 bricks, potential 1/r or 1/r^6
+ * with a smearing, table shift format, power-of-two nx.  The brick counters of a frame must be zero before its first
+ * use; every forward leaves them zero again. */
+typedef struct mipme_frame {
+  int64_t n_atoms;
+  const void* positions;      /* (N,3) */
+  const void* charges;        /* (N)   */
+  const void* cell;           /* (3,3) device copy of mesh.cell in the working dtype */
+  mipme_mesh_t mesh;          /* n_channels = 1 */
+  void* atom_bins;            /* mipme_atom_bins_bytes(mesh, N, dtype) */
+  void* brick_counters;       /* int32[bricks + 1] */
+  const void* row_ptr;        /* pair topology, see mipme_sr_rows_fused */
+  const void* entries_shift;
+  const void* entries;
+  int32_t full_list;
+  int32_t shift_format;       /* must be 1 (table) */
+  void* records;              /* 4N reals */
+  void* rho_mesh;             /* (nx,ny,nz): frame f's slice of the batched mesh buffers */
+  void* phi_mesh;
+  void* dc;                   /* 1 real: slice of the batched dc buffer */
+  void* out;                  /* (N)   potentials */
+  void* force;                /* (N,3) */
+  void* field;                /* (N,3) */
+  void* dist_out;             /* (P) nullable */
+  void* energy;               /* 1 real */
+  void* grad_positions;       /* (N,3) */
+} mipme_frame_t;
+int64_t mipme_frames_table_bytes(int dtype, int n_frames);
+int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frames, const mipme_potential_t* pot,
+                             void* host_table, int64_t host_table_bytes);
+int mipme_frames_forward(mipme_fft_plan* plan, void* stream, int dtype, int n_frames, const mipme_frame_t* frames,
+                         const mipme_potential_t* pot, const void* device_table, const void* G, int64_t G_stride,
+                         void* rho_mesh_all, void* hat_work_all, void* phi_mesh_all, void* dc_all);
+int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_frame_t* frames, const void* device_table,
+                          const void* grad_scale);
+
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan);
 
 /* Adjoint of mipme_kspace_forward for an upstream gradient g = dL/d(out_lr), shape (N,C).

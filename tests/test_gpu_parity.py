@@ -876,3 +876,42 @@ def test_graphed_recapture(golden_dir):
     assert abs(e_half - float(z["p3m5/f64/energy"])) > 1e-3 * abs(e_half)
     assert abs(E.item() - float(z["p3m5/f64/energy"])) < 1e-10 * abs(E.item())
     assert rell2(F.cpu(), -z["p3m5/f64/grad_positions"]) < 1e-10
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("kind", ["p3m-coulomb", "pme-p6"])
+def test_frames_in_one_launch(dtype, full, kind):
+    """``GraphedFrameBatch``: several independent frames (different atom counts, cells and neighbour lists, same mesh) with
+    one launch per kernel of the pipeline (blockIdx.y = frame) against one ``GraphedEnergyForces`` per frame: energies,
+    forces and the by-product distances, also after the positions are updated in place."""
+    rng = np.random.default_rng(31)
+    if kind == "p3m-coulomb":
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.45, interpolation_nodes=5,
+                                 full_neighbor_list=full)
+    else:
+        calc = tpa.PMECalculator(tpa.InversePowerLawPotential(exponent=6, smearing=1.0), mesh_spacing=0.45,
+                                 interpolation_nodes=4, full_neighbor_list=full)
+    calc = calc.to(dtype)
+    frames, singles = [], []
+    for k, (N, L) in enumerate([(150, 9.0), (230, 9.6), (90, 8.8)]):  # 2L / 0.45 + 1 in (32, 64]: meshes of 64^3
+        cell = np.array([[L, 0, 0], [0.05 * k * L, L, 0], [0, -0.03 * L, L]])
+        pos = rng.uniform(0, L, (N, 3))
+        q = rng.normal(size=(N, 1))
+        pairs, S, _ = tpa.neighbor_list(pos, cell, 3.5, full_list=full)
+        t = lambda a, dt=dtype: torch.tensor(a, device=DEV, dtype=dt)  # noqa: E731
+        frames.append((t(q), t(cell), t(pos), torch.tensor(pairs, device=DEV), t(S)))
+    batch = tpa.GraphedFrameBatch(calc, frames)
+    singles = [tpa.GraphedEnergyForces(calc, *(f[0], f[1], f[2], f[3], f[4])) for f in frames]
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    for shift in (0.0, 0.02):
+        new = [f[2] + shift for f in frames]
+        E, F = batch(new)
+        E = E.cpu().numpy().copy()
+        F = [x.cpu().numpy().copy() for x in F]
+        for k, g in enumerate(singles):
+            e1, f1 = g(new[k])
+            assert abs(E[k] - e1.item()) < tol * abs(e1.item())
+            assert rell2(F[k], f1.cpu().numpy()) < tol
+            d_ref = g.distances.cpu().numpy()
+            assert relmax(batch.distances[k].cpu().numpy(), d_ref) < (1e-13 if dtype == torch.float64 else 1e-6)

@@ -62,6 +62,14 @@ def test_abi_argument_errors_without_gpu():
                                    C.byref(pd), 0, 0, None, 0, None, None, None, None, None) == -1
     assert b"mipme_sr_rows_fused" in lib.mipme_last_error()
     assert C.sizeof(_lib.SrJob) == 104  # mipme_sr_job_t: int64 + 7 pointers + 2 x int32 + 4 pointers
+    # mipme_frame_t: int64 + 3 pointers + mipme_mesh_t (6 x int32 + 19 doubles) + 5 pointers + 2 x int32 + 10 pointers
+    assert C.sizeof(_lib.Frame) == 8 + 24 + C.sizeof(_lib.MeshDesc) + 40 + 8 + 80 and C.sizeof(_lib.MeshDesc) == 176
+    frames = (_lib.Frame * 2)()
+    assert lib.mipme_frames_table_bytes(_lib.F32, 2) > 0 and lib.mipme_frames_table_bytes(_lib.F32, 0) == 0
+    assert lib.mipme_frames_table_build(_lib.F32, 2, frames, C.byref(pd), None, 0) == -1  # invalid (empty) mesh descriptors
+    assert lib.mipme_frames_forward(None, None, _lib.F32, 0, frames, C.byref(pd), None, None, 0, None, None, None, None) == -1
+    assert b"no frames" in lib.mipme_last_error()
+    assert lib.mipme_frames_backward(None, _lib.F32, 0, frames, None, None) == -1
     assert lib.mipme_sr_rows_finalize(None, _lib.F32, 4, None, None, None, None, 0, None, None, None) == -1
     assert lib.mipme_topology_pack_entries(None, _lib.F32, 4, 2, None, None, None, 0, None, None) == -1
     assert lib.mipme_pair_distance_forward_packed(None, _lib.F32, 4, None, None, None, None, None) == -1

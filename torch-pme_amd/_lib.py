@@ -33,6 +33,7 @@ EXPORTS = (
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
+    "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
 )
 
 
@@ -80,6 +81,35 @@ class SrJob(C.Structure):
         ("out", C.c_void_p),
         ("force", C.c_void_p),
         ("dist_out", C.c_void_p),
+    ]
+
+
+class Frame(C.Structure):
+    """``mipme_frame_t``: one frame of ``mipme_frames_forward / backward`` (independent frames in one launch)."""
+
+    _fields_ = [
+        ("n_atoms", C.c_int64),
+        ("positions", C.c_void_p),
+        ("charges", C.c_void_p),
+        ("cell", C.c_void_p),
+        ("mesh", MeshDesc),
+        ("atom_bins", C.c_void_p),
+        ("brick_counters", C.c_void_p),
+        ("row_ptr", C.c_void_p),
+        ("entries_shift", C.c_void_p),
+        ("entries", C.c_void_p),
+        ("full_list", C.c_int32),
+        ("shift_format", C.c_int32),
+        ("records", C.c_void_p),
+        ("rho_mesh", C.c_void_p),
+        ("phi_mesh", C.c_void_p),
+        ("dc", C.c_void_p),
+        ("out", C.c_void_p),
+        ("force", C.c_void_p),
+        ("field", C.c_void_p),
+        ("dist_out", C.c_void_p),
+        ("energy", C.c_void_p),
+        ("grad_positions", C.c_void_p),
     ]
 
 
@@ -135,6 +165,9 @@ def _declare(lib):
         "mipme_pair_distance_forward_packed": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, ci, vp, ci, vp, vp, vp, vp, vp],
         "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
+        "mipme_frames_table_build": [ci, ci, C.POINTER(Frame), PP, vp, i64],
+        "mipme_frames_forward": [vp, vp, ci, ci, C.POINTER(Frame), PP, vp, vp, i64, vp, vp, vp, vp],
+        "mipme_frames_backward": [vp, ci, ci, C.POINTER(Frame), vp, vp],
         "mipme_ewald_filter": [vp, ci, PP, i64, vp, vp, vp],
         "mipme_ewald_structure": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp],
         "mipme_ewald_potential": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp, vp],
@@ -163,6 +196,8 @@ def _declare(lib):
     lib.mipme_nl_scratch_ints.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_fft_plan_xfused.restype = ci
     lib.mipme_fft_plan_xfused.argtypes = [vp]
+    lib.mipme_frames_table_bytes.restype = i64
+    lib.mipme_frames_table_bytes.argtypes = [ci, ci]
     lib.mipme_profile_enable.restype = ci
     lib.mipme_profile_enable.argtypes = [ci]
     lib.mipme_profile_report.restype = i64

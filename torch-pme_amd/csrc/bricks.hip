@@ -113,10 +113,10 @@ __device__ __forceinline__ void atom_mesh_coords(const Geom& g, bool even, const
 // Lanes of a wavefront that fall into the same brick share ONE returning atomic (atoms are usually stored in a
 // spatially coherent order, so a wave touches only a handful of bricks): leader election over the ballot mask.
 template <typename T>
-__global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bool even, int64_t N,
-                                                       const T* __restrict__ pos, int* __restrict__ count,
-                                                       int* __restrict__ slot, int* __restrict__ brick) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bin_count_body(const Geom& g, const BrickGeom& bg, bool even, int64_t N,
+                                               const T* __restrict__ pos, int* __restrict__ count, int* __restrict__ slot,
+                                               int* __restrict__ brick, unsigned block) {
+  const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
   const bool valid = i < N;
   const int lane = threadIdx.x & 63;
   int b = -1;
@@ -151,6 +151,13 @@ __global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bo
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bool even, int64_t N,
+                                                       const T* __restrict__ pos, int* __restrict__ count,
+                                                       int* __restrict__ slot, int* __restrict__ brick) {
+  bin_count_body<T>(g, bg, even, N, pos, count, slot, brick, blockIdx.x);
+}
+
 // exclusive scan of count[0..nb) into start[0..nb]; single block
 __global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __restrict__ count, int* __restrict__ start) {
   __shared__ int part[1024];
@@ -182,11 +189,11 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __res
 static constexpr int kFusedScanMax = 1024;
 
 template <int SCHEME, int N, bool FUSED_SCAN, typename T>
-__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t Natoms, const T* __restrict__ pos,
-                                                      const int* __restrict__ count, int* __restrict__ start,
-                                                      const int* __restrict__ slot, const int* __restrict__ brick,
-                                                      int4* __restrict__ rec, T* __restrict__ wts,
-                                                      const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
+__device__ __forceinline__ void bin_fill_body(const Geom& g, int nb, int64_t Natoms, const T* __restrict__ pos,
+                                              const int* __restrict__ count, int* __restrict__ start,
+                                              const int* __restrict__ slot, const int* __restrict__ brick,
+                                              int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
+                                              AtomRecord<T>* __restrict__ atom_rec, unsigned block) {
   __shared__ int sstart[FUSED_SCAN ? kFusedScanMax + 1 : 1];
   __shared__ int wsum[4];
   if constexpr (FUSED_SCAN) {
@@ -217,10 +224,10 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t N
     }
     if (t == 255 && nb == kFusedScanMax) sstart[nb] = base;
     __syncthreads();
-    if (blockIdx.x == 0)
+    if (block == 0)
       for (int idx = t; idx <= nb; idx += 256) start[idx] = sstart[idx];
   }
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
   if (i >= Natoms) return;
   int m[3];
   double x[3];
@@ -247,6 +254,15 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t N
       wr[(3 + d) * N + t] = dw[t];
     }
   }
+}
+
+template <int SCHEME, int N, bool FUSED_SCAN, typename T>
+__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t Natoms, const T* __restrict__ pos,
+                                                      const int* __restrict__ count, int* __restrict__ start,
+                                                      const int* __restrict__ slot, const int* __restrict__ brick,
+                                                      int4* __restrict__ rec, T* __restrict__ wts,
+                                                      const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
+  bin_fill_body<SCHEME, N, FUSED_SCAN, T>(g, nb, Natoms, pos, count, start, slot, brick, rec, wts, q, atom_rec, blockIdx.x);
 }
 
 // ---- shared device helpers ---------------------------------------------------------------------
@@ -559,23 +575,21 @@ __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz
 static constexpr int kGatherLanes = 8;
 
 template <int N, bool FIELD, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C,
-                                                                     const int* __restrict__ start,
-                                                                     const int4* __restrict__ rec,
-                                                                     const T* __restrict__ wts,
-                                                                     const T* __restrict__ mesh, const T* __restrict__ q,
-                                                                     const T* __restrict__ qsum, T inv_vol, T self_c,
-                                                                     T bg_c, bool accumulate, T* __restrict__ out,
-                                                                     T* __restrict__ raw, T* __restrict__ field) {
+__device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom& bg, int C, const int* __restrict__ start,
+                                                  const int4* __restrict__ rec, const T* __restrict__ wts,
+                                                  const T* __restrict__ mesh, const T* __restrict__ q,
+                                                  const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c, bool accumulate,
+                                                  T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
+                                                  unsigned block) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
   constexpr int LANES = kGatherLanes;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   __shared__ T tile[TL * TL * TL];
   int bx, by, bz;
-  brick_coords(bg, blockIdx.x, bx, by, bz);
+  brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
-  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
+  const int beg = start[block], end = start[block + 1];
   if (beg == end) return;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
@@ -662,6 +676,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
       }
     }
   }
+}
+
+template <int N, bool FIELD, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C,
+                                                                     const int* __restrict__ start,
+                                                                     const int4* __restrict__ rec,
+                                                                     const T* __restrict__ wts,
+                                                                     const T* __restrict__ mesh, const T* __restrict__ q,
+                                                                     const T* __restrict__ qsum, T inv_vol, T self_c,
+                                                                     T bg_c, bool accumulate, T* __restrict__ out,
+                                                                     T* __restrict__ raw, T* __restrict__ field) {
+  gather_brick_body<N, FIELD, T>(g, bg, C, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
+                                 blockIdx.x);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -943,6 +970,234 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
   return MIPME_OK;
 }
 
+// ---- independent frames in one launch (include/mipme.h: mipme_frames_*) -----------------------------------------
+// blockIdx.y = frame; every kernel reads its frame's arguments from a device-resident table (built once per batch), so a
+// step of F frames is as many launches as a step of one frame.  The bodies are the single-frame kernels' bodies.
+template <typename T>
+struct FrameDev {
+  // binning
+  Geom g;
+  BrickGeom bg;
+  int64_t N;
+  const T* pos;
+  const T* q;
+  int *count, *start, *slot, *brick;
+  int4* rec;
+  T* wts;
+  AtomRecord<T>* atom_rec;
+  int even;
+  // spread + pair sum
+  SpreadArgs<T> spread;
+  FusedRowsArgs<T> rows;
+  unsigned n_row_blocks;
+  // gather
+  const T* phi_mesh;
+  const T* dc;
+  T inv_vol, self_c, bg_c;
+  T* out;
+  T* field;
+  // energy, forces
+  T* energy;
+  const T* force;
+  T* grad_pos;
+  T force_scale;  // 1/2 for a full list
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void frames_bin_count_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  if (int64_t(blockIdx.x) * 256 >= f.N) return;
+  bin_count_body<T>(f.g, f.bg, f.even != 0, f.N, f.pos, f.count, f.slot, f.brick, blockIdx.x);
+}
+
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void frames_bin_fill_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  if (int64_t(blockIdx.x) * 256 >= f.N) return;
+  bin_fill_body<SCHEME, N, true, T>(f.g, f.bg.nb, f.N, f.pos, f.count, f.start, f.slot, f.brick, f.rec, f.wts, f.q,
+                                    f.atom_rec, blockIdx.x);
+}
+
+template <int N, typename T, int PFAST>
+__global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  const unsigned n_spread = unsigned(f.bg.nb);
+  if (blockIdx.x < n_spread)
+    spread_brick_body<N, T>(f.spread, blockIdx.x);
+  else if (blockIdx.x - n_spread < f.n_row_blocks)
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS>(f.rows, blockIdx.x - n_spread);
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void frames_gather_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  gather_brick_body<N, true, T>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c, true,
+                                f.out, nullptr, f.field, blockIdx.x);
+}
+
+// energy[f] = sum_a q_a V_a: one workgroup per frame, fixed summation order
+template <typename T>
+__global__ __launch_bounds__(1024) void frames_energy_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.x];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < f.N; i += 1024) acc += double(f.q[i]) * double(f.out[i]);
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    f.energy[0] = T(tot);
+  }
+}
+
+// grad_positions[f][a] = gscale[f] q_a (c force_a + field_a)
+template <typename T>
+__global__ __launch_bounds__(256) void frames_finalize_kernel(const FrameDev<T>* __restrict__ table,
+                                                             const T* __restrict__ gscale) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= 3 * f.N) return;
+  f.grad_pos[t] = gscale[blockIdx.y] * f.q[t / 3] * (f.force_scale * f.force[t] + f.field[t]);
+}
+
+static void frame_correction_terms(const mipme_potential_t* pot, double& self_c, double& bg_c) {
+  // potentials/coulomb.py:144-158, potentials/inversepowerlaw.py:143-166 (as correction_terms in api.hip)
+  const int p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  const double two_s2 = 2.0 * pot->smearing * pot->smearing;
+  self_c = pot->prefactor / std::tgamma(0.5 * p + 1.0) / std::pow(two_s2, 0.5 * p);
+  bg_c = p >= 3 ? 0.0
+                : pot->prefactor * std::pow(3.14159265358979323846, 1.5) * std::pow(two_s2, 0.5 * (3 - p)) /
+                      ((3 - p) * std::tgamma(0.5 * p));
+}
+
+static int frames_check(int dtype, int n_frames, const mipme_frame_t* fr) {
+  MIPME_REQUIRE(n_frames > 0 && fr, "no frames");
+  MIPME_REQUIRE(dtype == MIPME_F32 || dtype == MIPME_F64, "invalid dtype %d", dtype);
+  const mipme_mesh_t& m0 = fr[0].mesh;
+  for (int k = 0; k < n_frames; ++k) {
+    const mipme_frame_t& f = fr[k];
+    int rc = validate_mesh(&f.mesh);
+    if (rc) return rc;
+    MIPME_REQUIRE(f.mesh.nx == m0.nx && f.mesh.ny == m0.ny && f.mesh.nz == m0.nz && f.mesh.scheme == m0.scheme &&
+                      f.mesh.order == m0.order && f.mesh.n_channels == 1,
+                  "frame %d: all frames need the same mesh, scheme and order and a single channel", k);
+    MIPME_REQUIRE(bricks_supported(&f.mesh, dtype) && make_brick_geom(&f.mesh).nb <= kFusedScanMax,
+                  "frame %d: mesh %d x %d x %d is outside the brick kernels' range", k, f.mesh.nx, f.mesh.ny, f.mesh.nz);
+    MIPME_REQUIRE(f.n_atoms > 0 && f.positions && f.charges && f.cell && f.atom_bins && f.brick_counters && f.row_ptr &&
+                      f.entries_shift && f.entries && f.records && f.rho_mesh && f.phi_mesh && f.dc && f.out && f.force &&
+                      f.field && f.energy && f.grad_positions,
+                  "frame %d: NULL buffer or no atoms", k);
+    MIPME_REQUIRE(f.shift_format == kShiftTable, "frame %d: the frames path needs the table shift format", k);
+  }
+  return MIPME_OK;
+}
+
+template <typename T>
+static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mipme_potential_t* pot, void* host_table) {
+  SRPot s;
+  int rc = make_srpot(pot, s);
+  if (rc) return rc;
+  const int pfast = fast_rs_exponent(s);
+  MIPME_REQUIRE(pot->smearing > 0 && (pfast == 1 || pfast == 6), "the frames path covers 1/r and 1/r^6 with a smearing");
+  const FastRS cf = make_fast_rs(s);
+  double self_c, bg_c;
+  frame_correction_terms(pot, self_c, bg_c);
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  FrameDev<T>* out = (FrameDev<T>*)host_table;
+  for (int k = 0; k < n_frames; ++k) {
+    const mipme_frame_t& f = fr[k];
+    const mipme_mesh_t* m = &f.mesh;
+    const BinsView v = bins_view(m, f.n_atoms, dtype, f.atom_bins);
+    FrameDev<T> d;
+    d.g = make_geom(m);
+    d.bg = make_brick_geom(m);
+    d.N = f.n_atoms;
+    d.pos = (const T*)f.positions;
+    d.q = (const T*)f.charges;
+    d.count = (int*)f.brick_counters;
+    d.start = v.start;
+    d.slot = v.slot;
+    d.brick = v.brick;
+    d.rec = v.rec;
+    d.wts = (T*)v.wts;
+    d.atom_rec = (AtomRecord<T>*)f.records;
+    d.even = (m->order % 2) == 0;
+    d.spread.g = d.g;
+    d.spread.bg = d.bg;
+    d.spread.C = 1;
+    d.spread.start = v.start;
+    d.spread.rec = v.rec;
+    d.spread.wts = (const T*)v.wts;
+    d.spread.val = (const T*)f.charges;
+    d.spread.scale = T(1);
+    d.spread.mesh = (T*)f.rho_mesh;
+    d.spread.clear_count = (int*)f.brick_counters;
+    d.spread.stage_rows = spread_stage_rows(m->order, sizeof(T));
+    d.rows = make_fused_rows_args<T>(s, cf, f.n_atoms, f.row_ptr, f.entries_shift, f.entries, nullptr, f.positions, f.records,
+                                     f.cell, f.charges, nullptr, 0, f.full_list ? 0 : 1, f.full_list, 0, f.out, f.force, nullptr,
+                                     f.dist_out);
+    const int64_t rpb = SPREAD_THREADS / kRowLanes;
+    d.n_row_blocks = unsigned((f.n_atoms + rpb - 1) / rpb);
+    d.phi_mesh = (const T*)f.phi_mesh;
+    d.dc = (const T*)f.dc;
+    d.inv_vol = T(1.0 / m->volume);
+    d.self_c = T(self_c);
+    d.bg_c = T(bg_c);
+    d.out = (T*)f.out;
+    d.field = (T*)f.field;
+    d.energy = (T*)f.energy;
+    d.force = (const T*)f.force;
+    d.grad_pos = (T*)f.grad_positions;
+    d.force_scale = f.full_list ? T(0.5) : T(1);
+    out[k] = d;
+  }
+  return MIPME_OK;
+}
+
+int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t);
+bool fft_plan_xfused(const mipme_fft_plan*);
+int fft_plan_batch(const mipme_fft_plan*);
+
+template <typename T>
+static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, const mipme_frame_t* fr, const void* table,
+                            const mipme_potential_t* /*unused*/, const void* G, int64_t G_stride, void* rho_all, void* hat_all,
+                            void* phi_all, void* dc_all, int pfast) {
+  const FrameDev<T>* tb = (const FrameDev<T>*)table;
+  const mipme_mesh_t* m = &fr[0].mesh;
+  const BrickGeom bg = make_brick_geom(m);
+  int64_t max_atoms = 0;
+  for (int k = 0; k < n_frames; ++k) max_atoms = std::max<int64_t>(max_atoms, fr[k].n_atoms);
+  const unsigned atom_blocks = unsigned((max_atoms + 255) / 256);
+  const unsigned F = unsigned(n_frames);
+  frames_bin_count_kernel<T><<<dim3(atom_blocks, F), 256, 0, st>>>(tb);
+  MIPME_LAUNCH_CHECK();
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (frames_bin_fill_kernel<S, N, T><<<dim3(atom_blocks, F), 256, 0, st>>>(tb)));
+  MIPME_LAUNCH_CHECK();
+  const int stage_rows = spread_stage_rows(m->order, sizeof(T));
+  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
+  const int64_t rpb = SPREAD_THREADS / kRowLanes;
+  const unsigned grid_x = unsigned(bg.nb) + unsigned((max_atoms + rpb - 1) / rpb);
+  if (pfast == 1)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, frames_spread_rows_kernel<N, T, 1><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+  else
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, frames_spread_rows_kernel<N, T, 6><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+  MIPME_LAUNCH_CHECK();
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride);
+  if (rc) return rc;
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                           ((void)S, frames_gather_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(tb)));
+  MIPME_LAUNCH_CHECK();
+  frames_energy_kernel<T><<<F, 1024, 0, st>>>(tb);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
@@ -959,3 +1214,62 @@ template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_
                                         const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 }  // namespace mipme
+
+using namespace mipme;
+
+extern "C" {
+
+int64_t mipme_frames_table_bytes(int dtype, int n_frames) {
+  if (n_frames <= 0) return 0;
+  return int64_t(n_frames) * int64_t(dtype == MIPME_F32 ? sizeof(FrameDev<float>) : sizeof(FrameDev<double>));
+}
+
+int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frames, const mipme_potential_t* pot,
+                             void* host_table, int64_t host_table_bytes) {
+  int rc = frames_check(dtype, n_frames, frames);
+  if (rc) return rc;
+  MIPME_REQUIRE(pot && host_table && host_table_bytes >= mipme_frames_table_bytes(dtype, n_frames),
+                "invalid arguments to mipme_frames_table_build");
+  if (dtype == MIPME_F32) return frames_table_build_t<float>(n_frames, frames, pot, host_table);
+  return frames_table_build_t<double>(n_frames, frames, pot, host_table);
+}
+
+int mipme_frames_forward(mipme_fft_plan* plan, void* stream, int dtype, int n_frames, const mipme_frame_t* frames,
+                         const mipme_potential_t* pot, const void* device_table, const void* G, int64_t G_stride,
+                         void* rho_mesh_all, void* hat_work_all, void* phi_mesh_all, void* dc_all) {
+  int rc = frames_check(dtype, n_frames, frames);
+  if (rc) return rc;
+  MIPME_REQUIRE(plan && pot && device_table && G && rho_mesh_all && hat_work_all && phi_mesh_all && dc_all && G_stride >= 0,
+                "NULL buffer passed to mipme_frames_forward");
+  MIPME_REQUIRE(fft_plan_xfused(plan) && fft_plan_batch(plan) == n_frames,
+                "mipme_frames_forward needs a plan with batch = n_frames and a power-of-two nx");
+  SRPot s;
+  if ((rc = make_srpot(pot, s))) return rc;
+  const int pfast = fast_rs_exponent(s);
+  MIPME_REQUIRE(pfast == 1 || pfast == 6, "the frames path covers 1/r and 1/r^6 with a smearing");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    return frames_forward_t<float>(plan, st, n_frames, frames, device_table, pot, G, G_stride, rho_mesh_all, hat_work_all,
+                                   phi_mesh_all, dc_all, pfast);
+  return frames_forward_t<double>(plan, st, n_frames, frames, device_table, pot, G, G_stride, rho_mesh_all, hat_work_all,
+                                  phi_mesh_all, dc_all, pfast);
+}
+
+int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_frame_t* frames, const void* device_table,
+                          const void* grad_scale) {
+  int rc = frames_check(dtype, n_frames, frames);
+  if (rc) return rc;
+  MIPME_REQUIRE(device_table && grad_scale, "NULL buffer passed to mipme_frames_backward");
+  int64_t max_atoms = 0;
+  for (int k = 0; k < n_frames; ++k) max_atoms = std::max<int64_t>(max_atoms, frames[k].n_atoms);
+  const dim3 grid(unsigned((3 * max_atoms + 255) / 256), unsigned(n_frames));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    frames_finalize_kernel<float><<<grid, 256, 0, st>>>((const FrameDev<float>*)device_table, (const float*)grad_scale);
+  else
+    frames_finalize_kernel<double><<<grid, 256, 0, st>>>((const FrameDev<double>*)device_table, (const double*)grad_scale);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+}  // extern "C"

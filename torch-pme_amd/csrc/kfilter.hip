@@ -377,7 +377,7 @@ __device__ __forceinline__ Cplx<T> csub(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a
 // (bit-reversed) data order.
 template <typename T>
 __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
-                                                   Cplx<T>* __restrict__ hat, const T* __restrict__ G,
+                                                   Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
                                                    T* __restrict__ dc) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   const int KZ = 1 << kzs;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
     const int x = idx >> kzs, z = idx & (KZ - 1);
     if (z < kzn) {
       const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
-      const T gk = G[(int64_t(kx) * ny + ky) * nzh + kz0 + z];
+      const T gk = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];  // G_stride: one filter table per batch entry, or 0
       Cplx<T> v = tile[idx];
       v.re *= gk;
       v.im *= gk;
@@ -489,10 +489,11 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
 }
 
 bool fft_plan_xfused(const mipme_fft_plan* p) { return p->fwd2d != 0 && p->inv2d != 0; }
+int fft_plan_batch(const mipme_fft_plan* p) { return p->batch; }
 
 // mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
-                    void* dc) {
+                    void* dc, int64_t G_stride) {
   MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
   MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
   const int nzh = p->nz / 2 + 1;
@@ -511,13 +512,13 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
   if (p->dtype == MIPME_F32) {
     MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
     xconv_kernel<float><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat, (const float*)G,
-                                                (float*)dc);
+                                                G_stride, (float*)dc);
     MIPME_LAUNCH_CHECK();
     MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
   } else {
     MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
     xconv_kernel<double><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                 (const double*)G, (double*)dc);
+                                                 (const double*)G, G_stride, (double*)dc);
     MIPME_LAUNCH_CHECK();
     MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
   }

@@ -9,9 +9,12 @@ stay eager and reference-compatible.
 
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class GraphedEnergyForces:
@@ -93,3 +96,155 @@ class GraphedEnergyForces:
         if self.cell_gradient:
             return self.energy, self.forces, self.cell_grad
         return self.energy, self.forces
+
+
+class _FramesFunction(torch.autograd.Function):
+    """Energies of all frames of a :class:`GraphedFrameBatch` as one autograd node: forward = the batched pipeline
+    (``mipme_frames_forward``), backward = the batched force assembly (``mipme_frames_backward``)."""
+
+    @staticmethod
+    def forward(ctx, batch, *positions):
+        batch._launch_forward()
+        ctx.batch = batch
+        return batch.energies.detach()  # a fresh tensor object per call (the buffer itself is persistent)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        batch = ctx.batch
+        batch._launch_backward(g.contiguous())
+        return (None, *batch._grad_pos)
+
+
+class GraphedFrameBatch:
+    """Energy + forces of several independent frames (the frames a rank owns) with ONE launch per kernel of the
+    pipeline -- ``blockIdx.y`` = frame (``mipme_frames_forward / backward``, csrc/bricks.hip) -- replayed from one HIP graph.
+
+    The frames may differ in atoms, cell and neighbour list; they must give the same mesh dimensions and share the
+    calculator (P3M / PME with 1/r or 1/r^6), dtype and device.  ``energies, forces = batch(positions_list=None)``:
+    ``energies`` (F,), ``forces`` a list of (N_f, 3) tensors (static buffers of the graph: read them before the next call).
+
+    :param calculator: a :class:`PMECalculator` / :class:`P3MCalculator`
+    :param frames: sequence of ``(charges, cell, positions, neighbor_indices, neighbor_shifts)``
+    """
+
+    def __init__(self, calculator, frames, warmup: int = 2):
+        lib = _lib.load()
+        self.calc = calculator
+        frames = list(frames)
+        F = self.n_frames = len(frames)
+        if F == 0:
+            raise ValueError("no frames")
+        q0, _, p0, _, _ = frames[0]
+        device, dtype = p0.device, p0.dtype
+        _lib.require_device(p0, "positions")
+        self.device, self.dtype = device, dtype
+        dt = self._dt = _lib.dtype_code(dtype)
+        self._pot = calculator.potential._descriptor()
+        full = bool(calculator.full_neighbor_list)
+        self.pos, self._keep, geoms, Gs = [], [], [], []
+        for q, cell, pos, pairs, shifts in frames:
+            if q.shape[1] != 1:
+                raise ValueError("the frames path handles a single charge channel")
+            geom, G = calculator._kspace_setup(cell, dtype, device)
+            geoms.append(geom)
+            Gs.append(G.reshape(-1))
+        ns = geoms[0].ns
+        if any(g.ns != ns for g in geoms):
+            raise ValueError(f"all frames must give the same mesh, got {[g.ns for g in geoms]}")
+        self.ns = ns
+        M, Mh = geoms[0].n_mesh, geoms[0].n_half
+        cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
+        self._G = torch.stack(Gs).contiguous()
+        self._rho = torch.empty((F,) + ns, dtype=dtype, device=device)
+        self._phi = torch.empty((F,) + ns, dtype=dtype, device=device)
+        self._hat = torch.empty((F, Mh), dtype=cdtype, device=device)
+        self._dc = torch.empty((F,), dtype=dtype, device=device)
+        self.energies = torch.empty((F,), dtype=dtype, device=device)
+        self._plan = _lib.FFTPlan(device, dtype, ns, F)
+        self._frames = (_lib.Frame * F)()
+        self._grad_pos, self.distances = [], []
+        for k, (q, cell, pos, pairs, shifts) in enumerate(frames):
+            N, P = pos.shape[0], pairs.shape[0]
+            p = pos.detach().clone().contiguous().requires_grad_(True)
+            qc = q.detach().reshape(-1).contiguous()
+            cl = cell.detach().to(dtype).contiguous()
+            sh = shifts.to(dtype).contiguous()
+            topo = ops.get_topology(pairs, N)
+            ent_sh, fmt = topo.entries_with_shifts(sh, shifts, table=True)
+            if ent_sh is None or fmt != 1:
+                raise ValueError(f"frame {k}: cell shifts must be integers in [-3, 3] for the frames path")
+            md = geoms[k].desc(1)
+            nbytes = lib.mipme_atom_bins_bytes(C.byref(md), N, dt)
+            if nbytes <= 0:
+                raise ValueError(f"frame {k}: mesh {ns} is outside the brick kernels' range")
+            nb = ((ns[0] + 7) // 8) * ((ns[1] + 7) // 8) * ((ns[2] + 7) // 8)
+            buf = dict(
+                bins=torch.empty((nbytes,), dtype=torch.uint8, device=device),
+                counters=torch.zeros((nb + 1,), dtype=torch.int32, device=device),
+                records=torch.empty((N, 4), dtype=dtype, device=device),
+                out=torch.empty((N,), dtype=dtype, device=device),
+                force=torch.empty((N, 3), dtype=dtype, device=device),
+                field=torch.empty((N, 3), dtype=dtype, device=device),
+                grad=torch.empty((N, 3), dtype=dtype, device=device),
+                dist=torch.empty((P,), dtype=dtype, device=device) if topo.sorted_by_first and P > 0 else None,
+            )
+            f = self._frames[k]
+            f.n_atoms, f.positions, f.charges, f.cell, f.mesh = N, p.data_ptr(), qc.data_ptr(), cl.data_ptr(), md
+            f.atom_bins, f.brick_counters = buf["bins"].data_ptr(), buf["counters"].data_ptr()
+            f.row_ptr, f.entries_shift, f.entries = topo.row_ptr.data_ptr(), ent_sh.data_ptr(), topo.entries.data_ptr()
+            f.full_list, f.shift_format = int(full), int(fmt)
+            f.records = buf["records"].data_ptr()
+            f.rho_mesh, f.phi_mesh, f.dc = self._rho[k].data_ptr(), self._phi[k].data_ptr(), self._dc[k:].data_ptr()
+            f.out, f.force, f.field = buf["out"].data_ptr(), buf["force"].data_ptr(), buf["field"].data_ptr()
+            f.dist_out = _lib.ptr(buf["dist"])
+            f.energy, f.grad_positions = self.energies[k:].data_ptr(), buf["grad"].data_ptr()
+            self.pos.append(p)
+            self._grad_pos.append(buf["grad"])
+            self.distances.append(buf["dist"])
+            self._keep.append((qc, cl, sh, topo, ent_sh, buf, pairs))
+        nbytes = lib.mipme_frames_table_bytes(dt, F)
+        host = np.zeros((nbytes,), dtype=np.uint8)
+        _lib.check(lib.mipme_frames_table_build(dt, F, self._frames, C.byref(self._pot), host.ctypes.data, nbytes))
+        self._table = torch.from_numpy(host).to(device)
+        self._minus_one = torch.full((F,), -1.0, dtype=dtype, device=device)
+        # warm-up (plans, lazy module loads) off the default stream, then capture
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eval()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._eval()
+        self.forces = [p.grad for p in self.pos]
+
+    def _launch_forward(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().mipme_frames_forward(
+                self._plan.handle, _lib.current_stream(self.device), self._dt, self.n_frames, self._frames,
+                C.byref(self._pot), self._table.data_ptr(), self._G.data_ptr(), self._G.shape[1], self._rho.data_ptr(),
+                self._hat.data_ptr(), self._phi.data_ptr(), self._dc.data_ptr()))
+
+    def _launch_backward(self, g):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().mipme_frames_backward(
+                _lib.current_stream(self.device), self._dt, self.n_frames, self._frames, self._table.data_ptr(),
+                g.data_ptr()))
+
+    def _eval(self):
+        for p in self.pos:
+            p.grad = None
+        E = _FramesFunction.apply(self, *self.pos)
+        E.backward(self._minus_one)  # seeded with -1: positions.grad are the forces
+        return E
+
+    def __call__(self, positions=None):
+        if positions is not None:
+            with torch.no_grad():
+                for buf, new in zip(self.pos, positions):
+                    buf.copy_(new)
+        self.graph.replay()
+        return self.energies, self.forces
