@@ -26,3 +26,13 @@ for _ in range(20): step(True)
 torch.cuda.synchronize()
 print({k: round(ms / calls * 1000, 1) for k, (calls, ms) in _lib.profile_report().items()})
 print({k: round(sum(a.elapsed_time(b) for a, b in v) / len(v) * 1000, 1) for k, v in ops.PROFILE.items()})
+
+# the same step replayed as a HIP graph (GraphedEnergyForces), without and with the cell gradient
+for with_cell in (False, True):
+    g = tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos.detach(), f.pairs, f.shifts, cell_gradient=with_cell)
+    for _ in range(20): g()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(300): g()
+    torch.cuda.synchronize()
+    print("graph replay,", "energy + forces + dE/dcell" if with_cell else "energy + forces          ",
+          "%.4f ms/step" % ((time.perf_counter() - t0) / 300 * 1e3))
