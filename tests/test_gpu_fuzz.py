@@ -1,0 +1,84 @@
+"""Seeded random sweep of the hot path against the oracle: calculator type and interpolation order, potential (1/r^p,
+p = 1..6, with and without an exclusion radius), dtype, triclinic cells whose meshes differ per axis (brick kernels and
+atomic kernels, fused and 3-D convolution), atom counts that are not multiples of any block size, atoms outside the
+cell, half / full lists, pair masks, eager / deferred distances, energy-mode and general upstream gradients.  Every case
+checks potentials and the gradients w.r.t. positions, cell and charges."""
+import numpy as np
+import pytest
+import torch
+
+import torchpme_amd as tpa
+from oracle import pme_numpy as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rell2(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / (np.linalg.norm(np.asarray(b)) + 1e-300))
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_configuration(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dtype = torch.float64 if rng.uniform() < 0.6 else torch.float32
+    scheme = "P3M" if rng.uniform() < 0.5 else "Lagrange"
+    order = int(rng.integers(1, 6)) if scheme == "P3M" else int(rng.integers(3, 8))
+    lengths = rng.uniform(5.0, 13.0, 3)
+    cell = np.diag(lengths) + np.tril(rng.uniform(-0.15, 0.15, (3, 3)) * lengths.min(), -1)
+    h = float(rng.uniform(0.4, 1.1))
+    N = int(rng.integers(1, 260))
+    pos = rng.uniform(-0.3, 1.3, (N, 3)) @ cell
+    q = rng.normal(size=(N, 1))
+    full = bool(rng.uniform() < 0.4)
+    cutoff = float(rng.uniform(2.0, 4.5))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, cutoff, full_list=full)
+    if len(pairs) and dist.min() < 0.5:  # keep 1/r^6 within what fp32 can compare
+        keep = dist > 0.5
+        pairs, S, dist = pairs[keep], S[keep], dist[keep]
+    p = int(rng.integers(1, 7))
+    sm = float(rng.uniform(0.8, 1.5))
+    excl = float(rng.uniform(1.0, 2.0)) if rng.uniform() < 0.25 else None
+    if p == 1 and rng.uniform() < 0.5:
+        spec = O.PotentialSpec("coulomb", 1, sm, 1.0, exclusion_radius=excl, exclusion_degree=2 if excl else 1)
+        pot = tpa.CoulombPotential(smearing=sm, exclusion_radius=excl, exclusion_degree=2 if excl else 1)
+    else:
+        spec = O.PotentialSpec("ipl", p, sm, 1.0, exclusion_radius=excl, exclusion_degree=2 if excl else 1)
+        pot = tpa.InversePowerLawPotential(exponent=p, smearing=sm, exclusion_radius=excl, exclusion_degree=2 if excl else 1)
+    mask = (rng.uniform(size=len(pairs)) > 0.2) if rng.uniform() < 0.25 else None
+    energy_mode = bool(rng.uniform() < 0.5)
+    deferred = bool(rng.uniform() < 0.5)
+    need_q = not energy_mode or bool(rng.uniform() < 0.5)
+    gE = -1.3
+    g = gE * q if energy_mode else rng.normal(size=(N, 1))
+
+    Vo, cache = O.forward(spec, scheme, order, h, q, cell, pos, pairs, dist, full_list=full, pair_mask=mask, return_cache=True)
+    gr = O.backward(cache, g)
+    gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+
+    Calc = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    calc = Calc(pot, mesh_spacing=h, interpolation_nodes=order, full_neighbor_list=full).to(dtype)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=dtype, requires_grad=grad)  # noqa: E731
+    tq, tc, tp = t(q, need_q), t(cell, True), t(pos, True)
+    ti = torch.tensor(pairs.reshape(-1, 2), device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, t(S.reshape(-1, 3)), deferred=deferred)
+    V = calc(tq, tc, tp, ti, d, pair_mask=None if mask is None else torch.tensor(mask, device=DEV))
+    if energy_mode:
+        (gE * tpa.weighted_sum(V, tq)).backward()
+    else:
+        (V * t(g)).sum().backward()
+    f64 = dtype == torch.float64
+    # fp32: 1/r^p sums of either sign cancel; compare against the magnitude of the terms rather than of the sum
+    tolV, tolG = (1e-10, 1e-9) if f64 else (3e-4, 2e-3)
+    info = f"seed {seed}: {scheme}{order} p={p} excl={excl} N={N} P={len(pairs)} full={full} mask={mask is not None} " \
+           f"energy={energy_mode} deferred={deferred} {dtype}"
+    assert rell2(V.detach().cpu().numpy(), Vo) < tolV, info
+    assert rell2(tp.grad.cpu().numpy(), gr["positions"] + gpos_d) < tolG, info
+    # (the 9 cell-gradient components are sums over all pairs / mesh points with heavy cancellation: looser in fp32)
+    assert rell2(tc.grad.cpu().numpy(), gr["cell"] + gcell_d) < (tolG if f64 else 1e-2), info
+    if need_q:
+        # energy mode: L = gE sum_a q_a V_a(q) depends on q directly (gE V) and through V (the oracle's adjoint for g = gE q)
+        expect_q = gr["charges"] + (gE * Vo if energy_mode else 0.0)
+        assert rell2(tq.grad.cpu().numpy(), expect_q) < tolG, info
+    if len(pairs):
+        assert rell2(d.detach().cpu().numpy(), dist) < (1e-13 if f64 else 1e-5), info
