@@ -82,3 +82,57 @@ def test_random_configuration(seed):
         assert rell2(tq.grad.cpu().numpy(), expect_q) < tolG, info
     if len(pairs):
         assert rell2(d.detach().cpu().numpy(), dist) < (1e-13 if f64 else 1e-5), info
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphed_step(seed):
+    """The same kind of random configuration through ``GraphedEnergyForces`` (HIP-graph replay: deferred distances,
+    co-scheduled pair sum where the mesh allows it, direct energy gradient), optionally with the cell gradient, against the
+    oracle -- for the captured positions and after an in-place position update."""
+    rng = np.random.default_rng(5000 + seed)
+    dtype = torch.float64 if rng.uniform() < 0.6 else torch.float32
+    scheme = "P3M" if rng.uniform() < 0.5 else "Lagrange"
+    order = int(rng.integers(2, 6)) if scheme == "P3M" else int(rng.integers(3, 8))
+    lengths = rng.uniform(6.0, 12.0, 3)
+    cell = np.diag(lengths) + np.tril(rng.uniform(-0.1, 0.1, (3, 3)) * lengths.min(), -1)
+    h = float(rng.uniform(0.35, 0.9))
+    n_side = int(rng.integers(2, int(lengths.min() / 1.3) + 1))  # jittered lattice: no overlapping atoms
+    N = int(rng.integers(max(2, n_side**3 // 2), n_side**3 + 1))
+    full = bool(rng.uniform() < 0.4)
+    p = 6 if rng.uniform() < 0.3 else 1
+    sm = float(rng.uniform(0.8, 1.4))
+    with_cell = bool(rng.uniform() < 0.3)
+    spec = O.PotentialSpec("coulomb" if p == 1 else "ipl", p, sm, 1.0)
+    pot = tpa.CoulombPotential(smearing=sm) if p == 1 else tpa.InversePowerLawPotential(exponent=6, smearing=sm)
+    Calc = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    calc = Calc(pot, mesh_spacing=h, interpolation_nodes=order, full_neighbor_list=full).to(dtype)
+    sites = rng.permutation(n_side**3)[:N]
+    grid = np.stack(np.unravel_index(sites, (n_side,) * 3), -1)
+    frac = (grid + 0.5 + rng.uniform(-0.2, 0.2, (N, 3))) / n_side
+    q = rng.normal(size=(N, 1))
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    step = None
+    for k in range(2):
+        pos = (frac + (0.0 if k == 0 else 0.004) * rng.normal(size=(N, 3))) @ cell
+        # one list for both position sets (a Verlet list): build it for the first set with a margin
+        if k == 0:
+            pairs, S, _ = tpa.neighbor_list(pos, cell, 3.6, full_list=full)
+            ti, tS = torch.tensor(pairs.reshape(-1, 2), device=DEV), t(S.reshape(-1, 3))
+            step = tpa.GraphedEnergyForces(calc, t(q), t(cell), t(pos), ti, tS, cell_gradient=with_cell)
+        dist, _ = O.pair_distances(pos, cell, pairs, S)
+        if len(pairs) and dist.min() < 0.6:
+            pytest.skip("random configuration with overlapping atoms")
+        Vo, cache = O.forward(spec, scheme, order, h, q, cell, pos, pairs, dist, full_list=full, return_cache=True)
+        gr = O.backward(cache, q)
+        gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+        out = step(t(pos))
+        f64 = dtype == torch.float64
+        info = f"seed {seed}/{k}: {scheme}{order} p={p} N={N} P={len(pairs)} full={full} cell={with_cell} {dtype}"
+        Eo = float((q * Vo).sum())
+        scale = float(np.abs(q * Vo).sum())
+        assert abs(out[0].item() - Eo) < (1e-10 if f64 else 2e-5) * scale, info
+        assert rell2(out[1].cpu().numpy(), -(gr["positions"] + gpos_d)) < (1e-9 if f64 else 2e-3), info
+        if with_cell:
+            assert rell2(out[2].cpu().numpy(), gr["cell"] + gcell_d) < (1e-9 if f64 else 1e-2), info
+        if len(pairs):
+            assert rell2(step.distances.cpu().numpy(), dist) < (1e-13 if f64 else 1e-5), info
