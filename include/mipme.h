@@ -147,7 +147,15 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job);
+                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job, void* out_cell_partials);
+/* out_cell_partials (nullable, needs rho_hat == NULL; float64[mipme_cellgrad_partials_size]): the x stage of the fused
+ * convolution also forms the 12 k-grid sums of the cell gradient for the energy mode (dL/dG(k) = mu(k) |rho^(k)|^2 up to
+ * gE / 2V) while rho^ is in LDS -- mipme_fft_plan_kgrid_blocks(plan) partial sums that mipme_kspace_backward takes as
+ * kgrid_blocks_ready, so that neither rfftn(rho) nor the 3-D plans are needed for the stress. */
+int64_t mipme_fft_plan_kgrid_blocks(const mipme_fft_plan* plan);
+/* hat (C,nx,ny,nz/2+1 complex) = rfftn(mesh_in (C,nx,ny,nz)), un-normalised: for a backward pass with a general upstream
+ * gradient and a cell gradient after a forward that kept the charge mesh instead of rho^ (see out_cell_partials). */
+int mipme_fft_r2c(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh, const void* mesh_in, void* hat);
 
 /* ---- independent frames in one launch (the frames a rank owns) -----------------------------------------
  * Energy + forces of n_frames independent frames (own atoms, cell, pair list; same mesh
@@ -214,7 +222,12 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* atom_bins, const void* grad_scale);
+                          void* grad_cell, void* atom_bins, const void* grad_scale, const void* mesh_field,
+                          int64_t kgrid_blocks_ready);
+/* Energy mode extras (grad_scale != NULL): mesh_field (nullable; out_field of the forward call) with grad_positions ==
+ * grad_charges == NULL -- no gradient gather, the mesh part of dL/dr is grad_scale q_a field_a (the caller assembles the
+ * forces with mipme_sr_rows_finalize; the cell gradient uses the same expression); kgrid_blocks_ready > 0 -- `partials`
+ * already holds that many k-grid partial sums (out_cell_partials of the forward call) and rho_hat may be NULL. */
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
 
 /* atom_bins (nullable): device scratch of mipme_atom_bins_bytes() bytes.  When given, the atoms are counting-sorted

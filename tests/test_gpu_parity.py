@@ -767,6 +767,9 @@ def test_concurrent_frames_on_streams():
     for g in frames:
         E, F = g()
         ref.append((E.clone(), F.clone()))
+    # the side streams below do not wait for the default stream: the reference replays (and the clones of their static
+    # output buffers) must have finished before the concurrent replays overwrite those buffers
+    torch.cuda.synchronize()
     streams = [torch.cuda.Stream(DEV) for _ in frames]
     for _ in range(20):
         for g, st in zip(frames, streams):
@@ -774,8 +777,9 @@ def test_concurrent_frames_on_streams():
                 g.graph.replay()
     torch.cuda.synchronize()
     for g, (E, F) in zip(frames, ref):
-        torch.testing.assert_close(g.energy, E, rtol=1e-12, atol=0)
-        torch.testing.assert_close(g.forces, F, rtol=1e-10, atol=1e-12)
+        # (16^3 meshes use the atomic mesh kernels: the summation order of the fp64 atomics varies between runs)
+        torch.testing.assert_close(g.energy, E, rtol=1e-10, atol=0)
+        torch.testing.assert_close(g.forces, F, rtol=1e-9, atol=1e-11)
 
 
 def test_graph_survives_cache_eviction(golden_dir):

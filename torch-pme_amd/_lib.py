@@ -31,7 +31,7 @@ EXPORTS = (
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
     "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
-    "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused",
+    "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
 )
@@ -148,8 +148,8 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp, C.POINTER(SrJob)],
-        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19,
+        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp, C.POINTER(SrJob), vp],
+        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19 + [vp, i64],
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
         "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
@@ -165,6 +165,7 @@ def _declare(lib):
         "mipme_pair_distance_forward_packed": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_sr_rows_fused": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, PP, ci, ci, vp, ci, vp, vp, vp, vp, vp],
         "mipme_sr_rows_finalize": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
+        "mipme_fft_r2c": [vp, vp, ci, MP, vp, vp],
         "mipme_frames_table_build": [ci, ci, C.POINTER(Frame), PP, vp, i64],
         "mipme_frames_forward": [vp, vp, ci, ci, C.POINTER(Frame), PP, vp, vp, i64, vp, vp, vp, vp],
         "mipme_frames_backward": [vp, ci, ci, C.POINTER(Frame), vp, vp],
@@ -196,6 +197,8 @@ def _declare(lib):
     lib.mipme_nl_scratch_ints.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_fft_plan_xfused.restype = ci
     lib.mipme_fft_plan_xfused.argtypes = [vp]
+    lib.mipme_fft_plan_kgrid_blocks.restype = i64
+    lib.mipme_fft_plan_kgrid_blocks.argtypes = [vp]
     lib.mipme_frames_table_bytes.restype = i64
     lib.mipme_frames_table_bytes.argtypes = [ci, ci]
     lib.mipme_profile_enable.restype = ci
@@ -273,6 +276,8 @@ class FFTPlan:
         self.handle = handle
         #: the plan can run the convolution as (y,z) hipFFT planes + one fused x kernel (power-of-two nx)
         self.xfused = bool(load().mipme_fft_plan_xfused(handle))
+        #: number of k-grid partial sums the fused convolution writes when asked for the cell sums (out_cell_partials)
+        self.kgrid_blocks = int(load().mipme_fft_plan_kgrid_blocks(handle))
 
     def __del__(self):
         try:

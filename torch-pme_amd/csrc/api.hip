@@ -27,7 +27,8 @@ template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
 template <typename T> int apply_filter_cellgrad_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, const void*, const void*, const void*, void*, void*, void*);
-template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, void*);
+template <typename T> int cellgrad_finalize_impl(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, void*, int64_t, const void*, const void*);
+int64_t xconv_blocks(const mipme_fft_plan*);
 int64_t cellgrad_scratch_doubles();
 int64_t cellgrad_blocks(const mipme_mesh_t*);
 int fft_plan_create(int, int, int, int, int, mipme_fft_plan**);
@@ -35,7 +36,8 @@ int fft_plan_destroy(mipme_fft_plan*);
 int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
-int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t);
+int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
+                    const mipme_potential_t*, void*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
@@ -115,7 +117,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
                             void* wait_event, int accumulate, void* out_field, void* out_records,
-                            const mipme_sr_job_t* job) {
+                            const mipme_sr_job_t* job, void* cell_partials) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -144,7 +146,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   }
   if (!rho_hat) {
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -164,7 +166,8 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
                              int64_t N, const void* pos, const void* q, const void* gout, const void* G,
                              const void* phi_mesh, const void* rho_hat, const void* rho_dc, const void* phi_atoms,
                              void* psi_mesh, void* psi_hat, void* hat_work, void* chi_mesh, void* dc, void* partials,
-                             void* grad_pos, void* grad_q, void* grad_cell, void* bins, const void* grad_scale) {
+                             void* grad_pos, void* grad_q, void* grad_cell, void* bins, const void* grad_scale,
+                             const void* mesh_field, int64_t kgrid_blocks_ready) {
   int rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
@@ -172,17 +175,28 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
     // energy mode: grad_out = grad_scale * charges  =>  psi = (grad_scale/2V) rho, chi = (grad_scale/2V) phi:
     // no second spread / FFT / filter / inverse FFT (special case L = sum q V)
     MIPME_REQUIRE(rho_dc, "energy-mode backward needs rho_dc");
-    if (bins)
-      STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
-    else
-      STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+    // mesh_field (the forward gather's per-atom field, single channel): the mesh forces are gE q_a field_a -- no gradient
+    // gather; the caller assembles them (mipme_sr_rows_finalize) and passes grad_positions = grad_charges = NULL
+    const bool from_field = mesh_field != nullptr && !grad_pos && !grad_q;
+    if (!from_field) {
+      if (bins)
+        STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+      else
+        STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, phi_mesh, rho_dc, grad_scale, self_c, bg_c, grad_pos, grad_q));
+    }
     if (grad_cell) {
-      // dL/dG(k) = (gE / 2V) mu(k) |rho^(k)|^2: the 12 k-grid sums from the saved rho^ alone, scaled in the finalisation
-      MIPME_REQUIRE(rho_hat && phi_atoms && partials && grad_pos,
-                    "cell gradient needs rho_hat, phi_atoms, partials and grad_positions buffers");
-      STAGE(st, "apply_filter_cellgrad", apply_filter_cellgrad_impl<T>(st, m, pot, rho_hat, rho_hat, G, nullptr, nullptr, partials));
+      // dL/dG(k) = (gE / 2V) mu(k) |rho^(k)|^2: the 12 k-grid sums from rho^ alone, scaled in the finalisation -- either
+      // already in `partials` (kgrid_blocks_ready of them, written by the forward's fused convolution) or formed here from
+      // the saved rho^
+      MIPME_REQUIRE(phi_atoms && partials && (grad_pos || from_field),
+                    "cell gradient needs phi_atoms, partials and grad_positions (or the mesh field) buffers");
+      if (kgrid_blocks_ready <= 0) {
+        MIPME_REQUIRE(rho_hat, "cell gradient needs rho_hat unless the k-grid sums are ready");
+        STAGE(st, "apply_filter_cellgrad", apply_filter_cellgrad_impl<T>(st, m, pot, rho_hat, rho_hat, G, nullptr, nullptr, partials));
+      }
       STAGE(st, "cellgrad_finalize",
-            cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, rho_dc, grad_scale, grad_cell));
+            cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, from_field ? nullptr : grad_pos, gout, phi_atoms, rho_dc,
+                                      rho_dc, grad_scale, grad_cell, kgrid_blocks_ready, mesh_field, q));
     }
     return MIPME_OK;
   }
@@ -194,7 +208,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   }
@@ -213,7 +227,8 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
     STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
   if (grad_cell)
     STAGE(st, "cellgrad_finalize",
-          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, nullptr, grad_cell));
+          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, nullptr, grad_cell, 0,
+                                    nullptr, nullptr));
   return MIPME_OK;
 }
 
@@ -467,13 +482,14 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
                          const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
                          void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job) {
+                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job, void* out_cell_partials) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
   MIPME_REQUIRE(G && rho_mesh && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(rho_hat || fft_plan_xfused(plan), "rho_hat may only be NULL for plans with a power-of-two nx");
+  MIPME_REQUIRE(!out_cell_partials || !rho_hat, "out_cell_partials is produced by the fused convolution (rho_hat == NULL)");
   MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
   MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
@@ -489,9 +505,9 @@ int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mi
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job),
+                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job, out_cell_partials),
             kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job));
+                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job, out_cell_partials));
 }
 
 int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
@@ -499,7 +515,8 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
                           const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
                           const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
                           void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* bins, const void* grad_scale) {
+                          void* grad_cell, void* bins, const void* grad_scale, const void* mesh_field,
+                          int64_t kgrid_blocks_ready) {
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
@@ -514,13 +531,24 @@ int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const m
   DT_SWITCH(dtype,
             kspace_backward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                      rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                     grad_positions, grad_charges, grad_cell, bins, grad_scale),
+                                     grad_positions, grad_charges, grad_cell, bins, grad_scale, mesh_field, kgrid_blocks_ready),
             kspace_backward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
                                       rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                      grad_positions, grad_charges, grad_cell, bins, grad_scale));
+                                      grad_positions, grad_charges, grad_cell, bins, grad_scale, mesh_field, kgrid_blocks_ready));
 }
 
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan) { return plan && fft_plan_xfused(plan) ? 1 : 0; }
+
+int64_t mipme_fft_plan_kgrid_blocks(const mipme_fft_plan* plan) { return plan ? xconv_blocks(plan) : 0; }
+
+/* hat = rfftn(mesh) over the three mesh dimensions of every channel, un-normalised (the plan's 3-D R2C transform) */
+int mipme_fft_r2c(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh, const void* mesh_in, void* hat) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  if ((rc = check_plan(plan, dtype, mesh))) return rc;
+  MIPME_REQUIRE(mesh_in && hat, "NULL buffer passed to mipme_fft_r2c");
+  return fft_forward(plan, (hipStream_t)stream, mesh_in, hat);
+}
 
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
   if (!mesh || n_atoms < 0) return 0;
@@ -566,7 +594,10 @@ int64_t mipme_profile_report(char* buf, int64_t buflen) {
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms) {
   (void)n_atoms;
   if (!mesh) return 0;
-  return 12 * cellgrad_blocks(mesh) + cellgrad_scratch_doubles();
+  // k-grid partial sums come either from apply_filter_cellgrad (one block per 256 half-grid points) or from the x stage of
+  // the fused convolution (at most one block per (ky, kz) column and channel)
+  const int64_t xmax = int64_t(mesh->ny) * (mesh->nz / 2 + 1) * mesh->n_channels;
+  return 12 * std::max<int64_t>(cellgrad_blocks(mesh), xmax) + cellgrad_scratch_doubles();
 }
 
 int mipme_slab_forward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,

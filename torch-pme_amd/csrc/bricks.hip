@@ -1158,7 +1158,8 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
   return MIPME_OK;
 }
 
-int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t);
+int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
+                    const mipme_potential_t*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int fft_plan_batch(const mipme_fft_plan*);
 
@@ -1188,7 +1189,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, frames_spread_rows_kernel<N, T, 6><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
   MIPME_LAUNCH_CHECK();
-  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride);
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr);
   if (rc) return rc;
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, frames_gather_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(tb)));

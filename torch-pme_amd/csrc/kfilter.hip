@@ -9,6 +9,7 @@
 #include <hipfft/hipfft.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -217,7 +218,10 @@ __global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, 
                                                                const T* __restrict__ gout, const T* __restrict__ phi_atoms,
                                                                const T* __restrict__ rho_dc, const T* __restrict__ psi_dc,
                                                                const T* __restrict__ energy_scale,
-                                                               T* __restrict__ grad_cell) {
+                                                               T* __restrict__ grad_cell, const T* __restrict__ field,
+                                                               const T* __restrict__ q) {
+  // grad_pos == NULL (energy mode only): the mesh part of dL/dr_a is energy_scale * q_a * field_a, with the per-atom mesh
+  // field the forward gather wrote
   // energy_scale != NULL (energy mode, g = gE * charges): the k-grid partials were formed with psi^ = rho^ and psi_dc is
   // rho_dc; both are multiplied by gE / 2V here
   constexpr int NV = kFinalizeNV;
@@ -233,7 +237,17 @@ __global__ __launch_bounds__(256) void cellgrad_finalize_kernel(mipme_mesh_t m, 
   const int C = m.n_channels;
   for (int64_t a = t0; a < n_atoms; a += stride) {
     const double r[3] = {double(pos[3 * a]), double(pos[3 * a + 1]), double(pos[3 * a + 2])};
-    const double gp[3] = {double(grad_pos[3 * a]), double(grad_pos[3 * a + 1]), double(grad_pos[3 * a + 2])};
+    double gp[3];
+    if (grad_pos) {
+      gp[0] = double(grad_pos[3 * a]);
+      gp[1] = double(grad_pos[3 * a + 1]);
+      gp[2] = double(grad_pos[3 * a + 2]);
+    } else {
+      const double w = double(energy_scale[0]) * double(q[a]);
+      gp[0] = w * double(field[3 * a]);
+      gp[1] = w * double(field[3 * a + 1]);
+      gp[2] = w * double(field[3 * a + 2]);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -375,10 +389,13 @@ __device__ __forceinline__ Cplx<T> csub(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a
 // columns, padded ones compute on zeros).  Two radix-2 stages are done per pass by the thread that owns the four points
 // they couple, which halves the LDS round trips and barriers of the textbook radix-2 schedule without changing its
 // (bit-reversed) data order.
-template <typename T>
+// CELLSUMS: also form, per block, the 12 k-grid sums of the cell gradient for the energy mode (psi^ = rho^, i.e.
+// dL/dG(k) = mu(k) |rho^(k)|^2 up to the factor gE / 2V applied by cellgrad_finalize_kernel) from the transformed columns
+// while they are in LDS -- what apply_filter_cellgrad_kernel computes from a stored rfftn(rho) in the backward pass.
+template <typename T, bool CELLSUMS>
 __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                    Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
-                                                   T* __restrict__ dc) {
+                                                   T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   const int KZ = 1 << kzs;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
@@ -433,6 +450,47 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
     __syncthreads();
   }
   if (dc && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
+  if constexpr (CELLSUMS) {
+    double acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+    for (int idx = tid; idx < n_el; idx += nthr) {
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      if (z < kzn) {
+        const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+        const int iz = kz0 + z;
+        const Cplx<T> v = tile[idx];
+        const bool edge = (iz == 0) || ((kg.nz % 2 == 0) && (iz == kg.nz / 2));
+        const double dLdG = (double(v.re) * double(v.re) + double(v.im) * double(v.im)) * (edge ? 1.0 : 2.0);
+        KPoint p;
+        eval_point<true>(kg, kp, kx, ky, iz, p);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[3 * a + d] += 2.0 * kPi * dLdG * p.dGdk[a] * double(p.f[d]);
+          acc[9 + a] += dLdG * p.dGdh[a];
+        }
+      }
+    }
+    __shared__ double red[4][12];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      double v = acc[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 12) {
+      double v = 0.0;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) v += red[w][tid];
+      partials[int64_t(blockIdx.x) * 12 + tid] = v;
+    }
+    // the ticket counter of cellgrad_finalize_kernel lives behind its block sums, after the k-grid partials
+    if (blockIdx.x == 0 && tid == 0)
+      *reinterpret_cast<int*>(partials + int64_t(gridDim.x) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl) = 0;
+  }
   // ---- product with G: position x holds kx = bitrev(x) ----
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
@@ -492,8 +550,20 @@ bool fft_plan_xfused(const mipme_fft_plan* p) { return p->fwd2d != 0 && p->inv2d
 int fft_plan_batch(const mipme_fft_plan* p) { return p->batch; }
 
 // mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
+// blocks of the x stage (= number of 12-value partial sums it writes when asked for the cell sums)
+int64_t xconv_blocks(const mipme_fft_plan* p) {
+  const int nzh = p->nz / 2 + 1;
+  const size_t cs = p->dtype == MIPME_F32 ? 8 : 16;
+  int kzs = p->dtype == MIPME_F32 ? 3 : 2;
+  while (kzs > 0 && cs * (size_t(p->nx) << kzs) > 32768) --kzs;
+  const int KZ = 1 << kzs;
+  return int64_t((nzh + KZ - 1) / KZ) * p->ny * p->batch;
+}
+
+// cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
-                    void* dc, int64_t G_stride) {
+                    void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
+                    void* cell_partials) {
   MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
   MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
   const int nzh = p->nz / 2 + 1;
@@ -509,20 +579,143 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
   const size_t lds = cs * ((size_t(p->nx) << kzs) + size_t(p->nx / 2));
   int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  KGeom kg{};
+  KPot kp{};
+  if (cell_partials) {
+    MIPME_REQUIRE(cell_mesh && cell_pot, "the cell sums of the x stage need the mesh and potential descriptors");
+    int rc = make_kpot(cell_pot, kp);
+    if (rc) return rc;
+    kg = make_kgeom(cell_mesh);
+  }
   if (p->dtype == MIPME_F32) {
     MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
-    xconv_kernel<float><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat, (const float*)G,
-                                                G_stride, (float*)dc);
+    if (cell_partials)
+      xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
+                                                            (const float*)G, G_stride, (float*)dc, kg, kp,
+                                                            (double*)cell_partials);
+    else
+      xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
+                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr);
     MIPME_LAUNCH_CHECK();
     MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
   } else {
     MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
-    xconv_kernel<double><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                 (const double*)G, G_stride, (double*)dc);
+    if (cell_partials)
+      xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
+                                                             (const double*)G, G_stride, (double*)dc, kg, kp,
+                                                             (double*)cell_partials);
+    else
+      xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
+                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr);
     MIPME_LAUNCH_CHECK();
     MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
   }
   return MIPME_OK;
+}
+
+int fft_forward(mipme_fft_plan* p, hipStream_t st, const void* in, void* out);
+int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out);
+
+// ---- plan self-test ------------------------------------------------------------------------------------------------
+// hipFFT plans created AFTER another user of hipFFT in the same process has run certain transforms can return wrong
+// results without any error (observed with PyTorch 2.10+rocm7.0: after torch.fft.rfftn of a 64^3 fp64 tensor, the C2R
+// transforms of a (32,32,128) fp64 plan created later are wrong at every odd z index; tools/fft_interference_probe.py).
+// A plan is therefore checked once, when it is created: irfftn(rfftn(x)) must return M x for a pseudo-random x.
+template <typename T>
+__global__ void selftest_fill_kernel(int64_t n, T* __restrict__ x) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = unsigned(i) * 2654435761u;
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+  x[i] = T(double(h & 0xffffff) / double(0x1000000) - 0.5);
+}
+
+template <typename T>
+__global__ void selftest_check_kernel(int64_t n, const T* __restrict__ got, double scale, double* __restrict__ max_err) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  double e = 0.0;
+  if (i < n) {
+    unsigned h = unsigned(i) * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    const double want = double(T(double(h & 0xffffff) / double(0x1000000) - 0.5));
+    e = fabs(double(got[i]) / scale - want);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) e = fmax(e, __shfl_xor(e, off, 64));
+  if ((threadIdx.x & 63) == 0 && e > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(max_err), __double_as_longlong(e));
+}
+
+template <typename T>
+static int plan_selftest_t(mipme_fft_plan* p) {
+  const int64_t M = int64_t(p->nx) * p->ny * p->nz, Mh = int64_t(p->nx) * p->ny * (p->nz / 2 + 1);
+  const int64_t nr = M * p->batch, nc = 2 * Mh * p->batch;
+  T *x = nullptr, *y = nullptr, *hat = nullptr;
+  double* err = nullptr;
+  int rc = MIPME_OK;
+  double host_err[2] = {0.0, 0.0};
+  if (hipMalloc((void**)&x, sizeof(T) * nr) != hipSuccess || hipMalloc((void**)&y, sizeof(T) * nr) != hipSuccess ||
+      hipMalloc((void**)&hat, sizeof(T) * nc) != hipSuccess || hipMalloc((void**)&err, 2 * sizeof(double)) != hipSuccess ||
+      hipMemset(err, 0, 2 * sizeof(double)) != hipSuccess) {
+    set_error("could not allocate the scratch of the FFT plan self-test");
+    (void)hipGetLastError();
+    rc = MIPME_EHIP;
+  }
+  const unsigned blocks = unsigned((nr + 255) / 256);
+  hipStream_t st = nullptr;
+  if (!rc) {
+    selftest_fill_kernel<T><<<blocks, 256, 0, st>>>(nr, x);
+    rc = fft_forward(p, st, x, hat);
+    if (!rc) rc = fft_inverse(p, st, hat, y);
+    if (!rc) selftest_check_kernel<T><<<blocks, 256, 0, st>>>(nr, y, double(M), err);
+  }
+  if (!rc && p->fwd2d && p->inv2d) {
+    hipfftResult r1 = hipfftSetStream(p->fwd2d, st), r2 = hipfftSetStream(p->inv2d, st);
+    if (r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS) {
+      if constexpr (sizeof(T) == 4) {
+        r1 = hipfftExecR2C(p->fwd2d, (hipfftReal*)x, (hipfftComplex*)hat);
+        r2 = hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)y);
+      } else {
+        r1 = hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)x, (hipfftDoubleComplex*)hat);
+        r2 = hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)y);
+      }
+    }
+    if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) {
+      set_error("hipFFT failed in the plan self-test");
+      rc = MIPME_EFFT;
+    } else {
+      selftest_check_kernel<T><<<blocks, 256, 0, st>>>(nr, y, double(p->ny) * p->nz, err + 1);
+    }
+  }
+  if (!rc && hipMemcpy(host_err, err, 2 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("could not read back the FFT plan self-test");
+    (void)hipGetLastError();
+    rc = MIPME_EHIP;
+  }
+  (void)hipFree(x);
+  (void)hipFree(y);
+  (void)hipFree(hat);
+  (void)hipFree(err);
+  if (rc) return rc;
+  const double tol = sizeof(T) == 4 ? 1e-4 : 1e-10;
+  if (!(host_err[0] < tol) || !(host_err[1] < tol)) {
+    set_error("hipFFT returns wrong results for the %d x %d x %d (x%d) %s plan: irfftn(rfftn(x)) differs from x by %.3g (3-D) / "
+              "%.3g (2-D planes).  Known cause: another hipFFT user in the process (e.g. torch.fft) ran transforms whose "
+              "kernels this plan now shares; create the calculators / run one evaluation before such calls, or set "
+              "MIPME_FFT_SELFTEST=0 to skip this check",
+              p->nx, p->ny, p->nz, p->batch, sizeof(T) == 4 ? "fp32" : "fp64", host_err[0], host_err[1]);
+    return MIPME_EFFT;
+  }
+  return MIPME_OK;
+}
+
+static int plan_selftest(mipme_fft_plan* p) {
+  const char* e = getenv("MIPME_FFT_SELFTEST");
+  if (e && e[0] == '0') return MIPME_OK;
+  return p->dtype == MIPME_F32 ? plan_selftest_t<float>(p) : plan_selftest_t<double>(p);
 }
 
 int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {
@@ -576,6 +769,16 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     if (p->inv2d) hipfftDestroy(p->inv2d);
     delete p;
     return MIPME_EHIP;
+  }
+  const int st_rc = plan_selftest(p);
+  if (st_rc) {
+    (void)hipFree(p->brick_count);
+    hipfftDestroy(p->fwd);
+    hipfftDestroy(p->inv);
+    if (p->fwd2d) hipfftDestroy(p->fwd2d);
+    if (p->inv2d) hipfftDestroy(p->inv2d);
+    delete p;
+    return st_rc;
   }
   *out = p;
   return MIPME_OK;
@@ -656,13 +859,18 @@ int64_t cellgrad_scratch_doubles() { return int64_t(kFinalizeBlocks) * kFinalize
 template <typename T>
 int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int64_t n_atoms, void* partials,
                            const void* pos, const void* grad_pos, const void* gout, const void* phi_atoms,
-                           const void* rho_dc, const void* psi_dc, const void* energy_scale, void* grad_cell) {
-  double* scratch = (double*)partials + 12 * cellgrad_blocks(m);
-  cellgrad_finalize_kernel<T><<<kFinalizeBlocks, 256, 0, st>>>(*m, bg, n_atoms, int(cellgrad_blocks(m)),
+                           const void* rho_dc, const void* psi_dc, const void* energy_scale, void* grad_cell,
+                           int64_t kgrid_blocks, const void* field, const void* q) {
+  // kgrid_blocks: number of 12-value k-grid partial sums in `partials` (0: as written by apply_filter_cellgrad_impl)
+  const int64_t nb = kgrid_blocks > 0 ? kgrid_blocks : cellgrad_blocks(m);
+  MIPME_REQUIRE(grad_pos || (field && q && energy_scale), "cell gradient needs grad_positions or the mesh field + charges");
+  MIPME_REQUIRE(m->n_channels == 1 || grad_pos, "the mesh field is single-channel");
+  double* scratch = (double*)partials + 12 * nb;
+  cellgrad_finalize_kernel<T><<<kFinalizeBlocks, 256, 0, st>>>(*m, bg, n_atoms, int(nb),
                                                  (const double*)partials, scratch,
                                                  (const T*)pos, (const T*)grad_pos, (const T*)gout,
                                                  (const T*)phi_atoms, (const T*)rho_dc, (const T*)psi_dc,
-                                                 (const T*)energy_scale, (T*)grad_cell);
+                                                 (const T*)energy_scale, (T*)grad_cell, (const T*)field, (const T*)q);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -677,9 +885,9 @@ template int apply_filter_cellgrad_impl<double>(hipStream_t, const mipme_mesh_t*
                                                 const void*, const void*, const void*, void*, void*, void*);
 template int cellgrad_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
                                            const void*, const void*, const void*, const void*, const void*, const void*,
-                                           void*);
+                                           void*, int64_t, const void*, const void*);
 template int cellgrad_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, int64_t, void*, const void*,
                                             const void*, const void*, const void*, const void*, const void*, const void*,
-                                            void*);
+                                            void*, int64_t, const void*, const void*);
 
 }  // namespace mipme

@@ -401,9 +401,15 @@ class _PMEFunction(torch.autograd.Function):
                 rho_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 phi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 # rfftn(rho) itself is only needed by the cell gradient; without it the convolution runs fused (see mipme.h)
-                rho_hat = None
-                if need_cell or not plan.xfused or not XFUSED:
+                rho_hat = cell_partials = None
+                if not plan.xfused or not XFUSED:
                     rho_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
+                elif need_cell:
+                    # speculative, like the force sums: the k-grid sums of the cell gradient for the energy mode, formed by the
+                    # x stage of the fused convolution while rfftn(rho) is in LDS (the backward then needs neither rho^ nor
+                    # the 3-D plans; a general upstream gradient recomputes rho^ from the saved charge mesh)
+                    cell_partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
+                                                device=device)
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
@@ -448,7 +454,7 @@ class _PMEFunction(torch.autograd.Function):
                     G.data_ptr(), rho_mesh.data_ptr(), _lib.ptr(rho_hat), hat_work.data_ptr(),
                     phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
                     join.cuda_event if overlap else None, 1 if (overlap or job is not None) else 0, _lib.ptr(field),
-                    _lib.ptr(records_out), C.byref(job) if job is not None else None,
+                    _lib.ptr(records_out), C.byref(job) if job is not None else None, _lib.ptr(cell_partials),
                 )
                 if records_out is not None:
                     fused["records_ready"] = True
@@ -461,12 +467,14 @@ class _PMEFunction(torch.autograd.Function):
                         pos.data_ptr(), q.data_ptr(), moments.data_ptr(), out.data_ptr(),
                     )
                 saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
-                             bins=bins)
+                             bins=bins, rho_mesh=rho_mesh if cell_partials is not None else None,
+                             cell_partials=cell_partials)
                 if not overlap and job is None:
                     run_rspace(1)
             else:
                 run_rspace(0)
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")), out)
+        ctx.rho_mesh, ctx.cell_partials = saved.get("rho_mesh"), saved.get("cell_partials")
         ctx.field = field
         ctx.same_positions = src_positions is positions
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
@@ -510,8 +518,17 @@ class _PMEFunction(torch.autograd.Function):
                 sr_scale = tag[3]  # enough for the pair part
                 if ctx.slab_axis is None:
                     gscale = tag[3]
-            # with a cell gradient the mesh forces are needed as a tensor by its finalisation: take them from the gather
-            field = ctx.field if (gscale is not None and not need_cell) else None
+            # the mesh force field of the forward gather serves the forces AND (through cellgrad_finalize) the cell gradient
+            field = ctx.field if gscale is not None else None
+            cell_partials = ctx.cell_partials
+            if need_cell and rho_hat is None and gscale is None and geom is not None:
+                # general upstream gradient after a forward that kept the charge mesh instead of rfftn(rho): transform it now
+                # (with the calculator's own plan: torch.fft shares hipFFT state with it and broke later plans when tried)
+                md0 = geom.desc(Cn)
+                rho_hat = torch.empty((Cn, geom.n_half), device=device,
+                                      dtype=torch.complex64 if dtype == torch.float32 else torch.complex128)
+                _call("fft_r2c", lib.mipme_fft_r2c, _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store).handle, st, dt,
+                      C.byref(md0), ctx.rho_mesh.data_ptr(), rho_hat.data_ptr())
             energy_q = need_q and gscale is not None and not ctx.full_list
             if need_dist:
                 grad_dist = torch.empty((P,), dtype=dtype, device=device)
@@ -535,30 +552,37 @@ class _PMEFunction(torch.autograd.Function):
                     run_grad_dist(False)
                     join.record()
             if do_kspace and gscale is not None:
-                kb_pos = (need_pos and field is None) or need_cell
                 kb_q = need_q and not energy_q
-                if kb_pos or kb_q:
+                # with the field at hand the C call only finalises the cell gradient (no gradient gather)
+                from_field = field is not None and not kb_q
+                kb_pos = (need_pos or need_cell) and not from_field
+                if kb_pos or kb_q or need_cell:
                     md = geom.desc(Cn)
                     plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
                     if kb_pos:
                         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
                     if kb_q:
                         grad_q = torch.empty((N, Cn), dtype=dtype, device=device)
-                    partials = None
-                    if need_cell:  # energy mode: the k-grid sums come from the saved rho^ alone (no second spread / FFTs)
+                    partials, kgrid_ready = None, 0
+                    if need_cell:  # energy mode: the k-grid sums come from rho^ alone (no second spread / FFTs) ...
                         grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
-                        partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
-                                               device=device)
+                        if cell_partials is not None:  # ... and the forward's fused convolution has already formed them
+                            partials, kgrid_ready = cell_partials, plan.kgrid_blocks
+                        else:
+                            partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
+                                                   device=device)
                     _call(
                         "kspace_backward", lib.mipme_kspace_backward,
                         plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
                         g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat) if need_cell else None,
                         _lib.ptr(rho_dc), _lib.ptr(phi_atoms) if need_cell else None, None, None, None,
                         None, None, _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q), _lib.ptr(grad_cell),
-                        _lib.ptr(bins), gscale.data_ptr(),
+                        _lib.ptr(bins), gscale.data_ptr(), _lib.ptr(field) if from_field else None, kgrid_ready,
                     )
                     if not need_pos:
                         grad_pos = None
+                    if need_cell and not from_field:
+                        field = None  # the gradient gather above has produced the mesh forces
             elif do_kspace:
                 md = geom.desc(Cn)
                 plan = _lib.get_plan(device, dtype, geom.ns, Cn, geom.plan_store)
@@ -584,7 +608,7 @@ class _PMEFunction(torch.autograd.Function):
                     g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
                     _lib.ptr(phi_atoms), psi_mesh.data_ptr(), _lib.ptr(psi_hat), hat_work.data_ptr(),
                     chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
-                    _lib.ptr(grad_cell), _lib.ptr(bins), None,
+                    _lib.ptr(grad_cell), _lib.ptr(bins), None, None, 0,
                 )
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
