@@ -29,14 +29,19 @@ def test_random_configuration(seed):
     h = float(rng.uniform(0.4, 1.1))
     N = int(rng.integers(1, 260))
     pos = rng.uniform(-0.3, 1.3, (N, 3)) @ cell
-    q = rng.normal(size=(N, 1))
+    n_ch = int(rng.choice([1, 1, 1, 2, 3]))  # several charge channels take the unfused kernels
+    q = rng.normal(size=(N, n_ch))
     full = bool(rng.uniform() < 0.4)
     cutoff = float(rng.uniform(2.0, 4.5))
-    pairs, S, dist = tpa.neighbor_list(pos, cell, cutoff, full_list=full)
+    slab = bool(rng.uniform() < 0.15)  # 2-D periodic: one non-periodic axis (Coulomb only, potentials/coulomb.py:6-40)
+    periodic = [True, True, True]
+    if slab:
+        periodic[int(rng.integers(0, 3))] = False
+    pairs, S, dist = tpa.neighbor_list(pos, cell, cutoff, full_list=full, periodic=tuple(periodic))
     if len(pairs) and dist.min() < 0.5:  # keep 1/r^6 within what fp32 can compare
         keep = dist > 0.5
         pairs, S, dist = pairs[keep], S[keep], dist[keep]
-    p = int(rng.integers(1, 7))
+    p = 1 if slab else int(rng.integers(1, 7))
     sm = float(rng.uniform(0.8, 1.5))
     excl = float(rng.uniform(1.0, 2.0)) if rng.uniform() < 0.25 else None
     if p == 1 and rng.uniform() < 0.5:
@@ -50,9 +55,10 @@ def test_random_configuration(seed):
     deferred = bool(rng.uniform() < 0.5)
     need_q = not energy_mode or bool(rng.uniform() < 0.5)
     gE = -1.3
-    g = gE * q if energy_mode else rng.normal(size=(N, 1))
+    g = gE * q if energy_mode else rng.normal(size=(N, n_ch))
 
-    Vo, cache = O.forward(spec, scheme, order, h, q, cell, pos, pairs, dist, full_list=full, pair_mask=mask, return_cache=True)
+    Vo, cache = O.forward(spec, scheme, order, h, q, cell, pos, pairs, dist, full_list=full, pair_mask=mask,
+                          periodic=tuple(periodic) if slab else None, return_cache=True)
     gr = O.backward(cache, g)
     gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
 
@@ -62,7 +68,8 @@ def test_random_configuration(seed):
     tq, tc, tp = t(q, need_q), t(cell, True), t(pos, True)
     ti = torch.tensor(pairs.reshape(-1, 2), device=DEV)
     d = tpa.pair_distances(tp, ti, tc, t(S.reshape(-1, 3)), deferred=deferred)
-    V = calc(tq, tc, tp, ti, d, pair_mask=None if mask is None else torch.tensor(mask, device=DEV))
+    V = calc(tq, tc, tp, ti, d, pair_mask=None if mask is None else torch.tensor(mask, device=DEV),
+             periodic=torch.tensor(periodic, device=DEV) if slab else None)
     if energy_mode:
         (gE * tpa.weighted_sum(V, tq)).backward()
     else:
@@ -71,7 +78,7 @@ def test_random_configuration(seed):
     # fp32: 1/r^p sums of either sign cancel; compare against the magnitude of the terms rather than of the sum
     tolV, tolG = (1e-10, 1e-9) if f64 else (3e-4, 2e-3)
     info = f"seed {seed}: {scheme}{order} p={p} excl={excl} N={N} P={len(pairs)} full={full} mask={mask is not None} " \
-           f"energy={energy_mode} deferred={deferred} {dtype}"
+           f"energy={energy_mode} deferred={deferred} channels={n_ch} slab={slab} {dtype}"
     assert rell2(V.detach().cpu().numpy(), Vo) < tolV, info
     assert rell2(tp.grad.cpu().numpy(), gr["positions"] + gpos_d) < tolG, info
     # (the 9 cell-gradient components are sums over all pairs / mesh points with heavy cancellation: looser in fp32)
