@@ -327,6 +327,9 @@ struct mipme_fft_plan {
   hipfftHandle fwd = 0, inv = 0;
   // (y, z) plane transforms for the fused convolution (convolve_xfused): the x direction is done by xconv_kernel
   hipfftHandle fwd2d = 0, inv2d = 0;
+  // own (y, z) plane kernels (yz_planes_kernel) instead of the two hipFFT plans above: power-of-two ny, nz whose half-complex
+  // plane fits 64 KB of LDS
+  bool own_yz = false;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
@@ -384,6 +387,228 @@ template <typename T>
 __device__ __forceinline__ Cplx<T> cadd(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a.re + b.re, a.im + b.im}; }
 template <typename T>
 __device__ __forceinline__ Cplx<T> csub(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a.re - b.re, a.im - b.im}; }
+
+// ---- (y, z) plane transforms in LDS ----------------------------------------------------------------------------------
+// One workgroup per (channel, x) plane.  The real z rows are transformed as complex rows of half the length (even / odd
+// samples as real / imaginary part) plus the usual split step, so the plane lives in LDS as ny x (nz/2 + 1) complex values,
+// in place.  Bit reversal is folded into the loads / stores: every 1-D transform is either decimation in time (bit-reversed
+// in, natural out) or decimation in frequency (natural in, bit-reversed out), radix 2, one barrier per stage.  Same
+// conventions as the hipFFT plans they replace: un-normalised in both directions (kspace_filter.py:169-187), layouts
+// (C, nx, ny, nz) real and (C, nx, ny, nz/2 + 1) complex.  Besides being one launch of our own per direction, they keep
+// hipFFT out of the hot path (see the plan self-test above for why that matters).
+static bool own_yz_dims_ok(int dtype, int ny, int nz) {
+  const bool pow2 = ny >= 2 && nz >= 4 && (ny & (ny - 1)) == 0 && (nz & (nz - 1)) == 0;
+  const size_t cs = dtype == MIPME_F32 ? 8 : 16;
+  return pow2 && cs * (size_t(ny) * (nz / 2 + 1) + size_t(ny > nz / 2 ? ny : nz / 2) / 2 + size_t(nz / 2 + 1)) <= 64 * 1024;
+}
+
+template <typename T>
+__device__ __forceinline__ Cplx<T> cconj(Cplx<T> a) { return Cplx<T>{a.re, -a.im}; }
+
+// Transforms of `nbatch` sequences of length L = 2^logL in LDS: element i of sequence b at data[b * bstride + i * estride].
+// DIT: bit-reversed in -> natural out;  DIF: natural in -> bit-reversed out.  tw[j] = exp(-2 pi i j / Ltab), j < Ltab / 2.
+// Two radix-2 stages per pass (the thread that owns the four coupled points does both: half the barriers and LDS round
+// trips of the textbook schedule, same data order), plus one single stage when logL is odd.
+template <typename T, bool INVERSE>
+__device__ __forceinline__ Cplx<T> tw_at(const Cplx<T>* tw, int idx) {
+  Cplx<T> w = tw[idx];
+  if constexpr (INVERSE) w.im = -w.im;
+  return w;
+}
+
+template <typename T, bool DIT, bool INVERSE>
+__device__ __forceinline__ void lds_fft_single(Cplx<T>* data, int logL, int s, int nbatch, int bstride, int estride,
+                                               const Cplx<T>* tw, int Ltab) {
+  const int L = 1 << logL, half_total = nbatch << (logL - 1);
+  const int hm = 1 << (s - 1), f = Ltab >> s;
+  for (int t = threadIdx.x; t < half_total; t += blockDim.x) {
+    const int b = t >> (logL - 1), r = t & ((L >> 1) - 1);
+    const int j = r & (hm - 1), i = ((r >> (s - 1)) << s) + j;
+    Cplx<T>* p = data + b * bstride + i * estride;
+    const Cplx<T> w = tw_at<T, INVERSE>(tw, j * f);
+    const Cplx<T> u = p[0], v = p[hm * estride];
+    if constexpr (DIT) {
+      const Cplx<T> tv = cmul(v, w);
+      p[0] = cadd(u, tv);
+      p[hm * estride] = csub(u, tv);
+    } else {
+      p[0] = cadd(u, v);
+      p[hm * estride] = cmul(csub(u, v), w);
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T, bool DIT, bool INVERSE>
+__device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbatch, int bstride, int estride,
+                                               const Cplx<T>* tw, int Ltab) {
+  const int L = 1 << logL;
+  if (logL == 1) {
+    lds_fft_single<T, DIT, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+    return;
+  }
+  const int quarter_total = nbatch << (logL - 2);
+  if constexpr (DIT) {
+    int s = 1;  // next stage has sub-transform length 2^s
+    if (logL & 1) {
+      lds_fft_single<T, true, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+      s = 2;
+    }
+    for (; s + 1 <= logL; s += 2) {
+      const int h = 1 << (s - 1);          // stages of length 2h then 4h
+      const int f2 = Ltab >> s, f4 = Ltab >> (s + 1);
+      for (int t = threadIdx.x; t < quarter_total; t += blockDim.x) {
+        const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+        const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 1)) + j;
+        Cplx<T>* p = data + b * bstride + i * estride;
+        const int st = h * estride;
+        const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+        const Cplx<T> w1 = tw_at<T, INVERSE>(tw, j * f2);
+        const Cplx<T> b1 = cmul(x1, w1), b3 = cmul(x3, w1);
+        const Cplx<T> a0 = cadd(x0, b1), a1 = csub(x0, b1), a2 = cadd(x2, b3), a3 = csub(x2, b3);
+        const Cplx<T> c2 = cmul(a2, tw_at<T, INVERSE>(tw, j * f4)), c3 = cmul(a3, tw_at<T, INVERSE>(tw, (j + h) * f4));
+        p[0] = cadd(a0, c2);
+        p[2 * st] = csub(a0, c2);
+        p[st] = cadd(a1, c3);
+        p[3 * st] = csub(a1, c3);
+      }
+      __syncthreads();
+    }
+  } else {
+    int s = logL;  // current sub-transform length 2^s
+    for (; s >= 2; s -= 2) {
+      const int q = 1 << (s - 2);          // stages of length 4q then 2q
+      const int f4 = Ltab >> s, f2 = Ltab >> (s - 1);
+      for (int t = threadIdx.x; t < quarter_total; t += blockDim.x) {
+        const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+        const int j = r & (q - 1), i = ((r >> (s - 2)) << s) + j;
+        Cplx<T>* p = data + b * bstride + i * estride;
+        const int st = q * estride;
+        const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+        const Cplx<T> u0 = cadd(x0, x2), u2 = cmul(csub(x0, x2), tw_at<T, INVERSE>(tw, j * f4));
+        const Cplx<T> u1 = cadd(x1, x3), u3 = cmul(csub(x1, x3), tw_at<T, INVERSE>(tw, (j + q) * f4));
+        const Cplx<T> w2 = tw_at<T, INVERSE>(tw, j * f2);
+        p[0] = cadd(u0, u1);
+        p[st] = cmul(csub(u0, u1), w2);
+        p[2 * st] = cadd(u2, u3);
+        p[3 * st] = cmul(csub(u2, u3), w2);
+      }
+      __syncthreads();
+    }
+    if (s == 1) lds_fft_single<T, false, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+  }
+}
+
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(512) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
+                                                       Cplx<T>* __restrict__ hat, T* __restrict__ real_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_yz[];
+  const int Lz = nz >> 1, RZ = Lz + 1;
+  Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yz);  // [ny][RZ]
+  Cplx<T>* tw = tile + size_t(ny) * RZ;                  // exp(-2 pi i j / Ltab), j < Ltab / 2
+  const int Ltab = ny > Lz ? ny : Lz;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  Cplx<T>* twr = tw + (Ltab >> 1);                       // exp(-2 pi i k / nz), k <= nz / 2 (split / merge steps)
+  for (int j = tid; j < (Ltab >> 1); j += nthr) unit_root(j, Ltab, tw[j].re, tw[j].im);
+  for (int k = tid; k <= Lz; k += nthr) unit_root(k, nz, twr[k].re, twr[k].im);
+  const int64_t plane = blockIdx.x;  // (channel, x)
+  if constexpr (!INVERSE) {
+    // rows: c_j = a_2j + i a_2j+1, stored bit-reversed for the DIT z transform
+    const T* src = real_in + plane * int64_t(ny) * nz;
+    for (int idx = tid; idx < ny * Lz; idx += nthr) {
+      const int y = idx / Lz, j = idx - y * Lz;
+      const int jr = loglz ? int(__brev(unsigned(j)) >> (32 - loglz)) : 0;
+      tile[y * RZ + jr] = reinterpret_cast<const Cplx<T>*>(src)[idx];  // (a_2j, a_2j+1): the plane as ny x Lz pairs
+    }
+    __syncthreads();
+    lds_fft_radix2<T, true, false>(tile, loglz, ny, RZ, 1, tw, Ltab);
+    // split step, pairs (k, Lz - k):  A_k = E_k + e^{-2 pi i k / nz} O_k,  E = (C_k + conj C_{Lz-k}) / 2,  O = -i (C_k - conj C_{Lz-k}) / 2
+    for (int idx = tid; idx < ny * (Lz / 2 + 1); idx += nthr) {
+      const int y = idx / (Lz / 2 + 1), k = idx - y * (Lz / 2 + 1);
+      Cplx<T>* row = tile + y * RZ;
+      const int k2 = Lz - k;
+      const Cplx<T> ck = row[k == Lz ? 0 : k], cm = row[k2 == Lz ? 0 : k2];
+      const Cplx<T> wk = twr[k], wm = twr[k2];
+      auto split = [](Cplx<T> a, Cplx<T> b, Cplx<T> w) {  // a = C_k, b = C_{Lz-k}
+        const Cplx<T> e{T(0.5) * (a.re + b.re), T(0.5) * (a.im - b.im)};
+        const Cplx<T> d{T(0.5) * (a.re - b.re), T(0.5) * (a.im + b.im)};  // (C_k - conj C_{Lz-k}) / 2
+        const Cplx<T> o{d.im, -d.re};                                      // -i d
+        return cadd(e, cmul(o, w));
+      };
+      const Cplx<T> ak = split(ck, cm, wk), am = split(cm, ck, wm);
+      row[k] = ak;
+      row[k2] = am;
+    }
+    __syncthreads();
+    // columns: DIF along y (natural in, bit-reversed out); the store undoes the bit reversal
+    lds_fft_radix2<T, false, false>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    Cplx<T>* dst = hat + plane * int64_t(ny) * RZ;
+    for (int idx = tid; idx < ny * RZ; idx += nthr) {
+      const int y = idx / RZ, k = idx - y * RZ;
+      const int yr = int(__brev(unsigned(y)) >> (32 - logny));
+      dst[int64_t(yr) * RZ + k] = tile[idx];
+    }
+  } else {
+    const Cplx<T>* src = hat + plane * int64_t(ny) * RZ;
+    for (int idx = tid; idx < ny * RZ; idx += nthr) {
+      const int y = idx / RZ, k = idx - y * RZ;
+      const int yr = int(__brev(unsigned(y)) >> (32 - logny));
+      tile[yr * RZ + k] = src[idx];
+    }
+    __syncthreads();
+    lds_fft_radix2<T, true, true>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    // merge step (un-normalised: twice the textbook one):  C_k = (A_k + conj A_{Lz-k}) + i e^{+2 pi i k / nz} (A_k - conj A_{Lz-k})
+    for (int idx = tid; idx < ny * (Lz / 2 + 1); idx += nthr) {
+      const int y = idx / (Lz / 2 + 1), k = idx - y * (Lz / 2 + 1);
+      Cplx<T>* row = tile + y * RZ;
+      const int k2 = Lz - k;
+      Cplx<T> ak = row[k], am = row[k2];
+      if (k == 0) {
+        // a complex-to-real transform ignores the imaginary parts of the k_z = 0 and Nyquist entries (they vanish for a
+        // Hermitian input; G on the Nyquist plane of a triclinic cell is not exactly symmetric, so they do not here)
+        ak.im = T(0);
+        am.im = T(0);
+      }
+      const Cplx<T> wk = twr[k], wm = twr[k2];
+      auto merge = [](Cplx<T> a, Cplx<T> b, Cplx<T> w) {  // a = A_k, b = A_{Lz-k}, w = e^{-2 pi i k / nz}
+        const Cplx<T> e{a.re + b.re, a.im - b.im};
+        const Cplx<T> d{a.re - b.re, a.im + b.im};      // A_k - conj A_{Lz-k}
+        const Cplx<T> dw = cmulc(d, w);                  // times e^{+2 pi i k / nz}
+        return Cplx<T>{e.re - dw.im, e.im + dw.re};      // e + i dw
+      };
+      const Cplx<T> ck = merge(ak, am, wk), cm = merge(am, ak, wm);
+      if (k < Lz) row[k] = ck;  // C has Lz entries: index Lz is the alias of 0
+      if (k2 < Lz && k2 != k) row[k2] = cm;
+    }
+    __syncthreads();
+    // rows: DIF along z (natural in, bit-reversed out), read back through the bit reversal
+    lds_fft_radix2<T, false, true>(tile, loglz, ny, RZ, 1, tw, Ltab);
+    T* dst = real_out + plane * int64_t(ny) * nz;
+    for (int idx = tid; idx < ny * Lz; idx += nthr) {
+      const int y = idx / Lz, j = idx - y * Lz;
+      const int jr = loglz ? int(__brev(unsigned(j)) >> (32 - loglz)) : 0;
+      reinterpret_cast<Cplx<T>*>(dst)[idx] = tile[y * RZ + jr];
+    }
+  }
+}
+
+template <typename T>
+static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* real_in, void* hat, void* real_out) {
+  int logny = 0, loglz = 0;
+  while ((1 << logny) < p->ny) ++logny;
+  while ((1 << loglz) < p->nz / 2) ++loglz;
+  const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
+  const size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
+  const unsigned grid = unsigned(p->nx) * unsigned(p->batch);
+  const int work = p->ny * (Lz + 1);
+  const int threads = work >= 2048 ? 512 : (work >= 512 ? 256 : 64);
+  if (inverse)
+    yz_planes_kernel<T, true><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out);
+  else
+    yz_planes_kernel<T, false><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
 
 // One block: the columns (ky, kz0 .. kz0 + KZ) of channel c, all nx points of each, in LDS as tile[x][z] (KZ = 2^kzs
 // columns, padded ones compute on zeros).  Two radix-2 stages are done per pass by the thread that owns the four points
@@ -546,7 +771,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   }
 }
 
-bool fft_plan_xfused(const mipme_fft_plan* p) { return p->fwd2d != 0 && p->inv2d != 0; }
+bool fft_plan_xfused(const mipme_fft_plan* p) { return p->own_yz || (p->fwd2d != 0 && p->inv2d != 0); }
 int fft_plan_batch(const mipme_fft_plan* p) { return p->batch; }
 
 // mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
@@ -564,8 +789,10 @@ int64_t xconv_blocks(const mipme_fft_plan* p) {
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
                     void* cell_partials) {
-  MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
-  MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
+  if (!p->own_yz) {
+    MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
+    MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
+  }
   const int nzh = p->nz / 2 + 1;
   int log2nx = 0;
   while ((1 << log2nx) < p->nx) ++log2nx;
@@ -588,7 +815,12 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     kg = make_kgeom(cell_mesh);
   }
   if (p->dtype == MIPME_F32) {
-    MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
+    if (p->own_yz) {
+      int rc = yz_planes<float>(p, st, false, mesh_in, hat, nullptr);
+      if (rc) return rc;
+    } else {
+      MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
+    }
     if (cell_partials)
       xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
                                                             (const float*)G, G_stride, (float*)dc, kg, kp,
@@ -597,9 +829,19 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
       xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
                                                              (const float*)G, G_stride, (float*)dc, kg, kp, nullptr);
     MIPME_LAUNCH_CHECK();
-    MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
+    if (p->own_yz) {
+      int rc = yz_planes<float>(p, st, true, nullptr, hat, mesh_out);
+      if (rc) return rc;
+    } else {
+      MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
+    }
   } else {
-    MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
+    if (p->own_yz) {
+      int rc = yz_planes<double>(p, st, false, mesh_in, hat, nullptr);
+      if (rc) return rc;
+    } else {
+      MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
+    }
     if (cell_partials)
       xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
                                                              (const double*)G, G_stride, (double*)dc, kg, kp,
@@ -608,7 +850,12 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
       xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
                                                               (const double*)G, G_stride, (double*)dc, kg, kp, nullptr);
     MIPME_LAUNCH_CHECK();
-    MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
+    if (p->own_yz) {
+      int rc = yz_planes<double>(p, st, true, nullptr, hat, mesh_out);
+      if (rc) return rc;
+    } else {
+      MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
+    }
   }
   return MIPME_OK;
 }
@@ -666,11 +913,16 @@ static int plan_selftest_t(mipme_fft_plan* p) {
   }
   const unsigned blocks = unsigned((nr + 255) / 256);
   hipStream_t st = nullptr;
-  if (!rc) {
-    selftest_fill_kernel<T><<<blocks, 256, 0, st>>>(nr, x);
+  if (!rc) selftest_fill_kernel<T><<<blocks, 256, 0, st>>>(nr, x);
+  if (!rc && p->fwd && p->inv) {
     rc = fft_forward(p, st, x, hat);
     if (!rc) rc = fft_inverse(p, st, hat, y);
     if (!rc) selftest_check_kernel<T><<<blocks, 256, 0, st>>>(nr, y, double(M), err);
+  }
+  if (!rc && p->own_yz) {  // our own (y, z) plane kernels: same identity
+    rc = yz_planes<T>(p, st, false, x, hat, nullptr);
+    if (!rc) rc = yz_planes<T>(p, st, true, nullptr, hat, y);
+    if (!rc) selftest_check_kernel<T><<<blocks, 256, 0, st>>>(nr, y, double(p->ny) * p->nz, err + 1);
   }
   if (!rc && p->fwd2d && p->inv2d) {
     hipfftResult r1 = hipfftSetStream(p->fwd2d, st), r2 = hipfftSetStream(p->inv2d, st);
@@ -718,6 +970,39 @@ static int plan_selftest(mipme_fft_plan* p) {
   return p->dtype == MIPME_F32 ? plan_selftest_t<float>(p) : plan_selftest_t<double>(p);
 }
 
+static hipfftResult create_3d_plans(mipme_fft_plan* p) {
+  int n[3] = {p->nx, p->ny, p->nz};
+  int rembed[3] = {p->nx, p->ny, p->nz};
+  int cembed[3] = {p->nx, p->ny, p->nz / 2 + 1};
+  const int rdist = p->nx * p->ny * p->nz, cdist = p->nx * p->ny * (p->nz / 2 + 1);
+  hipfftResult r = hipfftPlanMany(&p->fwd, 3, n, rembed, 1, rdist, cembed, 1, cdist,
+                                  p->dtype == MIPME_F32 ? HIPFFT_R2C : HIPFFT_D2Z, p->batch);
+  if (r == HIPFFT_SUCCESS)
+    r = hipfftPlanMany(&p->inv, 3, n, cembed, 1, cdist, rembed, 1, rdist, p->dtype == MIPME_F32 ? HIPFFT_C2R : HIPFFT_Z2D,
+                       p->batch);
+  return r;
+}
+
+// 3-D plans on first use (plans with own_yz): created and self-tested here -- not possible during stream capture
+static int ensure_3d_plans(mipme_fft_plan* p) {
+  if (p->fwd && p->inv) return MIPME_OK;
+  const hipfftResult r = create_3d_plans(p);
+  if (r != HIPFFT_SUCCESS) {
+    set_error("hipfftPlanMany(%d,%d,%d x%d) failed: %s", p->nx, p->ny, p->nz, p->batch, fft_err(r));
+    if (p->fwd) hipfftDestroy(p->fwd);
+    if (p->inv) hipfftDestroy(p->inv);
+    p->fwd = p->inv = 0;
+    return MIPME_EFFT;
+  }
+  const int rc = plan_selftest(p);
+  if (rc) {
+    hipfftDestroy(p->fwd);
+    hipfftDestroy(p->inv);
+    p->fwd = p->inv = 0;
+  }
+  return rc;
+}
+
 int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {
   MIPME_REQUIRE(out != nullptr, "plan output pointer is NULL");
   MIPME_REQUIRE(nx > 0 && ny > 0 && nz > 0 && batch > 0, "invalid FFT dimensions %d %d %d x%d", nx, ny, nz, batch);
@@ -729,16 +1014,15 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
   p->ny = ny;
   p->nz = nz;
   p->batch = batch;
-  int n[3] = {nx, ny, nz};
-  int rembed[3] = {nx, ny, nz};
-  int cembed[3] = {nx, ny, nz / 2 + 1};
-  const int rdist = nx * ny * nz, cdist = nx * ny * (nz / 2 + 1);
-  hipfftResult r = hipfftPlanMany(&p->fwd, 3, n, rembed, 1, rdist, cembed, 1, cdist,
-                                  dtype == MIPME_F32 ? HIPFFT_R2C : HIPFFT_D2Z, batch);
-  if (r == HIPFFT_SUCCESS)
-    r = hipfftPlanMany(&p->inv, 3, n, cembed, 1, cdist, rembed, 1, rdist, dtype == MIPME_F32 ? HIPFFT_C2R : HIPFFT_Z2D,
-                       batch);
-  if (r == HIPFFT_SUCCESS && xfused_dims_ok(nx)) {
+  {
+    const char* e = getenv("MIPME_OWN_YZ");
+    p->own_yz = xfused_dims_ok(nx) && own_yz_dims_ok(dtype, ny, nz) && !(e && e[0] == '0');
+  }
+  // With our own plane kernels the fused convolution -- the hot path -- needs no hipFFT at all: the 3-D hipFFT plans (general
+  // backward with a cell gradient, mipme_convolve, mipme_fft_r2c) are then created on first use (ensure_3d_plans).
+  hipfftResult r = HIPFFT_SUCCESS;
+  if (!p->own_yz) r = create_3d_plans(p);
+  if (r == HIPFFT_SUCCESS && xfused_dims_ok(nx) && !p->own_yz) {
     int n2[2] = {ny, nz};
     int rembed2[2] = {ny, nz};
     int cembed2[2] = {ny, nz / 2 + 1};
@@ -763,8 +1047,8 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     set_error("could not allocate the brick counters of the plan (plans cannot be created during stream capture)");
     (void)hipGetLastError();
     if (p->brick_count) (void)hipFree(p->brick_count);
-    hipfftDestroy(p->fwd);
-    hipfftDestroy(p->inv);
+    if (p->fwd) hipfftDestroy(p->fwd);
+    if (p->inv) hipfftDestroy(p->inv);
     if (p->fwd2d) hipfftDestroy(p->fwd2d);
     if (p->inv2d) hipfftDestroy(p->inv2d);
     delete p;
@@ -773,8 +1057,8 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
   const int st_rc = plan_selftest(p);
   if (st_rc) {
     (void)hipFree(p->brick_count);
-    hipfftDestroy(p->fwd);
-    hipfftDestroy(p->inv);
+    if (p->fwd) hipfftDestroy(p->fwd);
+    if (p->inv) hipfftDestroy(p->inv);
     if (p->fwd2d) hipfftDestroy(p->fwd2d);
     if (p->inv2d) hipfftDestroy(p->inv2d);
     delete p;
@@ -800,6 +1084,8 @@ int fft_plan_destroy(mipme_fft_plan* p) {
 }
 
 int fft_forward(mipme_fft_plan* p, hipStream_t st, const void* in, void* out) {
+  int rc = ensure_3d_plans(p);
+  if (rc) return rc;
   MIPME_CHECK_FFT(hipfftSetStream(p->fwd, st));
   if (p->dtype == MIPME_F32)
     MIPME_CHECK_FFT(hipfftExecR2C(p->fwd, (hipfftReal*)in, (hipfftComplex*)out));
@@ -809,6 +1095,8 @@ int fft_forward(mipme_fft_plan* p, hipStream_t st, const void* in, void* out) {
 }
 
 int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out) {
+  int rc = ensure_3d_plans(p);
+  if (rc) return rc;
   MIPME_CHECK_FFT(hipfftSetStream(p->inv, st));
   if (p->dtype == MIPME_F32)
     MIPME_CHECK_FFT(hipfftExecC2R(p->inv, (hipfftComplex*)in, (hipfftReal*)out));
