@@ -396,10 +396,13 @@ __device__ __forceinline__ Cplx<T> csub(Cplx<T> a, Cplx<T> b) { return Cplx<T>{a
 // conventions as the hipFFT plans they replace: un-normalised in both directions (kspace_filter.py:169-187), layouts
 // (C, nx, ny, nz) real and (C, nx, ny, nz/2 + 1) complex.  Besides being one launch of our own per direction, they keep
 // hipFFT out of the hot path (see the plan self-test above for why that matters).
+// a single workgroup may use (almost) all 160 KB of a CU's LDS; above 64 KB the kernel needs its dynamic-LDS limit raised
+static constexpr size_t kYzMaxLds = 152 * 1024;
+
 static bool own_yz_dims_ok(int dtype, int ny, int nz) {
   const bool pow2 = ny >= 2 && nz >= 4 && (ny & (ny - 1)) == 0 && (nz & (nz - 1)) == 0;
   const size_t cs = dtype == MIPME_F32 ? 8 : 16;
-  return pow2 && cs * (size_t(ny) * (nz / 2 + 1) + size_t(ny > nz / 2 ? ny : nz / 2) / 2 + size_t(nz / 2 + 1)) <= 64 * 1024;
+  return pow2 && cs * (size_t(ny) * (nz / 2 + 1) + size_t(ny > nz / 2 ? ny : nz / 2) / 2 + size_t(nz / 2 + 1)) <= kYzMaxLds;
 }
 
 template <typename T>
@@ -604,6 +607,14 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
   // latency-bound, one workgroup per plane: the widest workgroup wins (1024 threads 24.0 us per convolution at 64^3 fp32,
   // 512 threads 25.6, 256 threads 30.9; the two hipFFT plans it replaces 25.3)
   const int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
+  if (lds > 64 * 1024) {  // once per instantiation: allow the large dynamic allocation
+    static bool raised[2] = {false, false};
+    if (!raised[inverse ? 1 : 0]) {
+      const void* fn = inverse ? (const void*)yz_planes_kernel<T, true> : (const void*)yz_planes_kernel<T, false>;
+      MIPME_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(kYzMaxLds)));
+      raised[inverse ? 1 : 0] = true;
+    }
+  }
   if (inverse)
     yz_planes_kernel<T, true><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out);
   else
