@@ -75,7 +75,9 @@ int mipme_version(void);
 
 /* ---- reciprocal-space convolution: KSpaceFilter.forward, lib/kspace_filter.py:122-197 -------- */
 
-/* hipFFT R2C + C2R plans for a (batch, nx, ny, nz) real mesh on the current device. */
+/* Transform plan for a (batch, nx, ny, nz) real mesh on the current device: own (y,z) plane kernels + x stage for the fused
+ * convolution, hipFFT R2C / C2R plans for everything else (3-D plans are created on first use when the own kernels cover the
+ * fused path).  Every hipFFT plan is self-tested when created (irfftn(rfftn(x)) == M x): MIPME_EFFT on failure. */
 int mipme_fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out);
 int mipme_fft_plan_destroy(mipme_fft_plan* plan);
 
@@ -119,7 +121,8 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * (records_ready = 1), written by the binning pass while the positions are in registers.
  * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time.
  * rho_hat == NULL (allowed when mipme_fft_plan_xfused(plan) != 0, i.e. nx is a power of two): rfftn(rho) is not kept and
- * the convolution runs as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT.
+ * the convolution runs as (y,z) plane transforms (own LDS kernels when a half-complex plane fits 152 KB of LDS, 2-D hipFFT
+ * plans otherwise) + one kernel doing x-FFT, * G and the inverse x-FFT.
  * sr_job (nullable; needs atom_bins, out_records, a single channel, job->records == out_records, job->out == out_lr and
  * accumulate_out = 1): the short-range pair sum of the same call -- mipme_sr_rows_fused in its potential + force-sum mode
  * (src = charges, no pair mask, no cell partials; the fields mean what the arguments of that function mean) -- run
@@ -164,7 +167,7 @@ int mipme_fft_r2c(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mes
  * (mipme_frames_table_build fills a HOST buffer of mipme_frames_table_bytes bytes; the caller copies it to the device);
  * every pointer in it must stay valid while the table is used.
  *   forward : binning -> spread co-scheduled with the fused distance + pair kernel (potentials, speculative force sums,
- *             distances) -> batched (y,z) hipFFT planes + x stage (plan: batch = n_frames; G: n_frames filter tables,
+ *             distances) -> batched (y,z) plane transforms + x stage (plan: batch = n_frames; G: n_frames filter tables,
  *             G_stride reals apart, 0 = shared) -> gather (+ mesh force field) -> energy[f] = sum_a q_a V_a
  *   backward: grad_positions[f] = grad_scale[f] q_a (c force_a + field_a)   (c = 1/2 for a full list)
  * Requirements (checked; MIPME_EINVAL otherwise): brick kernels support the mesh, <= 1024 bricks, potential 1/r or 1/r^6

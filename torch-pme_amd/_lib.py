@@ -266,7 +266,7 @@ def require_device(t, name: str):
 
 
 class FFTPlan:
-    """Owning wrapper of a ``mipme_fft_plan`` (hipFFT R2C + C2R)."""
+    """Owning wrapper of a ``mipme_fft_plan`` (own (y,z) plane kernels + x stage; hipFFT R2C / C2R for the general paths)."""
 
     def __init__(self, device, dtype, ns, batch):
         self.key = (torch.device(device).index, dtype, tuple(int(n) for n in ns), int(batch))
@@ -274,7 +274,7 @@ class FFTPlan:
         with torch.cuda.device(device):
             check(load().mipme_fft_plan_create(dtype_code(dtype), int(ns[0]), int(ns[1]), int(ns[2]), int(batch), C.byref(handle)))
         self.handle = handle
-        #: the plan can run the convolution as (y,z) hipFFT planes + one fused x kernel (power-of-two nx)
+        #: the plan can run the convolution as (y,z) plane transforms + one fused x kernel (power-of-two nx)
         self.xfused = bool(load().mipme_fft_plan_xfused(handle))
         #: number of k-grid partial sums the fused convolution writes when asked for the cell sums (out_cell_partials)
         self.kgrid_blocks = int(load().mipme_fft_plan_kgrid_blocks(handle))

@@ -2,7 +2,7 @@
 
 At 32k atoms a step is a dozen short kernels behind ~0.3 ms of Python / autograd / launch overhead when run eagerly.  For a fixed topology (same neighbour list, cell, charges; positions change) the whole
 ``pair_distances -> calculator.forward -> (q*V).sum().backward()`` chain is captured once into a HIP graph
-(``torch.cuda.CUDAGraph``: PyTorch is the capture front end, every captured node is a libmipme / hipFFT kernel
+(``torch.cuda.CUDAGraph``: PyTorch is the capture front end, every captured node is a libmipme kernel
 or a tiny reduction) and replayed per step.  This is the MD-loop form of the hot path; the calculators themselves
 stay eager and reference-compatible.
 """

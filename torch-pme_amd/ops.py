@@ -118,8 +118,8 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
 
-# Reciprocal-space convolution as (y,z) hipFFT planes + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two nx,
-# whenever rfftn(rho) itself is not needed, i.e. no cell gradient); "0" keeps the 3-D hipFFT plans + filter kernel.
+# Reciprocal-space convolution as (y,z) plane transforms + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two
+# nx); "0" keeps the 3-D hipFFT plans + filter kernel.
 XFUSED = os.environ.get("MIPME_XFUSED", "1") != "0"
 
 
