@@ -136,7 +136,9 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   // rec[o] = (position of o, src[o]) with src = charges except in the transposed potential pass
   // dist_out (potential passes without a mask, pair list ordered by its first index): the role-i entries of a row are the
   // consecutive pairs starting at the pair of its first entry, and their distances are written as a by-product
-  constexpr int U = kRowUnroll;
+  // entries in flight per lane: measured on MI355X -- fp32: 2 (cfg3 0.0840 ms; 0.0853 with 4, 0.0862 with 1, 0.0858 with 3),
+  // fp64: 1 (cfg2 0.0708 ms against 0.0797 with 2 or 4): beyond that the extra registers cost more than the loads they overlap
+  constexpr int U = sizeof(T) == 8 ? 1 : 2;
   constexpr bool POT = MODE == kPot || MODE == kPotForce;
   constexpr bool FORCE = MODE != kPot;
   T A[9];
