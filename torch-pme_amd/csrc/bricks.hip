@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(cons
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(f.spread, blockIdx.x);
   else if (blockIdx.x - n_spread < f.n_row_blocks)
-    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS>(f.rows, blockIdx.x - n_spread);
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2>(f.rows, blockIdx.x - n_spread);
 }
 
 template <int N, typename T>

@@ -113,7 +113,8 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
 }
 
 // BS = threads of the workgroup (BS / kRowLanes rows per workgroup); block = index of the workgroup among the row workgroups
-template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE, int BS>
+// UNROLL: entries in flight per lane (0 = the measured default for the dtype, see below)
+template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE, int BS, int UNROLL = 0>
 __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args, unsigned block) {
   const SRPot& s = args.s;
   const FastRS& cf = args.cf;
@@ -137,8 +138,9 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   // dist_out (potential passes without a mask, pair list ordered by its first index): the role-i entries of a row are the
   // consecutive pairs starting at the pair of its first entry, and their distances are written as a by-product
   // entries in flight per lane: measured on MI355X -- fp32: 2 (cfg3 0.0840 ms; 0.0853 with 4, 0.0862 with 1, 0.0858 with 3),
-  // fp64: 1 (cfg2 0.0708 ms against 0.0797 with 2 or 4): beyond that the extra registers cost more than the loads they overlap
-  constexpr int U = sizeof(T) == 8 ? 1 : 2;
+  // fp64: 1 for a single frame (cfg2 0.0708 ms against 0.0797 with 2 or 4: latency-bound), 2 when many frames fill the machine
+  // (8 x 8 000 atoms in one launch: 0.249 against 0.279 ms); beyond that the extra registers cost more than the loads they overlap
+  constexpr int U = UNROLL ? UNROLL : (sizeof(T) == 8 ? 1 : 2);
   constexpr bool POT = MODE == kPot || MODE == kPotForce;
   constexpr bool FORCE = MODE != kPot;
   T A[9];
