@@ -919,3 +919,22 @@ def test_frames_in_one_launch(dtype, full, kind):
             assert rell2(F[k], f1.cpu().numpy()) < tol
             d_ref = g.distances.cpu().numpy()
             assert relmax(batch.distances[k].cpu().numpy(), d_ref) < (1e-13 if dtype == torch.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_plane_kernels_large_lds(dtype, monkeypatch):
+    """(y,z) plane transforms of a 128^3 mesh: one workgroup holds a 128 x 65 half-complex plane in LDS (133 KB in fp64, above
+    the default 64 KB dynamic-LDS limit, which the launcher raises); against the 3-D hipFFT plans."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(1)
+    L, N = 40.0, 300
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    cell, pos, q = t(np.eye(3) * L), t(rng.uniform(0, L, (N, 3))), t(rng.normal(size=(N, 1)))
+    none, nod = torch.zeros((0, 2), dtype=torch.int64, device=DEV), torch.zeros((0,), dtype=dtype, device=DEV)
+    res = []
+    for xf in (True, False):
+        monkeypatch.setattr(ops, "XFUSED", xf)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.7, interpolation_nodes=5).to(dtype)
+        res.append(calc(q, cell, pos, none, nod).double().cpu().numpy())
+    assert rell2(res[0], res[1]) < (1e-13 if dtype == torch.float64 else 1e-6)
