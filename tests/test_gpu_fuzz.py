@@ -137,9 +137,37 @@ def test_random_graphed_step(seed):
         info = f"seed {seed}/{k}: {scheme}{order} p={p} N={N} P={len(pairs)} full={full} cell={with_cell} {dtype}"
         Eo = float((q * Vo).sum())
         scale = float(np.abs(q * Vo).sum())
-        assert abs(out[0].item() - Eo) < (1e-10 if f64 else 2e-5) * scale, info
+        assert abs(out[0].item() - Eo) < (1e-10 if f64 else 2e-5) * scale, info + f" energy {out[0].item()} vs {Eo} scale {scale}"
         assert rell2(out[1].cpu().numpy(), -(gr["positions"] + gpos_d)) < (1e-9 if f64 else 2e-3), info
         if with_cell:
             assert rell2(out[2].cpu().numpy(), gr["cell"] + gcell_d) < (1e-9 if f64 else 1e-2), info
         if len(pairs):
             assert rell2(step.distances.cpu().numpy(), dist) < (1e-13 if f64 else 1e-5), info
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_empty_pair_list_gradients(channels):
+    """Found by an extended run of the sweep above (seed 442): three atoms further apart than the cutoff -- an empty pair
+    list -- with gradients requested through the unfused kernels (several channels / general upstream gradient): the
+    distance op has no gradient buffer to hand to its adjoint kernel and must return zeros."""
+    rng = np.random.default_rng(442)
+    cell = np.diag([6.2, 9.1, 9.2])
+    pos = np.array([[0.5, 0.5, 0.5], [3.5, 5.0, 5.0], [1.0, 8.0, 2.0]])
+    q = rng.normal(size=(3, channels))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 2.0)
+    assert len(pairs) == 0
+    spec = O.PotentialSpec("coulomb", 1, 1.0, 1.0)
+    g = rng.normal(size=(3, channels))
+    Vo, cache = O.forward(spec, "P3M", 4, 1.0, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, g)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0, interpolation_nodes=4)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=torch.float64, requires_grad=grad)  # noqa: E731
+    tq, tc, tp = t(q, True), t(cell, True), t(pos, True)
+    ti = torch.zeros((0, 2), dtype=torch.int64, device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, torch.zeros((0, 3), dtype=torch.float64, device=DEV))
+    V = calc(tq, tc, tp, ti, d)
+    (V * t(g)).sum().backward()
+    assert rell2(V.detach().cpu().numpy(), Vo) < 1e-11
+    assert rell2(tp.grad.cpu().numpy(), gr["positions"]) < 1e-9
+    assert rell2(tc.grad.cpu().numpy(), gr["cell"]) < 1e-9
+    assert rell2(tq.grad.cpu().numpy(), gr["charges"]) < 1e-10

@@ -763,6 +763,9 @@ class _PairDistances(torch.autograd.Function):
         device, dtype = pos.device, pos.dtype
         N, P = pos.shape[0], pairs.shape[0]
         need_cell = cl is not None and ctx.needs_input_grad[1]
+        if P == 0:  # empty pair list: nothing depends on the positions or the cell (and there is no gradient buffer to pass)
+            return ((torch.zeros((N, 3), dtype=dtype, device=device) if ctx.needs_input_grad[0] else None),
+                    (torch.zeros((3, 3), dtype=dtype, device=device) if need_cell else None), None, None, None)
         grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
         grad_cell = partials = None
         topo = ctx.topo
