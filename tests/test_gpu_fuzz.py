@@ -224,3 +224,45 @@ def test_random_ewald(seed):
     fd = (vals[0] - vals[1]) / (2 * h)
     got = float(tp.grad[a, c])
     assert abs(got - fd) < 1e-6 * (abs(fd) + float(np.abs(w * Vo).sum())), info + f" dL/dr {got} vs {fd}"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_frame_batch(seed):
+    """Random batches of independent frames (2-6 frames, 10-250 atoms each, different triclinic cells that give the same
+    mesh, half / full lists, 1/r or 1/r^6, fp64 / fp32) through ``GraphedFrameBatch`` (one launch per kernel for all frames)
+    against the eager calculator frame by frame: energies and forces."""
+    rng = np.random.default_rng(7000 + seed)
+    dtype = torch.float64 if rng.uniform() < 0.6 else torch.float32
+    full = bool(rng.uniform() < 0.4)
+    p = 6 if rng.uniform() < 0.3 else 1
+    sm = float(rng.uniform(0.8, 1.3))
+    pot = tpa.CoulombPotential(smearing=sm) if p == 1 else tpa.InversePowerLawPotential(exponent=6, smearing=sm)
+    scheme = "P3M" if rng.uniform() < 0.5 else "PME"
+    order = int(rng.integers(2, 6)) if scheme == "P3M" else int(rng.integers(3, 8))
+    Calc = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    calc = Calc(pot, mesh_spacing=0.45, interpolation_nodes=order, full_neighbor_list=full).to(dtype)
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    frames = []
+    for _ in range(int(rng.integers(2, 7))):
+        lengths = rng.uniform(7.6, 13.8, 3)  # 2 L / 0.45 + 1 in (33, 64]: meshes of 64^3
+        cell = np.diag(lengths) + np.tril(rng.uniform(-0.02, 0.02, (3, 3)) * lengths.min(), -1)
+        n_side = int(rng.integers(2, 7))
+        N = int(rng.integers(max(2, n_side**3 // 2), n_side**3 + 1))
+        sites = rng.permutation(n_side**3)[:N]
+        grid = np.stack(np.unravel_index(sites, (n_side,) * 3), -1)
+        pos = ((grid + 0.5 + rng.uniform(-0.2, 0.2, (N, 3))) / n_side) @ cell
+        q = rng.normal(size=(N, 1))
+        pairs, S, _ = tpa.neighbor_list(pos, cell, 3.4, full_list=full)
+        frames.append((t(q), t(cell), t(pos), torch.tensor(pairs.reshape(-1, 2), device=DEV), t(S.reshape(-1, 3))))
+    batch = tpa.GraphedFrameBatch(calc, frames)
+    E, F = batch()
+    tol = 1e-10 if dtype == torch.float64 else 5e-5
+    for k, (q, cell, pos, pairs, S) in enumerate(frames):
+        tp = pos.clone().requires_grad_(True)
+        V = calc(q, cell, tp, pairs, tpa.pair_distances(tp, pairs, cell, S))
+        Ek = tpa.weighted_sum(V, q)
+        Ek.backward()
+        info = f"seed {seed} frame {k}: {scheme}{order} p={p} N={pos.shape[0]} P={pairs.shape[0]} full={full} {dtype}"
+        scale = float((q * V.detach()).abs().sum())
+        assert abs(float(E[k]) - float(Ek)) < tol * scale, info
+        assert rell2(F[k].cpu().numpy(), -tp.grad.cpu().numpy()) < (1e-9 if dtype == torch.float64 else 2e-3), info
