@@ -264,5 +264,5 @@ def test_random_frame_batch(seed):
         Ek.backward()
         info = f"seed {seed} frame {k}: {scheme}{order} p={p} N={pos.shape[0]} P={pairs.shape[0]} full={full} {dtype}"
         scale = float((q * V.detach()).abs().sum())
-        assert abs(float(E[k]) - float(Ek)) < tol * scale, info
+        assert abs(float(E[k]) - float(Ek.detach())) < tol * scale, info
         assert rell2(F[k].cpu().numpy(), -tp.grad.cpu().numpy()) < (1e-9 if dtype == torch.float64 else 2e-3), info
