@@ -266,3 +266,32 @@ def test_random_frame_batch(seed):
         scale = float((q * V.detach()).abs().sum())
         assert abs(float(E[k]) - float(Ek.detach())) < tol * scale, info
         assert rell2(F[k].cpu().numpy(), -tp.grad.cpu().numpy()) < (1e-9 if dtype == torch.float64 else 2e-3), info
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_device_neighbor_list(seed):
+    """The GPU cell-list builder against the host builder on random inputs: triclinic cells, atoms far outside the cell,
+    any combination of periodic axes, half / full lists, cutoffs up to a third of the cell, fp64 / fp32 positions."""
+    rng = np.random.default_rng(11000 + seed)
+    lengths = rng.uniform(9.0, 16.0, 3)
+    cell = np.diag(lengths) + np.tril(rng.uniform(-0.2, 0.2, (3, 3)) * lengths.min(), -1)
+    N = int(rng.integers(1, 500))
+    pos = rng.uniform(-0.8, 1.8, (N, 3)) @ cell
+    periodic = tuple(bool(v) for v in rng.uniform(size=3) < 0.75)
+    full = bool(rng.uniform() < 0.5)
+    width = [abs(np.linalg.det(cell)) / np.linalg.norm(np.cross(cell[(d + 1) % 3], cell[(d + 2) % 3])) for d in range(3)]
+    rc = float(rng.uniform(1.5, min(width) / 3.05))
+    hp, hS, hd = tpa.neighbor_list(pos, cell, rc, full_list=full, periodic=periodic)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    gp, gS, gd = tpa.neighbor_list_device(t(pos), t(cell), rc, full_list=full, periodic=periodic)
+    info = f"seed {seed}: N={N} rc={rc:.3f} periodic={periodic} full={full} host pairs {len(hp)} device pairs {len(gp)}"
+    assert len(gp) == len(hp), info
+
+    def canon(p, S, d):
+        key = np.lexsort((S[:, 2], S[:, 1], S[:, 0], p[:, 1], p[:, 0]))
+        return p[key], S[key], d[key]
+
+    a = canon(hp, hS.astype(np.int64), hd)
+    b = canon(gp.cpu().numpy(), np.rint(gS.cpu().numpy()).astype(np.int64), gd.cpu().numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), info
+    assert np.allclose(a[2], b[2], rtol=1e-12, atol=0), info
