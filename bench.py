@@ -1,17 +1,23 @@
 """Benchmark of the PME/P3M hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload water|ionic|dispersion]
+    python bench.py --gpus N --steps K --warmup W [--workload water|ionic|dispersion] [--preset cfg2|cfg3|cfg4|cfg5]
 
-One *step* = one energy + forces evaluation of one frame per GPU, the reference's protocol
-(BASELINE.md section 2): ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = sum(q*V)`` ->
-``E.backward()`` (forces = -dE/dpositions).  Inputs are resident in HBM before the timed region.  With N > 1
-every rank owns an independent frame (weak scaling, no intra-cell decomposition); the frame energies are exchanged
-with ONE RCCL all_gather after the last step (inside the timed region).
+One *step* = one energy + forces evaluation of one frame (or ``--frames-per-gpu`` frames) per GPU, the reference's
+protocol: ``d = pair_distances(...)`` -> ``V = calculator(...)`` -> ``E = sum(q*V)`` ->
+``E.backward()`` (forces = -dE/dpositions).  Inputs are resident in HBM before the timed region.
+
+Ranks.  ``--gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment re-executes this script under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one process per GPU, backend
+``nccl`` = RCCL); launched by an external ``torch.distributed.run`` it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+Every rank owns independent frames (weak scaling, no intra-cell decomposition); the frame energies are
+exchanged with ONE all_gather after the last step, inside the timed region.  The time is the MAX over ranks.
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
   cpu_baseline -- the PyTorch-CPU oracle ("port" of the reference's ATen op sequence) timed on this host's cores
-                  on a bounded sample (rank 0, N = 1 only)
+                  on a bounded sample, swept over thread counts (rank 0, N = 1 only)
+  drop_in      -- the same frame through the reference's own call sequence, eager, no graph, no package-specific
+                  helpers: caller-made distances -> calculator(...) -> (q*V).sum().backward()
 """
 
 from __future__ import annotations
@@ -19,6 +25,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,13 +36,64 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torchpme_amd as tpa  # noqa: E402
-from torchpme_amd import ops, workloads  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+PRESETS = {
+    # BASELINE.json configs[1..4]
+    "cfg2": dict(workload="ionic", frames_per_gpu=1),
+    "cfg3": dict(workload="water", frames_per_gpu=1),
+    "cfg4": dict(workload="ionic", frames_per_gpu=8),  # 64 frames of 8 000 atoms on 8 GPUs = 8 per rank
+    "cfg5": dict(workload="dispersion", frames_per_gpu=1),
+}
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
+    ap.add_argument("--preset", default=None, choices=sorted(PRESETS),
+                    help="BASELINE.json configuration: sets --workload / --frames-per-gpu (cfg4 = ionic, 8 frames per GPU)")
+    ap.add_argument("--frame-batch", default="one-launch", choices=["one-launch", "streams"],
+                    help="with several frames per GPU: every kernel of the pipeline launched once for all frames "
+                         "(GraphedFrameBatch), or one HIP graph per frame replayed on its own stream")
+    ap.add_argument("--frames-per-gpu", type=int, default=1,
+                    help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --preset cfg4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-drop-in", action="store_true")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
+    # test hook (tests/test_bench_launch.py): the launch / rendezvous / timing / reporting path on CPU ranks with the gloo
+    # backend and a trivial stand-in for the frame evaluation.  Its JSON line says so and is never a measurement.
+    ap.add_argument("--stub-evaluator", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    if args.preset is not None:
+        for k, v in PRESETS[args.preset].items():
+            setattr(args, k, v)
+    return args
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(args, argv) -> int:
+    """``--gpus N`` (N > 1) outside a torch.distributed launcher: start N ranks of this script, one per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def make_workload(name: str, seed_offset: int):
+    from torchpme_amd import workloads
+
     if name == "water":
         return workloads.water_box(seed=1234 + seed_offset)
     if name == "ionic":
@@ -48,6 +107,8 @@ class Frame:
     """Device-resident inputs of one frame + its calculator."""
 
     def __init__(self, w, device):
+        import torchpme_amd as tpa
+
         self.w = w
         dt = torch.float32 if w.dtype == "f32" else torch.float64
         self.dtype = dt
@@ -61,8 +122,11 @@ class Frame:
                else tpa.InversePowerLawPotential(exponent=w.exponent, smearing=w.smearing))
         Calc = tpa.P3MCalculator if w.scheme == "P3M" else tpa.PMECalculator
         self.calc = Calc(pot, mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order)
+        self._tpa = tpa
 
     def step(self):
+        """The package's fast eager form of the step (deferred distances + weighted_sum)."""
+        tpa = self._tpa
         self.pos.grad = None
         # deferred: the distance tensor is written by the calculator's fused distance + pair kernel (by-product of the row that
         # owns a pair's first atom) instead of by a separate pass over the pair list -- same tensor, one kernel less
@@ -73,30 +137,64 @@ class Frame:
         E.backward(self.minus_one)
         return E.detach(), self.pos.grad
 
+    def step_reference_protocol(self, distances: str = "helper"):
+        """The reference's call sequence with nothing package-specific but the distance helper (the counterpart of the
+        caller-side ``compute_distances``, tests/helpers.py:278-304): eager, no graph, no ``weighted_sum``, no deferral.
+        ``distances="torch"`` forms the distances with plain tensor ops instead, exactly as the reference's helper does."""
+        self.pos.grad = None
+        if distances == "torch":
+            vec = self.pos[self.pairs[:, 1]] - self.pos[self.pairs[:, 0]] + self.shifts @ self.cell
+            d = torch.linalg.norm(vec, dim=1)
+        else:
+            d = self._tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts)
+        V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
+        E = (self.q * V).sum()
+        E.backward()
+        return E.detach(), -self.pos.grad
+
+
+class StubFrame:
+    """Stand-in used by the CPU launch test (--stub-evaluator): no HIP, no oracle -- a dot product per 'frame'."""
+
+    class _W:
+        name, dtype, n_atoms, n_pairs, n_mesh, cutoff, scheme, order, exponent = "stub", "f64", 1000, 0, 0, 0.0, "-", 0, 1
+
+    def __init__(self, seed, device):
+        g = torch.Generator().manual_seed(seed)
+        self.w = self._W()
+        self.dtype = torch.float64
+        self.x = torch.rand((self.w.n_atoms,), generator=g, dtype=torch.float64).to(device)
+
+    def step(self):
+        return (self.x * self.x).sum(), None
+
 
 def algorithmic_bytes(w, s: int, fused: bool = True):
     """Minimum HBM bytes per energy+forces step (reference data formats) and per kernel launch.
 
     Per kernel the figure is what the launch must move IN THE FORMAT IT READS, never more than SURVEY's figure for the
     reference formats: the distance kernel streams int32 pairs + one packed shift word + writes d (8 + 4 + s bytes per
-    pair instead of 16 + 3s + s), and the fused pair kernel streams two 8-byte entries per pair and reads neither d nor
-    dL/dd (16 bytes per pair; SURVEY's three kernels it replaces add up to 48 + 7s).  DESIGN.md section 2 lists both."""
+    pair instead of 16 + 3s + s), and the fused pair kernel streams two entries per pair (``entry_bytes`` each) and reads
+    neither d nor dL/dd.  DESIGN.md section 2 lists both."""
+    from torchpme_amd import ops
+
     P, N, M = w.n_pairs, w.n_atoms, w.n_mesh**3
+    eb = getattr(ops, "FUSED_ENTRY_BYTES", 8)
     per_kernel = {
         "pair_distance_forward": (P * (8 + 4 + s) if fused else P * (16 + 3 * s + s)) + N * 3 * s,
         "pair_distance_backward": P * (16 + 3 * s + s) + N * 6 * s,
-        "rspace_forward": (2 * P * 8 + P * s + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
+        "rspace_forward": (2 * P * eb + P * s + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
         "rspace_backward": P * (16 + 2 * s) + N * 3 * s,
         # mesh stages (the meshes themselves are L2 / Infinity-Cache resident at these sizes)
         "spread": N * 4 * s + 2 * M * s,
         # the spread and the fused distance + pair kernel co-scheduled in one launch (mipme_sr_job_t): both byte counts
-        "spread+rspace_forward": (2 * P * 8 + P * s + N * 8 * s) + N * 4 * s + 2 * M * s,
+        "spread+rspace_forward": (2 * P * eb + P * s + N * 8 * s) + N * 4 * s + 2 * M * s,
         "gather": N * 5 * s + M * s,
         "gather_grad": N * 8 * s + 2 * M * s,
         "fft_r2c": 2 * M * s,
         "fft_c2r": 2 * M * s,
         "apply_filter": int(2.5 * M * s),
-        # (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT: the three stages above in one composite
+        # (y,z) plane transforms + one kernel for x-FFT * G * inverse x-FFT: the three stages above in one composite
         "convolve_xfused": int(6.5 * M * s),
         "bin_atoms": N * (3 * s + 8 + 16 + 4 * s),
         # energy reduction E = sum q V, its adjoint, and the energy-mode force assembly gE q_a (f F_a + field_a)
@@ -108,39 +206,62 @@ def algorithmic_bytes(w, s: int, fused: bool = True):
     return step, per_kernel
 
 
-def cpu_baseline(w, budget_s: float = 20.0):
+# ----------------------------------------------------------------------------------------------------------------------
+def _time_cpu_steps(fn, n_warm: int, n_max: int, budget_s: float):
+    times, t_all = [], time.monotonic()
+    while True:
+        t0 = time.monotonic()
+        res = fn()
+        times.append(time.monotonic() - t0)
+        if len(times) >= n_warm + n_max or (len(times) > n_warm and time.monotonic() - t_all + times[-1] > budget_s):
+            break
+    timed = times[n_warm:] if len(times) > n_warm else times[-1:]
+    return float(np.median(timed)), len(timed), len(times) - len(timed), res
+
+
+def cpu_baseline(w, budget_s: float = 40.0):
     """Time the CPU restatement of the reference's op sequence (``oracle/pme_torch.py``: ATen ops on CPU tensors,
-    all host threads, autograd) on this host, with the reference's own timing protocol (``tuning/tuner.py:337-373``:
-    warm-up calls, then repeated energy + forces evaluations of the SAME frame, monotonic clock, median)."""
+    autograd) on this host, with the reference's own timing protocol (``tuning/tuner.py:337-373``: warm-up calls, then
+    repeated energy + forces evaluations of the SAME frame, monotonic clock, median), swept over thread counts
+    {1, 8, 16, 32, 64, 128} (those the host has): ``value`` is the best, ``one_thread`` the 1-thread figure SURVEY 8(d)
+    asks for."""
     from oracle import pme_numpy as O
     from oracle import pme_torch as OT
 
     if w.exponent != 1:  # the torch oracle covers the Coulomb configurations; fall back to the NumPy port
-        return cpu_baseline_numpy(w, budget_s)
+        return cpu_baseline_numpy(w, 25.0)
     dt = torch.float32 if w.dtype == "f32" else torch.float64
     spec = O.PotentialSpec("coulomb", 1, w.smearing, 1.0)
     q, cell, pos, pairs, S = OT.as_tensors(w, dt)
     scheme = "P3M" if w.scheme == "P3M" else "Lagrange"
-    times = []
-    t_all = time.monotonic()
-    n_warm = 2
-    while True:
-        t0 = time.monotonic()
-        E, F = OT.energy_forces_step(spec, scheme, w.order, w.mesh_spacing, q, cell, pos, pairs, S)
-        times.append(time.monotonic() - t0)
-        if len(times) >= n_warm + 8 or (len(times) > n_warm and time.monotonic() - t_all + times[-1] > budget_s):
-            break
-    timed = times[n_warm:] if len(times) > n_warm else times[-1:]
-    best = float(np.median(timed))
+    n_logical = os.cpu_count() or 1
+    counts = [t for t in (1, 8, 16, 32, 64, 128) if t <= n_logical] or [1]
+    saved = torch.get_num_threads()
+    sweep, energy = {}, None
+    per = budget_s / len(counts)
+    try:
+        for t in counts:
+            torch.set_num_threads(t)
+            med, n_timed, n_warm, (E, _F) = _time_cpu_steps(
+                lambda: OT.energy_forces_step(spec, scheme, w.order, w.mesh_spacing, q, cell, pos, pairs, S),
+                n_warm=1, n_max=4, budget_s=per)
+            sweep[t] = {"s_per_step": round(med, 4), "atom_steps_per_s": w.n_atoms / med, "timed": n_timed, "warmup": n_warm}
+            energy = float(E)
+    finally:
+        torch.set_num_threads(saved)
+    best = min(sweep, key=lambda t: sweep[t]["s_per_step"])
     return {
-        "value": w.n_atoms / best,
+        "value": sweep[best]["atom_steps_per_s"],
         "unit": "atom-steps/s",
-        "cores": torch.get_num_threads(),
+        "cores": best,
         "kind": "port",
-        "sample": f"{len(timed)} timed (+{len(times) - len(timed)} warm-up) full energy+forces steps of the same "
-                  f"{w.n_atoms}-atom frame with oracle/pme_torch.py (PyTorch-CPU ATen ops + autograd, "
-                  f"{torch.get_num_threads()} threads of {os.cpu_count()} logical cores), median {best:.3f} s/step, "
-                  f"energy {float(E):.4f}",
+        "one_thread": sweep[1]["atom_steps_per_s"] if 1 in sweep else None,
+        "host_logical_cores": n_logical,
+        "thread_sweep": {str(t): v for t, v in sweep.items()},
+        "sample": f"full energy+forces steps of the same {w.n_atoms}-atom frame with oracle/pme_torch.py (PyTorch-CPU ATen "
+                  f"ops + autograd), 1 warm-up + up to 4 timed steps per thread count in {counts} (torch.set_num_threads; "
+                  f"host has {n_logical} logical cores), median per count; best = {best} threads at "
+                  f"{sweep[best]['s_per_step']:.3f} s/step, energy {energy:.4f}",
     }
 
 
@@ -152,86 +273,121 @@ def cpu_baseline_numpy(w, budget_s: float = 25.0):
     spec = O.PotentialSpec("coulomb" if w.exponent == 1 else "ipl", w.exponent, w.smearing, 1.0)
     pos, q, cell = w.positions.astype(dt), w.charges.astype(dt), w.cell.astype(dt)
     scheme = "P3M" if w.scheme == "P3M" else "Lagrange"
-    times = []
-    t_all = time.monotonic()
-    while True:
-        t0 = time.monotonic()
+
+    def step():
         dist, _ = O.pair_distances(pos, cell, w.pairs, w.shifts)
         V, cache = O.forward(spec, scheme, w.order, w.mesh_spacing, q, cell, pos, w.pairs, dist, return_cache=True)
         gr = O.backward(cache, q)
         gpos, _ = O.pair_distances_backward(pos, cell, w.pairs, w.shifts, gr["dist"])
-        _forces = -(gpos + gr["positions"])
-        times.append(time.monotonic() - t0)
-        if time.monotonic() - t_all + times[-1] > budget_s or len(times) >= 4:
-            break
-    best = float(np.median(times))
+        return -(gpos + gr["positions"])
+
+    med, n_timed, _, _ = _time_cpu_steps(step, n_warm=0, n_max=4, budget_s=budget_s)
     return {
-        "value": w.n_atoms / best,
+        "value": w.n_atoms / med,
         "unit": "atom-steps/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{len(times)} full energy+forces step(s) of the same {w.n_atoms}-atom frame with oracle/pme_numpy.py "
-                  f"(NumPy, single thread), median {best:.2f} s/step; host has {os.cpu_count()} logical cores",
+        "one_thread": w.n_atoms / med,
+        "host_logical_cores": os.cpu_count(),
+        "sample": f"{n_timed} full energy+forces step(s) of the same {w.n_atoms}-atom frame with oracle/pme_numpy.py "
+                  f"(NumPy, single thread), median {med:.2f} s/step",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="water", choices=["water", "ionic", "dispersion"])
-    ap.add_argument("--frame-batch", default="one-launch", choices=["one-launch", "streams"],
-                    help="with several frames per GPU: every kernel of the pipeline launched once for all frames "
-                         "(GraphedFrameBatch), or one HIP graph per frame replayed on its own stream")
-    ap.add_argument("--frames-per-gpu", type=int, default=1,
-                    help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --workload ionic "
-                         "--frames-per-gpu 8 on 8 GPUs = 64 frames)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
-    args = ap.parse_args()
+def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
+    """ms per step of the reference's own call sequence on the same frame (eager launches from Python, general autograd
+    nodes), and the parity of its result with the package's fast form of the step."""
+    out = {"protocol": "d = pair_distances(positions, pairs, cell, shifts); V = calculator(charges, cell, positions, "
+                       "pairs, d); E = (charges * V).sum(); E.backward() -- eager, no HIP graph, no weighted_sum, no "
+                       "deferred distances (reference: tuning/tuner.py:337-373, tests/helpers.py:278-304)"}
+    E_fast, F_fast = frame.step()
+    F_fast = F_fast.clone()
+    for key, mode in (("ms_per_step", "helper"), ("ms_per_step_torch_distances", "torch")):
+        for _ in range(n_warm):
+            E, F = frame.step_reference_protocol(mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            E, F = frame.step_reference_protocol(mode)
+        torch.cuda.synchronize()
+        out[key] = 1e3 * (time.perf_counter() - t0) / n_steps
+        out[f"{key}_steps"] = n_steps
+        if mode == "helper":
+            out["rel_energy_diff_vs_fast_path"] = abs(float(E) - float(E_fast)) / abs(float(E_fast))
+            out["force_rel_l2_diff_vs_fast_path"] = float((F - F_fast).norm() / F_fast.norm())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr)
+    stub = args.stub_evaluator
+    backend = "gloo" if stub else "nccl"
     distributed = world > 1 or os.environ.get("MIPME_FORCE_DIST") == "1"  # the latter: 1-rank smoke test of this path
+    dist = None
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if not stub:
+            torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on the C-level stdout when the communicator comes up; keep stdout for the one JSON
         # line by pointing fd 1 at stderr while the process group initialises and runs its first collective
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if stub:
+                dist.init_process_group(backend)
+            else:
+                dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
             dist.barrier()  # RCCL completes its lazy set-up before anything is timed or captured
-            torch.cuda.synchronize()
+            if not stub:
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        world = dist.get_world_size()  # what the backend (RCCL) reports, not what the environment claimed
+    device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    if not stub:
+        torch.cuda.set_device(device)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     n_frames = max(1, args.frames_per_gpu)
-    frames = [Frame(make_workload(args.workload, rank * n_frames + f), device) for f in range(n_frames)]
+    if stub:
+        frames = [StubFrame(rank * n_frames + f, device) for f in range(n_frames)]
+    else:
+        import torchpme_amd as tpa
+        from torchpme_amd import ops
+
+        frames = [Frame(make_workload(args.workload, rank * n_frames + f), device) for f in range(n_frames)]
     frame, w = frames[0], frames[0].w
     s = 4 if w.dtype == "f32" else 8
-    # the farm's ONE exchange: after its last frame evaluation every rank contributes its frame energy
-    # to an all-gather over RCCL (8 B per frame), inside the timed region
+    # the farm's ONE exchange (SURVEY.md 8(e)): after its last frame evaluation every rank contributes its frame energies
+    # to an all-gather (8 B per frame), inside the timed region
     my_energy = torch.zeros(n_frames, dtype=frame.dtype, device=device)
     all_energies = torch.zeros(world * n_frames, dtype=frame.dtype, device=device)
 
     def dbg(msg):
         if os.environ.get("MIPME_BENCH_DEBUG") == "1":
-            torch.cuda.synchronize()
+            sync()
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-    launch = args.launch
+    launch = "eager" if stub else args.launch
     graphed = None
     if launch == "graph":
         try:
@@ -278,27 +434,51 @@ def main():
     join_streams()
     exchange(E)
     dbg("warm-up done")
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         E = one_step()
     join_streams()
     exchange(E)
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     dbg("timed loop done")
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        gathered = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(gathered, tt)
+        per_rank_ms = [1e3 * float(v) / args.steps for v in gathered.tolist()]
+        elapsed = float(gathered.max().item())  # MAX over ranks
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n_frames * w.n_atoms * args.steps / elapsed
+    parallelism = {
+        "n_ranks": world,
+        "backend": (f"{backend} ({'RCCL' if backend == 'nccl' else 'CPU test'}), world size reported by the backend"
+                    if distributed else "none (single process)"),
+        "collective": "one all_gather_into_tensor of the frame energies per timed region" if distributed else None,
+        "per_rank_ms_per_step": [round(v, 6) for v in per_rank_ms],
+    }
+
+    if stub:
+        if rank == 0:
+            print(json.dumps({
+                "metric": "stub", "value": value, "unit": "stub-units/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64",
+                "data": "stub evaluator on CPU ranks (launch-path test; NOT a measurement of the hot path)",
+                "config": {"workload": "stub", "frames_per_gpu": n_frames}, "parallelism": parallelism,
+                "energies_gathered": int(all_energies.numel()) if distributed else n_frames,
+            }))
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     # ---- instrumented pass: per-call HIP-event timings on the launch stream (does not affect `value`) ----
     from torchpme_amd import _lib
@@ -338,23 +518,29 @@ def main():
 
     if rank == 0:
         step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES)
-        pair_kernels = {k: v for k, v in prof.items() if k in per_kernel}
-        pair_kernels.update({k: v for k, v in stages.items() if k in per_kernel})
+        kernels = {k: v for k, v in prof.items() if k in per_kernel}
+        kernels.update({k: v for k, v in stages.items() if k in per_kernel})
         # dominant kernel = the longest single launch (an HBM-streaming pair kernel at these sizes); the per-kernel
         # table below lists every kernel with its launches per step
-        dom = max(pair_kernels, key=pair_kernels.get)
-        achieved = per_kernel[dom] / (pair_kernels[dom] * 1e-3) / 1e9
-        # HBM bytes per launch from the rocprofv3 PMC passes of the same command (tools/profile_gpu.sh ->
-        # tools/pmc_to_json.py, committed under profiles/); bench.py cannot run the profiler on itself
-        traffic = None
+        dom = max(kernels, key=kernels.get)
+        achieved = per_kernel[dom] / (kernels[dom] * 1e-3) / 1e9
+        # HBM bytes per launch: bench.py cannot run the profiler on itself, so this is the figure of the COMMITTED rocprofv3
+        # PMC passes of this same command (tools/profile_gpu.sh -> tools/pmc_to_json.py -> profiles/pmc_traffic.json),
+        # labelled as such; null for workloads without a committed profile
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.workload == "water" and os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        if args.workload == "water" and n_frames == 1 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_source = (f"committed profile profiles/pmc_traffic.json (from {pmc.get('source')}; separate rocprofv3 "
+                              "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrections in the file), not "
+                              "measured in this run")
         table = {
             k: {"ms_per_launch": round(v, 5), "launches_per_step": stage_calls.get(k, 1.0),
                 "algorithmic_MB": round(per_kernel[k] / 1e6, 3), "GBps": round(per_kernel[k] / (v * 1e-3) / 1e9, 1)}
-            for k, v in sorted(pair_kernels.items(), key=lambda kv: -kv[1])
+            for k, v in sorted(kernels.items(), key=lambda kv: -kv[1])
         }
+        moved = sum(per_kernel[k] * stage_calls.get(k, 1.0) for k in kernels)
         out = {
             "metric": "atom-steps/sec (energy+forces)",
             "value": value,
@@ -372,13 +558,15 @@ def main():
                 "workload": f"{w.name}: {w.n_atoms} atoms, {w.n_pairs} half pairs (rc={w.cutoff} A), "
                             f"{w.scheme} order {w.order}, {w.n_mesh}^3 mesh, "
                             f"{'Coulomb' if w.exponent == 1 else '1/r^%d' % w.exponent}, {w.dtype}, energy+forces via autograd",
+                "preset": args.preset,
                 "frames_per_gpu": n_frames,
                 "launch": ("HIP graph replay of the captured step"
                            + (", all frames in one launch per kernel (GraphedFrameBatch)" if batch is not None
                               else ", one stream per frame" if streams is not None else ""))
                           if launch == "graph" else "eager kernel launches",
-                "parallelism": f"{world * n_frames} independent frame(s), {n_frames} per GPU",
+                "parallelism": f"{world * n_frames} independent frame(s), {n_frames} per GPU, {world} rank(s)",
             },
+            "parallelism": parallelism,
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
@@ -387,16 +575,24 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_kernel[dom],
-                "kernel_ms": pair_kernels[dom],
+                "kernel_ms": kernels[dom],
             },
-            "step_algorithmic_GB": step_bytes / 1e9,
-            "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # whole step: bytes the kernels of this build move in their own formats (sum of the per-kernel figures below)
+            # against the step time; SURVEY 8(d)'s figure for the reference's unfused formats is given for orientation only
+            "step_bytes": {
+                "moved_GB": moved / 1e9,
+                "hbm_frac_moved": moved / (ms_per_step / n_frames * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "survey_reference_formats_GB": step_bytes / 1e9,
+            },
             "kernels": table,
             "abi_call_ms": prof,
             "energy": float(E[0].item()),
             "accuracy": accuracy,
         }
+        if world == 1 and not args.no_drop_in:
+            out["drop_in"] = drop_in_timing(frame)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

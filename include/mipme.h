@@ -282,6 +282,12 @@ int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const v
 int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
                        void* grad_b);
 
+/* Energy-mode detection for callers that reduce with plain tensor ops, E = (charges * V).sum() (README.rst:112-114): the
+ * gradient arriving at the calculator's backward is then gE * charges.  result[0] = s = g[k] / q[k] at the k of the largest
+ * |q|; result[1] = 1 if |g[i] - s q[i]| <= 8 eps |s q[i]| for every i, else 0 (2 reals of `dtype`, device memory).  When it
+ * matches, result (the device scalar s) can be passed as grad_scale of the backward entry points.  One workgroup. */
+int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result);
+
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 
 /* d[p] = | r[j] - r[i] + shifts[p] @ cell |.  cell: DEVICE (9 reals); shifts (P,3) reals (nullable = 0). */

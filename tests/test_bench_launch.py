@@ -1,0 +1,49 @@
+"""``bench.py --gpus N`` must produce N ranks by itself (round-1 verdict: the flag was parsed and ignored).
+
+Runs the real entry point on CPU: ``--stub-evaluator`` swaps the HIP frame evaluation for a dot product and the
+``nccl`` backend for ``gloo``; everything else -- the re-exec under ``torch.distributed.run``, the rendezvous on
+127.0.0.1, the barrier-bracketed timed loop, the all-gather inside it, MAX over ranks, the single JSON line of
+rank 0 -- is the code path the GPU ranks take."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags, "--stub-evaluator"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_ranks():
+    out = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-gpu", "2")
+    assert out["n_gpus"] == 2
+    assert out["parallelism"]["n_ranks"] == 2
+    assert len(out["parallelism"]["per_rank_ms_per_step"]) == 2
+    assert out["energies_gathered"] == 4  # 2 ranks x 2 frames through the one all-gather
+    assert out["ms_per_step"] == pytest.approx(max(out["parallelism"]["per_rank_ms_per_step"]), rel=1e-6)
+    assert out["steps"] == 3 and out["warmup"] == 1
+
+
+def test_single_rank_default():
+    out = _run("--steps", "2", "--warmup", "1")
+    assert out["n_gpus"] == 1 and out["parallelism"]["n_ranks"] == 1
+
+
+def test_cfg4_preset():
+    import bench
+
+    args = bench.parse_args(["--preset", "cfg4", "--gpus", "8"])
+    assert (args.workload, args.frames_per_gpu, args.gpus) == ("ionic", 8, 8)

@@ -96,6 +96,65 @@ def test_cfg3_forward_against_oracle(water):
     assert rel(Box(w, torch.float32).potentials().cpu().double(), Vo) < 2e-5
 
 
+def _oracle_energy_forces(w):
+    """E = sum q V and F = -dE/dr of a workload from the NumPy oracle (fp64): forward + analytic adjoint with g = q, the
+    pair part chained through the distances (reference: autograd through compute_distances, tests/helpers.py:278-304)."""
+    spec = O.PotentialSpec("coulomb" if w.exponent == 1 else "ipl", w.exponent, w.smearing, 1.0)
+    dist = O.pair_distances(w.positions, w.cell, w.pairs, w.shifts)[0]
+    Vo, cache = O.forward(spec, w.scheme, w.order, w.mesh_spacing, w.charges, w.cell, w.positions, w.pairs, dist,
+                          return_cache=True)
+    gr = O.backward(cache, w.charges)
+    gpos_d, _ = O.pair_distances_backward(w.positions, w.cell, w.pairs, w.shifts, gr["dist"])
+    return float((Vo * w.charges).sum()), -(gr["positions"] + gpos_d), dist
+
+
+def test_cfg3_forces_against_oracle(water):
+    """cfg3 at full size, energy AND forces against the oracle's analytic adjoint: fp64 <= 1e-10, fp32 energy within 1e-5
+    and force rel-L2 within 1e-5 (north_star tolerance) -- through the eager calculators (fast and reference call
+    sequence) and through the graph-replayed step bench.py times (GraphedEnergyForces)."""
+    w = water
+    Eo, Fo, dist_o = _oracle_energy_forces(w)
+    Fo_t = torch.tensor(Fo)
+    for dtype, tol_e, tol_f in ((torch.float64, 1e-11, 1e-10), (torch.float32, 1e-5, 1e-5)):
+        box = Box(w, dtype)
+        for general in (False, True):
+            E, F = box.energy_forces(general=general)
+            assert abs(E - Eo) < tol_e * abs(Eo), (dtype, general)
+            assert rel(F.cpu().double(), Fo_t) < tol_f, (dtype, general)
+        step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts)
+        for _ in range(2):  # the second replay must reproduce the first
+            Eg, Fg = step()
+            assert abs(float(Eg) - Eo) < tol_e * abs(Eo), dtype
+            assert rel(Fg.cpu().double(), Fo_t) < tol_f, dtype
+        # the distances the step produced as a by-product of its pair kernel
+        dtol = 1e-13 if dtype == torch.float64 else 1e-5
+        assert float(((step.distances.cpu().double() - torch.tensor(dist_o)).abs() / torch.tensor(dist_o)).max()) < dtol
+
+
+def test_cfg4_one_gpu_share_against_oracle():
+    """BASELINE.json configs[3] on one GPU: the 8 frames a rank owns (8 000 charges each, fp64, seeds 100..107 = rank 0's
+    block of the 64) through GraphedFrameBatch -- ONE launch per kernel for all frames, the path
+    ``bench.py --preset cfg4`` times -- with the energy, forces and distances of EVERY frame checked against the oracle."""
+    ws = [workloads.ionic_box(seed=100 + f) for f in range(8)]
+    boxes = [Box(w, torch.float64) for w in ws]
+    batch = tpa.GraphedFrameBatch(boxes[0].calc, [(b.q, b.cell, b.pos, b.pairs, b.shifts) for b in boxes])
+    for replay in range(2):
+        energies, forces = batch()
+        torch.cuda.synchronize()
+        for f, w in enumerate(ws):
+            Eo, Fo, dist_o = _oracle_energy_forces(w)
+            assert abs(float(energies[f]) - Eo) < 1e-11 * abs(Eo), (replay, f)
+            assert rel(forces[f].cpu(), torch.tensor(Fo)) < 1e-10, (replay, f)
+            if batch.distances[f] is not None:
+                assert float((batch.distances[f].cpu() - torch.tensor(dist_o)).abs().max()) < 1e-12
+    # the same frames, one HIP graph per frame on its own stream (bench.py --frame-batch streams)
+    for f in (0, 7):
+        b = boxes[f]
+        Eo, Fo, _ = _oracle_energy_forces(ws[f])
+        Eg, Fg = tpa.GraphedEnergyForces(b.calc, b.q, b.cell, b.pos, b.pairs, b.shifts)()
+        assert abs(float(Eg) - Eo) < 1e-11 * abs(Eo) and rel(Fg.cpu(), torch.tensor(Fo)) < 1e-10
+
+
 @pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
 def test_fullsize_properties(cfg, request):
     w = request.getfixturevalue(cfg)

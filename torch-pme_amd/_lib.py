@@ -34,6 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
+    "mipme_scaled_match",
 )
 
 
@@ -175,6 +176,7 @@ def _declare(lib):
         "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12,
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
+        "mipme_scaled_match": [vp, ci, i64, vp, vp, vp],
         "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],
         "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
         "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp, vp, vp],

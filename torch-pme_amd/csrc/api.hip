@@ -371,6 +371,55 @@ __global__ __launch_bounds__(256) void dot_backward_kernel(int64_t n, const T* _
   if (out_b) out_b[i] = gv * a[i];
 }
 
+// Is g == s * q for one scalar s?  (the gradient (q * V).sum() sends back to V: energy mode of the backward passes.)
+// One workgroup: s = g[k] / q[k] at the k of the largest |q|, then max_i |g_i - s q_i| <= tol |s q_i|.  result = {s, 0 | 1}.
+template <typename T>
+__global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* __restrict__ g, const T* __restrict__ q,
+                                                            T* __restrict__ result) {
+  __shared__ double s_val[16];
+  __shared__ long long s_idx[16];
+  __shared__ int s_bad[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best = -1.0;
+  long long bi = 0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = fabs(double(q[i]));
+    if (v > best) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(best, off, 64);
+    const long long oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < int(blockDim.x >> 6); ++w)
+      if (s_val[w] > s_val[0] || (s_val[w] == s_val[0] && s_idx[w] < s_idx[0])) { s_val[0] = s_val[w]; s_idx[0] = s_idx[w]; }
+  }
+  __syncthreads();
+  const long long k = s_idx[0];
+  const bool usable = s_val[0] > 0.0;
+  const T scale = usable ? g[k] / q[k] : T(0);
+  const double sd = double(scale);
+  const double tol = 8.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
+  int bad = (usable && isfinite(sd)) ? 0 : 1;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double e = sd * double(q[i]);
+    if (!(fabs(double(g[i]) - e) <= tol * fabs(e))) bad = 1;
+  }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) s_bad[wave] = bad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) any |= s_bad[w];
+    result[0] = scale;
+    result[1] = any ? T(0) : T(1);
+  }
+}
+
 static double axis_length(const mipme_mesh_t* m, int axis) {
   const double* a = m->cell + 3 * axis;
   return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -725,6 +774,21 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
   else if (dtype == MIPME_F64)
     dot_backward_kernel<double><<<blocks, 256, 0, st>>>(n, (const double*)grad, (const double*)a, (const double*)b,
                                                         (double*)grad_a, (double*)grad_b);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result) {
+  MIPME_REQUIRE(n > 0 && g && q && result, "invalid arguments to mipme_scaled_match");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    scaled_match_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result);
+  else if (dtype == MIPME_F64)
+    scaled_match_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)g, (const double*)q, (double*)result);
   else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;

@@ -117,6 +117,8 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 #: run the short-range pair sum inside the spread launch of the mesh part (see mipme_sr_job_t in include/mipme.h)
 COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
+#: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
+ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
 
 # Reciprocal-space convolution as (y,z) plane transforms + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two
 # nx); "0" keeps the 3-D hipFFT plans + filter kernel.
@@ -266,7 +268,7 @@ class PairTopology:
 class DistanceSource:
     """Provenance of a distance tensor made by :func:`pair_distances` (attached to it as ``_mipme_src``)."""
 
-    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref", "pending")
+    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref", "pending", "direct")
 
     def __init__(self, positions, cell, pairs, shifts, shifts_key, dist, pending=False):
         self.positions, self.cell, self.pairs, self.shifts, self.shifts_key = positions, cell, pairs, shifts, shifts_key
@@ -274,6 +276,12 @@ class DistanceSource:
         self.dist_ref = weakref.ref(dist)
         #: True while the values of a ``deferred=True`` tensor have not been written yet
         self.pending = pending
+        #: how the pair part of a calculator's gradient reaches ``positions`` / ``cell`` when the fused kernels are used:
+        #: False (default) -- through this tensor's own autograd node, as ``dL/d(neighbor_distances)`` in lazy form
+        #: (:class:`LazyPairGradient`), so ``torch.autograd.grad(E, d)`` and hooks on ``d`` behave as in the reference;
+        #: True (``pair_distances(..., deferred=True)``: explicit opt-in) -- straight to ``positions`` / ``cell``; the
+        #: distance tensor is then NOT part of the result's autograd graph.
+        self.direct = pending
 
     def materialize(self) -> None:
         """Write the values of a deferred distance tensor with the stand-alone distance kernel (for consumers other than
@@ -323,12 +331,58 @@ def _slab_axis(periodic_host):
     return p.index(False)
 
 
+class LazyPairGradient(torch.Tensor):
+    """``dL/d(neighbor_distances)`` of a calculator call whose pair part ran in the fused distance + pair kernels.
+
+    Those kernels differentiate through ``d = |r_j - r_i + S cell|`` in the same pass, so what they produce is already the
+    product of this gradient with the Jacobian of the distances: ``dL/dpositions`` (N,3) and ``dL/dcell`` (3,3) of the
+    pair part.  The (P,) gradient itself is only a way-point of the chain rule -- unless somebody looks at it.  The
+    calculator's backward therefore hands autograd this placeholder for the ``neighbor_distances`` slot:
+
+    * the autograd node of :func:`pair_distances` recognises it and returns the two small products it carries -- no P-sized
+      array is written or read (the reference moves ``P (16 + 3s)`` bytes here);
+    * any other consumer -- ``torch.autograd.grad(E, d)``, a hook on ``d``, the accumulation with a second consumer's
+      gradient -- touches it through an ATen op, and the first such op materialises the true (P,) tensor with the
+      stand-alone adjoint kernel (``mipme_rspace_backward``), after which it is an ordinary tensor in every respect.
+
+    So the autograd contract of the reference (output differentiable w.r.t. ``neighbor_distances``,
+    ``tests/calculators/test_workflow.py:164-192``) holds by default and the fast path stays fast.  A wrapper subclass
+    (no storage of its own); ``materialize()`` returns the plain tensor."""
+
+    @staticmethod
+    def __new__(cls, n_pairs, dtype, device, grad_pos, grad_cell, make):
+        t = torch.Tensor._make_wrapper_subclass(cls, (n_pairs,), dtype=dtype, device=device, requires_grad=False)
+        t._grad_pos, t._grad_cell, t._make, t._value = grad_pos, grad_cell, make, None
+        return t
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def materialize(self) -> torch.Tensor:
+        if self._value is None:
+            self._value = self._make()
+            self._make = None
+        return self._value
+
+    @property
+    def materialized(self) -> bool:
+        return self._value is not None
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+
+        def plain(x):
+            return x.materialize() if isinstance(x, LazyPairGradient) else x
+
+        return func(*tree_map(plain, args), **tree_map(plain, kwargs or {}))
+
+
 class _PMEFunction(torch.autograd.Function):
     """SR + LR per-atom potentials as one autograd node."""
 
     @staticmethod
     def forward(ctx, charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G, pot_desc,
-                full_list, slab_axis, src_positions=None, src_cell=None, src=None):
+                full_list, slab_axis, src_positions=None, src_cell=None, src=None, lazy=False):
         lib = _lib.load()
         device, dtype = positions.device, positions.dtype
         dt = _lib.dtype_code(dtype)
@@ -477,6 +531,8 @@ class _PMEFunction(torch.autograd.Function):
         ctx.rho_mesh, ctx.cell_partials = saved.get("rho_mesh"), saved.get("cell_partials")
         ctx.field = field
         ctx.same_positions = src_positions is positions
+        #: the pair part's gradient leaves through the neighbor_distances slot as a LazyPairGradient (see pme_potential)
+        ctx.lazy = bool(lazy) and fused is not None
         ctx.geom, ctx.pot_desc, ctx.full_list, ctx.slab_axis = geom, pot_desc, full_list, slab_axis
         ctx.topo = topo
         ctx.fused = fused  # plain tensors made here, none of them an input or output of this node
@@ -486,6 +542,7 @@ class _PMEFunction(torch.autograd.Function):
         ctx.energy_direct = bool(
             ENERGY_FAST_PATH and Cn == 1 and fused is not None and fused["force"] is not None and src_positions is positions
             and not (ni[0] or ni[1] or ni[3] or ni[12]) and slab_axis is None and (geom is None or field is not None)
+            and not lazy
         )
         return out
 
@@ -496,6 +553,9 @@ class _PMEFunction(torch.autograd.Function):
         q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins, out = ctx.saved_tensors
         geom, pot_desc, fused, topo = ctx.geom, ctx.pot_desc, ctx.fused, ctx.topo
         need_q, need_cell, need_pos, need_dist = ctx.needs_input_grad[:4]
+        lazy = ctx.lazy
+        if lazy:  # the (P,) gradient is only formed if somebody other than the distance node asks for it (see below)
+            need_dist = False
         need_src_pos = fused is not None and ctx.needs_input_grad[11]
         need_src_cell = fused is not None and fused["cell"] is not None and ctx.needs_input_grad[12]
         device, dtype = pos.device, pos.dtype
@@ -516,8 +576,16 @@ class _PMEFunction(torch.autograd.Function):
             gscale = sr_scale = None
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
                 sr_scale = tag[3]  # enough for the pair part
-                if ctx.slab_axis is None:
-                    gscale = tag[3]
+            elif ENERGY_FAST_PATH and ENERGY_DETECT and tag is None and N > 0 and not torch.cuda.is_current_stream_capturing():
+                # no tag: the caller reduced with plain tensor ops, ``(charges * V).sum()`` (README.rst:112-114) -- ask the
+                # device whether the gradient is a multiple of the charges (one small kernel + a 2-value read; the general
+                # adjoint it saves is a second spread, an FFT pair and a gradient gather).  Not during graph capture.
+                res = torch.empty((2,), dtype=dtype, device=device)
+                _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr())
+                if float(res[1]) == 1.0:
+                    sr_scale = res[:1]
+            if sr_scale is not None and ctx.slab_axis is None:
+                gscale = sr_scale
             # the mesh force field of the forward gather serves the forces AND (through cellgrad_finalize) the cell gradient
             field = ctx.field if gscale is not None else None
             cell_partials = ctx.cell_partials
@@ -641,7 +709,7 @@ class _PMEFunction(torch.autograd.Function):
 
             if sr_done and need_src_cell:
                 grad_src_cell = torch.empty((3, 3), dtype=dtype, device=device)
-            if sr_done and mesh_done and ctx.same_positions and need_src_pos:
+            if sr_done and mesh_done and ctx.same_positions and need_src_pos and not lazy:
                 # both parts differentiate the same ``positions`` tensor: one kernel, one gradient
                 grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
                 finalize(fused["force"], field, fused["partials"], grad_pos, grad_src_cell)
@@ -691,17 +759,40 @@ class _PMEFunction(torch.autograd.Function):
                     grad_pos = torch.zeros((N, 3), dtype=dtype, device=device)
                 if need_cell:
                     grad_cell = torch.zeros((3, 3), dtype=dtype, device=device)
+            if lazy and ctx.needs_input_grad[3]:
+                # the pair part leaves through the neighbor_distances slot: the products with the distance Jacobian ride in
+                # the placeholder, the (P,) gradient is formed on demand
+                def make_grad_dist(g=g, sr_scale=sr_scale):
+                    out_d = torch.empty((P,), dtype=dtype, device=device)
+                    pl = pairs if topo is None else topo.pairs32
+                    with torch.cuda.device(device):
+                        _call(
+                            "rspace_backward", lib.mipme_rspace_backward,
+                            _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
+                            dist.data_ptr(), q.data_ptr(), _lib.ptr(mask), full, C.byref(pot_desc), g.data_ptr(),
+                            _lib.ptr(sr_scale), out_d.data_ptr(), None,
+                        )
+                    return out_d
+
+                grad_dist = LazyPairGradient(P, dtype, device, grad_src_pos, grad_src_cell, make_grad_dist)
+                grad_src_pos = grad_src_cell = None
         return (grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None, grad_src_pos,
-                grad_src_cell, None)
+                grad_src_cell, None, None)
 
 
 def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
                   full_list, slab_axis):
     src = getattr(neighbor_distances, "_mipme_src", None)
     if src is not None and src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1]):
-        # differentiate straight through to the tensors the distances were built from (see FUSE_DISTANCES)
+        # the fused kernels differentiate through the distances in the same pass (see FUSE_DISTANCES)
+        if not src.direct:
+            # default: the pair part's gradient flows through ``neighbor_distances`` (lazily, LazyPairGradient) and on to
+            # positions / cell via that tensor's own node -- the reference's autograd graph
+            return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom,
+                                      G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, True)
+        # opt-in (``deferred=True``): straight to the tensors the distances were built from, bypassing ``d``
         out = _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
-                                 G, pot_desc, full_list, slab_axis, src.positions, src.cell, src)
+                                 G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, False)
         node = out.grad_fn
         if node is not None and getattr(node, "energy_direct", False):
             out._mipme_energy = (node, positions, charges, charges._version)
@@ -709,7 +800,7 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
     if src is not None and src.pending:
         src.materialize()
     return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
-                              pot_desc, full_list, slab_axis, None, None, None)
+                              pot_desc, full_list, slab_axis, None, None, None, False)
 
 
 def _launch_pair_distances(pos, cl, pairs, sh, shifts_key, out):
@@ -763,6 +854,15 @@ class _PairDistances(torch.autograd.Function):
         device, dtype = pos.device, pos.dtype
         N, P = pos.shape[0], pairs.shape[0]
         need_cell = cl is not None and ctx.needs_input_grad[1]
+        if isinstance(grad_d, LazyPairGradient) and not grad_d.materialized:
+            # sole consumer was a calculator whose fused kernels already applied this node's Jacobian (see LazyPairGradient)
+            gp = grad_d._grad_pos if ctx.needs_input_grad[0] else None
+            gc = grad_d._grad_cell if need_cell else None
+            if (gp is not None or not ctx.needs_input_grad[0]) and (gc is not None or not need_cell):
+                return gp, gc, None, None, None
+            grad_d = grad_d.materialize()  # a product the calculator did not form: take the general route
+        elif isinstance(grad_d, LazyPairGradient):
+            grad_d = grad_d.materialize()
         if P == 0:  # empty pair list: nothing depends on the positions or the cell (and there is no gradient buffer to pass)
             return ((torch.zeros((N, 3), dtype=dtype, device=device) if ctx.needs_input_grad[0] else None),
                     (torch.zeros((3, 3), dtype=dtype, device=device) if need_cell else None), None, None, None)
