@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 100
+#define MIPME_VERSION 200
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -146,11 +146,47 @@ typedef struct mipme_sr_job {
   void* force;                /* (N,3) speculative force sums, nullable */
   void* dist_out;             /* (P)   pair distances, nullable (see mipme_sr_rows_fused) */
 } mipme_sr_job_t;
-int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
-                         const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
-                         const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* atom_bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job, void* out_cell_partials);
+/* Arguments of mipme_kspace_forward as ONE versioned struct (a 23-pointer positional call is how bindings drift: a missing
+ * trailing argument is undefined behaviour through ctypes, not an error).  The caller sets `size = sizeof(struct)` as IT was
+ * compiled and `version = MIPME_ARGS_VERSION`; the library rejects a mismatching version, reads only the first `size` bytes
+ * and treats every field beyond them as zero / NULL -- fields are only ever appended.  Field meanings: the comment above. */
+#define MIPME_ARGS_VERSION 2
+typedef struct mipme_kspace_forward_args {
+  uint32_t size;
+  uint32_t version;
+  mipme_fft_plan* plan;
+  void* stream;
+  int32_t dtype;
+  int32_t accumulate_out;
+  const mipme_mesh_t* mesh;
+  const mipme_potential_t* pot;
+  int64_t n_atoms;
+  const void* positions;
+  const void* charges;
+  const void* G;
+  void* rho_mesh;
+  void* rho_hat;
+  void* hat_work;
+  void* phi_mesh;
+  void* dc;
+  void* out_lr;
+  void* out_phi;
+  void* atom_bins;
+  void* gather_wait_event;
+  void* out_field;
+  void* out_records;
+  const mipme_sr_job_t* sr_job;
+  void* out_cell_partials;
+  /* Tail of an energy + forces step folded into the gather launch (all three nullable together; needs sr_job with force sums,
+   * out_field, no slab term): out_energy (1 real) = sum_a charges_a out_lr_a -- the reduction the caller's (q * V).sum()
+   * performs (README.rst:112-114) -- and out_grad_positions (N,3) = s q_a (c force_a + field_a), the gradient of that energy
+   * w.r.t. the positions times s = grad_seed[0] (device scalar; NULL = 1), c = 1/2 for a full list: what
+   * mipme_dot_forward + mipme_sr_rows_finalize would compute in two more launches. */
+  void* out_energy;
+  void* out_grad_positions;
+  const void* grad_seed;
+} mipme_kspace_forward_args_t;
+int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
 /* out_cell_partials (nullable, needs rho_hat == NULL; float64[mipme_cellgrad_partials_size]): the x stage of the fused
  * convolution also forms the 12 k-grid sums of the cell gradient for the energy mode (dL/dG(k) = mu(k) |rho^(k)|^2 up to
  * gE / 2V) while rho^ is in LDS -- mipme_fft_plan_kgrid_blocks(plan) partial sums that mipme_kspace_backward takes as
@@ -196,7 +232,14 @@ typedef struct mipme_frame {
   void* dist_out;             /* (P) nullable */
   void* energy;               /* 1 real */
   void* grad_positions;       /* (N,3) */
+  /* gather tail (see mipme_kspace_forward_args_t.out_energy): when tail_scratch != NULL the gather of the forward call also
+   * forms energy and grad_positions = grad_seed[0] q_a (c force_a + field_a) (grad_seed NULL = 1) -- no energy launch, and
+   * mipme_frames_backward is only needed for a different seed.  tail_scratch: mipme_gather_tail_scratch_bytes(mesh) bytes,
+   * zero before the first use (every call leaves it zero). */
+  void* tail_scratch;
+  const void* grad_seed;
 } mipme_frame_t;
+int64_t mipme_gather_tail_scratch_bytes(const mipme_mesh_t* mesh);
 int64_t mipme_frames_table_bytes(int dtype, int n_frames);
 int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frames, const mipme_potential_t* pot,
                              void* host_table, int64_t host_table_bytes);
@@ -220,13 +263,39 @@ int mipme_fft_plan_xfused(const mipme_fft_plan* plan);
  * the cell gradient are formed from the saved rho_hat alone (dL/dG = (gE/2V) mu |rho^|^2): needs rho_hat, phi_atoms,
  * partials and grad_positions, as in the general case.
  * psi_hat == NULL (only without grad_cell, plans with mipme_fft_plan_xfused): fused convolution as in the forward. */
-int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
-                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
-                          const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
-                          const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
-                          void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* atom_bins, const void* grad_scale, const void* mesh_field,
-                          int64_t kgrid_blocks_ready);
+typedef struct mipme_kspace_backward_args {
+  uint32_t size;     /* as mipme_kspace_forward_args_t */
+  uint32_t version;
+  mipme_fft_plan* plan;
+  void* stream;
+  int32_t dtype;
+  int32_t _pad;
+  const mipme_mesh_t* mesh;
+  const mipme_potential_t* pot;
+  int64_t n_atoms;
+  const void* positions;
+  const void* charges;
+  const void* grad_out;
+  const void* G;
+  const void* phi_mesh;
+  const void* rho_hat;
+  const void* rho_dc;
+  const void* phi_atoms;
+  void* psi_mesh;
+  void* psi_hat;
+  void* hat_work;
+  void* chi_mesh;
+  void* dc;
+  void* partials;
+  void* grad_positions;
+  void* grad_charges;
+  void* grad_cell;
+  void* atom_bins;
+  const void* grad_scale;
+  const void* mesh_field;
+  int64_t kgrid_blocks_ready;
+} mipme_kspace_backward_args_t;
+int mipme_kspace_backward(const mipme_kspace_backward_args_t* args);
 /* Energy mode extras (grad_scale != NULL): mesh_field (nullable; out_field of the forward call) with grad_positions ==
  * grad_charges == NULL -- no gradient gather, the mesh part of dL/dr is grad_scale q_a field_a (the caller assembles the
  * forces with mipme_sr_rows_finalize; the cell gradient uses the same expression); kgrid_blocks_ready > 0 -- `partials`

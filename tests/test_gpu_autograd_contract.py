@@ -163,7 +163,9 @@ def test_energy_gradient_detected_without_tag(dtype, monkeypatch):
     t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=dtype, requires_grad=grad)  # noqa: E731
     tq, tc = t(q), t(cell)
     ti, tS = torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV)
-    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.1), mesh_spacing=0.9, interpolation_nodes=4).to(dtype)
+    # mesh_spacing 0.45 -> (64, 32, 64): large enough for the brick kernels, whose forward gather forms the mesh force field
+    # the energy-mode backward needs (smaller meshes take the atomic kernels and a cheap energy-mode kspace_backward)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.1), mesh_spacing=0.45, interpolation_nodes=4).to(dtype)
     gen = t(rng.normal(size=q.shape))
 
     def run(reduce, detect):

@@ -34,7 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
-    "mipme_scaled_match",
+    "mipme_scaled_match", "mipme_gather_tail_scratch_bytes",
 )
 
 
@@ -111,6 +111,54 @@ class Frame(C.Structure):
         ("dist_out", C.c_void_p),
         ("energy", C.c_void_p),
         ("grad_positions", C.c_void_p),
+        ("tail_scratch", C.c_void_p),
+        ("grad_seed", C.c_void_p),
+    ]
+
+
+ARGS_VERSION = 2
+
+
+class _VersionedArgs(C.Structure):
+    """Base of the versioned argument structs (``include/mipme.h``): ``size`` / ``version`` are filled in here, every other
+    field is passed by NAME -- a binding that forgets a field passes NULL for it instead of shifting the rest."""
+
+    def __init__(self, **fields):
+        unknown = set(fields) - {name for name, _ in self._fields_}
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unknown field(s) {sorted(unknown)}")
+        super().__init__(size=C.sizeof(type(self)), version=ARGS_VERSION, **fields)
+
+
+class KspaceForwardArgs(_VersionedArgs):
+    """``mipme_kspace_forward_args_t``"""
+
+    _fields_ = [
+        ("size", C.c_uint32), ("version", C.c_uint32),
+        ("plan", C.c_void_p), ("stream", C.c_void_p), ("dtype", C.c_int32), ("accumulate_out", C.c_int32),
+        ("mesh", C.POINTER(MeshDesc)), ("pot", C.POINTER(PotentialDesc)), ("n_atoms", C.c_int64),
+        ("positions", C.c_void_p), ("charges", C.c_void_p), ("G", C.c_void_p),
+        ("rho_mesh", C.c_void_p), ("rho_hat", C.c_void_p), ("hat_work", C.c_void_p), ("phi_mesh", C.c_void_p),
+        ("dc", C.c_void_p), ("out_lr", C.c_void_p), ("out_phi", C.c_void_p), ("atom_bins", C.c_void_p),
+        ("gather_wait_event", C.c_void_p), ("out_field", C.c_void_p), ("out_records", C.c_void_p),
+        ("sr_job", C.POINTER(SrJob)), ("out_cell_partials", C.c_void_p),
+        ("out_energy", C.c_void_p), ("out_grad_positions", C.c_void_p), ("grad_seed", C.c_void_p),
+    ]
+
+
+class KspaceBackwardArgs(_VersionedArgs):
+    """``mipme_kspace_backward_args_t``"""
+
+    _fields_ = [
+        ("size", C.c_uint32), ("version", C.c_uint32),
+        ("plan", C.c_void_p), ("stream", C.c_void_p), ("dtype", C.c_int32), ("_pad", C.c_int32),
+        ("mesh", C.POINTER(MeshDesc)), ("pot", C.POINTER(PotentialDesc)), ("n_atoms", C.c_int64),
+        ("positions", C.c_void_p), ("charges", C.c_void_p), ("grad_out", C.c_void_p), ("G", C.c_void_p),
+        ("phi_mesh", C.c_void_p), ("rho_hat", C.c_void_p), ("rho_dc", C.c_void_p), ("phi_atoms", C.c_void_p),
+        ("psi_mesh", C.c_void_p), ("psi_hat", C.c_void_p), ("hat_work", C.c_void_p), ("chi_mesh", C.c_void_p),
+        ("dc", C.c_void_p), ("partials", C.c_void_p), ("grad_positions", C.c_void_p), ("grad_charges", C.c_void_p),
+        ("grad_cell", C.c_void_p), ("atom_bins", C.c_void_p), ("grad_scale", C.c_void_p), ("mesh_field", C.c_void_p),
+        ("kgrid_blocks_ready", C.c_int64),
     ]
 
 
@@ -149,8 +197,8 @@ def _declare(lib):
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
-        "mipme_kspace_forward": [vp, vp, ci, MP, PP, i64] + [vp] * 12 + [ci, vp, vp, C.POINTER(SrJob), vp],
-        "mipme_kspace_backward": [vp, vp, ci, MP, PP, i64] + [vp] * 19 + [vp, i64],
+        "mipme_kspace_forward": [C.POINTER(KspaceForwardArgs)],
+        "mipme_kspace_backward": [C.POINTER(KspaceBackwardArgs)],
         "mipme_slab_forward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp],
         "mipme_slab_backward": [vp, ci, ci, MP, dbl, i64, vp, vp, vp, vp, vp, vp, vp],
         "mipme_rspace_forward": [vp, ci, ci, i64, i64, ci, vp, vp, vp, vp, ci, PP, ci, vp],
@@ -201,6 +249,8 @@ def _declare(lib):
     lib.mipme_fft_plan_xfused.argtypes = [vp]
     lib.mipme_fft_plan_kgrid_blocks.restype = i64
     lib.mipme_fft_plan_kgrid_blocks.argtypes = [vp]
+    lib.mipme_gather_tail_scratch_bytes.restype = i64
+    lib.mipme_gather_tail_scratch_bytes.argtypes = [MP]
     lib.mipme_frames_table_bytes.restype = i64
     lib.mipme_frames_table_bytes.argtypes = [ci, ci]
     lib.mipme_profile_enable.restype = ci

@@ -56,7 +56,7 @@ template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_
                                         const mipme_sr_job_t*);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
-template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
@@ -117,7 +117,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
                             void* wait_event, int accumulate, void* out_field, void* out_records,
-                            const mipme_sr_job_t* job, void* cell_partials) {
+                            const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -155,7 +155,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   // the short-range sum may be running on another stream into out_lr: join it before the gather adds to it
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
-    STAGE(st, "gather", gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field));
+    STAGE(st, tail ? "gather+energy+forces" : "gather",
+          gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field, tail));
   else
     STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
   return MIPME_OK;
@@ -462,6 +463,24 @@ static int slab_backward_t(hipStream_t st, int axis, const mipme_mesh_t* m, doub
 
 }  // namespace mipme
 
+namespace mipme {
+int64_t gather_tail_scratch_bytes(const mipme_mesh_t*);
+void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
+}
+// Copy a caller's versioned argument struct into the library's own layout: only the first `size` bytes the caller
+// compiled are read, everything after them stays zero (fields are only ever appended).
+template <typename A>
+static int load_args(const A* in, A& out, const char* what) {
+  MIPME_REQUIRE(in != nullptr, "%s: NULL argument struct", what);
+  MIPME_REQUIRE(in->version == MIPME_ARGS_VERSION, "%s: argument struct version %u, library expects %u", what, in->version,
+                unsigned(MIPME_ARGS_VERSION));
+  MIPME_REQUIRE(in->size >= 16 && in->size <= 4096, "%s: implausible argument struct size %u", what, in->size);
+  memset(&out, 0, sizeof(A));
+  memcpy(&out, in, in->size < sizeof(A) ? in->size : sizeof(A));
+  return MIPME_OK;
+}
+
+
 using namespace mipme;
 
 #define DT_SWITCH(dtype, CALL_F32, CALL_F64)                    \
@@ -527,64 +546,79 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
             gather_impl<double>(st, mesh, n_atoms, positions, mesh_in, out));
 }
 
-int mipme_kspace_forward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
-                         const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
-                         const void* G, void* rho_mesh, void* rho_hat, void* hat_work, void* phi_mesh, void* dc,
-                         void* out_lr, void* out_phi, void* bins, void* gather_wait_event, int accumulate_out,
-                         void* out_field, void* out_records, const mipme_sr_job_t* sr_job, void* out_cell_partials) {
-  int rc = validate_mesh(mesh);
+int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
+  mipme_kspace_forward_args_t a;
+  int rc = load_args(args_in, a, "mipme_kspace_forward");
   if (rc) return rc;
-  if ((rc = check_plan(plan, dtype, mesh))) return rc;
-  MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
-  MIPME_REQUIRE(G && rho_mesh && hat_work && phi_mesh && dc, "NULL work buffer passed to mipme_kspace_forward");
-  MIPME_REQUIRE(rho_hat || fft_plan_xfused(plan), "rho_hat may only be NULL for plans with a power-of-two nx");
-  MIPME_REQUIRE(!out_cell_partials || !rho_hat, "out_cell_partials is produced by the fused convolution (rho_hat == NULL)");
-  MIPME_REQUIRE(n_atoms == 0 || (positions && charges && out_lr), "NULL atom buffer passed to mipme_kspace_forward");
-  MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
-  MIPME_REQUIRE(!out_field || (bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
-  MIPME_REQUIRE(!out_records || (bins && mesh->n_channels == 1), "out_records needs atom bins and a single channel");
-  if (sr_job) {
-    MIPME_REQUIRE(bins && out_records && mesh->n_channels == 1 && accumulate_out && !gather_wait_event,
+  if ((rc = validate_mesh(a.mesh))) return rc;
+  if ((rc = check_plan(a.plan, a.dtype, a.mesh))) return rc;
+  const mipme_mesh_t* mesh = a.mesh;
+  MIPME_REQUIRE(a.pot && a.pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
+  MIPME_REQUIRE(a.G && a.rho_mesh && a.hat_work && a.phi_mesh && a.dc, "NULL work buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(a.rho_hat || fft_plan_xfused(a.plan), "rho_hat may only be NULL for plans with a power-of-two nx");
+  MIPME_REQUIRE(!a.out_cell_partials || !a.rho_hat, "out_cell_partials is produced by the fused convolution (rho_hat == NULL)");
+  MIPME_REQUIRE(a.n_atoms == 0 || (a.positions && a.charges && a.out_lr), "NULL atom buffer passed to mipme_kspace_forward");
+  MIPME_REQUIRE(!a.atom_bins || bricks_supported(mesh, a.dtype), "atom bins passed for a mesh the brick kernels do not support");
+  MIPME_REQUIRE(!a.out_field || (a.atom_bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
+  MIPME_REQUIRE(!a.out_records || (a.atom_bins && mesh->n_channels == 1), "out_records needs atom bins and a single channel");
+  if (a.sr_job) {
+    MIPME_REQUIRE(a.atom_bins && a.out_records && mesh->n_channels == 1 && a.accumulate_out && !a.gather_wait_event,
                   "sr_job needs atom bins, out_records, a single channel and accumulate_out = 1 without a wait event");
-    MIPME_REQUIRE(sr_job->n_atoms == n_atoms && sr_job->records == out_records && sr_job->out == out_lr,
+    MIPME_REQUIRE(a.sr_job->n_atoms == a.n_atoms && a.sr_job->records == a.out_records && a.sr_job->out == a.out_lr,
                   "sr_job must describe the atoms, records and output of the same call");
-    MIPME_REQUIRE(sr_job->row_ptr && sr_job->entries_shift && sr_job->entries && sr_job->positions && sr_job->charges &&
-                      sr_job->pot, "NULL buffer in sr_job");
+    MIPME_REQUIRE(a.sr_job->row_ptr && a.sr_job->entries_shift && a.sr_job->entries && a.sr_job->positions &&
+                      a.sr_job->charges && a.sr_job->pot, "NULL buffer in sr_job");
   }
-  hipStream_t st = (hipStream_t)stream;
-  DT_SWITCH(dtype,
-            kspace_forward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                    phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job, out_cell_partials),
-            kspace_forward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, G, rho_mesh, rho_hat, hat_work,
-                                     phi_mesh, dc, out_lr, out_phi, bins, gather_wait_event, accumulate_out, out_field, out_records, sr_job, out_cell_partials));
+  GatherTailHost tail{}, *tp = nullptr;
+  if (a.out_energy || a.out_grad_positions) {
+    MIPME_REQUIRE(a.out_energy && a.out_grad_positions && a.sr_job && a.sr_job->force && a.out_field && a.n_atoms > 0,
+                  "the gather tail (out_energy, out_grad_positions) needs both outputs, sr_job with force sums and out_field");
+    tail.force = a.sr_job->force;
+    tail.force_scale = a.sr_job->full_list ? 0.5 : 1.0;
+    tail.seed = a.grad_seed;
+    tail.grad_pos = a.out_grad_positions;
+    tail.energy = a.out_energy;
+    tail.scratch = fft_plan_tail_scratch(a.plan, gather_tail_scratch_bytes(mesh));
+    MIPME_REQUIRE(tail.scratch, "could not allocate the gather tail scratch (not possible during stream capture: run one "
+                                "evaluation before capturing)");
+    tp = &tail;
+  }
+  hipStream_t st = (hipStream_t)a.stream;
+  DT_SWITCH(a.dtype,
+            kspace_forward_t<float>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
+                                    a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
+                                    a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp),
+            kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
+                                     a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
+                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp));
 }
 
-int mipme_kspace_backward(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mesh_t* mesh,
-                          const mipme_potential_t* pot, int64_t n_atoms, const void* positions, const void* charges,
-                          const void* grad_out, const void* G, const void* phi_mesh, const void* rho_hat,
-                          const void* rho_dc, const void* phi_atoms, void* psi_mesh, void* psi_hat, void* hat_work,
-                          void* chi_mesh, void* dc, void* partials, void* grad_positions, void* grad_charges,
-                          void* grad_cell, void* bins, const void* grad_scale, const void* mesh_field,
-                          int64_t kgrid_blocks_ready) {
-  int rc = validate_mesh(mesh);
+int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {
+  mipme_kspace_backward_args_t a;
+  int rc = load_args(args_in, a, "mipme_kspace_backward");
   if (rc) return rc;
-  if ((rc = check_plan(plan, dtype, mesh))) return rc;
-  MIPME_REQUIRE(pot && pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
-  MIPME_REQUIRE(G && phi_mesh && (grad_scale || (psi_mesh && hat_work && chi_mesh && dc)),
+  if ((rc = validate_mesh(a.mesh))) return rc;
+  if ((rc = check_plan(a.plan, a.dtype, a.mesh))) return rc;
+  MIPME_REQUIRE(a.pot && a.pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
+  MIPME_REQUIRE(a.G && a.phi_mesh && (a.grad_scale || (a.psi_mesh && a.hat_work && a.chi_mesh && a.dc)),
                 "NULL work buffer passed to mipme_kspace_backward");
-  MIPME_REQUIRE(grad_scale || psi_hat || (!grad_cell && fft_plan_xfused(plan)),
+  MIPME_REQUIRE(a.grad_scale || a.psi_hat || (!a.grad_cell && fft_plan_xfused(a.plan)),
                 "psi_hat may only be NULL without a cell gradient and for plans with a power-of-two nx");
-  MIPME_REQUIRE(n_atoms == 0 || (positions && charges && grad_out), "NULL atom buffer passed to mipme_kspace_backward");
-  MIPME_REQUIRE(!bins || bricks_supported(mesh, dtype), "atom bins passed for a mesh the brick kernels do not support");
-  hipStream_t st = (hipStream_t)stream;
-  DT_SWITCH(dtype,
-            kspace_backward_t<float>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
-                                     rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                     grad_positions, grad_charges, grad_cell, bins, grad_scale, mesh_field, kgrid_blocks_ready),
-            kspace_backward_t<double>(plan, st, mesh, pot, n_atoms, positions, charges, grad_out, G, phi_mesh, rho_hat,
-                                      rho_dc, phi_atoms, psi_mesh, psi_hat, hat_work, chi_mesh, dc, partials,
-                                      grad_positions, grad_charges, grad_cell, bins, grad_scale, mesh_field, kgrid_blocks_ready));
+  MIPME_REQUIRE(a.n_atoms == 0 || (a.positions && a.charges && a.grad_out), "NULL atom buffer passed to mipme_kspace_backward");
+  MIPME_REQUIRE(!a.atom_bins || bricks_supported(a.mesh, a.dtype), "atom bins passed for a mesh the brick kernels do not support");
+  hipStream_t st = (hipStream_t)a.stream;
+  DT_SWITCH(a.dtype,
+            kspace_backward_t<float>(a.plan, st, a.mesh, a.pot, a.n_atoms, a.positions, a.charges, a.grad_out, a.G, a.phi_mesh,
+                                     a.rho_hat, a.rho_dc, a.phi_atoms, a.psi_mesh, a.psi_hat, a.hat_work, a.chi_mesh, a.dc,
+                                     a.partials, a.grad_positions, a.grad_charges, a.grad_cell, a.atom_bins, a.grad_scale,
+                                     a.mesh_field, a.kgrid_blocks_ready),
+            kspace_backward_t<double>(a.plan, st, a.mesh, a.pot, a.n_atoms, a.positions, a.charges, a.grad_out, a.G, a.phi_mesh,
+                                      a.rho_hat, a.rho_dc, a.phi_atoms, a.psi_mesh, a.psi_hat, a.hat_work, a.chi_mesh, a.dc,
+                                      a.partials, a.grad_positions, a.grad_charges, a.grad_cell, a.atom_bins, a.grad_scale,
+                                      a.mesh_field, a.kgrid_blocks_ready));
 }
+
+int64_t mipme_gather_tail_scratch_bytes(const mipme_mesh_t* mesh) { return mesh ? gather_tail_scratch_bytes(mesh) : 0; }
 
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan) { return plan && fft_plan_xfused(plan) ? 1 : 0; }
 

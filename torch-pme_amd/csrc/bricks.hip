@@ -574,14 +574,88 @@ __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz
 // dependent 32-lane shuffle steps -- measured: 1.5 us per pass, not hidden by prefetching.)
 static constexpr int kGatherLanes = 8;
 
-template <int N, bool FIELD, typename T>
+// ---- tail of the energy + forces step, folded into the gather (TAIL = true) ------------------------------------------
+// When the potentials the gather completes are final (the pair sum ran before it: co-scheduled launch) the same kernel forms
+//   energy          = sum_a q_a V_a                      (what the caller's (q * V).sum() / weighted_sum computes), and
+//   grad_positions  = s q_a (c F_a + field_a)            (what the energy-mode backward computes; F = pair force sums,
+//                                                         c = 1/2 for a full list, s = seed[0] or 1),
+// which removes the energy-reduction and force-assembly launches of a step (4.8 + 4.2 us of 84 at cfg3, both pure launch
+// latency).  The energy is reduced deterministically: per-brick partial sums (fp64), then a two-level last-arrival ticket
+// (groups of kTailGroup bricks, then the groups) -- at most kTailGroup + n_groups same-address atomics in series instead
+// of one per brick.  partials: fp64[nb + n_groups]; tickets: int[n_groups + 1], zero between calls.
+static constexpr int kTailGroup = 32;
+
+template <typename T>
+struct GatherTail {
+  const T* force;     // (N,3) pair force sums
+  T force_scale;      // c
+  const T* seed;      // device scalar, nullable (= 1)
+  T* grad_pos;        // (N,3)
+  T* energy;          // 1
+  double* partials;
+  int* tickets;
+};
+
+static inline int tail_groups(int nb) { return (nb + kTailGroup - 1) / kTailGroup; }
+int64_t gather_tail_scratch_bytes(const mipme_mesh_t* m) {
+  const int nb = make_brick_geom(m).nb;
+  return int64_t(sizeof(double)) * (nb + tail_groups(nb)) + int64_t(sizeof(int)) * (tail_groups(nb) + 1);
+}
+
+// e = this thread's share of the brick's energy; every thread of the workgroup calls (uniform control flow)
+template <typename T, int THREADS>
+__device__ __forceinline__ void tail_reduce_energy(double e, const GatherTail<T>& tail, unsigned block, unsigned nb) {
+  __shared__ double tred[THREADS / 64];
+  __shared__ int tflag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+  if (lane == 0) tred[wave] = e;
+  __syncthreads();
+  const unsigned n_groups = (nb + kTailGroup - 1) / kTailGroup;
+  const unsigned grp = block / kTailGroup;
+  const unsigned gsize = min(unsigned(kTailGroup), nb - grp * kTailGroup);
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) tot += tred[w];
+    __hip_atomic_store(&tail.partials[block], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(&tail.tickets[grp], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    int state = 0;
+    if (ticket == int(gsize) - 1) {  // last brick of its group: group sum in index order
+      double gs = 0.0;
+      for (unsigned k = 0; k < gsize; ++k)
+        gs += __hip_atomic_load(&tail.partials[grp * kTailGroup + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&tail.partials[nb + grp], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&tail.tickets[grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int top = __hip_atomic_fetch_add(&tail.tickets[n_groups], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      state = top == int(n_groups) - 1 ? 1 : 0;
+    }
+    tflag = state;
+  }
+  __syncthreads();
+  if (!tflag || wave != 0) return;
+  // the last group to finish: sum of the group sums, fixed order (lane-strided, then the xor tree)
+  double tot = 0.0;
+  for (unsigned k = lane; k < n_groups; k += 64)
+    tot += __hip_atomic_load(&tail.partials[nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+  if (lane == 0) {
+    tail.energy[0] = T(tot);
+    __hip_atomic_store(&tail.tickets[n_groups], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int N, bool FIELD, typename T, bool TAIL = false>
 __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom& bg, int C, const int* __restrict__ start,
                                                   const int4* __restrict__ rec, const T* __restrict__ wts,
                                                   const T* __restrict__ mesh, const T* __restrict__ q,
                                                   const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c, bool accumulate,
                                                   T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
-                                                  unsigned block) {
+                                                  unsigned block, const GatherTail<T>* tail = nullptr) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
+  static_assert(!TAIL || FIELD, "the tail needs the mesh field");
   constexpr int LANES = kGatherLanes;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
@@ -590,7 +664,15 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int beg = start[block], end = start[block + 1];
-  if (beg == end) return;
+  double e_acc = 0.0;  // TAIL: this thread's share of sum_a q_a V_a
+  T seed = T(1);
+  if constexpr (TAIL) {
+    if (tail->seed) seed = tail->seed[0];
+  }
+  if (beg == end) {
+    if constexpr (TAIL) tail_reduce_energy<T, GATHER_THREADS>(0.0, *tail, block, unsigned(bg.nb));
+    return;
+  }
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
   const bool lane_active = l < N;
@@ -631,6 +713,8 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
         q_early = q[o_early];
         if (accumulate) out_early = out[o_early];
       }
+      T f_early = T(0);  // TAIL: lanes 0..2 hold the x, y, z components of the atom's pair force sum
+      if constexpr (TAIL) f_early = tail->force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
       if (base == beg) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       const T* tp = tile + ry * TL + (rz + tz);
@@ -655,7 +739,16 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
         const T fx = group_sum_b<LANES, T>(sB * wzv) * T(g.nx) * inv_vol;
         const T fy = group_sum_b<LANES, T>(sC * wzv) * T(g.ny) * inv_vol;
         const T fz = group_sum_b<LANES, T>(sA * dwzv) * T(g.nz) * inv_vol;
-        if (l == 0 && valid) {
+        if constexpr (TAIL) {
+          // lanes 0..2 own one Cartesian component each: field (kept for other consumers) and the assembled gradient
+          const int k3 = l < 3 ? l : 0;
+          const T fc = T(g.inv[3 * k3]) * fx + T(g.inv[3 * k3 + 1]) * fy + T(g.inv[3 * k3 + 2]) * fz;
+          if (l < 3 && valid) {
+            const int64_t o = int64_t(a.w);
+            field[3 * o + l] = fc;
+            tail->grad_pos[3 * o + l] = seed * q_early * (tail->force_scale * f_early + fc);
+          }
+        } else if (l == 0 && valid) {
           const int64_t o = int64_t(a.w);
           field[3 * o + 0] = T(g.inv[0]) * fx + T(g.inv[1]) * fy + T(g.inv[2]) * fz;
           field[3 * o + 1] = T(g.inv[3]) * fx + T(g.inv[4]) * fy + T(g.inv[5]) * fz;
@@ -668,14 +761,17 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
         if (q) {
           const T phi = acc * inv_vol;
           const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[c]);
-          out[o] = accumulate ? out_early + lr : lr;
+          const T v_final = accumulate ? out_early + lr : lr;
+          out[o] = v_final;
           if (raw) raw[o] = phi;
+          if constexpr (TAIL) e_acc += double(q_early) * double(v_final);
         } else {
           out[o] = acc;
         }
       }
     }
   }
+  if constexpr (TAIL) tail_reduce_energy<T, GATHER_THREADS>(e_acc, *tail, block, unsigned(bg.nb));
 }
 
 template <int N, bool FIELD, typename T>
@@ -689,6 +785,18 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      T* __restrict__ raw, T* __restrict__ field) {
   gather_brick_body<N, FIELD, T>(g, bg, C, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
                                  blockIdx.x);
+}
+
+// gather + energy + force assembly (see GatherTail)
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, const int* __restrict__ start,
+                                                                    const int4* __restrict__ rec, const T* __restrict__ wts,
+                                                                    const T* __restrict__ mesh, const T* __restrict__ q,
+                                                                    const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
+                                                                    T* __restrict__ out, T* __restrict__ raw,
+                                                                    T* __restrict__ field, GatherTail<T> tail) {
+  gather_brick_body<N, true, T, true>(g, bg, 1, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw, field,
+                                      blockIdx.x, &tail);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -924,15 +1032,35 @@ bool sr_job_fusable(const mipme_sr_job_t* job) {
   return pfast == 1 || pfast == 6;
 }
 
+// tail (nullable): energy + force assembly in the same launch (needs field, accumulate, a single channel)
 template <typename T>
 int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
-                  const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate, void* field) {
+                  const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate, void* field,
+                  const GatherTailHost* th) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
   MIPME_REQUIRE(!field || m->n_channels == 1, "the field output of the gather is single-channel");
+  if (th) {
+    MIPME_REQUIRE(field && accumulate && q && th->force && th->grad_pos && th->energy && th->scratch,
+                  "the gather tail needs the field output, accumulate = 1, pair force sums and output buffers");
+    GatherTail<T> tail;
+    tail.force = (const T*)th->force;
+    tail.force_scale = T(th->force_scale);
+    tail.seed = (const T*)th->seed;
+    tail.grad_pos = (T*)th->grad_pos;
+    tail.energy = (T*)th->energy;
+    tail.partials = (double*)th->scratch;
+    tail.tickets = (int*)((double*)th->scratch + bg.nb + tail_groups(bg.nb));
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                                 g, bg, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
+                                 T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail)));
+    MIPME_LAUNCH_CHECK();
+    return MIPME_OK;
+  }
   if (field)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_brick_kernel<N, true, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
@@ -1001,6 +1129,8 @@ struct FrameDev {
   const T* force;
   T* grad_pos;
   T force_scale;  // 1/2 for a full list
+  // gather tail (energy + forces in the gather launch); tail.partials == nullptr: separate energy / finalize kernels
+  GatherTail<T> tail;
 };
 
 template <typename T>
@@ -1033,6 +1163,14 @@ __global__ __launch_bounds__(GATHER_THREADS) void frames_gather_kernel(const Fra
   const FrameDev<T>& f = table[blockIdx.y];
   gather_brick_body<N, true, T>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c, true,
                                 f.out, nullptr, f.field, blockIdx.x);
+}
+
+// the same with the tail: every frame of the batch carries tail scratch
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void frames_gather_tail_kernel(const FrameDev<T>* __restrict__ table) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  gather_brick_body<N, true, T, true>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c,
+                                      true, f.out, nullptr, f.field, blockIdx.x, &f.tail);
 }
 
 // energy[f] = sum_a q_a V_a: one workgroup per frame, fixed summation order
@@ -1153,6 +1291,13 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.force = (const T*)f.force;
     d.grad_pos = (T*)f.grad_positions;
     d.force_scale = f.full_list ? T(0.5) : T(1);
+    d.tail.force = d.force;
+    d.tail.force_scale = d.force_scale;
+    d.tail.seed = (const T*)f.grad_seed;
+    d.tail.grad_pos = d.grad_pos;
+    d.tail.energy = d.energy;
+    d.tail.partials = (double*)f.tail_scratch;
+    d.tail.tickets = f.tail_scratch ? (int*)((double*)f.tail_scratch + d.bg.nb + tail_groups(d.bg.nb)) : nullptr;
     out[k] = d;
   }
   return MIPME_OK;
@@ -1191,6 +1336,14 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   MIPME_LAUNCH_CHECK();
   int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr);
   if (rc) return rc;
+  bool all_tail = true;
+  for (int k = 0; k < n_frames; ++k) all_tail = all_tail && fr[k].tail_scratch != nullptr;
+  if (all_tail) {  // energy + forces of every frame in the gather launch
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, frames_gather_tail_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(tb)));
+    MIPME_LAUNCH_CHECK();
+    return MIPME_OK;
+  }
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                            ((void)S, frames_gather_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(tb)));
   MIPME_LAUNCH_CHECK();
@@ -1206,9 +1359,9 @@ template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, voi
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                    const mipme_sr_job_t*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                  double, double, void*, void*, int, void*);
+                                  double, double, void*, void*, int, void*, const GatherTailHost*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                   double, double, void*, void*, int, void*);
+                                   double, double, void*, void*, int, void*, const GatherTailHost*);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
                                        const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,

@@ -208,6 +208,16 @@ struct StencilGroup {
   static constexpr int LANES = PLANE <= 1 ? 1 : PLANE <= 4 ? 4 : PLANE <= 16 ? 16 : PLANE <= 32 ? 32 : 64;
 };
 
+// Host-side description of the gather's tail (energy + force assembly in the gather launch, csrc/bricks.hip GatherTail)
+struct GatherTailHost {
+  const void* force;   // (N,3) pair force sums
+  double force_scale;  // 1/2 for a full list
+  const void* seed;    // device scalar, nullable
+  void* grad_pos;      // (N,3)
+  void* energy;        // 1 real
+  void* scratch;       // gather_tail_scratch_bytes(), zero between calls
+};
+
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position
 // and charge (or source value).  Written by pack_atom_records_kernel (topology.hip) or by the binning pass (bricks.hip).
 template <typename T>

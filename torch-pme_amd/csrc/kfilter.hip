@@ -334,6 +334,9 @@ struct mipme_fft_plan {
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
   int* brick_count = nullptr;
+  // scratch of the gather tail (csrc/bricks.hip GatherTail: per-brick energy partials + tickets), zero between calls
+  void* tail_scratch = nullptr;
+  int64_t tail_bytes = 0;
 };
 
 namespace mipme {
@@ -1085,6 +1088,21 @@ struct FftDims { int dtype, nx, ny, nz, batch; };
 FftDims fft_plan_dims(const mipme_fft_plan* p) { return FftDims{p->dtype, p->nx, p->ny, p->nz, p->batch}; }
 int* fft_plan_brick_count(const mipme_fft_plan* p) { return p->brick_count; }
 
+// Allocated on first use (a synchronous hipMalloc + hipMemset: not during stream capture -- the callers warm up first).
+void* fft_plan_tail_scratch(mipme_fft_plan* p, int64_t bytes) {
+  if (p->tail_scratch && p->tail_bytes >= bytes) return p->tail_scratch;
+  if (p->tail_scratch) return nullptr;  // the size is a function of the plan's mesh: cannot change
+  void* buf = nullptr;
+  if (hipMalloc(&buf, size_t(bytes)) != hipSuccess || hipMemset(buf, 0, size_t(bytes)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (buf) (void)hipFree(buf);
+    return nullptr;
+  }
+  p->tail_scratch = buf;
+  p->tail_bytes = bytes;
+  return buf;
+}
+
 int fft_plan_destroy(mipme_fft_plan* p) {
   if (!p) return MIPME_OK;
   if (p->fwd) hipfftDestroy(p->fwd);
@@ -1092,6 +1110,7 @@ int fft_plan_destroy(mipme_fft_plan* p) {
   if (p->fwd2d) hipfftDestroy(p->fwd2d);
   if (p->inv2d) hipfftDestroy(p->inv2d);
   if (p->brick_count) (void)hipFree(p->brick_count);
+  if (p->tail_scratch) (void)hipFree(p->tail_scratch);
   delete p;
   return MIPME_OK;
 }

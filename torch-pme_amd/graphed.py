@@ -83,7 +83,13 @@ class GraphedEnergyForces:
         d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts, deferred=True)
         #: the pair distances of the last evaluation (P,)
         self.distances = d.detach()
-        V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
+        # the backward pass below is seeded with self._minus_one: promise that to the forward, whose gather then writes the
+        # forces themselves (energy reduction and force assembly ride in the gather launch, see ops.SEED_PROMISE)
+        ops.SEED_PROMISE = None if self.cell_gradient else self._minus_one
+        try:
+            V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
+        finally:
+            ops.SEED_PROMISE = None
         E = ops.weighted_sum(V, self.q)
         E.backward(self._minus_one)
         return E.detach()
@@ -112,8 +118,11 @@ class _FramesFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         batch = ctx.batch
-        batch._launch_backward(g.contiguous())
-        return (None, *batch._grad_pos)
+        # seeded with the batch's own -1 vector the gradients are already there (written by the gather's tail of the forward
+        # pass); fresh aliases, so that the accumulation into positions.grad takes the buffers instead of copying them
+        if g.data_ptr() != batch._minus_one.data_ptr():
+            batch._launch_backward(g.contiguous())
+        return (None, *(b.detach() for b in batch._grad_pos))
 
 
 class GraphedFrameBatch:
@@ -163,6 +172,7 @@ class GraphedFrameBatch:
         self.energies = torch.empty((F,), dtype=dtype, device=device)
         self._plan = _lib.FFTPlan(device, dtype, ns, F)
         self._frames = (_lib.Frame * F)()
+        self._minus_one = torch.full((F,), -1.0, dtype=dtype, device=device)
         self._grad_pos, self.distances = [], []
         for k, (q, cell, pos, pairs, shifts) in enumerate(frames):
             N, P = pos.shape[0], pairs.shape[0]
@@ -179,7 +189,9 @@ class GraphedFrameBatch:
             if nbytes <= 0:
                 raise ValueError(f"frame {k}: mesh {ns} is outside the brick kernels' range")
             nb = ((ns[0] + 7) // 8) * ((ns[1] + 7) // 8) * ((ns[2] + 7) // 8)
+            tail_bytes = lib.mipme_gather_tail_scratch_bytes(C.byref(md))
             buf = dict(
+                tail=torch.zeros(((tail_bytes + 7) // 8,), dtype=torch.float64, device=device),
                 bins=torch.empty((nbytes,), dtype=torch.uint8, device=device),
                 counters=torch.zeros((nb + 1,), dtype=torch.int32, device=device),
                 records=torch.empty((N, 4), dtype=dtype, device=device),
@@ -199,6 +211,8 @@ class GraphedFrameBatch:
             f.out, f.force, f.field = buf["out"].data_ptr(), buf["force"].data_ptr(), buf["field"].data_ptr()
             f.dist_out = _lib.ptr(buf["dist"])
             f.energy, f.grad_positions = self.energies[k:].data_ptr(), buf["grad"].data_ptr()
+            # energy + forces of the frame in the gather launch, seeded with the -1 the backward pass of _eval() uses
+            f.tail_scratch, f.grad_seed = buf["tail"].data_ptr(), self._minus_one[k:].data_ptr()
             self.pos.append(p)
             self._grad_pos.append(buf["grad"])
             self.distances.append(buf["dist"])
@@ -207,7 +221,6 @@ class GraphedFrameBatch:
         host = np.zeros((nbytes,), dtype=np.uint8)
         _lib.check(lib.mipme_frames_table_build(dt, F, self._frames, C.byref(self._pot), host.ctypes.data, nbytes))
         self._table = torch.from_numpy(host).to(device)
-        self._minus_one = torch.full((F,), -1.0, dtype=dtype, device=device)
         # warm-up (plans, lazy module loads) off the default stream, then capture
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))

@@ -117,6 +117,12 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 #: run the short-range pair sum inside the spread launch of the mesh part (see mipme_sr_job_t in include/mipme.h)
 COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
+#: energy reduction + force assembly inside the gather launch when the forward can tell they will be wanted (see the tail
+#: block of _PMEFunction.forward and _EnergyDirectSum)
+TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
+#: a device scalar the caller promises to seed the next backward pass with (set by GraphedEnergyForces around its
+#: evaluation): the gather's tail then writes seed * dE/dpositions and the backward pass launches nothing
+SEED_PROMISE = None
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
 
@@ -396,7 +402,7 @@ class _PMEFunction(torch.autograd.Function):
         out = torch.empty((N, Cn), dtype=dtype, device=device)
         need_cell = ctx.needs_input_grad[1]
         saved = {}
-        field = None
+        field = tail = None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
             topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
@@ -502,14 +508,31 @@ class _PMEFunction(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         run_rspace(0)
                         join.record()
-                _call(
-                    "kspace_forward", lib.mipme_kspace_forward,
-                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                    G.data_ptr(), rho_mesh.data_ptr(), _lib.ptr(rho_hat), hat_work.data_ptr(),
-                    phi_mesh.data_ptr(), dc.data_ptr(), out.data_ptr(), _lib.ptr(phi_atoms), _lib.ptr(bins),
-                    join.cuda_event if overlap else None, 1 if (overlap or job is not None) else 0, _lib.ptr(field),
-                    _lib.ptr(records_out), C.byref(job) if job is not None else None, _lib.ptr(cell_partials),
+                # Tail of an energy + forces step in the gather launch (mipme_kspace_forward_args_t.out_energy): speculative like
+                # the force sums -- if the caller reduces with weighted_sum(V, charges) and asks for nothing but dE/dpositions
+                # (see energy_direct below), E and the assembled gradient are already there and neither the energy reduction
+                # nor the force assembly is launched.
+                ni = ctx.needs_input_grad
+                if (TAIL_FUSION and job is not None and field is not None and fused["force"] is not None and not lazy
+                        and ENERGY_FAST_PATH and not (ni[0] or ni[1] or ni[3] or ni[12])):
+                    seed = SEED_PROMISE
+                    if seed is not None and (seed.dtype != dtype or seed.device != device or seed.numel() != 1):
+                        seed = None
+                    tail = dict(energy=torch.empty((), dtype=dtype, device=device),
+                                grad=torch.empty((N, 3), dtype=dtype, device=device), seed=seed)
+                args = _lib.KspaceForwardArgs(
+                    plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if (overlap or job is not None) else 0,
+                    mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N, positions=pos.data_ptr(), charges=q.data_ptr(),
+                    G=G.data_ptr(), rho_mesh=rho_mesh.data_ptr(), rho_hat=_lib.ptr(rho_hat), hat_work=hat_work.data_ptr(),
+                    phi_mesh=phi_mesh.data_ptr(), dc=dc.data_ptr(), out_lr=out.data_ptr(), out_phi=_lib.ptr(phi_atoms),
+                    atom_bins=_lib.ptr(bins), gather_wait_event=join.cuda_event if overlap else None,
+                    out_field=_lib.ptr(field), out_records=_lib.ptr(records_out),
+                    sr_job=C.pointer(job) if job is not None else None, out_cell_partials=_lib.ptr(cell_partials),
+                    out_energy=None if tail is None else tail["energy"].data_ptr(),
+                    out_grad_positions=None if tail is None else tail["grad"].data_ptr(),
+                    grad_seed=None if tail is None else _lib.ptr(tail["seed"]),
                 )
+                _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
                     fused["records_ready"] = True
                 if job is not None and write_dist:
@@ -530,6 +553,7 @@ class _PMEFunction(torch.autograd.Function):
         ctx.save_for_backward(q, pos, dist, pairs, mask, G, *(saved.get(k) for k in ("phi_mesh", "rho_hat", "rho_dc", "phi_atoms", "bins")), out)
         ctx.rho_mesh, ctx.cell_partials = saved.get("rho_mesh"), saved.get("cell_partials")
         ctx.field = field
+        ctx.tail = tail  # {energy, grad, seed} written by the gather's tail, or None
         ctx.same_positions = src_positions is positions
         #: the pair part's gradient leaves through the neighbor_distances slot as a LazyPairGradient (see pme_potential)
         ctx.lazy = bool(lazy) and fused is not None
@@ -639,14 +663,16 @@ class _PMEFunction(torch.autograd.Function):
                         else:
                             partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
                                                    device=device)
-                    _call(
-                        "kspace_backward", lib.mipme_kspace_backward,
-                        plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                        g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat) if need_cell else None,
-                        _lib.ptr(rho_dc), _lib.ptr(phi_atoms) if need_cell else None, None, None, None,
-                        None, None, _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q), _lib.ptr(grad_cell),
-                        _lib.ptr(bins), gscale.data_ptr(), _lib.ptr(field) if from_field else None, kgrid_ready,
+                    args = _lib.KspaceBackwardArgs(
+                        plan=plan.handle, stream=st, dtype=dt, mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N,
+                        positions=pos.data_ptr(), charges=q.data_ptr(), grad_out=g.data_ptr(), G=G.data_ptr(),
+                        phi_mesh=phi_mesh.data_ptr(), rho_hat=_lib.ptr(rho_hat) if need_cell else None,
+                        rho_dc=_lib.ptr(rho_dc), phi_atoms=_lib.ptr(phi_atoms) if need_cell else None,
+                        partials=_lib.ptr(partials), grad_positions=_lib.ptr(grad_pos), grad_charges=_lib.ptr(grad_q),
+                        grad_cell=_lib.ptr(grad_cell), atom_bins=_lib.ptr(bins), grad_scale=gscale.data_ptr(),
+                        mesh_field=_lib.ptr(field) if from_field else None, kgrid_blocks_ready=kgrid_ready,
                     )
+                    _call("kspace_backward", lib.mipme_kspace_backward, C.byref(args))
                     if not need_pos:
                         grad_pos = None
                     if need_cell and not from_field:
@@ -670,14 +696,16 @@ class _PMEFunction(torch.autograd.Function):
                 if need_cell:
                     grad_cell = torch.empty((3, 3), dtype=dtype, device=device)
                     partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64, device=device)
-                _call(
-                    "kspace_backward", lib.mipme_kspace_backward,
-                    plan.handle, st, dt, C.byref(md), C.byref(pot_desc), N, pos.data_ptr(), q.data_ptr(),
-                    g.data_ptr(), G.data_ptr(), phi_mesh.data_ptr(), _lib.ptr(rho_hat), _lib.ptr(rho_dc),
-                    _lib.ptr(phi_atoms), psi_mesh.data_ptr(), _lib.ptr(psi_hat), hat_work.data_ptr(),
-                    chi_mesh.data_ptr(), dc.data_ptr(), _lib.ptr(partials), _lib.ptr(grad_pos), _lib.ptr(grad_q),
-                    _lib.ptr(grad_cell), _lib.ptr(bins), None, None, 0,
+                args = _lib.KspaceBackwardArgs(
+                    plan=plan.handle, stream=st, dtype=dt, mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N,
+                    positions=pos.data_ptr(), charges=q.data_ptr(), grad_out=g.data_ptr(), G=G.data_ptr(),
+                    phi_mesh=phi_mesh.data_ptr(), rho_hat=_lib.ptr(rho_hat), rho_dc=_lib.ptr(rho_dc),
+                    phi_atoms=_lib.ptr(phi_atoms), psi_mesh=psi_mesh.data_ptr(), psi_hat=_lib.ptr(psi_hat),
+                    hat_work=hat_work.data_ptr(), chi_mesh=chi_mesh.data_ptr(), dc=dc.data_ptr(),
+                    partials=_lib.ptr(partials), grad_positions=_lib.ptr(grad_pos), grad_charges=_lib.ptr(grad_q),
+                    grad_cell=_lib.ptr(grad_cell), atom_bins=_lib.ptr(bins),
                 )
+                _call("kspace_backward", lib.mipme_kspace_backward, C.byref(args))
                 if ctx.slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
                     _call(
@@ -999,12 +1027,17 @@ class _EnergyDirectSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, V, q, positions, node):
         lib = _lib.load()
-        V_c, q_c = V.contiguous(), q.detach().contiguous()
-        out = torch.empty((), dtype=V.dtype, device=V.device)
-        scratch = _dot_scratch(V.device, q.data_ptr())
-        with torch.cuda.device(V.device):
-            _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(V.device), _lib.dtype_code(V.dtype),
-                  V_c.numel(), V_c.data_ptr(), q_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
+        q_c = q.detach().contiguous()
+        ctx.tail = tail = getattr(node, "tail", None)
+        if tail is not None:
+            out = tail["energy"].detach()  # formed by the gather's tail: no reduction launch
+        else:
+            V_c = V.contiguous()
+            out = torch.empty((), dtype=V.dtype, device=V.device)
+            scratch = _dot_scratch(V.device, q.data_ptr())
+            with torch.cuda.device(V.device):
+                _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(V.device), _lib.dtype_code(V.dtype),
+                      V_c.numel(), V_c.data_ptr(), q_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
         ctx.q, ctx.force, ctx.field, ctx.full = q_c, node.fused["force"], node.field, int(node.full_list)
         return out
 
@@ -1013,6 +1046,11 @@ class _EnergyDirectSum(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         q = ctx.q
+        tail = ctx.tail
+        if tail is not None and tail["seed"] is not None and g.data_ptr() == tail["seed"].data_ptr() and g.numel() == 1:
+            # the promised seed: the gather's tail has already written seed * dE/dpositions (a fresh alias, so that the
+            # accumulation into positions.grad takes the buffer instead of copying it)
+            return None, None, tail["grad"].detach(), None
         grad_pos = torch.empty((q.shape[0], 3), dtype=q.dtype, device=q.device)
         g = g.contiguous()
         with torch.cuda.device(q.device):
