@@ -181,7 +181,10 @@ typedef struct mipme_kspace_forward_args {
    * out_field, no slab term): out_energy (1 real) = sum_a charges_a out_lr_a -- the reduction the caller's (q * V).sum()
    * performs (README.rst:112-114) -- and out_grad_positions (N,3) = s q_a (c force_a + field_a), the gradient of that energy
    * w.r.t. the positions times s = grad_seed[0] (device scalar; NULL = 1), c = 1/2 for a full list: what
-   * mipme_dot_forward + mipme_sr_rows_finalize would compute in two more launches. */
+   * mipme_dot_forward + mipme_sr_rows_finalize would compute in two more launches.  The energy is assembled without any
+   * reduction across the gather's workgroups, from partial sums the earlier kernels of the call leave behind:
+   * sum_a q_a V_sr,a and sum_a q_a^2 from the co-scheduled pair sum, (1/2V) sum_k mu_k G_k |rho^_k|^2 from the x stage of
+   * the convolution (= sum_a q_a gather(phi)_a / 2V, the gather being the adjoint of the spread). */
   void* out_energy;
   void* out_grad_positions;
   const void* grad_seed;
@@ -232,14 +235,13 @@ typedef struct mipme_frame {
   void* dist_out;             /* (P) nullable */
   void* energy;               /* 1 real */
   void* grad_positions;       /* (N,3) */
-  /* gather tail (see mipme_kspace_forward_args_t.out_energy): when tail_scratch != NULL the gather of the forward call also
-   * forms energy and grad_positions = grad_seed[0] q_a (c force_a + field_a) (grad_seed NULL = 1) -- no energy launch, and
-   * mipme_frames_backward is only needed for a different seed.  tail_scratch: mipme_gather_tail_scratch_bytes(mesh) bytes,
-   * zero before the first use (every call leaves it zero). */
-  void* tail_scratch;
+  /* gather tail (see mipme_kspace_forward_args_t.out_energy): with use_tail != 0 (for ALL frames of a batch) the gather of
+   * the forward call also forms energy and grad_positions = grad_seed[0] q_a (c force_a + field_a) (grad_seed: device
+   * scalar, NULL = 1) -- no energy launch, and mipme_frames_backward is only needed for a different seed. */
+  int32_t use_tail;
+  int32_t _pad;
   const void* grad_seed;
 } mipme_frame_t;
-int64_t mipme_gather_tail_scratch_bytes(const mipme_mesh_t* mesh);
 int64_t mipme_frames_table_bytes(int dtype, int n_frames);
 int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frames, const mipme_potential_t* pot,
                              void* host_table, int64_t host_table_bytes);

@@ -34,7 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
-    "mipme_scaled_match", "mipme_gather_tail_scratch_bytes",
+    "mipme_scaled_match",
 )
 
 
@@ -111,7 +111,8 @@ class Frame(C.Structure):
         ("dist_out", C.c_void_p),
         ("energy", C.c_void_p),
         ("grad_positions", C.c_void_p),
-        ("tail_scratch", C.c_void_p),
+        ("use_tail", C.c_int32),
+        ("_pad", C.c_int32),
         ("grad_seed", C.c_void_p),
     ]
 
@@ -249,8 +250,6 @@ def _declare(lib):
     lib.mipme_fft_plan_xfused.argtypes = [vp]
     lib.mipme_fft_plan_kgrid_blocks.restype = i64
     lib.mipme_fft_plan_kgrid_blocks.argtypes = [vp]
-    lib.mipme_gather_tail_scratch_bytes.restype = i64
-    lib.mipme_gather_tail_scratch_bytes.argtypes = [MP]
     lib.mipme_frames_table_bytes.restype = i64
     lib.mipme_frames_table_bytes.argtypes = [ci, ci]
     lib.mipme_profile_enable.restype = ci

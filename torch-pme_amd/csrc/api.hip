@@ -37,7 +37,7 @@ int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*);
+                    const mipme_potential_t*, void*, void*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
@@ -53,7 +53,7 @@ bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                        const mipme_sr_job_t*);
+                                        const mipme_sr_job_t*, bool);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*);
@@ -130,7 +130,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     {
       const bool co = job && sr_job_fusable(job);
       ProfScope _ps(st, co ? "spread+rspace_forward" : "spread");
-      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr))) {
+      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr))) {
         (void)hipMemsetAsync(counters, 0, sizeof(int) * (size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1), st);
         return rc;
       }
@@ -146,7 +146,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   }
   if (!rho_hat) {
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
+                                                 tail ? const_cast<void*>(tail->epart_k) : nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -203,13 +204,13 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   }
   // psi = spread(g / 2V); chi = F psi
   if (bins)
-    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr, nullptr));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr, nullptr, false));
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   }
@@ -464,7 +465,6 @@ static int slab_backward_t(hipStream_t st, int axis, const mipme_mesh_t* m, doub
 }  // namespace mipme
 
 namespace mipme {
-int64_t gather_tail_scratch_bytes(const mipme_mesh_t*);
 void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 }
 // Copy a caller's versioned argument struct into the library's own layout: only the first `size` bytes the caller
@@ -578,9 +578,12 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
     tail.seed = a.grad_seed;
     tail.grad_pos = a.out_grad_positions;
     tail.energy = a.out_energy;
-    tail.scratch = fft_plan_tail_scratch(a.plan, gather_tail_scratch_bytes(mesh));
-    MIPME_REQUIRE(tail.scratch, "could not allocate the gather tail scratch (not possible during stream capture: run one "
-                                "evaluation before capturing)");
+    MIPME_REQUIRE(!a.rho_hat && mesh->n_channels == 1 && sr_job_fusable(a.sr_job),
+                  "the gather tail needs the fused convolution (rho_hat == NULL), one channel and a co-schedulable sr_job");
+    tail.n_k = xconv_blocks(a.plan);
+    tail.epart_k = fft_plan_tail_scratch(a.plan, int64_t(sizeof(double)) * tail.n_k);
+    MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
+                                "capture: run one evaluation before capturing)");
     tp = &tail;
   }
   hipStream_t st = (hipStream_t)a.stream;
@@ -617,8 +620,6 @@ int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {
                                       a.partials, a.grad_positions, a.grad_charges, a.grad_cell, a.atom_bins, a.grad_scale,
                                       a.mesh_field, a.kgrid_blocks_ready));
 }
-
-int64_t mipme_gather_tail_scratch_bytes(const mipme_mesh_t* mesh) { return mesh ? gather_tail_scratch_bytes(mesh) : 0; }
 
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan) { return plan && fft_plan_xfused(plan) ? 1 : 0; }
 

@@ -57,8 +57,9 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 }
 
 struct BinsLayout {
-  size_t count, start, slot, brick, rec, wts, total;
+  size_t count, start, slot, brick, rec, wts, epart, total;
 };
+static constexpr int kRowsPerSpreadBlock = 512 / kRowLanes;  // rows per workgroup of the co-scheduled pair sum (SPREAD_THREADS)
 
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
@@ -72,6 +73,8 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.brick = off; off += al(sizeof(int) * size_t(N));
   l.rec = off;   off += al(sizeof(int4) * size_t(N));
   l.wts = off;   off += al(6 * size_t(m->order) * s * size_t(N));  // per atom: wx, wy, wz, dwx, dwy, dwz (n each)
+  // energy partial sums of the co-scheduled pair sum: 2 doubles per row workgroup (rows_body.h FusedRowsArgs::epart)
+  l.epart = off; off += al(2 * sizeof(double) * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.total = off;
   return l;
 }
@@ -576,15 +579,18 @@ static constexpr int kGatherLanes = 8;
 
 // ---- tail of the energy + forces step, folded into the gather (TAIL = true) ------------------------------------------
 // When the potentials the gather completes are final (the pair sum ran before it: co-scheduled launch) the same kernel forms
-//   energy          = sum_a q_a V_a                      (what the caller's (q * V).sum() / weighted_sum computes), and
 //   grad_positions  = s q_a (c F_a + field_a)            (what the energy-mode backward computes; F = pair force sums,
-//                                                         c = 1/2 for a full list, s = seed[0] or 1),
+//                                                         c = 1/2 for a full list, s = seed[0] or 1), and
+//   energy          = sum_a q_a V_a                      (what the caller's (q * V).sum() / weighted_sum computes),
 // which removes the energy-reduction and force-assembly launches of a step (4.8 + 4.2 us of 84 at cfg3, both pure launch
-// latency).  The energy is reduced deterministically: per-brick partial sums (fp64), then a two-level last-arrival ticket
-// (groups of kTailGroup bricks, then the groups) -- at most kTailGroup + n_groups same-address atomics in series instead
-// of one per brick.  partials: fp64[nb + n_groups]; tickets: int[n_groups + 1], zero between calls.
-static constexpr int kTailGroup = 32;
-
+// latency).  The energy needs no reduction ACROSS the gather's workgroups (a last-arrival ticket costs 6-8 us of serial
+// memory-side atomics at the very end of the step -- measured): it is assembled from partial sums that EARLIER kernels of the
+// step left behind, by workgroup 0 while it waits for its mesh tile,
+//   E = sum_a q_a V_sr,a                                  per-workgroup sums of the co-scheduled pair kernel (epart_sr[2w])
+//     + (1/2V) sum_k mu_k G_k |rho^_k|^2                  per-workgroup sums of the x stage of the convolution (epart_k)
+//     - (self/2) sum_a q_a^2 - bg Q^2 / V                 (epart_sr[2w + 1]; Q = Re rho^(0))
+// using sum_a q_a gather(phi)_a = <spread(q), phi> = sum_k mu_k G_k |rho^_k|^2 (the gather is the adjoint of the spread;
+// un-normalised transforms, mu = multiplicity of a half-grid point).  Sums in fp64, fixed order: deterministic.
 template <typename T>
 struct GatherTail {
   const T* force;     // (N,3) pair force sums
@@ -592,58 +598,36 @@ struct GatherTail {
   const T* seed;      // device scalar, nullable (= 1)
   T* grad_pos;        // (N,3)
   T* energy;          // 1
-  double* partials;
-  int* tickets;
+  const double* epart_sr;  // [2 * n_sr]
+  const double* epart_k;   // [n_k]
+  int n_sr, n_k;
 };
 
-static inline int tail_groups(int nb) { return (nb + kTailGroup - 1) / kTailGroup; }
-int64_t gather_tail_scratch_bytes(const mipme_mesh_t* m) {
-  const int nb = make_brick_geom(m).nb;
-  return int64_t(sizeof(double)) * (nb + tail_groups(nb)) + int64_t(sizeof(int)) * (tail_groups(nb) + 1);
-}
-
-// e = this thread's share of the brick's energy; every thread of the workgroup calls (uniform control flow)
 template <typename T, int THREADS>
-__device__ __forceinline__ void tail_reduce_energy(double e, const GatherTail<T>& tail, unsigned block, unsigned nb) {
-  __shared__ double tred[THREADS / 64];
-  __shared__ int tflag;
+__device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* __restrict__ qsum, T inv_vol, T self_c,
+                                            T bg_c) {
+  __shared__ double tred[THREADS / 64][3];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < tail.n_sr; i += THREADS) {
+    v[0] += tail.epart_sr[2 * i];
+    v[1] += tail.epart_sr[2 * i + 1];
+  }
+  for (int i = threadIdx.x; i < tail.n_k; i += THREADS) v[2] += tail.epart_k[i];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
-  if (lane == 0) tred[wave] = e;
-  __syncthreads();
-  const unsigned n_groups = (nb + kTailGroup - 1) / kTailGroup;
-  const unsigned grp = block / kTailGroup;
-  const unsigned gsize = min(unsigned(kTailGroup), nb - grp * kTailGroup);
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double x = v[k];
 #pragma unroll
-    for (int w = 0; w < THREADS / 64; ++w) tot += tred[w];
-    __hip_atomic_store(&tail.partials[block], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int ticket = __hip_atomic_fetch_add(&tail.tickets[grp], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    int state = 0;
-    if (ticket == int(gsize) - 1) {  // last brick of its group: group sum in index order
-      double gs = 0.0;
-      for (unsigned k = 0; k < gsize; ++k)
-        gs += __hip_atomic_load(&tail.partials[grp * kTailGroup + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&tail.partials[nb + grp], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&tail.tickets[grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int top = __hip_atomic_fetch_add(&tail.tickets[n_groups], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      state = top == int(n_groups) - 1 ? 1 : 0;
-    }
-    tflag = state;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    if (lane == 0) tred[wave][k] = x;
   }
   __syncthreads();
-  if (!tflag || wave != 0) return;
-  // the last group to finish: sum of the group sums, fixed order (lane-strided, then the xor tree)
-  double tot = 0.0;
-  for (unsigned k = lane; k < n_groups; k += 64)
-    tot += __hip_atomic_load(&tail.partials[nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-  if (lane == 0) {
-    tail.energy[0] = T(tot);
-    __hip_atomic_store(&tail.tickets[n_groups], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int w = 0; w < THREADS / 64; ++w)
+      for (int k = 0; k < 3; ++k) t[k] += tred[w][k];
+    const double Q = double(qsum[0]);
+    tail.energy[0] = T(t[0] + 0.5 * double(inv_vol) * t[2] - 0.5 * double(self_c) * t[1] - double(bg_c) * double(inv_vol) * Q * Q);
   }
 }
 
@@ -664,15 +648,12 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int beg = start[block], end = start[block + 1];
-  double e_acc = 0.0;  // TAIL: this thread's share of sum_a q_a V_a
   T seed = T(1);
   if constexpr (TAIL) {
     if (tail->seed) seed = tail->seed[0];
+    if (block == 0) tail_energy<T, GATHER_THREADS>(*tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
   }
-  if (beg == end) {
-    if constexpr (TAIL) tail_reduce_energy<T, GATHER_THREADS>(0.0, *tail, block, unsigned(bg.nb));
-    return;
-  }
+  if (beg == end) return;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
   const bool lane_active = l < N;
@@ -764,14 +745,12 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
           const T v_final = accumulate ? out_early + lr : lr;
           out[o] = v_final;
           if (raw) raw[o] = phi;
-          if constexpr (TAIL) e_acc += double(q_early) * double(v_final);
         } else {
           out[o] = acc;
         }
       }
     }
   }
-  if constexpr (TAIL) tail_reduce_energy<T, GATHER_THREADS>(e_acc, *tail, block, unsigned(bg.nb));
 }
 
 template <int N, bool FIELD, typename T>
@@ -921,13 +900,14 @@ struct BinsView {
   int *count, *start, *slot, *brick;
   int4* rec;
   void* wts;
+  double* epart;
 };
 
 static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
   const BinsLayout l = bins_layout(m, N, dtype);
   char* b = (char*)bins;
   return BinsView{(int*)(b + l.count), (int*)(b + l.start), (int*)(b + l.slot), (int*)(b + l.brick), (int4*)(b + l.rec),
-                  (void*)(b + l.wts)};
+                  (void*)(b + l.wts), (double*)(b + l.epart)};
 }
 
 // clean_count (nullable): brick counters that are zero on entry (plan-owned; spread_bricks clears them again); otherwise the
@@ -975,7 +955,7 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
 
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
-                  int* clear_count, const mipme_sr_job_t* job) {
+                  int* clear_count, const mipme_sr_job_t* job, bool want_epart) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
@@ -1004,15 +984,18 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const FusedRowsArgs<T> ra = make_fused_rows_args<T>(
         s, cf, job->n_atoms, job->row_ptr, job->entries_shift, job->entries, nullptr, job->positions, job->records,
         job->cell, job->charges, nullptr, lo, hi, job->full_list, 0, job->out, job->force, nullptr, job->dist_out);
+    static_assert(kRowsPerSpreadBlock == SPREAD_THREADS / kRowLanes, "epart layout");
+    FusedRowsArgs<T> ra_e = ra;
+    ra_e.epart = want_epart ? v.epart : nullptr;
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned grid = unsigned(bg.nb) + n_rows_blocks;
     if (pfast == 1)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
@@ -1044,7 +1027,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const BinsView v = bins_view(m, N, dtype, bins);
   MIPME_REQUIRE(!field || m->n_channels == 1, "the field output of the gather is single-channel");
   if (th) {
-    MIPME_REQUIRE(field && accumulate && q && th->force && th->grad_pos && th->energy && th->scratch,
+    MIPME_REQUIRE(field && accumulate && q && qsum && th->force && th->grad_pos && th->energy && th->epart_k,
                   "the gather tail needs the field output, accumulate = 1, pair force sums and output buffers");
     GatherTail<T> tail;
     tail.force = (const T*)th->force;
@@ -1052,8 +1035,10 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     tail.seed = (const T*)th->seed;
     tail.grad_pos = (T*)th->grad_pos;
     tail.energy = (T*)th->energy;
-    tail.partials = (double*)th->scratch;
-    tail.tickets = (int*)((double*)th->scratch + bg.nb + tail_groups(bg.nb));
+    tail.epart_sr = (const double*)v.epart;
+    tail.n_sr = int((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+    tail.epart_k = (const double*)th->epart_k;
+    tail.n_k = int(th->n_k);
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                  g, bg, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
@@ -1129,8 +1114,9 @@ struct FrameDev {
   const T* force;
   T* grad_pos;
   T force_scale;  // 1/2 for a full list
-  // gather tail (energy + forces in the gather launch); tail.partials == nullptr: separate energy / finalize kernels
+  // gather tail (energy + forces in the gather launch)
   GatherTail<T> tail;
+  bool use_tail;
 };
 
 template <typename T>
@@ -1167,10 +1153,14 @@ __global__ __launch_bounds__(GATHER_THREADS) void frames_gather_kernel(const Fra
 
 // the same with the tail: every frame of the batch carries tail scratch
 template <int N, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void frames_gather_tail_kernel(const FrameDev<T>* __restrict__ table) {
+__global__ __launch_bounds__(GATHER_THREADS) void frames_gather_tail_kernel(const FrameDev<T>* __restrict__ table,
+                                                                           const double* __restrict__ epart_k, int n_k) {
   const FrameDev<T>& f = table[blockIdx.y];
+  GatherTail<T> tail = f.tail;
+  tail.epart_k = epart_k + int64_t(blockIdx.y) * n_k;  // the x stage writes one block of partial sums per batch entry
+  tail.n_k = n_k;
   gather_brick_body<N, true, T, true>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c,
-                                      true, f.out, nullptr, f.field, blockIdx.x, &f.tail);
+                                      true, f.out, nullptr, f.field, blockIdx.x, &tail);
 }
 
 // energy[f] = sum_a q_a V_a: one workgroup per frame, fixed summation order
@@ -1296,15 +1286,21 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.tail.seed = (const T*)f.grad_seed;
     d.tail.grad_pos = d.grad_pos;
     d.tail.energy = d.energy;
-    d.tail.partials = (double*)f.tail_scratch;
-    d.tail.tickets = f.tail_scratch ? (int*)((double*)f.tail_scratch + d.bg.nb + tail_groups(d.bg.nb)) : nullptr;
+    d.tail.epart_sr = v.epart;
+    d.tail.n_sr = int(d.n_row_blocks);
+    d.tail.epart_k = nullptr;  // per batch entry: set by frames_forward (plan scratch)
+    d.tail.n_k = 0;
+    d.use_tail = f.use_tail != 0;
+    d.rows.epart = f.use_tail ? v.epart : nullptr;
     out[k] = d;
   }
   return MIPME_OK;
 }
 
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*);
+                    const mipme_potential_t*, void*, void*);
+int64_t xconv_blocks(const mipme_fft_plan*);
+void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int fft_plan_batch(const mipme_fft_plan*);
 
@@ -1334,13 +1330,18 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, frames_spread_rows_kernel<N, T, 6><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
   MIPME_LAUNCH_CHECK();
-  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr);
-  if (rc) return rc;
   bool all_tail = true;
-  for (int k = 0; k < n_frames; ++k) all_tail = all_tail && fr[k].tail_scratch != nullptr;
+  for (int k = 0; k < n_frames; ++k) all_tail = all_tail && fr[k].use_tail != 0;
+  const int64_t n_k = xconv_blocks(plan) / n_frames;  // blocks of the x stage per batch entry
+  double* epart_k = all_tail ? (double*)fft_plan_tail_scratch(plan, int64_t(sizeof(double)) * n_k * n_frames) : nullptr;
+  MIPME_REQUIRE(!all_tail || epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
+                                      "capture: run one evaluation before capturing)");
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k);
+  if (rc) return rc;
   if (all_tail) {  // energy + forces of every frame in the gather launch
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, frames_gather_tail_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(tb)));
+                             ((void)S, frames_gather_tail_kernel<N, T><<<dim3(unsigned(bg.nb), F), GATHER_THREADS, 0, st>>>(
+                                 tb, epart_k, int(n_k))));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
@@ -1355,9 +1356,9 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                  const mipme_sr_job_t*);
+                                  const mipme_sr_job_t*, bool);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                   const mipme_sr_job_t*);
+                                   const mipme_sr_job_t*, bool);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                   double, double, void*, void*, int, void*, const GatherTailHost*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,

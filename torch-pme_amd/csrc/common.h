@@ -215,7 +215,8 @@ struct GatherTailHost {
   const void* seed;    // device scalar, nullable
   void* grad_pos;      // (N,3)
   void* energy;        // 1 real
-  void* scratch;       // gather_tail_scratch_bytes(), zero between calls
+  const void* epart_k; // fp64[n_k]: per-workgroup sums of mu G |rho^|^2 written by the x stage of the convolution
+  int64_t n_k;
 };
 
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position

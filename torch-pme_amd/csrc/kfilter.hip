@@ -636,7 +636,8 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
 template <typename T, bool CELLSUMS>
 __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                    Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
-                                                   T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials) {
+                                                   T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
+                                                   double* __restrict__ epart) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   const int KZ = 1 << kzs;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
@@ -733,15 +734,37 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
       *reinterpret_cast<int*>(partials + int64_t(gridDim.x) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl) = 0;
   }
   // ---- product with G: position x holds kx = bitrev(x) ----
+  // epart (nullable): this block's share of sum_k mu_k G_k |rho^_k|^2 (mu = 2 except on the kz = 0 and kz = nz/2 planes of
+  // the half grid) -- the mesh part of the energy, assembled by the gather's tail (bricks.hip GatherTail)
+  double esum = 0.0;
+  const int nz_full = 2 * (nzh - 1);
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
     if (z < kzn) {
       const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
       const T gk = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];  // G_stride: one filter table per batch entry, or 0
       Cplx<T> v = tile[idx];
+      if (epart) {
+        const int iz = kz0 + z;
+        const bool edge = iz == 0 || iz == nz_full / 2;
+        esum += (edge ? 1.0 : 2.0) * double(gk) * (double(v.re) * double(v.re) + double(v.im) * double(v.im));
+      }
       v.re *= gk;
       v.im *= gk;
       tile[idx] = v;
+    }
+  }
+  if (epart) {  // uniform
+    __shared__ double ered[4];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
+    if (lane == 0) ered[wave] = esum;
+    __syncthreads();
+    if (tid == 0) {
+      double v = 0.0;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) v += ered[w];
+      epart[blockIdx.x] = v;
     }
   }
   __syncthreads();
@@ -804,7 +827,7 @@ int64_t xconv_blocks(const mipme_fft_plan* p) {
 // cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
-                    void* cell_partials) {
+                    void* cell_partials, void* epart) {
   if (!p->own_yz) {
     MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
     MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
@@ -840,10 +863,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
                                                             (const float*)G, G_stride, (float*)dc, kg, kp,
-                                                            (double*)cell_partials);
+                                                            (double*)cell_partials, (double*)epart);
     else
       xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
-                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr);
+                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart);
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<float>(p, st, true, nullptr, hat, mesh_out);
@@ -861,10 +884,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
                                                              (const double*)G, G_stride, (double*)dc, kg, kp,
-                                                             (double*)cell_partials);
+                                                             (double*)cell_partials, (double*)epart);
     else
       xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr);
+                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart);
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<double>(p, st, true, nullptr, hat, mesh_out);

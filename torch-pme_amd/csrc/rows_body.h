@@ -80,6 +80,9 @@ struct FusedRowsArgs {
   T* force;
   double* partials;
   T* dist_out;
+  // kPotForce only, nullable: per-workgroup sums {sum_a q_a out_a, sum_a q_a^2} over the rows of the workgroup (fp64[2] per
+  // workgroup) -- the pair part of the energy and the self-term sum, reduced later by the gather's tail (bricks.hip)
+  double* epart;
 };
 
 template <typename T>
@@ -109,6 +112,7 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
   a.force = (T*)force;
   a.partials = (double*)partials;
   a.dist_out = (T*)dist_out;
+  a.epart = nullptr;
   return a;
 }
 
@@ -300,6 +304,26 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   if constexpr (POT) {
     pot = row_sum(pot);
     if (sub == 0 && valid) out[a] = (accumulate ? out[a] : T(0)) + T(0.5) * pot;
+    if constexpr (MODE == kPotForce) {
+      if (args.epart) {  // uniform: energy partial sums of this workgroup's rows
+        __shared__ double ered[BS / 64][2];
+        const bool mine = sub == 0 && valid;
+        const double e1 = wave_sum(mine ? double(qa) * double(T(0.5) * pot) : 0.0);
+        const double e2 = wave_sum(mine ? double(qa) * double(qa) : 0.0);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+          ered[wave][0] = e1;
+          ered[wave][1] = e2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+          double v = 0.0;
+#pragma unroll
+          for (int w = 0; w < BS / 64; ++w) v += ered[w][threadIdx.x];
+          args.epart[2 * int64_t(block) + threadIdx.x] = v;
+        }
+      }
+    }
   }
   if constexpr (FORCE) {
     fx = row_sum(fx);

@@ -189,9 +189,7 @@ class GraphedFrameBatch:
             if nbytes <= 0:
                 raise ValueError(f"frame {k}: mesh {ns} is outside the brick kernels' range")
             nb = ((ns[0] + 7) // 8) * ((ns[1] + 7) // 8) * ((ns[2] + 7) // 8)
-            tail_bytes = lib.mipme_gather_tail_scratch_bytes(C.byref(md))
             buf = dict(
-                tail=torch.zeros(((tail_bytes + 7) // 8,), dtype=torch.float64, device=device),
                 bins=torch.empty((nbytes,), dtype=torch.uint8, device=device),
                 counters=torch.zeros((nb + 1,), dtype=torch.int32, device=device),
                 records=torch.empty((N, 4), dtype=dtype, device=device),
@@ -212,7 +210,7 @@ class GraphedFrameBatch:
             f.dist_out = _lib.ptr(buf["dist"])
             f.energy, f.grad_positions = self.energies[k:].data_ptr(), buf["grad"].data_ptr()
             # energy + forces of the frame in the gather launch, seeded with the -1 the backward pass of _eval() uses
-            f.tail_scratch, f.grad_seed = buf["tail"].data_ptr(), self._minus_one[k:].data_ptr()
+            f.use_tail, f.grad_seed = 1, self._minus_one[k:].data_ptr()
             self.pos.append(p)
             self._grad_pos.append(buf["grad"])
             self.distances.append(buf["dist"])

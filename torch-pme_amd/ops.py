@@ -513,8 +513,10 @@ class _PMEFunction(torch.autograd.Function):
                 # (see energy_direct below), E and the assembled gradient are already there and neither the energy reduction
                 # nor the force assembly is launched.
                 ni = ctx.needs_input_grad
+                p_eff = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
                 if (TAIL_FUSION and job is not None and field is not None and fused["force"] is not None and not lazy
-                        and ENERGY_FAST_PATH and not (ni[0] or ni[1] or ni[3] or ni[12])):
+                        and ENERGY_FAST_PATH and not (ni[0] or ni[1] or ni[3] or ni[12]) and rho_hat is None
+                        and p_eff in (1, 6) and pot_desc.exclusion_radius <= 0):
                     seed = SEED_PROMISE
                     if seed is not None and (seed.dtype != dtype or seed.device != device or seed.numel() != 1):
                         seed = None
