@@ -133,7 +133,7 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 typedef struct mipme_sr_job {
   int64_t n_atoms;
   const void* row_ptr;        /* int32[2N+1]     (mipme_topology_build) */
-  const void* entries_shift;  /* int32[2P+1][2]  (mipme_topology_pack_entries) */
+  const void* entries_shift;  /* int32[2P+1][2] (shift_format 1) or int32[2P+1] (shift_format 2)  (mipme_topology_pack_entries) */
   const void* entries;        /* int32[2P+1][2]  (mipme_topology_build) */
   const void* positions;      /* (N,3) reals the pair distances are computed from */
   const void* cell;           /* (3,3) */
@@ -224,7 +224,7 @@ typedef struct mipme_frame {
   const void* entries_shift;
   const void* entries;
   int32_t full_list;
-  int32_t shift_format;       /* must be 1 (table) */
+  int32_t shift_format;       /* 1 (table, int2 entries) or 2 (table, 4-byte entries); the same for every frame */
   void* records;              /* 4N reals */
   void* rho_mesh;             /* (nx,ny,nz): frame f's slice of the batched mesh buffers */
   void* phi_mesh;
@@ -418,7 +418,10 @@ int64_t mipme_rows_partials_size(int64_t n_atoms);
  *   entries_shift int32[2P][2] = { other atom, cell-shift code } from mipme_topology_pack_entries (shifts == NULL -> zero
  *                 shifts).  The shift is stored role-adjusted (S for role i, -S for role j).  shift_format 0: 3 x int8;
  *                 1: index into a 7^3 table of Cartesian shift vectors kept in LDS (needs |s| <= 3, no pair mask).
- *                 flag[0] bit 0: some shift is not an integer in [-127,127] (unusable); bit 1: some |s| > 3 (format 1
+ *                 2: the table code and the partner in ONE int32 per entry, other | code << 22 (int32[2P]; atoms < 2^22,
+ *                 |s| <= 3) -- half the entry stream; read by the co-scheduled pair sum of mipme_kspace_forward (sr_job) and
+ *                 by mipme_frames_forward only, mipme_sr_rows_fused takes formats 0 and 1.
+ *                 flag[0] bit 0: some shift is not an integer in [-127,127] (unusable); bit 1: some |s| > 3 (formats 1, 2
  *                 unusable).
  *   out   (N) nullable: out[a] (+)= 1/2 sum_{potential roles} src[o] v_SR(d_e)          (transpose as mipme_rspace_rows)
  *   force (N,3) nullable, OVERWRITTEN: sum_e sign_e w_e v_SR'(d_e) vec_e / d_e with

@@ -37,7 +37,8 @@ int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t);
+const void* bins_epart(const mipme_mesh_t*, int64_t, int, void*, int64_t*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
 template <typename T, typename I> int distance_forward_impl(hipStream_t, int64_t, const void*, const void*, const void*, const void*, void*);
@@ -146,8 +147,10 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   }
   if (!rho_hat) {
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
+    int64_t n_sr_part = 0;
+    const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
     STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
-                                                 tail ? const_cast<void*>(tail->epart_k) : nullptr));
+                                                 tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -210,7 +213,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   }
@@ -581,7 +584,8 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
     MIPME_REQUIRE(!a.rho_hat && mesh->n_channels == 1 && sr_job_fusable(a.sr_job),
                   "the gather tail needs the fused convolution (rho_hat == NULL), one channel and a co-schedulable sr_job");
     tail.n_k = xconv_blocks(a.plan);
-    tail.epart_k = fft_plan_tail_scratch(a.plan, int64_t(sizeof(double)) * tail.n_k);
+    tail.epart_k = fft_plan_tail_scratch(a.plan, 3 * int64_t(sizeof(double)) * tail.n_k);  // + the reduced pair partials
+    tail.sr_reduced = 1;
     MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
                                 "capture: run one evaluation before capturing)");
     tp = &tail;

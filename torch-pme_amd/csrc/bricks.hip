@@ -60,6 +60,7 @@ struct BinsLayout {
   size_t count, start, slot, brick, rec, wts, epart, total;
 };
 static constexpr int kRowsPerSpreadBlock = 512 / kRowLanes;  // rows per workgroup of the co-scheduled pair sum (SPREAD_THREADS)
+static constexpr int kSpreadWaves = 512 / 64;
 
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
@@ -73,8 +74,8 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.brick = off; off += al(sizeof(int) * size_t(N));
   l.rec = off;   off += al(sizeof(int4) * size_t(N));
   l.wts = off;   off += al(6 * size_t(m->order) * s * size_t(N));  // per atom: wx, wy, wz, dwx, dwy, dwz (n each)
-  // energy partial sums of the co-scheduled pair sum: 2 doubles per row workgroup (rows_body.h FusedRowsArgs::epart)
-  l.epart = off; off += al(2 * sizeof(double) * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
+  // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
+  l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.total = off;
   return l;
 }
@@ -541,12 +542,12 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs
 // and the remaining ones are row workgroups of the VALU-bound pair sum, which fill those issue slots.  The two parts are
 // independent (the pair sum reads the atom records that the binning pass emitted, not the mesh); the gather adds the mesh
 // part to the potentials the pair sum wrote.
-template <int N, typename T, int PFAST>
+template <int N, typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread) {
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(sa, blockIdx.x);
   else
-    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS>(ra, blockIdx.x - n_spread);
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread);
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -910,6 +911,12 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
                   (void*)(b + l.wts), (double*)(b + l.epart)};
 }
 
+// the per-wave energy partial sums of the co-scheduled pair sum inside the bins buffer (n = number of {e, q^2} pairs)
+const void* bins_epart(const mipme_mesh_t* m, int64_t N, int dtype, void* bins, int64_t* n) {
+  *n = int64_t(kSpreadWaves) * ((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  return bins_view(m, N, dtype, bins).epart;
+}
+
 // clean_count (nullable): brick counters that are zero on entry (plan-owned; spread_bricks clears them again); otherwise the
 // counters inside `bins` are zeroed here.  q + atom_rec (nullable, single channel): also emit the (position, charge) records.
 template <typename T>
@@ -990,12 +997,19 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned grid = unsigned(bg.nb) + n_rows_blocks;
-    if (pfast == 1)
+    const bool compact = job->shift_format == kShiftTable32;
+    if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+    else if (pfast == 1)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+    else if (compact)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
@@ -1008,7 +1022,9 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
 // the co-scheduled launch exists for the potential + force-sum mode of the fast range-separated potentials (1/r, 1/r^6)
 // with table shift codes
 bool sr_job_fusable(const mipme_sr_job_t* job) {
-  if (!job || !job->pot || !job->force || job->shift_format != kShiftTable || job->n_atoms <= 0) return false;
+  if (!job || !job->pot || !job->force || (job->shift_format != kShiftTable && job->shift_format != kShiftTable32) ||
+      job->n_atoms <= 0)
+    return false;
   SRPot s;
   if (make_srpot(job->pot, s)) return false;
   const int pfast = fast_rs_exponent(s);
@@ -1036,9 +1052,13 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     tail.grad_pos = (T*)th->grad_pos;
     tail.energy = (T*)th->energy;
     tail.epart_sr = (const double*)v.epart;
-    tail.n_sr = int((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+    tail.n_sr = kSpreadWaves * int((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
     tail.epart_k = (const double*)th->epart_k;
     tail.n_k = int(th->n_k);
+    if (th->sr_reduced) {  // pre-reduced by the x stage of the convolution (kfilter.hip xconv_kernel, sr_part)
+      tail.epart_sr = tail.epart_k + tail.n_k;
+      tail.n_sr = tail.n_k;
+    }
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                  g, bg, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
@@ -1134,14 +1154,14 @@ __global__ __launch_bounds__(256) void frames_bin_fill_kernel(const FrameDev<T>*
                                     f.atom_rec, blockIdx.x);
 }
 
-template <int N, typename T, int PFAST>
+template <int N, typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(const FrameDev<T>* __restrict__ table) {
   const FrameDev<T>& f = table[blockIdx.y];
   const unsigned n_spread = unsigned(f.bg.nb);
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(f.spread, blockIdx.x);
   else if (blockIdx.x - n_spread < f.n_row_blocks)
-    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2>(f.rows, blockIdx.x - n_spread);
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread);
 }
 
 template <int N, typename T>
@@ -1219,7 +1239,8 @@ static int frames_check(int dtype, int n_frames, const mipme_frame_t* fr) {
                       f.entries_shift && f.entries && f.records && f.rho_mesh && f.phi_mesh && f.dc && f.out && f.force &&
                       f.field && f.energy && f.grad_positions,
                   "frame %d: NULL buffer or no atoms", k);
-    MIPME_REQUIRE(f.shift_format == kShiftTable, "frame %d: the frames path needs the table shift format", k);
+    MIPME_REQUIRE((f.shift_format == kShiftTable || f.shift_format == kShiftTable32) && f.shift_format == fr[0].shift_format,
+                  "frame %d: the frames path needs the table shift format (1 or 2), the same for every frame", k);
   }
   return MIPME_OK;
 }
@@ -1287,7 +1308,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.tail.grad_pos = d.grad_pos;
     d.tail.energy = d.energy;
     d.tail.epart_sr = v.epart;
-    d.tail.n_sr = int(d.n_row_blocks);
+    d.tail.n_sr = kSpreadWaves * int(d.n_row_blocks);
     d.tail.epart_k = nullptr;  // per batch entry: set by frames_forward (plan scratch)
     d.tail.n_k = 0;
     d.use_tail = f.use_tail != 0;
@@ -1298,7 +1319,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
 }
 
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t);
 int64_t xconv_blocks(const mipme_fft_plan*);
 void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 bool fft_plan_xfused(const mipme_fft_plan*);
@@ -1323,12 +1344,19 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
   const int64_t rpb = SPREAD_THREADS / kRowLanes;
   const unsigned grid_x = unsigned(bg.nb) + unsigned((max_atoms + rpb - 1) / rpb);
-  if (pfast == 1)
+  const bool compact = fr[0].shift_format == kShiftTable32;  // frames_check: the same format for every frame
+  if (pfast == 1 && compact)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, frames_spread_rows_kernel<N, T, 1><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+                             ((void)S, frames_spread_rows_kernel<N, T, 1, true><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+  else if (pfast == 1)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, frames_spread_rows_kernel<N, T, 1, false><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+  else if (compact)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, frames_spread_rows_kernel<N, T, 6, true><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
   else
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, frames_spread_rows_kernel<N, T, 6><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
+                             ((void)S, frames_spread_rows_kernel<N, T, 6, false><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
   MIPME_LAUNCH_CHECK();
   bool all_tail = true;
   for (int k = 0; k < n_frames; ++k) all_tail = all_tail && fr[k].use_tail != 0;
@@ -1336,7 +1364,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   double* epart_k = all_tail ? (double*)fft_plan_tail_scratch(plan, int64_t(sizeof(double)) * n_k * n_frames) : nullptr;
   MIPME_REQUIRE(!all_tail || epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
                                       "capture: run one evaluation before capturing)");
-  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k);
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k, nullptr, 0);
   if (rc) return rc;
   if (all_tail) {  // energy + forces of every frame in the gather launch
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,

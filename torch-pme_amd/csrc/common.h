@@ -217,6 +217,7 @@ struct GatherTailHost {
   void* energy;        // 1 real
   const void* epart_k; // fp64[n_k]: per-workgroup sums of mu G |rho^|^2 written by the x stage of the convolution
   int64_t n_k;
+  int sr_reduced;      // the x stage has also reduced the pair kernel's per-wave partial sums to epart_k[n_k + 2 b ...]
 };
 
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position

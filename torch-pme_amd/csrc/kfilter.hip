@@ -637,7 +637,8 @@ template <typename T, bool CELLSUMS>
 __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                    Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
                                                    T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
-                                                   double* __restrict__ epart) {
+                                                   double* __restrict__ epart, const double* __restrict__ sr_part,
+                                                   int n_sr_part) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   const int KZ = 1 << kzs;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
@@ -649,6 +650,18 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   const int kz0 = chunk << kzs;
   const int kzn = min(KZ, nzh - kz0);
   const int half_n = nx >> 1;
+  // sr_part (nullable, single batch entry): pre-reduce this block's slice of the pair kernel's per-wave energy partial sums
+  // {sum q V_sr, sum q^2} (rows_body.h FusedRowsArgs::epart) into epart[gridDim.x + 2 b ...] -- they were written two
+  // launches ago, and the gather's tail then adds up gridDim.x pairs instead of N / 4
+  double sr0 = 0.0, sr1 = 0.0;
+  if (sr_part && tid < 64) {
+    const int per = (n_sr_part + int(gridDim.x) - 1) / int(gridDim.x);
+    const int lo = int(blockIdx.x) * per, hi = min(lo + per, n_sr_part);
+    for (int i = lo + tid; i < hi; i += 64) {
+      sr0 += sr_part[2 * i];
+      sr1 += sr_part[2 * i + 1];
+    }
+  }
   for (int j = tid; j < half_n; j += nthr) unit_root(j, nx, tw[j].re, tw[j].im);
   Cplx<T>* col = hat + (int64_t(c) * nx * ny + ky) * nzh + kz0;  // element (x, z): col[x * ny * nzh + z]
   const int64_t xs = int64_t(ny) * nzh;
@@ -766,6 +779,17 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
       for (int w = 0; w < (nthr + 63) / 64; ++w) v += ered[w];
       epart[blockIdx.x] = v;
     }
+    if (sr_part && tid < 64) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        sr0 += __shfl_xor(sr0, off, 64);
+        sr1 += __shfl_xor(sr1, off, 64);
+      }
+      if (tid == 0) {
+        epart[int64_t(gridDim.x) + 2 * int64_t(blockIdx.x)] = sr0;
+        epart[int64_t(gridDim.x) + 2 * int64_t(blockIdx.x) + 1] = sr1;
+      }
+    }
   }
   __syncthreads();
   // ---- inverse, decimation in time: stages m = 2, 4, ..., nx; conjugate twiddles, no normalisation
@@ -827,7 +851,7 @@ int64_t xconv_blocks(const mipme_fft_plan* p) {
 // cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
-                    void* cell_partials, void* epart) {
+                    void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part) {
   if (!p->own_yz) {
     MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
     MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
@@ -863,10 +887,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
                                                             (const float*)G, G_stride, (float*)dc, kg, kp,
-                                                            (double*)cell_partials, (double*)epart);
+                                                            (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part));
     else
       xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
-                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart);
+                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part));
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<float>(p, st, true, nullptr, hat, mesh_out);
@@ -884,10 +908,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
                                                              (const double*)G, G_stride, (double*)dc, kg, kp,
-                                                             (double*)cell_partials, (double*)epart);
+                                                             (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part));
     else
       xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart);
+                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part));
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<double>(p, st, true, nullptr, hat, mesh_out);

@@ -15,7 +15,11 @@ namespace mipme {
 // Code formats: kShiftPacked = 3 x int8 (little end first); kShiftTable = index (sx+3) + 7 (sy+3) + 49 (sz+3) into the
 // 343-entry table of Cartesian shift vectors the kernel keeps in LDS (needs |s| <= 3).
 // flag bits: 1 = some shift is not an integer in [-127,127]; 2 = some |shift| > 3 (table format unusable).
-enum ShiftFormat { kShiftPacked = 0, kShiftTable = 1 };
+// kShiftTable32: the table code AND the partner in ONE 32-bit word per entry -- other | code << 22 (343 codes < 2^9,
+// atoms < 2^22) -- which halves the entry stream of the co-scheduled pair sum (76 -> 38 MB at cfg3).
+enum ShiftFormat { kShiftPacked = 0, kShiftTable = 1, kShiftTable32 = 2 };
+static constexpr int kCompactAtomBits = 22;
+static constexpr int64_t kCompactMaxAtoms = int64_t(1) << kCompactAtomBits;
 static constexpr int kShiftTableRange = 3, kShiftTableBase = 2 * kShiftTableRange + 1;
 static constexpr int kShiftTableSize = kShiftTableBase * kShiftTableBase * kShiftTableBase;
 
@@ -80,8 +84,9 @@ struct FusedRowsArgs {
   T* force;
   double* partials;
   T* dist_out;
-  // kPotForce only, nullable: per-workgroup sums {sum_a q_a out_a, sum_a q_a^2} over the rows of the workgroup (fp64[2] per
-  // workgroup) -- the pair part of the energy and the self-term sum, reduced later by the gather's tail (bricks.hip)
+  // kPotForce only, nullable: per-WAVE sums {sum_a q_a out_a, sum_a q_a^2} over the rows of the wave (fp64[2] per wave, wave
+  // w of workgroup b at index b * BS/64 + w) -- the pair part of the energy and the self-term sum, reduced later by the
+  // gather's tail (bricks.hip)
   double* epart;
 };
 
@@ -118,13 +123,24 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
 
 // BS = threads of the workgroup (BS / kRowLanes rows per workgroup); block = index of the workgroup among the row workgroups
 // UNROLL: entries in flight per lane (0 = the measured default for the dtype, see below)
-template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE, int BS, int UNROLL = 0>
+// COMPACT: the entry stream is kShiftTable32 (one int per entry; implies TABLE)
+template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE, int BS, int UNROLL = 0, bool COMPACT = false>
 __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args, unsigned block) {
+  static_assert(!COMPACT || (TABLE && !MASK), "compact entries carry table codes and have no pair-mask variant");
   const SRPot& s = args.s;
   const FastRS& cf = args.cf;
   const int64_t N = args.N;
   const int* __restrict__ row_ptr = args.row_ptr;
   const int2* __restrict__ ent_sh = args.ent_sh;
+  const int* __restrict__ ent32 = reinterpret_cast<const int*>(args.ent_sh);
+  auto load_entry = [&](int e) -> int2 {
+    if constexpr (COMPACT) {
+      const int w = ent32[e];
+      return make_int2(w & int(kCompactMaxAtoms - 1), int(unsigned(w) >> kCompactAtomBits));
+    } else {
+      return ent_sh[e];
+    }
+  };
   const int2* __restrict__ entries = args.entries;
   const uint8_t* __restrict__ mask = args.mask;
   const T* __restrict__ pos = args.pos;
@@ -194,7 +210,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   for (int u = 0; u < U; ++u) {
     const int e = beg + u * kRowLanes + sub;
     const int ec = e < end ? e : beg;
-    en_next[u] = ent_sh[ec];
+    en_next[u] = load_entry(ec);
     if constexpr (MASK) pm_next[u] = entries[ec].y;
   }
   for (int base = beg; base < end; base += kRowLanes * U) {
@@ -222,7 +238,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
     for (int u = 0; u < U; ++u) {
       const int e = base + kRowLanes * U + u * kRowLanes + sub;
       const int ec = e < end ? e : beg;
-      en_next[u] = ent_sh[ec];
+      en_next[u] = load_entry(ec);
       if constexpr (MASK) pm_next[u] = entries[ec].y;
     }
 #pragma unroll
@@ -305,22 +321,14 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
     pot = row_sum(pot);
     if (sub == 0 && valid) out[a] = (accumulate ? out[a] : T(0)) + T(0.5) * pot;
     if constexpr (MODE == kPotForce) {
-      if (args.epart) {  // uniform: energy partial sums of this workgroup's rows
-        __shared__ double ered[BS / 64][2];
+      if (args.epart) {  // uniform: energy partial sums of this WAVE's rows (no barrier, no LDS: the waves retire independently)
         const bool mine = sub == 0 && valid;
-        const double e1 = wave_sum(mine ? double(qa) * double(T(0.5) * pot) : 0.0);
-        const double e2 = wave_sum(mine ? double(qa) * double(qa) : 0.0);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) {
-          ered[wave][0] = e1;
-          ered[wave][1] = e2;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2) {
-          double v = 0.0;
-#pragma unroll
-          for (int w = 0; w < BS / 64; ++w) v += ered[w][threadIdx.x];
-          args.epart[2 * int64_t(block) + threadIdx.x] = v;
+        const T e1 = wave_sum(mine ? qa * (T(0.5) * pot) : T(0));
+        const T e2 = wave_sum(mine ? qa * qa : T(0));
+        if ((threadIdx.x & 63) == 0) {
+          const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
+          args.epart[2 * w] = double(e1);
+          args.epart[2 * w + 1] = double(e2);
         }
       }
     }

@@ -152,11 +152,16 @@ __global__ void topo_pack_entries_kernel(int64_t E, int64_t n_rows, const int* _
     }
   }
   int word;
-  if (format == kShiftTable)
+  if (format == kShiftTable || format == kShiftTable32)
     word = (sh[0] + kShiftTableRange) + kShiftTableBase * ((sh[1] + kShiftTableRange) + kShiftTableBase * (sh[2] + kShiftTableRange));
   else
     word = (sh[0] & 0xff) | ((sh[1] & 0xff) << 8) | ((sh[2] & 0xff) << 16);
-  ent_sh[e] = make_int2(en.x, word);
+  if (format == kShiftTable32) {
+    const bool fits = !(bits & 2);  // codes of out-of-range shifts do not fit 9 bits: the caller sees flag bit 1 and discards
+    reinterpret_cast<int*>(ent_sh)[e] = en.x | ((fits ? word : 0) << kCompactAtomBits);
+  } else {
+    ent_sh[e] = make_int2(en.x, word);
+  }
   if (bits) atomicOr(flag, bits);
 }
 
@@ -676,7 +681,10 @@ int mipme_topology_pack_entries(void* stream, int dtype, int64_t n_pairs, int64_
                                 const void* entries, const void* shifts, int shift_format, void* entries_shift,
                                 void* flag) {
   MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && flag && row_ptr, "invalid arguments to mipme_topology_pack_entries");
-  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable, "invalid shift format %d", shift_format);
+  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable || shift_format == kShiftTable32,
+                "invalid shift format %d", shift_format);
+  MIPME_REQUIRE(shift_format != kShiftTable32 || n_atoms <= kCompactMaxAtoms,
+                "the 32-bit entry format holds atom indices below 2^22, got %lld atoms", (long long)n_atoms);
   hipStream_t st = (hipStream_t)stream;
   MIPME_CHECK_HIP(zero_async(flag, sizeof(int), st));
   const int64_t E = 2 * n_pairs;

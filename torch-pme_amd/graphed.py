@@ -174,6 +174,7 @@ class GraphedFrameBatch:
         self._frames = (_lib.Frame * F)()
         self._minus_one = torch.full((F,), -1.0, dtype=dtype, device=device)
         self._grad_pos, self.distances = [], []
+        compact_ok, ent_streams = True, []
         for k, (q, cell, pos, pairs, shifts) in enumerate(frames):
             N, P = pos.shape[0], pairs.shape[0]
             p = pos.detach().clone().contiguous().requires_grad_(True)
@@ -184,6 +185,9 @@ class GraphedFrameBatch:
             ent_sh, fmt = topo.entries_with_shifts(sh, shifts, table=True)
             if ent_sh is None or fmt != 1:
                 raise ValueError(f"frame {k}: cell shifts must be integers in [-3, 3] for the frames path")
+            ent32 = topo.compact_entries(sh, shifts)  # 4-byte entries when every frame has them
+            compact_ok = compact_ok and ent32 is not None
+            ent_streams.append((ent_sh, ent32))
             md = geoms[k].desc(1)
             nbytes = lib.mipme_atom_bins_bytes(C.byref(md), N, dt)
             if nbytes <= 0:
@@ -214,7 +218,10 @@ class GraphedFrameBatch:
             self.pos.append(p)
             self._grad_pos.append(buf["grad"])
             self.distances.append(buf["dist"])
-            self._keep.append((qc, cl, sh, topo, ent_sh, buf, pairs))
+            self._keep.append((qc, cl, sh, topo, ent_sh, ent32, buf, pairs))
+        if compact_ok:  # the same (compact) entry format for every frame
+            for k, (_, ent32) in enumerate(ent_streams):
+                self._frames[k].entries_shift, self._frames[k].shift_format = ent32.data_ptr(), 2
         nbytes = lib.mipme_frames_table_bytes(dt, F)
         host = np.zeros((nbytes,), dtype=np.uint8)
         _lib.check(lib.mipme_frames_table_build(dt, F, self._frames, C.byref(self._pot), host.ctypes.data, nbytes))

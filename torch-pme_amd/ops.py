@@ -117,6 +117,10 @@ MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
 #: run the short-range pair sum inside the spread launch of the mesh part (see mipme_sr_job_t in include/mipme.h)
 COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
 ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
+#: 4-byte entries {partner | shift code << 22} for the co-scheduled pair sum (half the entry stream; needs < 2^22 atoms)
+COMPACT_ENTRIES = os.environ.get("MIPME_COMPACT_ENTRIES", "1") != "0"
+#: bytes per entry of the pair stream the co-scheduled kernel reads (bench.py's algorithmic byte count)
+FUSED_ENTRY_BYTES = 4 if COMPACT_ENTRIES else 8
 #: energy reduction + force assembly inside the gather launch when the forward can tell they will be wanted (see the tail
 #: block of _PMEFunction.forward and _EnergyDirectSum)
 TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
@@ -170,6 +174,7 @@ class PairTopology:
         self._packed = None  # (weakref(shifts), version, tensor|None)
         self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
         self._pair_sh = None  # (weakref(shifts), version, tensor|None)
+        self._ent32 = None  # (weakref(shifts)|None, version, tensor|None)
         self._sorted = None
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
@@ -234,6 +239,33 @@ class PairTopology:
             packed = None
         self._pair_sh = (weakref.ref(key), key._version, packed)
         return packed
+
+    def compact_entries(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None):
+        """int32 (2P + 1,) entry stream of the co-scheduled pair sum, ``other | code << 22`` (format 2, see ``mipme.h``), or
+        ``None`` when it does not apply (more than 2^22 atoms, shifts beyond the table range or not integers).  Cached per
+        shifts tensor like the 8-byte streams."""
+        if not COMPACT_ENTRIES or self.n_atoms > (1 << 22):
+            return None
+        c = self._ent32
+        if c is not None and ((key is None and c[0] is None) or (key is not None and c[0] is not None and c[0]() is key
+                                                                   and c[1] == key._version)):
+            return c[2]
+        lib = _lib.load()
+        device = self.entries.device
+        ent32 = torch.zeros((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
+        flag = torch.empty((1,), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(
+                lib.mipme_topology_pack_entries(
+                    _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
+                    self.n_pairs, self.n_atoms, self.row_ptr.data_ptr(), self.entries.data_ptr(), _lib.ptr(shifts), 2,
+                    ent32.data_ptr(), flag.data_ptr(),
+                )
+            )
+        if shifts is not None and int(flag.item()) != 0:
+            ent32 = None
+        self._ent32 = (None if key is None else weakref.ref(key), 0 if key is None else key._version, ent32)
+        return ent32
 
     def entries_with_shifts(self, shifts: torch.Tensor | None, key: torch.Tensor | None = None, table: bool = True):
         """``(ent_sh, shift_format)``: the int32 (2P, 2) stream {other atom, role-adjusted cell-shift code} of the fused
@@ -492,10 +524,13 @@ class _PMEFunction(torch.autograd.Function):
                 job = None
                 if (COSCHEDULE and records_out is not None and mask is None and fused["fmt"] == 1
                         and fused["partials"] is None and N > 0):
+                    ent32 = topo.compact_entries(src.shifts, src.shifts_key)
                     job = _lib.SrJob(
-                        n_atoms=N, row_ptr=topo.row_ptr.data_ptr(), entries_shift=fused["ent_sh"].data_ptr(),
+                        n_atoms=N, row_ptr=topo.row_ptr.data_ptr(),
+                        entries_shift=(fused["ent_sh"] if ent32 is None else ent32).data_ptr(),
                         entries=topo.entries.data_ptr(), positions=fused["pos"].data_ptr(), cell=_lib.ptr(fused["cell"]),
-                        charges=q.data_ptr(), pot=C.pointer(pot_desc), full_list=int(full_list), shift_format=fused["fmt"],
+                        charges=q.data_ptr(), pot=C.pointer(pot_desc), full_list=int(full_list),
+                        shift_format=fused["fmt"] if ent32 is None else 2,
                         records=records_out.data_ptr(), out=out.data_ptr(), force=_lib.ptr(fused["force"]),
                         dist_out=dist.data_ptr() if write_dist else None,
                     )
