@@ -188,6 +188,10 @@ typedef struct mipme_kspace_forward_args {
   void* out_energy;
   void* out_grad_positions;
   const void* grad_seed;
+  /* NaN guard of KSpaceFilter.forward (lib/kspace_filter.py:189-195 raises when the filtered mesh holds a NaN, after a
+   * device synchronisation): nan_flag (nullable) points to ONE int32 the gather kernel sets to 1 if a long-range potential it
+   * writes is NaN -- device memory, or pinned host memory the caller reads without synchronising (at the next call, ...). */
+  void* nan_flag;
 } mipme_kspace_forward_args_t;
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
 /* out_cell_partials (nullable, needs rho_hat == NULL; float64[mipme_cellgrad_partials_size]): the x stage of the fused

@@ -1,6 +1,7 @@
 """CPU tests (no GPU) of the host side: the C-ABI library loads and exports every declared symbol, argument
 validation reproduces the reference's exception types and messages, constructors, prefactors, neighbour list."""
 
+import math
 import os
 import re
 
@@ -323,3 +324,79 @@ def test_ctypes_structs_mirror_the_header_field_by_field():
     b.size = 8
     assert lib.mipme_kspace_backward(C.byref(b)) == -1 and b"size" in lib.mipme_last_error()
     assert lib.mipme_kspace_forward(None) == -1
+
+
+# ---- copies, pickles, checkpoints (round-1 advisor: deepcopy / torch.save of a used calculator raised) ----
+def test_calculator_copies_pickles_and_reference_checkpoints():
+    import copy
+    import ctypes as C
+    import io
+    import pickle
+    import weakref
+
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.2, prefactor=3.0), mesh_spacing=0.4, interpolation_nodes=5)
+    cell = torch.eye(3)
+    # the state a forward pass leaves behind: a weak reference to the caller's cell, FFT plans holding raw device pointers,
+    # the pinned NaN flag
+    calc._cache = (weakref.ref(cell), 0, torch.float32, "cuda", None, None, None, None)
+    calc._plan_store = {"key": C.c_void_p(1234)}
+    calc._nan_flag = torch.zeros(1, dtype=torch.int32)
+    for clone in (copy.deepcopy(calc), pickle.loads(pickle.dumps(calc))):
+        assert clone._cache is None and clone._plan_store == {} and clone._nan_flag is None
+        assert clone.interpolation_nodes == 5 and clone.mesh_spacing == 0.4
+        assert float(clone.potential.smearing) == 1.2 and float(clone.potential.prefactor) == 3.0
+    assert calc._plan_store and calc._cache is not None  # the original keeps its state
+    buf = io.BytesIO()
+    torch.save(calc, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert type(again) is tpa.P3MCalculator and again._plan_store == {}
+    ew = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=0.5)
+    ew._freq_cache = (weakref.ref(cell), 0, "cuda", 0.5, cell)
+    assert copy.deepcopy(ew)._freq_cache is None
+    # a checkpoint written by the reference's P3MCalculator / PMECalculator: extra kspace_filter.* entries, strict load
+    ref_sd = {
+        "potential.smearing": torch.tensor(0.7, dtype=torch.float64), "potential.prefactor": torch.tensor(2.0, dtype=torch.float64),
+        "kspace_filter._diff_coeff": torch.zeros(6, 6), "kspace_filter.kernel.smearing": torch.tensor(0.7, dtype=torch.float64),
+        "kspace_filter.kernel.prefactor": torch.tensor(2.0, dtype=torch.float64),
+    }
+    res = calc.load_state_dict(ref_sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert float(calc.potential.smearing) == 0.7 and calc.potential._descriptor().smearing == 0.7
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        calc.load_state_dict({**ref_sd, "something.else": torch.zeros(1)}, strict=True)
+    # wrapped in a parent module the prefix logic still applies
+    parent = torch.nn.ModuleDict({"lr": tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.5)})
+    parent.load_state_dict({"lr." + k: v for k, v in ref_sd.items() if "_diff_coeff" not in k}, strict=True)
+    assert float(parent["lr"].potential.prefactor) == 2.0
+
+
+def test_potential_closed_forms_match_scipy():
+    """Python-side potential methods (inspection API): the lower incomplete gamma without cancellation at small distances
+    (advisor: 1 - Q lost 1.6e-7 at d = 0.05 for p = 6), the Fourier kernels of p = 3, 5 through E1, the 2-D slab term."""
+    import scipy.special as sp
+
+    d = torch.tensor([1e-3, 0.05, 0.3, 1.0, 2.5, 7.0], dtype=torch.float64)
+    sm = 1.3
+    for p in range(1, 7):
+        pot = tpa.InversePowerLawPotential(exponent=p, smearing=sm)
+        ref = sp.gammainc(0.5 * p, (0.5 * d * d / sm**2).numpy()) / d.numpy() ** p
+        np.testing.assert_allclose(pot.lr_from_dist(d).numpy(), ref, rtol=5e-14)
+    k2 = torch.tensor([0.0, 1e-6, 0.01, 0.5, 1.0, 3.0, 20.0], dtype=torch.float64)
+    z = (0.5 * sm**2 * k2[1:]).numpy()
+    for p, f in ((3, sp.exp1(z)), (5, np.exp(-z) - z * sp.exp1(z))):
+        c0 = np.pi**1.5 / math.gamma(0.5 * p) * (2 * sm**2) ** (0.5 * (3 - p))
+        got = tpa.InversePowerLawPotential(exponent=p, smearing=sm).lr_from_k_sq(k2).numpy()
+        np.testing.assert_allclose(got[1:], c0 * f, rtol=1e-12)
+        assert got[0] == (0.0 if p == 3 else -c0 / (0.5 * (3 - p)))
+    # slab term of CoulombPotential.pbc_correction against the formula of coulomb.py:6-40 written out with numpy
+    rng = np.random.default_rng(0)
+    pos, q = rng.uniform(0, 5, (7, 3)), rng.normal(size=(7, 2))
+    cell = np.array([[5.0, 0, 0], [1, 6, 0], [0.3, 0.2, 7]])
+    pot = tpa.CoulombPotential(smearing=1.0, prefactor=2.0)
+    got = pot.pbc_correction(torch.tensor([True, False, True]), torch.tensor(pos), torch.tensor(cell), torch.tensor(q)).numpy()
+    z1 = pos[:, 1:2]
+    Q, M, M2 = q.sum(0), (q * z1).sum(0), (q * z1 * z1).sum(0)
+    want = 2.0 * 4 * np.pi / abs(np.linalg.det(cell)) * (z1 * M - 0.5 * (M2 + Q * z1 * z1) - Q * np.linalg.norm(cell[1]) ** 2 / 12)
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    assert float(pot.pbc_correction(torch.tensor([True, True, True]), torch.tensor(pos), torch.tensor(cell), torch.tensor(q)).abs().max()) == 0.0

@@ -144,6 +144,7 @@ class KspaceForwardArgs(_VersionedArgs):
         ("gather_wait_event", C.c_void_p), ("out_field", C.c_void_p), ("out_records", C.c_void_p),
         ("sr_job", C.POINTER(SrJob)), ("out_cell_partials", C.c_void_p),
         ("out_energy", C.c_void_p), ("out_grad_positions", C.c_void_p), ("grad_seed", C.c_void_p),
+        ("nan_flag", C.c_void_p),
     ]
 
 

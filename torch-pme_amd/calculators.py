@@ -33,12 +33,61 @@ class Calculator(torch.nn.Module):
             raise TypeError(f"Potential must be an instance of Potential, got {type(potential)}")
         self.potential = potential
         self.full_neighbor_list = full_neighbor_list
-        #: opt-in NaN guard of the reference (``lib/kspace_filter.py:189-195``).  Off by default: it costs a device
-        #: synchronisation per call, which the reference pays unconditionally.
-        self.check_nan = False
+        #: NaN guard of the reference (``lib/kspace_filter.py:189-195``: ValueError when the k-space result holds a NaN).  The
+        #: reference pays a device synchronisation per call for it.  Here the gather kernels raise a flag in pinned host
+        #: memory whenever a potential they write is NaN (no extra launch, no synchronisation), and the flag is looked at
+        #:   "deferred" (default) -- at the start of the NEXT call of this calculator and in :meth:`check`: the same error,
+        #:                           one call late, at no cost;
+        #:   True                 -- right after the call (synchronises, as the reference does);
+        #:   False                -- never.
+        self.check_nan = "deferred"
+        self._nan_flag = None  # pinned int32[1], created on first use
+        self._nan_shape = None
         self._spec_str = None
         if type(self) is Calculator:
             self._spec()
+
+    # ---- copies and checkpoints ------------------------------------------------------------------------------------------
+    #: per-instance device state that must not travel with a copy / pickle (FFT plans own raw device pointers, the caches
+    #: hold weak references to the caller's tensors); rebuilt on first use
+    _TRANSIENT = {"_cache": None, "_plan_store": dict, "_freq_cache": None, "_nan_flag": None, "_nan_shape": None}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for name, fresh in self._TRANSIENT.items():
+            if name in state:
+                state[name] = fresh() if callable(fresh) else fresh
+        return state
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints written by the reference's calculators carry ``kspace_filter.*`` entries (copies of the potential's
+        buffers inside its filter module, and the finite-difference table of ``P3MKSpaceFilter``): this build derives the
+        filter from ``potential`` alone, so they are accepted and ignored -- a strict load of a reference checkpoint works."""
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        ignored = prefix + "kspace_filter."
+        unexpected_keys[:] = [k for k in unexpected_keys if not k.startswith(ignored)]
+
+    # ---- NaN guard ---------------------------------------------------------------------------------------------------------
+    def _nan_flag_ptr(self):
+        if self.check_nan is False or self.check_nan is None:
+            return None
+        if self._nan_flag is None:
+            self._nan_flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        return self._nan_flag.data_ptr()
+
+    def check(self) -> None:
+        """Raise the reference's ``ValueError`` if a NaN was seen in the results of an earlier call (see ``check_nan``).  The
+        flag is host memory written by the device: a call that is still running has not set it yet."""
+        flag = self._nan_flag
+        if flag is not None and int(flag[0]) != 0:
+            flag[0] = 0
+            shape = self._nan_shape
+            raise ValueError(
+                "NaNs detected in the k-space filter result. This are probably caused "
+                "by an unsuitable `mesh_spacing`, resulting in a problematic grid of "
+                f"shape: {shape}. Try adjsuting the grid by using a "
+                "different `mesh_spacing` value."
+            )
 
     # mesh calculators override this to return (MeshGeometry, G); the base class has no k-space part
     def _kspace_setup(self, cell, dtype, device):
@@ -111,6 +160,8 @@ class Calculator(torch.nn.Module):
             kvectors=kvectors,
         )
         _lib.require_device(positions, "positions")
+        if self.check_nan == "deferred":
+            self.check()  # a NaN seen by an earlier call surfaces here
         pot_desc = self.potential._descriptor()
         has_kspace = self.potential.smearing is not None
         if has_kspace and (node_mask is not None or kvectors is not None):
@@ -120,17 +171,16 @@ class Calculator(torch.nn.Module):
         is_coulombic = pot_desc.kind == _lib.COULOMB or pot_desc.exponent == 1  # the slab term exists for 1/r only
         if has_kspace and periodic is not None and is_coulombic:
             slab_axis = ops._slab_axis(periodic.tolist())
+        nan_flag = self._nan_flag_ptr() if geom is not None else None
+        if nan_flag is not None:
+            self._nan_shape = [charges.shape[1], *geom.ns]
         out = ops.pme_potential(
             charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
-            bool(self.full_neighbor_list), slab_axis,
+            bool(self.full_neighbor_list), slab_axis, nan_flag,
         )
-        if self.check_nan and geom is not None and bool(torch.isnan(out).any()):
-            raise ValueError(
-                "NaNs detected in the k-space filter result. This are probably caused "
-                "by an unsuitable `mesh_spacing`, resulting in a problematic grid of "
-                f"shape: {[charges.shape[1], *geom.ns]}. Try adjsuting the grid by using a "
-                "different `mesh_spacing` value."
-            )
+        if self.check_nan is True and geom is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(positions.device).synchronize()
+            self.check()
         return out
 
 
@@ -185,7 +235,7 @@ class PMECalculator(Calculator):
             and c[2] == dtype
             and c[3] == device
             and c[4] == pkey
-            and c[5] == self.mesh_spacing
+            and c[5] == (self.mesh_spacing, self.interpolation_nodes)
         ):
             return c[6], c[7]
         cell_host = cell.detach().to("cpu", torch.float64).numpy()
@@ -193,7 +243,8 @@ class PMECalculator(Calculator):
         geom = ops.MeshGeometry(cell_host, ns, self._scheme, self.interpolation_nodes)
         geom.plan_store = self._plan_store
         G = ops.build_filter(geom, pot_desc, dtype, device)
-        self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, self.mesh_spacing, geom, G)
+        self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, (self.mesh_spacing, self.interpolation_nodes),
+                       geom, G)
         return geom, G
 
 

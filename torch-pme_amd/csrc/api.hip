@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 // implemented in mesh.hip / kfilter.hip / rspace.hip
 template <typename T> int spread_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, double, void*);
 template <typename T> int gather_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
-template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*, int);
+template <typename T> int gather_epilogue_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, double, double, void*, void*, int, void*);
 template <typename T> int gather_grad_impl(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 template <typename T> int kfilter_build_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int apply_filter_impl(hipStream_t, int64_t, int, const void*, const void*, void*, void*);
@@ -57,7 +57,7 @@ template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_
                                         const mipme_sr_job_t*, bool);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
-template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*, void*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
@@ -118,7 +118,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
                             void* wait_event, int accumulate, void* out_field, void* out_records,
-                            const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail) {
+                            const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail, void* nan_flag) {
   int rc;
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
@@ -160,9 +160,9 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
     STAGE(st, tail ? "gather+energy+forces" : "gather",
-          gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field, tail));
+          gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field, tail, nan_flag));
   else
-    STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate));
+    STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, nan_flag));
   return MIPME_OK;
 }
 
@@ -594,10 +594,10 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
   DT_SWITCH(a.dtype,
             kspace_forward_t<float>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                     a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
-                                    a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp),
+                                    a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag),
             kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                      a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
-                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp));
+                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag));
 }
 
 int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {

@@ -638,7 +638,8 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
                                                   const T* __restrict__ mesh, const T* __restrict__ q,
                                                   const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c, bool accumulate,
                                                   T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
-                                                  unsigned block, const GatherTail<T>* tail = nullptr) {
+                                                  unsigned block, const GatherTail<T>* tail = nullptr,
+                                                  int* __restrict__ nan_flag = nullptr) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
   static_assert(!TAIL || FIELD, "the tail needs the mesh field");
   constexpr int LANES = kGatherLanes;
@@ -745,6 +746,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
           const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[c]);
           const T v_final = accumulate ? out_early + lr : lr;
           out[o] = v_final;
+          if (nan_flag && lr != lr) *nan_flag = 1;  // NaN guard of kspace_filter.py:189-195 (see mipme.h, nan_flag)
           if (raw) raw[o] = phi;
         } else {
           out[o] = acc;
@@ -762,9 +764,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      const T* __restrict__ mesh, const T* __restrict__ q,
                                                                      const T* __restrict__ qsum, T inv_vol, T self_c,
                                                                      T bg_c, bool accumulate, T* __restrict__ out,
-                                                                     T* __restrict__ raw, T* __restrict__ field) {
+                                                                     T* __restrict__ raw, T* __restrict__ field,
+                                                                     int* __restrict__ nan_flag) {
   gather_brick_body<N, FIELD, T>(g, bg, C, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
-                                 blockIdx.x);
+                                 blockIdx.x, nullptr, nan_flag);
 }
 
 // gather + energy + force assembly (see GatherTail)
@@ -774,9 +777,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_tail_kernel(Geom g, Bri
                                                                     const T* __restrict__ mesh, const T* __restrict__ q,
                                                                     const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
                                                                     T* __restrict__ out, T* __restrict__ raw,
-                                                                    T* __restrict__ field, GatherTail<T> tail) {
+                                                                    T* __restrict__ field, GatherTail<T> tail,
+                                                                    int* __restrict__ nan_flag) {
   gather_brick_body<N, true, T, true>(g, bg, 1, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw, field,
-                                      blockIdx.x, &tail);
+                                      blockIdx.x, &tail, nan_flag);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -1035,7 +1039,7 @@ bool sr_job_fusable(const mipme_sr_job_t* job) {
 template <typename T>
 int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
                   const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate, void* field,
-                  const GatherTailHost* th) {
+                  const GatherTailHost* th, void* nan_flag) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
@@ -1062,7 +1066,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                  g, bg, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
-                                 T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail)));
+                                 T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
@@ -1071,13 +1075,13 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
                              ((void)S, gather_brick_kernel<N, true, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                  g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
-                                 (T*)raw, (T*)field)));
+                                 (T*)raw, (T*)field, (int*)nan_flag)));
   else
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_brick_kernel<N, false, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
                                  g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
-                                 (T*)raw, nullptr)));
+                                 (T*)raw, nullptr, (int*)nan_flag)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -1388,9 +1392,9 @@ template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, voi
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                    const mipme_sr_job_t*, bool);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                  double, double, void*, void*, int, void*, const GatherTailHost*);
+                                  double, double, void*, void*, int, void*, const GatherTailHost*, void*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                   double, double, void*, void*, int, void*, const GatherTailHost*);
+                                   double, double, void*, void*, int, void*, const GatherTailHost*, void*);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
                                        const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,

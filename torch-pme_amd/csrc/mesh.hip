@@ -93,7 +93,8 @@ template <int SCHEME, int N, bool EPILOGUE, typename T>
 __global__ __launch_bounds__(256) void gather_kernel(Geom g, int64_t n_atoms, int C, const T* __restrict__ pos,
                                                     const T* __restrict__ mesh, const T* __restrict__ q,
                                                     const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
-                                                    bool accumulate, T* __restrict__ out, T* __restrict__ raw) {
+                                                    bool accumulate, T* __restrict__ out, T* __restrict__ raw,
+                                                    int* __restrict__ nan_flag = nullptr) {
   constexpr int LANES = StencilGroup<N>::LANES;
   constexpr int APB = 256 / LANES;
   const int l = threadIdx.x % LANES;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void gather_kernel(Geom g, int64_t n_atoms, in
         const T qi = q[atom * C + c];
         const T lr = T(0.5) * (phi - self_c * qi - T(2) * bg_c * inv_vol * qsum[c]);
         out[atom * C + c] = accumulate ? out[atom * C + c] + lr : lr;
+        if (nan_flag && lr != lr) *nan_flag = 1;  // NaN guard of kspace_filter.py:189-195 (see mipme.h, nan_flag)
         if (raw) raw[atom * C + c] = phi;
       } else {
         out[atom * C + c] = acc;
@@ -253,13 +255,13 @@ int gather_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const vo
 template <typename T>
 int gather_epilogue_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, const void* mesh,
                          const void* q, const void* qsum, double self_c, double bg_c, void* out, void* raw,
-                         int accumulate) {
+                         int accumulate, void* nan_flag) {
   if (n_atoms == 0) return MIPME_OK;
   const Geom g = make_geom(m);
   MIPME_DISPATCH_STENCIL(m->scheme, m->order,
                          (gather_kernel<S, N, true, T><<<blocks_for<N>(n_atoms), 256, 0, st>>>(
                              g, n_atoms, m->n_channels, (const T*)pos, (const T*)mesh, (const T*)q, (const T*)qsum,
-                             T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out, (T*)raw)));
+                             T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out, (T*)raw, (int*)nan_flag)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -285,9 +287,9 @@ template int spread_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, cons
 template int gather_impl<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
 template int gather_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, void*);
 template int gather_epilogue_impl<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*,
-                                         const void*, const void*, double, double, void*, void*, int);
+                                         const void*, const void*, double, double, void*, void*, int, void*);
 template int gather_epilogue_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*,
-                                          const void*, const void*, double, double, void*, void*, int);
+                                          const void*, const void*, double, double, void*, void*, int, void*);
 template int gather_grad_impl<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*,
                                      const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_impl<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, const void*, const void*,

@@ -150,6 +150,29 @@ __device__ __forceinline__ void upper_gamma(int p, T x, T& Q, T& dens) {
   }
 }
 
+// P(p/2, x) = 1 - Q, the regularised LOWER incomplete gamma, for small x from its power series
+//   P(a, x) = x^a e^-x sum_{k>=0} x^k / Gamma(a + k + 1)
+// (what the reference evaluates directly: torch.special.gammainc, inversepowerlaw.py:98-103).  1 - Q loses all relative
+// precision as x -> 0 -- P ~ x^a / Gamma(a+1) -- which matters inside an exclusion radius (mode 2: v = -v_LR f_cut): in fp32
+// with p = 5, 6 it rounded to zero below d ~ 0.13 sigma.  Used for x < 1, where 12 (float) / 22 (double) terms reach the
+// rounding level (term ratio x / (a + k)).
+template <typename T>
+__device__ __forceinline__ T lower_gamma_series(int p, T x) {
+  // 1 / Gamma(p/2 + 1), p = 1..6
+  constexpr double inv_gamma[6] = {1.1283791670955126, 1.0, 0.7522527780636751, 0.5, 0.30090111122547003, 1.0 / 6.0};
+  const T a = T(0.5) * T(p);
+  T term = T(inv_gamma[p - 1]), sum = term;
+  constexpr int K = sizeof(T) == 4 ? 12 : 22;
+#pragma unroll
+  for (int k = 1; k <= K; ++k) {
+    term *= x / (a + T(k));
+    sum += term;
+  }
+  T xa = powi(x, p / 2);
+  if (p & 1) xa *= fsqrt(x);
+  return xa * fexp(-x) * sum;
+}
+
 // v_SR(d) and dv_SR/dd (see oracle/pme_numpy.py::sr_pair for the derivation).
 template <typename T, bool DERIV>
 __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
@@ -187,7 +210,7 @@ __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
     v = pref * Q * invp;
     if constexpr (DERIV) dv = pref * (-dens * dxdd * invp - T(s.p) * Q * invp * inv);
   } else {
-    const T P = T(1) - Q;
+    const T P = x < T(1) ? lower_gamma_series<T>(s.p, x) : T(1) - Q;
     const T vl = pref * P * invp;
     v = -vl * fc;
     if constexpr (DERIV) {

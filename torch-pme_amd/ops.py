@@ -420,7 +420,7 @@ class _PMEFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G, pot_desc,
-                full_list, slab_axis, src_positions=None, src_cell=None, src=None, lazy=False):
+                full_list, slab_axis, src_positions=None, src_cell=None, src=None, lazy=False, nan_flag=None):
         lib = _lib.load()
         device, dtype = positions.device, positions.dtype
         dt = _lib.dtype_code(dtype)
@@ -524,7 +524,13 @@ class _PMEFunction(torch.autograd.Function):
                 job = None
                 if (COSCHEDULE and records_out is not None and mask is None and fused["fmt"] == 1
                         and fused["partials"] is None and N > 0):
-                    ent32 = topo.compact_entries(src.shifts, src.shifts_key)
+                    # the 4-byte entry stream is read by the co-scheduled kernel only (mipme.h, shift_format 2): use it when the
+                    # library will co-schedule -- force sums wanted, 1/r or 1/r^6 with a smearing and no exclusion radius
+                    p_job = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+                    ent32 = None
+                    if (fused["force"] is not None and p_job in (1, 6) and pot_desc.smearing > 0
+                            and pot_desc.exclusion_radius <= 0):
+                        ent32 = topo.compact_entries(src.shifts, src.shifts_key)
                     job = _lib.SrJob(
                         n_atoms=N, row_ptr=topo.row_ptr.data_ptr(),
                         entries_shift=(fused["ent_sh"] if ent32 is None else ent32).data_ptr(),
@@ -567,7 +573,7 @@ class _PMEFunction(torch.autograd.Function):
                     sr_job=C.pointer(job) if job is not None else None, out_cell_partials=_lib.ptr(cell_partials),
                     out_energy=None if tail is None else tail["energy"].data_ptr(),
                     out_grad_positions=None if tail is None else tail["grad"].data_ptr(),
-                    grad_seed=None if tail is None else _lib.ptr(tail["seed"]),
+                    grad_seed=None if tail is None else _lib.ptr(tail["seed"]), nan_flag=nan_flag,
                 )
                 _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
@@ -842,11 +848,11 @@ class _PMEFunction(torch.autograd.Function):
                 grad_dist = LazyPairGradient(P, dtype, device, grad_src_pos, grad_src_cell, make_grad_dist)
                 grad_src_pos = grad_src_cell = None
         return (grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None, grad_src_pos,
-                grad_src_cell, None, None)
+                grad_src_cell, None, None, None)
 
 
 def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
-                  full_list, slab_axis):
+                  full_list, slab_axis, nan_flag=None):
     src = getattr(neighbor_distances, "_mipme_src", None)
     if src is not None and src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1]):
         # the fused kernels differentiate through the distances in the same pass (see FUSE_DISTANCES)
@@ -854,10 +860,10 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
             # default: the pair part's gradient flows through ``neighbor_distances`` (lazily, LazyPairGradient) and on to
             # positions / cell via that tensor's own node -- the reference's autograd graph
             return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom,
-                                      G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, True)
+                                      G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, True, nan_flag)
         # opt-in (``deferred=True``): straight to the tensors the distances were built from, bypassing ``d``
         out = _PMEFunction.apply(charges, cell, positions, neighbor_distances.detach(), neighbor_indices, pair_mask, geom,
-                                 G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, False)
+                                 G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, False, nan_flag)
         node = out.grad_fn
         if node is not None and getattr(node, "energy_direct", False):
             out._mipme_energy = (node, positions, charges, charges._version)
@@ -865,7 +871,7 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
     if src is not None and src.pending:
         src.materialize()
     return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
-                              pot_desc, full_list, slab_axis, None, None, None, False)
+                              pot_desc, full_list, slab_axis, None, None, None, False, nan_flag)
 
 
 def _launch_pair_distances(pos, cl, pairs, sh, shifts_key, out):

@@ -40,6 +40,48 @@ def _reg_upper_gamma(p: int, x: torch.Tensor) -> torch.Tensor:
     return q
 
 
+def _exp1(z: torch.Tensor) -> torch.Tensor:
+    """E1(z) = Gamma(0, z) for z > 0 (what the reference gets from ``lib/math.py:5-83``): power series
+    -gamma - ln z - sum_k (-z)^k / (k k!) below z = 1, modified-Lentz continued fraction 1/(z+1-1/(z+3-4/(z+5-...))) above;
+    both to double-precision rounding, as plain tensor expressions (differentiable)."""
+    zs = z.clamp(max=1.0)
+    term = torch.ones_like(z)
+    ssum = torch.zeros_like(z)
+    for k in range(1, 26):
+        term = term * (-zs) / k
+        ssum = ssum - term / k
+    series = -0.5772156649015329 - torch.log(zs) + ssum
+    zl = z.clamp(min=1.0)
+    b = zl + 1.0
+    c = torch.full_like(z, 1e300)
+    d = 1.0 / b
+    h = d
+    for i in range(1, 61):
+        an = -float(i * i)
+        b = b + 2.0
+        d = 1.0 / (an * d + b)
+        c = b + an / c
+        h = h * (c * d)
+    return torch.where(z < 1.0, series, h * torch.exp(-zl))
+
+
+_INV_GAMMA_HALF = {p: 1.0 / math.gamma(0.5 * p + 1.0) for p in range(1, 7)}
+
+
+def _reg_lower_gamma(p: int, x: torch.Tensor) -> torch.Tensor:
+    """P(p/2, x) = 1 - Q without the cancellation at small x: power series x^a e^-x sum_k x^k / Gamma(a+k+1) below x = 1
+    (the reference calls ``torch.special.gammainc``, ``inversepowerlaw.py:98-103``), 1 - Q above."""
+    a = 0.5 * p
+    xs = x.clamp(max=1.0)
+    term = torch.full_like(x, _INV_GAMMA_HALF[p])
+    total = term.clone()
+    for k in range(1, 25):
+        term = term * xs / (a + k)
+        total = total + term
+    series = xs**a * torch.exp(-xs) * total
+    return torch.where(x < 1.0, series, 1 - _reg_upper_gamma(p, x))
+
+
 class Potential(torch.nn.Module):
     """Base interface of a pair potential (reference ``potentials/potential.py:4-212``).
 
@@ -143,6 +185,7 @@ class Potential(torch.nn.Module):
         raise NotImplementedError(f"background_correction is not implemented for {self.__class__.__name__}")
 
     def pbc_correction(self, periodic, positions, cell, charges):
+        """Correction for systems that are not periodic in all three directions; zero unless a subclass has one."""
         return self.prefactor * torch.zeros_like(charges)
 
 
@@ -165,7 +208,7 @@ class _PowerLawPotential(Potential):
             raise ValueError("Cannot compute long-range contribution without specifying `smearing`.")
         d = dist.clamp(min=1e-12)
         x = 0.5 * d * d / self.smearing**2
-        out = (1 - _reg_upper_gamma(self._p, x)) / d**self._p
+        out = _reg_lower_gamma(self._p, x) / d**self._p
         if pair_mask is not None:
             out = out * pair_mask
         return self.prefactor * out
@@ -187,11 +230,10 @@ class _PowerLawPotential(Potential):
             f = 2 * (ez - torch.sqrt(torch.pi * z) * torch.erfc(torch.sqrt(z)))
         elif p == 6:
             f = ((2 - 4 * z) * ez + 4 * torch.sqrt(torch.pi * z**3) * torch.erfc(torch.sqrt(z))) / 3
-        else:
-            raise NotImplementedError(
-                "the Python-side Fourier kernel for p = 3, 5 needs E1(z); it is evaluated in csrc/kfilter.hip "
-                "(use lib.KSpaceFilter to obtain it on the device)"
-            )
+        elif p == 3:  # Gamma(0, z) = E1(z)
+            f = _exp1(z)
+        else:  # p == 5: Gamma(-1, z) / z^-1 = e^-z - z E1(z)
+            f = ez - z * _exp1(z)
         k0 = -c0 / a if p > 3 else 0.0
         return self.prefactor * torch.where(zero, k0 * torch.ones_like(k_sq), c0 * f)
 
@@ -235,6 +277,23 @@ class CoulombPotential(_PowerLawPotential):
 
     _kind = _lib.COULOMB
     _p = 1
+
+    def pbc_correction(self, periodic, positions, cell, charges):
+        """2-D slab term (reference ``potentials/coulomb.py:6-40,160-167``), non-zero when exactly two of ``periodic`` are
+        True: ``(4 pi / V) (z_i M - (M2 + Q z_i^2) / 2 - Q L_z^2 / 12)`` with z along the non-periodic axis, Q, M, M2 the
+        zeroth / first / second moments of the charges along it and L_z the length of that cell vector.  (The calculators
+        evaluate the same expression in ``mipme_slab_forward``; this method is the inspectable tensor form.)"""
+        if periodic is None:
+            periodic = torch.ones(3, dtype=torch.bool, device=charges.device)
+        flags = [bool(v) for v in periodic.tolist()]
+        if sum(flags) != 2:
+            return self.prefactor * torch.zeros_like(charges)
+        axis = flags.index(False)
+        z = positions[:, axis : axis + 1]
+        volume = torch.abs(torch.det(cell))
+        Lz = torch.linalg.norm(cell[axis])
+        Q, M, M2 = charges.sum(dim=0), (charges * z).sum(dim=0), (charges * z * z).sum(dim=0)
+        return self.prefactor * (4 * math.pi / volume) * (z * M - 0.5 * (M2 + Q * z * z) - Q / 12.0 * Lz * Lz)
 
     def __init__(
         self,
