@@ -917,7 +917,7 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
 
 // the per-wave energy partial sums of the co-scheduled pair sum inside the bins buffer (n = number of {e, q^2} pairs)
 const void* bins_epart(const mipme_mesh_t* m, int64_t N, int dtype, void* bins, int64_t* n) {
-  *n = int64_t(kSpreadWaves) * ((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  *n = (N + 64 / kRowLanes - 1) / (64 / kRowLanes);  // waves that hold a valid row
   return bins_view(m, N, dtype, bins).epart;
 }
 
@@ -1056,7 +1056,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     tail.grad_pos = (T*)th->grad_pos;
     tail.energy = (T*)th->energy;
     tail.epart_sr = (const double*)v.epart;
-    tail.n_sr = kSpreadWaves * int((N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+    tail.n_sr = int((N + 64 / kRowLanes - 1) / (64 / kRowLanes));  // waves that hold a valid row (slot = first row / rows per wave)
     tail.epart_k = (const double*)th->epart_k;
     tail.n_k = int(th->n_k);
     if (th->sr_reduced) {  // pre-reduced by the x stage of the convolution (kfilter.hip xconv_kernel, sr_part)
@@ -1312,7 +1312,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.tail.grad_pos = d.grad_pos;
     d.tail.energy = d.energy;
     d.tail.epart_sr = v.epart;
-    d.tail.n_sr = kSpreadWaves * int(d.n_row_blocks);
+    d.tail.n_sr = int((f.n_atoms + 64 / kRowLanes - 1) / (64 / kRowLanes));
     d.tail.epart_k = nullptr;  // per batch entry: set by frames_forward (plan scratch)
     d.tail.n_k = 0;
     d.use_tail = f.use_tail != 0;
