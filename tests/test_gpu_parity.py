@@ -939,3 +939,51 @@ def test_plane_kernels_large_lds(dtype, monkeypatch):
         calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.7, interpolation_nodes=5).to(dtype)
         res.append(calc(q, cell, pos, none, nod).double().cpu().numpy())
     assert rell2(res[0], res[1]) < (1e-13 if dtype == torch.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("blob", ["corner", "two"])
+def test_bin_overflow_region(dtype, blob):
+    """One-pass binning: a brick owns a fixed number of slots (4 x the mean occupancy + 8) and the atoms that find it full go
+    to the overflow region, which every particle <-> mesh kernel also walks.  A dense blob in an otherwise empty cell puts
+    nearly all atoms there: potentials, energy and every gradient must still match the oracle (spread, gather, the general
+    adjoint's second spread + gradient gather, the energy-mode gather tail)."""
+    rng = np.random.default_rng(17)
+    L = 24.0
+    cell = np.eye(3) * L
+    N = 260
+    if blob == "corner":
+        pos = rng.uniform(0.2, 2.8, (N, 3))  # a 2.6 A cube: one or two mesh bricks out of 512
+    else:
+        pos = np.concatenate([rng.uniform(3.0, 5.5, (N // 2, 3)), rng.uniform(15.0, 17.5, (N - N // 2, 3))])
+    q = rng.normal(size=(N, 1))
+    q -= q.mean()
+    sm, h = 1.0, 2 * L / 62  # -> 64^3 mesh: 512 bricks, mean occupancy 0.5 -> 8 slots per brick
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 4.0)
+    spec = O.PotentialSpec("coulomb", 1, sm, 1.0)
+    g = rng.normal(size=(N, 1))
+    Vo, cache = O.forward(spec, "P3M", 5, h, q, cell, pos, pairs, dist, return_cache=True)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=sm), mesh_spacing=h, interpolation_nodes=5).to(dtype)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=dtype, requires_grad=grad)  # noqa: E731
+    ti, tS = torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV)
+    tolV, tolG = (1e-11, 1e-10) if dtype == torch.float64 else (2e-5, 2e-4)
+    for energy in (False, True):
+        gr = O.backward(cache, q if energy else g)
+        gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+        tq, tc, tp = t(q, not energy), t(cell, True), t(pos, True)
+        d = tpa.pair_distances(tp, ti, tc, tS, deferred=energy)
+        V = calc(tq, tc, tp, ti, d)
+        (tpa.weighted_sum(V, tq) if energy else (V * t(g)).sum()).backward()
+        assert rell2(V.detach().cpu().double(), Vo) < tolV
+        assert rell2(tp.grad.cpu().double(), gr["positions"] + gpos_d) < tolG
+        assert relmax(tc.grad.cpu().double(), gr["cell"] + gcell_d) < 10 * tolG
+        if not energy:
+            assert rell2(tq.grad.cpu().double(), gr["charges"]) < tolV * 10
+    # the graph-replayed step (gather tail: energy + forces in the gather launch) on the same blob
+    tq, tc, tp = t(q), t(cell), t(pos)
+    step = tpa.GraphedEnergyForces(calc, tq, tc, tp, ti, tS)
+    E, F = step()
+    gr = O.backward(cache, q)
+    gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    assert abs(float(E) - float((Vo * q).sum())) < (1e-11 if dtype == torch.float64 else 2e-5) * abs(float((Vo * q).sum()))
+    assert rell2(F.cpu().double(), -(gr["positions"] + gpos_d)) < tolG

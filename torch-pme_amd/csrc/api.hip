@@ -57,7 +57,7 @@ template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_
                                         const mipme_sr_job_t*, bool);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
-template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*, void*);
+template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
 template <typename T> int gather_grad_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, const void*, const void*, const void*, double, double, void*, void*);
 
 // ---- optional per-stage timing (bench.py): HIP events recorded on the launch stream around every stage ----
@@ -123,18 +123,27 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
+  // the plan's brick counters are zero here; the binning pass fills them and the gather -- the last consumer -- zeroes them
+  // again (no memset launch per call).  If anything in between fails they are cleared explicitly, so that a failed call does
+  // not poison the next one.
+  struct CounterGuard {
+    hipStream_t st;
+    int* counters;
+    size_t n;
+    bool armed;
+    ~CounterGuard() {
+      if (armed && counters) (void)zero_async(counters, sizeof(int) * n, st);
+    }
+  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1, false};
   if (bins) {
-    // the plan's counters are zero here and the spread clears them again (no memset launch); if the spread cannot be
-    // launched they are cleared explicitly so that a failed call does not poison the next one
     int* counters = fft_plan_brick_count(plan);
+    guard.counters = counters;
+    guard.armed = true;
     STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins, counters, q, out_records));
     {
       const bool co = job && sr_job_fusable(job);
       ProfScope _ps(st, co ? "spread+rspace_forward" : "spread");
-      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr))) {
-        (void)hipMemsetAsync(counters, 0, sizeof(int) * (size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1), st);
-        return rc;
-      }
+      if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr))) return rc;
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",
@@ -160,9 +169,12 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   if (wait_event) MIPME_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
   if (bins)
     STAGE(st, tail ? "gather+energy+forces" : "gather",
-          gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field, tail, nan_flag));
+          gather_bricks<T>(st, m, N, bins, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, out_field, tail, nan_flag,
+                           fft_plan_brick_count(plan)));
   else
     STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, nan_flag));
+  guard.armed = N == 0 && bins;  // the gather has zeroed the counters (it does not run without atoms: nothing was counted either)
+  guard.armed = false;
   return MIPME_OK;
 }
 

@@ -56,29 +56,59 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   return true;
 }
 
+// ---- atom bins: fixed-capacity brick slots, ONE binning pass -----------------------------------------------------------
+// Brick b owns the slots [b * cap, (b + 1) * cap) of the record / weight arrays; an atom takes the next free slot of its
+// brick with one (wave-aggregated) returning atomic on the brick's counter and writes its record and weights there at
+// once -- no counting pass, no scan, no second pass (round 1: bin_count 5.0 us + bin_fill 6.8 us at cfg3, both pure
+// latency).  Atoms that find their brick full go to the overflow region behind the brick slots (counter live[nb], home
+// brick in over_brick[k]); every consumer also scans it, which is a single load when it is empty.  cap = 4 x the mean
+// occupancy + 8 (multiple of 8), so overflow means a density contrast above 4.
+//   live  (plan / frame owned, zero between calls): int[nb + 1] counters; the binning pass fills them, the forward spread
+//         reads them and copies them to `snap`, the forward gather -- the last consumer -- zeroes them again.
+//   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
+//         gathers of the forward and by everything in the backward pass.
 struct BinsLayout {
-  size_t count, start, slot, brick, rec, wts, epart, total;
+  size_t snap, over_brick, rec, wts, epart, total;
+  int cap;
+  int64_t slots;  // nb * cap + N
 };
 static constexpr int kRowsPerSpreadBlock = 512 / kRowLanes;  // rows per workgroup of the co-scheduled pair sum (SPREAD_THREADS)
 static constexpr int kSpreadWaves = 512 / 64;
+
+static inline int bin_capacity(int nb, int64_t N) {
+  const int64_t mean = (N + nb - 1) / nb;
+  int64_t cap = (4 * mean + 8 + 7) / 8 * 8;
+  const int64_t all = (N + 7) / 8 * 8;  // never more than all atoms
+  if (cap > all) cap = all;
+  return int(cap < 8 ? 8 : cap);
+}
 
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
   const size_t s = dtype == MIPME_F32 ? 4 : 8;
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   BinsLayout l;
+  l.cap = bin_capacity(b.nb, N);
+  l.slots = int64_t(b.nb) * l.cap + N;
   size_t off = 0;
-  l.count = off; off += al(sizeof(int) * size_t(b.nb + 1));
-  l.start = off; off += al(sizeof(int) * size_t(b.nb + 1));
-  l.slot = off;  off += al(sizeof(int) * size_t(N));
-  l.brick = off; off += al(sizeof(int) * size_t(N));
-  l.rec = off;   off += al(sizeof(int4) * size_t(N));
-  l.wts = off;   off += al(6 * size_t(m->order) * s * size_t(N));  // per atom: wx, wy, wz, dwx, dwy, dwz (n each)
+  l.snap = off;       off += al(sizeof(int) * size_t(b.nb + 1));
+  l.over_brick = off; off += al(sizeof(int) * size_t(N));
+  l.rec = off;        off += al(sizeof(int4) * size_t(l.slots));
+  l.wts = off;        off += al(6 * size_t(m->order) * s * size_t(l.slots));  // per slot: wx, wy, wz, dwx, dwy, dwz (n each)
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.total = off;
   return l;
 }
+
+// what the consumers need to walk the bins
+struct BinIndex {
+  int* live;              // counters of the binning pass (see above); NULL in the backward pass
+  int* snap;              // per-call snapshot
+  const int* over_brick;  // home brick of every overflow atom
+  int nb, cap;
+  int64_t over_base;      // = nb * cap
+};
 
 int64_t bins_bytes(const mipme_mesh_t* m, int64_t N, int dtype) {
   if (!bricks_supported(m, dtype)) return 0;
@@ -115,19 +145,23 @@ __device__ __forceinline__ void atom_mesh_coords(const Geom& g, bool even, const
 
 // ---- binning -----------------------------------------------------------------------------------
 // Lanes of a wavefront that fall into the same brick share ONE returning atomic (atoms are usually stored in a
-// spatially coherent order, so a wave touches only a handful of bricks): leader election over the ballot mask.
-template <typename T>
-__device__ __forceinline__ void bin_count_body(const Geom& g, const BrickGeom& bg, bool even, int64_t N,
-                                               const T* __restrict__ pos, int* __restrict__ count, int* __restrict__ slot,
-                                               int* __restrict__ brick, unsigned block) {
+// spatially coherent order, so a wave touches only a handful of bricks): leader election over the ballot mask.  The atom
+// then writes its record {mesh coordinates, atom index} and its 1-D weights (and derivatives) -- evaluated ONCE, the four
+// particle<->mesh kernels of a step only load them -- straight into its slot, and (atom_rec) the (position, charge) record
+// of the fused pair kernels while the position is in registers anyway.
+template <int SCHEME, int N, typename T>
+__device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& bg, const BinIndex& bi, int64_t Natoms,
+                                               const T* __restrict__ pos, int* __restrict__ over_brick,
+                                               int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
+                                               AtomRecord<T>* __restrict__ atom_rec, unsigned block) {
   const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
-  const bool valid = i < N;
+  const bool valid = i < Natoms;
   const int lane = threadIdx.x & 63;
   int b = -1;
+  int m[3] = {0, 0, 0};
+  double x[3] = {0.0, 0.0, 0.0};
   if (valid) {
-    int m[3];
-    double x[3];
-    atom_mesh_coords<T>(g, even, pos, i, m, x);
+    atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
     b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
   }
   // pass 1 (no memory traffic): group the lanes by brick; every lane learns its leader lane and its rank
@@ -146,97 +180,19 @@ __device__ __forceinline__ void bin_count_body(const Geom& g, const BrickGeom& b
   }
   // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
   int base = 0;
-  if (valid && my_leader == lane) base = atomicAdd(&count[b], my_count);
+  if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
   base = __shfl(base, my_leader, 64);
+  if (!valid) return;
   const int myslot = base + my_rank;
-  if (valid) {
-    brick[i] = b;
-    slot[i] = myslot;
+  int64_t dst;
+  if (myslot < bi.cap) {
+    dst = int64_t(b) * bi.cap + myslot;
+  } else {  // brick full: overflow region (rare; one atomic per atom)
+    const int k = atomicAdd(&bi.live[bi.nb], 1);
+    over_brick[k] = b;
+    dst = bi.over_base + k;
   }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bin_count_kernel(Geom g, BrickGeom bg, bool even, int64_t N,
-                                                       const T* __restrict__ pos, int* __restrict__ count,
-                                                       int* __restrict__ slot, int* __restrict__ brick) {
-  bin_count_body<T>(g, bg, even, N, pos, count, slot, brick, blockIdx.x);
-}
-
-// exclusive scan of count[0..nb) into start[0..nb]; single block
-__global__ __launch_bounds__(1024) void bin_scan_kernel(int nb, const int* __restrict__ count, int* __restrict__ start) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (nb + 1023) / 1024;
-  const int lo = t * per, hi = min(lo + per, nb);
-  int s = 0;
-  for (int k = lo; k < hi; ++k) s += count[k];
-  part[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;
-  for (int k = lo; k < hi; ++k) {
-    start[k] = run;
-    run += count[k];
-  }
-  if (t == 1023) start[nb] = part[1023];
-}
-
-// Scatter the atoms into brick order and evaluate their 1-D weights (and derivatives) ONCE: the four
-// particle<->mesh kernels of a step (spread, gather, spread of the gradient, gradient gather) only load them.
-// FUSED_SCAN: every block first rebuilds the exclusive scan of the (<= 1024) brick counts in LDS -- cheaper than a
-// separate single-block scan kernel plus its launch boundary; block 0 also publishes it as `start`.
-static constexpr int kFusedScanMax = 1024;
-
-template <int SCHEME, int N, bool FUSED_SCAN, typename T>
-__device__ __forceinline__ void bin_fill_body(const Geom& g, int nb, int64_t Natoms, const T* __restrict__ pos,
-                                              const int* __restrict__ count, int* __restrict__ start,
-                                              const int* __restrict__ slot, const int* __restrict__ brick,
-                                              int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
-                                              AtomRecord<T>* __restrict__ atom_rec, unsigned block) {
-  __shared__ int sstart[FUSED_SCAN ? kFusedScanMax + 1 : 1];
-  __shared__ int wsum[4];
-  if constexpr (FUSED_SCAN) {
-    // 4 consecutive counts per thread, wave scan, then wave offsets
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int c[4], run = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = 4 * t + k;
-      c[k] = idx < nb ? count[idx] : 0;
-      run += c[k];
-    }
-    int incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - run;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = 4 * t + k;
-      if (idx <= nb) sstart[idx] = base;
-      base += c[k];
-    }
-    if (t == 255 && nb == kFusedScanMax) sstart[nb] = base;
-    __syncthreads();
-    if (block == 0)
-      for (int idx = t; idx <= nb; idx += 256) start[idx] = sstart[idx];
-  }
-  const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
-  if (i >= Natoms) return;
-  int m[3];
-  double x[3];
-  atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
-  if (atom_rec) {  // (position, charge) records for the fused pair kernels, while the position is in registers anyway
+  if (atom_rec) {
     AtomRecord<T> r;
     r.x = pos[3 * i];
     r.y = pos[3 * i + 1];
@@ -244,8 +200,6 @@ __device__ __forceinline__ void bin_fill_body(const Geom& g, int nb, int64_t Nat
     r.w = q[i];
     atom_rec[i] = r;
   }
-  const int b = brick[i];
-  const int64_t dst = int64_t(FUSED_SCAN ? sstart[b] : start[b]) + slot[i];
   rec[dst] = make_int4(m[0], m[1], m[2], int(i));
   T* wr = wts + dst * (6 * N);
 #pragma unroll
@@ -260,13 +214,19 @@ __device__ __forceinline__ void bin_fill_body(const Geom& g, int nb, int64_t Nat
   }
 }
 
-template <int SCHEME, int N, bool FUSED_SCAN, typename T>
-__global__ __launch_bounds__(256) void bin_fill_kernel(Geom g, int nb, int64_t Natoms, const T* __restrict__ pos,
-                                                      const int* __restrict__ count, int* __restrict__ start,
-                                                      const int* __restrict__ slot, const int* __restrict__ brick,
-                                                      int4* __restrict__ rec, T* __restrict__ wts,
-                                                      const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
-  bin_fill_body<SCHEME, N, FUSED_SCAN, T>(g, nb, Natoms, pos, count, start, slot, brick, rec, wts, q, atom_rec, blockIdx.x);
+template <int SCHEME, int N, typename T>
+__global__ __launch_bounds__(256) void bin_atoms_kernel(Geom g, BrickGeom bg, BinIndex bi, int64_t Natoms,
+                                                       const T* __restrict__ pos, int* __restrict__ over_brick,
+                                                       int4* __restrict__ rec, T* __restrict__ wts,
+                                                       const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
+  bin_atoms_body<SCHEME, N, T>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x);
+}
+
+// number of atoms of brick `b` (clamped to the slots it has) and of the overflow region, from the live counters of a
+// forward pass or from the snapshot
+__device__ __forceinline__ int bin_count_of(const BinIndex& bi, int b, bool from_live) {
+  const int c = from_live ? bi.live[b] : bi.snap[b];
+  return b == bi.nb ? c : min(c, bi.cap);
 }
 
 // ---- shared device helpers ---------------------------------------------------------------------
@@ -342,7 +302,7 @@ static constexpr int SPREAD_THREADS = 512;
 static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
 static constexpr int SPREAD_GROUP = 16;                           // threads per neighbouring brick in the candidate scan
 static constexpr int SPREAD_CPT = 6;                              // candidates per thread and round (96 per brick and round)
-static constexpr int SPREAD_ROUND = 27 * SPREAD_GROUP * SPREAD_CPT;  // candidates per round = capacity of the survivor lists
+static constexpr int SPREAD_ROUND = 28 * SPREAD_GROUP * SPREAD_CPT;  // candidates per round = capacity of the survivor lists (27 bricks + overflow)
 static constexpr size_t SPREAD_LDS_MAX = 64 * 1024;
 
 static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows) {
@@ -360,13 +320,13 @@ struct SpreadArgs {
   Geom g;
   BrickGeom bg;
   int C;
-  const int* start;
+  BinIndex bins;
+  bool from_live;  // forward: brick counts from the live counters (and snapshot them); backward: from the snapshot
   const int4* rec;
   const T* wts;
   const T* val;
   T scale;
   T* mesh;
-  int* clear_count;
   int stage_rows;
 };
 
@@ -376,16 +336,18 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   const Geom& g = args.g;
   const BrickGeom& bg = args.bg;
   const int C = args.C;
-  const int* __restrict__ start = args.start;
+  const BinIndex& bins = args.bins;
   const int4* __restrict__ rec = args.rec;
   const T* __restrict__ wts = args.wts;
   const T* __restrict__ val = args.val;
   const T scale = args.scale;
   T* __restrict__ mesh = args.mesh;
-  int* __restrict__ clear_count = args.clear_count;
   const int stage_rows = args.stage_rows;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (clear_count && threadIdx.x == 0) clear_count[block] = 0;  // leave the plan's brick counters clean (bins_build)
+  if (args.from_live && threadIdx.x == 0) {  // per-call snapshot of this brick's count for the gathers and the backward pass
+    bins.snap[block] = bin_count_of(bins, int(block), true);
+    if (block == 0) bins.snap[bins.nb] = bin_count_of(bins, bins.nb, true);
+  }
   constexpr int SW = sizeof(T) == 4 ? ((BRICK + 1 + 2 * N + 3) & ~3) : BRICK + 1 + 2 * N;  // staged reals per survivor (spread_row_reals)
   const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
@@ -399,18 +361,22 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // candidate scan: 16 threads per neighbouring brick (27 x 16 = 432 of the 512 threads) walk that brick's atom records
-  // in rounds of 64 -- the thread -> (brick, atom) mapping needs no search and the 16-byte record loads stay coalesced
+  // in rounds of 64 -- the thread -> (brick, atom) mapping needs no search and the 16-byte record loads stay coalesced;
+  // a 28th group walks the overflow region (atoms whose brick was full: normally none)
   const int grp = tid / SPREAD_GROUP, sub = tid % SPREAD_GROUP;
   int gstart = 0, glen = 0;
   if (grp < 27) {
     const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
     const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
-    gstart = start[nbr];
-    glen = start[nbr + 1] - gstart;
+    gstart = nbr * bins.cap;
+    glen = bin_count_of(bins, nbr, args.from_live);
+  } else if (grp == 27) {
+    gstart = int(bins.over_base);
+    glen = bin_count_of(bins, bins.nb, args.from_live);
   }
   if (tid == 0) maxlen = 0;
   __syncthreads();
-  if (grp < 27 && sub == 0) atomicMax(&maxlen, glen);
+  if (grp < 28 && sub == 0) atomicMax(&maxlen, glen);
   __syncthreads();
   const int total = maxlen;  // longest of the 27 candidate lists
   constexpr int s0 = stencil_start<N>();
@@ -633,7 +599,7 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
 }
 
 template <int N, bool FIELD, typename T, bool TAIL = false>
-__device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom& bg, int C, const int* __restrict__ start,
+__device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom& bg, int C, const BinIndex& bins,
                                                   const int4* __restrict__ rec, const T* __restrict__ wts,
                                                   const T* __restrict__ mesh, const T* __restrict__ q,
                                                   const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c, bool accumulate,
@@ -649,13 +615,20 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   int bx, by, bz;
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
-  const int beg = start[block], end = start[block + 1];
+  // this brick's atoms: its own slots, then -- normally none -- the atoms of the overflow region whose home brick it is
+  const int beg = int(block) * bins.cap, end = beg + bins.snap[block];
+  const int n_over = bins.snap[bins.nb];
+  if (bins.live && threadIdx.x == 0) {  // forward pass, last consumer of the live counters: leave them zero for the next call
+    bins.live[block] = 0;
+    if (block == 0) bins.live[bins.nb] = 0;
+  }
   T seed = T(1);
   if constexpr (TAIL) {
     if (tail->seed) seed = tail->seed[0];
     if (block == 0) tail_energy<T, GATHER_THREADS>(*tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
   }
-  if (beg == end) return;
+  if (beg == end && n_over == 0) return;
+  const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
   const bool lane_active = l < N;
@@ -667,11 +640,20 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
     // the third overlaps the stencil arithmetic -- not five in series (each is a trip to the Infinity Cache: the inputs
     // were written by other XCDs in the previous kernels).
     bool staged = false;
-    for (int base = beg; base < end; base += GROUPS) {
-      const int idx = base + grp;
-      const bool valid = idx < end;
-      const int id = valid ? idx : beg;
-      const int4 a = rec[id];
+    for (int it = 0; it < main_iters + over_iters; ++it) {
+      bool valid;
+      int id;
+      if (it < main_iters) {
+        const int idx = beg + it * GROUPS + grp;
+        valid = idx < end;
+        id = valid ? idx : beg;
+      } else {
+        const int k = (it - main_iters) * GROUPS + grp;
+        valid = k < n_over && bins.over_brick[k < n_over ? k : 0] == int(block);
+        id = int(bins.over_base) + (k < n_over ? k : 0);
+      }
+      int4 a = rec[id];
+      if (!valid) a = make_int4(ox, oy, oz, 0);  // a slot that may never have been written: keep every index derived from it in range
       const T* wr = wts + int64_t(id) * (6 * N);
       T wx[N], wy[N], dwx[FIELD ? N : 1], dwy[FIELD ? N : 1];
 #pragma unroll
@@ -698,7 +680,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
       }
       T f_early = T(0);  // TAIL: lanes 0..2 hold the x, y, z components of the atom's pair force sum
       if constexpr (TAIL) f_early = tail->force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
-      if (base == beg) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
+      if (it == 0) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       const T* tp = tile + ry * TL + (rz + tz);
       T sA = T(0), sB = T(0), sC = T(0);  // sum wx wy M,  sum dwx wy M,  sum wx dwy M   over (t_x, t_y) of this z column
@@ -757,8 +739,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
 }
 
 template <int N, bool FIELD, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C,
-                                                                     const int* __restrict__ start,
+__global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, BrickGeom bg, int C, BinIndex bins,
                                                                      const int4* __restrict__ rec,
                                                                      const T* __restrict__ wts,
                                                                      const T* __restrict__ mesh, const T* __restrict__ q,
@@ -766,27 +747,27 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      T bg_c, bool accumulate, T* __restrict__ out,
                                                                      T* __restrict__ raw, T* __restrict__ field,
                                                                      int* __restrict__ nan_flag) {
-  gather_brick_body<N, FIELD, T>(g, bg, C, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
+  gather_brick_body<N, FIELD, T>(g, bg, C, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
                                  blockIdx.x, nullptr, nan_flag);
 }
 
 // gather + energy + force assembly (see GatherTail)
 template <int N, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, const int* __restrict__ start,
+__global__ __launch_bounds__(GATHER_THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
                                                                     const int4* __restrict__ rec, const T* __restrict__ wts,
                                                                     const T* __restrict__ mesh, const T* __restrict__ q,
                                                                     const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
                                                                     T* __restrict__ out, T* __restrict__ raw,
                                                                     T* __restrict__ field, GatherTail<T> tail,
                                                                     int* __restrict__ nan_flag) {
-  gather_brick_body<N, true, T, true>(g, bg, 1, start, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw, field,
+  gather_brick_body<N, true, T, true>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw, field,
                                       blockIdx.x, &tail, nan_flag);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
 template <int N, typename T>
 __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
-    Geom g, BrickGeom bg, int C, const int* __restrict__ start, const int4* __restrict__ rec, const T* __restrict__ wts,
+    Geom g, BrickGeom bg, int C, BinIndex bins, const int4* __restrict__ rec, const T* __restrict__ wts,
     const T* __restrict__ q, const T* __restrict__ gout, const T* __restrict__ phi, const T* __restrict__ chi,
     const T* __restrict__ psi_dc, const T* __restrict__ gscale, T half_inv_vol, T self_c, T bg_c,
     T* __restrict__ grad_pos, T* __restrict__ grad_q) {
@@ -803,8 +784,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
   int bx, by, bz;
   brick_coords(bg, blockIdx.x, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
-  const int beg = start[blockIdx.x], end = start[blockIdx.x + 1];
-  if (beg == end) return;
+  const int block = int(blockIdx.x);
+  const int beg = block * bins.cap, end = beg + bins.snap[block];
+  const int n_over = bins.snap[bins.nb];
+  if (beg == end && n_over == 0) return;
+  const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
   const bool lane_active = l < N;
@@ -812,11 +796,20 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
   // stage phi and chi of every channel once: tile[(2c + {0: phi, 1: chi}) * TV + k]
   for (int c = 0; c < C; ++c) load_tiles<N, 2, T>(g, ox, oy, oz, phi + c * M, chi + c * M, tile + 2 * c * TV);
   __syncthreads();
-  for (int base = beg; base < end; base += GROUPS) {
-    const int idx = base + grp;
-    const bool valid = idx < end;
-    const int id = valid ? idx : beg;
-    const int4 a = rec[id];
+  for (int it = 0; it < main_iters + over_iters; ++it) {
+    bool valid;
+    int id;
+    if (it < main_iters) {
+      const int idx = beg + it * GROUPS + grp;
+      valid = idx < end;
+      id = valid ? idx : beg;
+    } else {  // overflow region: the atoms whose home brick this is
+      const int k = (it - main_iters) * GROUPS + grp;
+      valid = k < n_over && bins.over_brick[k < n_over ? k : 0] == block;
+      id = int(bins.over_base) + (k < n_over ? k : 0);
+    }
+    int4 a = rec[id];
+    if (!valid) a = make_int4(ox, oy, oz, 0);
     const T* wr = wts + int64_t(id) * (6 * N);
     T wx[N], wy[N], dwx[N], dwy[N];
 #pragma unroll
@@ -902,7 +895,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
   } while (0)
 
 struct BinsView {
-  int *count, *start, *slot, *brick;
+  BinIndex idx;  // live = NULL: set by the caller for forward passes
+  int* over_brick;
   int4* rec;
   void* wts;
   double* epart;
@@ -910,9 +904,15 @@ struct BinsView {
 
 static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, void* bins) {
   const BinsLayout l = bins_layout(m, N, dtype);
+  const BrickGeom bg = make_brick_geom(m);
   char* b = (char*)bins;
-  return BinsView{(int*)(b + l.count), (int*)(b + l.start), (int*)(b + l.slot), (int*)(b + l.brick), (int4*)(b + l.rec),
-                  (void*)(b + l.wts), (double*)(b + l.epart)};
+  BinsView v;
+  v.over_brick = (int*)(b + l.over_brick);
+  v.idx = BinIndex{nullptr, (int*)(b + l.snap), v.over_brick, bg.nb, l.cap, int64_t(bg.nb) * l.cap};
+  v.rec = (int4*)(b + l.rec);
+  v.wts = (void*)(b + l.wts);
+  v.epart = (double*)(b + l.epart);
+  return v;
 }
 
 // the per-wave energy partial sums of the co-scheduled pair sum inside the bins buffer (n = number of {e, q^2} pairs)
@@ -921,44 +921,24 @@ const void* bins_epart(const mipme_mesh_t* m, int64_t N, int dtype, void* bins, 
   return bins_view(m, N, dtype, bins).epart;
 }
 
-// clean_count (nullable): brick counters that are zero on entry (plan-owned; spread_bricks clears them again); otherwise the
-// counters inside `bins` are zeroed here.  q + atom_rec (nullable, single channel): also emit the (position, charge) records.
+// live: the int[nb + 1] counters of the binning pass, ZERO on entry (plan / frame owned); the forward gather zeroes them
+// again.  q + atom_rec (nullable, single channel): also emit the (position, charge) records.  One launch.
 template <typename T>
-int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins, int* clean_count,
+int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins, int* live,
                const void* q, void* atom_rec) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   BinsView v = bins_view(m, n_atoms, dtype, bins);
-  const bool even = (m->order % 2) == 0;
-  if (clean_count)
-    v.count = clean_count;
-  else
-    MIPME_CHECK_HIP(zero_async(v.count, sizeof(int) * size_t(bg.nb + 1), st));
+  MIPME_REQUIRE(live, "the binning pass needs the live brick counters");
+  MIPME_REQUIRE(bins_layout(m, n_atoms, dtype).slots < (int64_t(1) << 31), "too many bin slots for 32-bit slot indices");
+  v.idx.live = live;
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
   if (n_atoms > 0) {
-    bin_count_kernel<T><<<blocks, 256, 0, st>>>(g, bg, even, n_atoms, (const T*)pos, v.count, v.slot, v.brick);
-    MIPME_LAUNCH_CHECK();
-  }
-  const bool fused = bg.nb <= kFusedScanMax;
-  if (!fused) {
-    bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
-    MIPME_LAUNCH_CHECK();
-  }
-  if (n_atoms > 0) {
-    if (fused)
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               (bin_fill_kernel<S, N, true, T><<<blocks, 256, 0, st>>>(
-                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts,
-                                   (const T*)q, (AtomRecord<T>*)atom_rec)));
-    else
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               (bin_fill_kernel<S, N, false, T><<<blocks, 256, 0, st>>>(
-                                   g, bg.nb, n_atoms, (const T*)pos, v.count, v.start, v.slot, v.brick, v.rec, (T*)v.wts,
-                                   (const T*)q, (AtomRecord<T>*)atom_rec)));
-    MIPME_LAUNCH_CHECK();
-  } else if (fused) {
-    bin_scan_kernel<<<1, 1024, 0, st>>>(bg.nb, v.count, v.start);
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             (bin_atoms_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
+                                                                               v.rec, (T*)v.wts, (const T*)q,
+                                                                               (AtomRecord<T>*)atom_rec)));
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;
@@ -976,13 +956,14 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.g = make_geom(m);
   sa.bg = bg;
   sa.C = m->n_channels;
-  sa.start = v.start;
+  sa.bins = v.idx;
+  sa.bins.live = clear_count;  // forward pass: the live counters (counts are read from them and snapshot); else NULL
+  sa.from_live = clear_count != nullptr;
   sa.rec = v.rec;
   sa.wts = (const T*)v.wts;
   sa.val = (const T*)val;
   sa.scale = T(scale);
   sa.mesh = (T*)mesh;
-  sa.clear_count = clear_count;
   sa.stage_rows = stage_rows;
   if (job) {
     // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
@@ -1039,12 +1020,13 @@ bool sr_job_fusable(const mipme_sr_job_t* job) {
 template <typename T>
 int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* mesh, const void* q,
                   const void* qsum, double self_c, double bg_c, void* out, void* raw, int accumulate, void* field,
-                  const GatherTailHost* th, void* nan_flag) {
+                  const GatherTailHost* th, void* nan_flag, int* live) {
   if (N == 0) return MIPME_OK;
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
-  const BinsView v = bins_view(m, N, dtype, bins);
+  BinsView v = bins_view(m, N, dtype, bins);
+  v.idx.live = live;  // forward pass: this gather is the last consumer of the live counters and zeroes them
   MIPME_REQUIRE(!field || m->n_channels == 1, "the field output of the gather is single-channel");
   if (th) {
     MIPME_REQUIRE(field && accumulate && q && qsum && th->force && th->grad_pos && th->energy && th->epart_k,
@@ -1065,7 +1047,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     }
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
-                                 g, bg, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
+                                 g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
                                  T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
@@ -1073,13 +1055,13 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   if (field)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_brick_kernel<N, true, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
-                                 g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
+                                 g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
                                  (T*)raw, (T*)field, (int*)nan_flag)));
   else
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, gather_brick_kernel<N, false, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
-                                 g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
+                                 g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
                                  (T*)raw, nullptr, (int*)nan_flag)));
   MIPME_LAUNCH_CHECK();
@@ -1100,7 +1082,7 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
   MIPME_DISPATCH_STENCIL_B(
       m->scheme, m->order,
       ((void)S, gather_grad_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
-          g, bg, m->n_channels, v.start, v.rec, (const T*)v.wts, (const T*)q, (const T*)gout, (const T*)phi,
+          g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)q, (const T*)gout, (const T*)phi,
           (const T*)chi, (const T*)psi_dc, (const T*)gscale, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos,
           (T*)grad_q)));
   MIPME_LAUNCH_CHECK();
@@ -1118,7 +1100,8 @@ struct FrameDev {
   int64_t N;
   const T* pos;
   const T* q;
-  int *count, *start, *slot, *brick;
+  BinIndex bins;  // live = the frame's brick counters
+  int* over_brick;
   int4* rec;
   T* wts;
   AtomRecord<T>* atom_rec;
@@ -1143,19 +1126,11 @@ struct FrameDev {
   bool use_tail;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void frames_bin_count_kernel(const FrameDev<T>* __restrict__ table) {
-  const FrameDev<T>& f = table[blockIdx.y];
-  if (int64_t(blockIdx.x) * 256 >= f.N) return;
-  bin_count_body<T>(f.g, f.bg, f.even != 0, f.N, f.pos, f.count, f.slot, f.brick, blockIdx.x);
-}
-
 template <int SCHEME, int N, typename T>
-__global__ __launch_bounds__(256) void frames_bin_fill_kernel(const FrameDev<T>* __restrict__ table) {
+__global__ __launch_bounds__(256) void frames_bin_atoms_kernel(const FrameDev<T>* __restrict__ table) {
   const FrameDev<T>& f = table[blockIdx.y];
   if (int64_t(blockIdx.x) * 256 >= f.N) return;
-  bin_fill_body<SCHEME, N, true, T>(f.g, f.bg.nb, f.N, f.pos, f.count, f.start, f.slot, f.brick, f.rec, f.wts, f.q,
-                                    f.atom_rec, blockIdx.x);
+  bin_atoms_body<SCHEME, N, T>(f.g, f.bg, f.bins, f.N, f.pos, f.over_brick, f.rec, f.wts, f.q, f.atom_rec, blockIdx.x);
 }
 
 template <int N, typename T, int PFAST, bool COMPACT>
@@ -1171,7 +1146,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(cons
 template <int N, typename T>
 __global__ __launch_bounds__(GATHER_THREADS) void frames_gather_kernel(const FrameDev<T>* __restrict__ table) {
   const FrameDev<T>& f = table[blockIdx.y];
-  gather_brick_body<N, true, T>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c, true,
+  gather_brick_body<N, true, T>(f.g, f.bg, 1, f.bins, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c, true,
                                 f.out, nullptr, f.field, blockIdx.x);
 }
 
@@ -1183,7 +1158,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void frames_gather_tail_kernel(cons
   GatherTail<T> tail = f.tail;
   tail.epart_k = epart_k + int64_t(blockIdx.y) * n_k;  // the x stage writes one block of partial sums per batch entry
   tail.n_k = n_k;
-  gather_brick_body<N, true, T, true>(f.g, f.bg, 1, f.start, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c,
+  gather_brick_body<N, true, T, true>(f.g, f.bg, 1, f.bins, f.rec, f.wts, f.phi_mesh, f.q, f.dc, f.inv_vol, f.self_c, f.bg_c,
                                       true, f.out, nullptr, f.field, blockIdx.x, &tail);
 }
 
@@ -1237,7 +1212,7 @@ static int frames_check(int dtype, int n_frames, const mipme_frame_t* fr) {
     MIPME_REQUIRE(f.mesh.nx == m0.nx && f.mesh.ny == m0.ny && f.mesh.nz == m0.nz && f.mesh.scheme == m0.scheme &&
                       f.mesh.order == m0.order && f.mesh.n_channels == 1,
                   "frame %d: all frames need the same mesh, scheme and order and a single channel", k);
-    MIPME_REQUIRE(bricks_supported(&f.mesh, dtype) && make_brick_geom(&f.mesh).nb <= kFusedScanMax,
+    MIPME_REQUIRE(bricks_supported(&f.mesh, dtype) && make_brick_geom(&f.mesh).nb <= 1024,
                   "frame %d: mesh %d x %d x %d is outside the brick kernels' range", k, f.mesh.nx, f.mesh.ny, f.mesh.nz);
     MIPME_REQUIRE(f.n_atoms > 0 && f.positions && f.charges && f.cell && f.atom_bins && f.brick_counters && f.row_ptr &&
                       f.entries_shift && f.entries && f.records && f.rho_mesh && f.phi_mesh && f.dc && f.out && f.force &&
@@ -1271,10 +1246,9 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.N = f.n_atoms;
     d.pos = (const T*)f.positions;
     d.q = (const T*)f.charges;
-    d.count = (int*)f.brick_counters;
-    d.start = v.start;
-    d.slot = v.slot;
-    d.brick = v.brick;
+    d.bins = v.idx;
+    d.bins.live = (int*)f.brick_counters;
+    d.over_brick = v.over_brick;
     d.rec = v.rec;
     d.wts = (T*)v.wts;
     d.atom_rec = (AtomRecord<T>*)f.records;
@@ -1282,13 +1256,13 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.spread.g = d.g;
     d.spread.bg = d.bg;
     d.spread.C = 1;
-    d.spread.start = v.start;
+    d.spread.bins = d.bins;
+    d.spread.from_live = true;
     d.spread.rec = v.rec;
     d.spread.wts = (const T*)v.wts;
     d.spread.val = (const T*)f.charges;
     d.spread.scale = T(1);
     d.spread.mesh = (T*)f.rho_mesh;
-    d.spread.clear_count = (int*)f.brick_counters;
     d.spread.stage_rows = spread_stage_rows(m->order, sizeof(T));
     d.rows = make_fused_rows_args<T>(s, cf, f.n_atoms, f.row_ptr, f.entries_shift, f.entries, nullptr, f.positions, f.records,
                                      f.cell, f.charges, nullptr, 0, f.full_list ? 0 : 1, f.full_list, 0, f.out, f.force, nullptr,
@@ -1340,9 +1314,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   for (int k = 0; k < n_frames; ++k) max_atoms = std::max<int64_t>(max_atoms, fr[k].n_atoms);
   const unsigned atom_blocks = unsigned((max_atoms + 255) / 256);
   const unsigned F = unsigned(n_frames);
-  frames_bin_count_kernel<T><<<dim3(atom_blocks, F), 256, 0, st>>>(tb);
-  MIPME_LAUNCH_CHECK();
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (frames_bin_fill_kernel<S, N, T><<<dim3(atom_blocks, F), 256, 0, st>>>(tb)));
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (frames_bin_atoms_kernel<S, N, T><<<dim3(atom_blocks, F), 256, 0, st>>>(tb)));
   MIPME_LAUNCH_CHECK();
   const int stage_rows = spread_stage_rows(m->order, sizeof(T));
   const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
@@ -1392,9 +1364,9 @@ template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, voi
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                    const mipme_sr_job_t*, bool);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                  double, double, void*, void*, int, void*, const GatherTailHost*, void*);
+                                  double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
-                                   double, double, void*, void*, int, void*, const GatherTailHost*, void*);
+                                   double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
 template int gather_grad_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
                                        const void*, const void*, const void*, const void*, double, double, void*, void*);
 template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*,
