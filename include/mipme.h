@@ -468,14 +468,20 @@ int mipme_sr_rows_finalize(void* stream, int dtype, int64_t n_atoms, const void*
  *   (the charge gradient is mipme_ewald_potential with T in place of S) */
 int mipme_ewald_filter(void* stream, int dtype, const mipme_potential_t* pot, int64_t n_k, const void* kvectors, void* G,
                        void* dG);
+/* n_batch >= 1: padded batches (reference tests/calculators/test_padding.py: torch.vmap over zero-padded structures with
+ * node_mask / pair_mask / batched k-vectors) in ONE launch per kernel, blockIdx.y = structure: every array gains a leading
+ * batch dimension -- positions (B,N,3), weights / charges / grad_out / out (B,N,C), kvectors (B,K,3), G / dG (B,K), structure
+ * factors (B,K,C) -- with n_atoms = N and n_k = K the padded sizes.  Padding atoms carry zero weight, padding k-vectors are
+ * zero (G(0) = 0), so they drop out of every sum; mipme_ewald_filter takes the flat (B K, 3) k-vectors as it is. */
 int mipme_ewald_structure(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
-                          const void* weights, const void* kvectors, void* out_cos, void* out_sin);
+                          const void* weights, const void* kvectors, void* out_cos, void* out_sin, int64_t n_batch);
 int mipme_ewald_potential(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
-                          const void* kvectors, const void* G, const void* s_cos, const void* s_sin, void* out);
+                          const void* kvectors, const void* G, const void* s_cos, const void* s_sin, void* out,
+                          int64_t n_batch);
 int mipme_ewald_backward(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
                          const void* charges, const void* grad_out, const void* kvectors, const void* G, const void* dG,
                          const void* s_cos, const void* s_sin, const void* t_cos, const void* t_sin,
-                         void* grad_positions, void* grad_kvectors);
+                         void* grad_positions, void* grad_kvectors, int64_t n_batch);
 
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
  * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------

@@ -75,9 +75,9 @@ def test_abi_argument_errors_without_gpu():
     assert lib.mipme_topology_pack_entries(None, _lib.F32, 4, 2, None, None, None, 0, None, None) == -1
     assert lib.mipme_pair_distance_forward_packed(None, _lib.F32, 4, None, None, None, None, None) == -1
     assert b"mipme_pair_distance_forward_packed" in lib.mipme_last_error()
-    assert lib.mipme_ewald_structure(None, _lib.F32, 4, 0, 8, None, None, None, None, None) == -1
+    assert lib.mipme_ewald_structure(None, _lib.F32, 4, 0, 8, None, None, None, None, None, 1) == -1
     assert b"invalid sizes" in lib.mipme_last_error()
-    assert lib.mipme_ewald_backward(None, 99, 0, 1, 0, *([None] * 12)) == -1
+    assert lib.mipme_ewald_backward(None, 99, 0, 1, 0, *([None] * 12), 1) == -1
     assert b"invalid dtype 99" in lib.mipme_last_error()
     bad = _lib.PotentialDesc(kind=_lib.INVERSE_POWER_LAW, exponent=9, smearing=1.0, prefactor=1.0, exclusion_radius=-1,
                              exclusion_degree=1)

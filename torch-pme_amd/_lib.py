@@ -221,9 +221,9 @@ def _declare(lib):
         "mipme_frames_forward": [vp, vp, ci, ci, C.POINTER(Frame), PP, vp, vp, i64, vp, vp, vp, vp],
         "mipme_frames_backward": [vp, ci, ci, C.POINTER(Frame), vp, vp],
         "mipme_ewald_filter": [vp, ci, PP, i64, vp, vp, vp],
-        "mipme_ewald_structure": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp],
-        "mipme_ewald_potential": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp, vp],
-        "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12,
+        "mipme_ewald_structure": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp, i64],
+        "mipme_ewald_potential": [vp, ci, i64, ci, i64, vp, vp, vp, vp, vp, vp, i64],
+        "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12 + [i64],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_scaled_match": [vp, ci, i64, vp, vp, vp],

@@ -265,7 +265,7 @@ class EwaldCalculator(Calculator):
     frequencies times the reciprocal cell), the 1/V factor and the self / background / slab terms are a handful of small
     tensor ops here, so that the cell gradient is autograd's.  ``kvectors`` may be supplied by the caller; ``node_mask``
     masks atoms of the result.  Padded batches go through ``torch.vmap(calculator.forward)`` as in the reference
-    (``tests/calculators/test_padding.py``): the structures are evaluated one after the other.
+    (``tests/calculators/test_padding.py``): one launch per kernel for the whole batch (``_forward_batched``).
 
     :param potential: potential with a positive ``smearing``
     :param lr_wavelength: spatial resolution of the reciprocal-space part
@@ -298,6 +298,63 @@ class EwaldCalculator(Calculator):
         freq = torch.tensor(F, dtype=cell.dtype, device=cell.device)
         self._freq_cache = (weakref.ref(cell), cell._version, cell.device, self.lr_wavelength, freq)
         return freq
+
+    def _forward_batched(self, batch_size, in_dims, charges, cell, positions, neighbor_indices, neighbor_distances,
+                         periodic=None, node_mask=None, pair_mask=None, kvectors=None):
+        """``torch.vmap(self.forward)`` over a zero-padded batch (reference ``tests/calculators/test_padding.py:73-98``) as ONE
+        evaluation: the pair sum over the flattened pair list of all structures (atom indices offset by ``b N``; one pass of
+        the atomic pair kernel -- the list is new every call, a transposed list would not pay), the reciprocal-space sums with
+        ``blockIdx.y`` = structure (``ops._EwaldKSpace`` on (B,N,..) / (B,K,3) tensors), the self / background / slab terms as
+        broadcast tensor expressions.  Returns ``None`` (the caller then loops over the samples) unless every per-structure
+        tensor is batched along dimension 0 and the k-vectors are given, which is the reference's calling convention."""
+        d = dict(zip(("charges", "cell", "positions", "neighbor_indices", "neighbor_distances", "periodic", "node_mask",
+                      "pair_mask", "kvectors"), in_dims))
+        must = ("charges", "cell", "positions", "neighbor_indices", "neighbor_distances", "kvectors")
+        if kvectors is None or any(d[k] != 0 for k in must):
+            return None
+        if (node_mask is not None and d["node_mask"] != 0) or (pair_mask is not None and d["pair_mask"] != 0):
+            return None
+        B = batch_size
+        per0 = None if periodic is None else (periodic[0] if d["periodic"] == 0 else periodic)
+        _validate_parameters(
+            charges=charges[0], cell=cell[0], positions=positions[0], neighbor_indices=neighbor_indices[0],
+            neighbor_distances=neighbor_distances[0], periodic=per0, pair_mask=None if pair_mask is None else pair_mask[0],
+            node_mask=None if node_mask is None else node_mask[0], kvectors=kvectors[0],
+        )
+        _lib.require_device(positions, "positions")
+        N, Cn = charges.shape[1:]
+        P = neighbor_indices.shape[1]
+        pot_desc = self.potential._descriptor()
+        # ---- real space: all structures as one list
+        offsets = (torch.arange(B, device=positions.device, dtype=neighbor_indices.dtype) * N).view(B, 1, 1)
+        sr = ops.pme_potential(
+            charges.reshape(B * N, Cn), cell[0], positions.reshape(B * N, 3), (neighbor_indices + offsets).reshape(B * P, 2),
+            neighbor_distances.reshape(B * P), None if pair_mask is None else pair_mask.reshape(B * P), None, None, pot_desc,
+            bool(self.full_neighbor_list), None, None, atomic_pairs=True,
+        ).reshape(B, N, Cn)
+        # ---- reciprocal space
+        volume = torch.abs(torch.det(cell)).view(B, 1, 1)
+        lr = ops.ewald_kspace(charges, positions, kvectors, pot_desc) / volume
+        p = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+        two_s2 = 2.0 * pot_desc.smearing**2
+        lr = lr - charges * (pot_desc.prefactor / math.gamma(0.5 * p + 1.0) / two_s2 ** (0.5 * p))
+        if p < 3:
+            bg = pot_desc.prefactor * math.pi**1.5 * two_s2 ** (0.5 * (3 - p)) / ((3 - p) * math.gamma(0.5 * p))
+            lr = lr - (2.0 * bg) * charges.sum(dim=1, keepdim=True) / volume
+        if periodic is not None and p == 1:
+            flags = periodic.tolist() if d["periodic"] == 0 else [periodic.tolist()] * B
+            axes = [ops._slab_axis(f) for f in flags]
+            if any(a is not None for a in axes):  # 2-D periodic slabs among the structures, potentials/coulomb.py:6-40
+                ax = torch.tensor([0 if a is None else a for a in axes], device=positions.device)
+                on = torch.tensor([a is not None for a in axes], device=positions.device, dtype=positions.dtype).view(B, 1, 1)
+                z = positions.gather(2, ax.view(B, 1, 1).expand(B, N, 1))
+                Lz = torch.linalg.norm(cell.gather(1, ax.view(B, 1, 1).expand(B, 1, 3)), dim=2, keepdim=True)
+                Q, M = charges.sum(dim=1, keepdim=True), (charges * z).sum(dim=1, keepdim=True)
+                M2 = (charges * z * z).sum(dim=1, keepdim=True)
+                lr = lr + on * pot_desc.prefactor * (4 * math.pi / volume) * (z * M - 0.5 * (M2 + Q * z * z) - Q / 12.0 * Lz * Lz)
+        if node_mask is not None:
+            lr = lr * node_mask.unsqueeze(-1)
+        return sr + lr / 2
 
     def _forward_impl(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
                       pair_mask=None, kvectors=None):

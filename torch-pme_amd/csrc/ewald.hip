@@ -39,6 +39,14 @@ __global__ __launch_bounds__(256) void ewald_structure_kernel(int64_t N, int C, 
                                                              T* __restrict__ out_c, T* __restrict__ out_s) {
   __shared__ T sp[kEwaldTile * 3];
   __shared__ T sw[kEwaldTile * kEwaldCMax];
+  {  // blockIdx.y = structure of a padded batch: (B,N,3) positions, (B,N,C) weights, (B,K,3) k-vectors, (B,K,C) outputs
+    const int64_t b = blockIdx.y;
+    pos += b * N * 3;
+    w += b * N * C;
+    kvec += b * K * 3;
+    out_c += b * K * C;
+    out_s += b * K * C;
+  }
   const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool valid = k < K;
   const T kx = valid ? kvec[3 * k] : T(0), ky = valid ? kvec[3 * k + 1] : T(0), kz = valid ? kvec[3 * k + 2] : T(0);
@@ -92,6 +100,15 @@ __global__ __launch_bounds__(256) void ewald_potential_kernel(int C, int64_t K, 
                                                              const T* __restrict__ Sc, const T* __restrict__ Ss,
                                                              T* __restrict__ out) {
   __shared__ T red[4];
+  {  // blockIdx.y = structure of a padded batch (gridDim.x = atoms per structure)
+    const int64_t b = blockIdx.y, Nb = gridDim.x;
+    pos += b * Nb * 3;
+    kvec += b * K * 3;
+    G += b * K;
+    Sc += b * K * C;
+    Ss += b * K * C;
+    out += b * Nb * C;
+  }
   const int64_t i = blockIdx.x;
   const T x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
   for (int c0 = 0; c0 < C; c0 += kEwaldCMax) {
@@ -130,6 +147,19 @@ __global__ __launch_bounds__(256) void ewald_grad_positions_kernel(int C, int64_
                                                                   const T* __restrict__ Tc, const T* __restrict__ Ts,
                                                                   T* __restrict__ grad_pos) {
   __shared__ T red[4];
+  {  // blockIdx.y = structure of a padded batch (gridDim.x = atoms per structure)
+    const int64_t b = blockIdx.y, Nb = gridDim.x;
+    pos += b * Nb * 3;
+    q += b * Nb * C;
+    g += b * Nb * C;
+    kvec += b * K * 3;
+    G += b * K;
+    Sc += b * K * C;
+    Ss += b * K * C;
+    Tc += b * K * C;
+    Ts += b * K * C;
+    grad_pos += b * Nb * 3;
+  }
   const int64_t i = blockIdx.x;
   const T x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
   T ax = T(0), ay = T(0), az = T(0);
@@ -164,6 +194,20 @@ __global__ __launch_bounds__(256) void ewald_grad_kvectors_kernel(int64_t N, int
   __shared__ T sp[kEwaldTile * 3];
   __shared__ T sq[kEwaldTile * kEwaldCMax];
   __shared__ T sg[kEwaldTile * kEwaldCMax];
+  {  // blockIdx.y = structure of a padded batch
+    const int64_t b = blockIdx.y;
+    pos += b * N * 3;
+    q += b * N * C;
+    g += b * N * C;
+    kvec += b * K * 3;
+    G += b * K;
+    dG += b * K;
+    Sc += b * K * C;
+    Ss += b * K * C;
+    Tc += b * K * C;
+    Ts += b * K * C;
+    grad_k += b * K * 3;
+  }
   const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool valid = k < K;
   const int64_t kc = valid ? k : 0;
@@ -223,9 +267,9 @@ static int ewald_filter_t(hipStream_t st, const mipme_potential_t* pot, int64_t 
 
 template <typename T>
 static int ewald_structure_t(hipStream_t st, int64_t N, int C, int64_t K, const void* pos, const void* w,
-                             const void* kvec, void* out_c, void* out_s) {
+                             const void* kvec, void* out_c, void* out_s, int64_t B) {
   if (K == 0) return MIPME_OK;
-  ewald_structure_kernel<T><<<unsigned((K + 255) / 256), 256, 0, st>>>(N, C, K, (const T*)pos, (const T*)w,
+  ewald_structure_kernel<T><<<dim3(unsigned((K + 255) / 256), unsigned(B)), 256, 0, st>>>(N, C, K, (const T*)pos, (const T*)w,
                                                                       (const T*)kvec, (T*)out_c, (T*)out_s);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
@@ -233,9 +277,9 @@ static int ewald_structure_t(hipStream_t st, int64_t N, int C, int64_t K, const 
 
 template <typename T>
 static int ewald_potential_t(hipStream_t st, int64_t N, int C, int64_t K, const void* pos, const void* kvec,
-                             const void* G, const void* Sc, const void* Ss, void* out) {
+                             const void* G, const void* Sc, const void* Ss, void* out, int64_t B) {
   if (N == 0) return MIPME_OK;
-  ewald_potential_kernel<T><<<unsigned(N), 256, 0, st>>>(C, K, (const T*)pos, (const T*)kvec, (const T*)G, (const T*)Sc,
+  ewald_potential_kernel<T><<<dim3(unsigned(N), unsigned(B)), 256, 0, st>>>(C, K, (const T*)pos, (const T*)kvec, (const T*)G, (const T*)Sc,
                                                         (const T*)Ss, (T*)out);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
@@ -244,15 +288,15 @@ static int ewald_potential_t(hipStream_t st, int64_t N, int C, int64_t K, const 
 template <typename T>
 static int ewald_backward_t(hipStream_t st, int64_t N, int C, int64_t K, const void* pos, const void* q, const void* g,
                             const void* kvec, const void* G, const void* dG, const void* Sc, const void* Ss,
-                            const void* Tc, const void* Ts, void* grad_pos, void* grad_k) {
+                            const void* Tc, const void* Ts, void* grad_pos, void* grad_k, int64_t B) {
   if (grad_pos && N > 0) {
-    ewald_grad_positions_kernel<T><<<unsigned(N), 256, 0, st>>>(C, K, (const T*)pos, (const T*)q, (const T*)g,
+    ewald_grad_positions_kernel<T><<<dim3(unsigned(N), unsigned(B)), 256, 0, st>>>(C, K, (const T*)pos, (const T*)q, (const T*)g,
                                                                (const T*)kvec, (const T*)G, (const T*)Sc, (const T*)Ss,
                                                                (const T*)Tc, (const T*)Ts, (T*)grad_pos);
     MIPME_LAUNCH_CHECK();
   }
   if (grad_k && K > 0) {
-    ewald_grad_kvectors_kernel<T><<<unsigned((K + 255) / 256), 256, 0, st>>>(
+    ewald_grad_kvectors_kernel<T><<<dim3(unsigned((K + 255) / 256), unsigned(B)), 256, 0, st>>>(
         N, C, K, (const T*)pos, (const T*)q, (const T*)g, (const T*)kvec, (const T*)G, (const T*)dG, (const T*)Sc,
         (const T*)Ss, (const T*)Tc, (const T*)Ts, (T*)grad_k);
     MIPME_LAUNCH_CHECK();
@@ -282,39 +326,43 @@ int mipme_ewald_filter(void* stream, int dtype, const mipme_potential_t* pot, in
 }
 
 int mipme_ewald_structure(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
-                          const void* weights, const void* kvectors, void* out_cos, void* out_sin) {
-  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0, "invalid sizes passed to mipme_ewald_structure");
+                          const void* weights, const void* kvectors, void* out_cos, void* out_sin, int64_t n_batch) {
+  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0 && n_batch >= 1 && n_batch <= 65535,
+                "invalid sizes passed to mipme_ewald_structure");
   MIPME_REQUIRE(n_k == 0 || (kvectors && out_cos && out_sin && (n_atoms == 0 || (positions && weights))),
                 "NULL buffer passed to mipme_ewald_structure");
   hipStream_t st = (hipStream_t)stream;
-  EW_DT(dtype, ewald_structure_t<float>(st, n_atoms, n_channels, n_k, positions, weights, kvectors, out_cos, out_sin),
-        ewald_structure_t<double>(st, n_atoms, n_channels, n_k, positions, weights, kvectors, out_cos, out_sin));
+  EW_DT(dtype, ewald_structure_t<float>(st, n_atoms, n_channels, n_k, positions, weights, kvectors, out_cos, out_sin, n_batch),
+        ewald_structure_t<double>(st, n_atoms, n_channels, n_k, positions, weights, kvectors, out_cos, out_sin, n_batch));
 }
 
 int mipme_ewald_potential(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
-                          const void* kvectors, const void* G, const void* s_cos, const void* s_sin, void* out) {
-  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0, "invalid sizes passed to mipme_ewald_potential");
+                          const void* kvectors, const void* G, const void* s_cos, const void* s_sin, void* out,
+                          int64_t n_batch) {
+  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0 && n_batch >= 1 && n_batch <= 65535,
+                "invalid sizes passed to mipme_ewald_potential");
   MIPME_REQUIRE(n_atoms == 0 || (positions && out && (n_k == 0 || (kvectors && G && s_cos && s_sin))),
                 "NULL buffer passed to mipme_ewald_potential");
   hipStream_t st = (hipStream_t)stream;
-  EW_DT(dtype, ewald_potential_t<float>(st, n_atoms, n_channels, n_k, positions, kvectors, G, s_cos, s_sin, out),
-        ewald_potential_t<double>(st, n_atoms, n_channels, n_k, positions, kvectors, G, s_cos, s_sin, out));
+  EW_DT(dtype, ewald_potential_t<float>(st, n_atoms, n_channels, n_k, positions, kvectors, G, s_cos, s_sin, out, n_batch),
+        ewald_potential_t<double>(st, n_atoms, n_channels, n_k, positions, kvectors, G, s_cos, s_sin, out, n_batch));
 }
 
 int mipme_ewald_backward(void* stream, int dtype, int64_t n_atoms, int n_channels, int64_t n_k, const void* positions,
                          const void* charges, const void* grad_out, const void* kvectors, const void* G, const void* dG,
                          const void* s_cos, const void* s_sin, const void* t_cos, const void* t_sin,
-                         void* grad_positions, void* grad_kvectors) {
-  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0, "invalid sizes passed to mipme_ewald_backward");
+                         void* grad_positions, void* grad_kvectors, int64_t n_batch) {
+  MIPME_REQUIRE(n_atoms >= 0 && n_k >= 0 && n_channels > 0 && n_batch >= 1 && n_batch <= 65535,
+                "invalid sizes passed to mipme_ewald_backward");
   MIPME_REQUIRE(n_atoms == 0 || n_k == 0 || (positions && charges && grad_out && kvectors && G && s_cos && s_sin && t_cos && t_sin),
                 "NULL buffer passed to mipme_ewald_backward");
   MIPME_REQUIRE(!grad_kvectors || dG || n_k == 0, "grad_kvectors needs dG");
   hipStream_t st = (hipStream_t)stream;
   EW_DT(dtype,
         ewald_backward_t<float>(st, n_atoms, n_channels, n_k, positions, charges, grad_out, kvectors, G, dG, s_cos, s_sin,
-                                t_cos, t_sin, grad_positions, grad_kvectors),
+                                t_cos, t_sin, grad_positions, grad_kvectors, n_batch),
         ewald_backward_t<double>(st, n_atoms, n_channels, n_k, positions, charges, grad_out, kvectors, G, dG, s_cos, s_sin,
-                                 t_cos, t_sin, grad_positions, grad_kvectors));
+                                 t_cos, t_sin, grad_positions, grad_kvectors, n_batch));
 }
 
 }  // extern "C"

@@ -12,18 +12,29 @@ it.  Two dispatcher ops make the same path visible to both:
 Both have a fake (meta) implementation and an autograd formula, so ``torch.compile(model, fullgraph=True)`` keeps a model
 that contains a calculator in one graph, ``torch.jit.script(calculator.scriptable())`` gives the TorchScript module the
 reference's ``torch.jit.script(calculator)`` gives (``tests/calculators/test_workflow.py:136-162``) and
-``torch.library.opcheck`` passes.  The backward ops re-run the eager forward under autograd and differentiate it (the
-kernels of the eager backward), i.e. a compiled / scripted evaluation pays one extra forward; the eager calculators are
-the fast path (fused distances, graph replay) and are not routed through these ops.
+``torch.library.opcheck`` passes.  The forward op evaluates the calculator under its own autograd tape whenever gradient
+mode is on and keeps that tape, keyed by the storage of the output it returned (:data:`_TAPES`, a few entries); the backward
+op -- which receives the forward's output back -- differentiates the kept tape, i.e. runs the kernels of the eager backward
+and nothing else.  Only when the tape is gone (evicted by later forward calls, ``KEEP_TAPE = False`` or
+``torch.inference_mode``) does it re-run the forward first.  The eager calculators are the fast path (fused distances, graph replay) and are not routed
+through these ops.
 """
 
 import json
+from collections import OrderedDict
 from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
 
 _CALCULATORS = {}
+
+#: storage address of a forward output -> (output with its autograd graph, the four differentiable leaves); consumed by the
+#: backward op of the same call, bounded (a forward whose backward never comes is dropped after `_MAX_TAPES` later calls)
+_TAPES: "OrderedDict" = OrderedDict()
+_MAX_TAPES = 4
+#: keep the forward's autograd tape for the backward op (False: the backward op re-runs the forward, inference pays nothing)
+KEEP_TAPE = True
 
 
 def calculator_spec(calc) -> str:
@@ -104,8 +115,22 @@ def potentials(charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indice
                pair_mask: Optional[Tensor], periodic: Optional[Tensor], node_mask: Optional[Tensor],
                kvectors: Optional[Tensor], spec: str) -> Tensor:
     calc = calculator_from_spec(spec, positions.dtype, positions.device)
-    return calc._forward_impl(charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask, pair_mask,
-                              kvectors)
+    # Below the autograd key the implementation cannot tell whether a backward op will follow (gradient mode reads "off" here
+    # both under the user's no_grad and inside the dispatcher's own autograd node): the tape is kept unless the caller opted
+    # out (KEEP_TAPE = False, or torch.inference_mode()).  Its cost when no backward comes: the speculative per-atom sums of
+    # the forward kernels and at most _MAX_TAPES sets of saved buffers.
+    if not KEEP_TAPE or torch.is_inference_mode_enabled():
+        return calc._forward_impl(charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask,
+                                  pair_mask, kvectors)
+    with _autograd_recording():
+        leaves = [t.detach().requires_grad_(True) for t in (charges, cell, positions, neighbor_distances)]
+        V = calc._forward_impl(leaves[0], leaves[1], leaves[2], neighbor_indices, leaves[3], periodic, node_mask, pair_mask,
+                               kvectors)
+    out = V.detach()
+    _TAPES[out.data_ptr()] = (V, leaves)
+    while len(_TAPES) > _MAX_TAPES:
+        _TAPES.popitem(last=False)
+    return out
 
 
 @potentials.register_fake
@@ -114,16 +139,22 @@ def _(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask,
 
 
 @torch.library.custom_op("mipme::potentials_backward", mutates_args=(), device_types="cuda")
-def potentials_backward(grad: Tensor, charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indices: Tensor,
+def potentials_backward(grad: Tensor, out: Tensor, charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indices: Tensor,
                         neighbor_distances: Tensor, pair_mask: Optional[Tensor], periodic: Optional[Tensor],
                         node_mask: Optional[Tensor], kvectors: Optional[Tensor], spec: str, need_charges: bool,
                         need_cell: bool, need_positions: bool, need_distances: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     calc = calculator_from_spec(spec, positions.dtype, positions.device)
     needs = (need_charges, need_cell, need_positions, need_distances)
+    tape = _TAPES.pop(out.data_ptr(), None)
+    if tape is not None and (tape[0].shape != out.shape or tape[0].dtype != out.dtype):
+        tape = None  # the address was reused by an unrelated tensor
     with _autograd_recording():
-        leaves = [t.detach().requires_grad_(n) for t, n in zip((charges, cell, positions, neighbor_distances), needs)]
-        V = calc._forward_impl(leaves[0], leaves[1], leaves[2], neighbor_indices, leaves[3], periodic, node_mask, pair_mask,
-                               kvectors)
+        if tape is not None:  # the forward's own tape: only the backward kernels run
+            V, leaves = tape
+        else:
+            leaves = [t.detach().requires_grad_(n) for t, n in zip((charges, cell, positions, neighbor_distances), needs)]
+            V = calc._forward_impl(leaves[0], leaves[1], leaves[2], neighbor_indices, leaves[3], periodic, node_mask,
+                                   pair_mask, kvectors)
         wanted = [t for t, n in zip(leaves, needs) if n]
         got = list(torch.autograd.grad(V, wanted, grad.contiguous(), allow_unused=True)) if wanted else []
     out = []
@@ -134,23 +165,24 @@ def potentials_backward(grad: Tensor, charges: Tensor, cell: Tensor, positions: 
 
 
 @potentials_backward.register_fake
-def _(grad, charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, periodic, node_mask, kvectors, spec,
+def _(grad, out, charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, periodic, node_mask, kvectors, spec,
       need_charges, need_cell, need_positions, need_distances):
     return (torch.empty_like(charges), torch.empty_like(cell), torch.empty_like(positions),
             torch.empty_like(neighbor_distances))
 
 
 def _potentials_setup(ctx, inputs, output):
-    ctx.save_for_backward(*[t for t in inputs[:9] if isinstance(t, Tensor)])
+    ctx.save_for_backward(output, *[t for t in inputs[:9] if isinstance(t, Tensor)])
     ctx.present = [isinstance(t, Tensor) for t in inputs[:9]]
     ctx.spec = inputs[9]
 
 
 def _potentials_backward(ctx, grad):
     saved = list(ctx.saved_tensors)
+    out = saved.pop(0)
     args = [saved.pop(0) if p else None for p in ctx.present]
     n = ctx.needs_input_grad
-    gq, gc, gp, gd = torch.ops.mipme.potentials_backward(grad, *args, ctx.spec, n[0], n[1], n[2], n[4])
+    gq, gc, gp, gd = torch.ops.mipme.potentials_backward(grad, out, *args, ctx.spec, n[0], n[1], n[2], n[4])
     return (gq if n[0] else None, gc if n[1] else None, gp if n[2] else None, None, gd if n[4] else None, None, None, None,
             None, None)
 

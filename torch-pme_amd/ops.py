@@ -420,7 +420,8 @@ class _PMEFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G, pot_desc,
-                full_list, slab_axis, src_positions=None, src_cell=None, src=None, lazy=False, nan_flag=None):
+                full_list, slab_axis, src_positions=None, src_cell=None, src=None, lazy=False, nan_flag=None,
+                atomic_pairs=False):
         lib = _lib.load()
         device, dtype = positions.device, positions.dtype
         dt = _lib.dtype_code(dtype)
@@ -437,7 +438,9 @@ class _PMEFunction(torch.autograd.Function):
         field = tail = None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
-            topo = get_topology(pairs, N) if PAIR_MODE == "rows" else None
+            # atomic_pairs: one pass over the list with float atomics -- for lists that are new every call (the flattened pair
+            # list of a padded batch), where building the transposed list would cost more than it saves
+            topo = get_topology(pairs, N) if (PAIR_MODE == "rows" and not atomic_pairs) else None
             fused = None
             if src is not None:
                 ent_sh, shift_fmt = topo.entries_with_shifts(src.shifts, src.shifts_key, table=mask is None)
@@ -848,12 +851,17 @@ class _PMEFunction(torch.autograd.Function):
                 grad_dist = LazyPairGradient(P, dtype, device, grad_src_pos, grad_src_cell, make_grad_dist)
                 grad_src_pos = grad_src_cell = None
         return (grad_q, grad_cell, grad_pos, grad_dist, None, None, None, None, None, None, None, grad_src_pos,
-                grad_src_cell, None, None, None)
+                grad_src_cell, None, None, None, None)
 
 
 def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
-                  full_list, slab_axis, nan_flag=None):
+                  full_list, slab_axis, nan_flag=None, atomic_pairs=False):
     src = getattr(neighbor_distances, "_mipme_src", None)
+    if atomic_pairs:
+        if src is not None and src.pending:
+            src.materialize()
+        return _PMEFunction.apply(charges, cell, positions, neighbor_distances, neighbor_indices, pair_mask, geom, G,
+                                  pot_desc, full_list, slab_axis, None, None, None, False, nan_flag, True)
     if src is not None and src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1]):
         # the fused kernels differentiate through the distances in the same pass (see FUSE_DISTANCES)
         if not src.direct:
@@ -1106,7 +1114,10 @@ class _EnergyDirectSum(torch.autograd.Function):
 class _EwaldKSpace(torch.autograd.Function):
     """``core[i,c] = sum_k G(k) [cos(k r_i) S_c(k,c) + sin(k r_i) S_s(k,c)]`` with S the structure factors of the charges:
     the reciprocal-space sum of ``EwaldCalculator`` (reference ``calculators/ewald.py:97-113``) without the 1/V factor.
-    Differentiable w.r.t. charges, positions and the k-vectors (through which the cell gradient flows)."""
+    Differentiable w.r.t. charges, positions and the k-vectors (through which the cell gradient flows).
+
+    Inputs are one structure -- charges (N,C), positions (N,3), kvectors (K,3) -- or a padded batch with a leading batch
+    dimension on all three (B,N,C), (B,N,3), (B,K,3): ONE launch per kernel either way (``blockIdx.y`` = structure)."""
 
     @staticmethod
     def forward(ctx, charges, positions, kvectors, pot_desc):
@@ -1114,21 +1125,24 @@ class _EwaldKSpace(torch.autograd.Function):
         device, dtype = positions.device, positions.dtype
         dt = _lib.dtype_code(dtype)
         q, pos, kv = charges.detach().contiguous(), positions.detach().contiguous(), kvectors.detach().contiguous()
-        N, Cn = q.shape
-        K = kv.shape[0]
-        G = torch.empty((K,), dtype=dtype, device=device)
-        dG = torch.empty((K,), dtype=dtype, device=device)
-        Sc = torch.empty((K, Cn), dtype=dtype, device=device)
-        Ss = torch.empty((K, Cn), dtype=dtype, device=device)
-        out = torch.empty((N, Cn), dtype=dtype, device=device)
+        batched = pos.dim() == 3
+        B = pos.shape[0] if batched else 1
+        N, Cn = q.shape[-2:]
+        K = kv.shape[-2]
+        lead = (B,) if batched else ()
+        G = torch.empty(lead + (K,), dtype=dtype, device=device)
+        dG = torch.empty(lead + (K,), dtype=dtype, device=device)
+        Sc = torch.empty(lead + (K, Cn), dtype=dtype, device=device)
+        Ss = torch.empty(lead + (K, Cn), dtype=dtype, device=device)
+        out = torch.empty(lead + (N, Cn), dtype=dtype, device=device)
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
-            _call("ewald_filter", lib.mipme_ewald_filter, st, dt, C.byref(pot_desc), K, kv.data_ptr(), G.data_ptr(),
+            _call("ewald_filter", lib.mipme_ewald_filter, st, dt, C.byref(pot_desc), B * K, kv.data_ptr(), G.data_ptr(),
                   dG.data_ptr())
             _call("ewald_structure", lib.mipme_ewald_structure, st, dt, N, Cn, K, pos.data_ptr(), q.data_ptr(),
-                  kv.data_ptr(), Sc.data_ptr(), Ss.data_ptr())
+                  kv.data_ptr(), Sc.data_ptr(), Ss.data_ptr(), B)
             _call("ewald_potential", lib.mipme_ewald_potential, st, dt, N, Cn, K, pos.data_ptr(), kv.data_ptr(),
-                  G.data_ptr(), Sc.data_ptr(), Ss.data_ptr(), out.data_ptr())
+                  G.data_ptr(), Sc.data_ptr(), Ss.data_ptr(), out.data_ptr(), B)
         ctx.save_for_backward(q, pos, kv, G, dG, Sc, Ss)
         return out
 
@@ -1140,25 +1154,26 @@ class _EwaldKSpace(torch.autograd.Function):
         need_q, need_pos, need_k = ctx.needs_input_grad[:3]
         device, dtype = pos.device, pos.dtype
         dt = _lib.dtype_code(dtype)
-        N, Cn = q.shape
-        K = kv.shape[0]
+        B = pos.shape[0] if pos.dim() == 3 else 1
+        N, Cn = q.shape[-2:]
+        K = kv.shape[-2]
         g = grad_out.contiguous()
-        Tc = torch.empty((K, Cn), dtype=dtype, device=device)
-        Ts = torch.empty((K, Cn), dtype=dtype, device=device)
-        grad_q = torch.empty((N, Cn), dtype=dtype, device=device) if need_q else None
-        grad_pos = torch.empty((N, 3), dtype=dtype, device=device) if need_pos else None
-        grad_k = torch.empty((K, 3), dtype=dtype, device=device) if need_k else None
+        Tc = torch.empty_like(Sc)
+        Ts = torch.empty_like(Ss)
+        grad_q = torch.empty_like(q) if need_q else None
+        grad_pos = torch.empty_like(pos) if need_pos else None
+        grad_k = torch.empty_like(kv) if need_k else None
         with torch.cuda.device(device):
             st = _lib.current_stream(device)
             _call("ewald_structure", lib.mipme_ewald_structure, st, dt, N, Cn, K, pos.data_ptr(), g.data_ptr(),
-                  kv.data_ptr(), Tc.data_ptr(), Ts.data_ptr())
+                  kv.data_ptr(), Tc.data_ptr(), Ts.data_ptr(), B)
             if need_q:  # the sum is symmetric in (q, g): same kernel with the structure factors of g
                 _call("ewald_potential", lib.mipme_ewald_potential, st, dt, N, Cn, K, pos.data_ptr(), kv.data_ptr(),
-                      G.data_ptr(), Tc.data_ptr(), Ts.data_ptr(), grad_q.data_ptr())
+                      G.data_ptr(), Tc.data_ptr(), Ts.data_ptr(), grad_q.data_ptr(), B)
             if need_pos or need_k:
                 _call("ewald_backward", lib.mipme_ewald_backward, st, dt, N, Cn, K, pos.data_ptr(), q.data_ptr(),
                       g.data_ptr(), kv.data_ptr(), G.data_ptr(), dG.data_ptr(), Sc.data_ptr(), Ss.data_ptr(),
-                      Tc.data_ptr(), Ts.data_ptr(), _lib.ptr(grad_pos), _lib.ptr(grad_k))
+                      Tc.data_ptr(), Ts.data_ptr(), _lib.ptr(grad_pos), _lib.ptr(grad_k), B)
         return grad_q, grad_pos, grad_k, None
 
 
@@ -1192,6 +1207,12 @@ class _SampleLoop(torch.autograd.Function):
 
     @staticmethod
     def vmap(info, in_dims, fn, *args):
+        # a calculator with kernels that take the whole padded batch in one launch (EwaldCalculator) handles it itself
+        batched_impl = getattr(getattr(fn, "__self__", None), "_forward_batched", None)
+        if batched_impl is not None:
+            out = batched_impl(info.batch_size, in_dims[1:], *args)
+            if out is not None:
+                return out, 0
         outs = []
         for b in range(info.batch_size):
             sample = [a if d is None else a.select(d, b) for a, d in zip(args, in_dims[1:])]
