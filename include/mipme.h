@@ -360,8 +360,10 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
 /* Energy-mode detection for callers that reduce with plain tensor ops, E = (charges * V).sum() (README.rst:112-114): the
  * gradient arriving at the calculator's backward is then gE * charges.  result[0] = s = g[k] / q[k] at the k of the largest
  * |q|; result[1] = 1 if |g[i] - s q[i]| <= 8 eps |s q[i]| for every i, else 0 (2 reals of `dtype`, device memory).  When it
- * matches, result (the device scalar s) can be passed as grad_scale of the backward entry points.  One workgroup. */
-int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result);
+ * matches, result (the device scalar s) can be passed as grad_scale of the backward entry points.  One workgroup.
+ * host_flag (nullable): ONE int32 of pinned host memory that also receives the verdict (0 / 1, system-scope store) -- the
+ * caller presets it to -1 and polls it instead of copying `result` back. */
+int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag);
 
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 

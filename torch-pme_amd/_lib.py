@@ -226,7 +226,7 @@ def _declare(lib):
         "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12 + [i64],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
-        "mipme_scaled_match": [vp, ci, i64, vp, vp, vp],
+        "mipme_scaled_match": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],
         "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
         "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -306,7 +306,29 @@ def index_code(dtype) -> int:
 
 
 def current_stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """``hipStream_t`` of PyTorch's current stream on ``device`` (raw handle: no Stream object per call)."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def on_device(device):
+    """Context that makes ``device`` the current HIP device for the launches inside -- a no-op object when it already is
+    (``torch.cuda.device`` costs ~4 us per enter / exit, several times per call)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_CTX
+    return torch.cuda.device(device)
 
 
 def require_device(t, name: str):

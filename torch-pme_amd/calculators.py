@@ -52,6 +52,7 @@ class Calculator(torch.nn.Module):
     #: hold weak references to the caller's tensors); rebuilt on first use
     _TRANSIENT = {"_cache": None, "_plan_store": dict, "_freq_cache": None, "_nan_flag": None, "_nan_shape": None}
 
+
     def __getstate__(self):
         state = self.__dict__.copy()
         for name, fresh in self._TRANSIENT.items():

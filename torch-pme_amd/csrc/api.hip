@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void dot_backward_kernel(int64_t n, const T* _
 // One workgroup: s = g[k] / q[k] at the k of the largest |q|, then max_i |g_i - s q_i| <= tol |s q_i|.  result = {s, 0 | 1}.
 template <typename T>
 __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* __restrict__ g, const T* __restrict__ q,
-                                                            T* __restrict__ result) {
+                                                            T* __restrict__ result, int* __restrict__ host_flag) {
   __shared__ double s_val[16];
   __shared__ long long s_idx[16];
   __shared__ int s_bad[16];
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* 
     for (int w = 0; w < int(blockDim.x >> 6); ++w) any |= s_bad[w];
     result[0] = scale;
     result[1] = any ? T(0) : T(1);
+    if (host_flag) __hip_atomic_store(host_flag, any ? 0 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -833,13 +834,13 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
   return MIPME_OK;
 }
 
-int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result) {
+int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag) {
   MIPME_REQUIRE(n > 0 && g && q && result, "invalid arguments to mipme_scaled_match");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIPME_F32)
-    scaled_match_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result);
+    scaled_match_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result, (int*)host_flag);
   else if (dtype == MIPME_F64)
-    scaled_match_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)g, (const double*)q, (double*)result);
+    scaled_match_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)g, (const double*)q, (double*)result, (int*)host_flag);
   else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;

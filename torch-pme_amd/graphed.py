@@ -240,14 +240,14 @@ class GraphedFrameBatch:
         self.forces = [p.grad for p in self.pos]
 
     def _launch_forward(self):
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.load().mipme_frames_forward(
                 self._plan.handle, _lib.current_stream(self.device), self._dt, self.n_frames, self._frames,
                 C.byref(self._pot), self._table.data_ptr(), self._G.data_ptr(), self._G.shape[1], self._rho.data_ptr(),
                 self._hat.data_ptr(), self._phi.data_ptr(), self._dc.data_ptr()))
 
     def _launch_backward(self, g):
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.load().mipme_frames_backward(
                 _lib.current_stream(self.device), self._dt, self.n_frames, self._frames, self._table.data_ptr(),
                 g.data_ptr()))

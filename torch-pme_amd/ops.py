@@ -63,7 +63,13 @@ class MeshGeometry:
         self.plan_store = None
 
     def desc(self, n_channels: int) -> _lib.MeshDesc:
-        d = _lib.MeshDesc()
+        """``mipme_mesh_t`` of this geometry (one struct per channel count, built once: the struct is read-only for the
+        library)."""
+        cache = self.__dict__.setdefault("_desc_cache", {})
+        d = cache.get(n_channels)
+        if d is not None:
+            return d
+        d = cache[n_channels] = _lib.MeshDesc()
         d.scheme, d.order = self.scheme, self.order
         d.nx, d.ny, d.nz = self.ns
         d.n_channels = n_channels
@@ -91,7 +97,7 @@ def build_filter(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device
     """G(k) on the rfft half grid, computed on the device in fp64 and stored in ``dtype``."""
     G = torch.empty((geom.ns[0], geom.ns[1], geom.ns[2] // 2 + 1), dtype=dtype, device=device)
     md = geom.desc(1)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         _lib.check(
             _lib.load().mipme_kfilter_build(
                 _lib.current_stream(device), _lib.dtype_code(dtype), C.byref(md), C.byref(pot_desc), G.data_ptr()
@@ -178,7 +184,7 @@ class PairTopology:
         self._sorted = None
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             nbytes = lib.mipme_topology_workspace_bytes(P)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
             _lib.check(
@@ -209,7 +215,7 @@ class PairTopology:
         device = shifts.device
         packed = torch.zeros((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             _lib.check(
                 lib.mipme_topology_pack_shifts(
                     _lib.current_stream(device), _lib.dtype_code(shifts.dtype), self.n_pairs, self.entries.data_ptr(),
@@ -232,7 +238,7 @@ class PairTopology:
         device = shifts.device
         packed = torch.empty((max(self.n_pairs, 1),), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             _lib.check(lib.mipme_pack_pair_shifts(_lib.current_stream(device), _lib.dtype_code(shifts.dtype), self.n_pairs,
                                                   shifts.data_ptr(), packed.data_ptr(), flag.data_ptr()))
         if int(flag.item()) != 0:
@@ -254,7 +260,7 @@ class PairTopology:
         device = self.entries.device
         ent32 = torch.zeros((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
         flag = torch.empty((1,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             _lib.check(
                 lib.mipme_topology_pack_entries(
                     _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
@@ -282,7 +288,7 @@ class PairTopology:
         flag = torch.empty((1,), dtype=torch.int32, device=device)
         fmt = 1 if table else 0
         while True:
-            with torch.cuda.device(device):
+            with _lib.on_device(device):
                 _lib.check(
                     lib.mipme_topology_pack_entries(
                         _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32,
@@ -340,6 +346,18 @@ class DistanceSource:
             return False
         now = (self.positions._version, None if self.cell is None else self.cell._version, pairs._version, dist._version)
         return now == self.versions and dist.dtype == self.positions.dtype and dist.device == self.positions.device
+
+
+_MATCH_FLAG = None
+
+
+def _match_flag():
+    """Pinned int32 word (tensor, NumPy view) the energy-gradient detection kernel reports to."""
+    global _MATCH_FLAG
+    if _MATCH_FLAG is None:
+        t = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        _MATCH_FLAG = (t, t.numpy())
+    return _MATCH_FLAG
 
 
 _TOPOLOGIES: "OrderedDict" = OrderedDict()
@@ -436,7 +454,7 @@ class _PMEFunction(torch.autograd.Function):
         need_cell = ctx.needs_input_grad[1]
         saved = {}
         field = tail = None
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st = _lib.current_stream(device)
             # atomic_pairs: one pass over the list with float atomics -- for lists that are new every call (the flattened pair
             # list of a padded batch), where building the transposed list would cost more than it saves
@@ -635,7 +653,7 @@ class _PMEFunction(torch.autograd.Function):
         full = int(ctx.full_list)
         g = grad_out.contiguous()
         grad_q = grad_pos = grad_cell = grad_dist = grad_src_pos = grad_src_cell = None
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st = _lib.current_stream(device)
             do_kspace = geom is not None and (need_q or need_cell or need_pos)
             # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
@@ -651,8 +669,19 @@ class _PMEFunction(torch.autograd.Function):
                 # device whether the gradient is a multiple of the charges (one small kernel + a 2-value read; the general
                 # adjoint it saves is a second spread, an FFT pair and a gradient gather).  Not during graph capture.
                 res = torch.empty((2,), dtype=dtype, device=device)
-                _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr())
-                if float(res[1]) == 1.0:
+                flag, flag_np = _match_flag()
+                flag_np[0] = -1
+                _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
+                      flag.data_ptr())
+                # the kernel also writes its verdict to pinned host memory: poll that word instead of a device-to-host copy
+                # (hipMemcpy of 4 bytes costs 20-30 us on this stack; the poll ends a few us after the kernel does)
+                spins = 0
+                while flag_np[0] == -1:
+                    spins += 1
+                    if spins > 2_000_000:  # never seen; a stream synchronisation is the fallback
+                        torch.cuda.current_stream(device).synchronize()
+                        break
+                if flag_np[0] == 1:
                     sr_scale = res[:1]
             if sr_scale is not None and ctx.slab_axis is None:
                 gscale = sr_scale
@@ -839,7 +868,7 @@ class _PMEFunction(torch.autograd.Function):
                 def make_grad_dist(g=g, sr_scale=sr_scale):
                     out_d = torch.empty((P,), dtype=dtype, device=device)
                     pl = pairs if topo is None else topo.pairs32
-                    with torch.cuda.device(device):
+                    with _lib.on_device(device):
                         _call(
                             "rspace_backward", lib.mipme_rspace_backward,
                             _lib.current_stream(device), dt, _lib.index_code(pl.dtype), P, N, Cn, pl.data_ptr(),
@@ -890,7 +919,7 @@ def _launch_pair_distances(pos, cl, pairs, sh, shifts_key, out):
     topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
     pl = pairs if topo is None else topo.pairs32
     packed = topo.pair_packed_shifts(sh, shifts_key) if (topo is not None and sh is not None) else None
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         if packed is not None:
             _call(
                 "pair_distance_forward", lib.mipme_pair_distance_forward_packed,
@@ -954,7 +983,7 @@ class _PairDistances(torch.autograd.Function):
             partials = torch.empty((n_part,), dtype=torch.float64, device=device)
         if topo is not None:
             packed = None if sh is None else topo.packed_shifts(sh, ctx.shifts_key)
-            with torch.cuda.device(device):
+            with _lib.on_device(device):
                 _call(
                     "pair_distance_backward", lib.mipme_pair_distance_backward_rows,
                     _lib.current_stream(device), _lib.dtype_code(dtype), N, topo.row_ptr.data_ptr(),
@@ -963,7 +992,7 @@ class _PairDistances(torch.autograd.Function):
                     grad_pos.data_ptr(), _lib.ptr(grad_cell),
                 )
             return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None, None
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             _call(
                 "pair_distance_backward", lib.mipme_pair_distance_backward,
                     _lib.current_stream(device), _lib.dtype_code(dtype), _lib.index_code(pairs.dtype), P, N,
@@ -1029,7 +1058,7 @@ class _WeightedSum(torch.autograd.Function):
         a_c, b_c = a.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((), dtype=a.dtype, device=a.device)
         scratch = _dot_scratch(a.device, b.data_ptr())
-        with torch.cuda.device(a.device):
+        with _lib.on_device(a.device):
             _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
                   a_c.numel(), a_c.data_ptr(), b_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
         ctx.save_for_backward(a_c, b_c)
@@ -1043,7 +1072,7 @@ class _WeightedSum(torch.autograd.Function):
         ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
         g = g.contiguous()
-        with torch.cuda.device(a.device):
+        with _lib.on_device(a.device):
             _call("energy_sum_backward", lib.mipme_dot_backward, _lib.current_stream(a.device), _lib.dtype_code(a.dtype),
                   a.numel(), g.data_ptr(), a.data_ptr(), b.data_ptr(), _lib.ptr(ga), _lib.ptr(gb))
         if ga is not None:
@@ -1086,7 +1115,7 @@ class _EnergyDirectSum(torch.autograd.Function):
             V_c = V.contiguous()
             out = torch.empty((), dtype=V.dtype, device=V.device)
             scratch = _dot_scratch(V.device, q.data_ptr())
-            with torch.cuda.device(V.device):
+            with _lib.on_device(V.device):
                 _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(V.device), _lib.dtype_code(V.dtype),
                       V_c.numel(), V_c.data_ptr(), q_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
         ctx.q, ctx.force, ctx.field, ctx.full = q_c, node.fused["force"], node.field, int(node.full_list)
@@ -1104,7 +1133,7 @@ class _EnergyDirectSum(torch.autograd.Function):
             return None, None, tail["grad"].detach(), None
         grad_pos = torch.empty((q.shape[0], 3), dtype=q.dtype, device=q.device)
         g = g.contiguous()
-        with torch.cuda.device(q.device):
+        with _lib.on_device(q.device):
             _call("forces_finalize", lib.mipme_sr_rows_finalize, _lib.current_stream(q.device), _lib.dtype_code(q.dtype),
                   q.shape[0], _lib.ptr(ctx.force), _lib.ptr(ctx.field), q.data_ptr(), g.data_ptr(), ctx.full, None,
                   grad_pos.data_ptr(), None)
@@ -1135,7 +1164,7 @@ class _EwaldKSpace(torch.autograd.Function):
         Sc = torch.empty(lead + (K, Cn), dtype=dtype, device=device)
         Ss = torch.empty(lead + (K, Cn), dtype=dtype, device=device)
         out = torch.empty(lead + (N, Cn), dtype=dtype, device=device)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st = _lib.current_stream(device)
             _call("ewald_filter", lib.mipme_ewald_filter, st, dt, C.byref(pot_desc), B * K, kv.data_ptr(), G.data_ptr(),
                   dG.data_ptr())
@@ -1163,7 +1192,7 @@ class _EwaldKSpace(torch.autograd.Function):
         grad_q = torch.empty_like(q) if need_q else None
         grad_pos = torch.empty_like(pos) if need_pos else None
         grad_k = torch.empty_like(kv) if need_k else None
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st = _lib.current_stream(device)
             _call("ewald_structure", lib.mipme_ewald_structure, st, dt, N, Cn, K, pos.data_ptr(), g.data_ptr(),
                   kv.data_ptr(), Tc.data_ptr(), Ts.data_ptr(), B)

@@ -125,6 +125,12 @@ class Potential(torch.nn.Module):
     def _exponent_int(self) -> int:
         raise NotImplementedError
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_host_cache"] = None  # host copies of the buffers / the C descriptor: rebuilt on first use
+        state.pop("_desc_cache", None)
+        return state
+
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._host_cache = None
@@ -138,7 +144,11 @@ class Potential(torch.nn.Module):
                 "CoulombPotential and InversePowerLawPotential"
             )
         sm, pref, p = self._host_params()
-        return _lib.PotentialDesc(
+        key = (sm, pref, p, self.exclusion_radius, self.exclusion_degree)
+        cached = self.__dict__.get("_desc_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]  # read-only for the library: one struct per parameter set instead of one per call
+        desc = _lib.PotentialDesc(
             kind=self._kind,
             exponent=p,
             smearing=-1.0 if sm is None else sm,
@@ -146,6 +156,8 @@ class Potential(torch.nn.Module):
             exclusion_radius=-1.0 if self.exclusion_radius is None else float(self.exclusion_radius),
             exclusion_degree=int(self.exclusion_degree),
         )
+        self.__dict__["_desc_cache"] = (key, desc)
+        return desc
 
     # ---- reference method surface ------------------------------------------------------------
     def f_cutoff(self, dist: torch.Tensor, pair_mask: torch.Tensor | None = None) -> torch.Tensor:
