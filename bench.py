@@ -132,7 +132,9 @@ class Frame:
         # owns a pair's first atom) instead of by a separate pass over the pair list -- same tensor, one kernel less
         d = tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts, deferred=True)
         self.distances = d.detach()
-        V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
+        # the backward pass below is seeded with minus_one: promised to the forward, whose gather then writes the forces
+        with tpa.ops.seed_promise(self.minus_one):
+            V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
         E = tpa.weighted_sum(V, self.q)
         E.backward(self.minus_one)
         return E.detach(), self.pos.grad
@@ -190,13 +192,16 @@ def algorithmic_bytes(w, s: int, fused: bool = True):
         # the spread and the fused distance + pair kernel co-scheduled in one launch (mipme_sr_job_t): both byte counts
         "spread+rspace_forward": (2 * P * eb + P * s + N * 8 * s) + N * 4 * s + 2 * M * s,
         "gather": N * 5 * s + M * s,
+        # gather + energy + force assembly in one launch (the step's tail): also reads the pair force sums, writes field and forces
+        "gather+energy+forces": N * 14 * s + M * s,
         "gather_grad": N * 8 * s + 2 * M * s,
         "fft_r2c": 2 * M * s,
         "fft_c2r": 2 * M * s,
         "apply_filter": int(2.5 * M * s),
         # (y,z) plane transforms + one kernel for x-FFT * G * inverse x-FFT: the three stages above in one composite
         "convolve_xfused": int(6.5 * M * s),
-        "bin_atoms": N * (3 * s + 8 + 16 + 4 * s),
+        # one-pass binning: positions + charges in, record (16 B), 6 n weights and the (x, y, z, q) record out
+        "bin_atoms": N * (4 * s + 16 + 6 * w.order * s + 4 * s),
         # energy reduction E = sum q V, its adjoint, and the energy-mode force assembly gE q_a (f F_a + field_a)
         "energy_sum": N * 2 * s,
         "energy_sum_backward": N * 3 * s,

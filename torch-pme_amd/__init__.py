@@ -6,7 +6,7 @@ The directory is named ``torch-pme_amd``; import it as ``torchpme_amd`` (see ``t
 repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI in ``include/mipme.h``).
 """
 
-from . import lib, library, prefactors, tuning, workloads  # noqa: F401  (library registers the torch.ops.mipme ops)
+from . import lib, library, ops, prefactors, tuning, workloads  # noqa: F401  (library registers the torch.ops.mipme ops)
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, EwaldCalculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces, GraphedFrameBatch

@@ -85,11 +85,8 @@ class GraphedEnergyForces:
         self.distances = d.detach()
         # the backward pass below is seeded with self._minus_one: promise that to the forward, whose gather then writes the
         # forces themselves (energy reduction and force assembly ride in the gather launch, see ops.SEED_PROMISE)
-        ops.SEED_PROMISE = None if self.cell_gradient else self._minus_one
-        try:
+        with ops.seed_promise(None if self.cell_gradient else self._minus_one):
             V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
-        finally:
-            ops.SEED_PROMISE = None
         E = ops.weighted_sum(V, self.q)
         E.backward(self._minus_one)
         return E.detach()

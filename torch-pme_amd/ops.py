@@ -133,6 +133,26 @@ TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
 #: a device scalar the caller promises to seed the next backward pass with (set by GraphedEnergyForces around its
 #: evaluation): the gather's tail then writes seed * dE/dpositions and the backward pass launches nothing
 SEED_PROMISE = None
+
+
+class seed_promise:
+    """``with seed_promise(seed): V = calculator(...)`` -- the caller promises to seed the backward pass of ``weighted_sum(V,
+    charges)`` with the device scalar ``seed`` (unchanged until then), e.g. ``E.backward(seed)`` with ``seed = -1`` to get the
+    forces.  The gather's tail then writes ``seed * dE/dpositions`` in the forward pass and the backward launches nothing; any
+    other seed still gives the right gradient through the ordinary backward kernels."""
+
+    def __init__(self, seed):
+        self.seed = seed
+
+    def __enter__(self):
+        global SEED_PROMISE
+        self._prev, SEED_PROMISE = SEED_PROMISE, self.seed
+        return self
+
+    def __exit__(self, *exc):
+        global SEED_PROMISE
+        SEED_PROMISE = self._prev
+        return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
 
