@@ -942,6 +942,35 @@ def test_plane_kernels_large_lds(dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("cell_diag", [(20.0, 80.0, 80.0), (80.0, 20.0, 80.0), (20.0, 80.0, 20.0)])
+def test_split_plane_kernels_256(dtype, cell_diag, monkeypatch):
+    """(y,z) planes with a 256-wide axis exceed one workgroup's LDS (256 x 129 complex = 264 KB in fp32): the transforms run
+    as two launches per direction -- z rows (32 or 16 rows per workgroup), y columns (16 or 8 kz per workgroup) -- instead of
+    falling back to hipFFT's 2-D plans (round-1 verdict item 6).  Potentials and gradients against the 3-D hipFFT plans for
+    meshes (64, 256, 256), (256, 64, 256) and (64, 256, 64), general upstream gradient."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(2)
+    N = 400
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    cell = t(np.diag(cell_diag) + rng.normal(scale=0.05, size=(3, 3)))
+    pos, q, g = t(rng.uniform(0, 1, (N, 3)) * np.array(cell_diag)), t(rng.normal(size=(N, 1))), t(rng.normal(size=(N, 1)))
+    none, nod = torch.zeros((0, 2), dtype=torch.int64, device=DEV), torch.zeros((0,), dtype=dtype, device=DEV)
+    h = 0.7  # 80 A axes -> 2 * 80 / 0.7 + 1 = 230 -> 256 points, 20 A axes -> 58 -> 64 points
+    res = []
+    for xf in (True, False):
+        monkeypatch.setattr(ops, "XFUSED", xf)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.5), mesh_spacing=h, interpolation_nodes=4).to(dtype)
+        p = pos.clone().requires_grad_(True)
+        V = calc(q, cell, p, none, nod)
+        assert calc._cache[6].ns == tuple(256 if d > 50 else 64 for d in cell_diag)
+        (V * g).sum().backward()
+        res.append((V.detach().double().cpu().numpy(), p.grad.double().cpu().numpy()))
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    assert rell2(res[0][0], res[1][0]) < tol and rell2(res[0][1], res[1][1]) < tol * 10
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("blob", ["corner", "two"])
 def test_bin_overflow_region(dtype, blob):
     """One-pass binning: a brick owns a fixed number of slots (4 x the mean occupancy + 8) and the atoms that find it full go

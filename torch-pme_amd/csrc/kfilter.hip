@@ -330,6 +330,10 @@ struct mipme_fft_plan {
   // own (y, z) plane kernels (yz_planes_kernel) instead of the two hipFFT plans above: power-of-two ny, nz whose half-complex
   // plane fits 64 KB of LDS
   bool own_yz = false;
+  // planes too large for one workgroup's LDS (256-wide meshes): the same transforms as TWO launches per direction -- z rows
+  // (yz_planes_kernel without its y stage, `split_rows` rows per workgroup) and y columns (ycols_kernel) -- still no hipFFT
+  bool split_yz = false;
+  int split_rows = 0;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
@@ -505,14 +509,16 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
   }
 }
 
-template <typename T, bool INVERSE>
+// YSTAGE = false: only the z rows are transformed (`ny` is then just the number of rows this workgroup takes, y stays in natural
+// order, blockIdx.x = row group): the first / last of the two launches for planes that do not fit LDS (split_yz).
+template <typename T, bool INVERSE, bool YSTAGE = true>
 __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
                                                        Cplx<T>* __restrict__ hat, T* __restrict__ real_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_yz[];
   const int Lz = nz >> 1, RZ = Lz + 1;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yz);  // [ny][RZ]
   Cplx<T>* tw = tile + size_t(ny) * RZ;                  // exp(-2 pi i j / Ltab), j < Ltab / 2
-  const int Ltab = ny > Lz ? ny : Lz;
+  const int Ltab = (YSTAGE && ny > Lz) ? ny : Lz;
   const int tid = threadIdx.x, nthr = blockDim.x;
   Cplx<T>* twr = tw + (Ltab >> 1);                       // exp(-2 pi i k / nz), k <= nz / 2 (split / merge steps)
   for (int j = tid; j < (Ltab >> 1); j += nthr) unit_root(j, Ltab, tw[j].re, tw[j].im);
@@ -547,22 +553,22 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
     }
     __syncthreads();
     // columns: DIF along y (natural in, bit-reversed out); the store undoes the bit reversal
-    lds_fft_radix2<T, false, false>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    if constexpr (YSTAGE) lds_fft_radix2<T, false, false>(tile, logny, RZ, 1, RZ, tw, Ltab);
     Cplx<T>* dst = hat + plane * int64_t(ny) * RZ;
     for (int idx = tid; idx < ny * RZ; idx += nthr) {
       const int y = idx / RZ, k = idx - y * RZ;
-      const int yr = int(__brev(unsigned(y)) >> (32 - logny));
+      const int yr = YSTAGE ? int(__brev(unsigned(y)) >> (32 - logny)) : y;
       dst[int64_t(yr) * RZ + k] = tile[idx];
     }
   } else {
     const Cplx<T>* src = hat + plane * int64_t(ny) * RZ;
     for (int idx = tid; idx < ny * RZ; idx += nthr) {
       const int y = idx / RZ, k = idx - y * RZ;
-      const int yr = int(__brev(unsigned(y)) >> (32 - logny));
+      const int yr = YSTAGE ? int(__brev(unsigned(y)) >> (32 - logny)) : y;
       tile[yr * RZ + k] = src[idx];
     }
     __syncthreads();
-    lds_fft_radix2<T, true, true>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    if constexpr (YSTAGE) lds_fft_radix2<T, true, true>(tile, logny, RZ, 1, RZ, tw, Ltab);
     // merge step (un-normalised: twice the textbook one):  C_k = (A_k + conj A_{Lz-k}) + i e^{+2 pi i k / nz} (A_k - conj A_{Lz-k})
     for (int idx = tid; idx < ny * (Lz / 2 + 1); idx += nthr) {
       const int y = idx / (Lz / 2 + 1), k = idx - y * (Lz / 2 + 1);
@@ -598,8 +604,92 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
   }
 }
 
+// y columns of the half-complex mesh for planes that do not fit LDS (split_yz): one workgroup transforms the columns
+// (x, kz0 .. kz0 + KZ) along y in LDS as tile[y][z] -- forward: decimation in frequency, stored back through the bit reversal;
+// inverse: loaded through the bit reversal, decimation in time, conjugate twiddles -- in place, natural order in memory both
+// ways, un-normalised.  Segments of KZ complex values (>= 64 B) keep the strided accesses coalesced.
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, int kzs, int nchunk, Cplx<T>* __restrict__ hat) {
+  extern __shared__ __attribute__((aligned(16))) char smem_yc[];
+  const int KZ = 1 << kzs, KP = KZ + 1;                 // rows padded by one element: the butterflies stride over y, and an
+  Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yc);  // even row length would put a wave's 64 accesses on the same banks
+  Cplx<T>* tw = tile + size_t(ny) * KP;                 // exp(-2 pi i j / ny), j < ny / 2
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int chunk = blockIdx.x % nchunk;
+  const int64_t plane = blockIdx.x / nchunk;  // (channel, x)
+  const int kz0 = chunk << kzs, kzn = min(KZ, nzh - kz0);
+  for (int j = tid; j < (ny >> 1); j += nthr) unit_root(j, ny, tw[j].re, tw[j].im);
+  Cplx<T>* col = hat + plane * int64_t(ny) * nzh + kz0;  // element (y, z): col[y * nzh + z]
+  const int n_el = ny << kzs;
+  for (int idx = tid; idx < n_el; idx += nthr) {
+    const int y = idx >> kzs, z = idx & (KZ - 1);
+    const int yt = INVERSE ? int(__brev(unsigned(y)) >> (32 - logny)) : y;
+    tile[yt * KP + z] = z < kzn ? col[int64_t(y) * nzh + z] : Cplx<T>{T(0), T(0)};
+  }
+  __syncthreads();
+  lds_fft_radix2<T, INVERSE, INVERSE>(tile, logny, KZ, 1, KP, tw, ny);  // forward: DIF; inverse: DIT
+  for (int idx = tid; idx < n_el; idx += nthr) {
+    const int y = idx >> kzs, z = idx & (KZ - 1);
+    const int ys = INVERSE ? y : int(__brev(unsigned(y)) >> (32 - logny));
+    if (z < kzn) col[int64_t(ys) * nzh + z] = tile[y * KP + z];
+  }
+}
+
+template <typename T>
+static int ycols(mipme_fft_plan* p, hipStream_t st, bool inverse, void* hat) {
+  const int nzh = p->nz / 2 + 1;
+  int logny = 0;
+  while ((1 << logny) < p->ny) ++logny;
+  int kzs = sizeof(T) == 4 ? 4 : 3;  // 128-byte segments; tile <= 32 KiB
+  while (kzs > 0 && sizeof(Cplx<T>) * (size_t(p->ny) << kzs) > 32768) --kzs;
+  const int nchunk = (nzh + (1 << kzs) - 1) >> kzs;
+  const size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * ((size_t(1) << kzs) + 1) + size_t(p->ny / 2));
+  const unsigned grid = unsigned(nchunk) * unsigned(p->nx) * unsigned(p->batch);
+  if (inverse)
+    ycols_kernel<T, true><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat);
+  else
+    ycols_kernel<T, false><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+// rows per workgroup of the z-rows launch of split planes: the largest power of two (<= ny) whose tile fits 64 KB of LDS
+static int split_rows_for(int dtype, int ny, int nz) {
+  const size_t cs = dtype == MIPME_F32 ? 8 : 16;
+  const size_t Lz = size_t(nz / 2), RZ = Lz + 1;
+  int r = ny;
+  while (r > 1 && cs * (size_t(r) * RZ + Lz / 2 + RZ) > 64 * 1024) r >>= 1;
+  return cs * (size_t(r) * RZ + Lz / 2 + RZ) <= 64 * 1024 ? r : 0;
+}
+
+template <typename T>
+static int zrows(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* real_in, void* hat, void* real_out) {
+  int loglz = 0;
+  while ((1 << loglz) < p->nz / 2) ++loglz;
+  const int Lz = p->nz / 2, R = p->split_rows;
+  const size_t lds = sizeof(Cplx<T>) * (size_t(R) * (Lz + 1) + size_t(Lz) / 2 + size_t(Lz + 1));
+  const unsigned grid = unsigned(int64_t(p->nx) * p->ny * p->batch / R);
+  const int work = R * (Lz + 1);
+  const int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
+  if (inverse)
+    yz_planes_kernel<T, true, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out);
+  else
+    yz_planes_kernel<T, false, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
 template <typename T>
 static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* real_in, void* hat, void* real_out) {
+  if (p->split_yz) {  // planes beyond one workgroup's LDS: z rows and y columns as two launches
+    int rc;
+    if (!inverse) {
+      if ((rc = zrows<T>(p, st, false, real_in, hat, nullptr))) return rc;
+      return ycols<T>(p, st, false, hat);
+    }
+    if ((rc = ycols<T>(p, st, true, hat))) return rc;
+    return zrows<T>(p, st, true, nullptr, hat, real_out);
+  }
   int logny = 0, loglz = 0;
   while ((1 << logny) < p->ny) ++logny;
   while ((1 << loglz) < p->nz / 2) ++loglz;
@@ -1080,6 +1170,16 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
   {
     const char* e = getenv("MIPME_OWN_YZ");
     p->own_yz = xfused_dims_ok(nx) && own_yz_dims_ok(dtype, ny, nz) && !(e && e[0] == '0');
+    // power-of-two planes that do not fit one workgroup's LDS: split transforms (z rows + y columns), still own kernels
+    const bool pow2 = ny >= 2 && nz >= 4 && (ny & (ny - 1)) == 0 && (nz & (nz - 1)) == 0;
+    if (!p->own_yz && xfused_dims_ok(nx) && pow2 && !(e && e[0] == '0')) {
+      const int rows = split_rows_for(dtype, ny, nz);
+      const size_t cs = dtype == MIPME_F32 ? 8 : 16;
+      if (rows > 0 && cs * (size_t(ny) + size_t(ny / 2)) <= 32768) {  // a y column of one kz also has to fit its tile
+        p->own_yz = p->split_yz = true;
+        p->split_rows = rows;
+      }
+    }
   }
   // With our own plane kernels the fused convolution -- the hot path -- needs no hipFFT at all: the 3-D hipFFT plans (general
   // backward with a cell gradient, mipme_convolve, mipme_fft_r2c) are then created on first use (ensure_3d_plans).
