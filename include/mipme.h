@@ -119,10 +119,11 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
  * (mipme_sr_rows_finalize) and mipme_kspace_backward is not needed.
  * out_records (4N reals, 16-byte aligned), nullable, same conditions: (x, y, z, q) per atom for mipme_sr_rows_fused
  * (records_ready = 1), written by the binning pass while the positions are in registers.
- * The plan owns the per-brick atom counters of the binning pass: a plan serves one stream at a time.
+ * The plan owns the per-brick atom counters of the binning pass (zero between calls: the gather, their last consumer,
+ * clears them): a plan serves one stream at a time.
  * rho_hat == NULL (allowed when mipme_fft_plan_xfused(plan) != 0, i.e. nx is a power of two): rfftn(rho) is not kept and
- * the convolution runs as (y,z) plane transforms (own LDS kernels when a half-complex plane fits 152 KB of LDS, 2-D hipFFT
- * plans otherwise) + one kernel doing x-FFT, * G and the inverse x-FFT.
+ * the convolution runs as (y,z) plane transforms (own LDS kernels for power-of-two ny, nz: one launch per direction when a
+ * half-complex plane fits 152 KB of LDS, z rows + y columns as two launches otherwise; 2-D hipFFT plans for other sizes) + one kernel doing x-FFT, * G and the inverse x-FFT.
  * sr_job (nullable; needs atom_bins, out_records, a single channel, job->records == out_records, job->out == out_lr and
  * accumulate_out = 1): the short-range pair sum of the same call -- mipme_sr_rows_fused in its potential + force-sum mode
  * (src = charges, no pair mask, no cell partials; the fields mean what the arguments of that function mean) -- run
@@ -223,7 +224,7 @@ typedef struct mipme_frame {
   const void* cell;           /* (3,3) device copy of mesh.cell in the working dtype */
   mipme_mesh_t mesh;          /* n_channels = 1 */
   void* atom_bins;            /* mipme_atom_bins_bytes(mesh, N, dtype) */
-  void* brick_counters;       /* int32[bricks + 1] */
+  void* brick_counters;       /* int32[bricks + 1], zero before the first use (every forward leaves them zero) */
   const void* row_ptr;        /* pair topology, see mipme_sr_rows_fused */
   const void* entries_shift;
   const void* entries;
@@ -308,11 +309,14 @@ int mipme_kspace_backward(const mipme_kspace_backward_args_t* args);
  * already holds that many k-grid partial sums (out_cell_partials of the forward call) and rho_hat may be NULL. */
 int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
 
-/* atom_bins (nullable): device scratch of mipme_atom_bins_bytes() bytes.  When given, the atoms are counting-sorted
- * by 8x8x8 mesh brick in the forward call and the particle<->mesh stages run as brick kernels (owner-computes spread
- * into an LDS tile: no global atomics, no mesh memset; LDS-tiled gathers).  The SAME buffer must be handed to the
- * backward call (it reuses the bins).  mipme_atom_bins_bytes returns 0 when the mesh is too small for bricks
- * (< 17 points on an axis, or a last brick narrower than 4 points): pass NULL then (atomic-scatter kernels). */
+/* atom_bins (nullable): device scratch of mipme_atom_bins_bytes() bytes.  When given, the atoms are binned by 8x8x8 mesh
+ * brick in the forward call -- ONE pass: every brick owns a fixed number of slots (4 x the mean occupancy + 8), an atom takes
+ * the next free slot of its brick with one wave-aggregated atomic and writes its mesh coordinates and 1-D weights there;
+ * atoms that find their brick full go to an overflow region that every consumer also walks -- and the particle<->mesh stages
+ * run as brick kernels (owner-computes spread: no global atomics, no mesh memset; LDS-tiled gathers).  The SAME buffer must be
+ * handed to the backward call (it reuses the bins and the per-call copy of the brick counts kept inside).
+ * mipme_atom_bins_bytes returns 0 when the mesh is too small for bricks (< 17 points on an axis, or a last brick narrower
+ * than 4 points): pass NULL then (atomic-scatter kernels). */
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
 
 /* Per-stage timing for benchmarks: HIP events on the launch stream around every stage of the composite calls.

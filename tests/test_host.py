@@ -400,3 +400,61 @@ def test_potential_closed_forms_match_scipy():
     want = 2.0 * 4 * np.pi / abs(np.linalg.det(cell)) * (z1 * M - 0.5 * (M2 + Q * z1 * z1) - Q * np.linalg.norm(cell[1]) ** 2 / 12)
     np.testing.assert_allclose(got, want, rtol=1e-13)
     assert float(pot.pbc_correction(torch.tensor([True, True, True]), torch.tensor(pos), torch.tensor(cell), torch.tensor(q)).abs().max()) == 0.0
+
+
+def test_integration_snippets_match_the_header():
+    """Every ``lib.mipme_*(...)`` call and every argument-struct field shown in INTEGRATION.md exists in include/mipme.h with
+    the same number of arguments / the same field list (round 1: two snippets had drifted from the header unnoticed)."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mipme.h")).read(), flags=re.S)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = "\n".join(re.findall(r"```python\n(.*?)```", doc, flags=re.S))
+    code = re.sub(r"#.*", "", code)  # comments may contain commas and parentheses
+
+    def split_args(text):  # top-level commas of "a, f(b, c), d"
+        out, depth, cur = [], 0, ""
+        for ch in text:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return [a for a in out + [cur] if a.strip()]
+
+    protos = {}
+    for name, params in re.findall(r"\b(mipme_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        protos[name] = 0 if params.strip() in ("", "void") else len(split_args(params))
+    calls = 0
+    for m in re.finditer(r"lib\.(mipme_[a-z0-9_]+)\(", code):
+        name = m.group(1)
+        if name.endswith(("restype", "argtypes")) or code[m.end() - 1] != "(":
+            continue
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[i], 0)
+            i += 1
+        args = code[m.end():i - 1]
+        if args.strip() == "...":
+            continue
+        assert name in protos, f"INTEGRATION.md calls {name}, which include/mipme.h does not declare"
+        assert len(split_args(args)) == protos[name], (name, len(split_args(args)), protos[name])
+        calls += 1
+    assert calls >= 6
+    structs = _header_structs()
+    for cls, cname in (("KspaceForwardArgs", "mipme_kspace_forward_args_t"), ("KspaceBackwardArgs", "mipme_kspace_backward_args_t"),
+                       ("Potential", "mipme_potential_t"), ("Mesh", "mipme_mesh_t")):
+        body = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n" % cls, code, flags=re.S).group(1)
+        assert re.findall(r'\("(\w+)"', body) == structs[cname], cls
+    # keyword construction of the argument structs only uses declared fields
+    for cls, cname in (("KspaceForwardArgs", "mipme_kspace_forward_args_t"), ("KspaceBackwardArgs", "mipme_kspace_backward_args_t")):
+        for m in re.finditer(r"= %s\(" % cls, code):
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(code[i], 0)
+                i += 1
+            for arg in split_args(code[m.end():i - 1]):
+                key = arg.split("=", 1)[0].strip()
+                assert key in structs[cname], (cls, key)
