@@ -108,6 +108,16 @@ class Calculator(torch.nn.Module):
             self._spec_str = None
         return self._spec_str
 
+    #: public attributes the spec string encodes: assigning one of them refreshes it at once (eagerly -- building the JSON is
+    #: not traceable), so the compiled branch of ``forward`` never sees a stale description and dynamo, which guards on the
+    #: string, recompiles
+    _SPEC_ATTRS = frozenset({"full_neighbor_list", "mesh_spacing", "interpolation_nodes", "lr_wavelength", "potential"})
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name in self._SPEC_ATTRS and self.__dict__.get("_spec_str") is not None:
+            self._spec()
+
     def scriptable(self):
         """A TorchScript-compatible module with the same ``forward`` (``torch.jit.script(calculator.scriptable())``): the
         counterpart of the reference's ``torch.jit.script(calculator)`` (``tests/calculators/test_workflow.py:136-162``)."""
