@@ -37,7 +37,7 @@ int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*, const void*, int64_t);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*);
 const void* bins_epart(const mipme_mesh_t*, int64_t, int, void*, int64_t*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
@@ -159,7 +159,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     int64_t n_sr_part = 0;
     const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
     STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
-                                                 tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part));
+                                                 tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part,
+                                                 nullptr, nan_flag));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -225,7 +226,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   }

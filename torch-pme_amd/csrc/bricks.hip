@@ -1297,7 +1297,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
 }
 
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*, const void*, int64_t);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*);
 int64_t xconv_blocks(const mipme_fft_plan*);
 void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 bool fft_plan_xfused(const mipme_fft_plan*);
@@ -1340,7 +1340,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   double* epart_k = all_tail ? (double*)fft_plan_tail_scratch(plan, int64_t(sizeof(double)) * n_k * n_frames) : nullptr;
   MIPME_REQUIRE(!all_tail || epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
                                       "capture: run one evaluation before capturing)");
-  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k, nullptr, 0);
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k, nullptr, 0, nullptr, nullptr);
   if (rc) return rc;
   if (all_tail) {  // energy + forces of every frame in the gather launch
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,

@@ -218,6 +218,17 @@ struct GatherTailHost {
   const void* epart_k; // fp64[n_k]: per-workgroup sums of mu G |rho^|^2 written by the x stage of the convolution
   int64_t n_k;
   int sr_reduced;      // the x stage has also reduced the pair kernel's per-wave partial sums to epart_k[n_k + 2 b ...]
+  // rows that ride on the convolution launch finish after its x stage: their per-wave partial sums (waves sr2_first ..
+  // sr2_first + sr2_count of the bins buffer's epart array) are added up by the gather itself
+  int64_t sr2_first, sr2_count;
+};
+
+// Row workgroups of the co-scheduled pair sum that ride on the persistent convolution launch instead of the spread launch:
+// rows (atoms) [first_row, first_row + n_rows), first_row a multiple of 64.
+struct RowRideHost {
+  const mipme_sr_job_t* job;
+  void* epart;  // per-wave energy partial sums (bins buffer), nullable
+  int64_t first_row, n_rows;
 };
 
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position

@@ -334,6 +334,8 @@ struct mipme_fft_plan {
   // (yz_planes_kernel without its y stage, `split_rows` rows per workgroup) and y columns (ycols_kernel) -- still no hipFFT
   bool split_yz = false;
   int split_rows = 0;
+  // barrier counters of the persistent convolution launch (conv_persistent_kernel): 4 words, zero between calls
+  unsigned* conv_flags = nullptr;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
@@ -512,9 +514,9 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
 // YSTAGE = false: only the z rows are transformed (`ny` is then just the number of rows this workgroup takes, y stays in natural
 // order, blockIdx.x = row group): the first / last of the two launches for planes that do not fit LDS (split_yz).
 template <typename T, bool INVERSE, bool YSTAGE = true>
-__global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
-                                                       Cplx<T>* __restrict__ hat, T* __restrict__ real_out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_yz[];
+__device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
+                                              Cplx<T>* __restrict__ hat, T* __restrict__ real_out, int64_t plane,
+                                              char* smem_yz) {
   const int Lz = nz >> 1, RZ = Lz + 1;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yz);  // [ny][RZ]
   Cplx<T>* tw = tile + size_t(ny) * RZ;                  // exp(-2 pi i j / Ltab), j < Ltab / 2
@@ -523,7 +525,6 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
   Cplx<T>* twr = tw + (Ltab >> 1);                       // exp(-2 pi i k / nz), k <= nz / 2 (split / merge steps)
   for (int j = tid; j < (Ltab >> 1); j += nthr) unit_root(j, Ltab, tw[j].re, tw[j].im);
   for (int k = tid; k <= Lz; k += nthr) unit_root(k, nz, twr[k].re, twr[k].im);
-  const int64_t plane = blockIdx.x;  // (channel, x)
   if constexpr (!INVERSE) {
     // rows: c_j = a_2j + i a_2j+1, stored bit-reversed for the DIT z transform
     const T* src = real_in + plane * int64_t(ny) * nz;
@@ -602,6 +603,13 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
       reinterpret_cast<Cplx<T>*>(dst)[idx] = tile[y * RZ + jr];
     }
   }
+}
+
+template <typename T, bool INVERSE, bool YSTAGE = true>
+__global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
+                                                       Cplx<T>* __restrict__ hat, T* __restrict__ real_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_yz[];
+  yz_plane_body<T, INVERSE, YSTAGE>(ny, nz, logny, loglz, real_in, hat, real_out, blockIdx.x, smem_yz);  // plane = (channel, x)
 }
 
 // y columns of the half-complex mesh for planes that do not fit LDS (split_yz): one workgroup transforms the columns
@@ -723,20 +731,24 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
 // CELLSUMS: also form, per block, the 12 k-grid sums of the cell gradient for the energy mode (psi^ = rho^, i.e.
 // dL/dG(k) = mu(k) |rho^(k)|^2 up to the factor gE / 2V applied by cellgrad_finalize_kernel) from the transformed columns
 // while they are in LDS -- what apply_filter_cellgrad_kernel computes from a stored rfftn(rho) in the backward pass.
+// The body serves one TILE with a GROUP of `nthr` threads (`tid` = index inside the group, `grp` = index of the group in the
+// workgroup, `smem_x` = the group's own LDS region): the stand-alone kernel runs one group per workgroup, the persistent
+// convolution kernel several side by side.  Every __syncthreads() is workgroup-wide and unconditional, so all groups of a
+// workgroup run the same number of stages (same nx); a group without a tile (`active` = false) computes on zeros and touches
+// no global memory.  tile_id / n_tiles stand for blockIdx.x / gridDim.x of the stand-alone launch.
 template <typename T, bool CELLSUMS>
-__global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
-                                                   Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
-                                                   T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
-                                                   double* __restrict__ epart, const double* __restrict__ sr_part,
-                                                   int n_sr_part) {
-  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+__device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
+                                                Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
+                                                T* __restrict__ dc, const KGeom& kg, const KPot& kp,
+                                                double* __restrict__ partials, double* __restrict__ epart,
+                                                const double* __restrict__ sr_part, int n_sr_part, unsigned tile_id,
+                                                unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x) {
   const int KZ = 1 << kzs;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
   Cplx<T>* tw = tile + size_t(nx) * KZ;                 // [nx/2]: exp(-2 pi i j / nx)
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int chunk = blockIdx.x % nchunk;
-  const int ky = (blockIdx.x / nchunk) % ny;
-  const int c = blockIdx.x / (nchunk * ny);
+  const int chunk = tile_id % nchunk;
+  const int ky = (tile_id / nchunk) % ny;
+  const int c = tile_id / (nchunk * ny);
   const int kz0 = chunk << kzs;
   const int kzn = min(KZ, nzh - kz0);
   const int half_n = nx >> 1;
@@ -744,9 +756,9 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   // {sum q V_sr, sum q^2} (rows_body.h FusedRowsArgs::epart) into epart[gridDim.x + 2 b ...] -- they were written two
   // launches ago, and the gather's tail then adds up gridDim.x pairs instead of N / 4
   double sr0 = 0.0, sr1 = 0.0;
-  if (sr_part && tid < 64) {
-    const int per = (n_sr_part + int(gridDim.x) - 1) / int(gridDim.x);
-    const int lo = int(blockIdx.x) * per, hi = min(lo + per, n_sr_part);
+  if (sr_part && active && tid < 64) {
+    const int per = (n_sr_part + int(n_tiles) - 1) / int(n_tiles);
+    const int lo = int(tile_id) * per, hi = min(lo + per, n_sr_part);
     for (int i = lo + tid; i < hi; i += 64) {
       sr0 += sr_part[2 * i];
       sr1 += sr_part[2 * i + 1];
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   const int n_el = nx << kzs;
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
-    tile[idx] = z < kzn ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+    tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
   }
   __syncthreads();
   const int quarter = (nx >> 2) << kzs;  // 4-point groups per double stage
@@ -794,7 +806,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
     }
     __syncthreads();
   }
-  if (dc && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
+  if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
   if constexpr (CELLSUMS) {
     double acc[12];
 #pragma unroll
@@ -830,11 +842,11 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
     if (tid < 12) {
       double v = 0.0;
       for (int w = 0; w < (nthr + 63) / 64; ++w) v += red[w][tid];
-      partials[int64_t(blockIdx.x) * 12 + tid] = v;
+      partials[int64_t(tile_id) * 12 + tid] = v;
     }
     // the ticket counter of cellgrad_finalize_kernel lives behind its block sums, after the k-grid partials
-    if (blockIdx.x == 0 && tid == 0)
-      *reinterpret_cast<int*>(partials + int64_t(gridDim.x) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl) = 0;
+    if (tile_id == 0 && tid == 0)
+      *reinterpret_cast<int*>(partials + int64_t(n_tiles) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl) = 0;
   }
   // ---- product with G: position x holds kx = bitrev(x) ----
   // epart (nullable): this block's share of sum_k mu_k G_k |rho^_k|^2 (mu = 2 except on the kz = 0 and kz = nz/2 planes of
@@ -858,16 +870,16 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
     }
   }
   if (epart) {  // uniform
-    __shared__ double ered[4];
+    __shared__ double ered[16][4];  // [group][wave of the group]
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
-    if (lane == 0) ered[wave] = esum;
+    if (lane == 0) ered[grp][wave] = esum;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && active) {
       double v = 0.0;
-      for (int w = 0; w < (nthr + 63) / 64; ++w) v += ered[w];
-      epart[blockIdx.x] = v;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) v += ered[grp][w];
+      epart[tile_id] = v;
     }
     if (sr_part && tid < 64) {
 #pragma unroll
@@ -875,9 +887,9 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
         sr0 += __shfl_xor(sr0, off, 64);
         sr1 += __shfl_xor(sr1, off, 64);
       }
-      if (tid == 0) {
-        epart[int64_t(gridDim.x) + 2 * int64_t(blockIdx.x)] = sr0;
-        epart[int64_t(gridDim.x) + 2 * int64_t(blockIdx.x) + 1] = sr1;
+      if (tid == 0 && active) {
+        epart[int64_t(n_tiles) + 2 * int64_t(tile_id)] = sr0;
+        epart[int64_t(n_tiles) + 2 * int64_t(tile_id) + 1] = sr1;
       }
     }
   }
@@ -920,11 +932,106 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   }
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
-    if (z < kzn) col[x * xs + z] = tile[idx];
+    if (active && z < kzn) col[x * xs + z] = tile[idx];
+  }
+}
+
+template <typename T, bool CELLSUMS>
+__global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
+                                                   Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
+                                                   T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
+                                                   double* __restrict__ epart, const double* __restrict__ sr_part,
+                                                   int n_sr_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  xconv_tile_body<T, CELLSUMS>(nx, ny, nzh, log2nx, kzs, nchunk, hat, G, G_stride, dc, kg, kp, partials, epart, sr_part,
+                               n_sr_part, blockIdx.x, gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x);
+}
+
+// ---- the convolution as ONE persistent launch ----------------------------------------------------------------------------
+// (y,z) forward planes -> grid barrier -> x stage -> grid barrier -> (y,z) inverse planes, by n_conv = nx workgroups of 1024
+// threads that stay resident (n_conv <= 256 CUs, first in the workgroup index order), instead of three launches: two kernel
+// boundaries become two flag barriers.  EXPERIMENT, off by default (MIPME_PERSISTENT_CONV=1): measured slower than the three
+// launches (34.8 against 25.1 us at cfg3, profiles/r02_experiments.txt item 8) -- kept because it documents the hand-off
+// protocol and the cost of a software grid barrier on this part.
+// Inter-workgroup hand-off (MI355X: per-XCD L2s are not coherent): every wave drains its stores, the workgroup meets at a
+// barrier, ONE lane releases at agent scope (writes this XCD's dirty L2 lines back), takes a ticket on an agent-scope counter,
+// spins -- bounded -- until all n_conv tickets are taken, acquires at agent scope (invalidates), and the workgroup meets again;
+// plain loads after that see every other workgroup's data.  Nothing depends on dispatch order or placement beyond
+// co-residency, which the grid size guarantees.  A spin that gives up sets *err (results of that call are garbage, the GPU
+// does not hang).  The last workgroup to finish leaves the three counters at zero for the next call.
+template <typename T>
+struct ConvArgs {
+  int nx, ny, nz, nzh, log2nx, logny, loglz, kzs, nchunk, x_threads;
+  unsigned n_conv, n_tiles;
+  size_t x_group_lds;
+  const T* mesh_in;
+  Cplx<T>* hat;
+  T* mesh_out;
+  const T* G;
+  T* dc;
+  double* epart;
+  const double* sr_part;
+  int n_sr_part;
+  unsigned* flags;
+  int* err;
+};
+
+__device__ __forceinline__ void conv_grid_barrier(unsigned* counter, unsigned n, int* err) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) {  // >> any legitimate wait (a few microseconds): give up rather than hang the device
+        if (err) *err = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void conv_persistent_kernel(ConvArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  const unsigned w = blockIdx.x;
+  // ---- (y,z) forward: plane w = x (one channel)
+  yz_plane_body<T, false, true>(a.ny, a.nz, a.logny, a.loglz, a.mesh_in, a.hat, nullptr, int64_t(w), smem_c);
+  conv_grid_barrier(a.flags + 0, a.n_conv, a.err);
+  // ---- x stage: groups of x_threads threads, one tile each per round
+  {
+    const int G = 1024 / a.x_threads;
+    const int grp = int(threadIdx.x) / a.x_threads, gtid = int(threadIdx.x) % a.x_threads;
+    KGeom kg{};
+    KPot kp{};
+    for (unsigned base = 0; base < a.n_tiles; base += a.n_conv * unsigned(G)) {
+      const unsigned tile = base + w * unsigned(G) + unsigned(grp);
+      xconv_tile_body<T, false>(a.nx, a.ny, a.nzh, a.log2nx, a.kzs, a.nchunk, a.hat, a.G, 0, a.dc, kg, kp, nullptr, a.epart,
+                                a.sr_part, a.n_sr_part, tile < a.n_tiles ? tile : 0u, a.n_tiles, tile < a.n_tiles, gtid,
+                                a.x_threads, grp, smem_c + size_t(grp) * a.x_group_lds);
+      __syncthreads();  // the groups' LDS regions are reused by the next round
+    }
+  }
+  conv_grid_barrier(a.flags + 1, a.n_conv, a.err);
+  // ---- (y,z) inverse
+  yz_plane_body<T, true, true>(a.ny, a.nz, a.logny, a.loglz, nullptr, a.hat, a.mesh_out, int64_t(w), smem_c);
+  // ---- the last workgroup to get here resets the counters (everybody has left both spins by then)
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(a.flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == a.n_conv - 1) {
+      __hip_atomic_store(a.flags + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.flags + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.flags + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
 bool fft_plan_xfused(const mipme_fft_plan* p) { return p->own_yz || (p->fwd2d != 0 && p->inv2d != 0); }
+bool fft_plan_persistent(const mipme_fft_plan* p);
 int fft_plan_batch(const mipme_fft_plan* p) { return p->batch; }
 
 // mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
@@ -939,9 +1046,73 @@ int64_t xconv_blocks(const mipme_fft_plan* p) {
 }
 
 // cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
+// One persistent launch for the whole convolution (+ riding row workgroups of the pair sum), when the plan allows it
+static bool conv_persistent_ok(const mipme_fft_plan* p);
+bool fft_plan_persistent(const mipme_fft_plan* p) { return conv_persistent_ok(p); }
+static bool conv_persistent_ok(const mipme_fft_plan* p) {
+  if (!p->own_yz || p->split_yz || p->batch != 1 || p->nx > 256) return false;
+  if (p->ny * (p->nz / 2 + 1) < 2048) return false;  // the plane kernels then use fewer than 1024 threads
+  // measured (cfg3, 64^3 fp32): 34.8 us against 25.1 us for the three separate launches -- a software grid barrier
+  // (agent-scope release + counter + poll + acquire) costs MORE here than a kernel boundary inside a replayed graph, and
+  // the x stage of a resident grid has 64 workgroups to spread its tiles over instead of 320.  Opt-in, for experiments.
+  const char* e = getenv("MIPME_PERSISTENT_CONV");
+  return e && e[0] == '1';
+}
+
+template <typename T>
+static int convolve_persistent_t(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat,
+                                 void* mesh_out, void* dc, void* epart, const void* sr_part, int64_t n_sr_part,
+                                 const RowRideHost* rh, void* err_flag) {
+  ConvArgs<T> a{};
+  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz; a.nzh = p->nz / 2 + 1;
+  while ((1 << a.log2nx) < p->nx) ++a.log2nx;
+  while ((1 << a.logny) < p->ny) ++a.logny;
+  while ((1 << a.loglz) < p->nz / 2) ++a.loglz;
+  const size_t cs = sizeof(Cplx<T>);
+  a.kzs = sizeof(T) == 4 ? 3 : 2;
+  while (a.kzs > 0 && cs * (size_t(p->nx) << a.kzs) > 32768) --a.kzs;
+  a.nchunk = (a.nzh + (1 << a.kzs) - 1) >> a.kzs;
+  int threads = (p->nx >> 2) << a.kzs;
+  a.x_threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  a.n_conv = unsigned(p->nx);
+  a.n_tiles = unsigned(a.nchunk) * unsigned(p->ny);
+  a.x_group_lds = (cs * ((size_t(p->nx) << a.kzs) + size_t(p->nx / 2)) + 15) & ~size_t(15);
+  a.mesh_in = (const T*)mesh_in; a.hat = (Cplx<T>*)hat; a.mesh_out = (T*)mesh_out; a.G = (const T*)G; a.dc = (T*)dc;
+  a.epart = (double*)epart; a.sr_part = (const double*)sr_part; a.n_sr_part = int(n_sr_part);
+  if (!p->conv_flags) {  // first use (not during stream capture: the callers warm up)
+    if (hipMalloc((void**)&p->conv_flags, 4 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(p->conv_flags, 0, 4 * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("could not allocate the barrier counters of the convolution (not possible during stream capture: run one "
+                "evaluation before capturing)");
+      return MIPME_EHIP;
+    }
+  }
+  a.flags = p->conv_flags;
+  a.err = err_flag ? (int*)err_flag : (int*)(p->conv_flags + 3);
+  const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
+  const size_t lds_yz = cs * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
+  const size_t lds_x = a.x_group_lds * size_t(1024 / a.x_threads);
+  const size_t lds = lds_yz > lds_x ? lds_yz : lds_x;
+  MIPME_REQUIRE(!rh || rh->n_rows <= 0, "row riders are not implemented");
+  if (lds > 64 * 1024)
+    MIPME_CHECK_HIP(hipFuncSetAttribute((const void*)conv_persistent_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        int(kYzMaxLds)));
+  conv_persistent_kernel<T><<<a.n_conv, 1024, lds, st>>>(a);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
-                    void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part) {
+                    void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part, const RowRideHost* rh,
+                    void* err_flag) {
+  if (!cell_partials && G_stride == 0 && conv_persistent_ok(p)) {
+    if (p->dtype == MIPME_F32)
+      return convolve_persistent_t<float>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
+    return convolve_persistent_t<double>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
+  }
+  MIPME_REQUIRE(!rh || rh->n_rows <= 0, "row riders need the persistent convolution launch");
   if (!p->own_yz) {
     MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
     MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
@@ -1258,6 +1429,7 @@ int fft_plan_destroy(mipme_fft_plan* p) {
   if (p->inv2d) hipfftDestroy(p->inv2d);
   if (p->brick_count) (void)hipFree(p->brick_count);
   if (p->tail_scratch) (void)hipFree(p->tail_scratch);
+  if (p->conv_flags) (void)hipFree(p->conv_flags);
   delete p;
   return MIPME_OK;
 }
