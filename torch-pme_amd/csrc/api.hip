@@ -391,6 +391,10 @@ __global__ __launch_bounds__(256) void dot_backward_kernel(int64_t n, const T* _
 
 // Is g == s * q for one scalar s?  (the gradient (q * V).sum() sends back to V: energy mode of the backward passes.)
 // One workgroup: s = g[k] / q[k] at the k of the largest |q|, then max_i |g_i - s q_i| <= tol |s q_i|.  result = {s, 0 | 1}.
+// Both passes load kMatchUnroll elements per thread before touching any of them: a single workgroup has nothing else to hide
+// its memory latency behind (the first version, one dependent load per iteration, took 25 us for 32k values).
+static constexpr int kMatchUnroll = 8;
+
 template <typename T>
 __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* __restrict__ g, const T* __restrict__ q,
                                                             T* __restrict__ result, int* __restrict__ host_flag) {
@@ -398,11 +402,24 @@ __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* 
   __shared__ long long s_idx[16];
   __shared__ int s_bad[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t stride = blockDim.x;
   double best = -1.0;
   long long bi = 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const double v = fabs(double(q[i]));
-    if (v > best) { best = v; bi = i; }
+  for (int64_t base = threadIdx.x; base < n; base += stride * kMatchUnroll) {
+    T qv[kMatchUnroll];
+#pragma unroll
+    for (int u = 0; u < kMatchUnroll; ++u) {
+      const int64_t i = base + u * stride;
+      qv[u] = i < n ? q[i] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kMatchUnroll; ++u) {
+      const double v = fabs(double(qv[u]));
+      if (v > best) {
+        best = v;
+        bi = base + u * stride;
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -423,9 +440,19 @@ __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* 
   const double sd = double(scale);
   const double tol = 8.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
   int bad = (usable && isfinite(sd)) ? 0 : 1;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const double e = sd * double(q[i]);
-    if (!(fabs(double(g[i]) - e) <= tol * fabs(e))) bad = 1;
+  for (int64_t base = threadIdx.x; base < n; base += stride * kMatchUnroll) {
+    T qv[kMatchUnroll], gv[kMatchUnroll];
+#pragma unroll
+    for (int u = 0; u < kMatchUnroll; ++u) {
+      const int64_t i = base + u * stride;
+      qv[u] = i < n ? q[i] : T(0);
+      gv[u] = i < n ? g[i] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kMatchUnroll; ++u) {
+      const double e = sd * double(qv[u]);
+      if (!(fabs(double(gv[u]) - e) <= tol * fabs(e))) bad = 1;
+    }
   }
   bad = __any(bad) ? 1 : 0;
   if (lane == 0) s_bad[wave] = bad;
