@@ -182,26 +182,29 @@ def algorithmic_bytes(w, s: int, fused: bool = True):
 
     P, N, M = w.n_pairs, w.n_atoms, w.n_mesh**3
     eb = getattr(ops, "FUSED_ENTRY_BYTES", 8)
+    n = w.order
+    slot = 16 + 6 * n * s  # what the binning pass stores per atom: {mesh coordinates, index} + 6 n one-dimensional weights
+    halo = ((8 + n - 1) / 8) ** 3  # a gather workgroup stages the (8 + n - 1)^3 halo tile of its 8^3 brick
     per_kernel = {
         "pair_distance_forward": (P * (8 + 4 + s) if fused else P * (16 + 3 * s + s)) + N * 3 * s,
         "pair_distance_backward": P * (16 + 3 * s + s) + N * 6 * s,
         "rspace_forward": (2 * P * eb + P * s + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
         "rspace_backward": P * (16 + 2 * s) + N * 3 * s,
         # mesh stages (the meshes themselves are L2 / Infinity-Cache resident at these sizes)
-        "spread": N * 4 * s + 2 * M * s,
+        "spread": N * (slot + s) + M * s,
         # the spread and the fused distance + pair kernel co-scheduled in one launch (mipme_sr_job_t): both byte counts
-        "spread+rspace_forward": (2 * P * eb + P * s + N * 8 * s) + N * 4 * s + 2 * M * s,
-        "gather": N * 5 * s + M * s,
+        "spread+rspace_forward": (2 * P * eb + P * s + N * 8 * s) + N * (slot + s) + M * s,
+        "gather": N * (slot + 6 * s) + int(halo * M * s),
         # gather + energy + force assembly in one launch (the step's tail): also reads the pair force sums, writes field and forces
-        "gather+energy+forces": N * 14 * s + M * s,
-        "gather_grad": N * 8 * s + 2 * M * s,
+        "gather+energy+forces": N * (slot + 12 * s) + int(halo * M * s),
+        "gather_grad": N * (slot + 8 * s) + 2 * int(halo * M * s),
         "fft_r2c": 2 * M * s,
         "fft_c2r": 2 * M * s,
         "apply_filter": int(2.5 * M * s),
         # (y,z) plane transforms + one kernel for x-FFT * G * inverse x-FFT: the three stages above in one composite
         "convolve_xfused": int(6.5 * M * s),
         # one-pass binning: positions + charges in, record (16 B), 6 n weights and the (x, y, z, q) record out
-        "bin_atoms": N * (4 * s + 16 + 6 * w.order * s + 4 * s),
+        "bin_atoms": N * (4 * s + slot + 4 * s),
         # energy reduction E = sum q V, its adjoint, and the energy-mode force assembly gE q_a (f F_a + field_a)
         "energy_sum": N * 2 * s,
         "energy_sum_backward": N * 3 * s,
@@ -583,6 +586,14 @@ def main(argv=None):
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_kernel[dom],
                 "kernel_ms": kernels[dom],
+                # The dominant launch is the pair sum co-scheduled with the spread.  It is instruction-issue bound, not
+                # bandwidth bound (58 VALU instructions per pair entry, profiles/r02_*_sq_counters.txt): halving its entry
+                # stream (4-byte entries, this round) cut its bytes by 39 % and its time by 9 %, so `frac` fell while the
+                # kernel got faster.  For continuity with the previous round's line: the same launch time against the bytes
+                # of the 8-byte-entry format it replaced.
+                "note": "instruction-issue bound pair sum; bytes halved this round (4-byte entries)",
+                "frac_at_8_byte_entry_format": ((per_kernel[dom] + 2 * w.n_pairs * (8 - getattr(ops, "FUSED_ENTRY_BYTES", 8)))
+                                                / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if "rspace" in dom else None,
             },
             # whole step: bytes the kernels of this build move in their own formats (sum of the per-kernel figures below)
             # against the step time; SURVEY 8(d)'s figure for the reference's unfused formats is given for orientation only

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root:  bash tools/profile_final.sh <tag>
+# Everything profiles/ records for a round: kernel trace + FETCH_SIZE / WRITE_SIZE passes + one SQ-counter pass of the default
+# bench command, the counter calibration, and un-profiled bench lines of all BASELINE configurations, size sweep, frame probe.
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+bash tools/profile_gpu.sh ${TAG} --steps 200 --warmup 10
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+  -d $OUT/${TAG}_sq -o s -- python $ROOT/bench.py --no-cpu-baseline --no-drop-in --steps 5 --warmup 2 > /dev/null 2> $OUT/${TAG}_sq.err
+cd $ROOT
+python tools/rocpd_summary.py $(find $OUT/${TAG}_sq -name '*.db') > $OUT/${TAG}_sq_counters.txt
+rm -rf $OUT/${TAG}_sq
+bash tools/calib_gpu.sh ${TAG}
+python bench.py --steps 500 --warmup 20 > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+python bench.py --preset cfg2 --steps 300 --warmup 20 --no-drop-in > $OUT/${TAG}_bench_ionic_cfg2.json 2>> $OUT/${TAG}_bench_default.err
+python bench.py --preset cfg4 --steps 200 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_bench_cfg4_8frames_1gpu.json 2>> $OUT/${TAG}_bench_default.err
+python bench.py --preset cfg4 --frame-batch streams --steps 200 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_bench_cfg4_streams.json 2>> $OUT/${TAG}_bench_default.err
+python bench.py --preset cfg5 --steps 100 --warmup 10 --no-drop-in > $OUT/${TAG}_bench_dispersion_cfg5.json 2>> $OUT/${TAG}_bench_default.err
+python bench.py --launch eager --steps 200 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_bench_eager.json 2>> $OUT/${TAG}_bench_default.err
+python tools/size_sweep.py > $OUT/${TAG}_size_sweep.txt 2>&1
+python tools/frames_probe.py > $OUT/${TAG}_frames_probe.txt 2>&1
+python tools/time_stress.py > $OUT/${TAG}_stress.txt 2>&1
+ls -la $OUT | grep ${TAG}
