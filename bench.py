@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --preset cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
+    ap.add_argument("--store-distances", action="store_true",
+                    help="also store the pair distances the fused pair kernel forms (a by-product nobody reads in an energy + "
+                         "forces step; off: they stay in registers)")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
     # test hook (tests/test_bench_launch.py): the launch / rendezvous / timing / reporting path on CPU ranks with the gloo
@@ -106,10 +109,11 @@ def make_workload(name: str, seed_offset: int):
 class Frame:
     """Device-resident inputs of one frame + its calculator."""
 
-    def __init__(self, w, device):
+    def __init__(self, w, device, store_distances: bool = False):
         import torchpme_amd as tpa
 
         self.w = w
+        self.store_distances = store_distances
         dt = torch.float32 if w.dtype == "f32" else torch.float64
         self.dtype = dt
         self.pos = torch.tensor(w.positions, dtype=dt, device=device, requires_grad=True)
@@ -125,13 +129,14 @@ class Frame:
         self._tpa = tpa
 
     def step(self):
-        """The package's fast eager form of the step (deferred distances + weighted_sum)."""
+        """The package's fast eager form of the step (distances formed inside the pair kernel + weighted_sum)."""
         tpa = self._tpa
         self.pos.grad = None
-        # deferred: the distance tensor is written by the calculator's fused distance + pair kernel (by-product of the row that
-        # owns a pair's first atom) instead of by a separate pass over the pair list -- same tensor, one kernel less
-        d = tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts, deferred=True)
-        self.distances = d.detach()
+        # "virtual": the distance tensor only connects the calculator to the positions in the autograd graph -- the fused
+        # distance + pair kernel forms the distances in registers and nothing stores them (store_distances: by-product write)
+        d = tpa.pair_distances(self.pos, self.pairs, self.cell, self.shifts,
+                               deferred=True if self.store_distances else "virtual")
+        self.distances = d.detach() if self.store_distances else None
         # the backward pass below is seeded with minus_one: promised to the forward, whose gather then writes the forces
         with tpa.ops.seed_promise(self.minus_one):
             V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
@@ -171,7 +176,7 @@ class StubFrame:
         return (self.x * self.x).sum(), None
 
 
-def algorithmic_bytes(w, s: int, fused: bool = True):
+def algorithmic_bytes(w, s: int, fused: bool = True, store_distances: bool = False):
     """Minimum HBM bytes per energy+forces step (reference data formats) and per kernel launch.
 
     Per kernel the figure is what the launch must move IN THE FORMAT IT READS, never more than SURVEY's figure for the
@@ -182,18 +187,19 @@ def algorithmic_bytes(w, s: int, fused: bool = True):
 
     P, N, M = w.n_pairs, w.n_atoms, w.n_mesh**3
     eb = getattr(ops, "FUSED_ENTRY_BYTES", 8)
+    dw = P * s if store_distances else 0  # the distance by-product of the fused pair kernel, when somebody wants it
     n = w.order
     slot = 16 + 6 * n * s  # what the binning pass stores per atom: {mesh coordinates, index} + 6 n one-dimensional weights
     halo = ((8 + n - 1) / 8) ** 3  # a gather workgroup stages the (8 + n - 1)^3 halo tile of its 8^3 brick
     per_kernel = {
         "pair_distance_forward": (P * (8 + 4 + s) if fused else P * (16 + 3 * s + s)) + N * 3 * s,
         "pair_distance_backward": P * (16 + 3 * s + s) + N * 6 * s,
-        "rspace_forward": (2 * P * eb + P * s + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
+        "rspace_forward": (2 * P * eb + dw + N * 8 * s) if fused else (P * (16 + s) + N * 2 * s),
         "rspace_backward": P * (16 + 2 * s) + N * 3 * s,
         # mesh stages (the meshes themselves are L2 / Infinity-Cache resident at these sizes)
         "spread": N * (slot + s) + M * s,
         # the spread and the fused distance + pair kernel co-scheduled in one launch (mipme_sr_job_t): both byte counts
-        "spread+rspace_forward": (2 * P * eb + P * s + N * 8 * s) + N * (slot + s) + M * s,
+        "spread+rspace_forward": (2 * P * eb + dw + N * 8 * s) + N * (slot + s) + M * s,
         "gather": N * (slot + 6 * s) + int(halo * M * s),
         # gather + energy + force assembly in one launch (the step's tail): also reads the pair force sums, writes field and forces
         "gather+energy+forces": N * (slot + 12 * s) + int(halo * M * s),
@@ -382,7 +388,7 @@ def main(argv=None):
         import torchpme_amd as tpa
         from torchpme_amd import ops
 
-        frames = [Frame(make_workload(args.workload, rank * n_frames + f), device) for f in range(n_frames)]
+        frames = [Frame(make_workload(args.workload, rank * n_frames + f), device, args.store_distances) for f in range(n_frames)]
     frame, w = frames[0], frames[0].w
     s = 4 if w.dtype == "f32" else 8
     # the farm's ONE exchange: after its last frame evaluation every rank contributes its frame energies
@@ -512,7 +518,9 @@ def main(argv=None):
         w64.dtype = "f64"
         f64 = Frame(w64, device)
         E64, F64 = f64.step()
+        frame.store_distances = True  # this one evaluation also stores the distance by-product of the pair kernel
         E32, F32 = frame.step()
+        frame.store_distances = args.store_distances
         accuracy = {
             "reference": "same HIP path in fp64 (parity with torch-pme fp64 <= 1e-12, tests/test_gpu_parity.py)",
             "rel_energy_error": abs(float(E32) - float(E64)) / abs(float(E64)),
@@ -525,7 +533,7 @@ def main(argv=None):
         del f64
 
     if rank == 0:
-        step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES)
+        step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES, store_distances=args.store_distances)
         kernels = {k: v for k, v in prof.items() if k in per_kernel}
         kernels.update({k: v for k, v in stages.items() if k in per_kernel})
         # dominant kernel = the longest single launch (an HBM-streaming pair kernel at these sizes); the per-kernel

@@ -121,14 +121,18 @@ def test_cfg3_forces_against_oracle(water):
             E, F = box.energy_forces(general=general)
             assert abs(E - Eo) < tol_e * abs(Eo), (dtype, general)
             assert rel(F.cpu().double(), Fo_t) < tol_f, (dtype, general)
-        step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts)
-        for _ in range(2):  # the second replay must reproduce the first
-            Eg, Fg = step()
-            assert abs(float(Eg) - Eo) < tol_e * abs(Eo), dtype
-            assert rel(Fg.cpu().double(), Fo_t) < tol_f, dtype
-        # the distances the step produced as a by-product of its pair kernel
-        dtol = 1e-13 if dtype == torch.float64 else 1e-5
-        assert float(((step.distances.cpu().double() - torch.tensor(dist_o)).abs() / torch.tensor(dist_o)).max()) < dtol
+        for store in (False, True):  # default: distances stay in registers (fp32: the packed pair body); True: by-product
+            step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts, store_distances=store)
+            for _ in range(2):  # the second replay must reproduce the first
+                Eg, Fg = step()
+                assert abs(float(Eg) - Eo) < tol_e * abs(Eo), (dtype, store)
+                assert rel(Fg.cpu().double(), Fo_t) < tol_f, (dtype, store)
+            if not store:
+                assert step.distances is None
+                continue
+            # the distances the step produced as a by-product of its pair kernel
+            dtol = 1e-13 if dtype == torch.float64 else 1e-5
+            assert float(((step.distances.cpu().double() - torch.tensor(dist_o)).abs() / torch.tensor(dist_o)).max()) < dtol
 
 
 def test_cfg4_one_gpu_share_against_oracle():
@@ -137,7 +141,8 @@ def test_cfg4_one_gpu_share_against_oracle():
     ``bench.py --preset cfg4`` times -- with the energy, forces and distances of EVERY frame checked against the oracle."""
     ws = [workloads.ionic_box(seed=100 + f) for f in range(8)]
     boxes = [Box(w, torch.float64) for w in ws]
-    batch = tpa.GraphedFrameBatch(boxes[0].calc, [(b.q, b.cell, b.pos, b.pairs, b.shifts) for b in boxes])
+    batch = tpa.GraphedFrameBatch(boxes[0].calc, [(b.q, b.cell, b.pos, b.pairs, b.shifts) for b in boxes],
+                                  store_distances=True)
     for replay in range(2):
         energies, forces = batch()
         torch.cuda.synchronize()

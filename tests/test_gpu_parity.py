@@ -333,7 +333,7 @@ def test_graphed_energy_forces(golden_dir):
     t = lambda a, dt=torch.float64: torch.tensor(a, device=DEV, dtype=dt)  # noqa: E731
     pos, cell, q = t(z["positions"]), t(z["cell"]), t(z["charges"])
     pairs, S = torch.tensor(z["pairs"], device=DEV), t(z["shifts"])
-    step = tpa.GraphedEnergyForces(calc, q, cell, pos + 0.01, pairs, S)
+    step = tpa.GraphedEnergyForces(calc, q, cell, pos + 0.01, pairs, S, store_distances=True)
     eref = float(z["p3m5/f64/energy"])
     E, F = step(pos)  # (E, F) are the graph's static output buffers: read them before the next replay
     e1 = E.item()
@@ -906,8 +906,8 @@ def test_frames_in_one_launch(dtype, full, kind):
         pairs, S, _ = tpa.neighbor_list(pos, cell, 3.5, full_list=full)
         t = lambda a, dt=dtype: torch.tensor(a, device=DEV, dtype=dt)  # noqa: E731
         frames.append((t(q), t(cell), t(pos), torch.tensor(pairs, device=DEV), t(S)))
-    batch = tpa.GraphedFrameBatch(calc, frames)
-    singles = [tpa.GraphedEnergyForces(calc, *(f[0], f[1], f[2], f[3], f[4])) for f in frames]
+    batch = tpa.GraphedFrameBatch(calc, frames, store_distances=True)
+    singles = [tpa.GraphedEnergyForces(calc, *(f[0], f[1], f[2], f[3], f[4]), store_distances=True) for f in frames]
     tol = 1e-11 if dtype == torch.float64 else 2e-5
     for shift in (0.0, 0.02):
         new = [f[2] + shift for f in frames]

@@ -479,3 +479,53 @@ def test_fused_path_input_variants():
         V, g = run(pos, pairs, shifts)
         torch.testing.assert_close(V, ref_V, rtol=1e-12, atol=1e-13, msg=name)
         torch.testing.assert_close(g, ref_g, rtol=1e-11, atol=1e-12, msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_virtual_distances(dtype):
+    """``pair_distances(..., deferred="virtual")``: the tensor only carries provenance and autograd connectivity -- a calculator
+    that fuses the distances into its pair kernel does not store them (fp32: the packed pair body runs), values and gradients
+    equal those of the ordinary helper; a calculator call that needs the values in memory (several charge channels) writes
+    them first."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    L, N = 14.0, 600
+    cell = np.array([[L, 0, 0], [0.1 * L, L, 0], [0, -0.05 * L, L]])
+    pos = rng.uniform(0, L, (N, 3))
+    q = rng.normal(size=(N, 1))
+    pairs, S, _ = tpa.neighbor_list(pos, cell, 4.5)
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    tq, tc, ti, tS = t(q), t(cell), torch.tensor(pairs, device=DEV), t(S)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.2), mesh_spacing=0.45, interpolation_nodes=4).to(dtype)
+    res = {}
+    for mode in (False, True, "virtual"):
+        tp = t(pos).requires_grad_(True)
+        tcell = tc.clone().requires_grad_(True)
+        d = tpa.pair_distances(tp, ti, tcell, tS, deferred=mode)
+        V = calc(tq, tcell, tp, ti, d)
+        E = tpa.weighted_sum(V, tq)
+        E.backward()
+        res[mode] = (V.detach().cpu(), tp.grad.cpu(), tcell.grad.cpu(), d)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for mode in (True, "virtual"):
+        for a, b in zip(res[mode][:3], res[False][:3]):
+            assert float((a - b).norm() / b.norm()) < tol, mode
+    assert res["virtual"][3]._mipme_src.pending  # never written ...
+    assert not res[True][3]._mipme_src.pending
+    # ... until a consumer needs the values in memory: two charge channels take the unfused pair kernels
+    tp = t(pos).requires_grad_(True)
+    d = tpa.pair_distances(tp, ti, tc, tS, deferred="virtual")
+    V2 = calc(torch.cat([tq, 0.5 * tq], dim=1), tc, tp, ti, d)
+    assert not d._mipme_src.pending
+    assert float((V2[:, 0].detach().cpu() - res[False][0][:, 0]).norm() / res[False][0].norm()) < tol
+    assert float((d.detach() - res[False][3].detach()).abs().max()) < (1e-12 if dtype == torch.float64 else 1e-5)
+    # a pair mask is handled inside the fused kernel: same potentials, still nothing stored
+    tp = t(pos).requires_grad_(True)
+    d = tpa.pair_distances(tp, ti, tc, tS, deferred="virtual")
+    mask = torch.ones((ti.shape[0],), dtype=torch.bool, device=DEV)
+    Vm = calc(tq, tc, tp, ti, d, pair_mask=mask)
+    assert float((Vm.detach().cpu() - res[False][0]).norm() / res[False][0].norm()) < tol
+    with pytest.raises(ValueError, match="deferred"):
+        tpa.pair_distances(tp, ti, tc, tS, deferred="lazy")

@@ -508,12 +508,41 @@ __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs
 // and the remaining ones are row workgroups of the VALU-bound pair sum, which fill those issue slots.  The two parts are
 // independent (the pair sum reads the atom records that the binning pass emitted, not the mesh); the gather adds the mesh
 // part to the potentials the pair sum wrote.
+#ifdef MIPME_WG_TIMELINE  // measurement builds only (tools/wg_timeline.py): when and where every workgroup of the launch ran
+__device__ long long g_wg_timeline[4 * 16384];
+#define MIPME_WG_STAMP(k)                                                                                   \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
+      g_wg_timeline[blockIdx.x * 4 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();                    \
+      if ((k) == 0) { /* HW_ID (all 32 bits) and XCC_ID (4 bits) */                                         \
+        g_wg_timeline[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);           \
+        g_wg_timeline[blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);           \
+      }                                                                                                     \
+    }                                                                                                       \
+  } while (0)
+#else
+#define MIPME_WG_STAMP(k)
+#endif
+
 template <int N, typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread) {
+  MIPME_WG_STAMP(0);
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(sa, blockIdx.x);
-  else
-    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread);
+  else {
+    bool done = false;
+    if constexpr (COMPACT && std::is_same<T, float>::value) {
+      if (!ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
+        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, blockIdx.x - n_spread);
+        done = true;
+      }
+    }
+    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread);
+  }
+#ifdef MIPME_WG_TIMELINE
+  __syncthreads();
+#endif
+  MIPME_WG_STAMP(1);
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -1139,8 +1168,15 @@ __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(cons
   const unsigned n_spread = unsigned(f.bg.nb);
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(f.spread, blockIdx.x);
-  else if (blockIdx.x - n_spread < f.n_row_blocks)
+  else if (blockIdx.x - n_spread < f.n_row_blocks) {
+    if constexpr (COMPACT && std::is_same<T, float>::value) {
+      if (!f.rows.dist_out) {
+        sr_rows_pk_body<PFAST, SPREAD_THREADS>(f.rows, blockIdx.x - n_spread);
+        return;
+      }
+    }
     sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread);
+  }
 }
 
 template <int N, typename T>
@@ -1432,3 +1468,9 @@ int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_fra
 }
 
 }  // extern "C"
+
+#ifdef MIPME_WG_TIMELINE
+extern "C" int mipme_debug_wg_timeline(void* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mipme::g_wg_timeline), size_t(n_words) * 8);
+}
+#endif

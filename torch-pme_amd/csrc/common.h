@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 
 #include "../../include/mipme.h"
@@ -233,6 +234,12 @@ struct RowRideHost {
 
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position
 // and charge (or source value).  Written by pack_atom_records_kernel (topology.hip) or by the binning pass (bricks.hip).
+// boolean switch from the environment ("0" = off, anything else = on), for A/B measurements of kernel variants
+inline bool env_flag(const char* name, bool dflt) {
+  const char* e = getenv(name);
+  return e ? (e[0] != '0') : dflt;
+}
+
 template <typename T>
 struct alignas(4 * sizeof(T)) AtomRecord {
   T x, y, z, w;

@@ -4,6 +4,8 @@
 // the VALU-bound pair sum share the CUs.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 #include "srpot.h"
 
@@ -357,6 +359,194 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
       for (int w = 0; w < BS / 64; ++w) v += red[w][threadIdx.x];
       partials[int64_t(block) * 9 + threadIdx.x] = v;
     }
+  }
+}
+
+// ---- packed fp32 body of the potential + force pass -------------------------------------------------------------------
+// The row kernels are bound by VALU issue (profiles/r02_g_sq_counters.txt), so this body, used for the one case that carries
+// the headline workloads -- float, kPotForce, 4-byte entries, no mask / cell gradient / distance by-product --, is written for
+// the instruction count rather than for generality:
+//  * the two entries a lane has in flight are evaluated as ONE 2-vector, so the whole scalar chain of fast_rs_eval (the erfc
+//    polynomial, the powers of 1/d, the final products) issues as v_pk_{mul,add,fma}_f32 -- two entries per instruction --,
+//    and within an entry (x, y) travel as a pair (z alone); only rsq / exp2 / rcp remain one per entry;
+//  * entry words and partner records are fetched with buffer loads (32-bit offsets into a resource: no 64-bit address
+//    arithmetic per entry, and reads past the end of the stream return 0 = atom 0, code 0, so the prefetch needs no clamp);
+//  * invalid lanes (row tail) are neutralised by two selects (d^2 := 1, weight := 0) instead of clamped addresses.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2v pk_rsq(f2v x) { return f2v{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+__device__ __forceinline__ f2v pk_rcp(f2v x) { return f2v{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ f2v pk_exp2(f2v x) { return f2v{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+
+// fast_rs_eval for two distances at once (same formulas, same coefficients; see there)
+template <int P>
+__device__ __forceinline__ void fast_rs_eval_pk(float inv_2s2, float c1, float pref, f2v d2, f2v& v, f2v& dvd) {
+  const f2v inv = pk_rsq(d2);
+  const f2v inv2 = inv * inv;
+  const f2v e = pk_exp2(d2 * (-1.4426950408889634f * inv_2s2));
+  f2v Q, two_x_dens;
+  if constexpr (P % 2 == 0) {
+    const f2v x = d2 * inv_2s2;
+    f2v term = f2v{1.f, 1.f}, sum = f2v{1.f, 1.f};
+#pragma unroll
+    for (int k = 1; k < P / 2; ++k) {
+      term *= x * float(1.0 / k);
+      sum += term;
+    }
+    Q = e * sum;
+    two_x_dens = 2.f * x * e * term;
+  } else {
+    constexpr int m = (P - 1) / 2;
+    const f2v d = d2 * inv;
+    const f2v y = c1 * d;
+    const f2v t = pk_rcp(1.0f + 0.4f * y);
+    f2v p = 2.646481385e-02f * t + -6.557867191e-02f;
+    p = p * t + -7.738398321e-02f;
+    p = p * t + 2.820383187e-01f;
+    p = p * t + -6.220284696e-02f;
+    p = p * t + 2.579626189e-01f;
+    p = p * t + 1.840778096e-01f;
+    p = p * t + 2.291638826e-01f;
+    p = p * t + 2.254580744e-01f;
+    Q = (e * t) * p;
+    f2v term = (float(2.0 * 0.56418958354775628695) * c1) * d * e;  // term_1
+    if constexpr (m > 0) {
+      const f2v x = d2 * inv_2s2;
+#pragma unroll
+      for (int k = 1; k <= m; ++k) {
+        Q += term;
+        term *= x * float(1.0 / (k + 0.5));
+      }
+    }
+    two_x_dens = float(2 * m + 1) * term;
+  }
+  f2v invp = inv;
+#pragma unroll
+  for (int k = 1; k < P; ++k) invp *= inv;
+  const f2v pi = pref * invp;
+  v = pi * Q;
+  dvd = -(pi * inv2) * (two_x_dens + float(P) * Q);
+}
+
+// Raw buffer loads through the LLVM intrinsics (the __builtin_amdgcn_raw_buffer_load_b128 of this compiler lowers to a
+// one-dword load).  Resource over [base, base + bytes): stride 0, DATA_FORMAT = 32 bit -- the word composable_kernel uses for
+// gfx90a / gfx94x / gfx950; out-of-range reads return 0.
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ f4v llvm_raw_buffer_load_f4(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ int llvm_raw_buffer_load_i1(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return i4v{int(unsigned(a)), int(unsigned(a >> 32) & 0xffffu), int(bytes), 0x00020000};
+}
+
+template <int PFAST, int BS>
+__device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block) {
+  static_assert(kRowLanes == 16, "the packed body walks 2 x 16 entries per row and iteration");
+  const int64_t N = args.N;
+  const int* __restrict__ row_ptr = args.row_ptr;
+  const float* __restrict__ pos = args.pos;
+  const float* __restrict__ cell = args.cell;
+  float* __restrict__ out = args.out;
+  float* __restrict__ force = args.force;
+  const float c_inv2s2 = float(args.cf.inv_2s2), c1 = float(args.cf.c1), cpref = float(args.cf.pref);
+  // The dependent chain of a row -- row_ptr -> entry words -> partner records -> arithmetic -- is a large part of a row
+  // workgroup's lifetime (tools/wg_timeline.py: 9-14 us for 2.8 us of arithmetic), so the loads are issued as early as their
+  // addresses exist: row bounds and own position first, the shift table is built while they are in flight (moving these loads
+  // behind the table's barrier costs 3 us per launch), and the loop keeps the entry words two iterations and the partner
+  // records one iteration ahead of the arithmetic.
+  const int sub = threadIdx.x % kRowLanes;
+  unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = unsigned(N - 1);
+  const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
+  const int n_entries = row_ptr[2 * N];
+  const f2v axy = f2v{pos[3 * a], pos[3 * a + 1]};
+  const float az = pos[3 * a + 2];
+  const float qa = args.q[a];
+  __shared__ AtomRecord<float> shift_tab[kShiftTableSize];
+  {
+    float A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : 0.f;
+    for (int k = threadIdx.x; k < kShiftTableSize; k += BS) {
+      const float sx = float(k % kShiftTableBase - kShiftTableRange),
+                  sy = float((k / kShiftTableBase) % kShiftTableBase - kShiftTableRange),
+                  sz = float(k / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
+      shift_tab[k] = AtomRecord<float>{sx * A[0] + sy * A[3] + sz * A[6], sx * A[1] + sy * A[4] + sz * A[7],
+                                       sx * A[2] + sy * A[5] + sz * A[8], 0.f};
+    }
+  }
+  const int pot_end = args.full ? mid : 0x7fffffff;  // a full list feeds the potential from role i only
+  const int beg = r0, end = valid ? r2 : r0;
+  const i4v ent_rs = raw_buffer(args.ent_sh, unsigned(n_entries) * 4u);
+  const i4v rec_rs = raw_buffer(args.rec, unsigned(N) * 16u);
+  constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
+  int off = (beg + sub) * 4;  // byte offset of this lane's first entry of the iteration
+  // entry words of iterations 0 and 1 (sets 0 and 1), partner records of iteration 0
+  unsigned wA0 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
+  unsigned wB0 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+  unsigned wA1 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 8 * kRowLanes, 0, 0));
+  unsigned wB1 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 12 * kRowLanes, 0, 0));
+  f4v rA0 = llvm_raw_buffer_load_f4(rec_rs, int((wA0 & kAtomMask) << 4), 0, 0);
+  f4v rB0 = llvm_raw_buffer_load_f4(rec_rs, int((wB0 & kAtomMask) << 4), 0, 0);
+  f4v rA1, rB1;
+  __syncthreads();  // shift table
+  f2v pot2 = f2v{0.f, 0.f}, fxy = f2v{0.f, 0.f};
+  float fz = 0.f;
+  // one iteration: arithmetic on the records of set `c` (loaded one iteration ago) while the records of the next iteration
+  // (set `n`, words loaded one iteration ago) and the words of the one after (into set `c`) are fetched.  The loop alternates
+  // the two sets explicitly, so that no register moves (and no waits for them) sit on the back edge.
+  auto iteration = [&](int eA, f4v& cRA, f4v& cRB, unsigned& cWA, unsigned& cWB, f4v& nRA, f4v& nRB, const unsigned nWA,
+                       const unsigned nWB) {
+    const int eB = eA + kRowLanes;
+    const AtomRecord<float> sA = shift_tab[cWA >> kCompactAtomBits], sB = shift_tab[cWB >> kCompactAtomBits];
+    nRA = llvm_raw_buffer_load_f4(rec_rs, int((nWA & kAtomMask) << 4), 0, 0);
+    nRB = llvm_raw_buffer_load_f4(rec_rs, int((nWB & kAtomMask) << 4), 0, 0);
+    off += 8 * kRowLanes;
+    cWA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 8 * kRowLanes, 0, 0));
+    cWB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 12 * kRowLanes, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here (the scheduler sinks them to their first use otherwise)
+    const bool okA = eA < end, okB = eB < end;
+    const f2v vA = (f2v{cRA.x, cRA.y} - axy) + f2v{sA.x, sA.y};
+    const f2v vB = (f2v{cRB.x, cRB.y} - axy) + f2v{sB.x, sB.y};
+    const float zA = (cRA.z - az) + sA.z, zB = (cRB.z - az) + sB.z;
+    const f2v sqA = vA * vA, sqB = vB * vB;
+    const float dA = (sqA.x + sqA.y) + zA * zA, dB = (sqB.x + sqB.y) + zB * zB;
+    const f2v d2 = f2v{okA ? dA : 1.f, okB ? dB : 1.f};
+    const f2v sv = f2v{okA ? cRA.w : 0.f, okB ? cRB.w : 0.f};
+    f2v v, dvd;
+    fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
+    pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
+    const f2v sc = sv * dvd;
+    fxy -= sc.x * vA;
+    fz -= sc.x * zA;
+    fxy -= sc.y * vB;
+    fz -= sc.y * zB;
+  };
+  for (int eA = beg + sub; eA - sub < end; eA += 4 * kRowLanes) {
+    iteration(eA, rA0, rB0, wA0, wB0, rA1, rB1, wA1, wB1);
+    if (eA + 2 * kRowLanes - sub >= end) break;
+    iteration(eA + 2 * kRowLanes, rA1, rB1, wA1, wB1, rA0, rB0, wA0, wB0);
+  }
+  const float pot = row_sum(pot2.x + pot2.y);
+  if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.f) + 0.5f * pot;
+  if (args.epart) {  // see the generic body
+    const bool mine = sub == 0 && valid;
+    const float e1 = wave_sum(mine ? qa * (0.5f * pot) : 0.f);
+    const float e2 = wave_sum(mine ? qa * qa : 0.f);
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
+      args.epart[2 * w] = double(e1);
+      args.epart[2 * w + 1] = double(e2);
+    }
+  }
+  const float fx = row_sum(fxy.x), fy = row_sum(fxy.y);
+  fz = row_sum(fz);
+  if (sub == 0 && valid) {
+    force[3 * a] = fx;
+    force[3 * a + 1] = fy;
+    force[3 * a + 2] = fz;
   }
 }
 

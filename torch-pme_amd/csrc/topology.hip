@@ -384,6 +384,16 @@ __global__ __launch_bounds__(256) void sr_fused_rows_kernel(FusedRowsArgs<T> a) 
   sr_fused_rows_body<T, MODE, CELLGRAD, PFAST, MASK, TABLE, 256>(a, blockIdx.x);
 }
 
+// 4-byte entry stream (kShiftTable32), potential + force sums: the generic body (distance by-product) and the packed one
+template <typename T, int PFAST>
+__global__ __launch_bounds__(256) void sr_fused_rows_compact_kernel(FusedRowsArgs<T> a) {
+  sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, 256, 0, true>(a, blockIdx.x);
+}
+template <int PFAST>
+__global__ __launch_bounds__(256) void sr_rows_pk_kernel(FusedRowsArgs<float> a) {
+  sr_rows_pk_body<PFAST, 256>(a, blockIdx.x);
+}
+
 // energy mode: grad_pos[a] = gE q[a] (f F[a] + field[a]), grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list;
 // field = the mesh part from the forward gather, nullable, as is force)
 template <typename T>
@@ -510,8 +520,9 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   const unsigned grid = row_blocks(N);
   const FastRS cf = make_fast_rs(s);
   const int pfast = fast_rs_exponent(s);
-  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable, "invalid shift format %d", shift_format);
-  MIPME_REQUIRE(!(mask && shift_format == kShiftTable), "a pair mask needs entries packed in the int8 shift format");
+  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable || shift_format == kShiftTable32,
+                "invalid shift format %d", shift_format);
+  MIPME_REQUIRE(!(mask && shift_format != kShiftPacked), "a pair mask needs entries packed in the int8 shift format");
   if (!records_ready) {
     pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
         N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
@@ -532,6 +543,27 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   }
   const FusedRowsArgs<T> args = make_fused_rows_args<T>(s, cf, N, row_ptr, ent_sh, entries, mask, pos, records, cell, q, g, lo, hi,
                                                         full_list, accumulate, out, force, partials, dist_out);
+  if (shift_format == kShiftTable32) {
+    MIPME_REQUIRE(mode == kPotForce && !want_cg && pfast > 0 && N <= kCompactMaxAtoms,
+                  "4-byte entries serve the potential + force pass of the Coulomb / dispersion fast paths only");
+    static const bool packed_ok = env_flag("MIPME_ROWS_PK", true);
+    if constexpr (std::is_same<T, float>::value) {
+      if (!dist_out && packed_ok) {
+        if (pfast == 1)
+          sr_rows_pk_kernel<1><<<grid, 256, 0, st>>>(args);
+        else
+          sr_rows_pk_kernel<6><<<grid, 256, 0, st>>>(args);
+        MIPME_LAUNCH_CHECK();
+        return MIPME_OK;
+      }
+    }
+    if (pfast == 1)
+      sr_fused_rows_compact_kernel<T, 1><<<grid, 256, 0, st>>>(args);
+    else
+      sr_fused_rows_compact_kernel<T, 6><<<grid, 256, 0, st>>>(args);
+    MIPME_LAUNCH_CHECK();
+    return MIPME_OK;
+  }
 #define MIPME_FUSED_LAUNCH_(MODE, CG, CF, MK, TB) sr_fused_rows_kernel<T, MODE, CG, CF, MK, TB><<<grid, 256, 0, st>>>(args)
 #define MIPME_FUSED_MK(MODE, CG, CF)                                                                                  \
   do {                                                                                                                \

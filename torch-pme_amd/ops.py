@@ -332,9 +332,9 @@ class PairTopology:
 class DistanceSource:
     """Provenance of a distance tensor made by :func:`pair_distances` (attached to it as ``_mipme_src``)."""
 
-    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref", "pending", "direct")
+    __slots__ = ("positions", "cell", "pairs", "shifts", "shifts_key", "versions", "dist_ref", "pending", "direct", "virtual")
 
-    def __init__(self, positions, cell, pairs, shifts, shifts_key, dist, pending=False):
+    def __init__(self, positions, cell, pairs, shifts, shifts_key, dist, pending=False, virtual=False):
         self.positions, self.cell, self.pairs, self.shifts, self.shifts_key = positions, cell, pairs, shifts, shifts_key
         self.versions = (positions._version, None if cell is None else cell._version, pairs._version, dist._version)
         self.dist_ref = weakref.ref(dist)
@@ -346,6 +346,9 @@ class DistanceSource:
         #: True (``pair_distances(..., deferred=True)``: explicit opt-in) -- straight to ``positions`` / ``cell``; the
         #: distance tensor is then NOT part of the result's autograd graph.
         self.direct = pending
+        #: True (``deferred="virtual"``): a calculator that forms the distances inside its fused pair kernel does NOT store them
+        #: either -- the tensor stays unwritten (``pending``) until some consumer that needs the values calls materialize()
+        self.virtual = bool(virtual) and pending
 
     def materialize(self) -> None:
         """Write the values of a deferred distance tensor with the stand-alone distance kernel (for consumers other than
@@ -497,9 +500,12 @@ class _PMEFunction(torch.autograd.Function):
             # deferred distances (``pair_distances(..., deferred=True)``): the fused kernel writes them as a by-product
             write_dist = False
             if src is not None and src.pending:
-                write_dist = fused is not None and mask is None and P > 0 and topo.sorted_by_first
-                if not write_dist:
-                    src.materialize()
+                if src.virtual and fused is not None:
+                    pass  # nobody reads the values: the fused kernel forms the distances in registers and drops them
+                else:
+                    write_dist = fused is not None and mask is None and P > 0 and topo.sorted_by_first
+                    if not write_dist:
+                        src.materialize()
 
             def run_rspace(accumulate):
                 stream = _lib.current_stream(device)
@@ -1022,7 +1028,7 @@ class _PairDistances(torch.autograd.Function):
         return (grad_pos if ctx.needs_input_grad[0] else None), grad_cell, None, None, None
 
 
-def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None, deferred: bool = False):
+def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None, deferred: bool | str = False):
     """``d[p] = |r_j - r_i + S_p @ cell|``, differentiable w.r.t. ``positions`` and ``cell``.
 
     Counterpart of the reference's caller-side helper ``compute_distances``
@@ -1032,7 +1038,13 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None,
     it: its values are then written by the calculator's fused distance + pair kernel (the row that owns a pair's first
     atom stores ``d[p]``) instead of by a separate pass over the list; a calculator call that cannot do so (pair mask,
     non-integer shifts, list not ordered by its first index, ...) runs the stand-alone kernel first.  The values, the
-    autograd graph and the result of the calculator are the same either way."""
+    autograd graph and the result of the calculator are the same either way.
+
+    ``deferred="virtual"`` is the stronger promise that NOTHING but calculators of this package ever reads the tensor: it
+    connects the calculator to ``positions`` / ``cell`` in the autograd graph and carries the provenance, but a calculator
+    whose fused kernel forms the distances in registers no longer stores them (19 MB per step at 4.76 M pairs, and the
+    branch around the store); calculators that need the values in memory still write them first.  Its contents are
+    otherwise undefined -- use it for the internal distance tensor of an energy + forces step, not for one you look at."""
     if torch.compiler.is_compiling():  # one dispatcher op inside torch.compile (library.py); nothing to defer there
         return torch.ops.mipme.pair_distances(positions, neighbor_indices, cell, neighbor_shifts)
     return _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, deferred)
@@ -1045,12 +1057,15 @@ def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, de
     if cell is None and neighbor_shifts is not None:
         raise ValueError("Provided `neighbor_shifts` but no `cell`.")
     _lib.require_device(positions, "positions")
+    if deferred not in (True, False, "virtual"):
+        raise ValueError(f"`deferred` must be True, False or 'virtual', got {deferred!r}")
     dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts, bool(deferred))
     if neighbor_shifts is None or neighbor_shifts.dtype == positions.dtype:
         shifts_c = neighbor_shifts
     else:
         shifts_c = neighbor_shifts.to(positions.dtype)
-    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, bool(deferred))
+    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, bool(deferred),
+                                     virtual=deferred == "virtual")
     return dist
 
 
