@@ -305,9 +305,10 @@ static constexpr int SPREAD_CPT = 6;                              // candidates 
 static constexpr int SPREAD_ROUND = 28 * SPREAD_GROUP * SPREAD_CPT;  // candidates per round = capacity of the survivor lists (27 bricks + overflow)
 static constexpr size_t SPREAD_LDS_MAX = 64 * 1024;
 
+static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize, "the shift table of a row workgroup (4 reals per code) lives in the staging region");
 static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows) {
   const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
-  return real_bytes * region + sizeof(int) * (2 * SPREAD_ROUND + 2);
+  return real_bytes * region + sizeof(int) * (SPREAD_ROUND + 2) + sizeof(unsigned short) * SPREAD_ROUND;
 }
 static inline int spread_stage_rows(int order, size_t real_bytes) {
   for (int rows : {256, 128})
@@ -352,10 +353,12 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
-  int* srel = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND] packed rel
-  int* sidx = srel + SPREAD_ROUND;                          // [SPREAD_ROUND] sorted atom index
+  // survivors of a round: slot index (int) and stencil start relative to the brick (3 x 4 signed bits in a uint16 -- the
+  // launch's LDS caps the workgroups per CU of the co-scheduled launch, rows included: 36.6 KB = 4 per CU)
+  int* sidx = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND]
   int& nsurv = sidx[SPREAD_ROUND];
   int& maxlen = sidx[SPREAD_ROUND + 1];
+  unsigned short* srel = reinterpret_cast<unsigned short*>(sidx + SPREAD_ROUND + 2);  // [SPREAD_ROUND]
   int bx, by, bz;
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
@@ -407,7 +410,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
           const int rz = rel_start(crec[u].z, s0, oz, g.nz, N);
           if (rx < BRICK && ry < BRICK && rz < BRICK) {
             const int dst = atomicAdd(&nsurv, 1);
-            srel[dst] = (rx & 0xff) | ((ry & 0xff) << 8) | ((rz & 0xff) << 16);
+            srel[dst] = (unsigned short)((rx & 0xf) | ((ry & 0xf) << 4) | ((rz & 0xf) << 8));
             sidx[dst] = cidx[u];
           }
         }
@@ -424,7 +427,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
           T* dst = stage + tid * SW;
           // row: [wz placed on the brick's 8 z points (zero outside the stencil) | value | wx | wy] -- with the z weights
           // already shifted, the accumulation below is 8 FMAs per survivor with no dispatch on the z offset
-          const int rz = (srel[chunk + tid] << 8) >> 24;
+          const int rz = (int(srel[chunk + tid]) << 20) >> 28;
           T wzr[N];
 #pragma unroll
           for (int t = 0; t < N; ++t) wzr[t] = wr[2 * N + t];
@@ -445,7 +448,10 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         // Everything about a survivor except the lane's own (t_x, t_y) is wave-uniform: keep it in scalar registers
         // (readfirstlane) so that the loop -- VALU-issue bound, four waves per SIMD -- spends its vector instructions on
         // the column update only.
-        constexpr int UC = 4;
+#ifndef MIPME_SPREAD_UC
+#define MIPME_SPREAD_UC 3  // 3: the whole co-scheduled kernel fits 64 VGPRs; 4 measured 1 % slower (r02_experiments.txt)
+#endif
+        constexpr int UC = MIPME_SPREAD_UC;
         const int nstc = __builtin_amdgcn_readfirstlane(nst);
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         for (int sv0 = wave_u; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
@@ -455,7 +461,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
           for (int u = 0; u < UC; ++u) {
             const int sv = sv0 + u * SPREAD_WAVES;
             live[u] = sv < nstc;
-            pk[u] = __builtin_amdgcn_readfirstlane(srel[chunk + (live[u] ? sv : sv0)]);
+            pk[u] = __builtin_amdgcn_readfirstlane(int(srel[chunk + (live[u] ? sv : sv0)]));
           }
           T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC], fv[UC];
           bool in[UC];
@@ -464,7 +470,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
             const int sv = live[u] ? sv0 + u * SPREAD_WAVES : sv0;
-            const int rx = (pk[u] << 24) >> 24, ry = (pk[u] << 16) >> 24;
+            const int rx = (pk[u] << 28) >> 28, ry = (pk[u] << 24) >> 28;
             const unsigned tx = unsigned(px - rx), ty = unsigned(py - ry);
             in[u] = live[u] && tx < unsigned(N) && ty < unsigned(N);
             const T* sw = stage + sv * SW;
@@ -524,20 +530,28 @@ __device__ long long g_wg_timeline[4 * 16384];
 #define MIPME_WG_STAMP(k)
 #endif
 
+#ifndef MIPME_FUSED_WAVES
+#define MIPME_FUSED_WAVES 1  // minimum waves per SIMD the co-scheduled kernel is compiled for (register budget); experiments
+#endif
 template <int N, typename T, int PFAST, bool COMPACT>
-__global__ __launch_bounds__(SPREAD_THREADS) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread) {
+__global__ __launch_bounds__(SPREAD_THREADS, MIPME_FUSED_WAVES) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
+                                                                                              unsigned n_spread) {
   MIPME_WG_STAMP(0);
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(sa, blockIdx.x);
   else {
+    // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
+    extern __shared__ __attribute__((aligned(16))) char smem_rows[];
+    AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
     bool done = false;
     if constexpr (COMPACT && std::is_same<T, float>::value) {
       if (!ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, blockIdx.x - n_spread);
+        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, blockIdx.x - n_spread, tab);
         done = true;
       }
     }
-    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread);
+    if (!done)
+      sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread, tab);
   }
 #ifdef MIPME_WG_TIMELINE
   __syncthreads();
@@ -1169,13 +1183,15 @@ __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(cons
   if (blockIdx.x < n_spread)
     spread_brick_body<N, T>(f.spread, blockIdx.x);
   else if (blockIdx.x - n_spread < f.n_row_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rows[];  // see spread_rows_kernel
+    AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
     if constexpr (COMPACT && std::is_same<T, float>::value) {
       if (!f.rows.dist_out) {
-        sr_rows_pk_body<PFAST, SPREAD_THREADS>(f.rows, blockIdx.x - n_spread);
+        sr_rows_pk_body<PFAST, SPREAD_THREADS>(f.rows, blockIdx.x - n_spread, tab);
         return;
       }
     }
-    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread);
+    sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread, tab);
   }
 }
 

@@ -126,8 +126,11 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
 // BS = threads of the workgroup (BS / kRowLanes rows per workgroup); block = index of the workgroup among the row workgroups
 // UNROLL: entries in flight per lane (0 = the measured default for the dtype, see below)
 // COMPACT: the entry stream is kShiftTable32 (one int per entry; implies TABLE)
+// shift_tab: LDS storage of the workgroup for the kShiftTableSize Cartesian shift vectors (TABLE formats; the caller owns it so
+// that a kernel with dynamic LDS of its own -- the co-scheduled launch -- does not pay for a second, static allocation)
 template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE, int BS, int UNROLL = 0, bool COMPACT = false>
-__device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args, unsigned block) {
+__device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args, unsigned block,
+                                                   AtomRecord<T>* __restrict__ shift_tab = nullptr) {
   static_assert(!COMPACT || (TABLE && !MASK), "compact entries carry table codes and have no pair-mask variant");
   const SRPot& s = args.s;
   const FastRS& cf = args.cf;
@@ -169,8 +172,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
 #pragma unroll
   for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : T(0);
   const T c_inv2s2 = T(cf.inv_2s2), c1 = T(cf.c1), cpref = T(cf.pref);
-  __shared__ AtomRecord<T> shift_tab[TABLE ? kShiftTableSize : 1];  // Cartesian shift vector of every table code
-  if constexpr (TABLE) {
+  if constexpr (TABLE) {  // Cartesian shift vector of every table code
     for (int k = threadIdx.x; k < kShiftTableSize; k += BS) {
       const T sx = T(k % kShiftTableBase - kShiftTableRange), sy = T((k / kShiftTableBase) % kShiftTableBase - kShiftTableRange),
               sz = T(k / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
@@ -441,7 +443,8 @@ __device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
 }
 
 template <int PFAST, int BS>
-__device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block) {
+__device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
+                                                AtomRecord<float>* __restrict__ shift_tab) {
   static_assert(kRowLanes == 16, "the packed body walks 2 x 16 entries per row and iteration");
   const int64_t N = args.N;
   const int* __restrict__ row_ptr = args.row_ptr;
@@ -451,10 +454,9 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   float* __restrict__ force = args.force;
   const float c_inv2s2 = float(args.cf.inv_2s2), c1 = float(args.cf.c1), cpref = float(args.cf.pref);
   // The dependent chain of a row -- row_ptr -> entry words -> partner records -> arithmetic -- is a large part of a row
-  // workgroup's lifetime (tools/wg_timeline.py: 9-14 us for 2.8 us of arithmetic), so the loads are issued as early as their
-  // addresses exist: row bounds and own position first, the shift table is built while they are in flight (moving these loads
-  // behind the table's barrier costs 3 us per launch), and the loop keeps the entry words two iterations and the partner
-  // records one iteration ahead of the arithmetic.
+  // workgroup's lifetime (tools/wg_timeline.py: 9-14 us for 2.8 us of arithmetic), so the first loads are issued as early as
+  // their addresses exist: row bounds and own position first, the shift table is built while they are in flight (moving these
+  // loads behind the table's barrier costs 3 us per launch).
   const int sub = threadIdx.x % kRowLanes;
   unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
   const bool valid = a < N;
@@ -464,7 +466,6 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   const f2v axy = f2v{pos[3 * a], pos[3 * a + 1]};
   const float az = pos[3 * a + 2];
   const float qa = args.q[a];
-  __shared__ AtomRecord<float> shift_tab[kShiftTableSize];
   {
     float A[9];
 #pragma unroll
@@ -482,31 +483,23 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   const i4v ent_rs = raw_buffer(args.ent_sh, unsigned(n_entries) * 4u);
   const i4v rec_rs = raw_buffer(args.rec, unsigned(N) * 16u);
   constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
-  int off = (beg + sub) * 4;  // byte offset of this lane's first entry of the iteration
-  // entry words of iterations 0 and 1 (sets 0 and 1), partner records of iteration 0
-  unsigned wA0 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
-  unsigned wB0 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
-  unsigned wA1 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 8 * kRowLanes, 0, 0));
-  unsigned wB1 = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 12 * kRowLanes, 0, 0));
-  f4v rA0 = llvm_raw_buffer_load_f4(rec_rs, int((wA0 & kAtomMask) << 4), 0, 0);
-  f4v rB0 = llvm_raw_buffer_load_f4(rec_rs, int((wB0 & kAtomMask) << 4), 0, 0);
-  f4v rA1, rB1;
+  // entry words one iteration ahead, partner records fetched where they are used (62 VGPRs).  Fetching the records one
+  // iteration ahead as well (two register sets alternating, +10 VGPRs) changed nothing measurable: 18.3 vs 18.1 us alone,
+  // 27.2 vs 26.6 us inside the co-scheduled launch (profiles/r02_experiments.txt).
+  int off = (beg + sub) * 4;
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
   __syncthreads();  // shift table
   f2v pot2 = f2v{0.f, 0.f}, fxy = f2v{0.f, 0.f};
   float fz = 0.f;
-  // one iteration: arithmetic on the records of set `c` (loaded one iteration ago) while the records of the next iteration
-  // (set `n`, words loaded one iteration ago) and the words of the one after (into set `c`) are fetched.  The loop alternates
-  // the two sets explicitly, so that no register moves (and no waits for them) sit on the back edge.
-  auto iteration = [&](int eA, f4v& cRA, f4v& cRB, unsigned& cWA, unsigned& cWB, f4v& nRA, f4v& nRB, const unsigned nWA,
-                       const unsigned nWB) {
+  for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
     const int eB = eA + kRowLanes;
-    const AtomRecord<float> sA = shift_tab[cWA >> kCompactAtomBits], sB = shift_tab[cWB >> kCompactAtomBits];
-    nRA = llvm_raw_buffer_load_f4(rec_rs, int((nWA & kAtomMask) << 4), 0, 0);
-    nRB = llvm_raw_buffer_load_f4(rec_rs, int((nWB & kAtomMask) << 4), 0, 0);
+    const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
+    const f4v cRB = llvm_raw_buffer_load_f4(rec_rs, int((wB & kAtomMask) << 4), 0, 0);
+    const AtomRecord<float> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
     off += 8 * kRowLanes;
-    cWA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 8 * kRowLanes, 0, 0));
-    cWB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 12 * kRowLanes, 0, 0));
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here (the scheduler sinks them to their first use otherwise)
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
     const bool okA = eA < end, okB = eB < end;
     const f2v vA = (f2v{cRA.x, cRA.y} - axy) + f2v{sA.x, sA.y};
     const f2v vB = (f2v{cRB.x, cRB.y} - axy) + f2v{sB.x, sB.y};
@@ -523,11 +516,6 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     fz -= sc.x * zA;
     fxy -= sc.y * vB;
     fz -= sc.y * zB;
-  };
-  for (int eA = beg + sub; eA - sub < end; eA += 4 * kRowLanes) {
-    iteration(eA, rA0, rB0, wA0, wB0, rA1, rB1, wA1, wB1);
-    if (eA + 2 * kRowLanes - sub >= end) break;
-    iteration(eA + 2 * kRowLanes, rA1, rB1, wA1, wB1, rA0, rB0, wA0, wB0);
   }
   const float pot = row_sum(pot2.x + pot2.y);
   if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.f) + 0.5f * pot;

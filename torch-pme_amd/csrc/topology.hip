@@ -381,17 +381,20 @@ __global__ void pack_atom_records_kernel(int64_t N, const T* __restrict__ pos, c
 
 template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE>
 __global__ __launch_bounds__(256) void sr_fused_rows_kernel(FusedRowsArgs<T> a) {
-  sr_fused_rows_body<T, MODE, CELLGRAD, PFAST, MASK, TABLE, 256>(a, blockIdx.x);
+  __shared__ AtomRecord<T> shift_tab[TABLE ? kShiftTableSize : 1];
+  sr_fused_rows_body<T, MODE, CELLGRAD, PFAST, MASK, TABLE, 256>(a, blockIdx.x, shift_tab);
 }
 
 // 4-byte entry stream (kShiftTable32), potential + force sums: the generic body (distance by-product) and the packed one
 template <typename T, int PFAST>
 __global__ __launch_bounds__(256) void sr_fused_rows_compact_kernel(FusedRowsArgs<T> a) {
-  sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, 256, 0, true>(a, blockIdx.x);
+  __shared__ AtomRecord<T> shift_tab[kShiftTableSize];
+  sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, 256, 0, true>(a, blockIdx.x, shift_tab);
 }
 template <int PFAST>
 __global__ __launch_bounds__(256) void sr_rows_pk_kernel(FusedRowsArgs<float> a) {
-  sr_rows_pk_body<PFAST, 256>(a, blockIdx.x);
+  __shared__ AtomRecord<float> shift_tab[kShiftTableSize];
+  sr_rows_pk_body<PFAST, 256>(a, blockIdx.x, shift_tab);
 }
 
 // energy mode: grad_pos[a] = gE q[a] (f F[a] + field[a]), grad_cell = f gE sum_b partials[b]   (f = 1/2 for a full list;
