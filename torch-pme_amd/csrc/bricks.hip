@@ -19,14 +19,11 @@ namespace mipme {
 
 static constexpr int BRICK = 8;
 static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
-// spread: survivors staged together (rows of spread_row_reals reals); 128 when 256 rows would not fit next to the lists
+// spread: survivors staged together (rows of spread_row_reals reals); fewer than 256 when they would not fit next to the lists
 static inline int spread_stage_rows(int order, size_t real_bytes);
-// reals staged per survivor by the spread: [wz shifted to the brick's 8 z points | value | wx (n) | wy (n)], rows 16-byte
-// aligned in fp32 (vector LDS reads of the z weights)
-static inline size_t spread_row_reals(int order, size_t real_bytes) {
-  const size_t w = BRICK + 1 + 2 * size_t(order);
-  return real_bytes == 4 ? ((w + 3) & ~size_t(3)) : w;
-}
+// reals staged per survivor by the spread: its three 1-D weight vectors PLACED on the brick's 8 points of each axis (zero
+// outside the stencil), the x vector already times the value: [wz | wx * value | wy]
+static inline size_t spread_row_reals(int, size_t) { return 3 * BRICK; }
 
 struct BrickGeom {
   int nbx, nby, nbz, nb;
@@ -298,6 +295,9 @@ __device__ __forceinline__ void fma_row8(T (&acc)[BRICK], T w, const T (&row)[BR
   }
 }
 
+#ifndef MIPME_SPREAD_UC
+#define MIPME_SPREAD_UC 3  // survivors per iteration of the spread's accumulation loop (4 measured 1 % slower, r02_experiments.txt)
+#endif
 static constexpr int SPREAD_THREADS = 512;
 static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
 static constexpr int SPREAD_GROUP = 16;                           // threads per neighbouring brick in the candidate scan
@@ -311,7 +311,7 @@ static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_ro
   return real_bytes * region + sizeof(int) * (SPREAD_ROUND + 2) + sizeof(unsigned short) * SPREAD_ROUND;
 }
 static inline int spread_stage_rows(int order, size_t real_bytes) {
-  for (int rows : {256, 128})
+  for (int rows : {256, 192, 128})
     if (spread_lds_bytes(order, real_bytes, rows) <= SPREAD_LDS_MAX) return rows;
   return 0;
 }
@@ -349,7 +349,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     bins.snap[block] = bin_count_of(bins, int(block), true);
     if (block == 0) bins.snap[bins.nb] = bin_count_of(bins, bins.nb, true);
   }
-  constexpr int SW = sizeof(T) == 4 ? ((BRICK + 1 + 2 * N + 3) & ~3) : BRICK + 1 + 2 * N;  // staged reals per survivor (spread_row_reals)
+  constexpr int SW = 3 * BRICK;  // staged reals per survivor (spread_row_reals)
   const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
@@ -419,69 +419,60 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       const int ns = nsurv;
       for (int chunk = 0; chunk < ns; chunk += stage_rows) {
         const int nst = min(stage_rows, ns - chunk);
-        // A2: stage weights and the value of this channel
+        // A2: stage the survivor's weights, placed on the brick: row = [wz | wx * value | wy], 8 entries each, entry k of an
+        // axis = weight of the stencil point that falls on the brick's point k of that axis, zero if none does.  With all
+        // three vectors placed the accumulation below needs neither the stencil offsets nor an "inside the stencil" test:
+        // a lane reads its x and y entries at its own coordinates and everything outside the stencil multiplies by zero.
         if (tid < nst) {
           const int si = sidx[chunk + tid];
           const int orig = rec[si].w;
           const T* wr = wts + int64_t(si) * (6 * N);
           T* dst = stage + tid * SW;
-          // row: [wz placed on the brick's 8 z points (zero outside the stencil) | value | wx | wy] -- with the z weights
-          // already shifted, the accumulation below is 8 FMAs per survivor with no dispatch on the z offset
-          const int rz = (int(srel[chunk + tid]) << 20) >> 28;
-          T wzr[N];
+          const int rel = int(srel[chunk + tid]);
+          const int rx = (rel << 28) >> 28, ry = (rel << 24) >> 28, rz = (rel << 20) >> 28;
+          T w1[3][N];
 #pragma unroll
-          for (int t = 0; t < N; ++t) wzr[t] = wr[2 * N + t];
-#pragma unroll
-          for (int k = 0; k < BRICK; ++k) {
-            T w = T(0);
-#pragma unroll
-            for (int t = 0; t < N; ++t) w = (k - rz == t) ? wzr[t] : w;
-            dst[k] = w;
+          for (int t = 0; t < N; ++t) {
+            w1[0][t] = wr[2 * N + t];
+            w1[1][t] = wr[t];
+            w1[2][t] = wr[N + t];
           }
-          dst[BRICK] = val[int64_t(orig) * C + c] * scale;
+          const T v = val[int64_t(orig) * C + c] * scale;
+          const int r3[3] = {rz, rx, ry};
 #pragma unroll
-          for (int k = 0; k < 2 * N; ++k) dst[BRICK + 1 + k] = wr[k];
+          for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+            for (int k = 0; k < BRICK; ++k) {
+              T w = T(0);
+#pragma unroll
+              for (int t = 0; t < N; ++t) w = (k - r3[ax] == t) ? w1[ax][t] : w;
+              dst[ax * BRICK + k] = ax == 1 ? w * v : w;
+            }
+          }
         }
         __syncthreads();
-        // C: register accumulation; wave w takes survivors w, w+W, ...; four survivors per iteration so that
-        // their LDS reads overlap (the loop is a chain of dependent LDS reads otherwise)
-        // Everything about a survivor except the lane's own (t_x, t_y) is wave-uniform: keep it in scalar registers
-        // (readfirstlane) so that the loop -- VALU-issue bound, four waves per SIMD -- spends its vector instructions on
-        // the column update only.
-#ifndef MIPME_SPREAD_UC
-#define MIPME_SPREAD_UC 3  // 3: the whole co-scheduled kernel fits 64 VGPRs; 4 measured 1 % slower (r02_experiments.txt)
-#endif
+        // C: register accumulation; wave w takes survivors w, w+W, ...; UC survivors per iteration so that their LDS reads
+        // overlap (the loop is a chain of dependent LDS reads otherwise).  Per survivor and wave: the z row (wave-uniform
+        // address: LDS broadcast), the lane's x and y entries, one product, four packed FMAs -- about ten vector
+        // instructions; the loop shares the SIMDs with the pair sum's row workgroups, which are bound by the same issue slots.
         constexpr int UC = MIPME_SPREAD_UC;
         const int nstc = __builtin_amdgcn_readfirstlane(nst);
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         for (int sv0 = wave_u; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
-          int pk[UC];
+          T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC];
           bool live[UC];
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
             const int sv = sv0 + u * SPREAD_WAVES;
             live[u] = sv < nstc;
-            pk[u] = __builtin_amdgcn_readfirstlane(int(srel[chunk + (live[u] ? sv : sv0)]));
-          }
-          T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC], fv[UC];
-          bool in[UC];
-          // all LDS reads of the four survivors are unconditional (clamped addresses) and issued together: a read under
-          // `if (in)` becomes an exec-masked branch with its own wait, i.e. one LDS round trip per survivor in series
-#pragma unroll
-          for (int u = 0; u < UC; ++u) {
-            const int sv = live[u] ? sv0 + u * SPREAD_WAVES : sv0;
-            const int rx = (pk[u] << 28) >> 28, ry = (pk[u] << 24) >> 28;
-            const unsigned tx = unsigned(px - rx), ty = unsigned(py - ry);
-            in[u] = live[u] && tx < unsigned(N) && ty < unsigned(N);
-            const T* sw = stage + sv * SW;
-            fx[u] = sw[BRICK + 1 + min(tx, unsigned(N - 1))];
-            fy[u] = sw[BRICK + 1 + N + min(ty, unsigned(N - 1))];
-            fv[u] = sw[BRICK];
+            const T* sw = stage + (live[u] ? sv : sv0) * SW;
+            fx[u] = sw[BRICK + px];
+            fy[u] = sw[2 * BRICK + py];
             load_row8<T>(sw, wz[u]);  // wave-uniform address: LDS broadcast
           }
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
-            wxy[u] = in[u] ? fx[u] * fy[u] * fv[u] : T(0);
+            wxy[u] = live[u] ? fx[u] * fy[u] : T(0);
             fma_row8<T>(acc, wxy[u], wz[u]);
           }
         }
