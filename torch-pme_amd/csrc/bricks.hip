@@ -377,6 +377,8 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     gstart = int(bins.over_base);
     glen = bin_count_of(bins, bins.nb, args.from_live);
   }
+  // (fetching the first round's records speculatively up here, before the counts are known, saves a memory round trip on paper
+  // and nothing in the measurement: 25.8 against 25.2 us for the launch, and its 16 extra VGPRs cross the 80-register line)
   if (tid == 0) maxlen = 0;
   __syncthreads();
   if (grp < 28 && sub == 0) atomicMax(&maxlen, glen);
@@ -521,11 +523,11 @@ __device__ long long g_wg_timeline[4 * 16384];
 #define MIPME_WG_STAMP(k)
 #endif
 
-#ifndef MIPME_FUSED_WAVES
-#define MIPME_FUSED_WAVES 1  // minimum waves per SIMD the co-scheduled kernel is compiled for (register budget); experiments
-#endif
+// Register budget of the co-scheduled kernel: 6 waves per SIMD = 3 workgroups per CU (what its LDS allows too) needs <= 80
+// VGPRs -- the allocation granule turns 82 into 88 = 2 workgroups per CU, measured 10 % slower at cfg5; asked for 6 waves the
+// compiler fits the fp32 / 4-byte-entry kernels into 68-73 without spilling.  Other instantiations are left alone.
 template <int N, typename T, int PFAST, bool COMPACT>
-__global__ __launch_bounds__(SPREAD_THREADS, MIPME_FUSED_WAVES) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                               unsigned n_spread) {
   MIPME_WG_STAMP(0);
   if (blockIdx.x < n_spread)
