@@ -594,14 +594,16 @@ def main(argv=None):
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_kernel[dom],
                 "kernel_ms": kernels[dom],
-                # The dominant launch is the pair sum co-scheduled with the spread.  It is instruction-issue bound, not
-                # bandwidth bound (58 VALU instructions per pair entry, profiles/r02_*_sq_counters.txt): halving its entry
-                # stream (4-byte entries, this round) cut its bytes by 39 % and its time by 9 %, so `frac` fell while the
-                # kernel got faster.  For continuity with the previous round's line: the same launch time against the bytes
-                # of the 8-byte-entry format it replaced.
-                "note": "instruction-issue bound pair sum; bytes halved this round (4-byte entries)",
-                "frac_at_8_byte_entry_format": ((per_kernel[dom] + 2 * w.n_pairs * (8 - getattr(ops, "FUSED_ENTRY_BYTES", 8)))
-                                                / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if "rspace" in dom else None,
+                # The dominant launch is the pair sum co-scheduled with the spread.  It is bound by instruction issue and by
+                # workgroup slots, not by bandwidth (profiles/r02_*_sq_counters.txt, r02_experiments.txt
+                # item 10): over the round its bytes fell faster than its time -- 4-byte entries (-38 MB), distances no longer
+                # stored (-19 MB) -- so `frac` fell while the kernel got faster.  For continuity with round 1's line: the same
+                # launch time against the bytes of the formats it replaced (8-byte entries, distances stored).
+                "note": "issue- and slot-bound pair sum, not HBM-bound; bytes cut this round (4-byte entries, distances kept in "
+                        "registers) faster than time",
+                "frac_at_round1_byte_accounting": ((per_kernel[dom] + 2 * w.n_pairs * (8 - getattr(ops, "FUSED_ENTRY_BYTES", 8))
+                                                    + (0 if args.store_distances else w.n_pairs * s))
+                                                   / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if "rspace" in dom else None,
             },
             # whole step: bytes the kernels of this build move in their own formats (sum of the per-kernel figures below)
             # against the step time; SURVEY 8(d)'s figure for the reference's unfused formats is given for orientation only
