@@ -1016,3 +1016,52 @@ def test_bin_overflow_region(dtype, blob):
     gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
     assert abs(float(E) - float((Vo * q).sum())) < (1e-11 if dtype == torch.float64 else 2e-5) * abs(float((Vo * q).sum()))
     assert rell2(F.cpu().double(), -(gr["positions"] + gpos_d)) < tolG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_sparse_brick_kernels(dtype):
+    """Meshes with many sparsely filled bricks (here 128^3 = 4096 bricks, 1.5 atoms per brick on average plus a dense patch)
+    take the quarter-size workgroups of the spread and of the gather, and the pair sum runs in a launch of its own: potentials
+    and all gradients of the eager path and energy + forces of the replayed step (gather tail) against the oracle."""
+    rng = np.random.default_rng(23)
+    L = 64.0
+    cell = np.array([[L, 0, 0], [0.04 * L, L, 0], [0, -0.03 * L, L]])
+    N = 6000
+    frac = rng.uniform(0, 1, (N, 3))
+    frac[:600] = 0.45 + 0.08 * rng.uniform(0, 1, (600, 3))  # a patch at 20 x the mean density (bricks beyond their slot capacity)
+    pos = frac @ cell
+    q = rng.normal(size=(N, 1))
+    q -= q.mean()
+    sm, h = 1.2, 2 * L / 126  # -> 128^3
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 4.5)
+    keep = dist > 0.7
+    pairs, S, dist = pairs[keep], S[keep], dist[keep]
+    spec = O.PotentialSpec("coulomb", 1, sm, 1.0)
+    Vo, cache = O.forward(spec, "P3M", 5, h, q, cell, pos, pairs, dist, return_cache=True)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=sm), mesh_spacing=h, interpolation_nodes=5).to(dtype)
+    assert calc._kspace_setup(torch.tensor(cell, device=DEV, dtype=dtype), dtype, torch.device(DEV))[0].ns == (128, 128, 128)
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=dtype, requires_grad=grad)  # noqa: E731
+    ti, tS = torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV)
+    tolV, tolG = (1e-10, 1e-9) if dtype == torch.float64 else (5e-5, 5e-4)
+    g = rng.normal(size=(N, 1))
+    for energy in (False, True):
+        gr = O.backward(cache, q if energy else g)
+        gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+        tq, tc, tp = t(q, not energy), t(cell, True), t(pos, True)
+        d = tpa.pair_distances(tp, ti, tc, tS)
+        V = calc(tq, tc, tp, ti, d)
+        (tpa.weighted_sum(V, tq) if energy else (V * t(g)).sum()).backward()
+        assert rell2(V.detach().cpu().double(), Vo) < tolV
+        assert rell2(tp.grad.cpu().double(), gr["positions"] + gpos_d) < tolG
+        assert relmax(tc.grad.cpu().double(), gr["cell"] + gcell_d) < 20 * tolG
+        if not energy:
+            assert rell2(tq.grad.cpu().double(), gr["charges"]) < tolV * 10
+    gr = O.backward(cache, q)
+    gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    step = tpa.GraphedEnergyForces(calc, t(q), t(cell), t(pos), ti, tS)
+    for _ in range(2):
+        E, F = step()
+        Eo = float((q * Vo).sum())
+        assert abs(float(E) - Eo) < (1e-10 if dtype == torch.float64 else 2e-5) * float(np.abs(q * Vo).sum())
+        assert rell2(F.cpu().double(), -(gr["positions"] + gpos_d)) < tolG

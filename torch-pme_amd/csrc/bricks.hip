@@ -301,20 +301,35 @@ __device__ __forceinline__ void fma_row8(T (&acc)[BRICK], T w, const T (&row)[BR
 static constexpr int SPREAD_THREADS = 512;
 static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
 static constexpr int SPREAD_GROUP = 16;                           // threads per neighbouring brick in the candidate scan
-static constexpr int SPREAD_CPT = 6;                              // candidates per thread and round (96 per brick and round)
-static constexpr int SPREAD_ROUND = 28 * SPREAD_GROUP * SPREAD_CPT;  // candidates per round = capacity of the survivor lists (27 bricks + overflow)
 static constexpr size_t SPREAD_LDS_MAX = 64 * 1024;
+// Sparse bricks (see GATHER_THREADS_SPARSE): a brick workgroup is a chain of memory round trips whatever it holds, so with 16
+// atoms per brick (256^3 at water density: 32 768 bricks) the spread is bound by how many bricks a CU keeps in flight -- three
+// of the 512-thread workgroups (384 us for 526 848 atoms).  The sparse variant runs the same phases with 128 threads, a
+// 64-row staging area and shorter rounds: 11 KB of LDS, a dozen bricks per CU.
+static constexpr int SPREAD_THREADS_SPARSE = 128;
+// candidates per thread and round; groups are served 16 threads each, THREADS / 16 at a time
+template <int THREADS> struct SpreadShape {
+  static constexpr int kWaves = THREADS / 64;
+  static constexpr int kGroupsPerPass = THREADS / SPREAD_GROUP;
+  static constexpr int kPasses = (28 + kGroupsPerPass - 1) / kGroupsPerPass;  // 27 neighbouring bricks + the overflow region
+  static constexpr int kCpt = THREADS >= 512 ? 6 : 2;                         // 96 / 32 candidates per brick and round
+  static constexpr int kRound = 28 * SPREAD_GROUP * kCpt;                     // capacity of the survivor lists
+};
+static constexpr int SPREAD_ROUND = SpreadShape<SPREAD_THREADS>::kRound;
 
 static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize, "the shift table of a row workgroup (4 reals per code) lives in the staging region");
-static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows) {
-  const size_t region = std::max<size_t>(SPREAD_WAVES * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
-  return real_bytes * region + sizeof(int) * (SPREAD_ROUND + 2) + sizeof(unsigned short) * SPREAD_ROUND;
+static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows, bool sparse = false) {
+  const int waves = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kWaves : SPREAD_WAVES;
+  const int round = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kRound : SPREAD_ROUND;
+  const size_t region = std::max<size_t>(size_t(waves) * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
+  return real_bytes * region + sizeof(int) * (round + 2) + sizeof(unsigned short) * round;
 }
 static inline int spread_stage_rows(int order, size_t real_bytes) {
   for (int rows : {256, 192, 128})
     if (spread_lds_bytes(order, real_bytes, rows) <= SPREAD_LDS_MAX) return rows;
   return 0;
 }
+static constexpr int kSpreadStageRowsSparse = 64;
 
 template <typename T>
 struct SpreadArgs {
@@ -332,8 +347,10 @@ struct SpreadArgs {
 };
 
 // block = index of the brick (workgroup index among the spread workgroups of the launch)
-template <int N, typename T>
+template <int N, typename T, int THREADS = SPREAD_THREADS>
 __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, unsigned block) {
+  using Shape = SpreadShape<THREADS>;
+  constexpr int WAVES = Shape::kWaves, PASSES = Shape::kPasses, CPT = Shape::kCpt, ROUND = Shape::kRound;
   const Geom& g = args.g;
   const BrickGeom& bg = args.bg;
   const int C = args.C;
@@ -350,38 +367,46 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     if (block == 0) bins.snap[bins.nb] = bin_count_of(bins, bins.nb, true);
   }
   constexpr int SW = 3 * BRICK;  // staged reals per survivor (spread_row_reals)
-  const int region = max(SPREAD_WAVES * BRICK_PTS, stage_rows * SW);
+  const int region = max(WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
   // survivors of a round: slot index (int) and stencil start relative to the brick (3 x 4 signed bits in a uint16 -- the
   // launch's LDS caps the workgroups per CU of the co-scheduled launch, rows included: 36.6 KB = 4 per CU)
-  int* sidx = reinterpret_cast<int*>(stage + region);       // [SPREAD_ROUND]
-  int& nsurv = sidx[SPREAD_ROUND];
-  int& maxlen = sidx[SPREAD_ROUND + 1];
-  unsigned short* srel = reinterpret_cast<unsigned short*>(sidx + SPREAD_ROUND + 2);  // [SPREAD_ROUND]
+  int* sidx = reinterpret_cast<int*>(stage + region);       // [ROUND]
+  int& nsurv = sidx[ROUND];
+  int& maxlen = sidx[ROUND + 1];
+  unsigned short* srel = reinterpret_cast<unsigned short*>(sidx + ROUND + 2);  // [ROUND]
   int bx, by, bz;
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // candidate scan: 16 threads per neighbouring brick (27 x 16 = 432 of the 512 threads) walk that brick's atom records
-  // in rounds of 64 -- the thread -> (brick, atom) mapping needs no search and the 16-byte record loads stay coalesced;
-  // a 28th group walks the overflow region (atoms whose brick was full: normally none)
-  const int grp = tid / SPREAD_GROUP, sub = tid % SPREAD_GROUP;
-  int gstart = 0, glen = 0;
-  if (grp < 27) {
-    const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
-    const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
-    gstart = nbr * bins.cap;
-    glen = bin_count_of(bins, nbr, args.from_live);
-  } else if (grp == 27) {
-    gstart = int(bins.over_base);
-    glen = bin_count_of(bins, bins.nb, args.from_live);
+  // candidate scan: 16 threads per neighbouring brick (27 x 16 = 432 of the 512 threads; the 128-thread variant serves the
+  // groups eight at a time) walk that brick's atom records in rounds -- the thread -> (brick, atom) mapping needs no search
+  // and the 16-byte record loads stay coalesced; a 28th group walks the overflow region (atoms whose brick was full:
+  // normally none)
+  const int sub = tid % SPREAD_GROUP;
+  int gstart[PASSES], glen[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int grp = p * Shape::kGroupsPerPass + tid / SPREAD_GROUP;
+    gstart[p] = 0;
+    glen[p] = 0;
+    if (grp < 27) {
+      const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
+      const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
+      gstart[p] = nbr * bins.cap;
+      glen[p] = bin_count_of(bins, nbr, args.from_live);
+    } else if (grp == 27) {
+      gstart[p] = int(bins.over_base);
+      glen[p] = bin_count_of(bins, bins.nb, args.from_live);
+    }
   }
-  // (fetching the first round's records speculatively up here, before the counts are known, saves a memory round trip on paper
-  // and nothing in the measurement: 25.8 against 25.2 us for the launch, and its 16 extra VGPRs cross the 80-register line)
   if (tid == 0) maxlen = 0;
   __syncthreads();
-  if (grp < 28 && sub == 0) atomicMax(&maxlen, glen);
+  if (sub == 0) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) atomicMax(&maxlen, glen[p]);
+  }
   __syncthreads();
   const int total = maxlen;  // longest of the 27 candidate lists
   constexpr int s0 = stencil_start<N>();
@@ -391,21 +416,25 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     T acc[BRICK];
 #pragma unroll
     for (int k = 0; k < BRICK; ++k) acc[k] = T(0);
-    for (int round = 0; round < total; round += SPREAD_GROUP * SPREAD_CPT) {
+    for (int round = 0; round < total; round += SPREAD_GROUP * CPT) {
       if (tid == 0) nsurv = 0;
       __syncthreads();
-      // A1: which candidate stencils overlap this brick?  (SPREAD_ROUND candidates per round = list slots)
-      int cidx[SPREAD_CPT];
-      int4 crec[SPREAD_CPT];
+      // A1: which candidate stencils overlap this brick?  (ROUND candidates per round = list slots)
+      constexpr int NC = CPT * PASSES;
+      int cidx[NC];
+      int4 crec[NC];
 #pragma unroll
-      for (int u = 0; u < SPREAD_CPT; ++u) {
-        const int k = round + u * SPREAD_GROUP + sub;
-        cidx[u] = k < glen ? gstart + k : -1;
+      for (int p = 0; p < PASSES; ++p) {
+#pragma unroll
+        for (int v = 0; v < CPT; ++v) {
+          const int k = round + v * SPREAD_GROUP + sub;
+          cidx[p * CPT + v] = k < glen[p] ? gstart[p] + k : -1;
+        }
       }
 #pragma unroll
-      for (int u = 0; u < SPREAD_CPT; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
+      for (int u = 0; u < NC; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
 #pragma unroll
-      for (int u = 0; u < SPREAD_CPT; ++u) {
+      for (int u = 0; u < NC; ++u) {
         if (cidx[u] >= 0) {
           const int rx = rel_start(crec[u].x, s0, ox, g.nx, N);
           const int ry = rel_start(crec[u].y, s0, oy, g.ny, N);
@@ -460,12 +489,12 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         constexpr int UC = MIPME_SPREAD_UC;
         const int nstc = __builtin_amdgcn_readfirstlane(nst);
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        for (int sv0 = wave_u; sv0 < nstc; sv0 += SPREAD_WAVES * UC) {
+        for (int sv0 = wave_u; sv0 < nstc; sv0 += WAVES * UC) {
           T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC];
           bool live[UC];
 #pragma unroll
           for (int u = 0; u < UC; ++u) {
-            const int sv = sv0 + u * SPREAD_WAVES;
+            const int sv = sv0 + u * WAVES;
             live[u] = sv < nstc;
             const T* sw = stage + (live[u] ? sv : sv0) * SW;
             fx[u] = sw[BRICK + px];
@@ -485,10 +514,10 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
 #pragma unroll
     for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
     __syncthreads();
-    for (int k = tid; k < BRICK_PTS; k += SPREAD_THREADS) {
+    for (int k = tid; k < BRICK_PTS; k += THREADS) {
       T v = T(0);
 #pragma unroll
-      for (int w = 0; w < SPREAD_WAVES; ++w) v += part[w * BRICK_PTS + k];
+      for (int w = 0; w < WAVES; ++w) v += part[w * BRICK_PTS + k];
       const int qx = k / (BRICK * BRICK), qy = (k / BRICK) % BRICK, qz = k % BRICK;
       const int gx = ox + qx, gy = oy + qy, gz = oz + qz;
       if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = v;
@@ -500,6 +529,10 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs<T> a) {
   spread_brick_body<N, T>(a, blockIdx.x);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_kernel(SpreadArgs<T> a) {
+  spread_brick_body<N, T, SPREAD_THREADS_SPARSE>(a, blockIdx.x);
 }
 
 // Horizontal fusion of the spread with the fused distance + pair-sum row kernel (rows_body.h): the first `n_spread`
@@ -556,13 +589,20 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
 // NT = number of meshes staged (1: potential gather, 2: phi and chi for the gradient gather)
 static constexpr int GATHER_THREADS = 512;
 
-template <int N, int NT, typename T>
+// sparse bricks (a 1 A mesh over a dilute system, or 256^3 meshes at water density: 16 atoms per brick): a quarter-size
+// workgroup keeps the gather's lanes busy and four times as many bricks in flight per CU (the kernel is a chain of memory
+// round trips per brick: 526 848 atoms on 256^3, 32 768 bricks: 237 us with 512 threads per brick)
+static constexpr int GATHER_THREADS_SPARSE = 128;
+static constexpr int kSparseBrickAtoms = 40;  // mean atoms per brick at or below which the sparse variants are launched ...
+static constexpr int kSparseMinBricks = 4096;  // ... on meshes with many generations of bricks (fewer: latency matters, not slots)
+
+template <int N, int NT, typename T, int THREADS = GATHER_THREADS>
 __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz, const T* __restrict__ m0,
                                            const T* __restrict__ m1, T* tile) {
   constexpr int TL = BRICK + N - 1;
   constexpr int s0 = stencil_start<N>();
   const int64_t plane = int64_t(g.ny) * g.nz;
-  for (int k = threadIdx.x; k < TL * TL * TL; k += GATHER_THREADS) {
+  for (int k = threadIdx.x; k < TL * TL * TL; k += THREADS) {
     const int tx = k / (TL * TL), ty = (k / TL) % TL, tz = k % TL;
     const int gx = posmod(ox + s0 + tx, g.nx), gy = posmod(oy + s0 + ty, g.ny), gz = posmod(oz + s0 + tz, g.nz);
     const int64_t gi = gx * plane + int64_t(gy) * g.nz + gz;
@@ -634,7 +674,7 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
   }
 }
 
-template <int N, bool FIELD, typename T, bool TAIL = false>
+template <int N, bool FIELD, typename T, bool TAIL = false, int THREADS = GATHER_THREADS>
 __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom& bg, int C, const BinIndex& bins,
                                                   const int4* __restrict__ rec, const T* __restrict__ wts,
                                                   const T* __restrict__ mesh, const T* __restrict__ q,
@@ -645,7 +685,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
   static_assert(!TAIL || FIELD, "the tail needs the mesh field");
   constexpr int LANES = kGatherLanes;
-  constexpr int GROUPS = GATHER_THREADS / LANES;
+  constexpr int GROUPS = THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
   __shared__ T tile[TL * TL * TL];
   int bx, by, bz;
@@ -661,7 +701,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   T seed = T(1);
   if constexpr (TAIL) {
     if (tail->seed) seed = tail->seed[0];
-    if (block == 0) tail_energy<T, GATHER_THREADS>(*tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
+    if (block == 0) tail_energy<T, THREADS>(*tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
   }
   if (beg == end && n_over == 0) return;
   const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
@@ -704,7 +744,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
       const T wzv = lane_active ? wr[2 * N + tz] : T(0);
       const T dwzv = (FIELD && lane_active) ? wr[5 * N + tz] : T(0);
       if (!staged) {
-        load_tiles<N, 1, T>(g, ox, oy, oz, mesh + c * M, nullptr, tile);
+        load_tiles<N, 1, T, THREADS>(g, ox, oy, oz, mesh + c * M, nullptr, tile);
         staged = true;
       }
       // the atom's charge and (accumulate) its potential so far: needed only at the end of the pass
@@ -788,16 +828,15 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
 }
 
 // gather + energy + force assembly (see GatherTail)
-template <int N, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
-                                                                    const int4* __restrict__ rec, const T* __restrict__ wts,
-                                                                    const T* __restrict__ mesh, const T* __restrict__ q,
-                                                                    const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
-                                                                    T* __restrict__ out, T* __restrict__ raw,
-                                                                    T* __restrict__ field, GatherTail<T> tail,
-                                                                    int* __restrict__ nan_flag) {
-  gather_brick_body<N, true, T, true>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw, field,
-                                      blockIdx.x, &tail, nan_flag);
+template <int N, typename T, int THREADS = GATHER_THREADS>
+__global__ __launch_bounds__(THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
+                                                             const int4* __restrict__ rec, const T* __restrict__ wts,
+                                                             const T* __restrict__ mesh, const T* __restrict__ q,
+                                                             const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
+                                                             T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
+                                                             GatherTail<T> tail, int* __restrict__ nan_flag) {
+  gather_brick_body<N, true, T, true, THREADS>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw,
+                                               field, blockIdx.x, &tail, nan_flag);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -986,8 +1025,11 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
-  const int stage_rows = spread_stage_rows(m->order, sizeof(T));
-  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
+  // sparse bricks: quarter-size brick workgroups in a launch of their own, the pair sum (if any) in a second launch -- its row
+  // workgroups then carry only their shift table in LDS; nothing to co-schedule: the bricks alone are many generations
+  const bool sparse = N <= int64_t(kSparseBrickAtoms) * bg.nb && bg.nb >= kSparseMinBricks;
+  const int stage_rows = sparse ? kSpreadStageRowsSparse : spread_stage_rows(m->order, sizeof(T));
+  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows, sparse);
   SpreadArgs<T> sa;
   sa.g = make_geom(m);
   sa.bg = bg;
@@ -1017,25 +1059,38 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     ra_e.epart = want_epart ? v.epart : nullptr;
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
-    const unsigned grid = unsigned(bg.nb) + n_rows_blocks;
+    unsigned n_spread = unsigned(bg.nb);
+    size_t lds_k = lds;
+    if (sparse) {  // the bricks first, by themselves; then the same kernel with no brick workgroups and the rows' LDS only
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_brick_sparse_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
+      MIPME_LAUNCH_CHECK();
+      n_spread = 0;
+      lds_k = sizeof(AtomRecord<T>) * kShiftTableSize;
+    }
+    const unsigned grid = n_spread + n_rows_blocks;
     const bool compact = job->shift_format == kShiftTable32;
     if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
     else if (pfast == 1)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
     else if (compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra_e, unsigned(bg.nb))));
+                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                           ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(sa)));
+  if (sparse)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, spread_brick_sparse_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
+  else
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(sa)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -1081,10 +1136,16 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       tail.epart_sr = tail.epart_k + tail.n_k;
       tail.n_sr = tail.n_k;
     }
-    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
-                                 g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
-                                 T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
+    if (N <= int64_t(kSparseBrickAtoms) * bg.nb && bg.nb >= kSparseMinBricks)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, gather_tail_kernel<N, T, GATHER_THREADS_SPARSE><<<unsigned(bg.nb), GATHER_THREADS_SPARSE, 0, st>>>(
+                                   g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
+                                   T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
+    else
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                                   g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
+                                   T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
