@@ -27,6 +27,7 @@ static inline size_t spread_row_reals(int, size_t) { return 3 * BRICK; }
 
 struct BrickGeom {
   int nbx, nby, nbz, nb;
+  int xcd;  // 1: workgroup -> brick through xcd_contiguous() (common.h), launches padded to a multiple of 8 workgroups
 };
 
 static inline BrickGeom make_brick_geom(const mipme_mesh_t* m) {
@@ -35,7 +36,14 @@ static inline BrickGeom make_brick_geom(const mipme_mesh_t* m) {
   b.nby = (m->ny + BRICK - 1) / BRICK;
   b.nbz = (m->nz + BRICK - 1) / BRICK;
   b.nb = b.nbx * b.nby * b.nbz;
+  static const bool xcd_map = env_flag("MIPME_XCD_MAP", true);
+  b.xcd = xcd_map ? 1 : 0;
   return b;
+}
+// workgroups of a one-workgroup-per-brick launch, and the brick of a workgroup (>= nb: nothing to do)
+static inline unsigned brick_grid(const BrickGeom& b) { return b.xcd ? pad8(unsigned(b.nb)) : unsigned(b.nb); }
+__device__ __forceinline__ unsigned brick_of(const BrickGeom& b, unsigned wg) {
+  return b.xcd ? xcd_contiguous(wg, unsigned(b.nb)) : wg;
 }
 
 // Brick path preconditions: >= 3 bricks per axis (the 27 neighbours are distinct bricks) and enough LDS.
@@ -528,11 +536,13 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
 
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs<T> a) {
-  spread_brick_body<N, T>(a, blockIdx.x);
+  const unsigned b = brick_of(a.bg, blockIdx.x);
+  if (b < unsigned(a.bg.nb)) spread_brick_body<N, T>(a, b);
 }
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_kernel(SpreadArgs<T> a) {
-  spread_brick_body<N, T, SPREAD_THREADS_SPARSE>(a, blockIdx.x);
+  const unsigned b = brick_of(a.bg, blockIdx.x);
+  if (b < unsigned(a.bg.nb)) spread_brick_body<N, T, SPREAD_THREADS_SPARSE>(a, b);
 }
 
 // Horizontal fusion of the spread with the fused distance + pair-sum row kernel (rows_body.h): the first `n_spread`
@@ -563,21 +573,27 @@ template <int N, typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                               unsigned n_spread) {
   MIPME_WG_STAMP(0);
-  if (blockIdx.x < n_spread)
-    spread_brick_body<N, T>(sa, blockIdx.x);
-  else {
-    // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
-    extern __shared__ __attribute__((aligned(16))) char smem_rows[];
-    AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
-    bool done = false;
-    if constexpr (COMPACT && std::is_same<T, float>::value) {
-      if (!ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, blockIdx.x - n_spread, tab);
-        done = true;
+  // n_spread bricks (0: a rows-only launch), then the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
+  const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
+  if (blockIdx.x < n_pad) {
+    const unsigned b = brick_of(sa.bg, blockIdx.x);
+    if (b < n_spread) spread_brick_body<N, T>(sa, b);
+  } else {
+    const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_pad, n_row_blocks) : blockIdx.x - n_pad;
+    if (r < n_row_blocks) {
+      // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
+      extern __shared__ __attribute__((aligned(16))) char smem_rows[];
+      AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
+      bool done = false;
+      if constexpr (COMPACT && std::is_same<T, float>::value) {
+        if (!ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
+          sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, r, tab);
+          done = true;
+        }
       }
+      if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
     }
-    if (!done)
-      sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, blockIdx.x - n_spread, tab);
   }
 #ifdef MIPME_WG_TIMELINE
   __syncthreads();
@@ -823,8 +839,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
                                                                      T bg_c, bool accumulate, T* __restrict__ out,
                                                                      T* __restrict__ raw, T* __restrict__ field,
                                                                      int* __restrict__ nan_flag) {
-  gather_brick_body<N, FIELD, T>(g, bg, C, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field,
-                                 blockIdx.x, nullptr, nan_flag);
+  const unsigned b = brick_of(bg, blockIdx.x);
+  if (b < unsigned(bg.nb))
+    gather_brick_body<N, FIELD, T>(g, bg, C, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, accumulate, out, raw, field, b,
+                                   nullptr, nan_flag);
 }
 
 // gather + energy + force assembly (see GatherTail)
@@ -835,8 +853,10 @@ __global__ __launch_bounds__(THREADS) void gather_tail_kernel(Geom g, BrickGeom 
                                                              const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
                                                              T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
                                                              GatherTail<T> tail, int* __restrict__ nan_flag) {
-  gather_brick_body<N, true, T, true, THREADS>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw,
-                                               field, blockIdx.x, &tail, nan_flag);
+  const unsigned b = brick_of(bg, blockIdx.x);
+  if (b < unsigned(bg.nb))
+    gather_brick_body<N, true, T, true, THREADS>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw,
+                                                 field, b, &tail, nan_flag);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -1063,12 +1083,12 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     size_t lds_k = lds;
     if (sparse) {  // the bricks first, by themselves; then the same kernel with no brick workgroups and the rows' LDS only
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_brick_sparse_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
+                               ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
       MIPME_LAUNCH_CHECK();
       n_spread = 0;
       lds_k = sizeof(AtomRecord<T>) * kShiftTableSize;
     }
-    const unsigned grid = n_spread + n_rows_blocks;
+    const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_rows_blocks) : n_spread + n_rows_blocks;
     const bool compact = job->shift_format == kShiftTable32;
     if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
@@ -1087,10 +1107,10 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   }
   if (sparse)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, spread_brick_sparse_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
+                             ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
   else
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, spread_brick_kernel<N, T><<<unsigned(bg.nb), SPREAD_THREADS, lds, st>>>(sa)));
+                             ((void)S, spread_brick_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS, lds, st>>>(sa)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -1138,12 +1158,12 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     }
     if (N <= int64_t(kSparseBrickAtoms) * bg.nb && bg.nb >= kSparseMinBricks)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, gather_tail_kernel<N, T, GATHER_THREADS_SPARSE><<<unsigned(bg.nb), GATHER_THREADS_SPARSE, 0, st>>>(
+                               ((void)S, gather_tail_kernel<N, T, GATHER_THREADS_SPARSE><<<brick_grid(bg), GATHER_THREADS_SPARSE, 0, st>>>(
                                    g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
                                    T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, gather_tail_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                               ((void)S, gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                    g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
                                    T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     MIPME_LAUNCH_CHECK();
@@ -1151,13 +1171,13 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   }
   if (field)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, gather_brick_kernel<N, true, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                             ((void)S, gather_brick_kernel<N, true, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                  g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
                                  (T*)raw, (T*)field, (int*)nan_flag)));
   else
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, gather_brick_kernel<N, false, T><<<unsigned(bg.nb), GATHER_THREADS, 0, st>>>(
+                             ((void)S, gather_brick_kernel<N, false, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                  g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q,
                                  (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), accumulate != 0, (T*)out,
                                  (T*)raw, nullptr, (int*)nan_flag)));

@@ -234,6 +234,18 @@ struct RowRideHost {
 
 // (x, y, z, w) per atom, 16-byte aligned: one gather per entry of the fused pair kernels fetches the partner's position
 // and charge (or source value).  Written by pack_atom_records_kernel (topology.hip) or by the binning pass (bricks.hip).
+// XCD-aware workgroup -> work-item mapping.  The dispatcher hands consecutive workgroups of a launch to the eight XCDs round
+// robin, so neighbouring items (bricks of the mesh, blocks of rows of the pair list) land on eight different L2s and each L2
+// ends up caching the whole working set.  With item = (wg % 8) * ceil(n / 8) + wg / 8 the workgroups ONE XCD receives cover
+// a contiguous eighth of the items: halo tiles of neighbouring bricks and partner records of neighbouring rows are re-used in
+// that XCD's L2.  The launch is padded to a multiple of 8 workgroups; the ones mapped beyond n exit.  (A bijection whatever
+// the real dispatch order is -- only the locality depends on it.)
+__host__ __device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigned n_items) {
+  const unsigned chunk = (n_items + 7u) >> 3;
+  return (wg & 7u) * chunk + (wg >> 3);
+}
+__host__ __device__ __forceinline__ unsigned pad8(unsigned n) { return (n + 7u) & ~7u; }
+
 // boolean switch from the environment ("0" = off, anything else = on), for A/B measurements of kernel variants
 inline bool env_flag(const char* name, bool dflt) {
   const char* e = getenv(name);
