@@ -601,6 +601,24 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
   MIPME_WG_STAMP(1);
 }
 
+// The pair sum alone (sparse-brick path: the bricks ran in a launch of their own): 256-thread workgroups with nothing but the
+// shift table in LDS and no register bound, i.e. full occupancy -- the same bodies, the same per-wave energy partial sums.
+template <typename T, int PFAST, bool COMPACT>
+__global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int xcd) {
+  __shared__ AtomRecord<T> tab[kShiftTableSize];
+  constexpr int BS = 256;
+  const unsigned n_row_blocks = unsigned((ra.N + BS / kRowLanes - 1) / (BS / kRowLanes));
+  const unsigned r = xcd ? xcd_contiguous(blockIdx.x, n_row_blocks) : blockIdx.x;
+  if (r >= n_row_blocks) return;
+  if constexpr (COMPACT && std::is_same<T, float>::value) {
+    if (!ra.dist_out) {
+      sr_rows_pk_body<PFAST, BS>(ra, r, tab);
+      return;
+    }
+  }
+  sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, BS, 0, COMPACT>(ra, r, tab);
+}
+
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
 // NT = number of meshes staged (1: potential gather, 2: phi and chi for the gradient gather)
 static constexpr int GATHER_THREADS = 512;
@@ -1079,14 +1097,25 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     ra_e.epart = want_epart ? v.epart : nullptr;
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
-    unsigned n_spread = unsigned(bg.nb);
-    size_t lds_k = lds;
-    if (sparse) {  // the bricks first, by themselves; then the same kernel with no brick workgroups and the rows' LDS only
+    const unsigned n_spread = unsigned(bg.nb);
+    const size_t lds_k = lds;
+    if (sparse) {  // the bricks first, by themselves; then the pair sum in a launch of its own (rows_only_kernel)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
       MIPME_LAUNCH_CHECK();
-      n_spread = 0;
-      lds_k = sizeof(AtomRecord<T>) * kShiftTableSize;
+      const unsigned nrb = unsigned((job->n_atoms + 256 / kRowLanes - 1) / (256 / kRowLanes));
+      const unsigned rgrid = bg.xcd ? pad8(nrb) : nrb;
+      const bool compact_r = job->shift_format == kShiftTable32;
+      if (pfast == 1 && compact_r)
+        rows_only_kernel<T, 1, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      else if (pfast == 1)
+        rows_only_kernel<T, 1, false><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      else if (compact_r)
+        rows_only_kernel<T, 6, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      else
+        rows_only_kernel<T, 6, false><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      MIPME_LAUNCH_CHECK();
+      return MIPME_OK;
     }
     const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_rows_blocks) : n_spread + n_rows_blocks;
     const bool compact = job->shift_format == kShiftTable32;
