@@ -60,7 +60,7 @@ def main(src, dst, dtype_tag="float"):
             "fetch_correction": FETCH_CORRECTION,
             "hbm_bytes_per_launch": fetch * FETCH_CORRECTION + write,
         }
-    json.dump({"source": src, "calibration": "profiles/r02_fetch_calib.txt", "kernels": out}, open(dst, "w"), indent=1)
+    json.dump({"source": src, "calibration": "profiles/r02_j_fetch_calib.txt", "kernels": out}, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
