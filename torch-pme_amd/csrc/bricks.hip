@@ -154,7 +154,8 @@ __device__ __forceinline__ void atom_mesh_coords(const Geom& g, bool even, const
 // then writes its record {mesh coordinates, atom index} and its 1-D weights (and derivatives) -- evaluated ONCE, the four
 // particle<->mesh kernels of a step only load them -- straight into its slot, and (atom_rec) the (position, charge) record
 // of the fused pair kernels while the position is in registers anyway.
-template <int SCHEME, int N, typename T>
+static constexpr int64_t kCoalescedBinAtoms = 100000;  // atoms from which the binning pass stages its weight rows (see below)
+template <int SCHEME, int N, typename T, bool COALESCE = false>
 __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& bg, const BinIndex& bi, int64_t Natoms,
                                                const T* __restrict__ pos, int* __restrict__ over_brick,
                                                int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
@@ -187,44 +188,82 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
   int base = 0;
   if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
   base = __shfl(base, my_leader, 64);
-  if (!valid) return;
   const int myslot = base + my_rank;
-  int64_t dst;
-  if (myslot < bi.cap) {
-    dst = int64_t(b) * bi.cap + myslot;
-  } else {  // brick full: overflow region (rare; one atomic per atom)
-    const int k = atomicAdd(&bi.live[bi.nb], 1);
-    over_brick[k] = b;
-    dst = bi.over_base + k;
+  int64_t dst = 0;
+  if (valid) {
+    if (myslot < bi.cap) {
+      dst = int64_t(b) * bi.cap + myslot;
+    } else {  // brick full: overflow region (rare; one atomic per atom)
+      const int k = atomicAdd(&bi.live[bi.nb], 1);
+      over_brick[k] = b;
+      dst = bi.over_base + k;
+    }
+    if (atom_rec) {
+      AtomRecord<T> r;
+      r.x = pos[3 * i];
+      r.y = pos[3 * i + 1];
+      r.z = pos[3 * i + 2];
+      r.w = q[i];
+      atom_rec[i] = r;
+    }
+    rec[dst] = make_int4(m[0], m[1], m[2], int(i));
   }
-  if (atom_rec) {
-    AtomRecord<T> r;
-    r.x = pos[3 * i];
-    r.y = pos[3 * i + 1];
-    r.z = pos[3 * i + 2];
-    r.w = q[i];
-    atom_rec[i] = r;
-  }
-  rec[dst] = make_int4(m[0], m[1], m[2], int(i));
-  T* wr = wts + dst * (6 * N);
+  // The 6N weights of an atom go to its slot, anywhere in the bins: written by the atom's own lane that is 6N four-byte stores
+  // to 64 different cache lines per instruction.  Transposed through LDS instead: the wave stages its rows, then lane k of a
+  // group of 6N lanes writes value k of one atom -- contiguous 24N-byte segments, two atoms per instruction at N = 5
+  // (1 029 000 atoms: 95 -> ... us for this kernel).
+  constexpr int W = 6 * N;
+  // COALESCE is chosen by the launcher for large systems, where the kernel is bound by its store transactions (1 029 000 atoms:
+  // 95 -> 45 us); at 32k atoms it is a chain of latencies and the extra LDS round trip costs 1.3 us.  fp64 rows of n >= 5 nodes
+  // do not fit 48 KB of LDS and keep the direct stores.
+  constexpr bool STAGED = COALESCE && sizeof(T) * 64 * W * (256 / 64) <= 48 * 1024;
+  if constexpr (STAGED) {
+    __shared__ T sw[256 / 64][64 * W];
+    T* mine = sw[threadIdx.x >> 6] + lane * W;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    T w[N], dw[N];
-    weights_1d<SCHEME, N, true, T>(T(x[d]), w, dw);
+    for (int d = 0; d < 3; ++d) {
+      T w[N], dw[N];
+      weights_1d<SCHEME, N, true, T>(T(x[d]), w, dw);
 #pragma unroll
-    for (int t = 0; t < N; ++t) {
-      wr[d * N + t] = w[t];
-      wr[(3 + d) * N + t] = dw[t];
+      for (int t = 0; t < N; ++t) {
+        mine[d * N + t] = w[t];
+        mine[(3 + d) * N + t] = dw[t];
+      }
+    }
+    // (one wave reads what the same wave wrote: no workgroup barrier needed, only the LDS writes to have landed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PER = 64 / W;  // atoms per store instruction
+    const unsigned long long vmask = __ballot(valid);
+    const int sub = lane / W, k = lane % W;
+    const T* rows = sw[threadIdx.x >> 6];
+    for (int a0 = 0; a0 < 64; a0 += PER) {
+      const int j = a0 + (sub < PER ? sub : 0);
+      const int64_t dj = __shfl(dst, j < 64 ? j : 0, 64);
+      if (sub < PER && j < 64 && ((vmask >> j) & 1ull)) wts[dj * W + k] = rows[j * W + k];
+    }
+  } else {
+    if (!valid) return;
+    T* wr = wts + dst * W;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      T w[N], dw[N];
+      weights_1d<SCHEME, N, true, T>(T(x[d]), w, dw);
+#pragma unroll
+      for (int t = 0; t < N; ++t) {
+        wr[d * N + t] = w[t];
+        wr[(3 + d) * N + t] = dw[t];
+      }
     }
   }
 }
 
-template <int SCHEME, int N, typename T>
+template <int SCHEME, int N, typename T, bool COALESCE>
 __global__ __launch_bounds__(256) void bin_atoms_kernel(Geom g, BrickGeom bg, BinIndex bi, int64_t Natoms,
                                                        const T* __restrict__ pos, int* __restrict__ over_brick,
                                                        int4* __restrict__ rec, T* __restrict__ wts,
                                                        const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
-  bin_atoms_body<SCHEME, N, T>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x);
+  bin_atoms_body<SCHEME, N, T, COALESCE>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x);
 }
 
 // number of atoms of brick `b` (clamped to the slots it has) and of the overflow region, from the live counters of a
@@ -1048,10 +1087,16 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   v.idx.live = live;
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
   if (n_atoms > 0) {
-    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             (bin_atoms_kernel<S, N, T><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
-                                                                               v.rec, (T*)v.wts, (const T*)q,
-                                                                               (AtomRecord<T>*)atom_rec)));
+    if (n_atoms >= kCoalescedBinAtoms)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               (bin_atoms_kernel<S, N, T, true><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
+                                                                                       v.rec, (T*)v.wts, (const T*)q,
+                                                                                       (AtomRecord<T>*)atom_rec)));
+    else
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               (bin_atoms_kernel<S, N, T, false><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
+                                                                                        v.rec, (T*)v.wts, (const T*)q,
+                                                                                        (AtomRecord<T>*)atom_rec)));
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;
