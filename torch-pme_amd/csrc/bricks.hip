@@ -302,11 +302,11 @@ __device__ __forceinline__ int rel_start(int m, int s0, int origin, int nmesh, i
 // (LDS float atomics turned out to be the limiter of the first brick version: ~30 us for 4 M ds_add_f32.)
 //   A1  16 threads per neighbouring brick walk its atom records (independent, coalesced 16-byte loads) and append the
 //       atoms whose stencil overlaps this brick to an LDS list ("survivors");
-//   A2  survivors are staged up to 256 at a time: thread t copies the x / y weights, the value and the z weights --
-//       already shifted onto the brick's 8 z points, zero outside the stencil -- of survivor t to LDS;
-//   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+8, ..., four per
-//       iteration: two lane-dependent LDS reads (wx, wy) and one broadcast row (value + 8 z weights) per survivor, then
-//       8 FMAs -- no atomics, no dispatch on the z offset, no conditional reads;
+//   A2  survivors are staged up to 256 at a time: thread t writes the three 1-D weight vectors of survivor t to LDS, each
+//       PLACED on the brick's 8 points of its axis (zero outside the stencil), the x vector times the value;
+//   C   lane = (px,py) column of the brick, 8 z-accumulators in registers; wave w walks survivors w, w+8, ..., three per
+//       iteration: the lane's x and y entries and one broadcast row (8 z entries) per survivor, one product, then 8 FMAs
+//       (four packed) -- no atomics, no stencil offsets, no inside test, no conditional reads;
 //   R   the eight waves' partial bricks are summed through LDS and written with coalesced stores.
 // Per-phase clock stamps: tools/spread_phases.py (profiles/r01_j_spread_phases.txt).
 
