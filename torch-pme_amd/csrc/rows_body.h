@@ -268,7 +268,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
       const T d2 = vx * vx + vy * vy + vz * vz;
       T v, dvd;  // v_SR(d) and v_SR'(d) / d
       if constexpr (PFAST > 0) {
-        fast_rs_eval<PFAST, FORCE, T>(c_inv2s2, c1, cpref, d2, v, dvd);
+        fast_rs_eval<PFAST, FORCE, T>(c_inv2s2, c1, cpref, d2, v, dvd, cf.cheb);
       } else {
         const T d = fsqrt(d2);
         T dv;

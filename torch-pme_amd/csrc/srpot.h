@@ -63,40 +63,49 @@ __device__ __forceinline__ float erfc_from_exp(float y, float e) {
 // double: erfc(y) = e * t * C20(t) with the same substitution, C20 a degree-20 Chebyshev series of erfcx(y)/t on
 // t in [1/(1+0.4*27), 1] (interpolation at Chebyshev nodes; max relative error 4e-15 for 0 <= y <= 27, beyond which
 // e = exp(-y^2) underflows anyway), evaluated with Clenshaw's recurrence: ~45 flops instead of libm erfc's ~150.
-__device__ __forceinline__ double erfc_from_exp(double y, double e) {
-  constexpr double c[21] = {
-    0.5360362114901628,
-    0.36394201332405524,
-    0.08650903632395776,
-    0.013008876153714528,
-    0.0006814592277430882,
-    -0.00015462371847884464,
-    -2.5921853049941386e-05,
-    2.306253180458029e-06,
-    7.220220663501949e-07,
-    -6.169012444769808e-08,
-    -2.0618514118898877e-08,
-    2.6589056503780845e-09,
-    5.618178359727535e-10,
-    -1.305151311061305e-10,
-    -1.0535414781885487e-11,
-    5.9990625120232684e-12,
-    -2.000942951395261e-13,
-    -2.2583487398503573e-13,
-    3.6983871068685136e-14,
-    5.0608677594587146e-15,
-    -2.7192201719058864e-15};
+#define MIPME_ERFC_CHEB                                                                                            \
+  {0.5360362114901628,      0.36394201332405524,     0.08650903632395776,     0.013008876153714528,                   \
+   0.0006814592277430882,   -0.00015462371847884464, -2.5921853049941386e-05, 2.306253180458029e-06,                  \
+   7.220220663501949e-07,   -6.169012444769808e-08,  -2.0618514118898877e-08, 2.6589056503780845e-09,                 \
+   5.618178359727535e-10,   -1.305151311061305e-10,  -1.0535414781885487e-11, 5.9990625120232684e-12,                 \
+   -2.000942951395261e-13,  -2.2583487398503573e-13, 3.6983871068685136e-14,  5.0608677594587146e-15,                 \
+   -2.7192201719058864e-15}
+static constexpr int kErfcChebTerms = 21;
+// 1/x and 1/sqrt(x) in double from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) and two Newton steps each: within an
+// ulp or two of the IEEE sequences (v_div_scale / fmas / fixup, sqrt + division) at a third of their instruction count
+__device__ __forceinline__ double rcp_newton(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+// c: the 21 coefficients.  The fused pair kernels pass the copy that travels in their kernel arguments (FastRS::cheb): it is
+// loaded once into scalar registers, where 21 double literals would be re-materialised with two v_mov each per evaluation
+// (65 of the ~300 instructions of the fp64 pair loop).
+__device__ __forceinline__ double erfc_from_exp(double y, double e, const double* __restrict__ c) {
   constexpr double tlo = 0.0847457627118644;
-  const double t = 1.0 / (1.0 + 0.4 * y);
-  const double x = (2.0 * t - (1.0 + tlo)) / (1.0 - tlo);
+  constexpr double xs = 2.0 / (1.0 - tlo), x0 = -(1.0 + tlo) / (1.0 - tlo);
+  const double t = rcp_newton(1.0 + 0.4 * y);
+  const double x = __builtin_fma(xs, t, x0);  // (2 t - (1 + tlo)) / (1 - tlo)
+  const double x2 = 2.0 * x;
   double b1 = 0.0, b2 = 0.0;
 #pragma unroll
-  for (int k = 20; k >= 1; --k) {
-    const double b0 = c[k] + 2.0 * x * b1 - b2;
+  for (int k = kErfcChebTerms - 1; k >= 1; --k) {
+    const double b0 = __builtin_fma(x2, b1, c[k]) - b2;
     b2 = b1;
     b1 = b0;
   }
-  return e * t * (c[0] + x * b1 - b2);
+  return e * t * (__builtin_fma(x, b1, c[0]) - b2);
+}
+__device__ __forceinline__ double erfc_from_exp(double y, double e) {
+  constexpr double c[kErfcChebTerms] = MIPME_ERFC_CHEB;
+  return erfc_from_exp(y, e, c);
 }
 // same fit with the hardware reciprocal (1 ulp) for t
 __device__ __forceinline__ float erfc_from_exp_fast(float y, float e) {
@@ -227,22 +236,26 @@ __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
 // which made the fused kernels VALU-bound.  P = 1 is the Coulomb potential.
 struct FastRS {
   double inv_2s2, c1, pref;  // c1 = 1/(sigma sqrt 2)
+  double cheb[kErfcChebTerms];  // erfc coefficients of the fp64 path (see erfc_from_exp)
 };
-inline FastRS make_fast_rs(const SRPot& s) { return FastRS{s.inv_2s2, sqrt(s.inv_2s2), s.pref}; }
+inline FastRS make_fast_rs(const SRPot& s) {
+  FastRS f{s.inv_2s2, sqrt(s.inv_2s2), s.pref, MIPME_ERFC_CHEB};
+  return f;
+}
 // exponents with a dedicated instantiation (others take the generic sr_eval): Coulomb and dispersion
 inline int fast_rs_exponent(const SRPot& s) { return (s.mode == 1 && (s.p == 1 || s.p == 6)) ? s.p : 0; }
 
 __device__ __forceinline__ float rs_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double rs_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double rs_rsqrt(double x) { return rsqrt_newton(x); }
 __device__ __forceinline__ float rs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double rs_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double rs_rcp(double x) { return rcp_newton(x); }
 __device__ __forceinline__ float rs_exp_neg(float x) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * x); }
 __device__ __forceinline__ double rs_exp_neg(double x) { return exp(-x); }
-__device__ __forceinline__ float rs_erfc(float y, float e) { return erfc_from_exp_fast(y, e); }
-__device__ __forceinline__ double rs_erfc(double y, double e) { return erfc_from_exp(y, e); }
+__device__ __forceinline__ float rs_erfc(float y, float e, const double*) { return erfc_from_exp_fast(y, e); }
+__device__ __forceinline__ double rs_erfc(double y, double e, const double* c) { return erfc_from_exp(y, e, c); }
 
 template <int P, bool DERIV, typename T>
-__device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v, T& dvd) {
+__device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v, T& dvd, const double* cheb) {
   d2 = d2 > T(1e-30) ? d2 : T(1e-30);
   const T inv = rs_rsqrt(d2);
   const T inv2 = inv * inv;
@@ -263,7 +276,7 @@ __device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v
     // division by y is needed: Q = erfc(y) + sum_{k=1..m} term_k and 2 x dens = 2 x term_m = (2m+1) term_{m+1}
     constexpr int m = (P - 1) / 2;
     const T y = c1 * (d2 * inv);
-    Q = rs_erfc(y, e);
+    Q = rs_erfc(y, e, cheb);
     T term = T(2.0 * 0.56418958354775628695) * y * e;  // term_1
 #pragma unroll
     for (int k = 1; k <= m; ++k) {
