@@ -29,6 +29,9 @@ static constexpr int kShiftTableSize = kShiftTableBase * kShiftTableBase * kShif
 #ifndef MIPME_ROW_UNROLL
 #define MIPME_ROW_UNROLL 4
 #endif
+#ifndef MIPME_ROW_UNROLL_F64
+#define MIPME_ROW_UNROLL_F64 2  // entries in flight per lane of the fused fp64 body (see sr_fused_rows_body)
+#endif
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -162,10 +165,11 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   // rec[o] = (position of o, src[o]) with src = charges except in the transposed potential pass
   // dist_out (potential passes without a mask, pair list ordered by its first index): the role-i entries of a row are the
   // consecutive pairs starting at the pair of its first entry, and their distances are written as a by-product
-  // entries in flight per lane: measured on MI355X -- fp32: 2 (cfg3 0.0840 ms; 0.0853 with 4, 0.0862 with 1, 0.0858 with 3),
-  // fp64: 1 for a single frame (cfg2 0.0708 ms against 0.0797 with 2 or 4: latency-bound), 2 when many frames fill the machine
-  // (8 x 8 000 atoms in one launch: 0.249 against 0.279 ms); beyond that the extra registers cost more than the loads they overlap
-  constexpr int U = UNROLL ? UNROLL : (sizeof(T) == 8 ? 1 : 2);
+  // entries in flight per lane: measured on MI355X -- fp32: 2 (cfg3 0.0840 ms; 0.0853 with 4, 0.0862 with 1, 0.0858 with 3);
+  // fp64: 2 since the loop went from 126 to 86 VGPRs (cfg2 0.0548 against 0.0560 ms with 1; with the earlier, register-heavier
+  // loop 1 was better for a single frame: 0.0708 against 0.0797); beyond that the extra registers cost more than the loads
+  // they overlap
+  constexpr int U = UNROLL ? UNROLL : (sizeof(T) == 8 ? MIPME_ROW_UNROLL_F64 : 2);
   constexpr bool POT = MODE == kPot || MODE == kPotForce;
   constexpr bool FORCE = MODE != kPot;
   T A[9];
