@@ -1065,3 +1065,21 @@ def test_sparse_brick_kernels(dtype):
         Eo = float((q * Vo).sum())
         assert abs(float(E) - Eo) < (1e-10 if dtype == torch.float64 else 2e-5) * float(np.abs(q * Vo).sum())
         assert rell2(F.cpu().double(), -(gr["positions"] + gpos_d)) < tolG
+
+
+@pytest.mark.gpu
+def test_random_sweeps_through_the_sparse_brick_kernels():
+    """The sparse-brick variants (128-thread spread and gather tail, pair sum in its own launch) are chosen for large, thinly
+    filled meshes only; with MIPME_SPARSE_FORCE=1 every brick mesh takes them, so the seeded random sweeps of the graph-replayed
+    step and of the eager calculators (all schemes, orders, dtypes, triclinic cells, half / full lists) check them against the
+    oracle too.  Separate process: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MIPME_SPARSE_FORCE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fuzz.py", "-q", "-x", "-m", "gpu", "-k",
+                        "test_random_graphed_step or test_random_configuration", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

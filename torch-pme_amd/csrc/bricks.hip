@@ -668,6 +668,12 @@ static constexpr int GATHER_THREADS = 512;
 static constexpr int GATHER_THREADS_SPARSE = 128;
 static constexpr int kSparseBrickAtoms = 40;  // mean atoms per brick at or below which the sparse variants are launched ...
 static constexpr int kSparseMinBricks = 4096;  // ... on meshes with many generations of bricks (fewer: latency matters, not slots)
+// MIPME_SPARSE_FORCE=1: the sparse variants for every brick mesh (they are correct at any occupancy) -- how the random sweeps
+// of tests/test_gpu_fuzz.py, whose meshes are small, are run through them (tests/test_gpu_parity.py)
+static inline bool sparse_bricks(int64_t n_atoms, int nb) {
+  static const bool force = env_flag("MIPME_SPARSE_FORCE", false);
+  return force || (n_atoms <= int64_t(kSparseBrickAtoms) * nb && nb >= kSparseMinBricks);
+}
 
 template <int N, int NT, typename T, int THREADS = GATHER_THREADS>
 __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz, const T* __restrict__ m0,
@@ -1110,7 +1116,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const BinsView v = bins_view(m, N, dtype, bins);
   // sparse bricks: quarter-size brick workgroups in a launch of their own, the pair sum (if any) in a second launch -- its row
   // workgroups then carry only their shift table in LDS; nothing to co-schedule: the bricks alone are many generations
-  const bool sparse = N <= int64_t(kSparseBrickAtoms) * bg.nb && bg.nb >= kSparseMinBricks;
+  const bool sparse = sparse_bricks(N, bg.nb);
   const int stage_rows = sparse ? kSpreadStageRowsSparse : spread_stage_rows(m->order, sizeof(T));
   const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows, sparse);
   SpreadArgs<T> sa;
@@ -1230,7 +1236,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       tail.epart_sr = tail.epart_k + tail.n_k;
       tail.n_sr = tail.n_k;
     }
-    if (N <= int64_t(kSparseBrickAtoms) * bg.nb && bg.nb >= kSparseMinBricks)
+    if (sparse_bricks(N, bg.nb))
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, gather_tail_kernel<N, T, GATHER_THREADS_SPARSE><<<brick_grid(bg), GATHER_THREADS_SPARSE, 0, st>>>(
                                    g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
