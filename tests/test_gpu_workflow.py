@@ -529,3 +529,43 @@ def test_virtual_distances(dtype):
     assert float((Vm.detach().cpu() - res[False][0]).norm() / res[False][0].norm()) < tol
     with pytest.raises(ValueError, match="deferred"):
         tpa.pair_distances(tp, ti, tc, tS, deferred="lazy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_graphed_ewald_step(dtype):
+    """``GraphedEnergyForces`` with an ``EwaldCalculator``: the replayed step (k-vector generation from the cell, structure
+    factors, potentials, both backward kernels, pair sum) reproduces the eager evaluation, follows new positions, and returns the
+    cell gradient when asked."""
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    L, N = 16.0, 400
+    cell = np.array([[L, 0, 0], [0.1 * L, 0.9 * L, 0], [0, -0.05 * L, 1.1 * L]])
+    pos = rng.uniform(0, 1, (N, 3)) @ cell
+    q = rng.normal(size=(N, 1))
+    q -= q.mean()
+    pairs, S, _ = tpa.neighbor_list(pos, cell, 5.0)
+    t = lambda a: torch.tensor(a, device=DEV, dtype=dtype)  # noqa: E731
+    tq, tc, ti, tS = t(q), t(cell), torch.tensor(pairs, device=DEV), t(S)
+    calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.1), lr_wavelength=1.8).to(dtype)
+
+    def eager(p):
+        tp = t(p).requires_grad_(True)
+        tcell = tc.clone().requires_grad_(True)
+        V = calc(tq, tcell, tp, ti, tpa.pair_distances(tp, ti, tcell, tS))
+        E = tpa.weighted_sum(V, tq)
+        E.backward()
+        return float(E.detach()), -tp.grad, tcell.grad
+
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    for with_cell in (False, True):
+        step = tpa.GraphedEnergyForces(calc, tq, tc, t(pos), ti, tS, cell_gradient=with_cell)
+        for shift in (0.0, 0.03):
+            p = pos + shift * rng.normal(size=pos.shape)
+            out = step(t(p))
+            E0, F0, gc0 = eager(p)
+            assert abs(float(out[0]) - E0) < tol * abs(E0)
+            assert float((out[1] - F0).norm() / F0.norm()) < 10 * tol
+            if with_cell:
+                assert float((out[2] - gc0).norm() / gc0.norm()) < 10 * tol

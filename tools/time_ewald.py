@@ -40,6 +40,15 @@ for N, L, lr in ((512, 18.0, 2.0), (2048, 28.0, 2.0), (8000, 43.1, 2.5)):
             E = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        tpa.profile_start() if hasattr(tpa, "profile_start") else None
-        nk = int(getattr(calc, "_last_n_kvectors", 0))
-        print(f"N={N} pairs={len(pairs)} {dtype}: {ms:.3f} ms/step (energy+forces), E={float(E):.6f}", flush=True)
+        g = tpa.GraphedEnergyForces(calc, tq, tc, tp.detach(), ti, tS)
+        for _ in range(3):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g()
+        torch.cuda.synchronize()
+        ms_g = (time.perf_counter() - t0) / n * 1e3
+        nk = calc._frequencies(tc).shape[0]
+        print(f"N={N} pairs={len(pairs)} k-vectors={nk} {dtype}: eager {ms:.3f} ms/step, graph replay {ms_g:.3f} ms/step "
+              f"(energy + forces), E={float(E):.6f} / {float(g.energy):.6f}", flush=True)
