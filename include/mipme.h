@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 200
+#define MIPME_VERSION 300
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -490,32 +490,50 @@ int mipme_ewald_backward(void* stream, int dtype, int64_t n_atoms, int n_channel
                          void* grad_positions, void* grad_kvectors, int64_t n_batch);
 
 /* ---- device neighbour list (the reference uses third-party vesin on the host,
- * tests/helpers.py:240-275): pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), d < cutoff. ------
- * Scope: >= 3 cells of perpendicular width >= cutoff along every PERIODIC axis (n_cells[d] = floor(width_d / cutoff) >= 3);
- * a non-periodic axis (periodic[d] = 0: no images, shift 0) may have any n_cells[d] >= 1 and bins the fractional coordinate
- * (f_d - frac_offset[d]) * frac_scale[d], which the caller chooses so that all atoms fall in [0, 1) and a cell is at least
- * cutoff wide.  Other cases use the host builder.  Protocol: mipme_nl_bin -> mipme_nl_count -> (caller: exclusive
- * scan of counts into int64 offsets[N+1], allocate P = offsets[N]) -> mipme_nl_fill. */
+ * tests/helpers.py:240-275, and hands a fresh list to every call, examples/02-neighbor-lists-usage.py:97-164) -------------
+ * One cell-list traversal, two products:
+ *   (a) the reference's quantities: pairs (P,2) int64, integer cell shifts (P,3) as reals, distances (P), strict d < cutoff,
+ *       half or full list:  mipme_nl_bin -> mipme_nl_count -> (caller: exclusive scan of counts into int64 offsets[N+1],
+ *       allocate P = offsets[N]) -> mipme_nl_fill;
+ *   (b) the ROW STREAM the fused pair kernels read, directly:  mipme_nl_bin -> mipme_nl_stream.  For every atom a row of fixed
+ *       capacity holding the 4-byte words  other | shift code << 22  (shift_format 2) of ALL its neighbours; pass the
+ *       row_ptr / words pair to mipme_sr_rows_fused / mipme_sr_job_t with shift_format = 2 | MIPME_ROWS_PADDED.  Every buffer
+ *       keeps its address and nothing is read back by the host, so a captured HIP graph of these two calls refreshes the
+ *       list of a captured energy + forces step in place.
+ * Any cell, box size and cutoff: n_cells[d] cells along axis d (the caller picks them at least cutoff / 2 wide where the box
+ * allows it), reach[d] = ceil(cutoff / cell width) cells are walked to either side, and the walk wraps with the image shift
+ * it crosses (a box smaller than the cutoff meets the same cell several times with different shifts).  A non-periodic axis
+ * (periodic[d] = 0: no images, shift 0) bins the fractional coordinate (f_d - frac_offset[d]) * frac_scale[d], which the
+ * caller chooses so that the atoms fall in [0, 1); atoms beyond join the edge cells.
+ * workspace: mipme_nl_workspace_bytes() bytes of device memory owned by the list, ZERO-INITIALISED ONCE by the caller (the
+ * kernels leave their counters at zero); it carries the binned atoms from mipme_nl_bin to the walks. */
 typedef struct {
   double cell[9];      /* row-major, rows = lattice vectors */
   double inv_cell[9];
   int32_t n_cells[3];
   int32_t periodic[3];
   double cutoff;
-  int32_t full_list;
+  int32_t full_list;   /* mipme_nl_count / mipme_nl_fill only; the stream always holds every neighbour of every atom */
   int32_t _pad;
   double frac_offset[3]; /* non-periodic axes only; 0 / 1 for periodic axes */
   double frac_scale[3];
+  int32_t reach[3];    /* cells walked to either side along each axis */
+  int32_t _pad2;
 } mipme_nl_t;
-int64_t mipme_nl_scratch_ints(const mipme_nl_t* nl, int64_t n_atoms);
-/* cell_of int32[N], wrap int32[N][3], cell_start int32[ncells+1], cell_atoms int32[N], scratch int32[mipme_nl_scratch_ints] */
-int mipme_nl_bin(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, void* cell_of,
-                 void* wrap, void* cell_start, void* cell_atoms, void* scratch);
-int mipme_nl_count(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, const void* wrap,
-                   const void* cell_start, const void* cell_atoms, void* counts /* int32[N] */);
-int mipme_nl_fill(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, const void* wrap,
-                  const void* cell_start, const void* cell_atoms, const void* offsets /* int64[N+1] */, void* pairs,
-                  void* shifts, void* dist /* nullable */);
+#define MIPME_ROWS_PADDED 0x100 /* OR-ed into shift_format: row_ptr is int32[3N+1] = {begin, end, end} per atom + buffer size */
+int64_t mipme_nl_workspace_bytes(const mipme_nl_t* nl, int64_t n_atoms);
+int mipme_nl_bin(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, const void* positions, void* workspace);
+int mipme_nl_count(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, void* workspace,
+                   void* counts /* int32[N] */);
+int mipme_nl_fill(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, void* workspace,
+                  const void* offsets /* int64[N+1] */, void* pairs, void* shifts, void* dist /* nullable */);
+/* row_ptr int32[3N+1], words int32[N * row_capacity + 1].  host_status (nullable): int32[4] of PINNED host memory that
+ * receives, when the call has run, {longest row, flags, refresh counter}: flags bit 0 = a row exceeded row_capacity (its
+ * surplus entries were dropped: enlarge and rebuild), bit 1 = a cell shift beyond the pair kernels' table (|S| > 3: wrap the
+ * positions or use (a)), bit 2 = an atom more than 400 cells outside the unit cell.  The counter (written last, release order)
+ * increases by one per call. */
+int mipme_nl_stream(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, void* workspace, int64_t row_capacity,
+                    void* row_ptr, void* words, void* host_status);
 
 #ifdef __cplusplus
 }

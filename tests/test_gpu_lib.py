@@ -281,10 +281,11 @@ def test_device_neighbor_list_feeds_the_calculator():
     np.testing.assert_allclose(results[1][2], results[0][2], rtol=0, atol=1e-11 * np.abs(results[0][2]).max())
 
 
-def test_device_neighbor_list_scope():
-    with pytest.raises(ValueError, match="device neighbour list needs >= 3 cells"):
-        tpa.neighbor_list_device(torch.zeros((2, 3), device=DEV, dtype=torch.float64),
-                                 torch.eye(3, device=DEV, dtype=torch.float64), 2.0)
+def test_device_neighbor_list_small_box():
+    """A box smaller than three cutoffs stays on the device since round 3 (tests/test_gpu_neighbors.py has the sweep)."""
+    pairs, S, d = tpa.neighbor_list_device(torch.tensor([[0.0, 0, 0], [0.5, 0.5, 0.5]], device=DEV, dtype=torch.float64),
+                                           torch.eye(3, device=DEV, dtype=torch.float64), 2.0)
+    assert len(pairs) == 58 and float(d.max()) < 2.0
 
 
 @pytest.mark.parametrize("periodic", [(True, True, False), (False, True, True), (False, False, False), (True, False, False)])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmipme.so does not export {name}"
     assert sorted(declared) == sorted(_lib.EXPORTS)
-    assert lib.mipme_version() == 200
+    assert lib.mipme_version() == 300
 
 
 def test_abi_struct_layout_matches_header():
@@ -33,7 +33,8 @@ def test_abi_struct_layout_matches_header():
     assert C.sizeof(_lib.PotentialDesc) == 40
     assert C.sizeof(_lib.MeshDesc) == 24 + 19 * 8
     assert _lib.MeshDesc.cell.offset == 24 and _lib.MeshDesc.volume.offset == 24 + 18 * 8
-    assert C.sizeof(_lib.NlDesc) == 18 * 8 + 6 * 4 + 8 + 8 + 6 * 8 and _lib.NlDesc.frac_offset.offset == 18 * 8 + 24 + 16
+    assert C.sizeof(_lib.NlDesc) == 18 * 8 + 6 * 4 + 8 + 8 + 6 * 8 + 16 and _lib.NlDesc.frac_offset.offset == 18 * 8 + 24 + 16
+    assert _lib.NlDesc.reach.offset == 18 * 8 + 24 + 16 + 48
 
 
 def test_no_cpu_fallback():

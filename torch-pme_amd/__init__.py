@@ -10,7 +10,7 @@ from . import lib, library, ops, prefactors, tuning, workloads  # noqa: F401  (l
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, EwaldCalculator, P3MCalculator, PMECalculator
 from .graphed import GraphedEnergyForces, GraphedFrameBatch
-from .neighbors import neighbor_list, neighbor_list_device
+from .neighbors import NeighborStream, neighbor_list, neighbor_list_device
 from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
 from .tuning import tune_ewald, tune_p3m, tune_pme
@@ -31,6 +31,7 @@ __all__ = [
     "GraphedFrameBatch",
     "neighbor_list",
     "neighbor_list_device",
+    "NeighborStream",
     "tune_ewald",
     "tune_p3m",
     "tune_pme",

@@ -29,7 +29,7 @@ EXPORTS = (
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
     "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
-    "mipme_nl_scratch_ints", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill",
+    "mipme_nl_workspace_bytes", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill", "mipme_nl_stream",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
@@ -175,7 +175,13 @@ class NlDesc(C.Structure):
         ("_pad", C.c_int32),
         ("frac_offset", C.c_double * 3),
         ("frac_scale", C.c_double * 3),
+        ("reach", C.c_int32 * 3),
+        ("_pad2", C.c_int32),
     ]
+
+
+#: OR-ed into a shift format: rows written by ``mipme_nl_stream`` (``row_ptr`` int32[3N+1], every neighbour once per row)
+ROWS_PADDED = 0x100
 
 
 class MipmeError(RuntimeError):
@@ -227,9 +233,10 @@ def _declare(lib):
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_scaled_match": [vp, ci, i64, vp, vp, vp, vp],
-        "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp],
-        "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
-        "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp, vp, vp, vp],
+        "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp],
+        "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp],
+        "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
+        "mipme_nl_stream": [vp, ci, C.POINTER(NlDesc), i64, vp, i64, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -245,8 +252,8 @@ def _declare(lib):
     lib.mipme_rows_partials_size.argtypes = [i64]
     lib.mipme_atom_bins_bytes.restype = i64
     lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
-    lib.mipme_nl_scratch_ints.restype = i64
-    lib.mipme_nl_scratch_ints.argtypes = [C.POINTER(NlDesc), i64]
+    lib.mipme_nl_workspace_bytes.restype = i64
+    lib.mipme_nl_workspace_bytes.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_fft_plan_xfused.restype = ci
     lib.mipme_fft_plan_xfused.argtypes = [vp]
     lib.mipme_fft_plan_kgrid_blocks.restype = i64

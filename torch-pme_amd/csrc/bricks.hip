@@ -1142,7 +1142,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const int lo = 0, hi = job->full_list ? 0 : 1;  // roles that feed the potential (as mipme_sr_rows_fused, transpose = 0)
     const FusedRowsArgs<T> ra = make_fused_rows_args<T>(
         s, cf, job->n_atoms, job->row_ptr, job->entries_shift, job->entries, nullptr, job->positions, job->records,
-        job->cell, job->charges, nullptr, lo, hi, job->full_list, 0, job->out, job->force, nullptr, job->dist_out);
+        job->cell, job->charges, nullptr, lo, hi, job->full_list, 0, job->out, job->force, nullptr, job->dist_out,
+        job->shift_format);
     static_assert(kRowsPerSpreadBlock == SPREAD_THREADS / kRowLanes, "epart layout");
     FusedRowsArgs<T> ra_e = ra;
     ra_e.epart = want_epart ? v.epart : nullptr;
@@ -1156,7 +1157,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       MIPME_LAUNCH_CHECK();
       const unsigned nrb = unsigned((job->n_atoms + 256 / kRowLanes - 1) / (256 / kRowLanes));
       const unsigned rgrid = bg.xcd ? pad8(nrb) : nrb;
-      const bool compact_r = job->shift_format == kShiftTable32;
+      const bool compact_r = (job->shift_format & kShiftFormatMask) == kShiftTable32;
       if (pfast == 1 && compact_r)
         rows_only_kernel<T, 1, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
       else if (pfast == 1)
@@ -1169,7 +1170,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       return MIPME_OK;
     }
     const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_rows_blocks) : n_spread + n_rows_blocks;
-    const bool compact = job->shift_format == kShiftTable32;
+    const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
     if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
@@ -1198,9 +1199,9 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
 // the co-scheduled launch exists for the potential + force-sum mode of the fast range-separated potentials (1/r, 1/r^6)
 // with table shift codes
 bool sr_job_fusable(const mipme_sr_job_t* job) {
-  if (!job || !job->pot || !job->force || (job->shift_format != kShiftTable && job->shift_format != kShiftTable32) ||
-      job->n_atoms <= 0)
-    return false;
+  const int fmt = job ? (job->shift_format & kShiftFormatMask) : -1;
+  if (!job || !job->pot || !job->force || (fmt != kShiftTable && fmt != kShiftTable32) || job->n_atoms <= 0) return false;
+  if ((job->shift_format & kRowsPadded) && job->dist_out) return false;
   SRPot s;
   if (make_srpot(job->pot, s)) return false;
   const int pfast = fast_rs_exponent(s);

@@ -24,6 +24,12 @@ static constexpr int kCompactAtomBits = 22;
 static constexpr int64_t kCompactMaxAtoms = int64_t(1) << kCompactAtomBits;
 static constexpr int kShiftTableRange = 3, kShiftTableBase = 2 * kShiftTableRange + 1;
 static constexpr int kShiftTableSize = kShiftTableBase * kShiftTableBase * kShiftTableBase;
+// Row layout flag, OR-ed into the shift format a caller passes: PADDED rows as the device neighbour list writes them
+// (neighbors.hip, mipme_nl_stream) -- row_ptr is int32[3 N + 1] = {begin, middle, end} of every row (the last word: the size of
+// the entry buffer) instead of the shared-boundary int32[2 N + 1], and a row holds EVERY neighbour of its atom once (both
+// directions of each pair are in the stream, middle == end), so sums that must count a pair once -- the cell gradient -- take
+// half of every entry.  Such rows always stand for a half list.
+static constexpr int kRowsPadded = 0x100, kShiftFormatMask = 0xff;
 
 // ---- owner-computes pair kernels ---------------------------------------------------------------
 #ifndef MIPME_ROW_UNROLL
@@ -93,6 +99,8 @@ struct FusedRowsArgs {
   // w of workgroup b at index b * BS/64 + w) -- the pair part of the energy and the self-term sum, reduced later by the
   // gather's tail (bricks.hip)
   double* epart;
+  int row_stride;  // words of row_ptr per atom: 2 (rows share their boundaries) or 3 (kRowsPadded)
+  bool symmetric;  // kRowsPadded: every pair appears in both of its rows as a "role i" entry
 };
 
 template <typename T>
@@ -100,7 +108,8 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
                                                     const void* ent_sh, const void* entries, const void* mask,
                                                     const void* pos, const void* records, const void* cell, const void* q,
                                                     const void* g, int pot_lo, int pot_hi, int full_list, int accumulate,
-                                                    void* out, void* force, void* partials, void* dist_out) {
+                                                    void* out, void* force, void* partials, void* dist_out,
+                                                    int shift_format = 0) {
   FusedRowsArgs<T> a;
   a.s = s;
   a.cf = cf;
@@ -123,6 +132,9 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
   a.partials = (double*)partials;
   a.dist_out = (T*)dist_out;
   a.epart = nullptr;
+  a.symmetric = (shift_format & kRowsPadded) != 0;
+  a.row_stride = a.symmetric ? 3 : 2;
+  if (a.symmetric) a.full = false;
   return a;
 }
 
@@ -189,7 +201,8 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
   const bool valid = a < N;
   if (!valid) a = unsigned(N - 1);
-  const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
+  const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
+  const int r0 = rp[0], mid = rp[1], r2 = rp[2];
   const int pbeg = pot_lo == 0 ? r0 : mid, pend = pot_hi == 0 ? mid : r2;  // entries that feed the potential
   // in the potential + force pass (roles i and j both visited) a full list feeds the potential from role i only
   const int pot_end = (MODE == kPotForce && full) ? mid : 0x7fffffff;
@@ -315,7 +328,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
               sy = T(unpack8(en[u].y, 1));
               sz = T(unpack8(en[u].y, 2));
             }
-            const double wq = MODE == kForceG ? 1.0 : double(qa);
+            const double wq = (MODE == kForceG ? 1.0 : double(qa)) * (args.symmetric ? 0.5 : 1.0);
             const double px = wq * double(sc * vx), py = wq * double(sc * vy), pz = wq * double(sc * vz);
             cg[0] += double(sx) * px; cg[1] += double(sx) * py; cg[2] += double(sx) * pz;
             cg[3] += double(sy) * px; cg[4] += double(sy) * py; cg[5] += double(sy) * pz;
@@ -465,8 +478,9 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
   const bool valid = a < N;
   if (!valid) a = unsigned(N - 1);
-  const int r0 = row_ptr[2 * a], mid = row_ptr[2 * a + 1], r2 = row_ptr[2 * a + 2];
-  const int n_entries = row_ptr[2 * N];
+  const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
+  const int r0 = rp[0], mid = rp[1], r2 = rp[2];
+  const int n_entries = row_ptr[int64_t(args.row_stride) * N];
   const f2v axy = f2v{pos[3 * a], pos[3 * a + 1]};
   const float az = pos[3 * a + 2];
   const float qa = args.q[a];

@@ -523,9 +523,14 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
   const unsigned grid = row_blocks(N);
   const FastRS cf = make_fast_rs(s);
   const int pfast = fast_rs_exponent(s);
-  MIPME_REQUIRE(shift_format == kShiftPacked || shift_format == kShiftTable || shift_format == kShiftTable32,
-                "invalid shift format %d", shift_format);
+  const int row_flags = shift_format & ~kShiftFormatMask;  // kRowsPadded: rows written by mipme_nl_stream
+  shift_format &= kShiftFormatMask;
+  MIPME_REQUIRE((shift_format == kShiftPacked || shift_format == kShiftTable || shift_format == kShiftTable32) &&
+                    (row_flags & ~kRowsPadded) == 0,
+                "invalid shift format %d", shift_format | row_flags);
   MIPME_REQUIRE(!(mask && shift_format != kShiftPacked), "a pair mask needs entries packed in the int8 shift format");
+  MIPME_REQUIRE(!(row_flags & kRowsPadded) || (!mask && !dist_out),
+                "padded rows (device neighbour stream) carry no pair indices: no pair mask, no distance by-product");
   if (!records_ready) {
     pack_atom_records_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(
         N, (const T*)pos, (const T*)(out && !force ? src : q), (AtomRecord<T>*)records);
@@ -545,7 +550,8 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
     return MIPME_EINVAL;
   }
   const FusedRowsArgs<T> args = make_fused_rows_args<T>(s, cf, N, row_ptr, ent_sh, entries, mask, pos, records, cell, q, g, lo, hi,
-                                                        full_list, accumulate, out, force, partials, dist_out);
+                                                        full_list, accumulate, out, force, partials, dist_out,
+                                                        shift_format | row_flags);
   if (shift_format == kShiftTable32) {
     MIPME_REQUIRE(mode == kPotForce && !want_cg && pfast > 0 && N <= kCompactMaxAtoms,
                   "4-byte entries serve the potential + force pass of the Coulomb / dispersion fast paths only");

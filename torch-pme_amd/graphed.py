@@ -27,12 +27,27 @@ class GraphedEnergyForces:
     :param store_distances: keep the pair distances of the last evaluation in ``self.distances`` (P,) -- written by the pair
         kernel as a by-product; off by default: the kernel then forms them in registers only (19 MB less per step at 4.76 M
         pairs, and the packed fp32 body of the pair sum applies)
+    :param neighbors: instead of ``neighbor_indices`` / ``neighbor_shifts``: a cutoff (float, skin included) or a
+        :class:`~torchpme_amd.neighbors.NeighborStream`.  The object then owns a device neighbour list in the pair kernels' own
+        format, built from ITS positions buffer, and :meth:`refresh` rebuilds it in place by replaying a second captured graph
+        (cell-list binning + the walk that writes the rows): no list tensors, no sort, no re-capture of the step -- the MD form
+        of the reference's "new list every call" (``examples/02-neighbor-lists-usage.py:97-164``).
+    :param periodic: per-axis periodicity of the neighbour list made for ``neighbors=<cutoff>``
     """
 
-    def __init__(self, calculator, charges, cell, positions, neighbor_indices, neighbor_shifts, warmup: int = 3,
-                 cell_gradient: bool = False, store_distances: bool = False):
+    def __init__(self, calculator, charges, cell, positions, neighbor_indices=None, neighbor_shifts=None, warmup: int = 3,
+                 cell_gradient: bool = False, store_distances: bool = False, neighbors=None,
+                 periodic=(True, True, True)):
         self.calc = calculator
         self.store_distances = bool(store_distances)
+        self.stream = None
+        if neighbors is not None:
+            if neighbor_indices is not None or neighbor_shifts is not None:
+                raise ValueError("give either `neighbors` or `neighbor_indices` / `neighbor_shifts`")
+            if store_distances:
+                raise ValueError("a device neighbour stream has no pair order to store distances in")
+        elif neighbor_indices is None or neighbor_shifts is None:
+            raise ValueError("`neighbor_indices` and `neighbor_shifts` (or `neighbors`) are required")
         self.q = charges.detach()
         #: with ``cell_gradient=True`` every call also returns dE/dcell (3,3) -- the virial is ``-cell.T @ dE/dcell``
         self.cell_gradient = cell_gradient
@@ -42,7 +57,64 @@ class GraphedEnergyForces:
         # seeding the backward pass with -1 makes ``pos.grad`` the forces directly (no fill and no negation kernel)
         self._minus_one = torch.tensor(-1.0, dtype=positions.dtype, device=device)
         self._warmup = max(1, warmup)
-        self._capture(neighbor_indices, neighbor_shifts)
+        self.refresh_graph = None
+        if neighbors is not None:
+            from .neighbors import NeighborStream
+
+            if isinstance(neighbors, NeighborStream):
+                if neighbors.n_atoms != self.pos.shape[0] or neighbors.dtype != self.pos.dtype:
+                    raise ValueError("`neighbors` was built for other positions")
+                self.stream = neighbors
+                self.stream.positions = self.pos  # from now on the list is rebuilt from the graph's own buffer
+                self.stream.update()
+            else:
+                self.stream = NeighborStream(self.pos, self.cell, float(neighbors), periodic=periodic)
+            self.stream.check(synchronize=True)
+            self._capture_refresh()
+            self._capture(self.stream.indices, None)
+        else:
+            self._capture(neighbor_indices, neighbor_shifts)
+
+    # ---- device neighbour list --------------------------------------------------------------------------------------------
+    def _capture_refresh(self):
+        device = self.pos.device
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            self.stream.update()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.refresh_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.refresh_graph):
+            self.stream.update()
+
+    def refresh(self, positions: torch.Tensor | None = None, check: bool = False) -> None:
+        """Rebuild the neighbour list from the current positions, in place (``neighbors=`` form only): one graph replay --
+        binning, the walk that writes the rows, the status report --, after which the step graph reads the new list at the
+        same addresses.  ``check=True`` waits for it and handles a row that outgrew its capacity (larger buffers, both
+        graphs captured again); otherwise the status word is looked at when the object is next used."""
+        if self.stream is None:
+            raise RuntimeError("refresh() needs the `neighbors=` form; use recapture() with a new list otherwise")
+        self._deferred_check()
+        if positions is not None:
+            with torch.no_grad():
+                self.pos.copy_(positions)
+        self.refresh_graph.replay()
+        if check:
+            torch.cuda.current_stream(self.pos.device).synchronize()
+            self._deferred_check(recover=True)
+
+    def _deferred_check(self, recover: bool = False):
+        st = self.stream
+        if st is None or not int(st._host_np[1]):
+            return
+        if recover and int(st._host_np[1]) == 1:  # only a row overflow: grow, capture again, rebuild
+            st.grow()
+            st.check(synchronize=True)
+            self._capture_refresh()
+            self._capture(st.indices, None)
+            return
+        st.check()
 
     def recapture(self, neighbor_indices, neighbor_shifts, positions: torch.Tensor | None = None) -> None:
         """New neighbour list (e.g. after the atoms moved by more than the skin): rebuild the pair topology and capture the
@@ -55,7 +127,7 @@ class GraphedEnergyForces:
     def _capture(self, neighbor_indices, neighbor_shifts):
         calculator, cell_gradient, device, warmup = self.calc, self.cell_gradient, self.pos.device, self._warmup
         self.pairs = neighbor_indices
-        self.shifts = neighbor_shifts.to(self.pos.dtype).contiguous()
+        self.shifts = None if neighbor_shifts is None else neighbor_shifts.to(self.pos.dtype).contiguous()
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):  # warm-up off the default stream: plans, topology, filter caches get built
@@ -70,11 +142,18 @@ class GraphedEnergyForces:
         # The captured graph holds raw pointers into buffers that were built during the warm-up and live in caches: the
         # transposed pair list (+ packed shifts), the calculator's filter table, the reduction scratch.  Keep them alive
         # for the lifetime of the graph, whatever the caches evict later.
+        topo = ops.get_topology(self.pairs, self.pos.shape[0]) if ops.PAIR_MODE == "rows" else None
         self._keepalive = [
-            ops.get_topology(self.pairs, self.pos.shape[0]) if ops.PAIR_MODE == "rows" else None,
+            topo,
             getattr(calculator, "_cache", None),
             ops._dot_scratch(device, self.q.data_ptr()),
         ]
+        if isinstance(topo, ops.PairTopology):
+            # the entry streams are single-slot caches keyed by the shifts tensor: an eager call with the same pairs and other
+            # shifts would replace the slot and free the buffer the graph reads -- pin the concrete tensors
+            self._keepalive += [topo.row_ptr, topo.entries, topo._ent32, topo._ent_sh, topo._packed, topo._pair_sh]
+        elif topo is not None:
+            self._keepalive += [self.stream.row_ptr, self.stream.words]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
@@ -85,8 +164,11 @@ class GraphedEnergyForces:
     def _eval(self):
         # the pair kernel of the calculator forms the distances itself (no separate pass over the list); "virtual": in
         # registers only, True: stored as a by-product
-        d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts,
-                               deferred=True if self.store_distances else "virtual")
+        if self.stream is not None:
+            d = self.stream.distances(self.pos, self.cell)
+        else:
+            d = ops.pair_distances(self.pos, self.pairs, self.cell, self.shifts,
+                                   deferred=True if self.store_distances else "virtual")
         #: the pair distances of the last evaluation (P,) with ``store_distances=True``, else None
         self.distances = d.detach() if self.store_distances else None
         # the backward pass below is seeded with self._minus_one: promise that to the forward, whose gather then writes the
@@ -98,6 +180,8 @@ class GraphedEnergyForces:
         return E.detach()
 
     def __call__(self, positions: torch.Tensor | None = None):
+        self._deferred_check()
+        self.calc.check()  # a NaN a previous replay met (pinned word, no synchronisation)
         if positions is not None:
             with torch.no_grad():
                 self.pos.copy_(positions)

@@ -189,6 +189,9 @@ def _side_stream(device):
 class PairTopology:
     """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
 
+    #: row-layout flags OR-ed into the shift format handed to the library (0: rows that share their boundaries)
+    fmt_flags = 0
+
     def __init__(self, pairs: torch.Tensor, n_atoms: int):
         lib = _lib.load()
         device = pairs.device
@@ -383,12 +386,63 @@ def _match_flag():
     return _MATCH_FLAG
 
 
+class _LazyEntries8:
+    """8-byte ``{partner, shift code}`` entries of a :class:`NeighborStream`, expanded from its 4-byte words the first time
+    a kernel asks for their address (the energy + forces path never does)."""
+
+    def __init__(self, stream):
+        self._stream = stream
+
+    def data_ptr(self):
+        return self._stream.entries8().data_ptr()
+
+
+class StreamTopology:
+    """What the pair kernels need of a :class:`~torchpme_amd.neighbors.NeighborStream`: the rows the device neighbour list
+    wrote directly (``mipme_nl_stream``: padded rows, every neighbour once per row, 4-byte words) in the clothes of a
+    :class:`PairTopology`.  There are no pair indices behind it: no pair mask, no stored distances, no (P,) gradients."""
+
+    fmt_flags = _lib.ROWS_PADDED
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.n_atoms = stream.n_atoms
+        self.entries = torch.zeros((1, 2), dtype=torch.int32, device=stream.device)  # never read (no mask / distance output)
+        self.sorted_by_first = False
+
+    @property
+    def row_ptr(self):
+        return self.stream.row_ptr
+
+    @property
+    def n_pairs(self):
+        return self.stream.indices.shape[0]
+
+    @property
+    def pairs32(self):
+        raise NotImplementedError("a NeighborStream has no (P,2) pair list; call stream.pairs() for one in the reference's format")
+
+    def compact_entries(self, shifts=None, key=None):
+        return self.stream.words if COMPACT_ENTRIES else None
+
+    def entries_with_shifts(self, shifts=None, key=None, table: bool = True):
+        if not table:
+            raise NotImplementedError("a NeighborStream carries no pair indices: `pair_mask` is not supported with it")
+        return _LazyEntries8(self.stream), 1
+
+
 _TOPOLOGIES: "OrderedDict" = OrderedDict()
 
 
 def get_topology(pairs: torch.Tensor, n_atoms: int) -> PairTopology:
     """Topology of ``pairs``, cached on the identity and version counter of the tensor object: keep the
     neighbour-list tensor alive across steps (a Verlet list) and the transposition is paid once."""
+    stream = getattr(pairs, "_mipme_stream", None)
+    if stream is not None:  # the handle of a NeighborStream: rows written by the device neighbour list, nothing to build
+        topo = stream._handle
+        if topo is None:
+            topo = stream._handle = StreamTopology(stream)
+        return topo
     key = (pairs.data_ptr(), pairs.shape[0], n_atoms, pairs.device.index)
     hit = _TOPOLOGIES.get(key)
     if hit is not None and hit[0]() is pairs and hit[1] == pairs._version:
@@ -482,12 +536,14 @@ class _PMEFunction(torch.autograd.Function):
             # atomic_pairs: one pass over the list with float atomics -- for lists that are new every call (the flattened pair
             # list of a padded batch), where building the transposed list would cost more than it saves
             topo = get_topology(pairs, N) if (PAIR_MODE == "rows" and not atomic_pairs) else None
+            if topo is not None and topo.fmt_flags:
+                full_list = False  # rows of a NeighborStream hold every neighbour once: a half list whatever the calculator says
             fused = None
             if src is not None:
                 ent_sh, shift_fmt = topo.entries_with_shifts(src.shifts, src.shifts_key, table=mask is None)
                 if ent_sh is not None:
                     fused = dict(
-                        ent_sh=ent_sh, fmt=shift_fmt, pos=src_positions.detach().contiguous(),
+                        ent_sh=ent_sh, fmt=shift_fmt | topo.fmt_flags, pos=src_positions.detach().contiguous(),
                         cell=None if src_cell is None else src_cell.detach().contiguous(), force=None, partials=None,
                         records=torch.empty((N, 4), dtype=dtype, device=device),
                     )
@@ -569,7 +625,7 @@ class _PMEFunction(torch.autograd.Function):
                 # co-scheduled pair sum: the spread launch also carries the row workgroups of the fused distance + pair kernel
                 # (mipme_sr_job_t); the gather then adds the mesh part to the potentials the pair sum wrote
                 job = None
-                if (COSCHEDULE and records_out is not None and mask is None and fused["fmt"] == 1
+                if (COSCHEDULE and records_out is not None and mask is None and (fused["fmt"] & 0xFF) == 1
                         and fused["partials"] is None and N > 0):
                     # the 4-byte entry stream is read by the co-scheduled kernel only (mipme.h, shift_format 2): use it when the
                     # library will co-schedule -- force sums wanted, 1/r or 1/r^6 with a smearing and no exclusion radius
@@ -583,7 +639,7 @@ class _PMEFunction(torch.autograd.Function):
                         entries_shift=(fused["ent_sh"] if ent32 is None else ent32).data_ptr(),
                         entries=topo.entries.data_ptr(), positions=fused["pos"].data_ptr(), cell=_lib.ptr(fused["cell"]),
                         charges=q.data_ptr(), pot=C.pointer(pot_desc), full_list=int(full_list),
-                        shift_format=fused["fmt"] if ent32 is None else 2,
+                        shift_format=fused["fmt"] if ent32 is None else (2 | topo.fmt_flags),
                         records=records_out.data_ptr(), out=out.data_ptr(), force=_lib.ptr(fused["force"]),
                         dist_out=dist.data_ptr() if write_dist else None,
                     )
@@ -912,6 +968,13 @@ class _PMEFunction(torch.autograd.Function):
 def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
                   full_list, slab_axis, nan_flag=None, atomic_pairs=False):
     src = getattr(neighbor_distances, "_mipme_src", None)
+    if getattr(neighbor_indices, "_mipme_stream", None) is not None:
+        if (src is None or atomic_pairs or pair_mask is not None or not src.direct
+                or not src.usable_for(neighbor_distances, neighbor_indices, charges.shape[1])):
+            raise ValueError(
+                "the handles of a NeighborStream serve single-channel calculators without a pair mask, together with the "
+                "distances from `stream.distances(positions, cell)` of the current positions; use `stream.pairs()` for a list in "
+                "the reference's format")
     if atomic_pairs:
         if src is not None and src.pending:
             src.materialize()
@@ -1066,6 +1129,16 @@ def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, de
         shifts_c = neighbor_shifts.to(positions.dtype)
     dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, bool(deferred),
                                      virtual=deferred == "virtual")
+    return dist
+
+
+def stream_distances(stream, positions, cell):
+    """The ``neighbor_distances`` handle of a :class:`~torchpme_amd.neighbors.NeighborStream`: an unwritten ("virtual")
+    tensor whose provenance tells the calculator to form the distances inside its fused pair kernel from ``positions`` /
+    ``cell`` and to send the pair part of the gradient straight to those tensors."""
+    _lib.require_device(positions, "positions")
+    dist = torch.empty((stream.indices.shape[0],), dtype=positions.dtype, device=positions.device)
+    dist._mipme_src = DistanceSource(positions, cell, stream.indices, None, None, dist, pending=True, virtual=True)
     return dist
 
 

@@ -24,8 +24,8 @@ def _build_list(pos: np.ndarray, cell: np.ndarray, cutoff: float):
         if torch.cuda.is_available():
             p, s, _ = neighbor_list_device(torch.tensor(pos, device="cuda"), torch.tensor(cell, device="cuda"), cutoff)
             return p.cpu().numpy(), s.cpu().numpy().round().astype(np.int64)
-    except ValueError:
-        pass  # box too small for the device cell list
+    except ImportError:
+        pass
     p, s, _ = neighbor_list(pos, cell, cutoff)
     return p, s
 
