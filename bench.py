@@ -9,15 +9,26 @@ protocol: ``d = pair_distances(...)`` -> ``V = calculato
 Ranks.  ``--gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment re-executes this script under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one process per GPU, backend
 ``nccl`` = RCCL); launched by an external ``torch.distributed.run`` it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
-Every rank owns independent frames (weak scaling, no intra-cell decomposition); the frame energies are
-exchanged with ONE all_gather after the last step, inside the timed region.  The time is the MAX over ranks.
+Every rank owns independent frames (weak scaling, no intra-cell decomposition).  With more than one rank the frame
+energies are exchanged with an all_gather AFTER EVERY EVALUATION, inside the timed loop (``--exchange per-step``, the default:
+what ``farm.farm_energies`` does; ``pipelined`` overlaps it with the next evaluation; ``final`` is round 2's single exchange
+after the last step).  Every rank binds itself to a disjoint set of host cores on its GPU's NUMA node.  The time is the MAX
+over ranks; ``weak_efficiency`` = rank 0's time with the other ranks idle / the time with all ranks busy, same invocation.
+
+Timing protocol: >= ``--prewarm-ms`` of untimed replays (clock ramp), the W warm-up steps, then ``--blocks`` blocks of EXACTLY K
+steps, each bracketed by barrier + synchronize.  ``ms_per_step`` / ``value`` are the FIRST block's (the contract's one timed
+region); ``ms_per_step_median`` is the median over the blocks.
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
   cpu_baseline -- the PyTorch-CPU oracle ("port" of the reference's ATen op sequence) timed on this host's cores
                   on a bounded sample, swept over thread counts (rank 0, N = 1 only)
   drop_in      -- the same frame through the reference's own call sequence, eager, no graph, no package-specific
-                  helpers: caller-made distances -> calculator(...) -> (q*V).sum().backward()
+                  helpers: caller-made distances -> calculator(...) -> (q*V).sum().backward(); ``cold_list_ms`` = the same
+                  with a NEW neighbor_indices tensor every call (what the reference's users do)
+  list_refresh -- the neighbour list on the device: reference-format build, the in-place refresh of the row stream the pair
+                  kernels read (one graph replay), the first step after it, and ``md_amortized_ms_per_step`` = a loop of
+                  steps with a refresh every 10 / 20 steps
 """
 
 from __future__ import annotations
@@ -65,6 +76,15 @@ def parse_args(argv=None):
     ap.add_argument("--store-distances", action="store_true",
                     help="also store the pair distances the fused pair kernel forms (a by-product nobody reads in an energy + "
                          "forces step; off: they stay in registers)")
+    ap.add_argument("--exchange", default=None, choices=["per-step", "pipelined", "final"],
+                    help="all-gather of the frame energies: after every evaluation, on the compute stream (default with more "
+                         "than one rank); after every evaluation but overlapped with the next one; or once after the last step")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (first = the reported value)")
+    ap.add_argument("--prewarm-ms", type=float, default=30.0, help="untimed replays before the warm-up steps (clock ramp)")
+    ap.add_argument("--no-list-refresh", action="store_true")
+    ap.add_argument("--neighbors", default="list", choices=["list", "stream"],
+                    help="list: the step reads the transposed (P,2) list of the workload; stream: rows written by the device "
+                         "neighbour list (GraphedEnergyForces(neighbors=cutoff))")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph: replay the captured step (HIP graph); eager: launch every kernel from Python")
     # test hook (tests/test_bench_launch.py): the launch / rendezvous / timing / reporting path on CPU ranks with the gloo
@@ -91,6 +111,49 @@ def respawn_under_torchrun(args, argv) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def _cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def bind_rank_to_cores(local_rank: int, local_world: int, device_index):
+    """Pin this rank to a disjoint slice of host cores, on its GPU's NUMA node when sysfs tells which one that is (eight
+    Python ranks replaying 70 us graphs are host-sensitive: without this they migrate across sockets).  Returns a short
+    description for the JSON line; never fails the run."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node, cores = None, None
+        if device_index is not None:
+            try:
+                props = torch.cuda.get_device_properties(device_index)
+                bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+                node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+                if node >= 0:
+                    cores = [c for c in _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in allowed]
+            except Exception:
+                node, cores = None, None
+        if cores:
+            # the ranks whose GPUs share this node split its cores: without knowing the others' nodes, use the rank's position
+            # among `local_world` ranks spread evenly over the nodes
+            n_nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]))
+            share = max(1, local_world // n_nodes)
+            k = local_rank % share
+            per = max(1, len(cores) // share)
+            mine = cores[k * per:(k + 1) * per] or cores
+        else:
+            per = max(1, len(allowed) // max(1, local_world))
+            mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        return {"numa_node": node, "cores": f"{mine[0]}-{mine[-1]}", "n_cores": len(mine)}
+    except Exception as exc:  # not fatal: report and go on unbound
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -143,6 +206,25 @@ class Frame:
         E = tpa.weighted_sum(V, self.q)
         E.backward(self.minus_one)
         return E.detach(), self.pos.grad
+
+    def step_cold_list(self, mode: str = "list"):
+        """The reference's usage with a NEW neighbour list every call (``examples/02-neighbor-lists-usage.py:97-164``).
+        ``list``: fresh ``neighbor_indices`` / shifts tensors (same values: the cost is the per-list work of the row kernels
+        -- the radix-sort transposition and the entry streams); ``stream``: the device neighbour list rebuilt in place
+        (``NeighborStream.update``) and its handles passed through the same calculator call."""
+        self.pos.grad = None
+        if mode == "stream":
+            if getattr(self, "_stream", None) is None:
+                self._stream = self._tpa.NeighborStream(self.pos, self.cell, self.w.cutoff)
+            nl = self._stream.update()
+            pairs, d = nl.indices, nl.distances(self.pos, self.cell)
+        else:
+            pairs, shifts = self.pairs.clone(), self.shifts.clone()
+            d = self._tpa.pair_distances(self.pos, pairs, self.cell, shifts)
+        V = self.calc(self.q, self.cell, self.pos, pairs, d)
+        E = (self.q * V).sum()
+        E.backward()
+        return E.detach(), -self.pos.grad
 
     def step_reference_protocol(self, distances: str = "helper"):
         """The reference's call sequence with nothing package-specific but the distance helper (the counterpart of the
@@ -329,6 +411,94 @@ def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
         if mode == "helper":
             out["rel_energy_diff_vs_fast_path"] = abs(float(E) - float(E_fast)) / abs(float(E_fast))
             out["force_rel_l2_diff_vs_fast_path"] = float((F - F_fast).norm() / F_fast.norm())
+    # a NEW list every call, as the reference's users supply it
+    for key, mode in (("cold_list_ms", "list"), ("cold_stream_ms", "stream")):
+        n = max(5, n_steps // 4)
+        for _ in range(3):
+            E, F = frame.step_cold_list(mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            E, F = frame.step_cold_list(mode)
+        torch.cuda.synchronize()
+        out[key] = 1e3 * (time.perf_counter() - t0) / n
+        out[f"{key}_rel_energy_diff_vs_fast_path"] = abs(float(E) - float(E_fast)) / abs(float(E_fast))
+    out["cold_list_note"] = ("cold_list_ms: fresh neighbor_indices / shifts tensors every call (per-list work: radix-sort "
+                             "transposition + entry streams, then the same kernels); cold_stream_ms: NeighborStream.update() "
+                             "(device cell list writes the pair kernels' rows in place) + the same calculator call")
+    return out
+
+
+def _event_ms(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def list_refresh_timing(frame, frozen_list_ms: float):
+    """What a new neighbour list costs (rank 0, one GPU), in ms: the reference-format build on the device; the per-list work
+    of the list-based row kernels; the in-place refresh of the device row stream (one replay of the captured refresh graph);
+    the first step after a refresh; and an MD-like loop with a refresh every 10 / 20 steps."""
+    tpa, w = frame._tpa, frame.w
+    from torchpme_amd import ops
+
+    out = {}
+    pos = frame.pos.detach()
+
+    def host_timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return float(np.median(ts))
+
+    out["reference_format_build_ms"] = host_timed(lambda: tpa.neighbor_list_device(pos, frame.cell, w.cutoff))
+
+    def new_list_topology():
+        pairs = frame.pairs.clone()
+        topo = ops.get_topology(pairs, w.n_atoms)
+        topo.compact_entries(frame.shifts, frame.shifts)
+
+    out["list_path_transposition_ms"] = host_timed(new_list_topology)
+    step = tpa.GraphedEnergyForces(frame.calc, frame.q, frame.cell, pos, neighbors=w.cutoff)
+    st = step.stream
+    out["row_capacity"], out["longest_row"], out["entries"] = st.row_capacity, st.longest_row, st.n_entries
+    E_stream = float(step()[0])
+    out["stream_refresh_ms"] = _event_ms(step.refresh_graph.replay, 30)
+    out["stream_step_ms"] = _event_ms(step.graph.replay, 200, 20)
+
+    def refresh_then_step():
+        step.refresh_graph.replay()
+        step.graph.replay()
+
+    out["first_step_after_refresh_ms"] = _event_ms(refresh_then_step, 30) - out["stream_refresh_ms"]
+
+    def md(interval, n=200):
+        def run():
+            for it in range(n):
+                if it % interval == 0:
+                    step.refresh_graph.replay()
+                step.graph.replay()
+        return _event_ms(run, 1, 1) / n
+
+    out["md_amortized_ms_per_step"] = {"refresh_every_10": md(10), "refresh_every_20": md(20)}
+    st.check(synchronize=True)
+    out["frozen_list_ms_per_step"] = frozen_list_ms
+    out["stream_energy"] = E_stream
+    out["note"] = ("stream_refresh_ms = one replay of the captured refresh graph (cell-list binning: 4 kernels; the walk that "
+                   "writes the 4-byte row stream + row bounds; status report) -- no (P,2) list, no sort, no re-capture of the "
+                   "step; md_amortized = wall time of 200 graph replays with a refresh every k steps / 200")
     return out
 
 
@@ -376,6 +546,9 @@ def main(argv=None):
     device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     if not stub:
         torch.cuda.set_device(device)
+    affinity = None
+    if distributed or os.environ.get("MIPME_BIND") == "1":
+        affinity = bind_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None if stub else local_rank)
 
     def sync():
         if not stub:
@@ -391,10 +564,14 @@ def main(argv=None):
         frames = [Frame(make_workload(args.workload, rank * n_frames + f), device, args.store_distances) for f in range(n_frames)]
     frame, w = frames[0], frames[0].w
     s = 4 if w.dtype == "f32" else 8
-    # the farm's ONE exchange: after its last frame evaluation every rank contributes its frame energies
-    # to an all-gather (8 B per frame), inside the timed region
+    # the farm's exchange: every rank contributes its frame energies to an all-gather (8 B per frame)
+    exchange_mode = (args.exchange or "per-step") if (distributed and world > 1) else ("final" if distributed else "none")
+    if distributed and args.exchange is not None:
+        exchange_mode = args.exchange
     my_energy = torch.zeros(n_frames, dtype=frame.dtype, device=device)
     all_energies = torch.zeros(world * n_frames, dtype=frame.dtype, device=device)
+    ring = [(torch.zeros_like(my_energy), torch.zeros_like(all_energies)) for _ in range(2)]
+    pending = [None, None]
 
     def dbg(msg):
         if os.environ.get("MIPME_BENCH_DEBUG") == "1":
@@ -405,7 +582,10 @@ def main(argv=None):
     graphed = None
     if launch == "graph":
         try:
-            graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames]
+            if args.neighbors == "stream":
+                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, neighbors=f.w.cutoff) for f in frames]
+            else:
+                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames]
         except Exception as exc:  # capture not possible on this stack: fall back to eager launches, and say so
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
             launch, graphed = "eager", None
@@ -436,49 +616,143 @@ def main(argv=None):
             for st in streams:
                 torch.cuda.current_stream(device).wait_stream(st)
 
-    def exchange(energies):
+    def energies_tensor(energies):
+        """This rank's frame energies as ONE contiguous tensor (the graphs' own static buffers where there are such)."""
+        if batch is not None:
+            return batch.energies
+        if graphed is not None and n_frames == 1:
+            return graphed[0].energy.reshape(1)
+        for k, E in enumerate(energies):
+            my_energy[k] = E.reshape(())
+        return my_energy
+
+    def exchange(i, energies):
+        """The all-gather of one evaluation.  per-step / final: on the compute stream (the next evaluation waits for it);
+        pipelined: copied to one of two slots and gathered asynchronously, waited for before the slot is reused."""
+        if not distributed:
+            return
+        src = energies_tensor(energies)
+        if exchange_mode == "pipelined":
+            k = i % 2
+            if pending[k] is not None:
+                pending[k].wait()
+            ring[k][0].copy_(src)
+            pending[k] = dist.all_gather_into_tensor(ring[k][1], ring[k][0], async_op=True)
+        else:
+            dist.all_gather_into_tensor(all_energies, src)
+
+    def drain(last_i):
+        if distributed and exchange_mode == "pipelined":
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+            all_energies.copy_(ring[last_i % 2][1])
+
+    def run_steps(n, with_exchange=True):
+        E = None
+        for i in range(n):
+            E = one_step()
+            if with_exchange and exchange_mode in ("per-step", "pipelined"):
+                join_streams()
+                exchange(i, E)
+        join_streams()
+        if with_exchange and exchange_mode == "final" and E is not None:
+            exchange(0, E)
+        if with_exchange and n > 0:
+            drain(n - 1)
+        return E
+
+    def timed_block(n, only_rank0=False):
+        """EXACTLY n steps bracketed by barrier + synchronize on both sides; only_rank0: the other ranks stay idle (and there
+        is no exchange), for the one-rank reference time of weak_efficiency."""
+        sync()
         if distributed:
-            for k, E in enumerate(energies):
-                my_energy[k] = E.reshape(())
-            dist.all_gather_into_tensor(all_energies, my_energy)
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        E = None
+        if not only_rank0 or rank == 0:
+            E = run_steps(n, with_exchange=not only_rank0)
+        sync()
+        dt_own = time.perf_counter() - t0  # this rank's own time (before it waits for the others)
+        if distributed:
+            dist.barrier()
+        sync()
+        return dt_own, E
 
     dbg("graph captured" if graphed is not None else "eager mode")
-    for _ in range(args.warmup):
-        E = one_step()
-    join_streams()
-    exchange(E)
+    # clock ramp: a fresh box needs tens of ms of work before its clocks settle (round 2: 7 % between a 1.5 ms timed region
+    # right after 5 replays and a long run)
+    n_prewarm, t_pre = 0, time.perf_counter()
+    while not stub and 1e3 * (time.perf_counter() - t_pre) < args.prewarm_ms:
+        run_steps(20, with_exchange=False)
+        sync()
+        n_prewarm += 20
+    E = run_steps(args.warmup)
     dbg("warm-up done")
-    sync()
+    t_alone = None
+    if distributed and world > 1:
+        t_alone, _ = timed_block(args.steps, only_rank0=True)
+    block_times = []
+    for b in range(max(1, args.blocks)):
+        dt_own, Eb = timed_block(args.steps)
+        E = Eb if Eb is not None else E
+        block_times.append(dt_own)
+    dbg("timed loops done")
+    own = torch.tensor(block_times + [t_alone or 0.0], dtype=torch.float64, device=device)
     if distributed:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        E = one_step()
-    join_streams()
-    exchange(E)
-    sync()
-    if distributed:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
-    dbg("timed loop done")
-    per_rank_ms = [1e3 * elapsed / args.steps]
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        gathered = torch.zeros(world, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(gathered, tt)
-        per_rank_ms = [1e3 * float(v) / args.steps for v in gathered.tolist()]
-        elapsed = float(gathered.max().item())  # MAX over ranks
+        flat = torch.zeros(world * own.numel(), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(flat, own)
+        gathered = flat.reshape(world, own.numel())
+    else:
+        gathered = own.reshape(1, -1)
+    per_block = gathered[:, :-1].max(dim=0).values.tolist()  # MAX over ranks, per block
+    per_rank_ms = [1e3 * float(v) / args.steps for v in gathered[:, 0].tolist()]
+    elapsed = per_block[0]  # the contract's one timed region: the first block
     ms_per_step = 1e3 * elapsed / args.steps
+    blocks_ms = [1e3 * v / args.steps for v in per_block]
     value = world * n_frames * w.n_atoms * args.steps / elapsed
+    weak_efficiency = None
+    if t_alone is not None or (distributed and world > 1):
+        t1 = float(gathered[0, -1])
+        weak_efficiency = {
+            "value": t1 / elapsed if elapsed > 0 else None,
+            "median_blocks": t1 / float(np.median(per_block)),
+            "one_rank_ms_per_step": 1e3 * t1 / args.steps,
+            "definition": "rank 0's time for the same K steps with the other ranks idle (no exchange) / MAX-over-ranks time "
+                          "with all ranks busy and the exchange in the loop; same invocation, same clocks",
+        }
+    rank_info = {"rank": rank, "local_rank": local_rank, "affinity": affinity}
+    if not stub:
+        props = torch.cuda.get_device_properties(device)
+        rank_info["device"] = {"name": props.name, "uuid": str(getattr(props, "uuid", None)),
+                               "pci": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:"
+                                      f"{getattr(props, 'pci_device_id', 0):02x}"}
+    ranks = [rank_info]
+    if distributed:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
     parallelism = {
         "n_ranks": world,
         "backend": (f"{backend} ({'RCCL' if backend == 'nccl' else 'CPU test'}), world size reported by the backend"
                     if distributed else "none (single process)"),
-        "collective": "one all_gather_into_tensor of the frame energies per timed region" if distributed else None,
+        "exchange": exchange_mode,
+        "collective": ({"per-step": "all_gather_into_tensor of the frame energies after EVERY evaluation, on the compute stream, "
+                                    "inside the timed loop",
+                        "pipelined": "all_gather_into_tensor after every evaluation, asynchronous (two slots), inside the timed loop",
+                        "final": "one all_gather_into_tensor of the frame energies per timed region"}[exchange_mode]
+                       if distributed else None),
         "per_rank_ms_per_step": [round(v, 6) for v in per_rank_ms],
+        "ranks": ranks,
     }
+    timing = {
+        "prewarm_ms": args.prewarm_ms, "prewarm_steps": n_prewarm, "blocks": len(blocks_ms),
+        "blocks_ms_per_step": [round(v, 6) for v in blocks_ms],
+        "protocol": "untimed replays for >= prewarm_ms, W warm-up steps, then `blocks` blocks of exactly K steps, each bracketed by "
+                    "barrier + synchronize; ms_per_step / value = first block, ms_per_step_median = median over the blocks",
+    }
+    ms_per_step_median = float(np.median(blocks_ms))
 
     if stub:
         if rank == 0:
@@ -489,6 +763,8 @@ def main(argv=None):
                 "data": "stub evaluator on CPU ranks (launch-path test; NOT a measurement of the hot path)",
                 "config": {"workload": "stub", "frames_per_gpu": n_frames}, "parallelism": parallelism,
                 "energies_gathered": int(all_energies.numel()) if distributed else n_frames,
+                "energies_sum": float(all_energies.sum()) if distributed else None,
+                "ms_per_step_median": ms_per_step_median, "timing": timing, "weak_efficiency": weak_efficiency,
             }))
         if distributed:
             dist.destroy_process_group()
@@ -565,6 +841,10 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_median": ms_per_step_median,
+            "value_median": world * n_frames * w.n_atoms / (ms_per_step_median * 1e-3),
+            "timing": timing,
+            "weak_efficiency": weak_efficiency,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -576,6 +856,7 @@ def main(argv=None):
                             f"{'Coulomb' if w.exponent == 1 else '1/r^%d' % w.exponent}, {w.dtype}, energy+forces via autograd",
                 "preset": args.preset,
                 "frames_per_gpu": n_frames,
+                "neighbors": args.neighbors,
                 "launch": ("HIP graph replay of the captured step"
                            + (", all frames in one launch per kernel (GraphedFrameBatch)" if batch is not None
                               else ", one stream per frame" if streams is not None else ""))
@@ -617,6 +898,12 @@ def main(argv=None):
             "energy": float(E[0].item()),
             "accuracy": accuracy,
         }
+        if world == 1 and n_frames == 1 and not args.no_list_refresh:
+            try:
+                out["list_refresh"] = list_refresh_timing(frame, ms_per_step_median)
+                out["md_amortized_ms_per_step"] = out["list_refresh"]["md_amortized_ms_per_step"]
+            except Exception as exc:  # e.g. more than 2^22 atoms: say so instead of losing the line
+                out["list_refresh"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_drop_in:
             out["drop_in"] = drop_in_timing(frame)
         if world == 1 and not args.no_cpu_baseline:

@@ -527,7 +527,9 @@ int mipme_nl_count(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atom
                    void* counts /* int32[N] */);
 int mipme_nl_fill(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, void* workspace,
                   const void* offsets /* int64[N+1] */, void* pairs, void* shifts, void* dist /* nullable */);
-/* row_ptr int32[3N+1], words int32[N * row_capacity + 1].  host_status (nullable): int32[4] of PINNED host memory that
+/* row_ptr int32[3N+1], words int32[N * row_capacity + 1], ZERO-FILLED ONCE by the caller (the pair kernels prefetch one step
+ * past the end of a row and give what they find zero weight: it must decode to a valid atom and shift code, which zero and
+ * any stale entry do).  host_status (nullable): int32[4] of PINNED host memory that
  * receives, when the call has run, {longest row, flags, refresh counter}: flags bit 0 = a row exceeded row_capacity (its
  * surplus entries were dropped: enlarge and rebuild), bit 1 = a cell shift beyond the pair kernels' table (|S| > 3: wrap the
  * positions or use (a)), bit 2 = an atom more than 400 cells outside the unit cell.  The counter (written last, release order)

@@ -37,6 +37,25 @@ def test_gpus_flag_spawns_ranks():
     assert out["steps"] == 3 and out["warmup"] == 1
 
 
+def test_exchange_modes_gather_the_same_energies():
+    """per-step (default with > 1 rank: the all-gather after EVERY evaluation, inside the timed loop), pipelined (asynchronous,
+    two slots) and final (round 2's single exchange) must deliver the same frame energies; the line carries the protocol."""
+    sums = {}
+    for mode in ("per-step", "pipelined", "final"):
+        out = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-gpu", "2", "--blocks", "2", "--exchange", mode)
+        assert out["parallelism"]["exchange"] == mode and out["energies_gathered"] == 4
+        assert out["timing"]["blocks"] == 2 and len(out["timing"]["blocks_ms_per_step"]) == 2
+        assert out["ms_per_step"] == pytest.approx(out["timing"]["blocks_ms_per_step"][0], rel=1e-4)
+        assert out["weak_efficiency"]["value"] > 0 and out["weak_efficiency"]["one_rank_ms_per_step"] > 0
+        assert [r["rank"] for r in out["parallelism"]["ranks"]] == [0, 1]
+        cores = [r["affinity"].get("cores") for r in out["parallelism"]["ranks"]]
+        assert cores[0] != cores[1] or cores[0] is None  # disjoint core sets when the host has more than one core
+        sums[mode] = out["energies_sum"]
+    assert sums["per-step"] == pytest.approx(sums["final"], rel=1e-12) == pytest.approx(sums["pipelined"], rel=1e-12)
+    out = _run("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert out["parallelism"]["exchange"] == "per-step"  # the default with more than one rank
+
+
 def test_single_rank_default():
     out = _run("--steps", "2", "--warmup", "1")
     assert out["n_gpus"] == 1 and out["parallelism"]["n_ranks"] == 1

@@ -215,10 +215,11 @@ enum NlMode { kNlCount = 0, kNlFill = 1, kNlStream = 2 };
 
 static constexpr int kNlCap = 1216;   // candidates staged per round (19 x 64)
 static constexpr int kNlBatch = 32;   // atoms of the cell served per staging
+static constexpr int kNlList = 512;   // survivors a wavefront gathers before it emits them
 static constexpr int kNlSegs = 256;   // runs of cells described per staging group
 static constexpr int kNlThreads = 256;
-// LDS: 32 B per candidate + 2 B per candidate and wavefront (survivor lists) + run table + the batch's own records = 53 KB:
-// three workgroups per CU
+static_assert(kNlSegs == kNlThreads && (kNlSegs & (kNlSegs - 1)) == 0 && kNlCap % 64 == 0, "run table: one run per thread");
+// LDS: 32 B per candidate + the survivor lists + run table + the batch's own records = 49 KB: three workgroups per CU
 
 struct NlOut {
   // kNlCount
@@ -241,10 +242,10 @@ __device__ __forceinline__ int floordiv(int a, int n) {
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(kNlThreads) void nl_walk_kernel(NlGeom g, int64_t N, unsigned n_cells, NlWorkspace ws, NlOut o) {
-  __shared__ double sX[kNlCap], sY[kNlCap], sZ[kNlCap];
-  __shared__ int sJ[kNlCap], sS[kNlCap];
-  __shared__ unsigned short sList[kNlThreads / 64][kNlCap];
-  __shared__ int gBeg[kNlSegs], gOff[kNlSegs + 1], gShift[kNlSegs];
+  __shared__ double sX[kNlCap + 64], sY[kNlCap + 64], sZ[kNlCap + 64];
+  __shared__ int sJ[kNlCap + 64], sS[kNlCap + 64];
+  __shared__ unsigned short sList[kNlThreads / 64][kNlList];
+  __shared__ int gBeg[kNlSegs], gOff[kNlSegs + 1], gShift[kNlSegs], gWave[kNlThreads / 64];
   __shared__ double oX[kNlBatch], oY[kNlBatch], oZ[kNlBatch];
   __shared__ int oA[kNlBatch], oW[kNlBatch], oCur[kNlBatch], oBad[kNlBatch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,8 +254,6 @@ __global__ __launch_bounds__(kNlThreads) void nl_walk_kernel(NlGeom g, int64_t N
   }
   const unsigned c = xcd_contiguous(blockIdx.x, n_cells);
   if (c >= n_cells) return;
-  const int cbeg = ws.start[c], na = ws.start[c + 1] - cbeg;
-  if (na == 0) return;
   const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
   const int cz0 = int(c % unsigned(ncz)), cy0 = int((c / unsigned(ncz)) % unsigned(ncy)), cx0 = int(c / unsigned(ncz * ncy));
   // runs of cells along z that are contiguous in memory and share one image shift: the same for every (x, y) column
@@ -267,70 +266,116 @@ __global__ __launch_bounds__(kNlThreads) void nl_walk_kernel(NlGeom g, int64_t N
   }
   const int nxs = 2 * g.reach[0] + 1, nys = 2 * g.reach[1] + 1;
   const int nseg = nxs * nys * nzrun;
+  // the run table of a group of kNlSegs runs: first record, record count, image shift -- one run per thread, so that all
+  // the cell-start loads of the group are in flight together (and, for the first group, together with the cell's own bounds)
+  auto describe_runs = [&](int seg0) {
+    const int ns = min(kNlSegs, nseg - seg0);
+    int cnt = 0;
+    if (tid < ns) {
+      const int sidx = seg0 + tid;
+      const int ir = sidx % nzrun, iy = (sidx / nzrun) % nys, ix = sidx / (nzrun * nys);
+      const int X = cx0 + ix - g.reach[0], sx = floordiv(X, ncx), xx = X - sx * ncx;
+      const int Y = cy0 + iy - g.reach[1], sy = floordiv(Y, ncy), yy = Y - sy * ncy;
+      int z = zlo, sz = 0, zz = 0, len = 0;
+      for (int r = 0; r <= ir; ++r) {
+        sz = floordiv(z, ncz);
+        zz = z - sz * ncz;
+        len = min(ncz - zz, zhi - z + 1);
+        z += len;
+      }
+      const bool valid = (g.periodic[0] || sx == 0) && (g.periodic[1] || sy == 0) && (g.periodic[2] || sz == 0);
+      if (valid) {
+        const int cell0 = (xx * ncy + yy) * ncz + zz;
+        const int beg = ws.start[cell0];
+        cnt = ws.start[cell0 + len] - beg;
+        gBeg[tid] = beg;
+        gShift[tid] = pack3(sx, sy, sz);
+      }
+    }
+    gOff[tid + 1] = cnt;
+    if (tid == 0) gOff[0] = 0;
+  };
+  describe_runs(0);
+  const int cbeg = ws.start[c], na = ws.start[c + 1] - cbeg;
+  if (na == 0) return;
 
   // survivors of `n` staged candidates for the atoms of the batch this wavefront owns: a pass over all candidates that only
-  // measures distances and compacts the indices of the close ones, then a dense pass over those
+  // measures distances and compacts the indices of the close ones (two blocks of 64 per step, all LDS loads of a step in
+  // flight together), and a dense pass over the survivors whenever kNlList of them have gathered
   auto process = [&](int n, int nb) {
     unsigned short* __restrict__ list = sList[wave];
     for (int k = wave; k < nb; k += kNlThreads / 64) {
       const double rx = oX[k], ry = oY[k], rz = oZ[k];
       const int a = oA[k], wi = oW[k];
-      int cnt = 0;
-      for (int base = 0; base < n; base += 64) {
-        const int cc = base + lane;  // (kNlCap is a multiple of 64: always inside the arrays)
-        const double vx = sX[cc] - rx, vy = sY[cc] - ry, vz = sZ[cc] - rz;
-        const double d2 = vx * vx + vy * vy + vz * vz;
-        // the atom itself (its image with zero shift) is the one candidate at distance exactly 0 with its own index
-        const bool ok = cc < n && d2 < g.cutoff2 && !(d2 == 0.0 && sJ[cc] == a);
-        const unsigned long long m = __ballot(ok);
-        if (ok) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)cc;
-        cnt += __popcll(m);
-      }
-      __threadfence_block();  // the list is read back by other lanes of this wavefront
       const int wix = unpack3(wi, 0), wiy = unpack3(wi, 1), wiz = unpack3(wi, 2);
       int cur = oCur[k];
       bool bad = false;
-      for (int k0 = 0; k0 < cnt; k0 += 64) {
-        const bool in = k0 + lane < cnt;
-        const int cc = in ? int(list[k0 + lane]) : 0;
-        const int j = sJ[cc], sp = sS[cc];
-        const int Sx = unpack3(sp, 0) + wix, Sy = unpack3(sp, 1) + wiy, Sz = unpack3(sp, 2) + wiz;  // S = s - w_j + w_i
-        bool ok = in;
-        if constexpr (MODE != kNlStream) {
-          if (!g.full_list) {
-            const bool lexpos = Sx > 0 || (Sx == 0 && (Sy > 0 || (Sy == 0 && Sz > 0)));
-            ok = ok && ((a < j) || (a == j && lexpos));
+      int cnt = 0;
+      auto emit = [&]() {
+        __threadfence_block();  // the list is read back by other lanes of this wavefront
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+          const bool in = k0 + lane < cnt;
+          const int cc = in ? int(list[k0 + lane]) : 0;
+          const int j = sJ[cc], sp = sS[cc];
+          const int Sx = unpack3(sp, 0) + wix, Sy = unpack3(sp, 1) + wiy, Sz = unpack3(sp, 2) + wiz;  // S = s - w_j + w_i
+          bool ok = in;
+          if constexpr (MODE != kNlStream) {
+            if (!g.full_list) {
+              const bool lexpos = Sx > 0 || (Sx == 0 && (Sy > 0 || (Sy == 0 && Sz > 0)));
+              ok = ok && ((a < j) || (a == j && lexpos));
+            }
           }
-        }
-        int at = cur + lane, step = min(64, cnt - k0);
-        if constexpr (MODE != kNlStream) {
-          const unsigned long long m = __ballot(ok);
-          at = cur + __popcll(m & ((1ull << lane) - 1ull));
-          step = __popcll(m);
-        }
-        if constexpr (MODE == kNlFill) {
-          if (ok) {
-            const double vx = sX[cc] - rx, vy = sY[cc] - ry, vz = sZ[cc] - rz;
-            const int64_t dst = o.offsets[a] + at;
-            o.pairs[2 * dst] = a;
-            o.pairs[2 * dst + 1] = j;
-            T* __restrict__ sh = (T*)o.shifts;
-            sh[3 * dst] = T(Sx);
-            sh[3 * dst + 1] = T(Sy);
-            sh[3 * dst + 2] = T(Sz);
-            if (o.dist) ((T*)o.dist)[dst] = T(sqrt(vx * vx + vy * vy + vz * vz));
+          int at = cur + lane, step = min(64, cnt - k0);
+          if constexpr (MODE != kNlStream) {
+            const unsigned long long m = __ballot(ok);
+            at = cur + __popcll(m & ((1ull << lane) - 1ull));
+            step = __popcll(m);
           }
+          if constexpr (MODE == kNlFill) {
+            if (ok) {
+              const double vx = sX[cc] - rx, vy = sY[cc] - ry, vz = sZ[cc] - rz;
+              const int64_t dst = o.offsets[a] + at;
+              o.pairs[2 * dst] = a;
+              o.pairs[2 * dst + 1] = j;
+              T* __restrict__ sh = (T*)o.shifts;
+              sh[3 * dst] = T(Sx);
+              sh[3 * dst + 1] = T(Sy);
+              sh[3 * dst + 2] = T(Sz);
+              if (o.dist) ((T*)o.dist)[dst] = T(sqrt(vx * vx + vy * vy + vz * vz));
+            }
+          }
+          if constexpr (MODE == kNlStream) {
+            const unsigned ux = unsigned(Sx + kShiftTableRange), uy = unsigned(Sy + kShiftTableRange),
+                           uz = unsigned(Sz + kShiftTableRange);
+            const bool fits = max(max(ux, uy), uz) < unsigned(kShiftTableBase);
+            bad |= ok && !fits;
+            const int code = fits ? int(ux + kShiftTableBase * (uy + kShiftTableBase * uz)) : 0;
+            if (ok && at < o.stride) o.words[a * o.stride + at] = j | (code << kCompactAtomBits);
+          }
+          cur += step;
         }
-        if constexpr (MODE == kNlStream) {
-          const unsigned ux = unsigned(Sx + kShiftTableRange), uy = unsigned(Sy + kShiftTableRange),
-                         uz = unsigned(Sz + kShiftTableRange);
-          const bool fits = ux < unsigned(kShiftTableBase) && uy < unsigned(kShiftTableBase) && uz < unsigned(kShiftTableBase);
-          bad |= ok && !fits;
-          const int code = fits ? int(ux + kShiftTableBase * (uy + kShiftTableBase * uz)) : 0;
-          if (ok && at < o.stride) o.words[a * o.stride + at] = j | (code << kCompactAtomBits);
-        }
-        cur += step;
+        cnt = 0;
+      };
+      // the atom itself (its image with zero shift) is the one candidate at distance exactly 0 that carries its own index
+      auto close = [&](int cc, double x, double y, double z, int j) {
+        const double vx = x - rx, vy = y - ry, vz = z - rz;
+        const double d2 = vx * vx + vy * vy + vz * vz;
+        return (cc < n) & (d2 < g.cutoff2) & !((d2 == 0.0) & (j == a));
+      };
+      for (int base = 0; base < n; base += 128) {
+        const int c0 = base + lane, c1 = c0 + 64;  // (the arrays are padded by 64: always inside)
+        const double x0 = sX[c0], y0 = sY[c0], z0 = sZ[c0], x1 = sX[c1], y1 = sY[c1], z1 = sZ[c1];
+        const int j0 = sJ[c0], j1 = sJ[c1];
+        const bool ok0 = close(c0, x0, y0, z0, j0), ok1 = close(c1, x1, y1, z1, j1);
+        const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ok0) list[cnt + __popcll(m0 & below)] = (unsigned short)c0;
+        cnt += __popcll(m0);
+        if (ok1) list[cnt + __popcll(m1 & below)] = (unsigned short)c1;
+        cnt += __popcll(m1);
+        if (cnt > kNlList - 128) emit();
       }
+      emit();
       if (lane == 0) oCur[k] = cur;
       if constexpr (MODE == kNlStream) {
         if (__ballot(bad) != 0ull && lane == 0) oBad[k] = 1;
@@ -352,65 +397,63 @@ __global__ __launch_bounds__(kNlThreads) void nl_walk_kernel(NlGeom g, int64_t N
       oBad[tid] = 0;
     }
     for (int seg0 = 0; seg0 < nseg; seg0 += kNlSegs) {
-      const int ns = min(kNlSegs, nseg - seg0);
-      // (a) the runs of this group: first record, record count, image shift -- one run per thread, loads in parallel
-      if (tid < kNlSegs) {
-        int cnt = 0;
-        if (tid < ns) {
-          const int sidx = seg0 + tid;
-          const int ir = sidx % nzrun, iy = (sidx / nzrun) % nys, ix = sidx / (nzrun * nys);
-          const int X = cx0 + ix - g.reach[0], sx = floordiv(X, ncx), xx = X - sx * ncx;
-          const int Y = cy0 + iy - g.reach[1], sy = floordiv(Y, ncy), yy = Y - sy * ncy;
-          int z = zlo, sz = 0, zz = 0, len = 0;
-          for (int r = 0; r <= ir; ++r) {
-            sz = floordiv(z, ncz);
-            zz = z - sz * ncz;
-            len = min(ncz - zz, zhi - z + 1);
-            z += len;
-          }
-          const bool valid = (g.periodic[0] || sx == 0) && (g.periodic[1] || sy == 0) && (g.periodic[2] || sz == 0);
-          if (valid) {
-            const int cell0 = (xx * ncy + yy) * ncz + zz;
-            const int beg = ws.start[cell0];
-            cnt = ws.start[cell0 + len] - beg;
-            gBeg[tid] = beg;
-            gShift[tid] = pack3(sx, sy, sz);
-          }
-        }
-        gOff[tid + 1] = cnt;
-      }
-      if (tid == 0) gOff[0] = 0;
+      // (a) the run table (the first group's is already there, and stays valid across batches when it is the only one)
+      if (seg0 > 0 || (b0 > 0 && nseg > kNlSegs)) describe_runs(seg0);
+      const bool rescan = b0 == 0 || nseg > kNlSegs;
       __syncthreads();
-      // (b) inclusive scan of the counts (kNlSegs values, one per thread)
-      for (int off = 1; off < kNlSegs; off <<= 1) {
-        int v = 0;
-        if (tid < kNlSegs && tid >= off) v = gOff[tid + 1 - off];
+      // (b) inclusive scan of the counts: one value per thread, shuffle scan inside each wavefront + the totals of the
+      // wavefronts before it (two barriers instead of sixteen)
+      if (rescan) {
+        int v = gOff[tid + 1];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int u = __shfl_up(v, off, 64);
+          if (lane >= off) v += u;
+        }
+        if (lane == 63) gWave[wave] = v;
         __syncthreads();
-        if (tid < kNlSegs) gOff[tid + 1] += v;
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < kNlThreads / 64; ++w) before += (w < wave) ? gWave[w] : 0;
+        gOff[tid + 1] = v + before;
         __syncthreads();
       }
       const int total = gOff[kNlSegs];
-      // (c) candidates in flattened order, kNlCap at a time
+      // (c) candidates in flattened order, kNlCap at a time: every thread first finds the runs of all its candidates, then
+      // issues all its record loads, then writes (a loop of search -> load -> store per candidate spent a memory round trip
+      // per candidate and thread)
       for (int f0 = 0; f0 < total; f0 += kNlCap) {
         const int n = min(kNlCap, total - f0);
-        for (int t = tid; t < n; t += kNlThreads) {
-          const int f = f0 + t;
-          int lo = 0, hi = kNlSegs - 1;  // largest run with gOff[run] <= f
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (gOff[mid] <= f)
-              lo = mid;
-            else
-              hi = mid - 1;
+        constexpr int K = (kNlCap + kNlThreads - 1) / kNlThreads;
+        int run[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int f = f0 + tid + u * kNlThreads;
+          int lo = 0;  // largest run with gOff[run] <= f
+#pragma unroll
+          for (int stp = kNlSegs / 2; stp > 0; stp >>= 1) lo += (gOff[lo + stp] <= f) ? stp : 0;
+          run[u] = lo;
+        }
+        CellRec rec[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int t = tid + u * kNlThreads;
+          const int src = t < n ? gBeg[run[u]] + (f0 + t - gOff[run[u]]) : cbeg;
+          rec[u] = ws.rec[src];
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int t = tid + u * kNlThreads;
+          if (t < n) {
+            const CellRec r = rec[u];
+            const int sp = gShift[run[u]];
+            const int sx = unpack3(sp, 0), sy = unpack3(sp, 1), sz = unpack3(sp, 2);
+            sX[t] = r.x + (sx * g.cell[0] + sy * g.cell[3] + sz * g.cell[6]);
+            sY[t] = r.y + (sx * g.cell[1] + sy * g.cell[4] + sz * g.cell[7]);
+            sZ[t] = r.z + (sx * g.cell[2] + sy * g.cell[5] + sz * g.cell[8]);
+            sJ[t] = r.j;
+            sS[t] = pack3(sx - unpack3(r.w, 0), sy - unpack3(r.w, 1), sz - unpack3(r.w, 2));
           }
-          const CellRec r = ws.rec[gBeg[lo] + (f - gOff[lo])];
-          const int sp = gShift[lo];
-          const int sx = unpack3(sp, 0), sy = unpack3(sp, 1), sz = unpack3(sp, 2);
-          sX[t] = r.x + (sx * g.cell[0] + sy * g.cell[3] + sz * g.cell[6]);
-          sY[t] = r.y + (sx * g.cell[1] + sy * g.cell[4] + sz * g.cell[7]);
-          sZ[t] = r.z + (sx * g.cell[2] + sy * g.cell[5] + sz * g.cell[8]);
-          sJ[t] = r.j;
-          sS[t] = pack3(sx - unpack3(r.w, 0), sy - unpack3(r.w, 1), sz - unpack3(r.w, 2));
         }
         __syncthreads();
         process(n, nb);

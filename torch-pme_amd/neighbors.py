@@ -304,7 +304,10 @@ class NeighborStream:
         #: (3N + 1,) int32: begin, end, end of every row; the last word is the size of the entry buffer
         self.row_ptr = torch.zeros((3 * N + 1,), dtype=torch.int32, device=self.device)
         #: (N * row_capacity + 1,) int32 words ``partner | shift code << 22``
-        self.words = torch.empty((N * row_capacity + 1,), dtype=torch.int32, device=self.device)
+        # zero-filled ONCE: the packed pair kernel prefetches one step past the end of a row and multiplies what it finds by
+        # a zero weight -- the padding must decode to a valid atom / shift code (0 | 0 does; so does any stale entry), never
+        # to whatever the allocator left behind
+        self.words = torch.zeros((N * row_capacity + 1,), dtype=torch.int32, device=self.device)
         #: opaque handle for the ``neighbor_indices`` argument of the calculators: a (1, 2) tensor whose contents are undefined
         self.indices = torch.zeros((1, 2), dtype=torch.int32, device=self.device)
         self.indices._mipme_stream = self
