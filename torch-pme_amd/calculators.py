@@ -313,7 +313,11 @@ class EwaldCalculator(Calculator):
         c = self._freq_cache
         if c is not None and c[0]() is cell and c[1] == cell._version and c[2] == cell.device and c[3] == self.lr_wavelength:
             return c[4]
-        norms = np.linalg.norm(cell.detach().to("cpu", torch.float64).numpy(), axis=1)
+        cell_host = cell.detach().to("cpu", torch.float64).numpy()
+        det = float(np.linalg.det(cell_host))
+        if det == 0.0 or not np.isfinite(det):  # the cross-product inverse below would quietly produce inf / NaN k-vectors
+            raise ValueError(f"provided `cell` has a determinant of {det}, i.e. it is not a valid unit cell")
+        norms = np.linalg.norm(cell_host, axis=1)
         ns = np.ceil(norms / self.lr_wavelength).astype(np.int64)
         f = [np.fft.fftfreq(int(n)) * int(n) for n in ns]
         F = np.stack(np.meshgrid(*f, indexing="ij"), axis=-1).reshape(-1, 3)

@@ -12,6 +12,8 @@
 // (reference lib/mesh_interpolator.py:303-457).
 #include <algorithm>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 #include "rows_body.h"
 
@@ -73,10 +75,21 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 //   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
 //         gathers of the forward and by everything in the backward pass.
 struct BinsLayout {
-  size_t snap, over_brick, rec, wts, epart, total;
+  size_t snap, over_brick, rec, wts, epart, det, det_sort_bytes, total;
   int cap;
   int64_t slots;  // nb * cap + N
 };
+
+// MIPME_DETERMINISTIC=1: bit-reproducible results run to run ("race detection").  The one-pass binning hands out
+// brick slots with returning atomics and the spread's candidate scan appends its survivors with LDS atomics, so in fp32 the
+// mesh values -- sums over a brick's atoms -- depend on arrival order in the last bits.  In this mode the slots come from a
+// stable radix sort of the atoms by brick (slot = rank by atom index inside the brick; the overflow region is ordered the
+// same way) and every round of survivors is sorted by slot before it is staged: every sum then runs in one fixed order.
+// Costs a sort per evaluation (three more launches); read once per process.
+static bool deterministic_mode() {
+  static const bool on = env_flag("MIPME_DETERMINISTIC", false);
+  return on;
+}
 static constexpr int kRowsPerSpreadBlock = 512 / kRowLanes;  // rows per workgroup of the co-scheduled pair sum (SPREAD_THREADS)
 static constexpr int kSpreadWaves = 512 / 64;
 
@@ -102,6 +115,15 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.wts = off;        off += al(6 * size_t(m->order) * s * size_t(l.slots));  // per slot: wx, wy, wz, dwx, dwy, dwz (n each)
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
+  l.det = off;
+  l.det_sort_bytes = 0;
+  if (deterministic_mode()) {  // keys, vals, keys2, vals2, slot_of, over_flag (N words each) + the sort's scratch
+    size_t sb = 0;
+    unsigned* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, sb, nul, nul, nul, nul, size_t(N > 0 ? N : 1), 0u, 32u, hipStream_t(0), false);
+    l.det_sort_bytes = sb;
+    off += 6 * al(sizeof(int) * size_t(N > 0 ? N : 1)) + al(sb);
+  }
   l.total = off;
   return l;
 }
@@ -159,7 +181,8 @@ template <int SCHEME, int N, typename T, bool COALESCE = false>
 __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& bg, const BinIndex& bi, int64_t Natoms,
                                                const T* __restrict__ pos, int* __restrict__ over_brick,
                                                int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
-                                               AtomRecord<T>* __restrict__ atom_rec, unsigned block) {
+                                               AtomRecord<T>* __restrict__ atom_rec, unsigned block,
+                                               const int* __restrict__ slot_of = nullptr) {
   const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
   const bool valid = i < Natoms;
   const int lane = threadIdx.x & 63;
@@ -170,31 +193,39 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     atom_mesh_coords<T>(g, (N % 2) == 0, pos, i, m, x);
     b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
   }
-  // pass 1 (no memory traffic): group the lanes by brick; every lane learns its leader lane and its rank
-  unsigned long long remaining = __ballot(valid);
-  int my_leader = lane, my_rank = 0, my_count = 0;
-  while (remaining) {
-    const int leader = __ffsll((long long)remaining) - 1;
-    const int b0 = __shfl(b, leader, 64);
-    const unsigned long long peers = __ballot(valid && b == b0);
-    if (valid && b == b0) {
-      my_leader = leader;
-      my_rank = __popcll(peers & ((1ull << lane) - 1ull));
-      my_count = __popcll(peers);
+  int myslot = 0, over_k = -1;
+  if (slot_of) {  // deterministic mode: slots (and the live counters) come from the sorted atom list, see det_slots_kernel
+    if (valid) {
+      myslot = slot_of[i];
+      if (myslot >= bi.cap) over_k = myslot - bi.cap;
     }
-    remaining &= ~peers;
+  } else {
+    // pass 1 (no memory traffic): group the lanes by brick; every lane learns its leader lane and its rank
+    unsigned long long remaining = __ballot(valid);
+    int my_leader = lane, my_rank = 0, my_count = 0;
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int b0 = __shfl(b, leader, 64);
+      const unsigned long long peers = __ballot(valid && b == b0);
+      if (valid && b == b0) {
+        my_leader = leader;
+        my_rank = __popcll(peers & ((1ull << lane) - 1ull));
+        my_count = __popcll(peers);
+      }
+      remaining &= ~peers;
+    }
+    // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
+    int base = 0;
+    if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
+    base = __shfl(base, my_leader, 64);
+    myslot = base + my_rank;
   }
-  // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
-  int base = 0;
-  if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
-  base = __shfl(base, my_leader, 64);
-  const int myslot = base + my_rank;
   int64_t dst = 0;
   if (valid) {
     if (myslot < bi.cap) {
       dst = int64_t(b) * bi.cap + myslot;
     } else {  // brick full: overflow region (rare; one atomic per atom)
-      const int k = atomicAdd(&bi.live[bi.nb], 1);
+      const int k = over_k >= 0 ? over_k : atomicAdd(&bi.live[bi.nb], 1);
       over_brick[k] = b;
       dst = bi.over_base + k;
     }
@@ -262,8 +293,79 @@ template <int SCHEME, int N, typename T, bool COALESCE>
 __global__ __launch_bounds__(256) void bin_atoms_kernel(Geom g, BrickGeom bg, BinIndex bi, int64_t Natoms,
                                                        const T* __restrict__ pos, int* __restrict__ over_brick,
                                                        int4* __restrict__ rec, T* __restrict__ wts,
-                                                       const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec) {
-  bin_atoms_body<SCHEME, N, T, COALESCE>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x);
+                                                       const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec,
+                                                       const int* __restrict__ slot_of) {
+  bin_atoms_body<SCHEME, N, T, COALESCE>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x, slot_of);
+}
+
+// ---- deterministic slots (MIPME_DETERMINISTIC) -----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void det_keys_kernel(Geom g, BrickGeom bg, bool even, int64_t Natoms, const T* __restrict__ pos,
+                                                      unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= Natoms) return;
+  int m[3];
+  double x[3];
+  atom_mesh_coords<T>(g, even, pos, i, m, x);
+  keys[i] = unsigned(((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK);
+  vals[i] = unsigned(i);
+}
+
+// atoms sorted by (brick, index): slot = position - first position of the brick; the first atom of a brick also writes the
+// brick's live counter (= its atom count)
+__global__ __launch_bounds__(256) void det_slots_kernel(int64_t Natoms, int cap, const unsigned* __restrict__ keys2,
+                                                       const unsigned* __restrict__ vals2, int* __restrict__ slot_of,
+                                                       int* __restrict__ over_flag, int* __restrict__ live) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= Natoms) return;
+  const unsigned b = keys2[p];
+  int64_t lo = 0, hi = p;  // first position with key == b
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys2[mid] < b)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int slot = int(p - lo);
+  slot_of[vals2[p]] = slot;
+  over_flag[p] = slot >= cap ? 1 : 0;
+  if (slot == 0) {
+    int64_t l2 = p, h2 = Natoms;  // first position with key > b
+    while (l2 < h2) {
+      const int64_t mid = (l2 + h2) >> 1;
+      if (keys2[mid] <= b)
+        l2 = mid + 1;
+      else
+        h2 = mid;
+    }
+    live[b] = int(l2 - p);
+  }
+}
+
+// overflow atoms (slot >= cap) in sorted order: slot_of = cap + rank among them; live[nb] = their number.  One workgroup.
+__global__ __launch_bounds__(1024) void det_overflow_kernel(int64_t Natoms, int cap, int nb, const unsigned* __restrict__ vals2,
+                                                           const int* __restrict__ over_flag, int* __restrict__ slot_of,
+                                                           int* __restrict__ live) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (Natoms + 1023) / 1024;
+  const int64_t lo = min(int64_t(t) * per, Natoms), hi = min(lo + per, Natoms);
+  int sum = 0;
+  for (int64_t k = lo; k < hi; ++k) sum += over_flag[k];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  if (sum > 0)
+    for (int64_t k = lo; k < hi; ++k)
+      if (over_flag[k]) slot_of[vals2[k]] = cap + run++;
+  if (t == 1023) live[nb] = part[1023];
 }
 
 // number of atoms of brick `b` (clamped to the slots it has) and of the overflow region, from the live counters of a
@@ -391,6 +493,7 @@ struct SpreadArgs {
   T scale;
   T* mesh;
   int stage_rows;
+  bool det;  // deterministic mode: order every round of survivors by slot before staging
 };
 
 // block = index of the brick (workgroup index among the spread workgroups of the launch)
@@ -495,6 +598,34 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       }
       __syncthreads();
       const int ns = nsurv;
+      if (args.det && ns > 1) {  // rank by counting on the (unique) slot index: the order of the LDS atomics above drops out
+        constexpr int PER = (ROUND + THREADS - 1) / THREADS;
+        int key[PER], rnk[PER];
+        unsigned short rl[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int t = tid + u * THREADS;
+          key[u] = 0;
+          rnk[u] = 0;
+          rl[u] = 0;
+          if (t < ns) {
+            key[u] = sidx[t];
+            rl[u] = srel[t];
+            int r = 0;
+            for (int v = 0; v < ns; ++v) r += sidx[v] < key[u];
+            rnk[u] = r;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          if (tid + u * THREADS < ns) {
+            sidx[rnk[u]] = key[u];
+            srel[rnk[u]] = rl[u];
+          }
+        }
+        __syncthreads();
+      }
       for (int chunk = 0; chunk < ns; chunk += stage_rows) {
         const int nst = min(stage_rows, ns - chunk);
         // A2: stage the survivor's weights, placed on the brick: row = [wz | wx * value | wy], 8 entries each, entry k of an
@@ -1092,17 +1223,38 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   MIPME_REQUIRE(bins_layout(m, n_atoms, dtype).slots < (int64_t(1) << 31), "too many bin slots for 32-bit slot indices");
   v.idx.live = live;
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
+  const int* slot_of = nullptr;
+  if (n_atoms > 0 && deterministic_mode()) {
+    const BinsLayout l = bins_layout(m, n_atoms, dtype);
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t arr = al(sizeof(int) * size_t(n_atoms));
+    char* base = (char*)bins + l.det;
+    unsigned *keys = (unsigned*)base, *vals = (unsigned*)(base + arr), *keys2 = (unsigned*)(base + 2 * arr),
+             *vals2 = (unsigned*)(base + 3 * arr);
+    int *slots = (int*)(base + 4 * arr), *over_flag = (int*)(base + 5 * arr);
+    det_keys_kernel<T><<<blocks, 256, 0, st>>>(g, bg, (m->order % 2) == 0, n_atoms, (const T*)pos, keys, vals);
+    MIPME_LAUNCH_CHECK();
+    unsigned bits = 1;
+    while ((int64_t(1) << bits) < bg.nb) ++bits;
+    size_t sb = l.det_sort_bytes;
+    MIPME_CHECK_HIP(rocprim::radix_sort_pairs(base + 6 * arr, sb, keys, keys2, vals, vals2, size_t(n_atoms), 0u, bits, st, false));
+    det_slots_kernel<<<blocks, 256, 0, st>>>(n_atoms, v.idx.cap, keys2, vals2, slots, over_flag, live);
+    MIPME_LAUNCH_CHECK();
+    det_overflow_kernel<<<1, 1024, 0, st>>>(n_atoms, v.idx.cap, bg.nb, vals2, over_flag, slots, live);
+    MIPME_LAUNCH_CHECK();
+    slot_of = slots;
+  }
   if (n_atoms > 0) {
     if (n_atoms >= kCoalescedBinAtoms)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_atoms_kernel<S, N, T, true><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
                                                                                        v.rec, (T*)v.wts, (const T*)q,
-                                                                                       (AtomRecord<T>*)atom_rec)));
+                                                                                       (AtomRecord<T>*)atom_rec, slot_of)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_atoms_kernel<S, N, T, false><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
                                                                                         v.rec, (T*)v.wts, (const T*)q,
-                                                                                        (AtomRecord<T>*)atom_rec)));
+                                                                                        (AtomRecord<T>*)atom_rec, slot_of)));
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;
@@ -1132,6 +1284,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.scale = T(scale);
   sa.mesh = (T*)mesh;
   sa.stage_rows = stage_rows;
+  sa.det = deterministic_mode();
   if (job) {
     // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
     SRPot s;
@@ -1471,6 +1624,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.spread.scale = T(1);
     d.spread.mesh = (T*)f.rho_mesh;
     d.spread.stage_rows = spread_stage_rows(m->order, sizeof(T));
+    d.spread.det = false;  // (the frames path keeps the one-pass binning: MIPME_DETERMINISTIC covers single-frame evaluations)
     d.rows = make_fused_rows_args<T>(s, cf, f.n_atoms, f.row_ptr, f.entries_shift, f.entries, nullptr, f.positions, f.records,
                                      f.cell, f.charges, nullptr, 0, f.full_list ? 0 : 1, f.full_list, 0, f.out, f.force, nullptr,
                                      f.dist_out);

@@ -355,5 +355,6 @@ class GraphedFrameBatch:
             with torch.no_grad():
                 for buf, new in zip(self.pos, positions):
                     buf.copy_(new)
+        self.calc.check()  # a NaN a previous replay met (pinned word, no synchronisation)
         self.graph.replay()
         return self.energies, self.forces

@@ -374,16 +374,21 @@ class DistanceSource:
         return now == self.versions and dist.dtype == self.positions.dtype and dist.device == self.positions.device
 
 
-_MATCH_FLAG = None
+_MATCH_FLAGS: dict = {}
 
 
-def _match_flag():
-    """Pinned int32 word (tensor, NumPy view) the energy-gradient detection kernel reports to."""
-    global _MATCH_FLAG
-    if _MATCH_FLAG is None:
+def _match_flag(device):
+    """Pinned int32 word (tensor, NumPy view) the energy-gradient detection kernel reports to -- one per (device, host
+    thread): autograd runs the backward passes of different GPUs on different threads, and a shared word would let one thread
+    read the other's verdict."""
+    import threading
+
+    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    slot = _MATCH_FLAGS.get(key)
+    if slot is None:
         t = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        _MATCH_FLAG = (t, t.numpy())
-    return _MATCH_FLAG
+        slot = _MATCH_FLAGS[key] = (t, t.numpy())
+    return slot
 
 
 class _LazyEntries8:
@@ -746,12 +751,13 @@ class _PMEFunction(torch.autograd.Function):
             gscale = sr_scale = None
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
                 sr_scale = tag[3]  # enough for the pair part
-            elif ENERGY_FAST_PATH and ENERGY_DETECT and tag is None and N > 0 and not torch.cuda.is_current_stream_capturing():
+            elif (ENERGY_FAST_PATH and ENERGY_DETECT and tag is None and N > 0 and (fused is not None or do_kspace)
+                  and not torch.cuda.is_current_stream_capturing()):
                 # no tag: the caller reduced with plain tensor ops, ``(charges * V).sum()`` (README.rst:112-114) -- ask the
                 # device whether the gradient is a multiple of the charges (one small kernel + a 2-value read; the general
                 # adjoint it saves is a second spread, an FFT pair and a gradient gather).  Not during graph capture.
                 res = torch.empty((2,), dtype=dtype, device=device)
-                flag, flag_np = _match_flag()
+                flag, flag_np = _match_flag(device)
                 flag_np[0] = -1
                 _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
                       flag.data_ptr())

@@ -192,6 +192,9 @@ class TuningTimings(torch.nn.Module):
                 value.backward(retain_graph=True)
             stop.record()
             stop.synchronize()
+            check = getattr(calculator, "check", None)
+            if check is not None:
+                check()  # the deferred NaN guard would blame the NEXT candidate of a search: look at the flag now (synchronised)
             if it >= self.n_warmup:
                 times.append(start.elapsed_time(stop) * 1e-3)
         times.sort()
