@@ -429,6 +429,35 @@ def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
     return out
 
 
+def oracle_accuracy(w, name, E32, F32, E64=None, F64=None):
+    """The timed dtype's energy and forces (and the fp64 path's) against the PINNED ORACLE's numbers for this very box, committed
+    as tests/golden/workloads.npz by tests/golden/make_workloads_golden.py (oracle/pme_numpy.py in fp64; itself pinned to the
+    reference's golden vectors, tests/test_oracle_golden.py).  Nothing under oracle/ runs here."""
+    path = os.path.join(ROOT, "tests", "golden", "workloads.npz")
+    if not os.path.exists(path):
+        return {"reference": "tests/golden/workloads.npz missing"}
+    z = np.load(path)
+    if f"{name}_energy" not in z.files:
+        return {"reference": f"no committed oracle numbers for workload {name}"}
+    chk = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
+    if int(z[f"{name}_n_pairs"]) != w.n_pairs or not np.allclose(chk, z[f"{name}_pos_checksum"], rtol=1e-12, atol=1e-9):
+        return {"reference": "committed oracle numbers belong to a different box (seed / size)"}
+    Eo, sample, Fs = float(z[f"{name}_energy"]), z[f"{name}_sample"], z[f"{name}_force_sample"]
+
+    def errs(E, F):
+        F = F.detach().cpu().double().numpy()
+        return {"rel_energy_error": abs(E - Eo) / abs(Eo),
+                "force_rel_l2_error_256_atoms": float(np.linalg.norm(F[sample] - Fs) / np.linalg.norm(Fs)),
+                "force_sq_rel_error": abs(float((F * F).sum()) - float(z[f"{name}_force_sq"])) / float(z[f"{name}_force_sq"])}
+
+    out = {"reference": "pinned oracle (oracle/pme_numpy.py, fp64) for this box: tests/golden/workloads.npz",
+           "oracle_energy": Eo}
+    out.update(errs(E32, F32))
+    if E64 is not None:
+        out["fp64_path_vs_oracle"] = errs(E64, F64)
+    return out
+
+
 def _event_ms(fn, n, warm=3):
     for _ in range(warm):
         fn()
@@ -798,15 +827,18 @@ def main(argv=None):
         E32, F32 = frame.step()
         frame.store_distances = args.store_distances
         accuracy = {
-            "reference": "same HIP path in fp64 (parity with torch-pme fp64 <= 1e-12, tests/test_gpu_parity.py)",
-            "rel_energy_error": abs(float(E32) - float(E64)) / abs(float(E64)),
-            "force_rel_l2_error": float((F32.double() - F64).norm() / F64.norm()),
+            "vs_own_fp64": {"rel_energy_error": abs(float(E32) - float(E64)) / abs(float(E64)),
+                            "force_rel_l2_error": float((F32.double() - F64).norm() / F64.norm())},
         }
+        accuracy.update(oracle_accuracy(w, args.workload, float(E32), F32, float(E64), F64))
         # the distance tensor the step produced (by-product of the pair kernel) against plain tensor arithmetic in fp64
         p64, c64 = frame.pos.detach().double(), frame.cell.double()
         d_ref = (p64[frame.pairs[:, 1]] - p64[frame.pairs[:, 0]] + frame.shifts.double() @ c64).norm(dim=1)
         accuracy["distance_max_rel_error"] = float(((frame.distances.double() - d_ref).abs() / d_ref).max())
         del f64
+    elif rank == 0:
+        Ed, Fd = frame.step()
+        accuracy = oracle_accuracy(w, args.workload, float(Ed), Fd)
 
     if rank == 0:
         step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES, store_distances=args.store_distances)

@@ -240,6 +240,42 @@ def test_cfg5_energy_forces(dispersion):
     assert abs(Eg - E32) < 2e-6 * abs(E32) and rel(Fg, F32) < 1e-4
 
 
+@pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
+def test_fullsize_against_committed_oracle(cfg, request, golden_dir):
+    """Every benchmark workload at FULL size against the pinned oracle's energy and forces (tests/golden/workloads.npz, made
+    by tests/golden/make_workloads_golden.py: the 39 M-pair cfg5 evaluation is a minute of NumPy and tens of GB, so its result
+    is committed instead of recomputed on the GPU box): fp64 -- energy 1e-11, 256 sampled forces 1e-9 of the largest, the
+    whole-array checksums sum |F|^2 and sum r.F (seeded r) 1e-10 --, fp32 -- energy 1e-5, sampled forces rel-L2 1e-4 (cfg5's
+    1/r^6 forces are small differences of large terms) --, through the eager calculators, the graph-replayed step and the
+    device neighbour stream."""
+    w = request.getfixturevalue(cfg)
+    z = np.load(os.path.join(golden_dir, "workloads.npz"))
+    g = {k[len(cfg) + 1:]: z[k] for k in z.files if k.startswith(cfg + "_")}
+    chk = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
+    assert int(g["n_pairs"]) == w.n_pairs and np.allclose(chk, g["pos_checksum"], rtol=1e-13, atol=1e-9)
+    Eo, sample, Fs = float(g["energy"]), g["sample"], torch.tensor(g["force_sample"])
+    r = torch.tensor(np.random.default_rng(4242).normal(size=(w.n_atoms, 3)))
+    for dtype, tol_e, tol_s, tol_c in ((torch.float64, 1e-11, 1e-9, 1e-10), (torch.float32, 1e-5, 1e-4, 1e-4)):
+        box = Box(w, dtype)
+        results = {"eager": box.energy_forces()}
+        step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts)
+        Eg, Fg = step()
+        results["graph"] = (float(Eg), Fg.clone())
+        del step
+        st = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, neighbors=w.cutoff)
+        Es, Fst = st()
+        results["stream"] = (float(Es), Fst.clone())
+        del st
+        for name, (E, F) in results.items():
+            F = F.cpu().double()
+            assert abs(E - Eo) <= tol_e * abs(Eo), (cfg, dtype, name, E, Eo)
+            assert float((F[sample] - Fs).abs().max()) <= tol_s * float(Fs.abs().max()) * (1 if dtype == torch.float64 else 10), (cfg, dtype, name)
+            assert rel(F[sample], Fs) <= tol_s * (1 if dtype == torch.float64 else 1), (cfg, dtype, name, rel(F[sample], Fs))
+            assert abs(float((F * F).sum()) - float(g["force_sq"])) <= tol_c * float(g["force_sq"]), (cfg, dtype, name)
+            scale = float(F.norm() * r.norm())
+            assert abs(float((r * F).sum()) - float(g["force_dot"])) <= tol_c * scale, (cfg, dtype, name)
+
+
 def test_nve_energy_conservation():
     """examples/nve_ions.py: 1 728 charged soft spheres (Coulomb + 1/r^6, two graphed calculators, device neighbour list),
     200 velocity-Verlet steps -- the total energy is conserved to a small fraction of the kinetic energy, and halving the

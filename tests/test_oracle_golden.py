@@ -197,3 +197,23 @@ def test_ref_ewald_oracle(golden_dir):
         V = O.ewald_forward(spec, meta["lr_wavelength"], z[f"{nm}/charges"], z["cell"], z[f"{nm}/positions"],
                             z[f"{nm}/pairs"], z[f"{nm}/dist"], meta["full_list"], meta["periodic"], None, kv, mask)
         assert relmax(V, z[f"{nm}/V"]) < 1e-12, (nm, meta)
+
+
+def test_workload_goldens_come_from_the_oracle(golden_dir):
+    """tests/golden/workloads.npz (bench.py's accuracy block and the full-size GPU tests read it) is what the pinned oracle
+    gives for the synthetic boxes: re-derived here for cfg2 (8 000 charges, seconds on the CPU)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(golden_dir))
+    import make_workloads_golden as M
+    from torchpme_amd import workloads
+
+    z = np.load(os.path.join(golden_dir, "workloads.npz"))
+    res = M.summarise(workloads.ionic_box())
+    assert abs(res["energy"] - float(z["ionic_energy"])) <= 1e-12 * abs(res["energy"])
+    np.testing.assert_array_equal(res["sample"], z["ionic_sample"])
+    np.testing.assert_allclose(res["force_sample"], z["ionic_force_sample"], rtol=0, atol=1e-12 * np.abs(res["force_sample"]).max())
+    assert abs(res["force_dot"] - float(z["ionic_force_dot"])) <= 1e-10 * abs(res["force_dot"]) + 1e-9
+    for name in ("water", "dispersion"):
+        assert f"{name}_energy" in z.files and z[f"{name}_force_sample"].shape == (256, 3)
