@@ -518,7 +518,7 @@ typedef struct {
   double frac_offset[3]; /* non-periodic axes only; 0 / 1 for periodic axes */
   double frac_scale[3];
   int32_t reach[3];    /* cells walked to either side along each axis */
-  int32_t _pad2;
+  int32_t position_stride; /* reals per atom in `positions`: 0 or 3 = (N,3); 4 = (N,4) records x, y, z, charge (mipme_md_step) */
 } mipme_nl_t;
 #define MIPME_ROWS_PADDED 0x100 /* OR-ed into shift_format: row_ptr is int32[3N+1] = {begin, end, end} per atom + buffer size */
 int64_t mipme_nl_workspace_bytes(const mipme_nl_t* nl, int64_t n_atoms);
@@ -536,6 +536,49 @@ int mipme_nl_fill(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms
  * increases by one per call. */
 int mipme_nl_stream(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_atoms, void* workspace, int64_t row_capacity,
                     void* row_ptr, void* words, void* host_status);
+
+/* ---- energy + forces step of an MD-like loop on device-resident neighbour structures (no reference counterpart: the
+ * reference rebuilds everything from a fresh list every call, examples/02-neighbor-lists-usage.py:97-164) ------------------
+ * Between two refreshes of the neighbour list the atoms move by a fraction of a mesh spacing.  mipme_md_rebin does, once per
+ * refresh, what mipme_kspace_forward does every call: it bins the atoms by mesh brick, and it writes per brick the list of
+ * atoms whose stencil can reach the brick while they stay within one mesh point of where they were binned.  mipme_md_step then
+ * evaluates E = sum q V and seed * dE/dpositions for the CURRENT records with five launches -- spread from the lists + the pair
+ * sum over the rows of mipme_nl_stream (co-scheduled), (y,z) transforms, x stage * G, (y,z) transforms, gather + energy +
+ * forces -- with every weight evaluated on the fly from the current positions; only the atom -> brick bookkeeping is reused.
+ * An atom that has moved more than one mesh point since the rebin sets bit 1 of host_flags (the step's results are invalid:
+ * rebin sooner); bit 0: a brick list overflowed at the rebin.  P3M / PME with 1/r or 1/r^6, one channel, meshes the brick
+ * kernels cover (mipme_md_supported). */
+typedef struct {
+  uint32_t size, version;   /* sizeof(mipme_md_args_t), 1 */
+  struct mipme_fft_plan* plan;
+  void* stream;
+  int32_t dtype, shift_format; /* shift_format of the rows: 2 | MIPME_ROWS_PADDED for mipme_nl_stream's */
+  const mipme_mesh_t* mesh;
+  const mipme_potential_t* pot;
+  int64_t n_atoms;
+  const void* records;      /* (N,4) reals: x, y, z, charge -- the atoms' storage, read by every kernel of the step */
+  const void* cell;         /* DEVICE, 9 reals */
+  const void* G;            /* mipme_kfilter_build */
+  void* rho_mesh;           /* work: (nx,ny,nz) */
+  void* hat_work;           /* work: (nx,ny,nz/2+1) complex */
+  void* phi_mesh;           /* work: (nx,ny,nz) */
+  void* dc;                 /* work: 1 real */
+  void* atom_bins;          /* mipme_atom_bins_bytes(); written by mipme_md_rebin, read by the steps */
+  void* live_lists;         /* 4 * mipme_md_lists_ints() bytes; likewise */
+  const void* row_ptr;      /* neighbour rows */
+  const void* words;
+  void* potentials;         /* out (N) */
+  void* pair_force;         /* work (N,3) */
+  void* energy;             /* out: 1 real */
+  void* grad_positions;     /* out (N,3): grad_seed[0] * dE/dpositions */
+  const void* grad_seed;    /* device scalar, nullable (= 1) */
+  void* nan_flag;           /* pinned int32, nullable (see mipme_kspace_forward) */
+  void* host_flags;         /* pinned int32, nullable: bit 0 list overflow (rebin), bit 1 an atom moved beyond the margin (step) */
+} mipme_md_args_t;
+int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype);
+int64_t mipme_md_lists_ints(const mipme_mesh_t* mesh, int64_t n_atoms);
+int mipme_md_rebin(const mipme_md_args_t* args);
+int mipme_md_step(const mipme_md_args_t* args);
 
 #ifdef __cplusplus
 }

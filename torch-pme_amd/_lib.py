@@ -34,7 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
-    "mipme_scaled_match",
+    "mipme_scaled_match", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step",
 )
 
 
@@ -176,8 +176,26 @@ class NlDesc(C.Structure):
         ("frac_offset", C.c_double * 3),
         ("frac_scale", C.c_double * 3),
         ("reach", C.c_int32 * 3),
-        ("_pad2", C.c_int32),
+        ("position_stride", C.c_int32),
     ]
+
+
+class MdArgs(_VersionedArgs):
+    """``mipme_md_args_t`` (version 1)"""
+
+    _fields_ = [
+        ("size", C.c_uint32), ("version", C.c_uint32),
+        ("plan", C.c_void_p), ("stream", C.c_void_p), ("dtype", C.c_int32), ("shift_format", C.c_int32),
+        ("mesh", C.POINTER(MeshDesc)), ("pot", C.POINTER(PotentialDesc)), ("n_atoms", C.c_int64),
+        ("records", C.c_void_p), ("cell", C.c_void_p), ("G", C.c_void_p),
+        ("rho_mesh", C.c_void_p), ("hat_work", C.c_void_p), ("phi_mesh", C.c_void_p), ("dc", C.c_void_p),
+        ("atom_bins", C.c_void_p), ("live_lists", C.c_void_p), ("row_ptr", C.c_void_p), ("words", C.c_void_p),
+        ("potentials", C.c_void_p), ("pair_force", C.c_void_p), ("energy", C.c_void_p), ("grad_positions", C.c_void_p),
+        ("grad_seed", C.c_void_p), ("nan_flag", C.c_void_p), ("host_flags", C.c_void_p),
+    ]
+
+    def __init__(self, **fields):
+        C.Structure.__init__(self, size=C.sizeof(type(self)), version=1, **fields)
 
 
 #: OR-ed into a shift format: rows written by ``mipme_nl_stream`` (``row_ptr`` int32[3N+1], every neighbour once per row)
@@ -237,6 +255,8 @@ def _declare(lib):
         "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp],
         "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],
         "mipme_nl_stream": [vp, ci, C.POINTER(NlDesc), i64, vp, i64, vp, vp, vp],
+        "mipme_md_rebin": [C.POINTER(MdArgs)],
+        "mipme_md_step": [C.POINTER(MdArgs)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -252,6 +272,10 @@ def _declare(lib):
     lib.mipme_rows_partials_size.argtypes = [i64]
     lib.mipme_atom_bins_bytes.restype = i64
     lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
+    lib.mipme_md_supported.restype = ci
+    lib.mipme_md_supported.argtypes = [MP, PP, i64, ci]
+    lib.mipme_md_lists_ints.restype = i64
+    lib.mipme_md_lists_ints.argtypes = [MP, i64]
     lib.mipme_nl_workspace_bytes.restype = i64
     lib.mipme_nl_workspace_bytes.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_fft_plan_xfused.restype = ci

@@ -535,6 +535,74 @@ using namespace mipme;
     return MIPME_EINVAL;                                        \
   } while (0)
 
+// ---- MD step on live bins (bricks.hip) ---------------------------------------------------------------------------------------
+namespace mipme {
+bool live_supported(const mipme_mesh_t*, int64_t, int);
+int64_t live_lists_ints(const mipme_mesh_t*, int64_t);
+template <typename T> int live_rebin(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
+template <typename T> int live_spread(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
+template <typename T> int live_gather(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
+                                      double, double, void*, void*, const GatherTailHost*, void*);
+}  // namespace mipme
+
+static int md_check(const mipme_md_args_t* in, mipme_md_args_t& a, const char* who) {
+  MIPME_REQUIRE(in && in->size >= 16 && in->version == 1, "%s: NULL or unversioned argument struct", who);
+  std::memset(&a, 0, sizeof(a));
+  std::memcpy(&a, in, std::min<size_t>(in->size, sizeof(a)));
+  int rc;
+  if ((rc = validate_mesh(a.mesh))) return rc;
+  MIPME_REQUIRE(a.dtype == MIPME_F32 || a.dtype == MIPME_F64, "invalid dtype %d", a.dtype);
+  MIPME_REQUIRE(a.pot && a.pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
+  MIPME_REQUIRE(live_supported(a.mesh, a.n_atoms, a.dtype), "%s: mesh / atom count outside the live-bin kernels' range", who);
+  MIPME_REQUIRE(a.records && a.atom_bins && a.live_lists, "%s: NULL buffer", who);
+  return MIPME_OK;
+}
+
+template <typename T>
+static int md_step_t(const mipme_md_args_t& a) {
+  int rc;
+  hipStream_t st = (hipStream_t)a.stream;
+  const mipme_mesh_t* m = a.mesh;
+  double self_c, bg_c;
+  correction_terms(a.pot, self_c, bg_c);
+  mipme_sr_job_t job{};
+  job.n_atoms = a.n_atoms;
+  job.row_ptr = a.row_ptr;
+  job.entries_shift = a.words;
+  job.entries = a.words;  // (no pair indices behind the rows: never read)
+  job.positions = nullptr;
+  job.cell = a.cell;
+  job.charges = nullptr;
+  job.pot = a.pot;
+  job.full_list = 0;
+  job.shift_format = a.shift_format;
+  job.records = const_cast<void*>(a.records);
+  job.out = a.potentials;
+  job.force = a.pair_force;
+  job.dist_out = nullptr;
+  GatherTailHost tail{};
+  tail.force = a.pair_force;
+  tail.force_scale = 1.0;
+  tail.seed = a.grad_seed;
+  tail.grad_pos = a.grad_positions;
+  tail.energy = a.energy;
+  tail.n_k = xconv_blocks(a.plan);
+  tail.epart_k = fft_plan_tail_scratch(a.plan, 3 * int64_t(sizeof(double)) * tail.n_k);
+  tail.sr_reduced = 1;
+  MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream capture: run "
+                              "one evaluation before capturing)");
+  STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job));
+  int64_t n_sr_part = 0;
+  const void* sr_part = bins_epart(m, a.n_atoms, a.dtype, a.atom_bins, &n_sr_part);
+  STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot, nullptr,
+                                               const_cast<void*>(tail.epart_k), sr_part, n_sr_part, nullptr, a.nan_flag));
+  STAGE(st, "gather+energy+forces",
+        live_gather<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.host_flags, a.phi_mesh, a.dc, self_c, bg_c, a.potentials, nullptr,
+                       &tail, a.nan_flag));
+  return MIPME_OK;
+}
+
+
 extern "C" {
 
 const char* mipme_last_error(void) { return g_error; }
@@ -639,6 +707,41 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
             kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                      a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
                                      a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag));
+}
+
+int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype) {
+  if (!mesh || !pot || validate_mesh(mesh) || pot->smearing <= 0 || pot->exclusion_radius > 0) return 0;
+  const int p = pot->kind == MIPME_COULOMB ? 1 : pot->exponent;
+  if (p != 1 && p != 6) return 0;
+  if (mesh->nx < 2 || (mesh->nx & (mesh->nx - 1))) return 0;  // the fused convolution needs a power-of-two nx
+  return live_supported(mesh, n_atoms, dtype) ? 1 : 0;
+}
+
+int64_t mipme_md_lists_ints(const mipme_mesh_t* mesh, int64_t n_atoms) {
+  if (!mesh || validate_mesh(mesh) || n_atoms <= 0) return 0;
+  return live_lists_ints(mesh, n_atoms);
+}
+
+int mipme_md_rebin(const mipme_md_args_t* args_in) {
+  mipme_md_args_t a;
+  int rc = md_check(args_in, a, "mipme_md_rebin");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)a.stream;
+  DT_SWITCH(a.dtype, live_rebin<float>(st, a.mesh, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.host_flags),
+            live_rebin<double>(st, a.mesh, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.host_flags));
+}
+
+int mipme_md_step(const mipme_md_args_t* args_in) {
+  mipme_md_args_t a;
+  int rc = md_check(args_in, a, "mipme_md_step");
+  if (rc) return rc;
+  if ((rc = check_plan(a.plan, a.dtype, a.mesh))) return rc;
+  MIPME_REQUIRE(fft_plan_xfused(a.plan), "mipme_md_step needs a plan with a power-of-two nx");
+  MIPME_REQUIRE(mipme_md_supported(a.mesh, a.pot, a.n_atoms, a.dtype), "mipme_md_step: potential / mesh outside its range");
+  MIPME_REQUIRE(a.cell && a.G && a.rho_mesh && a.hat_work && a.phi_mesh && a.dc && a.row_ptr && a.words && a.potentials &&
+                    a.pair_force && a.energy && a.grad_positions, "NULL buffer passed to mipme_md_step");
+  MIPME_REQUIRE((a.shift_format & 0xff) == 2, "mipme_md_step reads 4-byte entries (shift_format 2, with or without MIPME_ROWS_PADDED)");
+  DT_SWITCH(a.dtype, md_step_t<float>(a), md_step_t<double>(a));
 }
 
 int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {

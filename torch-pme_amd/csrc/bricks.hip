@@ -48,6 +48,12 @@ __device__ __forceinline__ unsigned brick_of(const BrickGeom& b, unsigned wg) {
   return b.xcd ? xcd_contiguous(wg, unsigned(b.nb)) : wg;
 }
 
+// a mod n for a in (-n, 2n)
+__device__ __forceinline__ int wrap1(int a, int n) {
+  a += a < 0 ? n : 0;
+  return a >= n ? a - n : a;
+}
+
 // Brick path preconditions: >= 3 bricks per axis (the 27 neighbours are distinct bricks) and enough LDS.
 bool bricks_supported(const mipme_mesh_t* m, int dtype) {
   const size_t s = dtype == MIPME_F32 ? 4 : 8;
@@ -543,7 +549,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     glen[p] = 0;
     if (grp < 27) {
       const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
-      const int nbr = (posmod(bx + dx, bg.nbx) * bg.nby + posmod(by + dy, bg.nby)) * bg.nbz + posmod(bz + dz, bg.nbz);
+      const int nbr = (wrap1(bx + dx, bg.nbx) * bg.nby + wrap1(by + dy, bg.nby)) * bg.nbz + wrap1(bz + dz, bg.nbz);
       gstart[p] = nbr * bins.cap;
       glen[p] = bin_count_of(bins, nbr, args.from_live);
     } else if (grp == 27) {
@@ -732,8 +738,14 @@ __device__ long long g_wg_timeline[4 * 16384];
       }                                                                                                     \
     }                                                                                                       \
   } while (0)
+__device__ long long g_wg_phase[8 * 1024];
+#define MIPME_WG_PHASE(k)                                                                              \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_phase[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define MIPME_WG_STAMP(k)
+#define MIPME_WG_PHASE(k)
 #endif
 
 // Register budget of the co-scheduled kernel: 6 waves per SIMD = 3 workgroups per CU (what its LDS allows too) needs <= 80
@@ -814,7 +826,9 @@ __device__ __forceinline__ void load_tiles(const Geom& g, int ox, int oy, int oz
   const int64_t plane = int64_t(g.ny) * g.nz;
   for (int k = threadIdx.x; k < TL * TL * TL; k += THREADS) {
     const int tx = k / (TL * TL), ty = (k / TL) % TL, tz = k % TL;
-    const int gx = posmod(ox + s0 + tx, g.nx), gy = posmod(oy + s0 + ty, g.ny), gz = posmod(oz + s0 + tz, g.nz);
+    // (o + s0 + t lies in (-n, 2n): bricks_supported guarantees n > 2 BRICK >= BRICK + N; one conditional add / subtract
+    // instead of an integer division per coordinate -- the staging loop was ~120 instructions per element)
+    const int gx = wrap1(ox + s0 + tx, g.nx), gy = wrap1(oy + s0 + ty, g.ny), gz = wrap1(oz + s0 + tz, g.nz);
     const int64_t gi = gx * plane + int64_t(gy) * g.nz + gz;
     tile[k] = m0[gi];
     if constexpr (NT == 2) tile[TL * TL * TL + k] = m1[gi];
@@ -1047,10 +1061,15 @@ __global__ __launch_bounds__(THREADS) void gather_tail_kernel(Geom g, BrickGeom 
                                                              const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
                                                              T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
                                                              GatherTail<T> tail, int* __restrict__ nan_flag) {
+  MIPME_WG_STAMP(0);
   const unsigned b = brick_of(bg, blockIdx.x);
   if (b < unsigned(bg.nb))
     gather_brick_body<N, true, T, true, THREADS>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw,
                                                  field, b, &tail, nan_flag);
+#ifdef MIPME_WG_TIMELINE
+  __syncthreads();
+#endif
+  MIPME_WG_STAMP(1);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -1718,6 +1737,560 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   return MIPME_OK;
 }
 
+// ==========================================================================================================================
+// Live bins: the particle <-> mesh kernels of an MD-like loop (mipme_md_rebin / mipme_md_step, csrc/api.hip)
+// --------------------------------------------------------------------------------------------------------------------------
+// Between two refreshes of its neighbour list an MD step changes the positions by a fraction of a mesh spacing, yet the step
+// above bins every atom again (7 us of pure latency at cfg3, on the critical path), and every brick of the spread scans its 27
+// neighbours for the atoms whose stencils reach it (two more memory round trips and a round of LDS atomics).  Here both
+// belong to the REFRESH, like the pair list: mipme_md_rebin bins the atoms once and writes, per brick, the list of atoms whose
+// stencil can reach the brick while the atom stays within kLiveMargin mesh points of where it was binned.  A step then
+//   spread   reads its brick's list, fetches the atoms' CURRENT (x, y, z, q) records, evaluates their 1-D weights on the fly and
+//            accumulates as before (an atom whose stencil no longer overlaps contributes zeros);
+//   gather   walks the brick's home atoms (bin slots), evaluates weights and derivatives on the fly from the current record and
+//            reads a halo tile that is kLiveMargin points wider on every side; an atom that has moved further than the margin
+//            sets a flag in pinned host memory (the results of that step are then invalid: refresh sooner).
+// Every position-dependent quantity is recomputed every step; only the atom -> brick bookkeeping is reused.  One channel.
+static constexpr int kLiveMargin = 1;
+enum LiveFlags { kLiveListOverflow = 1, kLiveMoved = 2 };
+
+struct LiveLists {
+  int* counters;  // [nb + 1] binning counters of the rebin (zero outside it)
+  int* count;     // [nb] atoms in the brick's list
+  int* atoms;     // [nb][lcap]
+  int lcap;
+  int* host_flags;  // pinned int32, nullable: LiveFlags
+};
+
+static inline int live_list_capacity(const mipme_mesh_t* m, int64_t N) {
+  double frac = 1.0;
+  const int ns[3] = {m->nx, m->ny, m->nz};
+  for (int d = 0; d < 3; ++d) frac *= std::min(1.0, double(BRICK + m->order - 1 + 2 * kLiveMargin) / ns[d]);
+  const int64_t want = (int64_t(2.0 * frac * double(N)) + 64 + 63) / 64 * 64;
+  const int64_t all = (N + 63) / 64 * 64;
+  return int(std::min<int64_t>(want, std::max<int64_t>(all, 64)));
+}
+int64_t live_lists_ints(const mipme_mesh_t* m, int64_t N) {
+  const BrickGeom bg = make_brick_geom(m);
+  return 8 + (bg.nb + 1) + bg.nb + int64_t(bg.nb) * live_list_capacity(m, N);
+}
+static inline LiveLists live_view(const mipme_mesh_t* m, int64_t N, void* lists, void* host_flags) {
+  const BrickGeom bg = make_brick_geom(m);
+  int* b = (int*)lists;
+  LiveLists l;
+  l.counters = b + 8;
+  l.count = l.counters + (bg.nb + 1);
+  l.atoms = l.count + bg.nb;
+  l.lcap = live_list_capacity(m, N);
+  l.host_flags = (int*)host_flags;
+  return l;
+}
+
+// current mesh coordinates and 1-D weights (DERIV: and their derivatives) of an atom record; the scheme is a run-time switch
+// where an order exists in both (3..5).  One call per axis with its own arrays: a [3][N] array indexed by the axis went to
+// scratch memory.
+template <int N, bool DERIV, typename T>
+__device__ __forceinline__ void live_axis(int scheme, T x, T (&w)[N], T (&dw)[N]) {
+  if constexpr (N <= 2) {
+    weights_1d<MIPME_P3M, N, DERIV, T>(x, w, dw);
+  } else if constexpr (N >= 6) {
+    weights_1d<MIPME_LAGRANGE, N, DERIV, T>(x, w, dw);
+  } else {
+    if (scheme == MIPME_P3M)
+      weights_1d<MIPME_P3M, N, DERIV, T>(x, w, dw);
+    else
+      weights_1d<MIPME_LAGRANGE, N, DERIV, T>(x, w, dw);
+  }
+}
+template <int N, typename T>
+__device__ __forceinline__ void live_coords(const Geom& g, const AtomRecord<T>& r, int& mx, int& my, int& mz, T& x0, T& x1, T& x2) {
+  const double rx = double(r.x), ry = double(r.y), rz = double(r.z);
+  const double ux = double(g.nx) * (rx * g.inv[0] + ry * g.inv[3] + rz * g.inv[6]);
+  const double uy = double(g.ny) * (rx * g.inv[1] + ry * g.inv[4] + rz * g.inv[7]);
+  const double uz = double(g.nz) * (rx * g.inv[2] + ry * g.inv[5] + rz * g.inv[8]);
+  int m;
+  double x;
+  split_runtime(ux, (N % 2) == 0, m, x);
+  mx = posmod(m, g.nx);
+  x0 = T(x);
+  split_runtime(uy, (N % 2) == 0, m, x);
+  my = posmod(m, g.ny);
+  x1 = T(x);
+  split_runtime(uz, (N % 2) == 0, m, x);
+  mz = posmod(m, g.nz);
+  x2 = T(x);
+}
+
+// ---- rebin: slots (no weights), snapshot, per-brick lists -------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void live_bin_kernel(Geom g, BrickGeom bg, bool even, BinIndex bi, int* __restrict__ counters,
+                                                      int64_t Natoms, const AtomRecord<T>* __restrict__ rec4,
+                                                      int* __restrict__ over_brick, int4* __restrict__ rec) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= Natoms) return;
+  const AtomRecord<T> r = rec4[i];
+  const T p3[3] = {r.x, r.y, r.z};
+  int m[3];
+  double x[3];
+  atom_mesh_coords<T>(g, even, p3, 0, m, x);
+  const int b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
+  const int slot = atomicAdd(&counters[b], 1);
+  int64_t dst;
+  if (slot < bi.cap) {
+    dst = int64_t(b) * bi.cap + slot;
+  } else {
+    const int k = atomicAdd(&counters[bi.nb], 1);
+    over_brick[k] = b;
+    dst = bi.over_base + k;
+  }
+  rec[dst] = make_int4(m[0], m[1], m[2], int(i));
+}
+
+__global__ void live_snapshot_kernel(BinIndex bi, int* __restrict__ counters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > bi.nb) return;
+  const int c = counters[b];
+  bi.snap[b] = b == bi.nb ? c : min(c, bi.cap);
+  counters[b] = 0;
+}
+
+// atoms whose stencil -- started anywhere within kLiveMargin points of where it starts now -- reaches this brick, from the bins
+// of the 27 surrounding bricks (+ the overflow region); the list is then ordered by atom index, so that the spread's sums run in
+// one fixed order whatever the order of the atomics was
+__device__ __forceinline__ bool live_reach(int m, int s0, int origin, int nmesh, int order) {
+  const int r = rel_start(m, s0, origin, nmesh, order);
+  return r <= BRICK - 1 + kLiveMargin || r >= nmesh - order + 1 - kLiveMargin;
+}
+
+template <int N>
+__global__ __launch_bounds__(SPREAD_THREADS) void live_lists_kernel(Geom g, BrickGeom bg, BinIndex bins,
+                                                                   const int4* __restrict__ rec, LiveLists ll) {
+  __shared__ int n_list;
+  __shared__ int keys[4096];
+  const unsigned block = brick_of(bg, blockIdx.x);
+  if (block >= unsigned(bg.nb)) return;
+  int bx, by, bz;
+  brick_coords(bg, block, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int tid = threadIdx.x, sub = tid % SPREAD_GROUP, grp = tid / SPREAD_GROUP;
+  constexpr int s0 = stencil_start<N>();
+  int* __restrict__ out = ll.atoms + int64_t(block) * ll.lcap;
+  if (tid == 0) n_list = 0;
+  __syncthreads();
+  if (grp < 28) {
+    int start, len;
+    if (grp < 27) {
+      const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
+      const int nbr = (wrap1(bx + dx, bg.nbx) * bg.nby + wrap1(by + dy, bg.nby)) * bg.nbz + wrap1(bz + dz, bg.nbz);
+      start = nbr * bins.cap;
+      len = bins.snap[nbr];
+    } else {
+      start = int(bins.over_base);
+      len = bins.snap[bins.nb];
+    }
+    for (int k = sub; k < len; k += SPREAD_GROUP) {
+      const int4 a = rec[start + k];
+      if (live_reach(a.x, s0, ox, g.nx, N) && live_reach(a.y, s0, oy, g.ny, N) && live_reach(a.z, s0, oz, g.nz, N)) {
+        const int dst = atomicAdd(&n_list, 1);
+        if (dst < ll.lcap) out[dst] = a.w;
+      }
+    }
+  }
+  __syncthreads();
+  const int n = n_list;
+  if (n > ll.lcap) {
+    if (tid == 0) {
+      ll.count[block] = ll.lcap;
+      if (ll.host_flags) atomicOr(ll.host_flags, kLiveListOverflow);
+    }
+    return;
+  }
+  if (tid == 0) ll.count[block] = n;
+  if (n > 1 && n <= 4096) {  // rank by counting on the (unique) atom index
+    for (int k = tid; k < n; k += SPREAD_THREADS) keys[k] = out[k];
+    __syncthreads();
+    for (int k = tid; k < n; k += SPREAD_THREADS) {
+      const int me = keys[k];
+      int r = 0;
+      for (int v = 0; v < n; ++v) r += keys[v] < me;
+      out[r] = me;
+    }
+  }
+}
+
+// ---- step: spread from the lists -----------------------------------------------------------------------------------------
+template <typename T>
+struct LiveSpreadArgs {
+  Geom g;
+  BrickGeom bg;
+  int scheme;
+  const int* count;
+  const int* atoms;
+  int lcap;
+  const AtomRecord<T>* rec4;
+  T* mesh;
+  int stage_rows;
+};
+
+template <int N, typename T>
+__device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, unsigned block) {
+  constexpr int THREADS = SPREAD_THREADS, WAVES = SPREAD_WAVES;
+  const Geom& g = args.g;
+  const BrickGeom& bg = args.bg;
+  const int stage_rows = args.stage_rows;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int SW = 3 * BRICK;
+  T* stage = reinterpret_cast<T*>(smem_raw);  // [stage_rows][SW]
+  T* part = stage;                            // [waves][512] partial bricks (aliases the stage, phase R)
+  int bx, by, bz;
+  brick_coords(bg, block, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ns = min(args.count[block], args.lcap);
+  const int* __restrict__ latoms = args.atoms + int64_t(block) * args.lcap;
+  constexpr int s0 = stencil_start<N>();
+  const int px = lane >> 3, py = lane & 7;
+  const int64_t plane = int64_t(g.ny) * g.nz;
+  T acc[BRICK];
+#pragma unroll
+  for (int k = 0; k < BRICK; ++k) acc[k] = T(0);
+  for (int chunk = 0; chunk < ns; chunk += stage_rows) {
+    const int nst = min(stage_rows, ns - chunk);
+    if (tid < nst) {
+      const AtomRecord<T> r = args.rec4[latoms[chunk + tid]];
+      int mx, my, mz;
+      T x0, x1, x2;
+      live_coords<N, T>(g, r, mx, my, mz, x0, x1, x2);
+      T wx[N], wy[N], wz[N], dum[N];
+      live_axis<N, false, T>(args.scheme, x0, wx, dum);
+      live_axis<N, false, T>(args.scheme, x1, wy, dum);
+      live_axis<N, false, T>(args.scheme, x2, wz, dum);
+      // row = [wz | wx * q | wy], each placed on the brick's 8 points of its axis (zero where the stencil has no point)
+      const int rz = rel_start(mz, s0, oz, g.nz, N), rx = rel_start(mx, s0, ox, g.nx, N), ry = rel_start(my, s0, oy, g.ny, N);
+      T* dst = stage + tid * SW;
+#pragma unroll
+      for (int k = 0; k < BRICK; ++k) {
+        T vz = T(0), vx = T(0), vy = T(0);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+          vz = (k - rz == t) ? wz[t] : vz;
+          vx = (k - rx == t) ? wx[t] : vx;
+          vy = (k - ry == t) ? wy[t] : vy;
+        }
+        dst[k] = vz;
+        dst[BRICK + k] = vx * r.w;
+        dst[2 * BRICK + k] = vy;
+      }
+    }
+    __syncthreads();
+    constexpr int UC = MIPME_SPREAD_UC;
+    const int nstc = __builtin_amdgcn_readfirstlane(nst);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int sv0 = wave_u; sv0 < nstc; sv0 += WAVES * UC) {
+      T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC];
+      bool live[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        const int sv = sv0 + u * WAVES;
+        live[u] = sv < nstc;
+        const T* sw = stage + (live[u] ? sv : sv0) * SW;
+        fx[u] = sw[BRICK + px];
+        fy[u] = sw[2 * BRICK + py];
+        load_row8<T>(sw, wz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        wxy[u] = live[u] ? fx[u] * fy[u] : T(0);
+        fma_row8<T>(acc, wxy[u], wz[u]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
+  __syncthreads();
+  for (int k = tid; k < BRICK_PTS; k += THREADS) {
+    T v = T(0);
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += part[w * BRICK_PTS + k];
+    const int qx = k / (BRICK * BRICK), qy = (k / BRICK) % BRICK, qz = k % BRICK;
+    const int gx = ox + qx, gy = oy + qy, gz = oz + qz;
+    if (gx < g.nx && gy < g.ny && gz < g.nz) args.mesh[gx * plane + int64_t(gy) * g.nz + gz] = v;
+  }
+}
+
+// bricks first, then the row workgroups of the pair sum (4-byte entries), as spread_rows_kernel
+template <int N, typename T, int PFAST>
+__global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
+                                                                                        unsigned n_spread) {
+  const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
+  if (blockIdx.x < n_pad) {
+    const unsigned b = brick_of(sa.bg, blockIdx.x);
+    if (b < n_spread) live_spread_body<N, T>(sa, b);
+  } else {
+    const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_pad, n_row_blocks) : blockIdx.x - n_pad;
+    if (r < n_row_blocks) {
+      extern __shared__ __attribute__((aligned(16))) char smem_rows[];
+      AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
+      if constexpr (std::is_same<T, float>::value)
+        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, r, tab);
+      else
+        sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, true>(ra, r, tab);
+    }
+  }
+}
+
+// ---- step: gather + energy + forces with weights evaluated on the fly --------------------------------------------------------
+template <int N, typename T>
+__global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g, BrickGeom bg, int scheme, BinIndex bins,
+                                                                         const int4* __restrict__ rec,
+                                                                         const AtomRecord<T>* __restrict__ rec4,
+                                                                         const T* __restrict__ mesh, const T* __restrict__ qsum,
+                                                                         T inv_vol, T self_c, T bg_c, T* __restrict__ out,
+                                                                         T* __restrict__ field, GatherTail<T> tail,
+                                                                         int* __restrict__ nan_flag, int* __restrict__ host_flags) {
+  static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
+  MIPME_WG_STAMP(0);
+  constexpr int THREADS = GATHER_THREADS, LANES = kGatherLanes, GROUPS = THREADS / LANES, MG = kLiveMargin;
+  constexpr int TL = BRICK + N - 1 + 2 * MG;
+  __shared__ T tile[TL * TL * TL];
+  const unsigned block = brick_of(bg, blockIdx.x);
+  if (block >= unsigned(bg.nb)) return;
+  int bx, by, bz;
+  brick_coords(bg, block, bx, by, bz);
+  const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
+  const int beg = int(block) * bins.cap, end = beg + bins.snap[block];
+  const int n_over = bins.snap[bins.nb];
+  T seed = T(1);
+  if (tail.seed) seed = tail.seed[0];
+  if (block == 0) tail_energy<T, THREADS>(tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
+  if (beg == end && n_over == 0) return;
+  const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
+  const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  const bool lane_active = l < N;
+  const int tz = lane_active ? l : 0;
+  constexpr int s0 = stencil_start<N>();
+  const int64_t plane = int64_t(g.ny) * g.nz;
+  bool staged = false, moved = false;
+  for (int it = 0; it < main_iters + over_iters; ++it) {
+    bool valid;
+    int id;
+    if (it < main_iters) {
+      const int idx = beg + it * GROUPS + grp;
+      valid = idx < end;
+      id = valid ? idx : beg;
+    } else {
+      const int k = (it - main_iters) * GROUPS + grp;
+      valid = k < n_over && bins.over_brick[k < n_over ? k : 0] == int(block);
+      id = int(bins.over_base) + (k < n_over ? k : 0);
+    }
+    int4 a = rec[id];
+    if (!valid) a = make_int4(ox, oy, oz, 0);
+    const AtomRecord<T> r = rec4[a.w];
+    const T out_early = out[a.w];
+    const T f_early = tail.force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
+    if (!staged) {  // halo tile, kLiveMargin points wider than the stencils of the brick's own mesh points need
+      for (int k = threadIdx.x; k < TL * TL * TL; k += THREADS) {
+        const int tx = k / (TL * TL), ty = (k / TL) % TL, tzz = k % TL;
+        const int gx = wrap1(ox + s0 - MG + tx, g.nx), gy = wrap1(oy + s0 - MG + ty, g.ny), gz = wrap1(oz + s0 - MG + tzz, g.nz);
+        tile[k] = mesh[gx * plane + int64_t(gy) * g.nz + gz];
+      }
+      staged = true;
+    }
+    int mx, my, mz;
+    T x0, x1, x2;
+    live_coords<N, T>(g, r, mx, my, mz, x0, x1, x2);
+    T wx[N], dwx[N], wy[N], dwy[N], wz[N], dwz[N];
+    live_axis<N, true, T>(scheme, x0, wx, dwx);
+    live_axis<N, true, T>(scheme, x1, wy, dwy);
+    live_axis<N, true, T>(scheme, x2, wz, dwz);
+    // where the atom is now, relative to where it was binned (a.x, a.y, a.z lie inside this brick)
+    auto tile_start = [&](int m_now, int m_bin, int n, int o) {
+      int dm = m_now - m_bin;
+      dm = dm > n / 2 ? dm - n : (dm < -(n / 2) ? dm + n : dm);
+      if (dm > MG || dm < -MG) {
+        moved = moved || valid;
+        dm = 0;  // keep the reads inside the tile; the step is flagged invalid
+      }
+      return m_bin - o + dm + MG;
+    };
+    const int rtx = tile_start(mx, a.x, g.nx, ox), rty = tile_start(my, a.y, g.ny, oy), rtz = tile_start(mz, a.z, g.nz, oz);
+    if (it == 0) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
+    const T* tp = tile + rty * TL + (rtz + tz);
+    T sA = T(0), sB = T(0), sC = T(0);
+#pragma unroll
+    for (int ty = 0; ty < N; ++ty) {
+      T sx = T(0), sdx = T(0);
+#pragma unroll
+      for (int tx = 0; tx < N; ++tx) {
+        const T v = tp[(rtx + tx) * TL * TL + ty * TL];
+        sx += v * wx[tx];
+        sdx += v * dwx[tx];
+      }
+      sA += sx * wy[ty];
+      sB += sdx * wy[ty];
+      sC += sx * dwy[ty];
+    }
+    // this lane's z weight: a masked sum, NOT common.h's pick<>() -- LLVM turns that select chain back into an indexed load of a
+    // private array, promotes the array to LDS, and the per-thread slice index it then needs makes every wave read the
+    // workgroup size from the AQL dispatch packet in host memory: the first load of a workgroup returned after 3-16 us
+    T wzv = T(0), dwzv = T(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const T on = (lane_active && tz == t) ? T(1) : T(0);
+      wzv += on * wz[t];
+      dwzv += on * dwz[t];
+    }
+    const T fx = group_sum_b<LANES, T>(sB * wzv) * T(g.nx) * inv_vol;
+    const T fy = group_sum_b<LANES, T>(sC * wzv) * T(g.ny) * inv_vol;
+    const T fz = group_sum_b<LANES, T>(sA * dwzv) * T(g.nz) * inv_vol;
+    // row l of the inverse cell by selects: indexing the by-value kernel argument with a lane-dependent index makes the compiler
+    // fetch it with VECTOR loads from the kernarg segment -- 8 192 waves queueing on the same few bytes of host-visible memory
+    // cost this kernel 20 us (tools/wg_timeline: the first load of half the workgroups returned after 27 us)
+    const T i0 = T(l == 1 ? g.inv[3] : (l == 2 ? g.inv[6] : g.inv[0])), i1 = T(l == 1 ? g.inv[4] : (l == 2 ? g.inv[7] : g.inv[1])),
+            i2 = T(l == 1 ? g.inv[5] : (l == 2 ? g.inv[8] : g.inv[2]));
+    const T fc = i0 * fx + i1 * fy + i2 * fz;
+    if (l < 3 && valid) {
+      const int64_t o = int64_t(a.w);
+      if (field) field[3 * o + l] = fc;
+      tail.grad_pos[3 * o + l] = seed * r.w * (tail.force_scale * f_early + fc);
+    }
+    const T acc = group_sum_b<LANES, T>(sA * wzv);
+    if (l == 0 && valid) {
+      const T phi = acc * inv_vol;
+      const T lr = T(0.5) * (phi - self_c * r.w - T(2) * bg_c * inv_vol * qsum[0]);
+      out[a.w] = out_early + lr;
+      if (nan_flag && lr != lr) *nan_flag = 1;
+    }
+  }
+  if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0 && host_flags) atomicOr(host_flags, kLiveMoved);
+#ifdef MIPME_WG_TIMELINE
+  __syncthreads();
+#endif
+  MIPME_WG_STAMP(1);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------
+#define MIPME_DISPATCH_ORDER(ORDER_V, BODY)                       \
+  do {                                                            \
+    switch (ORDER_V) {                                            \
+      case 1: { constexpr int N = 1; BODY; } break;               \
+      case 2: { constexpr int N = 2; BODY; } break;               \
+      case 3: { constexpr int N = 3; BODY; } break;               \
+      case 4: { constexpr int N = 4; BODY; } break;               \
+      case 5: { constexpr int N = 5; BODY; } break;               \
+      case 6: { constexpr int N = 6; BODY; } break;               \
+      case 7: { constexpr int N = 7; BODY; } break;               \
+      default: set_error("unsupported interpolation order %d", int(ORDER_V)); return MIPME_EINVAL; \
+    }                                                             \
+  } while (0)
+
+bool live_supported(const mipme_mesh_t* m, int64_t N, int dtype) {
+  if (!bricks_supported(m, dtype) || m->n_channels != 1 || N <= 0) return false;
+  const BrickGeom bg = make_brick_geom(m);
+  if (sparse_bricks(N, bg.nb)) return false;  // (the sparse-brick variants have no live form yet)
+  const size_t s = dtype == MIPME_F32 ? 4 : 8;
+  const size_t tl = BRICK + m->order - 1 + 2 * kLiveMargin;
+  return tl * tl * tl * s <= 60 * 1024 && live_list_capacity(m, N) >= 1;
+}
+
+template <typename T>
+int live_rebin(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* lists, void* host_flags) {
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  MIPME_REQUIRE(live_supported(m, N, dtype), "mesh / atom count outside the live-bin kernels' range");
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  BinsView v = bins_view(m, N, dtype, bins);
+  const LiveLists ll = live_view(m, N, lists, host_flags);
+  MIPME_CHECK_HIP(zero_async(ll.counters, sizeof(int) * size_t(bg.nb + 1), st));
+  live_bin_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(g, bg, (m->order % 2) == 0, v.idx, ll.counters, N,
+                                                              (const AtomRecord<T>*)rec4, v.over_brick, v.rec);
+  MIPME_LAUNCH_CHECK();
+  live_snapshot_kernel<<<unsigned((bg.nb + 1 + 255) / 256), 256, 0, st>>>(v.idx, ll.counters);
+  MIPME_LAUNCH_CHECK();
+  MIPME_DISPATCH_ORDER(m->order, (live_lists_kernel<N><<<brick_grid(bg), SPREAD_THREADS, 0, st>>>(g, bg, v.idx, v.rec, ll)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* lists, void* mesh,
+                const mipme_sr_job_t* job) {
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  const LiveLists ll = live_view(m, N, lists, nullptr);
+  const int stage_rows = spread_stage_rows(m->order, sizeof(T));
+  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
+  LiveSpreadArgs<T> sa;
+  sa.g = make_geom(m);
+  sa.bg = bg;
+  sa.scheme = m->scheme;
+  sa.count = ll.count;
+  sa.atoms = ll.atoms;
+  sa.lcap = ll.lcap;
+  sa.rec4 = (const AtomRecord<T>*)rec4;
+  sa.mesh = (T*)mesh;
+  sa.stage_rows = stage_rows;
+  MIPME_REQUIRE(job && sr_job_fusable(job) && (job->shift_format & kShiftFormatMask) == kShiftTable32 && !job->dist_out,
+                "the live step needs a co-schedulable pair job with 4-byte entries");
+  SRPot s;
+  int rc = make_srpot(job->pot, s);
+  if (rc) return rc;
+  const FastRS cf = make_fast_rs(s);
+  const int pfast = fast_rs_exponent(s);
+  FusedRowsArgs<T> ra = make_fused_rows_args<T>(s, cf, job->n_atoms, job->row_ptr, job->entries_shift, job->entries, nullptr,
+                                                job->positions, job->records, job->cell, job->charges, nullptr, 0,
+                                                job->full_list ? 0 : 1, job->full_list, 0, job->out, job->force, nullptr, nullptr,
+                                                job->shift_format);
+  ra.epart = v.epart;
+  const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  const unsigned n_spread = unsigned(bg.nb);
+  const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks;
+  if (pfast == 1)
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+  else
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* host_flags, const void* mesh,
+                const void* qsum, double self_c, double bg_c, void* out, void* field, const GatherTailHost* th, void* nan_flag) {
+  const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  const Geom g = make_geom(m);
+  const BrickGeom bg = make_brick_geom(m);
+  const BinsView v = bins_view(m, N, dtype, bins);
+  MIPME_REQUIRE(th && th->force && th->grad_pos && th->energy && th->epart_k && out && qsum, "NULL buffer passed to the live gather");
+  GatherTail<T> tail;
+  tail.force = (const T*)th->force;
+  tail.force_scale = T(th->force_scale);
+  tail.seed = (const T*)th->seed;
+  tail.grad_pos = (T*)th->grad_pos;
+  tail.energy = (T*)th->energy;
+  tail.epart_k = (const double*)th->epart_k;
+  tail.n_k = int(th->n_k);
+  tail.epart_sr = tail.epart_k + tail.n_k;  // pre-reduced by the x stage of the convolution
+  tail.n_sr = tail.n_k;
+  MIPME_DISPATCH_ORDER(m->order, (live_gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
+                                     g, bg, m->scheme, v.idx, v.rec, (const AtomRecord<T>*)rec4, (const T*)mesh, (const T*)qsum,
+                                     T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail, (int*)nan_flag,
+                                     (int*)host_flags)));
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template int live_rebin<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
+template int live_rebin<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
+template int live_spread<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
+template int live_spread<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
+template int live_gather<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
+                                double, double, void*, void*, const GatherTailHost*, void*);
+template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
+                                 double, double, void*, void*, const GatherTailHost*, void*);
+
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
@@ -1795,6 +2368,9 @@ int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_fra
 }  // extern "C"
 
 #ifdef MIPME_WG_TIMELINE
+extern "C" int mipme_debug_wg_phase(void* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mipme::g_wg_phase), size_t(n_words) * 8);
+}
 extern "C" int mipme_debug_wg_timeline(void* out, int n_words) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mipme::g_wg_timeline), size_t(n_words) * 8);
 }

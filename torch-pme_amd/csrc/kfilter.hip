@@ -430,10 +430,10 @@ __device__ __forceinline__ Cplx<T> tw_at(const Cplx<T>* tw, int idx) {
 
 template <typename T, bool DIT, bool INVERSE>
 __device__ __forceinline__ void lds_fft_single(Cplx<T>* data, int logL, int s, int nbatch, int bstride, int estride,
-                                               const Cplx<T>* tw, int Ltab) {
+                                               const Cplx<T>* tw, int Ltab, int tid, int nthr) {
   const int L = 1 << logL, half_total = nbatch << (logL - 1);
   const int hm = 1 << (s - 1), f = Ltab >> s;
-  for (int t = threadIdx.x; t < half_total; t += blockDim.x) {
+  for (int t = tid; t < half_total; t += nthr) {
     const int b = t >> (logL - 1), r = t & ((L >> 1) - 1);
     const int j = r & (hm - 1), i = ((r >> (s - 1)) << s) + j;
     Cplx<T>* p = data + b * bstride + i * estride;
@@ -451,63 +451,182 @@ __device__ __forceinline__ void lds_fft_single(Cplx<T>* data, int logL, int s, i
   __syncthreads();
 }
 
+// multiply by exp(-+ 2 pi i k / 8) (upper sign: forward), k = 0..3 a compile-time constant
+template <typename T, bool INVERSE, int K>
+__device__ __forceinline__ Cplx<T> rot8(Cplx<T> a) {
+  constexpr T r = T(0.70710678118654752440);
+  if constexpr (K == 0) return a;
+  if constexpr (K == 2) return INVERSE ? Cplx<T>{-a.im, a.re} : Cplx<T>{a.im, -a.re};
+  if constexpr (K == 1) return INVERSE ? Cplx<T>{r * (a.re - a.im), r * (a.re + a.im)} : Cplx<T>{r * (a.re + a.im), r * (a.im - a.re)};
+  return INVERSE ? Cplx<T>{-r * (a.re + a.im), r * (a.re - a.im)} : Cplx<T>{r * (a.im - a.re), -r * (a.re + a.im)};  // K == 3
+}
+
+// THREE radix-2 stages in one pass, by the thread that owns the eight points they couple (same data order as the radix-2
+// schedule, a third of its barriers and LDS round trips).  Three twiddle loads per eight points: the others differ from them by
+// eighth roots of unity.
+// DIT, stages with half-lengths h = 2^(s-1), 2h, 4h: points p[k * st], k < 8, st = h * estride.
+template <typename T, bool INVERSE>
+__device__ __forceinline__ void r8_dit(Cplx<T>* p, int st, Cplx<T> w1, Cplx<T> w2, Cplx<T> w3) {
+  Cplx<T> x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = p[k * st];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {  // length 2h: (k, k+1), twiddle w^j
+    const Cplx<T> t = cmul(x[k + 1], w1);
+    x[k + 1] = csub(x[k], t);
+    x[k] = cadd(x[k], t);
+  }
+#pragma unroll
+  for (int g = 0; g < 8; g += 4) {  // length 4h: (k, k+2); the pair that starts h further carries a quarter turn
+    const Cplx<T> t0 = cmul(x[g + 2], w2), t1 = rot8<T, INVERSE, 2>(cmul(x[g + 3], w2));
+    x[g + 2] = csub(x[g], t0);
+    x[g] = cadd(x[g], t0);
+    x[g + 3] = csub(x[g + 1], t1);
+    x[g + 1] = cadd(x[g + 1], t1);
+  }
+  {  // length 8h: (k, k+4), twiddle w^j times the k-th eighth root
+    const Cplx<T> t0 = cmul(x[4], w3), t1 = rot8<T, INVERSE, 1>(cmul(x[5], w3)), t2 = rot8<T, INVERSE, 2>(cmul(x[6], w3)),
+                  t3 = rot8<T, INVERSE, 3>(cmul(x[7], w3));
+    p[0] = cadd(x[0], t0);
+    p[4 * st] = csub(x[0], t0);
+    p[st] = cadd(x[1], t1);
+    p[5 * st] = csub(x[1], t1);
+    p[2 * st] = cadd(x[2], t2);
+    p[6 * st] = csub(x[2], t2);
+    p[3 * st] = cadd(x[3], t3);
+    p[7 * st] = csub(x[3], t3);
+  }
+}
+// DIF, stages of length 8q, 4q, 2q (q = 2^(s-3)): points p[k * st], st = q * estride.
+template <typename T, bool INVERSE>
+__device__ __forceinline__ void r8_dif(Cplx<T>* p, int st, Cplx<T> w8, Cplx<T> w4, Cplx<T> w2) {
+  Cplx<T> x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = p[k * st];
+  {  // length 8q: (k, k+4)
+    const Cplx<T> d0 = csub(x[0], x[4]), d1 = csub(x[1], x[5]), d2 = csub(x[2], x[6]), d3 = csub(x[3], x[7]);
+    x[0] = cadd(x[0], x[4]);
+    x[1] = cadd(x[1], x[5]);
+    x[2] = cadd(x[2], x[6]);
+    x[3] = cadd(x[3], x[7]);
+    x[4] = cmul(d0, w8);
+    x[5] = cmul(rot8<T, INVERSE, 1>(d1), w8);
+    x[6] = cmul(rot8<T, INVERSE, 2>(d2), w8);
+    x[7] = cmul(rot8<T, INVERSE, 3>(d3), w8);
+  }
+#pragma unroll
+  for (int g = 0; g < 8; g += 4) {  // length 4q: (k, k+2)
+    const Cplx<T> d0 = csub(x[g], x[g + 2]), d1 = csub(x[g + 1], x[g + 3]);
+    x[g] = cadd(x[g], x[g + 2]);
+    x[g + 1] = cadd(x[g + 1], x[g + 3]);
+    x[g + 2] = cmul(d0, w4);
+    x[g + 3] = cmul(rot8<T, INVERSE, 2>(d1), w4);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {  // length 2q: (k, k+1)
+    const Cplx<T> d = csub(x[k], x[k + 1]);
+    p[k * st] = cadd(x[k], x[k + 1]);
+    p[(k + 1) * st] = cmul(d, w2);
+  }
+}
+
+// radix of the passes: logL = 3a (+2: one radix-4 pass; +1: two radix-4 passes, or a single radix-2 stage for logL = 1)
+#ifndef MIPME_FFT_RADIX8
+#define MIPME_FFT_RADIX8 1
+#endif
+
 template <typename T, bool DIT, bool INVERSE>
 __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbatch, int bstride, int estride,
-                                               const Cplx<T>* tw, int Ltab) {
+                                               const Cplx<T>* tw, int Ltab, int tid = int(threadIdx.x),
+                                               int nthr = int(blockDim.x)) {
   const int L = 1 << logL;
   if (logL == 1) {
-    lds_fft_single<T, DIT, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+    lds_fft_single<T, DIT, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
     return;
   }
   const int quarter_total = nbatch << (logL - 2);
+  // radix-4 passes this transform takes besides its radix-8 ones
+  int n4 = MIPME_FFT_RADIX8 ? ((logL % 3 == 0) ? 0 : (logL % 3 == 2 ? 1 : 2)) : (logL >> 1);
+  const bool odd = !MIPME_FFT_RADIX8 && (logL & 1);
+  const int eighth_total = logL >= 3 ? nbatch << (logL - 3) : 0;
   if constexpr (DIT) {
     int s = 1;  // next stage has sub-transform length 2^s
-    if (logL & 1) {
-      lds_fft_single<T, true, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+    if (odd) {
+      lds_fft_single<T, true, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
       s = 2;
     }
-    for (; s + 1 <= logL; s += 2) {
-      const int h = 1 << (s - 1);          // stages of length 2h then 4h
-      const int f2 = Ltab >> s, f4 = Ltab >> (s + 1);
-      for (int t = threadIdx.x; t < quarter_total; t += blockDim.x) {
-        const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
-        const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 1)) + j;
-        Cplx<T>* p = data + b * bstride + i * estride;
-        const int st = h * estride;
-        const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
-        const Cplx<T> w1 = tw_at<T, INVERSE>(tw, j * f2);
-        const Cplx<T> b1 = cmul(x1, w1), b3 = cmul(x3, w1);
-        const Cplx<T> a0 = cadd(x0, b1), a1 = csub(x0, b1), a2 = cadd(x2, b3), a3 = csub(x2, b3);
-        const Cplx<T> c2 = cmul(a2, tw_at<T, INVERSE>(tw, j * f4)), c3 = cmul(a3, tw_at<T, INVERSE>(tw, (j + h) * f4));
-        p[0] = cadd(a0, c2);
-        p[2 * st] = csub(a0, c2);
-        p[st] = cadd(a1, c3);
-        p[3 * st] = csub(a1, c3);
+    while (s <= logL) {
+      if (n4 > 0) {
+        --n4;
+        const int h = 1 << (s - 1);          // stages of length 2h then 4h
+        const int f2 = Ltab >> s, f4 = Ltab >> (s + 1);
+        for (int t = tid; t < quarter_total; t += nthr) {
+          const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+          const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 1)) + j;
+          Cplx<T>* p = data + b * bstride + i * estride;
+          const int st = h * estride;
+          const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+          const Cplx<T> w1 = tw_at<T, INVERSE>(tw, j * f2);
+          const Cplx<T> b1 = cmul(x1, w1), b3 = cmul(x3, w1);
+          const Cplx<T> a0 = cadd(x0, b1), a1 = csub(x0, b1), a2 = cadd(x2, b3), a3 = csub(x2, b3);
+          const Cplx<T> c2 = cmul(a2, tw_at<T, INVERSE>(tw, j * f4)), c3 = cmul(a3, tw_at<T, INVERSE>(tw, (j + h) * f4));
+          p[0] = cadd(a0, c2);
+          p[2 * st] = csub(a0, c2);
+          p[st] = cadd(a1, c3);
+          p[3 * st] = csub(a1, c3);
+        }
+        s += 2;
+      } else {
+        const int h = 1 << (s - 1);          // stages of length 2h, 4h, 8h
+        const int f2 = Ltab >> s, f4 = Ltab >> (s + 1), f8 = Ltab >> (s + 2);
+        for (int t = tid; t < eighth_total; t += nthr) {
+          const int b = t >> (logL - 3), r = t & ((L >> 3) - 1);
+          const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 2)) + j;
+          r8_dit<T, INVERSE>(data + b * bstride + i * estride, h * estride, tw_at<T, INVERSE>(tw, j * f2),
+                             tw_at<T, INVERSE>(tw, j * f4), tw_at<T, INVERSE>(tw, j * f8));
+        }
+        s += 3;
       }
       __syncthreads();
     }
   } else {
     int s = logL;  // current sub-transform length 2^s
-    for (; s >= 2; s -= 2) {
-      const int q = 1 << (s - 2);          // stages of length 4q then 2q
-      const int f4 = Ltab >> s, f2 = Ltab >> (s - 1);
-      for (int t = threadIdx.x; t < quarter_total; t += blockDim.x) {
-        const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
-        const int j = r & (q - 1), i = ((r >> (s - 2)) << s) + j;
-        Cplx<T>* p = data + b * bstride + i * estride;
-        const int st = q * estride;
-        const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
-        const Cplx<T> u0 = cadd(x0, x2), u2 = cmul(csub(x0, x2), tw_at<T, INVERSE>(tw, j * f4));
-        const Cplx<T> u1 = cadd(x1, x3), u3 = cmul(csub(x1, x3), tw_at<T, INVERSE>(tw, (j + q) * f4));
-        const Cplx<T> w2 = tw_at<T, INVERSE>(tw, j * f2);
-        p[0] = cadd(u0, u1);
-        p[st] = cmul(csub(u0, u1), w2);
-        p[2 * st] = cadd(u2, u3);
-        p[3 * st] = cmul(csub(u2, u3), w2);
+    // the mirror image of the DIT schedule: radix-8 passes first, the radix-4 ones last
+    while (s >= 2) {
+      const int left8 = (s - 2 * n4) / 3;  // radix-8 passes still to come
+      if (MIPME_FFT_RADIX8 && left8 > 0) {
+        const int q = 1 << (s - 3);          // stages of length 8q, 4q, 2q
+        const int f8 = Ltab >> s, f4 = Ltab >> (s - 1), f2 = Ltab >> (s - 2);
+        for (int t = tid; t < eighth_total; t += nthr) {
+          const int b = t >> (logL - 3), r = t & ((L >> 3) - 1);
+          const int j = r & (q - 1), i = ((r >> (s - 3)) << s) + j;
+          r8_dif<T, INVERSE>(data + b * bstride + i * estride, q * estride, tw_at<T, INVERSE>(tw, j * f8),
+                             tw_at<T, INVERSE>(tw, j * f4), tw_at<T, INVERSE>(tw, j * f2));
+        }
+        s -= 3;
+      } else {
+        const int q = 1 << (s - 2);          // stages of length 4q then 2q
+        const int f4 = Ltab >> s, f2 = Ltab >> (s - 1);
+        for (int t = tid; t < quarter_total; t += nthr) {
+          const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+          const int j = r & (q - 1), i = ((r >> (s - 2)) << s) + j;
+          Cplx<T>* p = data + b * bstride + i * estride;
+          const int st = q * estride;
+          const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+          const Cplx<T> u0 = cadd(x0, x2), u2 = cmul(csub(x0, x2), tw_at<T, INVERSE>(tw, j * f4));
+          const Cplx<T> u1 = cadd(x1, x3), u3 = cmul(csub(x1, x3), tw_at<T, INVERSE>(tw, (j + q) * f4));
+          const Cplx<T> w2 = tw_at<T, INVERSE>(tw, j * f2);
+          p[0] = cadd(u0, u1);
+          p[st] = cmul(csub(u0, u1), w2);
+          p[2 * st] = cadd(u2, u3);
+          p[3 * st] = cmul(csub(u2, u3), w2);
+        }
+        s -= 2;
+        if (n4 > 0) --n4;
       }
       __syncthreads();
     }
-    if (s == 1) lds_fft_single<T, false, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab);
+    if (s == 1) lds_fft_single<T, false, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
   }
 }
 
@@ -773,39 +892,9 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
   }
   __syncthreads();
-  const int quarter = (nx >> 2) << kzs;  // 4-point groups per double stage
-  // ---- forward, decimation in frequency: stages m = nx, nx/2, ..., 2 (two per pass) ----
-  int s = log2nx;  // current sub-transform length m = 2^s
-  for (; s >= 2; s -= 2) {
-    const int q = 1 << (s - 2);  // m/4
-    const int f = nx >> s;       // nx/m
-    for (int b = tid; b < quarter; b += nthr) {
-      const int z = b & (KZ - 1), t = b >> kzs;
-      const int j = t & (q - 1);
-      const int i = ((t >> (s - 2)) << s) + j;
-      Cplx<T>* p = tile + (i << kzs) + z;
-      const int st = q << kzs;
-      const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
-      const Cplx<T> u0 = cadd(x0, x2), u2 = cmul(csub(x0, x2), tw[j * f]);
-      const Cplx<T> u1 = cadd(x1, x3), u3 = cmul(csub(x1, x3), tw[(j + q) * f]);
-      const Cplx<T> w2 = tw[j * 2 * f];
-      p[0] = cadd(u0, u1);
-      p[st] = cmul(csub(u0, u1), w2);
-      p[2 * st] = cadd(u2, u3);
-      p[3 * st] = cmul(csub(u2, u3), w2);
-    }
-    __syncthreads();
-  }
-  if (s == 1) {  // last radix-2 stage (m = 2, twiddle 1)
-    for (int b = tid; b < (half_n << kzs); b += nthr) {
-      const int z = b & (KZ - 1), t = b >> kzs;
-      Cplx<T>* p = tile + ((2 * t) << kzs) + z;
-      const Cplx<T> a = p[0], bb = p[KZ];
-      p[0] = cadd(a, bb);
-      p[KZ] = csub(a, bb);
-    }
-    __syncthreads();
-  }
+  // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
+  //      tile[(x << kzs) + z] ----
+  lds_fft_radix2<T, false, false>(tile, log2nx, KZ, 1, KZ, tw, nx, tid, nthr);
   if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
   if constexpr (CELLSUMS) {
     double acc[12];
@@ -894,42 +983,9 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     }
   }
   __syncthreads();
-  // ---- inverse, decimation in time: stages m = 2, 4, ..., nx; conjugate twiddles, no normalisation
+  // ---- inverse, decimation in time (bit-reversed in, natural out); conjugate twiddles, no normalisation
   //      (kspace_filter.py:169-187: norm="backward" forward, norm="forward" inverse) ----
-  s = 0;  // next stage has half-length h = 2^s
-  if (log2nx & 1) {
-    for (int b = tid; b < (half_n << kzs); b += nthr) {
-      const int z = b & (KZ - 1), t = b >> kzs;
-      Cplx<T>* p = tile + ((2 * t) << kzs) + z;
-      const Cplx<T> a = p[0], bb = p[KZ];
-      p[0] = cadd(a, bb);
-      p[KZ] = csub(a, bb);
-    }
-    __syncthreads();
-    s = 1;
-  }
-  for (; s + 1 < log2nx + 1 && s + 2 <= log2nx; s += 2) {
-    const int h = 1 << s;              // stage lengths 2h then 4h
-    const int f2 = nx >> (s + 1);      // nx / 2h
-    const int f4 = nx >> (s + 2);      // nx / 4h
-    for (int b = tid; b < quarter; b += nthr) {
-      const int z = b & (KZ - 1), t = b >> kzs;
-      const int j = t & (h - 1);
-      const int i = ((t >> s) << (s + 2)) + j;
-      Cplx<T>* p = tile + (i << kzs) + z;
-      const int st = h << kzs;
-      const Cplx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
-      const Cplx<T> w = tw[j * f2];
-      const Cplx<T> b1 = cmulc(x1, w), b3 = cmulc(x3, w);
-      const Cplx<T> u0 = cadd(x0, b1), u1 = csub(x0, b1), u2 = cadd(x2, b3), u3 = csub(x2, b3);
-      const Cplx<T> c2 = cmulc(u2, tw[j * f4]), c3 = cmulc(u3, tw[(j + h) * f4]);
-      p[0] = cadd(u0, c2);
-      p[2 * st] = csub(u0, c2);
-      p[st] = cadd(u1, c3);
-      p[3 * st] = csub(u1, c3);
-    }
-    __syncthreads();
-  }
+  lds_fft_radix2<T, true, true>(tile, log2nx, KZ, 1, KZ, tw, nx, tid, nthr);
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
     if (active && z < kzn) col[x * xs + z] = tile[idx];

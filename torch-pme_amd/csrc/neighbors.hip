@@ -34,6 +34,7 @@ struct NlGeom {
   int reach[3];
   double cutoff2;
   int full_list;
+  int ps;                     // reals per atom in the positions array: 3, or 4 for (x, y, z, charge) records
   double foff[3], fscale[3];  // binning map of the non-periodic axes
 };
 
@@ -52,6 +53,7 @@ static inline NlGeom make_nl(const mipme_nl_t* d) {
   }
   g.cutoff2 = d->cutoff * d->cutoff;
   g.full_list = d->full_list;
+  g.ps = d->position_stride > 0 ? d->position_stride : 3;
   return g;
 }
 
@@ -119,7 +121,7 @@ enum NlFlags {
 template <typename T>
 __device__ __forceinline__ void atom_cell(const NlGeom& g, const T* __restrict__ pos, int64_t i, double (&rw)[3],
                                           int (&w)[3], int (&c)[3]) {
-  const double r[3] = {double(pos[3 * i]), double(pos[3 * i + 1]), double(pos[3 * i + 2])};
+  const double r[3] = {double(pos[g.ps * i]), double(pos[g.ps * i + 1]), double(pos[g.ps * i + 2])};
   double f[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -512,6 +514,7 @@ static int validate_nl(const mipme_nl_t* d) {
     MIPME_REQUIRE(d->reach[k] >= 0 && d->reach[k] <= kImageLimit * d->n_cells[k],
                   "the cell walk along axis %d spans more than %d images of the box (cutoff too large for this cell)", k, kImageLimit);
     MIPME_REQUIRE(d->periodic[k] || d->frac_scale[k] > 0.0, "a non-periodic axis needs a positive frac_scale");
+    MIPME_REQUIRE(d->position_stride == 0 || d->position_stride == 3 || d->position_stride == 4, "position_stride must be 3 or 4");
     ncells *= d->n_cells[k];
   }
   MIPME_REQUIRE(ncells < (int64_t(1) << 30), "cell grid too large");

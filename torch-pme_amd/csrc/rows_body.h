@@ -208,14 +208,26 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
   const int pot_end = (MODE == kPotForce && full) ? mid : 0x7fffffff;
   const int beg = FORCE ? r0 : pbeg;
   const int end = valid ? (FORCE ? r2 : pend) : beg;
-  const T ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+  // own position (and charge): from the caller's arrays, or -- pos == NULL: the records ARE the atoms' storage (live-bin step,
+  // bricks.hip) -- from the atom's own record
+  T ax, ay, az;
+  if (pos) {
+    ax = pos[3 * a];
+    ay = pos[3 * a + 1];
+    az = pos[3 * a + 2];
+  } else {
+    const AtomRecord<T> own = rec[a];
+    ax = own.x;
+    ay = own.y;
+    az = own.z;
+  }
   constexpr bool CAN_WRITE_D = POT && !MASK;
   int64_t pair_base = 0;  // pair index of entry r0 minus r0
   if constexpr (CAN_WRITE_D) {
     if (dist_out) pair_base = int64_t(entries[r0].y) - r0;
   }
   T qa = T(0), ga = T(0);
-  if constexpr (FORCE) qa = q[a];
+  if constexpr (FORCE) qa = q ? q[a] : rec[a].w;
   if constexpr (MODE == kForceG) ga = g[a];
   // general weights: half list 1/2 (g_a q_o + g_o q_a); full list keeps the first term for role i, the second for role j
   const T keep_i = T(0.5), keep_j_of_i = full ? T(0) : T(0.5);
@@ -481,9 +493,18 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
   const int r0 = rp[0], mid = rp[1], r2 = rp[2];
   const int n_entries = row_ptr[int64_t(args.row_stride) * N];
-  const f2v axy = f2v{pos[3 * a], pos[3 * a + 1]};
-  const float az = pos[3 * a + 2];
-  const float qa = args.q[a];
+  f2v axy;
+  float az, qa;
+  if (pos) {
+    axy = f2v{pos[3 * a], pos[3 * a + 1]};
+    az = pos[3 * a + 2];
+    qa = args.q[a];
+  } else {  // the records are the atoms' storage (live-bin step): own position and charge from the atom's own record
+    const AtomRecord<float> own = args.rec[a];
+    axy = f2v{own.x, own.y};
+    az = own.z;
+    qa = own.w;
+  }
   {
     float A[9];
 #pragma unroll

@@ -17,6 +17,82 @@ import torch
 from . import _lib, ops
 
 
+class _LiveStep:
+    """Buffers and argument struct of ``mipme_md_rebin`` / ``mipme_md_step`` (include/mipme.h): the energy + forces step of an
+    MD-like loop on device-resident neighbour structures.  The atoms live in ONE (N, 4) array of records (x, y, z, charge) that
+    every kernel of the step reads; the atom -> mesh-brick bookkeeping (bins, per-brick atom lists) is rebuilt only when the
+    neighbour list is (``rebin``), while every weight is evaluated from the current positions in every step."""
+
+    def __init__(self, calculator, charges, cell, positions):
+        lib = self.lib = _lib.load()
+        device, dtype = positions.device, positions.dtype
+        N = positions.shape[0]
+        self.device, self.dtype, self.n_atoms = device, dtype, N
+        geom, G = calculator._kspace_setup(cell, dtype, device)
+        self.geom, self.G = geom, G
+        self.md = geom.desc(1)
+        self.pot = calculator.potential._descriptor()
+        self.dt = _lib.dtype_code(dtype)
+        if charges.shape[1] != 1 or not lib.mipme_md_supported(C.byref(self.md), C.byref(self.pot), N, self.dt):
+            raise NotImplementedError("outside the range of the live-bin step")
+        self.plan = _lib.get_plan(device, dtype, geom.ns, 1, geom.plan_store)
+        if not self.plan.xfused:
+            raise NotImplementedError("the live-bin step needs a power-of-two mesh along x")
+        self.rec = torch.empty((N, 4), dtype=dtype, device=device)
+        self.rec[:, :3] = positions.detach()
+        self.rec[:, 3] = charges.detach()[:, 0]
+        cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
+        self.cell = cell.detach().to(dtype).contiguous()
+        self.rho = torch.empty(geom.ns, dtype=dtype, device=device)
+        self.phi = torch.empty(geom.ns, dtype=dtype, device=device)
+        self.hat = torch.empty((geom.n_half,), dtype=cdtype, device=device)
+        self.dc = torch.empty((1,), dtype=dtype, device=device)
+        self.bins = torch.empty((lib.mipme_atom_bins_bytes(C.byref(self.md), N, self.dt),), dtype=torch.uint8, device=device)
+        self.lists = torch.zeros((lib.mipme_md_lists_ints(C.byref(self.md), N),), dtype=torch.int32, device=device)
+        self.potentials = torch.empty((N,), dtype=dtype, device=device)
+        self.pair_force = torch.empty((N, 3), dtype=dtype, device=device)
+        self.energy = torch.empty((), dtype=dtype, device=device)
+        self.grad = torch.empty((N, 3), dtype=dtype, device=device)
+        self.minus_one = torch.tensor(-1.0, dtype=dtype, device=device)
+        self.flags = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.flags_np = self.flags.numpy()
+        self.nan_flag = calculator._nan_flag_ptr()
+        calculator._nan_shape = [1, *geom.ns]
+        self.rows = None  # (row_ptr, words, shift_format)
+
+    def _args(self):
+        row_ptr, words, fmt = self.rows if self.rows is not None else (self.lists, self.lists, 2)  # (rebin reads no rows)
+        return _lib.MdArgs(
+            plan=self.plan.handle, stream=_lib.current_stream(self.device), dtype=self.dt, shift_format=fmt,
+            mesh=C.pointer(self.md), pot=C.pointer(self.pot), n_atoms=self.n_atoms, records=self.rec.data_ptr(),
+            cell=self.cell.data_ptr(), G=self.G.data_ptr(), rho_mesh=self.rho.data_ptr(), hat_work=self.hat.data_ptr(),
+            phi_mesh=self.phi.data_ptr(), dc=self.dc.data_ptr(), atom_bins=self.bins.data_ptr(),
+            live_lists=self.lists.data_ptr(), row_ptr=row_ptr.data_ptr(), words=words.data_ptr(),
+            potentials=self.potentials.data_ptr(), pair_force=self.pair_force.data_ptr(), energy=self.energy.data_ptr(),
+            grad_positions=self.grad.data_ptr(), grad_seed=self.minus_one.data_ptr(), nan_flag=self.nan_flag,
+            host_flags=self.flags.data_ptr())
+
+    def rebin(self):
+        with _lib.on_device(self.device):
+            a = self._args()
+            _lib.check(self.lib.mipme_md_rebin(C.byref(a)))
+
+    def step(self):
+        with _lib.on_device(self.device):
+            a = self._args()
+            _lib.check(self.lib.mipme_md_step(C.byref(a)))
+
+    def check(self):
+        f = int(self.flags_np[0])
+        if f:
+            self.flags_np[0] = 0
+            if f & 2:
+                raise RuntimeError("GraphedEnergyForces: an atom has moved more than one mesh point since the last refresh(); "
+                                   "the results of that step are invalid -- refresh the neighbour structures sooner")
+            raise RuntimeError("GraphedEnergyForces: a brick's atom list overflowed at the last refresh (very non-uniform "
+                               "system); construct with live_bins=False")
+
+
 class GraphedEnergyForces:
     """``E, F = step(positions)`` with ``E = sum_i q_i V_i`` and ``F = -dE/dpositions``, replayed from a HIP graph.
 
@@ -33,11 +109,16 @@ class GraphedEnergyForces:
         (cell-list binning + the walk that writes the rows): no list tensors, no sort, no re-capture of the step -- the MD form
         of the reference's "new list every call" (``examples/02-neighbor-lists-usage.py:97-164``).
     :param periodic: per-axis periodicity of the neighbour list made for ``neighbors=<cutoff>``
+    :param live_bins: (``neighbors=`` form) also keep the atom -> mesh-brick bookkeeping across steps and rebuild it in
+        :meth:`refresh`, evaluating every mesh weight on the fly from the current positions (``mipme_md_step``: five launches
+        per step instead of six, no per-step binning pass, no per-brick candidate scan).  Valid while no atom has moved more
+        than ONE MESH POINT since the last refresh -- checked in every step, reported like a row overflow.  Default: on where
+        the kernels cover the case (mesh calculators with 1/r or 1/r^6, no cell gradient).
     """
 
     def __init__(self, calculator, charges, cell, positions, neighbor_indices=None, neighbor_shifts=None, warmup: int = 3,
                  cell_gradient: bool = False, store_distances: bool = False, neighbors=None,
-                 periodic=(True, True, True)):
+                 periodic=(True, True, True), live_bins: bool | None = None):
         self.calc = calculator
         self.store_distances = bool(store_distances)
         self.stream = None
@@ -58,9 +139,26 @@ class GraphedEnergyForces:
         self._minus_one = torch.tensor(-1.0, dtype=positions.dtype, device=device)
         self._warmup = max(1, warmup)
         self.refresh_graph = None
+        self._live = None
+        if neighbors is not None and live_bins is not False and not cell_gradient and hasattr(calculator, "_kspace_setup") \
+                and calculator.potential.smearing is not None:
+            try:
+                live = _LiveStep(calculator, self.q, self.cell, self.pos)
+                live.rebin()  # trial: a very non-uniform system overflows the per-brick lists -> keep the binned step
+                torch.cuda.current_stream(device).synchronize()
+                live.check()
+                self._live = live
+                # the records are the atoms' storage from here on: `pos` is their (N, 3) view
+                self.pos = live.rec[:, :3]
+            except (NotImplementedError, RuntimeError):
+                if live_bins:
+                    raise
+                self._live = None
         if neighbors is not None:
             from .neighbors import NeighborStream
 
+            if isinstance(neighbors, NeighborStream) and self._live is not None:
+                raise ValueError("with live bins the neighbour stream is built on the object's own records: pass the cutoff")
             if isinstance(neighbors, NeighborStream):
                 if neighbors.n_atoms != self.pos.shape[0] or neighbors.dtype != self.pos.dtype:
                     raise ValueError("`neighbors` was built for other positions")
@@ -80,13 +178,20 @@ class GraphedEnergyForces:
         device = self.pos.device
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
+        if self._live is not None:
+            self._live.rows = (self.stream.row_ptr, self.stream.words, 2 | _lib.ROWS_PADDED)
         with torch.cuda.stream(side):
-            self.stream.update()
+            self._refresh_eager()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.refresh_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.refresh_graph):
-            self.stream.update()
+            self._refresh_eager()
+
+    def _refresh_eager(self):
+        self.stream.update()
+        if self._live is not None:
+            self._live.rebin()
 
     def refresh(self, positions: torch.Tensor | None = None, check: bool = False) -> None:
         """Rebuild the neighbour list from the current positions, in place (``neighbors=`` form only): one graph replay --
@@ -105,6 +210,8 @@ class GraphedEnergyForces:
             self._deferred_check(recover=True)
 
     def _deferred_check(self, recover: bool = False):
+        if self._live is not None:
+            self._live.check()
         st = self.stream
         if st is None or not int(st._host_np[1]):
             return
@@ -124,7 +231,25 @@ class GraphedEnergyForces:
                 self.pos.copy_(positions)
         self._capture(neighbor_indices, neighbor_shifts)
 
+    def _capture_live(self):
+        device = self.pos.device
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):  # warm-up off the default stream (the plan allocates its scratch on first use)
+            for _ in range(self._warmup):
+                self._live.step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self._keepalive = [self._live, self.stream, getattr(self.calc, "_cache", None)]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._live.step()
+        self.energy, self.forces, self.cell_grad, self.distances = self._live.energy, self._live.grad, None, None
+        self.pairs, self.shifts = self.stream.indices, None
+
     def _capture(self, neighbor_indices, neighbor_shifts):
+        if self._live is not None:
+            return self._capture_live()
         calculator, cell_gradient, device, warmup = self.calc, self.cell_gradient, self.pos.device, self._warmup
         self.pairs = neighbor_indices
         self.shifts = None if neighbor_shifts is None else neighbor_shifts.to(self.pos.dtype).contiguous()

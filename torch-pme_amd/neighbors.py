@@ -276,9 +276,11 @@ class NeighborStream:
             raise ValueError("a NeighborStream addresses at most 2^22 atoms (4-byte entries)")
         self._dt = _lib.dtype_code(self.dtype)
         pos = positions.detach()
-        if not pos.is_contiguous():
-            raise ValueError("`positions` must be contiguous (the stream re-reads this tensor in place)")
+        # (N,3) contiguous, or the (N,3) view of (N,4) records x, y, z, charge (GraphedEnergyForces keeps its atoms that way)
+        if pos.dim() != 2 or pos.shape[1] != 3 or pos.stride(1) != 1 or pos.stride(0) not in (3, 4):
+            raise ValueError("`positions` must be a contiguous (N, 3) tensor (the stream re-reads this tensor in place)")
         self._desc = _nl_descriptor(cell.detach().to("cpu", torch.float64).numpy(), cutoff, self.periodic, pos, True)
+        self._desc.position_stride = int(pos.stride(0)) if N > 1 else 3
         self._ws = torch.zeros((lib.mipme_nl_workspace_bytes(C.byref(self._desc), N),), dtype=torch.uint8, device=self.device)
         self._host = torch.zeros((4,), dtype=torch.int32).pin_memory()
         self._host_np = self._host.numpy()
