@@ -564,7 +564,7 @@ typedef struct {
   void* phi_mesh;           /* work: (nx,ny,nz) */
   void* dc;                 /* work: 1 real */
   void* atom_bins;          /* mipme_atom_bins_bytes(); written by mipme_md_rebin, read by the steps */
-  void* live_lists;         /* 4 * mipme_md_lists_ints() bytes; likewise */
+  void* live_lists;         /* 4 * mipme_md_lists_ints() bytes, ZERO-FILLED ONCE by the caller; likewise */
   const void* row_ptr;      /* neighbour rows */
   const void* words;
   void* potentials;         /* out (N) */

@@ -26,3 +26,10 @@ python tools/size_sweep.py > $OUT/${TAG}_size_sweep.txt 2>&1
 python tools/frames_probe.py > $OUT/${TAG}_frames_probe.txt 2>&1
 python tools/time_stress.py > $OUT/${TAG}_stress.txt 2>&1
 ls -la $OUT | grep ${TAG}
+# round 3: device neighbour stream + live-bin step
+python bench.py --neighbors stream --steps 500 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_bench_stream.json 2>> $OUT/${TAG}_bench_default.err
+python tools/time_refresh.py > $OUT/${TAG}_refresh.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_live -o l -- python $ROOT/tools/prof_live.py > /dev/null 2>&1)
+python tools/rocpd_summary.py $(find $OUT/${TAG}_live -name '*.db') > $OUT/${TAG}_kernel_stats_live_step.txt
+rm -rf $OUT/${TAG}_live
+ls -la $OUT | grep ${TAG}

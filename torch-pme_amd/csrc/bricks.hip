@@ -1827,14 +1827,32 @@ __global__ __launch_bounds__(256) void live_bin_kernel(Geom g, BrickGeom bg, boo
                                                       int64_t Natoms, const AtomRecord<T>* __restrict__ rec4,
                                                       int* __restrict__ over_brick, int4* __restrict__ rec) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= Natoms) return;
+  if (i >= Natoms) return;  // (whole-wave exits aside, the ballots below see the exec mask of the remaining lanes)
   const AtomRecord<T> r = rec4[i];
   const T p3[3] = {r.x, r.y, r.z};
   int m[3];
   double x[3];
   atom_mesh_coords<T>(g, even, p3, 0, m, x);
   const int b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
-  const int slot = atomicAdd(&counters[b], 1);
+  // lanes of the wave that fall into the same brick share one returning atomic (as bin_atoms_body)
+  const int lane = threadIdx.x & 63;
+  unsigned long long remaining = __ballot(true);
+  int my_leader = lane, my_rank = 0, my_count = 1;
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int b0 = __shfl(b, leader, 64);
+    const unsigned long long peers = __ballot(b == b0) & remaining;
+    if (b == b0) {
+      my_leader = leader;
+      my_rank = __popcll(peers & ((1ull << lane) - 1ull));
+      my_count = __popcll(peers);
+    }
+    remaining &= ~peers;
+  }
+  int base = 0;
+  if (my_leader == lane) base = atomicAdd(&counters[b], my_count);
+  base = __shfl(base, my_leader, 64);
+  const int slot = base + my_rank;
   int64_t dst;
   if (slot < bi.cap) {
     dst = int64_t(b) * bi.cap + slot;
@@ -2203,7 +2221,7 @@ int live_rebin(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec
   const BrickGeom bg = make_brick_geom(m);
   BinsView v = bins_view(m, N, dtype, bins);
   const LiveLists ll = live_view(m, N, lists, host_flags);
-  MIPME_CHECK_HIP(zero_async(ll.counters, sizeof(int) * size_t(bg.nb + 1), st));
+  // (the counters are zero here: the lists buffer starts zeroed and live_snapshot_kernel leaves them so)
   live_bin_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(g, bg, (m->order % 2) == 0, v.idx, ll.counters, N,
                                                               (const AtomRecord<T>*)rec4, v.over_brick, v.rec);
   MIPME_LAUNCH_CHECK();
