@@ -41,6 +41,11 @@ class Calculator(torch.nn.Module):
         #:   True                 -- right after the call (synchronises, as the reference does);
         #:   False                -- never.
         self.check_nan = "deferred"
+        #: second derivatives (``create_graph=True``: training on forces).  The HIP kernels are first order; ``None`` (default)
+        #: makes a double differentiation raise a RuntimeError that names this attribute, ``"finite-difference"`` routes the
+        #: call through ``ops.second_order_by_finite_differences``: first order exactly as before, the backward of the backward
+        #: from central differences of the analytic gradients (two more evaluations; use float64)
+        self.double_backward = None
         self._nan_flag = None  # pinned int32[1], created on first use
         self._nan_shape = None
         self._spec_str = None
@@ -155,6 +160,23 @@ class Calculator(torch.nn.Module):
     def _eager_forward(self, *args):
         if ops.inside_vmap(*args):
             return ops.vmap_bridge(self._forward_impl, *args)
+        if self.double_backward is not None and torch.is_grad_enabled() and any(
+                isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+            if self.double_backward != "finite-difference":
+                raise ValueError(f"`double_backward` is {self.double_backward!r} but must be None or 'finite-difference'")
+            charges, cell, positions, pairs, dist, *rest = args
+            # the distances are an ordinary differentiable input here (no fused / lazy pair gradient: the chain through
+            # `pair_distances` is exact second order by itself)
+            dist = dist.materialize() if isinstance(dist, ops.LazyPairGradient) else dist
+            src = getattr(dist, "_mipme_src", None)
+            if src is not None and src.pending:
+                src.materialize()
+
+            def first_order_eval(q, c, p, d, *others):
+                # plain (unfused) evaluation: `d` carries no provenance, so the calculator differentiates w.r.t. it as a tensor
+                return self._forward_impl(q, c, p, pairs, d, *others)
+
+            return ops.second_order_by_finite_differences(first_order_eval, (charges, cell, positions, dist), tuple(rest))
         return self._forward_impl(*args)
 
     def _forward_impl(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,

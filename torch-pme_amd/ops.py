@@ -24,6 +24,43 @@ import torch
 from . import _lib
 
 
+SECOND_ORDER_HINT = (
+    "torchpme_amd: the HIP kernels provide FIRST-order gradients; this graph is being differentiated twice (create_graph=True, "
+    "e.g. a loss on forces).  Set `calculator.double_backward = \"finite-difference\"` before the forward call: the second "
+    "derivative is then formed from central differences of the analytic first-order gradients (two more evaluations per "
+    "double-backward pass; use float64), and distances from `pair_distances` differentiate twice exactly.")
+
+
+def first_order(fn):
+    """``torch.autograd.function.once_differentiable`` with an error message that names the way out (reference behaviour:
+    plain ATen ops differentiate any number of times, ``calculators/calculator.py:103-189``)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        with torch.no_grad():
+            outputs = fn(ctx, *args)
+        if not torch.is_grad_enabled():
+            return outputs
+        # create_graph=True: the results depend on the node's SAVED inputs as well, whether or not the incoming gradient
+        # carries a graph (torch's once_differentiable only looks at the latter and then returns constants silently): every
+        # output points at a node that raises when something differentiates through it
+        single = not isinstance(outputs, tuple)
+        outs = (outputs,) if single else outputs
+        err = torch._C._functions.DelayedError(SECOND_ORDER_HINT.encode(), len(outs))
+
+        def fake_requires_grad(v):
+            if v is not None:
+                v = v.detach()
+                v.requires_grad = True
+            return v
+
+        res = err(*[fake_requires_grad(v) for v in outs])
+        return res[0] if single else res
+
+    return wrapper
+
+
 # Optional per-call timing used by bench.py: when PROFILE is a dict, every C-ABI call below is bracketed by
 # HIP events recorded on the launch stream (torch.cuda.Event records on the current stream, which is the
 # stream handed to libmipme).  PROFILE[name] collects (start, end) event pairs.
@@ -722,7 +759,7 @@ class _PMEFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    @first_order
     def backward(ctx, grad_out):
         lib = _lib.load()
         q, pos, dist, pairs, mask, G, phi_mesh, rho_hat, rho_dc, phi_atoms, bins, out = ctx.saved_tensors
@@ -1047,11 +1084,32 @@ class _PairDistances(torch.autograd.Function):
         ctx.save_for_backward(pos, cl, pairs, sh)
         ctx.topo = topo
         ctx.shifts_key = shifts
+        #: the inputs as the caller passed them (with their autograd history), for a backward pass that is itself recorded
+        ctx.inputs_for_second_order = (positions, cell) if SECOND_ORDER_DISTANCES else None
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_d):
+        if torch.is_grad_enabled() and ctx.inputs_for_second_order is not None:
+            # create_graph=True: the adjoint of the distances as differentiable tensor ops (exact second order; what the
+            # reference's helper does, tests/helpers.py:278-304) -- the HIP adjoint kernel is first order
+            positions, cell = ctx.inputs_for_second_order
+            _, _, pairs, sh = ctx.saved_tensors
+            if isinstance(grad_d, LazyPairGradient):
+                grad_d = grad_d.materialize()
+            i, j = pairs[:, 0].long(), pairs[:, 1].long()
+            vec = positions[j] - positions[i]
+            if sh is not None:
+                vec = vec + sh @ cell
+            gvec = (grad_d / torch.linalg.norm(vec, dim=1)).unsqueeze(1) * vec
+            gp = torch.zeros_like(positions).index_add(0, j, gvec).index_add(0, i, -gvec)
+            gc = sh.T @ gvec if (sh is not None and cell is not None and ctx.needs_input_grad[1]) else None
+            return (gp if ctx.needs_input_grad[0] else None), gc, None, None, None
+        return _PairDistances._backward_first_order(ctx, grad_d)
+
+    @staticmethod
+    @first_order
+    def _backward_first_order(ctx, grad_d):
         lib = _lib.load()
         pos, cl, pairs, sh = ctx.saved_tensors
         device, dtype = pos.device, pos.dtype
@@ -1148,6 +1206,90 @@ def stream_distances(stream, positions, cell):
     return dist
 
 
+#: keep the distance node's inputs alive for a recorded (create_graph=True) backward pass; costs nothing unless used
+SECOND_ORDER_DISTANCES = True
+
+
+class _FiniteDifferenceSecondOrder(torch.autograd.Function):
+    """``V = f(*z)`` for a black-box first-order evaluation ``f`` (a calculator's forward on the HIP kernels) as a node whose
+    BACKWARD is differentiable too: the vector-Jacobian product ``G(g, z) = grad_z <g, f(z)>`` is formed analytically by the
+    first-order path; when that pass is itself being recorded (``create_graph=True``), ``G`` is issued as a second node whose
+    backward -- the Hessian-vector product and ``d<c, G>/dg`` -- comes from central differences of the analytic ``G`` and of
+    ``f`` along the incoming cotangent ``c``:  H c = [G(g, z + e c) - G(g, z - e c)] / 2e,  d/dg = [f(z + e c) - f(z - e c)] / 2e.
+    Two more evaluations per double-backward pass; error O(e^2) + rounding / e (float64: ~1e-7 relative with e = 1e-4 |z| / |c|)."""
+
+    @staticmethod
+    def forward(ctx, f, n_diff, *z):
+        ctx.f, ctx.n_diff = f, n_diff
+        with torch.no_grad():
+            out = f(*[t.detach() if isinstance(t, torch.Tensor) else t for t in z])
+        ctx.save_for_backward(*[t for t in z[:n_diff]])
+        ctx.rest = z[n_diff:]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            needs = tuple(ctx.needs_input_grad[2:2 + ctx.n_diff])
+            grads = _FiniteDifferenceGradient.apply(ctx.f, ctx.n_diff, ctx.rest, needs, g, *z)
+            grads = [x if n else None for x, n in zip(grads, needs)]
+        else:
+            grads = _fd_vjp(ctx.f, ctx.rest, tuple(ctx.needs_input_grad[2:2 + ctx.n_diff]), g, z)
+        return (None, None, *grads, *([None] * len(ctx.rest)))
+
+
+def _fd_vjp(f, rest, needs, g, z):
+    """grad_z <g, f(z, *rest)> through the first-order autograd nodes of the HIP path (None where not needed)."""
+    with torch.enable_grad():
+        leaves = [t.detach().requires_grad_(n) for t, n in zip(z, needs)]
+        V = f(*leaves, *rest)
+        wanted = [t for t, n in zip(leaves, needs) if n]
+        got = list(torch.autograd.grad(V, wanted, g.detach(), allow_unused=True)) if wanted else []
+    out = []
+    for t, n in zip(leaves, needs):
+        gr = got.pop(0) if n else None
+        out.append(torch.zeros_like(t) if (n and gr is None) else (gr.detach() if gr is not None else None))
+    return out
+
+
+class _FiniteDifferenceGradient(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, n_diff, rest, needs, g, *z):
+        ctx.f, ctx.rest, ctx.needs = f, rest, needs
+        ctx.save_for_backward(g, *z)
+        grads = _fd_vjp(f, rest, needs, g, z)
+        out = tuple(torch.zeros((), device=g.device, dtype=g.dtype) if x is None else x for x in grads)
+        ctx.mark_non_differentiable(*[o for o, x in zip(out, grads) if x is None])
+        return out
+
+    @staticmethod
+    @first_order
+    def backward(ctx, *cot):
+        g, *z = ctx.saved_tensors
+        f, rest, needs = ctx.f, ctx.rest, ctx.needs
+        c = [ci if (n and ci is not None) else None for ci, n in zip(cot, needs)]
+        cmax = max((float(ci.abs().max()) for ci in c if ci is not None and ci.numel()), default=0.0)
+        if cmax == 0.0:
+            return (None, None, None, None, torch.zeros_like(g), *[torch.zeros_like(t) if n else None for t, n in zip(z, needs)])
+        # largest change of any input component along the direction: 1e-4 (float64) / 1e-2 (float32) in the inputs' own units
+        # (Angstrom, charges: scales of order one)
+        eps = (1e-4 if g.dtype == torch.float64 else 1e-2) / cmax
+        zp = [t.detach() + eps * ci if ci is not None else t.detach() for t, ci in zip(z, c)]
+        zm = [t.detach() - eps * ci if ci is not None else t.detach() for t, ci in zip(z, c)]
+        with torch.no_grad():
+            Vp, Vm = f(*zp, *rest), f(*zm, *rest)
+        Gp, Gm = _fd_vjp(f, rest, needs, g, zp), _fd_vjp(f, rest, needs, g, zm)
+        grad_g = (Vp - Vm) / (2 * eps)
+        Hc = [((a - b) / (2 * eps)) if n else None for a, b, n in zip(Gp, Gm, needs)]
+        return (None, None, None, None, grad_g, *Hc)
+
+
+def second_order_by_finite_differences(f, diff_inputs, other_inputs):
+    """``f(*diff_inputs, *other_inputs)`` with a differentiable backward pass (see :class:`_FiniteDifferenceSecondOrder`)."""
+    return _FiniteDifferenceSecondOrder.apply(f, len(diff_inputs), *diff_inputs, *other_inputs)
+
+
 _DOT_SCRATCH = {}
 
 
@@ -1179,7 +1321,7 @@ class _WeightedSum(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    @first_order
     def backward(ctx, g):
         lib = _lib.load()
         a, b = ctx.saved_tensors
@@ -1236,7 +1378,7 @@ class _EnergyDirectSum(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    @first_order
     def backward(ctx, g):
         lib = _lib.load()
         q = ctx.q
@@ -1290,7 +1432,7 @@ class _EwaldKSpace(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    @first_order
     def backward(ctx, grad_out):
         lib = _lib.load()
         q, pos, kv, G, dG, Sc, Ss = ctx.saved_tensors
