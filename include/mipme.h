@@ -368,6 +368,18 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
  * host_flag (nullable): ONE int32 of pinned host memory that also receives the verdict (0 / 1, system-scope store) -- the
  * caller presets it to -1 and polls it instead of copying `result` back. */
 int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag);
+/* The same decision WITHOUT a host round trip (the poll above makes the host wait for everything queued before it: the eager
+ * reference call sequence then runs GPU and host one after the other).  The caller launches mipme_scaled_match with a DEVICE
+ * int32 as `host_flag`, announces it with mipme_set_skip_flag(flag) -- kernels launched by THIS THREAD through
+ * mipme_kspace_backward (general path) and mipme_sr_rows_fused until mipme_set_skip_flag(NULL) read it first and return at once
+ * if it is 1; best effort: kernels without the check (hipFFT plans, atomic mesh kernels) just do their work -- runs the general
+ * backward, and finally mipme_energy_select: if the verdict (`result` of mipme_scaled_match) is a match it overwrites
+ *   grad_mesh[a] = s q_a field_a            (nullable; field = out_field of the forward)
+ *   grad_pair[a] = s q_a f force_a          (nullable; force = pair force sums of the forward; f = 1/2 for a full list)
+ * and otherwise leaves the general path's results in place. */
+int mipme_set_skip_flag(const void* device_flag);
+int mipme_energy_select(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
+                        const void* field, int full_list, void* grad_mesh, void* grad_pair);
 
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 

@@ -168,8 +168,10 @@ def test_energy_gradient_detected_without_tag(dtype, monkeypatch):
     calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.1), mesh_spacing=0.45, interpolation_nodes=4).to(dtype)
     gen = t(rng.normal(size=q.shape))
 
-    def run(reduce, detect):
+    def run(reduce, detect, on_device=False):
         monkeypatch.setattr(ops, "ENERGY_DETECT", detect)
+        monkeypatch.setattr(ops, "DEVICE_SELECT", on_device)
+        monkeypatch.setattr(ops, "DEVICE_SELECT_MIN_ATOMS", 0)
         tp = t(pos, True)
         calls = {}
         monkeypatch.setattr(ops, "PROFILE", calls)
@@ -192,3 +194,8 @@ def test_energy_gradient_detected_without_tag(dtype, monkeypatch):
         assert ("kspace_backward" not in calls) == is_energy, (is_energy, calls.keys())
         assert "kspace_backward" in calls_off
         assert rell2(g_on.cpu().double(), g_off.cpu().double()) < tol
+        # the same decision taken ON THE DEVICE (default: no host poll): the general adjoint is launched with a skip flag and
+        # mipme_energy_select swaps in the energy-mode expressions when the verdict is a match -- same gradients either way
+        g_dev, calls_dev = run(reduce, True, on_device=True)
+        assert "scaled_match" in calls_dev and "energy_select" in calls_dev and "kspace_backward" in calls_dev
+        assert rell2(g_dev.cpu().double(), g_off.cpu().double()) < tol

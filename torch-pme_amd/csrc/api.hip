@@ -466,6 +466,21 @@ __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* 
   }
 }
 
+// verdict = result of scaled_match_kernel: {s, 1 or 0}.  1: the upstream gradient is s * charges -- overwrite the general path's
+// (skipped) outputs with the energy-mode expressions from the forward's per-atom sums; 0: leave them.
+template <typename T>
+__global__ __launch_bounds__(256) void energy_select_kernel(int64_t N, const T* __restrict__ verdict, const T* __restrict__ q,
+                                                           const T* __restrict__ force, const T* __restrict__ field, T f,
+                                                           T* __restrict__ grad_mesh, T* __restrict__ grad_pair) {
+  if (verdict[1] != T(1)) return;
+  const T s = verdict[0];
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < 3 * N; t += int64_t(gridDim.x) * blockDim.x) {
+    const T sq = s * q[t / 3];
+    if (grad_mesh) grad_mesh[t] = sq * field[t];
+    if (grad_pair) grad_pair[t] = sq * f * force[t];
+  }
+}
+
 static double axis_length(const mipme_mesh_t* m, int axis) {
   const double* a = m->cell + 3 * axis;
   return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -981,5 +996,31 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 }
 
 int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }
+
+int mipme_set_skip_flag(const void* device_flag) {
+  skip_flag_slot() = (const int*)device_flag;
+  return MIPME_OK;
+}
+
+int mipme_energy_select(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
+                        const void* field, int full_list, void* grad_mesh, void* grad_pair) {
+  MIPME_REQUIRE(n_atoms >= 0 && verdict && charges, "invalid arguments to mipme_energy_select");
+  MIPME_REQUIRE((!grad_mesh || field) && (!grad_pair || force), "mipme_energy_select: an output without its forward sum");
+  if (n_atoms == 0) return MIPME_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = unsigned(std::min<int64_t>((3 * n_atoms + 255) / 256, 4096));
+  if (dtype == MIPME_F32)
+    energy_select_kernel<float><<<blocks, 256, 0, st>>>(n_atoms, (const float*)verdict, (const float*)charges, (const float*)force,
+                                                       (const float*)field, full_list ? 0.5f : 1.0f, (float*)grad_mesh, (float*)grad_pair);
+  else if (dtype == MIPME_F64)
+    energy_select_kernel<double><<<blocks, 256, 0, st>>>(n_atoms, (const double*)verdict, (const double*)charges, (const double*)force,
+                                                        (const double*)field, full_list ? 0.5 : 1.0, (double*)grad_mesh, (double*)grad_pair);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
 
 }  // extern "C"

@@ -500,6 +500,7 @@ struct SpreadArgs {
   T* mesh;
   int stage_rows;
   bool det;  // deterministic mode: order every round of survivors by slot before staging
+  const int* skip;  // nullable: return at once if *skip == 1 (mipme_set_skip_flag)
 };
 
 // block = index of the brick (workgroup index among the spread workgroups of the launch)
@@ -712,11 +713,13 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
 
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS) void spread_brick_kernel(SpreadArgs<T> a) {
+  MIPME_SKIP_IF_SET(a.skip);
   const unsigned b = brick_of(a.bg, blockIdx.x);
   if (b < unsigned(a.bg.nb)) spread_brick_body<N, T>(a, b);
 }
 template <int N, typename T>
 __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_kernel(SpreadArgs<T> a) {
+  MIPME_SKIP_IF_SET(a.skip);
   const unsigned b = brick_of(a.bg, blockIdx.x);
   if (b < unsigned(a.bg.nb)) spread_brick_body<N, T, SPREAD_THREADS_SPARSE>(a, b);
 }
@@ -1078,8 +1081,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
     Geom g, BrickGeom bg, int C, BinIndex bins, const int4* __restrict__ rec, const T* __restrict__ wts,
     const T* __restrict__ q, const T* __restrict__ gout, const T* __restrict__ phi, const T* __restrict__ chi,
     const T* __restrict__ psi_dc, const T* __restrict__ gscale, T half_inv_vol, T self_c, T bg_c,
-    T* __restrict__ grad_pos, T* __restrict__ grad_q) {
+    T* __restrict__ grad_pos, T* __restrict__ grad_q, const int* __restrict__ skip) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
+  MIPME_SKIP_IF_SET(skip);
   constexpr int LANES = kGatherLanes;
   constexpr int GROUPS = GATHER_THREADS / LANES;
   constexpr int TL = BRICK + N - 1;
@@ -1304,6 +1308,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.mesh = (T*)mesh;
   sa.stage_rows = stage_rows;
   sa.det = deterministic_mode();
+  sa.skip = job ? nullptr : skip_flag_slot();  // (the co-scheduled forward launch is never conditional)
   if (job) {
     // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
     SRPot s;
@@ -1454,7 +1459,7 @@ int gather_grad_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* b
       ((void)S, gather_grad_brick_kernel<N, T><<<unsigned(bg.nb), GATHER_THREADS, lds, st>>>(
           g, bg, m->n_channels, v.idx, v.rec, (const T*)v.wts, (const T*)q, (const T*)gout, (const T*)phi,
           (const T*)chi, (const T*)psi_dc, (const T*)gscale, T(0.5 / m->volume), T(self_c), T(bg_c), (T*)grad_pos,
-          (T*)grad_q)));
+          (T*)grad_q, skip_flag_slot())));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -1643,6 +1648,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.spread.scale = T(1);
     d.spread.mesh = (T*)f.rho_mesh;
     d.spread.stage_rows = spread_stage_rows(m->order, sizeof(T));
+    d.spread.skip = nullptr;
     d.spread.det = false;  // (the frames path keeps the one-pass binning: MIPME_DETERMINISTIC covers single-frame evaluations)
     d.rows = make_fused_rows_args<T>(s, cf, f.n_atoms, f.row_ptr, f.entries_shift, f.entries, nullptr, f.positions, f.records,
                                      f.cell, f.charges, nullptr, 0, f.full_list ? 0 : 1, f.full_list, 0, f.out, f.force, nullptr,

@@ -172,7 +172,10 @@ __device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
   }
 }
 
-// Register-array select with a runtime index (keeps the arrays in VGPRs).
+// Register-array select with a runtime index.  CAUTION: LLVM may turn the select chain back into an indexed load of a private
+// array and promote that array to LDS; the per-thread slice index then needs the workgroup size, which every wave reads from the
+// AQL dispatch packet in HOST memory (3-16 us for the first load of a workgroup: profiles/r03_experiments.txt item 4).  Check
+// "LDS Size" in -Rpass-analysis=kernel-resource-usage when using it in a latency-bound kernel; a masked sum is immune.
 template <int N, typename T>
 __device__ __forceinline__ T pick(const T (&a)[N], int idx) {
   T r = a[0];
@@ -245,6 +248,17 @@ __host__ __device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigne
   return (wg & 7u) * chunk + (wg >> 3);
 }
 __host__ __device__ __forceinline__ unsigned pad8(unsigned n) { return (n + 7u) & ~7u; }
+
+// Conditional launches without a host round trip (mipme_set_skip_flag, include/mipme.h): a device int32 that the kernels of the
+// general backward path read first; 1 = return at once.  Per host thread; kernels that do not take the pointer simply run.
+inline const int*& skip_flag_slot() {
+  static thread_local const int* p = nullptr;
+  return p;
+}
+#define MIPME_SKIP_IF_SET(ptr)                          \
+  do {                                                  \
+    if ((ptr) != nullptr && *(ptr) == 1) return;        \
+  } while (0)
 
 // boolean switch from the environment ("0" = off, anything else = on), for A/B measurements of kernel variants
 inline bool env_flag(const char* name, bool dflt) {

@@ -726,7 +726,9 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
 
 template <typename T, bool INVERSE, bool YSTAGE = true>
 __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
-                                                       Cplx<T>* __restrict__ hat, T* __restrict__ real_out) {
+                                                       Cplx<T>* __restrict__ hat, T* __restrict__ real_out,
+                                                       const int* __restrict__ skip) {
+  MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_yz[];
   yz_plane_body<T, INVERSE, YSTAGE>(ny, nz, logny, loglz, real_in, hat, real_out, blockIdx.x, smem_yz);  // plane = (channel, x)
 }
@@ -736,7 +738,9 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
 // inverse: loaded through the bit reversal, decimation in time, conjugate twiddles -- in place, natural order in memory both
 // ways, un-normalised.  Segments of KZ complex values (>= 64 B) keep the strided accesses coalesced.
 template <typename T, bool INVERSE>
-__global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, int kzs, int nchunk, Cplx<T>* __restrict__ hat) {
+__global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, int kzs, int nchunk, Cplx<T>* __restrict__ hat,
+                                                   const int* __restrict__ skip) {
+  MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_yc[];
   const int KZ = 1 << kzs, KP = KZ + 1;                 // rows padded by one element: the butterflies stride over y, and an
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yc);  // even row length would put a wave's 64 accesses on the same banks
@@ -773,9 +777,9 @@ static int ycols(mipme_fft_plan* p, hipStream_t st, bool inverse, void* hat) {
   const size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * ((size_t(1) << kzs) + 1) + size_t(p->ny / 2));
   const unsigned grid = unsigned(nchunk) * unsigned(p->nx) * unsigned(p->batch);
   if (inverse)
-    ycols_kernel<T, true><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat);
+    ycols_kernel<T, true><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat, skip_flag_slot());
   else
-    ycols_kernel<T, false><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat);
+    ycols_kernel<T, false><<<grid, 256, lds, st>>>(p->ny, nzh, logny, kzs, nchunk, (Cplx<T>*)hat, skip_flag_slot());
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -799,9 +803,9 @@ static int zrows(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* re
   const int work = R * (Lz + 1);
   const int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
   if (inverse)
-    yz_planes_kernel<T, true, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out);
+    yz_planes_kernel<T, true, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out, skip_flag_slot());
   else
-    yz_planes_kernel<T, false, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr);
+    yz_planes_kernel<T, false, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr, skip_flag_slot());
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -836,9 +840,9 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
     }
   }
   if (inverse)
-    yz_planes_kernel<T, true><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out);
+    yz_planes_kernel<T, true><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out, skip_flag_slot());
   else
-    yz_planes_kernel<T, false><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr);
+    yz_planes_kernel<T, false><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr, skip_flag_slot());
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -997,7 +1001,8 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
                                                    Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
                                                    T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
                                                    double* __restrict__ epart, const double* __restrict__ sr_part,
-                                                   int n_sr_part) {
+                                                   int n_sr_part, const int* __restrict__ skip) {
+  MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   xconv_tile_body<T, CELLSUMS>(nx, ny, nzh, log2nx, kzs, nchunk, hat, G, G_stride, dc, kg, kp, partials, epart, sr_part,
                                n_sr_part, blockIdx.x, gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x);
@@ -1204,10 +1209,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
                                                             (const float*)G, G_stride, (float*)dc, kg, kp,
-                                                            (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part));
+                                                            (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
     else
       xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
-                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part));
+                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<float>(p, st, true, nullptr, hat, mesh_out);
@@ -1225,10 +1230,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     if (cell_partials)
       xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
                                                              (const double*)G, G_stride, (double*)dc, kg, kp,
-                                                             (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part));
+                                                             (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
     else
       xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part));
+                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
     MIPME_LAUNCH_CHECK();
     if (p->own_yz) {
       int rc = yz_planes<double>(p, st, true, nullptr, hat, mesh_out);

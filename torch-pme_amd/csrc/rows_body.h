@@ -99,6 +99,7 @@ struct FusedRowsArgs {
   // w of workgroup b at index b * BS/64 + w) -- the pair part of the energy and the self-term sum, reduced later by the
   // gather's tail (bricks.hip)
   double* epart;
+  const int* skip;  // nullable: the stand-alone kernels return at once if *skip == 1 (mipme_set_skip_flag)
   int row_stride;  // words of row_ptr per atom: 2 (rows share their boundaries) or 3 (kRowsPadded)
   bool symmetric;  // kRowsPadded: every pair appears in both of its rows as a "role i" entry
 };
@@ -132,6 +133,7 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
   a.partials = (double*)partials;
   a.dist_out = (T*)dist_out;
   a.epart = nullptr;
+  a.skip = nullptr;
   a.symmetric = (shift_format & kRowsPadded) != 0;
   a.row_stride = a.symmetric ? 3 : 2;
   if (a.symmetric) a.full = false;

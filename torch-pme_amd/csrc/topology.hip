@@ -381,6 +381,7 @@ __global__ void pack_atom_records_kernel(int64_t N, const T* __restrict__ pos, c
 
 template <typename T, int MODE, bool CELLGRAD, int PFAST, bool MASK, bool TABLE>
 __global__ __launch_bounds__(256) void sr_fused_rows_kernel(FusedRowsArgs<T> a) {
+  MIPME_SKIP_IF_SET(a.skip);
   __shared__ AtomRecord<T> shift_tab[TABLE ? kShiftTableSize : 1];
   sr_fused_rows_body<T, MODE, CELLGRAD, PFAST, MASK, TABLE, 256>(a, blockIdx.x, shift_tab);
 }
@@ -549,9 +550,10 @@ static int sr_fused_rows_impl(hipStream_t st, int64_t N, const void* row_ptr, co
     set_error("mipme_sr_rows_fused: nothing to compute");
     return MIPME_EINVAL;
   }
-  const FusedRowsArgs<T> args = make_fused_rows_args<T>(s, cf, N, row_ptr, ent_sh, entries, mask, pos, records, cell, q, g, lo, hi,
-                                                        full_list, accumulate, out, force, partials, dist_out,
-                                                        shift_format | row_flags);
+  FusedRowsArgs<T> args = make_fused_rows_args<T>(s, cf, N, row_ptr, ent_sh, entries, mask, pos, records, cell, q, g, lo, hi,
+                                                  full_list, accumulate, out, force, partials, dist_out,
+                                                  shift_format | row_flags);
+  args.skip = skip_flag_slot();
   if (shift_format == kShiftTable32) {
     MIPME_REQUIRE(mode == kPotForce && !want_cg && pfast > 0 && N <= kCompactMaxAtoms,
                   "4-byte entries serve the potential + force pass of the Coulomb / dispersion fast paths only");

@@ -192,6 +192,14 @@ class seed_promise:
         return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
+#: ... and act on the verdict ON THE DEVICE (mipme_set_skip_flag / mipme_energy_select) where only position gradients are asked
+#: for, instead of polling it on the host: the poll makes the host wait for everything queued before it, i.e. the eager
+#: reference call sequence ran GPU and host one after the other
+DEVICE_SELECT = os.environ.get("MIPME_DEVICE_SELECT", "1") != "0"
+#: ... from this many atoms on: below, the eager step is bound by the host (0.3 ms of Python for 0.13 ms of kernels at 32k atoms)
+#: and the extra launches of the skipped general adjoint cost more host time than the poll (measured on one box: 0.39 against
+#: 0.33-0.37 ms at 31 944 atoms, 0.69 against 0.75 ms at 262 144)
+DEVICE_SELECT_MIN_ATOMS = int(os.environ.get("MIPME_DEVICE_SELECT_MIN_ATOMS", "65536"))
 
 # Reciprocal-space convolution as (y,z) plane transforms + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two
 # nx); "0" keeps the 3-D hipFFT plans + filter kernel.
@@ -552,6 +560,21 @@ class LazyPairGradient(torch.Tensor):
         return func(*tree_map(plain, args), **tree_map(plain, kwargs or {}))
 
 
+class _SkipGuard:
+    """Clears the library's per-thread skip flag (``mipme_set_skip_flag``) on the way out of a backward pass, whatever happened in
+    between: the flag points at a tensor that dies with the pass."""
+
+    armed = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.armed:
+            _lib.load().mipme_set_skip_flag(None)
+        return False
+
+
 class _PMEFunction(torch.autograd.Function):
     """SR + LR per-atom potentials as one autograd node."""
 
@@ -777,7 +800,8 @@ class _PMEFunction(torch.autograd.Function):
         full = int(ctx.full_list)
         g = grad_out.contiguous()
         grad_q = grad_pos = grad_cell = grad_dist = grad_src_pos = grad_src_cell = None
-        with _lib.on_device(device):
+        guard = _SkipGuard()
+        with _lib.on_device(device), guard:
             st = _lib.current_stream(device)
             do_kspace = geom is not None and (need_q or need_cell or need_pos)
             # Energy mode: if the upstream gradient was produced by ``weighted_sum(V, charges)`` with OUR charges it is
@@ -785,7 +809,7 @@ class _PMEFunction(torch.autograd.Function):
             # (b) the forces are gE q_a times the per-atom sums the forward pass already formed (``field`` from the gather,
             # ``force`` from the fused pair kernel), (c) for a half list dL/dq = gE * V (V is a symmetric bilinear form).
             tag = getattr(grad_out, "_mipme_scaled", None) if ENERGY_FAST_PATH else None
-            gscale = sr_scale = None
+            gscale = sr_scale = select = None
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
                 sr_scale = tag[3]  # enough for the pair part
             elif (ENERGY_FAST_PATH and ENERGY_DETECT and tag is None and N > 0 and (fused is not None or do_kspace)
@@ -794,20 +818,37 @@ class _PMEFunction(torch.autograd.Function):
                 # device whether the gradient is a multiple of the charges (one small kernel + a 2-value read; the general
                 # adjoint it saves is a second spread, an FFT pair and a gradient gather).  Not during graph capture.
                 res = torch.empty((2,), dtype=dtype, device=device)
-                flag, flag_np = _match_flag(device)
-                flag_np[0] = -1
-                _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
-                      flag.data_ptr())
-                # the kernel also writes its verdict to pinned host memory: poll that word instead of a device-to-host copy
-                # (hipMemcpy of 4 bytes costs 20-30 us on this stack; the poll ends a few us after the kernel does)
-                spins = 0
-                while flag_np[0] == -1:
-                    spins += 1
-                    if spins > 2_000_000:  # never seen; a stream synchronisation is the fallback
-                        torch.cuda.current_stream(device).synchronize()
-                        break
-                if flag_np[0] == 1:
-                    sr_scale = res[:1]
+                # (rows of a NeighborStream: the general pair kernel reads 8-byte entries, which would have to be expanded from
+                # the stream's words on every call -- those keep the host poll)
+                on_device = (DEVICE_SELECT and N >= DEVICE_SELECT_MIN_ATOMS and Cn == 1 and fused is not None
+                             and fused["force"] is not None
+                             and not (topo is not None and topo.fmt_flags)
+                             and ctx.slab_axis is None and not (need_q or need_cell or need_dist or need_src_cell)
+                             and (geom is None or ctx.field is not None) and (need_pos or need_src_pos))
+                if on_device:
+                    # only position gradients are wanted: run the GENERAL adjoint below with every kernel told to return at
+                    # once when the verdict is a match, then let one kernel replace its outputs by the energy-mode expressions
+                    # in that case -- no host read, the host keeps running ahead of the GPU
+                    select = dict(res=res, flag=torch.empty((1,), dtype=torch.int32, device=device))
+                    _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
+                          select["flag"].data_ptr())
+                    lib.mipme_set_skip_flag(select["flag"].data_ptr())
+                    guard.armed = True
+                else:
+                    flag, flag_np = _match_flag(device)
+                    flag_np[0] = -1
+                    _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
+                          flag.data_ptr())
+                    # the kernel also writes its verdict to pinned host memory: poll that word instead of a device-to-host copy
+                    # (hipMemcpy of 4 bytes costs 20-30 us on this stack; the poll ends a few us after the kernel does)
+                    spins = 0
+                    while flag_np[0] == -1:
+                        spins += 1
+                        if spins > 2_000_000:  # never seen; a stream synchronisation is the fallback
+                            torch.cuda.current_stream(device).synchronize()
+                            break
+                    if flag_np[0] == 1:
+                        sr_scale = res[:1]
             if sr_scale is not None and ctx.slab_axis is None:
                 gscale = sr_scale
             # the mesh force field of the forward gather serves the forces AND (through cellgrad_finalize) the cell gradient
@@ -964,6 +1005,13 @@ class _PMEFunction(torch.autograd.Function):
                 )
                 if not need_src_pos:
                     grad_src_pos = None
+
+            if select is not None:
+                lib.mipme_set_skip_flag(None)
+                guard.armed = False
+                _call("energy_select", lib.mipme_energy_select, st, dt, N, select["res"].data_ptr(), q.data_ptr(),
+                      _lib.ptr(fused["force"]), _lib.ptr(ctx.field), full, _lib.ptr(grad_pos) if geom is not None else None,
+                      _lib.ptr(grad_src_pos))
 
             # ---- charge gradient of the pair part ----
             if energy_q:
