@@ -60,16 +60,18 @@ __device__ __forceinline__ float erfc_from_exp(float y, float e) {
   p = p * t + 2.254580744e-01f;
   return e * t * p;
 }
-// double: erfc(y) = e * t * C20(t) with the same substitution, C20 a degree-20 Chebyshev series of erfcx(y)/t on
-// t in [1/(1+0.4*27), 1] (interpolation at Chebyshev nodes; max relative error 4e-15 for 0 <= y <= 27, beyond which
-// e = exp(-y^2) underflows anyway), evaluated with Clenshaw's recurrence: ~45 flops instead of libm erfc's ~150.
-#define MIPME_ERFC_CHEB                                                                                            \
-  {0.5360362114901628,      0.36394201332405524,     0.08650903632395776,     0.013008876153714528,                   \
-   0.0006814592277430882,   -0.00015462371847884464, -2.5921853049941386e-05, 2.306253180458029e-06,                  \
-   7.220220663501949e-07,   -6.169012444769808e-08,  -2.0618514118898877e-08, 2.6589056503780845e-09,                 \
-   5.618178359727535e-10,   -1.305151311061305e-10,  -1.0535414781885487e-11, 5.9990625120232684e-12,                 \
-   -2.000942951395261e-13,  -2.2583487398503573e-13, 3.6983871068685136e-14,  5.0608677594587146e-15,                 \
-   -2.7192201719058864e-15}
+// double: erfc(y) = e * t * P20(x), x = (2 t - (1 + tlo)) / (1 - tlo) in [-1, 1] for t in [1/(1+0.4*27), 1]: a degree-20 fit of
+// erfcx(y)/t at Chebyshev nodes (max relative error 2e-15 for 0 <= y <= 27, beyond which e = exp(-y^2) underflows anyway), given
+// by its MONOMIAL coefficients in x and evaluated with Horner's rule: 20 FMAs (the Chebyshev form with Clenshaw's recurrence,
+// round 2, needed 40 operations for the same accuracy; the coefficients decay faster than the basis grows, so the monomial
+// form loses nothing: 3.8e-15 against 4.2e-15).
+#define MIPME_ERFC_CHEB                                                                                                   \
+  {4.50235299459692540e-01,  3.24125536248557999e-01,  1.67075628387939157e-01,  5.52651679935470402e-02,                \
+   6.82018143828926407e-03,  -2.76262477755241610e-03, -1.03953621374069873e-03, 1.92114029446880925e-04,                \
+   1.22950360871657786e-04,  -2.59317092799155009e-05, -1.43585248578882984e-05, 5.12388472713849280e-06,                \
+   1.35756476325816326e-06,  -1.02658932393014442e-06, -3.47187889529154472e-09, 1.73400820276635575e-07,                \
+   -4.17454076893041247e-08, -2.09125782862454419e-08, 1.11490864632721937e-08,  1.28815160249804723e-09,                \
+   -1.26127363551349624e-09}
 static constexpr int kErfcChebTerms = 21;
 // 1/x and 1/sqrt(x) in double from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) and two Newton steps each: within an
 // ulp or two of the IEEE sequences (v_div_scale / fmas / fixup, sqrt + division) at a third of their instruction count
@@ -93,15 +95,34 @@ __device__ __forceinline__ double erfc_from_exp(double y, double e, const double
   constexpr double xs = 2.0 / (1.0 - tlo), x0 = -(1.0 + tlo) / (1.0 - tlo);
   const double t = rcp_newton(1.0 + 0.4 * y);
   const double x = __builtin_fma(xs, t, x0);  // (2 t - (1 + tlo)) / (1 - tlo)
-  const double x2 = 2.0 * x;
-  double b1 = 0.0, b2 = 0.0;
+  double p = c[kErfcChebTerms - 1];
 #pragma unroll
-  for (int k = kErfcChebTerms - 1; k >= 1; --k) {
-    const double b0 = __builtin_fma(x2, b1, c[k]) - b2;
-    b2 = b1;
-    b1 = b0;
-  }
-  return e * t * (__builtin_fma(x, b1, c[0]) - b2);
+  for (int k = kErfcChebTerms - 2; k >= 0; --k) p = __builtin_fma(p, x, c[k]);
+  return e * t * p;
+}
+// exp(-x), x >= 0, in double: n = round(-x log2 e), r = -x - n ln 2 (two-step reduction), e^r from its degree-13 Taylor
+// polynomial (|r| <= ln 2 / 2: 2e-16), scaled by 2^n -- 18 instructions where libm's exp takes about twice as many (its range
+// checks and table look-ups are for arguments this one never sees)
+__device__ __forceinline__ double exp_neg_fast(double x) {
+  x = x < 700.0 ? x : 700.0;
+  const double n = __builtin_rint(-x * 1.4426950408889634);
+  double r = __builtin_fma(n, -0.693147180369123816490, -x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;  // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);
+  p = __builtin_fma(p, r, 2.505210838544172e-08);
+  p = __builtin_fma(p, r, 2.755731922398589e-07);
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);
+  p = __builtin_fma(p, r, 2.48015873015873e-05);
+  p = __builtin_fma(p, r, 0.0001984126984126984);
+  p = __builtin_fma(p, r, 0.001388888888888889);
+  p = __builtin_fma(p, r, 0.008333333333333333);
+  p = __builtin_fma(p, r, 0.041666666666666664);
+  p = __builtin_fma(p, r, 0.16666666666666666);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, int(n));
 }
 __device__ __forceinline__ double erfc_from_exp(double y, double e) {
   constexpr double c[kErfcChebTerms] = MIPME_ERFC_CHEB;
@@ -250,7 +271,7 @@ __device__ __forceinline__ double rs_rsqrt(double x) { return rsqrt_newton(x); }
 __device__ __forceinline__ float rs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double rs_rcp(double x) { return rcp_newton(x); }
 __device__ __forceinline__ float rs_exp_neg(float x) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * x); }
-__device__ __forceinline__ double rs_exp_neg(double x) { return exp(-x); }
+__device__ __forceinline__ double rs_exp_neg(double x) { return exp_neg_fast(x); }
 __device__ __forceinline__ float rs_erfc(float y, float e, const double*) { return erfc_from_exp_fast(y, e); }
 __device__ __forceinline__ double rs_erfc(double y, double e, const double* c) { return erfc_from_exp(y, e, c); }
 
