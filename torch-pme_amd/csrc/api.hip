@@ -555,7 +555,7 @@ namespace mipme {
 bool live_supported(const mipme_mesh_t*, int64_t, int);
 int64_t live_lists_ints(const mipme_mesh_t*, int64_t);
 template <typename T> int live_rebin(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
-template <typename T> int live_spread(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
+template <typename T> int live_spread(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*, void*);
 template <typename T> int live_gather(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
                                       double, double, void*, void*, const GatherTailHost*, void*);
 }  // namespace mipme
@@ -606,13 +606,13 @@ static int md_step_t(const mipme_md_args_t& a) {
   tail.sr_reduced = 1;
   MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream capture: run "
                               "one evaluation before capturing)");
-  STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job));
+  STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job, a.host_flags));
   int64_t n_sr_part = 0;
   const void* sr_part = bins_epart(m, a.n_atoms, a.dtype, a.atom_bins, &n_sr_part);
   STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot, nullptr,
                                                const_cast<void*>(tail.epart_k), sr_part, n_sr_part, nullptr, a.nan_flag));
   STAGE(st, "gather+energy+forces",
-        live_gather<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.host_flags, a.phi_mesh, a.dc, self_c, bg_c, a.potentials, nullptr,
+        live_gather<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.phi_mesh, a.dc, self_c, bg_c, a.potentials, nullptr,
                        &tail, a.nan_flag));
   return MIPME_OK;
 }

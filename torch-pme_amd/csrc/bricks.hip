@@ -107,6 +107,46 @@ static inline int bin_capacity(int nb, int64_t N) {
   return int(cap < 8 ? 8 : cap);
 }
 
+// A slot's weights: wx, wy, wz, dwx, dwy, dwz (N each), padded to whole 16-byte chunks so that the atom's own lane writes them
+// with 16-byte stores (8 instructions at N = 5 instead of 30).  Measured at 32 000 atoms this is neutral (+-0.1 us, A/B on one
+// box, profiles/r03_experiments.txt); what these stores cost a kernel -- ~3 us whether four-byte or sixteen-byte, scattered by slot
+// or dense by atom, cached, non-temporal or system-scope -- comes with their 4 MB however they are issued.
+template <int N, typename T>
+constexpr int wts_stride() {
+  constexpr int V = 16 / int(sizeof(T));
+  return (6 * N + V - 1) / V * V;
+}
+static inline size_t wts_stride_rt(int order, size_t elem) { return (6 * size_t(order) * elem + 15) / 16 * 16 / elem; }
+
+template <int N, typename T>
+__device__ __forceinline__ void store_slot_weights(T* __restrict__ wr, const T (&wx)[N], const T (&wy)[N], const T (&wz)[N],
+                                                   const T (&dwx)[N], const T (&dwy)[N], const T (&dwz)[N]) {
+  constexpr int W = wts_stride<N, T>(), V = 16 / int(sizeof(T));
+  struct alignas(16) Chunk {
+    T e[V];
+  };
+  T v[W];
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    v[t] = wx[t];
+    v[N + t] = wy[t];
+    v[2 * N + t] = wz[t];
+    v[3 * N + t] = dwx[t];
+    v[4 * N + t] = dwy[t];
+    v[5 * N + t] = dwz[t];
+  }
+#pragma unroll
+  for (int t = 6 * N; t < W; ++t) v[t] = T(0);
+  Chunk* d = reinterpret_cast<Chunk*>(wr);
+#pragma unroll
+  for (int k = 0; k < W / V; ++k) {
+    Chunk c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) c.e[e] = v[k * V + e];
+    d[k] = c;
+  }
+}
+
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
   const size_t s = dtype == MIPME_F32 ? 4 : 8;
@@ -118,7 +158,7 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.snap = off;       off += al(sizeof(int) * size_t(b.nb + 1));
   l.over_brick = off; off += al(sizeof(int) * size_t(N));
   l.rec = off;        off += al(sizeof(int4) * size_t(l.slots));
-  l.wts = off;        off += al(6 * size_t(m->order) * s * size_t(l.slots));  // per slot: wx, wy, wz, dwx, dwy, dwz (n each)
+  l.wts = off;        off += al(wts_stride_rt(m->order, s) * s * size_t(l.slots));  // per slot: see wts_stride
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.det = off;
@@ -249,7 +289,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
   // to 64 different cache lines per instruction.  Transposed through LDS instead: the wave stages its rows, then lane k of a
   // group of 6N lanes writes value k of one atom -- contiguous 24N-byte segments, two atoms per instruction at N = 5
   // (1 029 000 atoms: 95 -> ... us for this kernel).
-  constexpr int W = 6 * N;
+  constexpr int W = wts_stride<N, T>();
   // COALESCE is chosen by the launcher for large systems, where the kernel is bound by its store transactions (1 029 000 atoms:
   // 95 -> 45 us); at 32k atoms it is a chain of latencies and the extra LDS round trip costs 1.3 us.  fp64 rows of n >= 5 nodes
   // do not fit 48 KB of LDS and keep the direct stores.
@@ -277,21 +317,15 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     for (int a0 = 0; a0 < 64; a0 += PER) {
       const int j = a0 + (sub < PER ? sub : 0);
       const int64_t dj = __shfl(dst, j < 64 ? j : 0, 64);
-      if (sub < PER && j < 64 && ((vmask >> j) & 1ull)) wts[dj * W + k] = rows[j * W + k];
+      if (sub < PER && k < 6 * N && j < 64 && ((vmask >> j) & 1ull)) wts[dj * W + k] = rows[j * W + k];
     }
   } else {
     if (!valid) return;
-    T* wr = wts + dst * W;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      T w[N], dw[N];
-      weights_1d<SCHEME, N, true, T>(T(x[d]), w, dw);
-#pragma unroll
-      for (int t = 0; t < N; ++t) {
-        wr[d * N + t] = w[t];
-        wr[(3 + d) * N + t] = dw[t];
-      }
-    }
+    T wx[N], wy[N], wz[N], dwx[N], dwy[N], dwz[N];
+    weights_1d<SCHEME, N, true, T>(T(x[0]), wx, dwx);
+    weights_1d<SCHEME, N, true, T>(T(x[1]), wy, dwy);
+    weights_1d<SCHEME, N, true, T>(T(x[2]), wz, dwz);
+    store_slot_weights<N, T>(wts + dst * W, wx, wy, wz, dwx, dwy, dwz);
   }
 }
 
@@ -642,7 +676,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         if (tid < nst) {
           const int si = sidx[chunk + tid];
           const int orig = rec[si].w;
-          const T* wr = wts + int64_t(si) * (6 * N);
+          const T* wr = wts + int64_t(si) * wts_stride<N, T>();
           T* dst = stage + tid * SW;
           const int rel = int(srel[chunk + tid]);
           const int rx = (rel << 28) >> 28, ry = (rel << 24) >> 28, rz = (rel << 20) >> 28;
@@ -957,7 +991,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
       }
       int4 a = rec[id];
       if (!valid) a = make_int4(ox, oy, oz, 0);  // a slot that may never have been written: keep every index derived from it in range
-      const T* wr = wts + int64_t(id) * (6 * N);
+      const T* wr = wts + int64_t(id) * wts_stride<N, T>();
       T wx[N], wy[N], dwx[FIELD ? N : 1], dwy[FIELD ? N : 1];
 #pragma unroll
       for (int t = 0; t < N; ++t) {
@@ -1122,7 +1156,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_grad_brick_kernel(
     }
     int4 a = rec[id];
     if (!valid) a = make_int4(ox, oy, oz, 0);
-    const T* wr = wts + int64_t(id) * (6 * N);
+    const T* wr = wts + int64_t(id) * wts_stride<N, T>();
     T wx[N], wy[N], dwx[N], dwy[N];
 #pragma unroll
     for (int t = 0; t < N; ++t) {
@@ -1765,6 +1799,8 @@ struct LiveLists {
   int* count;     // [nb] atoms in the brick's list
   int* atoms;     // [nb][lcap]
   int lcap;
+  int4* rec_now;  // [slots] {current mesh coordinates, atom} of the atom in the slot, written by every step's spread
+  int4* home_rec;  // [N] {mesh coordinates at the rebin, bin slot} of every atom
   int* host_flags;  // pinned int32, nullable: LiveFlags
 };
 
@@ -1776,9 +1812,14 @@ static inline int live_list_capacity(const mipme_mesh_t* m, int64_t N) {
   const int64_t all = (N + 63) / 64 * 64;
   return int(std::min<int64_t>(want, std::max<int64_t>(all, 64)));
 }
+static inline int64_t live_slots(const mipme_mesh_t* m, int64_t N) {
+  const BrickGeom bg = make_brick_geom(m);
+  return int64_t(bg.nb) * bin_capacity(bg.nb, N) + N;
+}
 int64_t live_lists_ints(const mipme_mesh_t* m, int64_t N) {
   const BrickGeom bg = make_brick_geom(m);
-  return 8 + (bg.nb + 1) + bg.nb + int64_t(bg.nb) * live_list_capacity(m, N);
+  const int64_t head = ((8 + (bg.nb + 1) + bg.nb + int64_t(bg.nb) * live_list_capacity(m, N)) + 3) / 4 * 4;
+  return head + 4 * live_slots(m, N) + 4 * N;
 }
 static inline LiveLists live_view(const mipme_mesh_t* m, int64_t N, void* lists, void* host_flags) {
   const BrickGeom bg = make_brick_geom(m);
@@ -1788,6 +1829,9 @@ static inline LiveLists live_view(const mipme_mesh_t* m, int64_t N, void* lists,
   l.count = l.counters + (bg.nb + 1);
   l.atoms = l.count + bg.nb;
   l.lcap = live_list_capacity(m, N);
+  const int64_t head = ((8 + (bg.nb + 1) + bg.nb + int64_t(bg.nb) * l.lcap) + 3) / 4 * 4;  // 16-byte aligned
+  l.rec_now = (int4*)(b + head);
+  l.home_rec = l.rec_now + live_slots(m, N);
   l.host_flags = (int*)host_flags;
   return l;
 }
@@ -1831,7 +1875,8 @@ __device__ __forceinline__ void live_coords(const Geom& g, const AtomRecord<T>& 
 template <typename T>
 __global__ __launch_bounds__(256) void live_bin_kernel(Geom g, BrickGeom bg, bool even, BinIndex bi, int* __restrict__ counters,
                                                       int64_t Natoms, const AtomRecord<T>* __restrict__ rec4,
-                                                      int* __restrict__ over_brick, int4* __restrict__ rec) {
+                                                      int* __restrict__ over_brick, int4* __restrict__ rec,
+                                                      int4* __restrict__ home_rec) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= Natoms) return;  // (whole-wave exits aside, the ballots below see the exec mask of the remaining lanes)
   const AtomRecord<T> r = rec4[i];
@@ -1868,6 +1913,7 @@ __global__ __launch_bounds__(256) void live_bin_kernel(Geom g, BrickGeom bg, boo
     dst = bi.over_base + k;
   }
   rec[dst] = make_int4(m[0], m[1], m[2], int(i));
+  home_rec[i] = make_int4(m[0], m[1], m[2], int(dst));
 }
 
 __global__ void live_snapshot_kernel(BinIndex bi, int* __restrict__ counters) {
@@ -1954,7 +2000,44 @@ struct LiveSpreadArgs {
   const AtomRecord<T>* rec4;
   T* mesh;
   int stage_rows;
+  // home atoms of the brick: the spread also leaves their current mesh coordinates and 6 N weights / derivatives in the bins
+  // (what the binning pass of the ordinary step writes), for this step's gather
+  int64_t n_atoms;
+  const int4* home_rec;  // [N] {mesh coordinates at the rebin, bin slot} per atom
+  int4* rec_now;
+  T* wts;
+  int* host_flags;
 };
+
+// One thread per atom: current mesh coordinates and the 6 N weights / derivatives into the atom's bin slot -- what the binning pass
+// of the ordinary step leaves there for the gather -- and the check that it has not moved further than the margin the lists were
+// built with.  These workgroups sit at the FRONT of the spread's grid.  (Evaluating the weights in the gather instead, in each of
+// the 8 lanes of an atom, cost that kernel 4 us; here the 4 MB of stores cost the spread 2.7 us, wherever in the kernel they are
+// issued -- by the brick workgroups for their home atoms, on an otherwise idle wave of those, or here.)
+template <int N, typename T>
+__device__ __forceinline__ void live_home_body(const LiveSpreadArgs<T>& args, unsigned wg) {
+  const int64_t i = int64_t(wg) * SPREAD_THREADS + threadIdx.x;
+  if (i >= args.n_atoms) return;
+  const Geom& g = args.g;
+  const AtomRecord<T> r = args.rec4[i];
+  const int4 was = args.home_rec[i];  // {mesh coordinates at the rebin, slot}
+  int mx, my, mz;
+  T x0, x1, x2;
+  live_coords<N, T>(g, r, mx, my, mz, x0, x1, x2);
+  T wx[N], wy[N], wz[N], dwx[N], dwy[N], dwz[N];
+  live_axis<N, true, T>(args.scheme, x0, wx, dwx);
+  live_axis<N, true, T>(args.scheme, x1, wy, dwy);
+  live_axis<N, true, T>(args.scheme, x2, wz, dwz);
+  auto far = [](int now, int then, int n) {
+    int d = now - then;
+    d = d > n / 2 ? d - n : (d < -(n / 2) ? d + n : d);
+    return d > kLiveMargin || d < -kLiveMargin;
+  };
+  if ((far(mx, was.x, g.nx) || far(my, was.y, g.ny) || far(mz, was.z, g.nz)) && args.host_flags) atomicOr(args.host_flags, kLiveMoved);
+  const int64_t slot = was.w;
+  args.rec_now[slot] = make_int4(mx, my, mz, int(i));
+  store_slot_weights<N, T>(args.wts + slot * wts_stride<N, T>(), wx, wy, wz, dwx, dwy, dwz);
+}
 
 template <int N, typename T>
 __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, unsigned block) {
@@ -1981,14 +2064,15 @@ __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, 
   for (int chunk = 0; chunk < ns; chunk += stage_rows) {
     const int nst = min(stage_rows, ns - chunk);
     if (tid < nst) {
-      const AtomRecord<T> r = args.rec4[latoms[chunk + tid]];
+      const int atom = latoms[chunk + tid];
+      const AtomRecord<T> r = args.rec4[atom];
       int mx, my, mz;
       T x0, x1, x2;
       live_coords<N, T>(g, r, mx, my, mz, x0, x1, x2);
-      T wx[N], wy[N], wz[N], dum[N];
-      live_axis<N, false, T>(args.scheme, x0, wx, dum);
-      live_axis<N, false, T>(args.scheme, x1, wy, dum);
-      live_axis<N, false, T>(args.scheme, x2, wz, dum);
+      T wx[N], wy[N], wz[N], unused[N];
+      live_axis<N, false, T>(args.scheme, x0, wx, unused);
+      live_axis<N, false, T>(args.scheme, x1, wy, unused);
+      live_axis<N, false, T>(args.scheme, x2, wz, unused);
       // row = [wz | wx * q | wy], each placed on the brick's 8 points of its axis (zero where the stencil has no point)
       const int rz = rel_start(mz, s0, oz, g.nz, N), rx = rel_start(mx, s0, ox, g.nx, N), ry = rel_start(my, s0, oy, g.ny, N);
       T* dst = stage + tid * SW;
@@ -2043,17 +2127,23 @@ __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, 
   }
 }
 
-// bricks first, then the row workgroups of the pair sum (4-byte entries), as spread_rows_kernel
+// the home-atom workgroups, then the bricks, then the row workgroups of the pair sum (4-byte entries) as in spread_rows_kernel
+__host__ __device__ inline unsigned live_home_blocks(int64_t n_atoms, bool xcd) {
+  const unsigned n = unsigned((n_atoms + SPREAD_THREADS - 1) / SPREAD_THREADS);
+  return xcd ? (n + 7u) / 8u * 8u : n;  // a multiple of 8 keeps blockIdx % 8 (the XCD) of everything behind them
+}
 template <int N, typename T, int PFAST>
 __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                         unsigned n_spread) {
-  const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
-  if (blockIdx.x < n_pad) {
-    const unsigned b = brick_of(sa.bg, blockIdx.x);
+  const unsigned n_home = live_home_blocks(sa.n_atoms, sa.bg.xcd), n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
+  if (blockIdx.x < n_home) {
+    live_home_body<N, T>(sa, blockIdx.x);
+  } else if (blockIdx.x - n_home < n_pad) {
+    const unsigned b = brick_of(sa.bg, blockIdx.x - n_home);
     if (b < n_spread) live_spread_body<N, T>(sa, b);
   } else {
     const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_pad, n_row_blocks) : blockIdx.x - n_pad;
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_home - n_pad, n_row_blocks) : blockIdx.x - n_home - n_pad;
     if (r < n_row_blocks) {
       extern __shared__ __attribute__((aligned(16))) char smem_rows[];
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
@@ -2065,15 +2155,20 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_s
   }
 }
 
-// ---- step: gather + energy + forces with weights evaluated on the fly --------------------------------------------------------
+// ---- step: gather + energy + forces from the slots the spread of THIS step filled --------------------------------------------
+// As gather_brick_body<TAIL>, with two differences: the records are rec_now (current mesh coordinates), which may lie up to
+// kLiveMargin points outside the brick, so the halo tile is that much wider on every side; and the charge comes from the (x, y, z,
+// q) record.  (The first version evaluated the weights here, in each of the 8 lanes of an atom: 12.2 us against 7.4; now the spread,
+// which evaluates them anyway for its staging, leaves them in the bins for its home atoms.)
 template <int N, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g, BrickGeom bg, int scheme, BinIndex bins,
-                                                                         const int4* __restrict__ rec,
+__global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
+                                                                         const int4* __restrict__ rec_now,
+                                                                         const T* __restrict__ wts,
                                                                          const AtomRecord<T>* __restrict__ rec4,
                                                                          const T* __restrict__ mesh, const T* __restrict__ qsum,
                                                                          T inv_vol, T self_c, T bg_c, T* __restrict__ out,
                                                                          T* __restrict__ field, GatherTail<T> tail,
-                                                                         int* __restrict__ nan_flag, int* __restrict__ host_flags) {
+                                                                         int* __restrict__ nan_flag) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
   MIPME_WG_STAMP(0);
   constexpr int THREADS = GATHER_THREADS, LANES = kGatherLanes, GROUPS = THREADS / LANES, MG = kLiveMargin;
@@ -2096,7 +2191,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
   const int tz = lane_active ? l : 0;
   constexpr int s0 = stencil_start<N>();
   const int64_t plane = int64_t(g.ny) * g.nz;
-  bool staged = false, moved = false;
+  bool staged = false;
   for (int it = 0; it < main_iters + over_iters; ++it) {
     bool valid;
     int id;
@@ -2109,11 +2204,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
       valid = k < n_over && bins.over_brick[k < n_over ? k : 0] == int(block);
       id = int(bins.over_base) + (k < n_over ? k : 0);
     }
-    int4 a = rec[id];
-    if (!valid) a = make_int4(ox, oy, oz, 0);
-    const AtomRecord<T> r = rec4[a.w];
-    const T out_early = out[a.w];
-    const T f_early = tail.force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
+    int4 a = rec_now[id];
+    if (!valid) a = make_int4(ox, oy, oz, 0);  // a slot that may never have been written: keep every index derived from it in range
+    const T* wr = wts + int64_t(id) * wts_stride<N, T>();
+    T wx[N], wy[N], dwx[N], dwy[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      wx[t] = wr[t];
+      wy[t] = wr[N + t];
+      dwx[t] = wr[3 * N + t];
+      dwy[t] = wr[4 * N + t];
+    }
+    const T wzv = lane_active ? wr[2 * N + tz] : T(0);
+    const T dwzv = lane_active ? wr[5 * N + tz] : T(0);
     if (!staged) {  // halo tile, kLiveMargin points wider than the stencils of the brick's own mesh points need
       for (int k = threadIdx.x; k < TL * TL * TL; k += THREADS) {
         const int tx = k / (TL * TL), ty = (k / TL) % TL, tzz = k % TL;
@@ -2122,25 +2225,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
       }
       staged = true;
     }
-    int mx, my, mz;
-    T x0, x1, x2;
-    live_coords<N, T>(g, r, mx, my, mz, x0, x1, x2);
-    T wx[N], dwx[N], wy[N], dwy[N], wz[N], dwz[N];
-    live_axis<N, true, T>(scheme, x0, wx, dwx);
-    live_axis<N, true, T>(scheme, x1, wy, dwy);
-    live_axis<N, true, T>(scheme, x2, wz, dwz);
-    // where the atom is now, relative to where it was binned (a.x, a.y, a.z lie inside this brick)
-    auto tile_start = [&](int m_now, int m_bin, int n, int o) {
-      int dm = m_now - m_bin;
-      dm = dm > n / 2 ? dm - n : (dm < -(n / 2) ? dm + n : dm);
-      if (dm > MG || dm < -MG) {
-        moved = moved || valid;
-        dm = 0;  // keep the reads inside the tile; the step is flagged invalid
-      }
-      return m_bin - o + dm + MG;
-    };
-    const int rtx = tile_start(mx, a.x, g.nx, ox), rty = tile_start(my, a.y, g.ny, oy), rtz = tile_start(mz, a.z, g.nz, oz);
+    const T q_early = rec4[a.w].w;
+    const T out_early = out[a.w];
+    const T f_early = tail.force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
     if (it == 0) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
+    // the atom's mesh coordinates relative to the tile's origin (brick origin - margin), wrapped to the nearest image and
+    // clamped into the tile (beyond the margin the spread has flagged the step invalid)
+    auto tile_start = [&](int m_now, int n, int o) {
+      int d = m_now - o;
+      d = d > n / 2 ? d - n : (d < -(n / 2) ? d + n : d);
+      d += MG;
+      return d < 0 ? 0 : (d > BRICK - 1 + 2 * MG ? BRICK - 1 + 2 * MG : d);
+    };
+    const int rtx = tile_start(a.x, g.nx, ox), rty = tile_start(a.y, g.ny, oy), rtz = tile_start(a.z, g.nz, oz);
     const T* tp = tile + rty * TL + (rtz + tz);
     T sA = T(0), sB = T(0), sC = T(0);
 #pragma unroll
@@ -2156,39 +2253,27 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
       sB += sdx * wy[ty];
       sC += sx * dwy[ty];
     }
-    // this lane's z weight: a masked sum, NOT common.h's pick<>() -- LLVM turns that select chain back into an indexed load of a
-    // private array, promotes the array to LDS, and the per-thread slice index it then needs makes every wave read the
-    // workgroup size from the AQL dispatch packet in host memory: the first load of a workgroup returned after 3-16 us
-    T wzv = T(0), dwzv = T(0);
-#pragma unroll
-    for (int t = 0; t < N; ++t) {
-      const T on = (lane_active && tz == t) ? T(1) : T(0);
-      wzv += on * wz[t];
-      dwzv += on * dwz[t];
-    }
     const T fx = group_sum_b<LANES, T>(sB * wzv) * T(g.nx) * inv_vol;
     const T fy = group_sum_b<LANES, T>(sC * wzv) * T(g.ny) * inv_vol;
     const T fz = group_sum_b<LANES, T>(sA * dwzv) * T(g.nz) * inv_vol;
     // row l of the inverse cell by selects: indexing the by-value kernel argument with a lane-dependent index makes the compiler
     // fetch it with VECTOR loads from the kernarg segment -- 8 192 waves queueing on the same few bytes of host-visible memory
-    // cost this kernel 20 us (tools/wg_timeline: the first load of half the workgroups returned after 27 us)
     const T i0 = T(l == 1 ? g.inv[3] : (l == 2 ? g.inv[6] : g.inv[0])), i1 = T(l == 1 ? g.inv[4] : (l == 2 ? g.inv[7] : g.inv[1])),
             i2 = T(l == 1 ? g.inv[5] : (l == 2 ? g.inv[8] : g.inv[2]));
     const T fc = i0 * fx + i1 * fy + i2 * fz;
     if (l < 3 && valid) {
       const int64_t o = int64_t(a.w);
       if (field) field[3 * o + l] = fc;
-      tail.grad_pos[3 * o + l] = seed * r.w * (tail.force_scale * f_early + fc);
+      tail.grad_pos[3 * o + l] = seed * q_early * (tail.force_scale * f_early + fc);
     }
     const T acc = group_sum_b<LANES, T>(sA * wzv);
     if (l == 0 && valid) {
       const T phi = acc * inv_vol;
-      const T lr = T(0.5) * (phi - self_c * r.w - T(2) * bg_c * inv_vol * qsum[0]);
+      const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[0]);
       out[a.w] = out_early + lr;
       if (nan_flag && lr != lr) *nan_flag = 1;
     }
   }
-  if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0 && host_flags) atomicOr(host_flags, kLiveMoved);
 #ifdef MIPME_WG_TIMELINE
   __syncthreads();
 #endif
@@ -2229,7 +2314,7 @@ int live_rebin(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec
   const LiveLists ll = live_view(m, N, lists, host_flags);
   // (the counters are zero here: the lists buffer starts zeroed and live_snapshot_kernel leaves them so)
   live_bin_kernel<T><<<unsigned((N + 255) / 256), 256, 0, st>>>(g, bg, (m->order % 2) == 0, v.idx, ll.counters, N,
-                                                              (const AtomRecord<T>*)rec4, v.over_brick, v.rec);
+                                                              (const AtomRecord<T>*)rec4, v.over_brick, v.rec, ll.home_rec);
   MIPME_LAUNCH_CHECK();
   live_snapshot_kernel<<<unsigned((bg.nb + 1 + 255) / 256), 256, 0, st>>>(v.idx, ll.counters);
   MIPME_LAUNCH_CHECK();
@@ -2240,7 +2325,7 @@ int live_rebin(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec
 
 template <typename T>
 int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* lists, void* mesh,
-                const mipme_sr_job_t* job) {
+                const mipme_sr_job_t* job, void* host_flags) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
@@ -2257,6 +2342,11 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   sa.rec4 = (const AtomRecord<T>*)rec4;
   sa.mesh = (T*)mesh;
   sa.stage_rows = stage_rows;
+  sa.n_atoms = N;
+  sa.home_rec = ll.home_rec;
+  sa.rec_now = ll.rec_now;
+  sa.wts = (T*)v.wts;
+  sa.host_flags = (int*)host_flags;
   MIPME_REQUIRE(job && sr_job_fusable(job) && (job->shift_format & kShiftFormatMask) == kShiftTable32 && !job->dist_out,
                 "the live step needs a co-schedulable pair job with 4-byte entries");
   SRPot s;
@@ -2271,7 +2361,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   ra.epart = v.epart;
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
-  const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks;
+  const unsigned grid = live_home_blocks(N, bg.xcd) + (bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks);
   if (pfast == 1)
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   else
@@ -2281,12 +2371,13 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
 }
 
 template <typename T>
-int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* host_flags, const void* mesh,
+int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* lists, const void* mesh,
                 const void* qsum, double self_c, double bg_c, void* out, void* field, const GatherTailHost* th, void* nan_flag) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
+  const LiveLists ll = live_view(m, N, lists, nullptr);
   MIPME_REQUIRE(th && th->force && th->grad_pos && th->energy && th->epart_k && out && qsum, "NULL buffer passed to the live gather");
   GatherTail<T> tail;
   tail.force = (const T*)th->force;
@@ -2299,17 +2390,19 @@ int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   tail.epart_sr = tail.epart_k + tail.n_k;  // pre-reduced by the x stage of the convolution
   tail.n_sr = tail.n_k;
   MIPME_DISPATCH_ORDER(m->order, (live_gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
-                                     g, bg, m->scheme, v.idx, v.rec, (const AtomRecord<T>*)rec4, (const T*)mesh, (const T*)qsum,
-                                     T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail, (int*)nan_flag,
-                                     (int*)host_flags)));
+                                     g, bg, v.idx, ll.rec_now, (const T*)v.wts, (const AtomRecord<T>*)rec4, (const T*)mesh,
+                                     (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail,
+                                     (int*)nan_flag)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
 
 template int live_rebin<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
 template int live_rebin<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
-template int live_spread<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
-template int live_spread<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*);
+template int live_spread<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*,
+                                void*);
+template int live_spread<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*,
+                                 void*);
 template int live_gather<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
                                 double, double, void*, void*, const GatherTailHost*, void*);
 template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,

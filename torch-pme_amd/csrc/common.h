@@ -172,15 +172,16 @@ __device__ __forceinline__ void weights_1d(T x, T (&w)[N], T (&dw)[N]) {
   }
 }
 
-// Register-array select with a runtime index.  CAUTION: LLVM may turn the select chain back into an indexed load of a private
-// array and promote that array to LDS; the per-thread slice index then needs the workgroup size, which every wave reads from the
-// AQL dispatch packet in HOST memory (3-16 us for the first load of a workgroup: profiles/r03_experiments.txt item 4).  Check
-// "LDS Size" in -Rpass-analysis=kernel-resource-usage when using it in a latency-bound kernel; a masked sum is immune.
+// Register-array select with a runtime index, as a SUM of masked elements.  The obvious select chain
+// (r = idx == t ? a[t] : r) is turned back by LLVM into an indexed load of a private array, which it then promotes to LDS; the
+// per-thread slice index of that needs the workgroup size, and every wave reads it from the AQL dispatch packet in HOST memory
+// (3-16 us for the first load of a workgroup: profiles/r03_experiments.txt item 4; tell-tale: "LDS Size" above the kernel's
+// __shared__ declarations in -Rpass-analysis=kernel-resource-usage).  A sum of selects has no such lowering.
 template <int N, typename T>
 __device__ __forceinline__ T pick(const T (&a)[N], int idx) {
-  T r = a[0];
+  T r = T(0);
 #pragma unroll
-  for (int t = 1; t < N; ++t) r = (idx == t) ? a[t] : r;
+  for (int t = 0; t < N; ++t) r += (idx == t) ? a[t] : T(0);
   return r;
 }
 
