@@ -21,6 +21,7 @@ region); ``ms_per_step_median`` is the median over the blocks.
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
+  roofline_valu -- the same launch against the VALU issue rate (pair-row instruction-lanes / peak); fp32 Coulomb rows only
   cpu_baseline -- the PyTorch-CPU oracle ("port" of the reference's ATen op sequence) timed on this host's cores
                   on a bounded sample, swept over thread counts (rank 0, N = 1 only)
   drop_in      -- the same frame through the reference's own call sequence, eager, no graph, no package-specific
@@ -256,6 +257,40 @@ class StubFrame:
 
     def step(self):
         return (self.x * self.x).sum(), None
+
+
+# VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes, one instruction-lane per clock at the 2.4 GHz peak engine clock (a v_pk_*
+# instruction counts once, as it issues once) -- /opt/skills/guides/MI355X_MICROARCH.md's CU model
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# hot-loop ISA counts of the pair-row bodies: (VALU instructions per entry, of which quarter-rate)
+PAIR_BODY_VALU = {("f32", 1): (37, 3)}
+
+
+def valu_roofline(w, kernel: str, kernel_ms: float):
+    """Second roofline of the dominant launch (the pair sum co-scheduled with the spread): instruction-lanes issued by the pair
+    rows (entries x VALU instructions per entry, ISA count of the packed body's hot loop) against the chip's VALU issue rate.
+    The spread bricks that share the launch are left out of the numerator, so `frac` understates the launch's VALU use by their
+    share (~15 % at cfg3).  `frac_issue` weights the quarter-rate transcendentals by the four issue slots they hold."""
+    body = PAIR_BODY_VALU.get((w.dtype, w.exponent))
+    if body is None or "rspace" not in kernel:
+        return None
+    ops, quarter = body
+    entries = 2 * w.n_pairs  # full rows: every pair once in each of its two rows
+    achieved = entries * ops / (kernel_ms * 1e-3) / 1e12
+    return {
+        "bound": "valu",
+        "kernel": kernel,
+        "achieved": achieved,
+        "peak": VALU_PEAK_TLANEOPS,
+        "unit": "Tlane-op/s",
+        "frac": achieved / VALU_PEAK_TLANEOPS,
+        "frac_issue": entries * (ops + 3 * quarter) / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
+        "entries_per_launch": entries,
+        "valu_per_entry": ops,
+        "quarter_rate_per_entry": quarter,
+        "kernel_ms": kernel_ms,
+        "floor_ms": entries * (ops + 3 * quarter) / (VALU_PEAK_TLANEOPS * 1e12) * 1e3,
+    }
 
 
 def algorithmic_bytes(w, s: int, fused: bool = True, store_distances: bool = False):
@@ -918,6 +953,7 @@ def main(argv=None):
                                                     + (0 if args.store_distances else w.n_pairs * s))
                                                    / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if "rspace" in dom else None,
             },
+            "roofline_valu": valu_roofline(w, dom, kernels[dom]),
             # whole step: bytes the kernels of this build move in their own formats (sum of the per-kernel figures below)
             # against the step time; SURVEY 8(d)'s figure for the reference's unfused formats is given for orientation only
             "step_bytes": {

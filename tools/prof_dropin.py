@@ -42,6 +42,8 @@ torch.cuda.synchronize()
 pr.disable()
 print("==== main thread")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
+print("==== main thread, by own time")
+pstats.Stats(pr).sort_stats("tottime").print_stats(35)
 
 # ---- profile: engine thread (enable a profiler from inside the backward)
 state = {}

@@ -473,6 +473,7 @@ __device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
   return i4v{int(unsigned(a)), int(unsigned(a >> 32) & 0xffffu), int(bytes), 0x00020000};
 }
 
+#if MIPME_ROW_LANES == 16
 template <int PFAST, int BS>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
                                                 AtomRecord<float>* __restrict__ shift_tab) {
@@ -578,5 +579,14 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     force[3 * a + 2] = fz;
   }
 }
+
+#else
+// experiment builds with another row width (tools/build_variant.sh ... -DMIPME_ROW_LANES=32): no packed body, the generic one
+template <int PFAST, int BS>
+__device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
+                                                AtomRecord<float>* __restrict__ shift_tab) {
+  sr_fused_rows_body<float, kPotForce, false, PFAST, false, true, BS, 0, true>(args, block, shift_tab);
+}
+#endif
 
 }  // namespace mipme
