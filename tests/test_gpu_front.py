@@ -1,0 +1,262 @@
+"""The compiled front end (csrc/front.cpp: C++ autograd nodes for the reference call sequence) against
+the oracle and against the Python path it stands in for (``-m gpu``): same potentials, same gradients for the positions, the
+reference's autograd contract for ``neighbor_distances`` (``tests/calculators/test_workflow.py:164-192``: gradient on request,
+hooks, a second consumer), the general upstream gradient, and every way out of its case falling back to the Python nodes."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import torchpme_amd as tpa  # noqa: E402
+from oracle import pme_numpy as O  # noqa: E402
+from torchpme_amd import _front, ops  # noqa: E402
+
+DEV = "cuda"
+CALC_NODE, DIST_NODE = "MipmeCalculatorBackward", "MipmePairDistancesBackward"
+
+
+def rell2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def _system(seed=5, N=200, triclinic=True):
+    rng = np.random.default_rng(seed)
+    cell = np.array([[9.0, 0, 0], [0.7, 8.0, 0], [0.2, -0.5, 10.0]]) if triclinic else np.diag([9.0, 8.0, 10.0])
+    pos = rng.uniform(-1, 10, (N, 3))  # some atoms outside the cell
+    q = rng.normal(size=(N, 1))
+    q -= q.mean()
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 4.0)
+    return rng, cell, pos, q, pairs, S, dist
+
+
+def _tensors(cell, pos, q, pairs, S, dtype):
+    t = lambda a, grad=False: torch.tensor(a, device=DEV, dtype=dtype, requires_grad=grad)  # noqa: E731
+    return t(q), t(cell), t(pos, True), torch.tensor(pairs, device=DEV), t(S)
+
+
+def _calc(scheme="P3M", exponent=1):
+    pot = tpa.CoulombPotential(smearing=1.1) if exponent == 1 else tpa.InversePowerLawPotential(exponent=exponent, smearing=1.1)
+    cls = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    return cls(pot, mesh_spacing=0.9, interpolation_nodes=4)
+
+
+def _reference_sequence(calc, tq, tc, tp, ti, tS, weights=None):
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    V = calc(tq, tc, tp, ti, d)
+    E = ((tq if weights is None else weights) * V).sum()
+    return d, V, E
+
+
+def test_extension_is_built_and_loaded():
+    assert _front.module() is not None, "torch-pme_amd/_mipme_front.so missing: make -C torch-pme_amd/csrc front"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("scheme,exponent", [("P3M", 1), ("Lagrange", 1), ("P3M", 6)])
+def test_reference_sequence_against_oracle(dtype, tol, scheme, exponent):
+    rng, cell, pos, q, pairs, S, dist = _system()
+    spec = O.PotentialSpec("coulomb" if exponent == 1 else "ipl", exponent, 1.1, 1.0)
+    Vo, cache = O.forward(spec, scheme, 4, 0.9, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, q)
+    gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, dtype)
+    calc = _calc(scheme, exponent)
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS)
+    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() == CALC_NODE  # the compiled nodes served the call
+    E.backward()
+    assert rell2(d.detach().cpu(), dist) < (1e-12 if dtype == torch.float64 else 1e-6)
+    if dtype == torch.float32 and exponent == 6:
+        tol = 1e-4  # 1/r^6 over a random gas: close pairs dominate the sums
+    assert rell2(V.detach().cpu(), Vo) < tol
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 10 * tol
+    calc.check()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("energy", [True, False])
+def test_same_results_as_the_python_nodes(dtype, energy, monkeypatch):
+    rng, cell, pos, q, pairs, S, dist = _system(seed=9, triclinic=False)
+    w = None if energy else torch.tensor(rng.normal(size=q.shape), device=DEV, dtype=dtype)
+    calc = _calc()
+    out = {}
+    for front in (True, False):
+        monkeypatch.setattr(ops, "FRONT", front)
+        tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, dtype)
+        d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, w)
+        assert (V.grad_fn.name() == CALC_NODE) == front
+        E.backward()
+        out[front] = (V.detach().cpu().numpy(), tp.grad.cpu().numpy(), float(E))
+    tol = 1e-12 if dtype == torch.float64 else 3e-6
+    assert rell2(out[True][0], out[False][0]) < tol
+    assert rell2(out[True][1], out[False][1]) < tol
+    assert abs(out[True][2] - out[False][2]) <= tol * abs(out[False][2])
+
+
+@pytest.mark.parametrize("energy", [True, False])
+def test_distance_gradient_on_request_hooks_and_second_consumer(energy):
+    rng, cell, pos, q, pairs, S, dist = _system(seed=11)
+    g = q.copy() if energy else rng.normal(size=q.shape)
+    spec = O.PotentialSpec("coulomb", 1, 1.1, 1.0)
+    Vo, cache = O.forward(spec, "P3M", 4, 0.9, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, g)
+    gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    tg = torch.tensor(g, device=DEV)
+    calc = _calc()
+    # (1) autograd.grad(E, d): d is among the inputs of the graph task
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, tg)
+    assert V.grad_fn.name() == CALC_NODE
+    gd, gp = torch.autograd.grad(E, [d, tp], retain_graph=True)
+    assert rell2(gd.cpu(), gr["dist"]) < 1e-11
+    assert rell2(gp.cpu(), gr["positions"] + gpos_d) < 1e-10
+    # (2) a hook registered AFTER the calculator call sees the true (P,) gradient; the positions still get everything
+    seen = []
+    d.register_hook(lambda x: seen.append(x.clone()))
+    E.backward()
+    assert len(seen) == 1 and rell2(seen[0].cpu(), gr["dist"]) < 1e-11
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    # (3) retain_grad() after the call
+    tp.grad = None
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, tg)
+    d.retain_grad()
+    E.backward()
+    assert rell2(d.grad.cpu(), gr["dist"]) < 1e-11 and rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    # (4) retain_grad() BEFORE the call: the calculator leaves the compiled path, same numbers
+    tp.grad = None
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    d.retain_grad()
+    V = calc(tq, tc, tp, ti, d)
+    assert V.grad_fn.name() != CALC_NODE
+    (tg * V).sum().backward()
+    assert rell2(d.grad.cpu(), gr["dist"]) < 1e-11 and rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    # (5) a second consumer of d: its gradient and the calculator's both reach the positions
+    tp.grad = None
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, tg)
+    extra = 1e-2 * (d * d).sum()
+    (E + extra).backward()
+    gd_extra = 2e-2 * dist
+    gpos_extra, _ = O.pair_distances_backward(pos, cell, pairs, S, gd_extra)
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d + gpos_extra) < 1e-10
+
+
+def test_calls_outside_the_case_use_the_python_nodes():
+    rng, cell, pos, q, pairs, S, dist = _system(seed=13)
+    spec = O.PotentialSpec("coulomb", 1, 1.1, 1.0)
+    Vo, cache = O.forward(spec, "P3M", 4, 0.9, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, q)
+    gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    calc = _calc()
+    # charges with a gradient: compiled distances node + Python calculator node (its LazyPairGradient reaches the C++ node)
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    tq.requires_grad_(True)
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, tq.detach())
+    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() != CALC_NODE
+    E.backward()
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    assert rell2(tq.grad.cpu(), gr["charges"]) < 1e-10
+    # cell with a gradient: both nodes are the Python ones
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    tc.requires_grad_(True)
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS)
+    assert d.grad_fn.name() != DIST_NODE and V.grad_fn.name() != CALC_NODE
+    E.backward()
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    assert rell2(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+    # a `periodic` argument, a pair mask, no gradient at all, distances from elsewhere
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    V = calc(tq, tc, tp, ti, d, periodic=torch.tensor([True, True, True], device=DEV))
+    assert V.grad_fn.name() != CALC_NODE and rell2(V.detach().cpu(), Vo) < 1e-10
+    V = calc(tq, tc, tp, ti, d, pair_mask=torch.ones(len(pairs), dtype=torch.bool, device=DEV))
+    assert V.grad_fn.name() != CALC_NODE and rell2(V.detach().cpu(), Vo) < 1e-10
+    with torch.no_grad():
+        V = calc(tq, tc, tp, ti, tpa.pair_distances(tp, ti, tc, tS))
+    assert V.grad_fn is None and rell2(V.cpu(), Vo) < 1e-10
+    V = calc(tq, tc, tp, ti, torch.tensor(dist, device=DEV))
+    assert V.grad_fn.name() != CALC_NODE and rell2(V.detach().cpu(), Vo) < 1e-10
+    # other positions than the distances were made from
+    tp2 = tp.detach().clone().requires_grad_(True)
+    V = calc(tq, tc, tp2, ti, d)
+    assert V.grad_fn.name() != CALC_NODE and rell2(V.detach().cpu(), Vo) < 1e-10
+
+
+def test_errors_stay_the_reference_ones():
+    rng, cell, pos, q, pairs, S, dist = _system(seed=17)
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    calc = _calc()
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    with pytest.raises(ValueError, match="charges"):
+        calc(tq[:-1], tc, tp, ti, d)
+    with pytest.raises(TypeError):
+        calc(tq.float(), tc, tp, ti, d)
+    # positions modified in place between the forward and the backward pass
+    V = calc(tq, tc, tp, ti, d)
+    assert V.grad_fn.name() == CALC_NODE
+    with torch.no_grad():
+        tp.add_(0.01)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        (tq * V).sum().backward()
+
+
+def test_nan_guard_through_the_compiled_path():
+    rng, cell, pos, q, pairs, S, dist = _system(seed=19)
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    calc = _calc()
+    bad = tq.clone()
+    bad[3, 0] = float("nan")
+    V = calc(bad, tc, tp, ti, tpa.pair_distances(tp, ti, tc, tS))
+    assert V.grad_fn.name() == CALC_NODE
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="NaNs detected in the k-space filter result"):
+        calc(tq, tc, tp, ti, tpa.pair_distances(tp, ti, tc, tS))  # "deferred": surfaces at the next call
+
+
+def test_repeated_steps_and_moving_atoms():
+    """An MD-like loop through the reference call sequence: new positions tensor every step, same list; every step equals the
+    Python path."""
+    rng, cell, pos, q, pairs, S, dist = _system(seed=23, triclinic=False)
+    calc = _calc()
+    tq, tc, _, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float32)
+    x = torch.tensor(pos, device=DEV, dtype=torch.float32)
+    for step in range(4):
+        res = {}
+        for front in (True, False):
+            ops.FRONT = front
+            try:
+                p = x.clone().requires_grad_(True)
+                d, V, E = _reference_sequence(calc, tq, tc, p, ti, tS)
+                E.backward()
+                res[front] = (float(E), p.grad.clone())
+            finally:
+                ops.FRONT = True
+        assert abs(res[True][0] - res[False][0]) <= 3e-6 * abs(res[False][0])
+        assert rell2(res[True][1].cpu(), res[False][1].cpu()) < 3e-6
+        x = x - 0.01 * res[True][1]
+
+
+def test_recorded_backward_pass():
+    """create_graph=True: the distances node differentiates twice exactly; the calculator node raises the hint instead of
+    returning an incomplete Hessian."""
+    rng, cell, pos, q, pairs, S, dist = _system(seed=29, N=60)
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    # (1) distances alone: Hessian-vector product of sum(d^2) against plain tensor ops
+    w = torch.tensor(rng.normal(size=pos.shape), device=DEV)
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    assert d.grad_fn.name() == DIST_NODE
+    (g,) = torch.autograd.grad((d * d).sum(), tp, create_graph=True)
+    (hv,) = torch.autograd.grad((g * w).sum(), tp)
+    p2 = tp.detach().clone().requires_grad_(True)
+    vec = p2[ti[:, 1]] - p2[ti[:, 0]] + tS @ tc
+    (g2,) = torch.autograd.grad((vec * vec).sum(), p2, create_graph=True)
+    (hv2,) = torch.autograd.grad((g2 * w).sum(), p2)
+    assert rell2(g.detach().cpu(), g2.detach().cpu()) < 1e-12 and rell2(hv.cpu(), hv2.cpu()) < 1e-12
+    # (2) the calculator node
+    calc = _calc()
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS)
+    assert V.grad_fn.name() == CALC_NODE
+    (g,) = torch.autograd.grad(E, tp, create_graph=True)
+    with pytest.raises(RuntimeError, match="double_backward"):
+        torch.autograd.grad((g * w).sum(), tp)

@@ -27,6 +27,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.mipme_version() == 300
 
 
+def test_compiled_front_end_loads_and_declines_cpu_tensors():
+    """csrc/front.cpp (C++ autograd nodes of the reference call sequence): the extension is built in-tree, binds libmipme at
+    the path the ctypes layer uses, and -- host logic only, no kernel runs here -- declines anything that is not its case."""
+    from torchpme_amd import _front
+
+    mod = _front.module()
+    assert mod is not None, "torch-pme_amd/_mipme_front.so is not built (make -C torch-pme_amd/csrc front)"
+    for name in ("pair_distances", "calc_forward", "is_front_distances", "Topology", "Calculator", "load_library"):
+        assert hasattr(mod, name)
+    x = torch.zeros(5, requires_grad=True)
+    assert not mod.is_front_distances(x) and not mod.is_front_distances(x * 2)
+    # descriptor sizes of the ctypes mirror and of include/mipme.h as front.cpp was compiled against it
+    pot = tpa.CoulombPotential(smearing=1.0)._descriptor()
+    with pytest.raises(RuntimeError, match="descriptor size mismatch"):
+        mod.Calculator(b"x", bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None)
+    md = _lib.MeshDesc()
+    fc = mod.Calculator(bytes(md), bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None)
+    # CPU tensors: not this file's case -> None, the Python path (which raises the reference's errors) takes over
+    pos = torch.zeros((4, 3), requires_grad=True)
+    assert mod.calc_forward(fc, torch.zeros((4, 1)), torch.eye(3), pos, torch.zeros((2, 2), dtype=torch.int64), torch.zeros(2)) is None
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0)
+    assert calc._front_forward(torch.zeros((4, 1)), torch.eye(3), pos, torch.zeros((2, 2), dtype=torch.int64), torch.zeros(2)) is None
+
+
 def test_abi_struct_layout_matches_header():
     import ctypes as C
 

@@ -1,0 +1,50 @@
+"""Loader of the compiled front end (``csrc/front.cpp`` -> ``_mipme_front.so``): C++ autograd nodes for the reference call
+sequence ``pair_distances -> calculator -> (q * V).sum().backward()`` in its common case.  ``module()`` returns the extension
+or ``None`` (``MIPME_FRONT=0``, or the file was not built: the Python path of ``ops.py`` then serves every call, as it does for
+everything outside the common case anyway)."""
+from __future__ import annotations
+
+import importlib.util
+import os
+import warnings
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(_HERE, "_mipme_front.so")
+ENABLED = os.environ.get("MIPME_FRONT", "1") != "0"
+
+_mod = None
+_tried = False
+
+
+def module():
+    global _mod, _tried
+    if _tried:
+        return _mod
+    _tried = True
+    if not ENABLED:
+        return None
+    if not os.path.exists(PATH):
+        warnings.warn(f"{PATH} is not built (make -C torch-pme_amd/csrc front): eager calculator calls keep their Python host "
+                      "path", RuntimeWarning, stacklevel=2)
+        return None
+    _lib.load()
+    spec = importlib.util.spec_from_file_location("_mipme_front", PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.load_library(_lib.LIB_PATH)
+    from . import ops
+
+    def unwrap(g):
+        """What a distances node made by the extension does with a gradient that is a tensor subclass."""
+        if isinstance(g, ops.LazyPairGradient):
+            if not g.materialized and g._grad_pos is not None:
+                return g._grad_pos, None
+            return None, g.materialize()
+        return None, g
+
+    mod.set_unwrap(unwrap)
+    mod.set_second_order_hint(ops.SECOND_ORDER_HINT)
+    _mod = mod
+    return mod

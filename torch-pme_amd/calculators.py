@@ -15,7 +15,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _front, _lib, ops
 from ._utils import _validate_parameters
 from .potentials import Potential
 
@@ -177,7 +177,14 @@ class Calculator(torch.nn.Module):
                 return self._forward_impl(q, c, p, pairs, d, *others)
 
             return ops.second_order_by_finite_differences(first_order_eval, (charges, cell, positions, dist), tuple(rest))
+        if ops.FRONT and ops.PROFILE is None and len(args) >= 5 and all(a is None for a in args[5:]) and self.check_nan is not True:
+            out = self._front_forward(*args[:5])  # compiled host path of the common case (csrc/front.cpp); None: not that case
+            if out is not None:
+                return out
         return self._forward_impl(*args)
+
+    def _front_forward(self, charges, cell, positions, neighbor_indices, neighbor_distances):
+        return None
 
     def _forward_impl(self, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
                       pair_mask=None, kvectors=None):
@@ -279,6 +286,39 @@ class PMECalculator(Calculator):
         self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, (self.mesh_spacing, self.interpolation_nodes),
                        geom, G)
         return geom, G
+
+
+    def _front_forward(self, charges, cell, positions, neighbor_indices, neighbor_distances):
+        """The call through the C++ autograd nodes of ``csrc/front.cpp`` when ``neighbor_distances`` comes from this package's
+        ``pair_distances`` (its compiled node) and only ``positions`` wants a gradient; ``None`` sends the call down the Python
+        path, which also owns every error message: nothing is validated here beyond what decides the route."""
+        mod = _front.module()
+        if (mod is None or type(neighbor_distances) is not torch.Tensor or not mod.is_front_distances(neighbor_distances)
+                or type(cell) is not torch.Tensor or cell.shape != (3, 3) or type(positions) is not torch.Tensor
+                or cell.dtype != positions.dtype or cell.device != positions.device):
+            return None
+        geom, G = self._kspace_setup(cell, positions.dtype, positions.device)
+        key = (bool(self.full_neighbor_list), self.check_nan)
+        c = geom.__dict__.get("_front")
+        if c is None or c[0] != key:
+            fc = None
+            pot_desc = self.potential._descriptor()
+            p_eff = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+            plan = _lib.get_plan(positions.device, positions.dtype, geom.ns, 1, geom.plan_store)
+            if (p_eff in (1, 6) and pot_desc.smearing > 0 and pot_desc.exclusion_radius <= 0 and plan.xfused and ops.XFUSED
+                    and ops.MESH_MODE == "bricks" and ops.PAIR_MODE == "rows" and ops.COSCHEDULE and ops.ENERGY_FAST_PATH
+                    and ops.ENERGY_DETECT and ops.COMPACT_ENTRIES and ops.FUSE_DISTANCES and not ops.OVERLAP):
+                fc = mod.Calculator(bytes(geom.desc(1)), bytes(pot_desc), plan.handle.value, G, cell,
+                                    bool(self.full_neighbor_list), self._nan_flag_ptr() or 0, geom.n_half, plan)
+            c = geom._front = (key, fc)
+        if c[1] is None:
+            return None
+        if self.check_nan == "deferred":
+            self.check()  # a NaN seen by an earlier call surfaces here
+        out = mod.calc_forward(c[1], charges, cell, positions, neighbor_indices, neighbor_distances)
+        if out is not None and self._nan_flag is not None:
+            self._nan_shape = [1, *geom.ns]
+        return out
 
 
 class P3MCalculator(PMECalculator):

@@ -21,7 +21,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import _lib
+from . import _front, _lib
 
 
 SECOND_ORDER_HINT = (
@@ -63,7 +63,8 @@ def first_order(fn):
 
 # Optional per-call timing used by bench.py: when PROFILE is a dict, every C-ABI call below is bracketed by
 # HIP events recorded on the launch stream (torch.cuda.Event records on the current stream, which is the
-# stream handed to libmipme).  PROFILE[name] collects (start, end) event pairs.
+# stream handed to libmipme).  PROFILE[name] collects (start, end) event pairs.  (While it is set the compiled front end,
+# whose C-ABI calls do not pass through _call, stands aside.)
 PROFILE = None
 
 
@@ -192,6 +193,8 @@ class seed_promise:
         return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
+#: compiled host side of the reference call sequence for its common case (csrc/front.cpp, _front.py); "0": Python nodes only
+FRONT = os.environ.get("MIPME_FRONT", "1") != "0"
 #: ... and act on the verdict ON THE DEVICE (mipme_set_skip_flag / mipme_energy_select) where only position gradients are asked
 #: for, instead of polling it on the host: the poll makes the host wait for everything queued before it, i.e. the eager
 #: reference call sequence ran GPU and host one after the other
@@ -261,6 +264,26 @@ class PairTopology:
                     ws.data_ptr(), nbytes, self.row_ptr.data_ptr(), self.entries.data_ptr(),
                 )
             )
+
+    def front(self, pairs: torch.Tensor, shifts: torch.Tensor, key: torch.Tensor):
+        """Handle of this list (with the shift streams of ``key``) for the compiled front end (``_front.py``), or ``None``
+        when its kernels do not apply (shifts that are not small integers, more than 2^22 atoms, ...).  Cached per shifts
+        tensor; the first call packs every stream the fast path reads."""
+        c = self.__dict__.get("_front")
+        if c is not None and c[0]() is key and c[1] == key._version and c[2] == shifts.dtype:
+            return c[3]
+        handle = None
+        mod = _front.module()
+        if mod is not None and self.fmt_flags == 0 and self.n_pairs > 0:
+            pair_packed = self.pair_packed_shifts(shifts, key)
+            row_packed = self.packed_shifts(shifts, key)
+            ent_sh, fmt = self.entries_with_shifts(shifts, key, table=True)
+            ent32 = self.compact_entries(shifts, key)
+            if pair_packed is not None and row_packed is not None and ent_sh is not None and fmt == 1 and ent32 is not None:
+                handle = mod.Topology(pairs, shifts, self.pairs32, pair_packed, self.row_ptr, self.entries, row_packed, ent_sh, fmt,
+                                      ent32, self.n_atoms)
+        self._front = (weakref.ref(key), key._version, shifts.dtype, handle)
+        return handle
 
     @property
     def sorted_by_first(self) -> bool:
@@ -1234,11 +1257,24 @@ def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, de
     _lib.require_device(positions, "positions")
     if deferred not in (True, False, "virtual"):
         raise ValueError(f"`deferred` must be True, False or 'virtual', got {deferred!r}")
-    dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts, bool(deferred))
     if neighbor_shifts is None or neighbor_shifts.dtype == positions.dtype:
         shifts_c = neighbor_shifts
     else:
         shifts_c = neighbor_shifts.to(positions.dtype)
+    if (deferred is False and FRONT and PROFILE is None and cell is not None and PAIR_MODE == "rows" and FUSE_DISTANCES and positions.requires_grad
+            and not cell.requires_grad and torch.is_grad_enabled() and type(positions) is torch.Tensor
+            and type(neighbor_indices) is torch.Tensor and neighbor_indices.is_contiguous() and neighbor_indices.dim() == 2
+            and getattr(neighbor_indices, "_mipme_stream", None) is None and shifts_c.is_contiguous()):
+        # compiled front end (csrc/front.cpp): the same kernel, a C++ autograd node, ~8 us of host time instead of ~50
+        mod = _front.module()
+        if mod is not None:
+            ft = get_topology(neighbor_indices, positions.shape[0]).front(neighbor_indices, shifts_c, neighbor_shifts)
+            if ft is not None:
+                dist = mod.pair_distances(ft, positions, cell, neighbor_indices)
+                if dist is not None:
+                    dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, False)
+                    return dist
+    dist = _PairDistances.apply(positions, cell, neighbor_indices, neighbor_shifts, bool(deferred))
     dist._mipme_src = DistanceSource(positions, cell, neighbor_indices, shifts_c, neighbor_shifts, dist, bool(deferred),
                                      virtual=deferred == "virtual")
     return dist
