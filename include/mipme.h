@@ -380,6 +380,10 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 int mipme_set_skip_flag(const void* device_flag);
 int mipme_energy_select(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
                         const void* field, int full_list, void* grad_mesh, void* grad_pair);
+/* The same for a caller that wants one gradient: out[a] = match ? s q_a (f force_a + field_a) : grad_mesh[a] + grad_pair[a]
+ * (all (N,3); out may alias grad_mesh or grad_pair). */
+int mipme_energy_select_sum(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
+                            const void* field, int full_list, const void* grad_mesh, const void* grad_pair, void* out);
 
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 

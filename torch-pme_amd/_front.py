@@ -46,5 +46,6 @@ def module():
 
     mod.set_unwrap(unwrap)
     mod.set_second_order_hint(ops.SECOND_ORDER_HINT)
+    mod.set_device_select(os.environ.get("MIPME_FRONT_POLL", "0") == "0")
     _mod = mod
     return mod

@@ -481,6 +481,17 @@ __global__ __launch_bounds__(256) void energy_select_kernel(int64_t N, const T* 
   }
 }
 
+// ... and the variant for a caller that wants ONE gradient: out = match ? s q (f force + field) : grad_mesh + grad_pair
+template <typename T>
+__global__ __launch_bounds__(256) void energy_select_sum_kernel(int64_t N, const T* __restrict__ verdict, const T* __restrict__ q,
+                                                               const T* __restrict__ force, const T* __restrict__ field, T f,
+                                                               const T* grad_mesh, const T* grad_pair, T* out) {
+  const bool match = verdict[1] == T(1);
+  const T s = verdict[0];
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < 3 * N; t += int64_t(gridDim.x) * blockDim.x)
+    out[t] = match ? s * q[t / 3] * (f * force[t] + field[t]) : grad_mesh[t] + grad_pair[t];
+}
+
 static double axis_length(const mipme_mesh_t* m, int axis) {
   const double* a = m->cell + 3 * axis;
   return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -1015,6 +1026,29 @@ int mipme_energy_select(void* stream, int dtype, int64_t n_atoms, const void* ve
   else if (dtype == MIPME_F64)
     energy_select_kernel<double><<<blocks, 256, 0, st>>>(n_atoms, (const double*)verdict, (const double*)charges, (const double*)force,
                                                         (const double*)field, full_list ? 0.5 : 1.0, (double*)grad_mesh, (double*)grad_pair);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_energy_select_sum(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
+                            const void* field, int full_list, const void* grad_mesh, const void* grad_pair, void* out) {
+  MIPME_REQUIRE(n_atoms >= 0 && verdict && charges && force && field && grad_mesh && grad_pair && out,
+                "invalid arguments to mipme_energy_select_sum");
+  if (n_atoms == 0) return MIPME_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = unsigned(std::min<int64_t>((3 * n_atoms + 255) / 256, 4096));
+  if (dtype == MIPME_F32)
+    energy_select_sum_kernel<float><<<blocks, 256, 0, st>>>(n_atoms, (const float*)verdict, (const float*)charges, (const float*)force,
+                                                           (const float*)field, full_list ? 0.5f : 1.0f, (const float*)grad_mesh,
+                                                           (const float*)grad_pair, (float*)out);
+  else if (dtype == MIPME_F64)
+    energy_select_sum_kernel<double><<<blocks, 256, 0, st>>>(n_atoms, (const double*)verdict, (const double*)charges,
+                                                            (const double*)force, (const double*)field, full_list ? 0.5 : 1.0,
+                                                            (const double*)grad_mesh, (const double*)grad_pair, (double*)out);
   else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;

@@ -64,6 +64,8 @@ struct Api {
   decltype(&mipme_sr_rows_finalize) sr_rows_finalize = nullptr;
   decltype(&mipme_sr_rows_fused) sr_rows_fused = nullptr;
   decltype(&mipme_rspace_backward) rspace_backward = nullptr;
+  decltype(&mipme_set_skip_flag) set_skip_flag = nullptr;
+  decltype(&mipme_energy_select_sum) energy_select_sum = nullptr;
 };
 Api g_api;
 
@@ -88,6 +90,8 @@ void load_library(const std::string& path) {
   bind(g_api.sr_rows_finalize, "mipme_sr_rows_finalize");
   bind(g_api.sr_rows_fused, "mipme_sr_rows_fused");
   bind(g_api.rspace_backward, "mipme_rspace_backward");
+  bind(g_api.set_skip_flag, "mipme_set_skip_flag");
+  bind(g_api.energy_select_sum, "mipme_energy_select_sum");
   if (g_api.version() != MIPME_VERSION)
     throw std::runtime_error("libmipme version " + std::to_string(g_api.version()) + " != header " + std::to_string(MIPME_VERSION));
 }
@@ -257,6 +261,8 @@ std::optional<at::Tensor> pair_distances(const std::shared_ptr<FrontTopo>& topo,
 
 // ---- the calculator node -----------------------------------------------------------------------------------------------------
 thread_local at::Tensor t_match_flag;  // pinned int32[1] per thread: the verdict of mipme_scaled_match
+bool g_device_select = true;           // MIPME_FRONT_POLL=1: decide the energy mode by polling instead (A/B, debugging)
+void set_device_select(bool on) { g_device_select = on; }
 
 struct CalcNode : public Node {
   std::shared_ptr<FrontCalc> calc;
@@ -301,93 +307,120 @@ struct CalcNode : public Node {
     const auto opts = pos.options();
     const bool real_dd = need_dist && distances_observed();
 
-    // energy mode? (g == gE * charges, decided on the device; the verdict lands in pinned memory)
-    bool match = false;
-    at::Tensor res = at::empty({2}, opts);
-    if (!stream_is_capturing(stream)) {
-      if (!t_match_flag.defined()) t_match_flag = at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
-      volatile int* flag = static_cast<volatile int*>(t_match_flag.data_ptr());
-      *flag = -1;
-      check(g_api.scaled_match(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), const_cast<int*>(flag)), "scaled_match");
-      int64_t spins = 0;
-      while (*flag == -1) {
-        if (++spins > 200000000) {  // never seen; a synchronisation is the fallback
-          (void)hipStreamSynchronize(stream);
-          break;
-        }
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-      match = *flag == 1;
-    }
     at::Tensor grad_pos, grad_dist;
-    if (match) {
-      at::Tensor scale = res.narrow(0, 0, 1);
-      if (need_pos) {
-        grad_pos = at::empty_like(pos);
-        // both parts differentiate the same positions: one kernel, gE q_a (f force_a + field_a); with an observed dE/dd the
-        // pair part travels through the distances node instead
-        check(g_api.sr_rows_finalize(stream, dt, N, real_dd ? nullptr : force.data_ptr(), field.data_ptr(), q.data_ptr(),
-                                     scale.data_ptr(), calc->full_list, nullptr, grad_pos.data_ptr(), nullptr),
-              "forces_finalize");
-      }
-      if (real_dd) {
-        grad_dist = at::empty({P}, opts);
-        check(g_api.rspace_backward(stream, dt, MIPME_I32, P, N, 1, topo->pairs32.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                                    nullptr, calc->full_list, &calc->pot, g.data_ptr(), scale.data_ptr(), grad_dist.data_ptr(),
-                                    nullptr),
-              "rspace_backward");
-      }
-    } else {
-      // general upstream gradient: second spread, convolution and gradient gather for the mesh part ...
+    at::Tensor res = at::empty({2}, opts);  // verdict of mipme_scaled_match: {gE, 1 or 0}
+    at::Tensor work;
+    // general upstream gradient, mesh part: second spread, convolution and gradient gather
+    auto mesh_adjoint = [&](at::Tensor& out_pos) {
       const int64_t nx = calc->mesh.nx, ny = calc->mesh.ny, nz = calc->mesh.nz;
       const size_t s = dt == MIPME_F32 ? 4 : 8;
       const size_t mesh_bytes = align256(size_t(nx) * ny * nz * s), hat_bytes = align256(size_t(calc->n_half) * 2 * s);
-      at::Tensor work = at::empty({int64_t(2 * mesh_bytes + hat_bytes + 256)}, opts.dtype(at::kByte));
+      work = at::empty({int64_t(2 * mesh_bytes + hat_bytes + 256)}, opts.dtype(at::kByte));
       char* w = static_cast<char*>(work.data_ptr());
-      if (need_pos) {
-        grad_pos = at::empty_like(pos);
-        mipme_kspace_backward_args_t a;
-        std::memset(&a, 0, sizeof(a));
-        a.size = sizeof(a);
-        a.version = MIPME_ARGS_VERSION;
-        a.plan = calc->plan;
-        a.stream = stream;
-        a.dtype = dt;
-        a.mesh = &calc->mesh;
-        a.pot = &calc->pot;
-        a.n_atoms = N;
-        a.positions = pos.data_ptr();
-        a.charges = q.data_ptr();
-        a.grad_out = g.data_ptr();
-        a.G = calc->G.data_ptr();
-        a.phi_mesh = slab(off_phi);
-        a.rho_dc = slab(off_dc);
-        a.psi_mesh = w;
-        a.chi_mesh = w + mesh_bytes;
-        a.hat_work = w + 2 * mesh_bytes;
-        a.dc = w + 2 * mesh_bytes + hat_bytes;
-        a.grad_positions = grad_pos.data_ptr();
-        a.atom_bins = slab(off_bins);
-        check(g_api.kspace_backward(&a), "kspace_backward");
+      out_pos = at::empty_like(pos);
+      mipme_kspace_backward_args_t a;
+      std::memset(&a, 0, sizeof(a));
+      a.size = sizeof(a);
+      a.version = MIPME_ARGS_VERSION;
+      a.plan = calc->plan;
+      a.stream = stream;
+      a.dtype = dt;
+      a.mesh = &calc->mesh;
+      a.pot = &calc->pot;
+      a.n_atoms = N;
+      a.positions = pos.data_ptr();
+      a.charges = q.data_ptr();
+      a.grad_out = g.data_ptr();
+      a.G = calc->G.data_ptr();
+      a.phi_mesh = slab(off_phi);
+      a.rho_dc = slab(off_dc);
+      a.psi_mesh = w;
+      a.chi_mesh = w + mesh_bytes;
+      a.hat_work = w + 2 * mesh_bytes;
+      a.dc = w + 2 * mesh_bytes + hat_bytes;
+      a.grad_positions = out_pos.data_ptr();
+      a.atom_bins = slab(off_bins);
+      check(g_api.kspace_backward(&a), "kspace_backward");
+    };
+    // ... pair part, straight to the positions with the fused adjoint kernel
+    auto pair_adjoint = [&](at::Tensor& out_pos) {
+      out_pos = at::empty_like(pos);
+      check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh.data_ptr(), topo->entries.data_ptr(), nullptr,
+                                pos.data_ptr(), cell.data_ptr(), q.data_ptr(), nullptr, g.data_ptr(), 0, calc->full_list, &calc->pot,
+                                0, topo->ent_sh_format, slab(off_rec), 0, nullptr, out_pos.data_ptr(), nullptr, nullptr, nullptr),
+            "rspace_backward");
+    };
+    // ... or as a (P,) gradient through the distances node
+    auto pair_adjoint_dd = [&](const void* scale) {
+      grad_dist = at::empty({P}, opts);
+      check(g_api.rspace_backward(stream, dt, MIPME_I32, P, N, 1, topo->pairs32.data_ptr(), dist.data_ptr(), q.data_ptr(), nullptr,
+                                  calc->full_list, &calc->pot, g.data_ptr(), scale, grad_dist.data_ptr(), nullptr),
+            "rspace_backward");
+    };
+    const bool capturing = stream_is_capturing(stream);
+
+    if (need_pos && !real_dd && !capturing && g_device_select) {
+      // Energy mode (g == gE * charges: the gradient of (charges * V).sum()) decided ON THE DEVICE and acted on there: the general
+      // adjoint is launched with every kernel told to return at once on a match, then one kernel writes gE q_a (f force_a +
+      // field_a) from the per-atom sums of the forward in that case, or adds up the general adjoint's two parts otherwise.  The
+      // host never waits: polling the verdict instead (below) makes it wait for everything queued before, and the GPU then
+      // idles while the host prepares the next step.
+      at::Tensor flag = at::empty({1}, opts.dtype(at::kInt));
+      check(g_api.scaled_match(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag.data_ptr()), "scaled_match");
+      struct SkipGuard {
+        ~SkipGuard() { g_api.set_skip_flag(nullptr); }
+      };
+      at::Tensor pair_pos;
+      {
+        g_api.set_skip_flag(flag.data_ptr());
+        SkipGuard guard_skip;
+        mesh_adjoint(grad_pos);
+        pair_adjoint(pair_pos);
       }
-      // ... and the pair part: as a (P,) gradient through the distances node when somebody looks at it, else straight to the
-      // positions with the fused adjoint kernel
-      if (real_dd) {
-        grad_dist = at::empty({P}, opts);
-        check(g_api.rspace_backward(stream, dt, MIPME_I32, P, N, 1, topo->pairs32.data_ptr(), dist.data_ptr(), q.data_ptr(),
-                                    nullptr, calc->full_list, &calc->pot, g.data_ptr(), nullptr, grad_dist.data_ptr(), nullptr),
-              "rspace_backward");
-      } else if (need_pos || need_dist) {
-        at::Tensor pair_pos = at::empty_like(pos);
-        check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh.data_ptr(), topo->entries.data_ptr(),
-                                  nullptr, pos.data_ptr(), cell.data_ptr(), q.data_ptr(), nullptr, g.data_ptr(), 0,
-                                  calc->full_list, &calc->pot, 0, topo->ent_sh_format, slab(off_rec), 0, nullptr,
-                                  pair_pos.data_ptr(), nullptr, nullptr, nullptr),
-              "rspace_backward");
-        if (grad_pos.defined())
-          grad_pos.add_(pair_pos);
-        else
-          grad_pos = pair_pos;
+      check(g_api.energy_select_sum(stream, dt, N, res.data_ptr(), q.data_ptr(), force.data_ptr(), field.data_ptr(), calc->full_list,
+                                    grad_pos.data_ptr(), pair_pos.data_ptr(), grad_pos.data_ptr()),
+            "energy_select");
+    } else {
+      // the verdict polled in pinned memory (when dE/d(neighbor_distances) itself is wanted: rare)
+      bool match = false;
+      if (!capturing) {
+        if (!t_match_flag.defined()) t_match_flag = at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+        volatile int* flag = static_cast<volatile int*>(t_match_flag.data_ptr());
+        *flag = -1;
+        check(g_api.scaled_match(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), const_cast<int*>(flag)), "scaled_match");
+        int64_t spins = 0;
+        while (*flag == -1) {
+          if (++spins > 200000000) {  // never seen; a synchronisation is the fallback
+            (void)hipStreamSynchronize(stream);
+            break;
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        match = *flag == 1;
+      }
+      if (match) {
+        at::Tensor scale = res.narrow(0, 0, 1);
+        if (need_pos) {
+          grad_pos = at::empty_like(pos);
+          // both parts differentiate the same positions: one kernel, gE q_a (f force_a + field_a); with an observed dE/dd the
+          // pair part travels through the distances node instead
+          check(g_api.sr_rows_finalize(stream, dt, N, real_dd ? nullptr : force.data_ptr(), field.data_ptr(), q.data_ptr(),
+                                       scale.data_ptr(), calc->full_list, nullptr, grad_pos.data_ptr(), nullptr),
+                "forces_finalize");
+        }
+        if (real_dd) pair_adjoint_dd(scale.data_ptr());
+      } else {
+        if (need_pos) mesh_adjoint(grad_pos);
+        if (real_dd) {
+          pair_adjoint_dd(nullptr);
+        } else if (need_pos || need_dist) {
+          at::Tensor pair_pos;
+          pair_adjoint(pair_pos);
+          if (grad_pos.defined())
+            grad_pos.add_(pair_pos);
+          else
+            grad_pos = pair_pos;
+        }
       }
     }
     if (at::GradMode::is_enabled()) {
@@ -541,6 +574,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled host side of the reference call sequence (see front.cpp)";
   m.def("load_library", &load_library);
   m.def("set_unwrap", &set_unwrap);
+  m.def("set_device_select", &set_device_select);
   m.def("set_second_order_hint", &set_second_order_hint);
   py::class_<FrontTopo, std::shared_ptr<FrontTopo>>(m, "Topology")
       .def(py::init([](at::Tensor pairs, at::Tensor shifts, at::Tensor pairs32, at::Tensor pair_packed, at::Tensor row_ptr, at::Tensor entries,
