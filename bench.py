@@ -446,6 +446,24 @@ def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
         if mode == "helper":
             out["rel_energy_diff_vs_fast_path"] = abs(float(E) - float(E_fast)) / abs(float(E_fast))
             out["force_rel_l2_diff_vs_fast_path"] = float((F - F_fast).norm() / F_fast.norm())
+    # the same sequence through the Python autograd nodes only (MIPME_FRONT=0): what the compiled front end (csrc/front.cpp)
+    # takes off the host
+    from torchpme_amd import _front, ops
+
+    out["compiled_front_end"] = bool(ops.FRONT and _front.module() is not None)
+    if out["compiled_front_end"]:
+        ops.FRONT = False
+        try:
+            for _ in range(n_warm):
+                frame.step_reference_protocol("helper")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                frame.step_reference_protocol("helper")
+            torch.cuda.synchronize()
+            out["ms_per_step_python_nodes"] = 1e3 * (time.perf_counter() - t0) / n_steps
+        finally:
+            ops.FRONT = True
     # a NEW list every call, as the reference's users supply it
     for key, mode in (("cold_list_ms", "list"), ("cold_stream_ms", "stream")):
         n = max(5, n_steps // 4)

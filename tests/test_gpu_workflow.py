@@ -161,6 +161,40 @@ def test_library_backward_reuses_the_forward(monkeypatch):
     torch.testing.assert_close(grads[0], tp.grad, rtol=1e-12, atol=1e-12)
 
 
+def test_library_records_no_tape_when_no_backward_can_follow():
+    """ADVICE round 2 (library.py): under no_grad, or when nothing requires a gradient, the compiled / scripted path keeps no
+    tape (the callers pass what they know as the op's `needs` argument); with gradients only the leaves that need one record."""
+    from torchpme_amd import library
+
+    rng = np.random.default_rng(14)
+    cell = np.eye(3) * 7.0
+    pos = rng.uniform(0, 7, (40, 3))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 3.0)
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.5).to(torch.float64)
+    t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+    q, tc, tp, ti, td = t(rng.normal(size=(40, 1))), t(cell), t(pos), t(pairs), t(dist)
+    scripted = torch.jit.script(calc.scriptable())
+    compiled = torch.compile(calc, fullgraph=True)
+    library._TAPES.clear()
+    V_ref = calc(q, tc, tp, ti, td)
+    for fn in (scripted, compiled):
+        torch.testing.assert_close(fn(q, tc, tp, ti, td), V_ref, rtol=1e-12, atol=1e-12)  # nothing requires a gradient
+        assert not library._TAPES
+        p = tp.clone().requires_grad_(True)
+        with torch.no_grad():
+            fn(q, tc, p, ti, td)
+        assert not library._TAPES
+        V = fn(q, tc, p, ti, td)
+        assert len(library._TAPES) == 1
+        leaves = next(iter(library._TAPES.values()))[1]
+        assert [x.requires_grad for x in leaves] == [False, False, True, False]
+        (V * V).sum().backward()
+        assert not library._TAPES
+        p2 = tp.clone().requires_grad_(True)
+        (calc(q, tc, p2, ti, td) ** 2).sum().backward()
+        torch.testing.assert_close(p.grad, p2.grad, rtol=1e-12, atol=1e-12)
+
+
 def test_exclusion_radius():
     """Reference test_calculator.py:246-289: with an exclusion radius the direct potential is scaled by (1 - f_cut)."""
     rx, deg = 4.0, 8

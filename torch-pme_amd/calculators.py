@@ -151,8 +151,11 @@ class Calculator(torch.nn.Module):
         if torch.compiler.is_compiling() and self._spec_str is not None:
             # inside torch.compile: one dispatcher op (fake implementation + autograd formula in library.py) instead of
             # ctypes + HIP launches, which cannot be traced -- the model stays a single graph
+            from . import library
+
             return torch.ops.mipme.potentials(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask,
-                                              periodic, node_mask, kvectors, self._spec_str)
+                                              periodic, node_mask, kvectors, self._spec_str,
+                                              library.needs_mask(charges, cell, positions, neighbor_distances))
         return self._eager_forward(charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask,
                                    pair_mask, kvectors)
 

@@ -113,17 +113,22 @@ class _autograd_recording:
 @torch.library.custom_op("mipme::potentials", mutates_args=(), device_types="cuda")
 def potentials(charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indices: Tensor, neighbor_distances: Tensor,
                pair_mask: Optional[Tensor], periodic: Optional[Tensor], node_mask: Optional[Tensor],
-               kvectors: Optional[Tensor], spec: str) -> Tensor:
+               kvectors: Optional[Tensor], spec: str, needs: int = -1) -> Tensor:
     calc = calculator_from_spec(spec, positions.dtype, positions.device)
     # Below the autograd key the implementation cannot tell whether a backward op will follow (gradient mode reads "off" here
     # both under the user's no_grad and inside the dispatcher's own autograd node): the tape is kept unless the caller opted
     # out (KEEP_TAPE = False, or torch.inference_mode()).  Its cost when no backward comes: the speculative per-atom sums of
     # the forward kernels and at most _MAX_TAPES sets of saved buffers.
-    if not KEEP_TAPE or torch.is_inference_mode_enabled():
+    # `needs` is what the caller -- above the autograd key, where it can still be seen -- knows about the backward to come: bit k
+    # set = input k of (charges, cell, positions, neighbor_distances) requires a gradient and gradient mode is on; 0 = no backward
+    # can follow (no_grad, or nothing requires a gradient): no tape, no speculative sums; -1 = unknown (direct callers of the
+    # op): all four leaves record, as before.  (needs_mask() below computes it; Calculator.forward and ScriptableCalculator pass it.)
+    if needs == 0 or not KEEP_TAPE or torch.is_inference_mode_enabled():
         return calc._forward_impl(charges, cell, positions, neighbor_indices, neighbor_distances, periodic, node_mask,
                                   pair_mask, kvectors)
     with _autograd_recording():
-        leaves = [t.detach().requires_grad_(True) for t in (charges, cell, positions, neighbor_distances)]
+        leaves = [t.detach().requires_grad_(needs < 0 or bool(needs & (1 << k)))
+                  for k, t in enumerate((charges, cell, positions, neighbor_distances))]
         V = calc._forward_impl(leaves[0], leaves[1], leaves[2], neighbor_indices, leaves[3], periodic, node_mask, pair_mask,
                                kvectors)
     out = V.detach()
@@ -134,7 +139,7 @@ def potentials(charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indice
 
 
 @potentials.register_fake
-def _(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, periodic, node_mask, kvectors, spec):
+def _(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, periodic, node_mask, kvectors, spec, needs=-1):
     return torch.empty_like(charges)
 
 
@@ -148,6 +153,8 @@ def potentials_backward(grad: Tensor, out: Tensor, charges: Tensor, cell: Tensor
     tape = _TAPES.pop(out.data_ptr(), None)
     if tape is not None and (tape[0].shape != out.shape or tape[0].dtype != out.dtype):
         tape = None  # the address was reused by an unrelated tensor
+    if tape is not None and any(n and not t.requires_grad for t, n in zip(tape[1], needs)):
+        tape = None  # recorded for fewer leaves than this backward asks for (a caller that understated `needs`): start over
     with _autograd_recording():
         if tape is not None:  # the forward's own tape: only the backward kernels run
             V, leaves = tape
@@ -171,6 +178,21 @@ def _(grad, out, charges, cell, positions, neighbor_indices, neighbor_distances,
             torch.empty_like(neighbor_distances))
 
 
+def needs_mask(charges: Tensor, cell: Tensor, positions: Tensor, neighbor_distances: Tensor) -> int:
+    """The `needs` argument of ``mipme::potentials`` for these inputs (traceable by dynamo and TorchScript)."""
+    needs = 0
+    if torch.is_grad_enabled():
+        if charges.requires_grad:
+            needs += 1
+        if cell.requires_grad:
+            needs += 2
+        if positions.requires_grad:
+            needs += 4
+        if neighbor_distances.requires_grad:
+            needs += 8
+    return needs
+
+
 def _potentials_setup(ctx, inputs, output):
     ctx.save_for_backward(output, *[t for t in inputs[:9] if isinstance(t, Tensor)])
     ctx.present = [isinstance(t, Tensor) for t in inputs[:9]]
@@ -184,7 +206,7 @@ def _potentials_backward(ctx, grad):
     n = ctx.needs_input_grad
     gq, gc, gp, gd = torch.ops.mipme.potentials_backward(grad, out, *args, ctx.spec, n[0], n[1], n[2], n[4])
     return (gq if n[0] else None, gc if n[1] else None, gp if n[2] else None, None, gd if n[4] else None, None, None, None,
-            None, None)
+            None, None, None)
 
 
 potentials.register_autograd(_potentials_backward, setup_context=_potentials_setup)
@@ -259,5 +281,15 @@ class ScriptableCalculator(torch.nn.Module):
     def forward(self, charges: Tensor, cell: Tensor, positions: Tensor, neighbor_indices: Tensor,
                 neighbor_distances: Tensor, periodic: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
                 pair_mask: Optional[Tensor] = None, kvectors: Optional[Tensor] = None) -> Tensor:
+        needs = 0
+        if torch.is_grad_enabled():
+            if charges.requires_grad:
+                needs += 1
+            if cell.requires_grad:
+                needs += 2
+            if positions.requires_grad:
+                needs += 4
+            if neighbor_distances.requires_grad:
+                needs += 8
         return torch.ops.mipme.potentials(charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask,
-                                          periodic, node_mask, kvectors, self.spec)
+                                          periodic, node_mask, kvectors, self.spec, needs)
