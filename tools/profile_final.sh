@@ -33,3 +33,8 @@ python tools/time_refresh.py > $OUT/${TAG}_refresh.txt 2>&1
 python tools/rocpd_summary.py $(find $OUT/${TAG}_live -name '*.db') > $OUT/${TAG}_kernel_stats_live_step.txt
 rm -rf $OUT/${TAG}_live
 ls -la $OUT | grep ${TAG}
+# round 3: the reference call sequence through the compiled front end and through the Python nodes
+python tools/prof_dropin.py 300 > $OUT/${TAG}_prof_dropin_front.txt 2>&1
+MIPME_FRONT=0 python tools/prof_dropin.py 300 > $OUT/${TAG}_prof_dropin_python_nodes.txt 2>&1
+python tools/prof_size.py 56 256 > /dev/null 2>&1 || true
+ls -la $OUT | grep ${TAG}
