@@ -260,3 +260,20 @@ def test_recorded_backward_pass():
     (g,) = torch.autograd.grad(E, tp, create_graph=True)
     with pytest.raises(RuntimeError, match="double_backward"):
         torch.autograd.grad((g * w).sum(), tp)
+
+
+def test_pair_list_is_not_kept_alive():
+    """The front end's per-list handle identifies the caller's neighbor_indices without owning it."""
+    import gc
+    import weakref
+
+    rng, cell, pos, q, pairs, S, dist = _system(seed=31, N=80)
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    calc = _calc()
+    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS)
+    assert V.grad_fn.name() == CALC_NODE
+    E.backward()
+    ref = weakref.ref(ti)
+    del d, V, E, ti
+    gc.collect()
+    assert ref() is None

@@ -108,7 +108,9 @@ inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 
 // ---- what the Python layer prepares once per (pair list, shifts) and per (calculator, cell) -------------------------------------
 struct FrontTopo {
-  at::Tensor pairs;  // the caller's neighbor_indices (identity + version are the key)
+  // the caller's neighbor_indices: identity + version are the key; held WEAKLY (the list is 76 MB at cfg3 and the Python-side
+  // topology cache must not keep every list it has seen alive)
+  c10::weak_intrusive_ptr<c10::TensorImpl> pairs{c10::intrusive_ptr<c10::TensorImpl>()};
   uint32_t pairs_version = 0;
   at::Tensor shifts;                         // (P,3) cell shifts in the working dtype
   at::Tensor pairs32, pair_packed;           // list order: the distance kernel
@@ -117,6 +119,10 @@ struct FrontTopo {
   int64_t n_atoms = 0, n_pairs = 0;
   int ent_sh_format = 1;
 };
+
+bool is_list_of(const at::Tensor& pairs, const FrontTopo& topo) {
+  return !topo.pairs.expired() && topo.pairs._unsafe_get_target() == pairs.unsafeGetTensorImpl();
+}
 
 struct FrontCalc {
   mipme_mesh_t mesh;
@@ -188,7 +194,7 @@ struct DistNode : public Node {
     if (at::GradMode::is_enabled()) {
       // create_graph=True: the adjoint as differentiable tensor ops -- exact second order, what the reference's helper gives
       // (tests/helpers.py:278-304) and what ops._PairDistances.backward does
-      at::Tensor i = topo->pairs.select(1, 0).to(at::kLong), j = topo->pairs.select(1, 1).to(at::kLong);
+      at::Tensor i = topo->pairs32.select(1, 0).to(at::kLong), j = topo->pairs32.select(1, 1).to(at::kLong);
       at::Tensor vec = pos_in.index_select(0, j) - pos_in.index_select(0, i) + topo->shifts.matmul(cell_in);
       at::Tensor gvec = (g / at::linalg_vector_norm(vec, 2, at::IntArrayRef{1})).unsqueeze(1) * vec;
       out[0] = at::zeros_like(pos_in).index_add(0, j, gvec).index_add(0, i, -gvec);
@@ -231,7 +237,7 @@ std::optional<at::Tensor> pair_distances(const std::shared_ptr<FrontTopo>& topo,
   if (!topo || !eligible_real(positions) || !eligible_real(cell) || positions.dim() != 2 || positions.size(1) != 3 ||
       positions.size(0) != topo->n_atoms || cell.dim() != 2 || cell.size(0) != 3 || cell.size(1) != 3 ||
       cell.scalar_type() != positions.scalar_type() || cell.device() != positions.device() || cell.requires_grad() ||
-      !same_tensor(pairs, topo->pairs) || pairs._version() != topo->pairs_version || topo->n_pairs == 0 ||
+      !is_list_of(pairs, *topo) || pairs._version() != topo->pairs_version || topo->n_pairs == 0 ||
       topo->pair_packed.device() != positions.device())
     return std::nullopt;
   const bool need_grad = at::GradMode::is_enabled() && positions.requires_grad();
@@ -468,7 +474,7 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   // the distances are those of THESE positions, cell and pair list, untouched since
   if (dn->pos_impl != positions.unsafeGetTensorImpl() || dn->pos_version != positions._version() ||
       dn->cell_impl != cell.unsafeGetTensorImpl() || dn->cell_version != cell._version() ||
-      dn->dist_impl != dist.unsafeGetTensorImpl() || dist._version() != 0 || !same_tensor(pairs, topo->pairs) ||
+      dn->dist_impl != dist.unsafeGetTensorImpl() || dist._version() != 0 || !is_list_of(pairs, *topo) ||
       pairs._version() != topo->pairs_version)
     return std::nullopt;
   // ... and the geometry / G(k) are those of this cell
@@ -580,7 +586,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(py::init([](at::Tensor pairs, at::Tensor shifts, at::Tensor pairs32, at::Tensor pair_packed, at::Tensor row_ptr, at::Tensor entries,
                        at::Tensor row_packed, at::Tensor ent_sh, int ent_sh_format, std::optional<at::Tensor> ent32, int64_t n_atoms) {
         auto t = std::make_shared<FrontTopo>();
-        t->pairs = pairs;
+        t->pairs = c10::weak_intrusive_ptr<c10::TensorImpl>(pairs.getIntrusivePtr());
         t->pairs_version = pairs._version();
         t->shifts = shifts;
         t->pairs32 = pairs32;
