@@ -506,7 +506,8 @@ template <int THREADS> struct SpreadShape {
 };
 static constexpr int SPREAD_ROUND = SpreadShape<SPREAD_THREADS>::kRound;
 
-static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize, "the shift table of a row workgroup (4 reals per code) lives in the staging region");
+static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize + kErfcxLdsDoubles,
+              "the shift table of a row workgroup (4 reals per code) and the fp64 body's erfcx table live in the staging region");
 static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows, bool sparse = false) {
   const int waves = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kWaves : SPREAD_WAVES;
   const int round = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kRound : SPREAD_ROUND;
@@ -811,6 +812,14 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
           done = true;
         }
       }
+#if MIPME_ROW_LANES == 16
+      if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
+        if (!ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
+          sr_rows_f64_body<SPREAD_THREADS>(ra, r, smem_rows);
+          done = true;
+        }
+      }
+#endif
       if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
     }
   }
@@ -1557,6 +1566,14 @@ __global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(cons
         return;
       }
     }
+#if MIPME_ROW_LANES == 16
+    if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
+      if (!f.rows.dist_out) {
+        sr_rows_f64_body<SPREAD_THREADS>(f.rows, blockIdx.x - n_spread, smem_rows);
+        return;
+      }
+    }
+#endif
     sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread, tab);
   }
 }

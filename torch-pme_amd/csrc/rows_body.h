@@ -473,6 +473,144 @@ __device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
   return i4v{int(unsigned(a)), int(unsigned(a >> 32) & 0xffffu), int(bytes), 0x00020000};
 }
 
+// The fp64 counterpart of the packed body below (Coulomb, 4-byte entries, potential + force sums, nobody asks for the
+// distances): raw buffer loads (no 64-bit address arithmetic), no distance by-product and its branches, erfc from the LDS table
+// of srpot.h instead of the whole-range polynomial whose 21 scalar-register constants made the generic body spill.  ISA of the
+// hot loop: 223 -> ... VALU per two entries (profiles/r03_experiments.txt).
+// lds: kShiftTableSize AtomRecord<double> (the shift table) followed by kErfcxLdsDoubles doubles (the erfcx table).
+__device__ __forceinline__ i4v uniform_rsrc(i4v r) {
+  return i4v{__builtin_amdgcn_readfirstlane(r.x), __builtin_amdgcn_readfirstlane(r.y), __builtin_amdgcn_readfirstlane(r.z),
+             __builtin_amdgcn_readfirstlane(r.w)};
+}
+static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(AtomRecord<double>) + sizeof(double) * kErfcxLdsDoubles;
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ d2v llvm_raw_buffer_load_d2(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f64");
+
+template <int BS>
+__device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
+  static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
+  AtomRecord<double>* __restrict__ shift_tab = reinterpret_cast<AtomRecord<double>*>(lds);
+  double* __restrict__ etab = reinterpret_cast<double*>(lds + size_t(kShiftTableSize) * sizeof(AtomRecord<double>));
+  const int64_t N = args.N;
+  const int* __restrict__ row_ptr = args.row_ptr;
+  const double* __restrict__ pos = args.pos;
+  const double* __restrict__ cell = args.cell;
+  double* __restrict__ out = args.out;
+  double* __restrict__ force = args.force;
+  const double c_inv2s2 = args.cf.inv_2s2, c1 = args.cf.c1, cpref = args.cf.pref;
+  const int sub = threadIdx.x % kRowLanes;
+  unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = unsigned(N - 1);
+  const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
+  const int r0 = rp[0], mid = rp[1], r2 = rp[2];
+  // (uniform by construction; said so explicitly, or the buffer descriptor built from it is treated as divergent and every
+  // entry load becomes a waterfall loop)
+  const int n_entries = __builtin_amdgcn_readfirstlane(row_ptr[int64_t(args.row_stride) * N]);
+  double ax, ay, az, qa;
+  if (pos) {
+    ax = pos[3 * a];
+    ay = pos[3 * a + 1];
+    az = pos[3 * a + 2];
+    qa = args.q[a];
+  } else {
+    const AtomRecord<double> own = args.rec[a];
+    ax = own.x;
+    ay = own.y;
+    az = own.z;
+    qa = own.w;
+  }
+  {
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = cell ? cell[k] : 0.0;
+    for (int k = threadIdx.x; k < kShiftTableSize; k += BS) {
+      const double sx = double(k % kShiftTableBase - kShiftTableRange),
+                   sy = double((k / kShiftTableBase) % kShiftTableBase - kShiftTableRange),
+                   sz = double(k / (kShiftTableBase * kShiftTableBase) - kShiftTableRange);
+      shift_tab[k] = AtomRecord<double>{sx * A[0] + sy * A[3] + sz * A[6], sx * A[1] + sy * A[4] + sz * A[7],
+                                        sx * A[2] + sy * A[5] + sz * A[8], 0.0};
+    }
+    erfcx_table_to_lds(etab, threadIdx.x, BS);
+  }
+  const int pot_end = args.full ? mid : 0x7fffffff;
+  const int beg = r0, end = valid ? r2 : r0;
+  const i4v ent_rs = uniform_rsrc(raw_buffer(args.ent_sh, unsigned(n_entries) * 4u));
+  const i4v rec_rs = uniform_rsrc(raw_buffer(args.rec, unsigned(N) * 32u));
+  constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
+  int off = (beg + sub) * 4;
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+  __syncthreads();  // shift table + erfcx table
+  double pot = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+  for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
+    const int eB = eA + kRowLanes;
+    const int oA = int((wA & kAtomMask) << 5), oB = int((wB & kAtomMask) << 5);
+    const d2v pAxy = llvm_raw_buffer_load_d2(rec_rs, oA, 0, 0), pAzq = llvm_raw_buffer_load_d2(rec_rs, oA + 16, 0, 0);
+    const d2v pBxy = llvm_raw_buffer_load_d2(rec_rs, oB, 0, 0), pBzq = llvm_raw_buffer_load_d2(rec_rs, oB + 16, 0, 0);
+    const AtomRecord<double> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
+    off += 8 * kRowLanes;
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+    // the two entries side by side, operation by operation: each constant of the polynomials then serves two FMAs from the
+    // same scalar register pair.  No select on d2 for entries beyond the row's end: they read some valid record (the buffer
+    // descriptor bounds the loads), everything stays finite in double, and their weight sv is zero.
+    const double vx[2] = {(pAxy.x - ax) + sA.x, (pBxy.x - ax) + sB.x};
+    const double vy[2] = {(pAxy.y - ay) + sA.y, (pBxy.y - ay) + sB.y};
+    const double vz[2] = {(pAzq.x - az) + sA.z, (pBzq.x - az) + sB.z};
+    const double sv[2] = {eA < end ? pAzq.y : 0.0, eB < end ? pBzq.y : 0.0};
+    const double sp[2] = {eA < pot_end ? sv[0] : 0.0, eB < pot_end ? sv[1] : 0.0};
+    double d2[2], inv[2], x[2], e[2], y[2], Q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) d2[u] = __builtin_fmax(__builtin_fma(vz[u], vz[u], __builtin_fma(vy[u], vy[u], vx[u] * vx[u])), 1e-30);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) inv[u] = __builtin_amdgcn_rsq(d2[u]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) inv[u] = inv[u] * __builtin_fma(-0.5 * d2[u] * inv[u], inv[u], 1.5);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      x[u] = d2[u] * c_inv2s2;
+      y[u] = c1 * (d2[u] * inv[u]);
+    }
+    exp_neg_fast2(x, e);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double term = (2.0 * 0.56418958354775628695) * y[u] * e[u];
+      const double pi = cpref * inv[u];
+      pot = __builtin_fma(sp[u], pi * Q[u], pot);
+      const double sc = sv[u] * ((pi * (inv[u] * inv[u])) * (term + Q[u]));  // = -sv dv/dd / d
+      fx = __builtin_fma(sc, vx[u], fx);
+      fy = __builtin_fma(sc, vy[u], fy);
+      fz = __builtin_fma(sc, vz[u], fz);
+    }
+  }
+  pot = row_sum(pot);
+  if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.0) + 0.5 * pot;
+  if (args.epart) {  // see the generic body
+    const bool mine = sub == 0 && valid;
+    const double e1 = wave_sum(mine ? qa * (0.5 * pot) : 0.0);
+    const double e2 = wave_sum(mine ? qa * qa : 0.0);
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
+      args.epart[2 * w] = e1;
+      args.epart[2 * w + 1] = e2;
+    }
+  }
+  fx = row_sum(fx);
+  fy = row_sum(fy);
+  fz = row_sum(fz);
+  if (sub == 0 && valid) {
+    force[3 * a] = fx;
+    force[3 * a + 1] = fy;
+    force[3 * a + 2] = fz;
+  }
+}
+
 #if MIPME_ROW_LANES == 16
 template <int PFAST, int BS>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
