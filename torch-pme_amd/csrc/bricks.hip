@@ -833,7 +833,9 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
 // shift table in LDS and no register bound, i.e. full occupancy -- the same bodies, the same per-wave energy partial sums.
 template <typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int xcd) {
-  __shared__ AtomRecord<T> tab[kShiftTableSize];
+  constexpr bool F64_BODY = COMPACT && std::is_same<T, double>::value && PFAST == 1 && kRowLanes == 16;
+  __shared__ __attribute__((aligned(16))) char tab_raw[F64_BODY ? kRowsF64LdsBytes : sizeof(AtomRecord<T>) * kShiftTableSize];
+  AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(tab_raw);
   constexpr int BS = 256;
   const unsigned n_row_blocks = unsigned((ra.N + BS / kRowLanes - 1) / (BS / kRowLanes));
   const unsigned r = xcd ? xcd_contiguous(blockIdx.x, n_row_blocks) : blockIdx.x;
@@ -844,6 +846,14 @@ __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int
       return;
     }
   }
+#if MIPME_ROW_LANES == 16
+  if constexpr (F64_BODY) {
+    if (!ra.dist_out) {
+      sr_rows_f64_body<BS>(ra, r, tab_raw);
+      return;
+    }
+  }
+#endif
   sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, BS, 0, COMPACT>(ra, r, tab);
 }
 
@@ -2166,6 +2176,10 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_s
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
       if constexpr (std::is_same<T, float>::value)
         sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, r, tab);
+#if MIPME_ROW_LANES == 16
+      else if constexpr (PFAST == 1)
+        sr_rows_f64_body<SPREAD_THREADS>(ra, r, smem_rows);
+#endif
       else
         sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, true>(ra, r, tab);
     }
