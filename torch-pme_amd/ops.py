@@ -1264,7 +1264,8 @@ def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, de
     if (deferred is False and FRONT and PROFILE is None and cell is not None and PAIR_MODE == "rows" and FUSE_DISTANCES and positions.requires_grad
             and not cell.requires_grad and torch.is_grad_enabled() and type(positions) is torch.Tensor
             and type(neighbor_indices) is torch.Tensor and neighbor_indices.is_contiguous() and neighbor_indices.dim() == 2
-            and getattr(neighbor_indices, "_mipme_stream", None) is None and shifts_c.is_contiguous()):
+            and getattr(neighbor_indices, "_mipme_stream", None) is None and shifts_c.is_contiguous()
+            and not inside_vmap(positions, cell, neighbor_indices, shifts_c)):
         # compiled front end (csrc/front.cpp): the same kernel, a C++ autograd node, ~8 us of host time instead of ~50
         mod = _front.module()
         if mod is not None:
