@@ -403,6 +403,82 @@ __global__ __launch_bounds__(256) void dot_backward_kernel(int64_t n, const T* _
 // its memory latency behind (the first version, one dependent load per iteration, took 25 us for 32k values).
 static constexpr int kMatchUnroll = 8;
 
+// n <= 1024 * kMatchRegs: every thread loads ALL its elements of q and g at once and keeps them in registers -- one memory
+// round trip for the whole kernel (the reference element's g and q reach the other threads through LDS, not through a second
+// trip).  The looped version below needs ~9 dependent trips to data other kernels have just written on other XCDs: 24 us at
+// 32 000 values in the kernel trace of the reference call sequence, this one 8.9 (profiles/r03_h_kernel_stats_dropin.txt).
+static constexpr int kMatchRegs = 32;
+template <typename T>
+__global__ __launch_bounds__(1024) void scaled_match_small_kernel(int n, const T* __restrict__ g, const T* __restrict__ q,
+                                                                  T* __restrict__ result, int* __restrict__ host_flag) {
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_bad[16];
+  __shared__ T s_ref[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T qv[kMatchRegs], gv[kMatchRegs];
+#pragma unroll
+  for (int u = 0; u < kMatchRegs; ++u) {
+    const int i = threadIdx.x + u * 1024;
+    qv[u] = i < n ? q[i] : T(0);
+    gv[u] = i < n ? g[i] : T(0);
+  }
+  double best = -1.0;
+  int bi = 0;
+#pragma unroll
+  for (int u = 0; u < kMatchRegs; ++u) {  // ascending index within the thread: the first maximum wins, as below
+    const double v = fabs(double(qv[u]));
+    if (v > best) {
+      best = v;
+      bi = threadIdx.x + u * 1024;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (s_val[w] > s_val[0] || (s_val[w] == s_val[0] && s_idx[w] < s_idx[0])) { s_val[0] = s_val[w]; s_idx[0] = s_idx[w]; }
+  }
+  __syncthreads();
+  const int k = s_idx[0];
+  const bool usable = s_val[0] > 0.0;
+  if (int(threadIdx.x) == (k & 1023)) {  // the owner of element k hands its g and q to everybody
+    const int u = k >> 10;
+    T gk = T(0), qk = T(1);
+#pragma unroll
+    for (int t = 0; t < kMatchRegs; ++t)
+      if (t == u) { gk = gv[t]; qk = qv[t]; }
+    s_ref[0] = gk;
+    s_ref[1] = qk;
+  }
+  __syncthreads();
+  const T scale = usable ? s_ref[0] / s_ref[1] : T(0);
+  const double sd = double(scale);
+  const double tol = 8.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
+  int bad = (usable && isfinite(sd)) ? 0 : 1;
+#pragma unroll
+  for (int u = 0; u < kMatchRegs; ++u) {
+    const double e = sd * double(qv[u]);
+    if (!(fabs(double(gv[u]) - e) <= tol * fabs(e))) bad = 1;
+  }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) s_bad[wave] = bad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int w = 0; w < 16; ++w) any |= s_bad[w];
+    result[0] = scale;
+    result[1] = any ? T(0) : T(1);
+    if (host_flag) __hip_atomic_store(host_flag, any ? 0 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* __restrict__ g, const T* __restrict__ q,
                                                             T* __restrict__ result, int* __restrict__ host_flag) {
@@ -1002,7 +1078,13 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
 int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag) {
   MIPME_REQUIRE(n > 0 && g && q && result, "invalid arguments to mipme_scaled_match");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIPME_F32)
+  const bool small = n <= 1024 * kMatchRegs;
+  if (dtype == MIPME_F32 && small)
+    scaled_match_small_kernel<float><<<1, 1024, 0, st>>>(int(n), (const float*)g, (const float*)q, (float*)result, (int*)host_flag);
+  else if (dtype == MIPME_F64 && small)
+    scaled_match_small_kernel<double><<<1, 1024, 0, st>>>(int(n), (const double*)g, (const double*)q, (double*)result,
+                                                          (int*)host_flag);
+  else if (dtype == MIPME_F32)
     scaled_match_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result, (int*)host_flag);
   else if (dtype == MIPME_F64)
     scaled_match_kernel<double><<<1, 1024, 0, st>>>(n, (const double*)g, (const double*)q, (double*)result, (int*)host_flag);
