@@ -353,7 +353,8 @@ struct CalcNode : public Node {
       out_pos = at::empty_like(pos);
       check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh.data_ptr(), topo->entries.data_ptr(), nullptr,
                                 pos.data_ptr(), cell.data_ptr(), q.data_ptr(), nullptr, g.data_ptr(), 0, calc->full_list, &calc->pot,
-                                0, topo->ent_sh_format, slab(off_rec), 0, nullptr, out_pos.data_ptr(), nullptr, nullptr, nullptr),
+                                0, topo->ent_sh_format, slab(off_rec), 1 /* the forward's records: same positions and charges */, nullptr,
+                                out_pos.data_ptr(), nullptr, nullptr, nullptr),
             "rspace_backward");
     };
     // ... or as a (P,) gradient through the distances node
