@@ -309,3 +309,57 @@ def test_device_neighbor_list_nonperiodic_axes(periodic, full):
     for d in range(3):
         if not periodic[d]:
             assert (gS[:, d] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 1000, 32768, 32769, 100_000, 300_001])
+def test_scaled_match_verdicts(dtype, n):
+    """mipme_scaled_match / _wide (is g == s * q for one scalar s? -- the energy-mode test of the backward passes): one workgroup
+    up to 32 768 values, blocks + a combining launch beyond; the same verdicts either way: exact multiples match, one perturbed
+    element (anywhere, also in a block whose own check would pass with its own scale) does not, zeros in q demand zeros in g."""
+    import ctypes as C  # noqa: F401
+
+    from torchpme_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    st = _lib.current_stream(dev)
+    dt = _lib.dtype_code(dtype)
+    gen = torch.Generator(device="cpu").manual_seed(n)
+    q = torch.randn(n, generator=gen, dtype=torch.float64).to(dev, dtype)
+    res = torch.empty(2, device=dev, dtype=dtype)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.empty(max(1, lib.mipme_scaled_match_work(n)), dtype=torch.float64, device=dev)
+    assert (lib.mipme_scaled_match_work(n) == 0) == (n <= 32768)
+
+    def verdict(g, wide):
+        flag.fill_(-7)
+        if wide:
+            _lib.check(lib.mipme_scaled_match_wide(st, dt, n, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag.data_ptr(), work.data_ptr()))
+        else:
+            _lib.check(lib.mipme_scaled_match(st, dt, n, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(flag[0]) == int(res[1])
+        return int(flag[0]), float(res[0])
+
+    for wide in (False, True):
+        ok, s = verdict(-1.75 * q, wide)
+        assert ok == 1 and abs(s + 1.75) <= 4 * 1.75 * torch.finfo(dtype).eps
+        for where in sorted({0, n // 2, n - 1}) if n > 1 else []:  # (a single value is a multiple of anything)
+            g = -1.75 * q
+            g[where] = g[where] * (1 + 1e-3) + 1e-3
+            assert verdict(g, wide)[0] == 0
+        g = -1.75 * q
+        if n > 40000:  # a whole block of the many-block form consistent with ANOTHER scale
+            g[32768:65536] = -1.75 * (1 + 100 * torch.finfo(dtype).eps) * q[32768:65536]
+            assert verdict(g, wide)[0] == 0
+        assert verdict(torch.zeros_like(q), wide) == (1, 0.0)
+    if n > 2:  # zeros in q: g must be zero there
+        q[: n // 2] = 0
+        g = 0.5 * q
+        assert verdict(g, True)[0] == 1 and verdict(g, False)[0] == 1
+        g[0] = 1e-3
+        assert verdict(g, True)[0] == 0 and verdict(g, False)[0] == 0
+    q.zero_()
+    assert verdict(torch.zeros_like(q), True)[0] == 0  # no reference element at all: not a match (as with one workgroup)
+    assert verdict(torch.zeros_like(q), False)[0] == 0

@@ -34,7 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
-    "mipme_scaled_match", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum",
+    "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum",
 )
 
 
@@ -251,6 +251,8 @@ def _declare(lib):
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_scaled_match": [vp, ci, i64, vp, vp, vp, vp],
+        "mipme_scaled_match_work": [i64],
+        "mipme_scaled_match_wide": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_nl_bin": [vp, ci, C.POINTER(NlDesc), i64, vp, vp],
         "mipme_nl_count": [vp, ci, C.POINTER(NlDesc), i64, vp, vp],
         "mipme_nl_fill": [vp, ci, C.POINTER(NlDesc), i64, vp, vp, vp, vp, vp],

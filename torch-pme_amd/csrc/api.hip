@@ -408,13 +408,20 @@ static constexpr int kMatchUnroll = 8;
 // trip).  The looped version below needs ~9 dependent trips to data other kernels have just written on other XCDs: 24 us at
 // 32 000 values in the kernel trace of the reference call sequence, this one 8.9 (profiles/r03_h_kernel_stats_dropin.txt).
 static constexpr int kMatchRegs = 32;
-template <typename T>
-__global__ __launch_bounds__(1024) void scaled_match_small_kernel(int n, const T* __restrict__ g, const T* __restrict__ q,
-                                                                  T* __restrict__ result, int* __restrict__ host_flag) {
+// PARTS: block b of many does this for ITS 32 768 values and leaves {scale_b, max |q|_b, bad_b} in parts[3 b ..] for
+// scaled_match_combine_kernel (a block without a non-zero q demands g == 0 of its values and lets the others name the scale).
+template <typename T, bool PARTS>
+__global__ __launch_bounds__(1024) void scaled_match_small_kernel(int64_t n_all, const T* __restrict__ g_all,
+                                                                  const T* __restrict__ q_all, T* __restrict__ result,
+                                                                  int* __restrict__ host_flag, double* __restrict__ parts) {
   __shared__ double s_val[16];
   __shared__ int s_idx[16];
   __shared__ int s_bad[16];
   __shared__ T s_ref[2];
+  const int64_t first = int64_t(blockIdx.x) * (1024 * kMatchRegs);
+  const int n = int(n_all - first < 1024 * kMatchRegs ? n_all - first : 1024 * kMatchRegs);
+  const T* __restrict__ g = g_all + first;
+  const T* __restrict__ q = q_all + first;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T qv[kMatchRegs], gv[kMatchRegs];
 #pragma unroll
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(1024) void scaled_match_small_kernel(int n, const T
   const T scale = usable ? s_ref[0] / s_ref[1] : T(0);
   const double sd = double(scale);
   const double tol = 8.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
-  int bad = (usable && isfinite(sd)) ? 0 : 1;
+  int bad = PARTS ? ((!usable || isfinite(sd)) ? 0 : 1) : ((usable && isfinite(sd)) ? 0 : 1);
 #pragma unroll
   for (int u = 0; u < kMatchRegs; ++u) {
     const double e = sd * double(qv[u]);
@@ -473,7 +480,63 @@ __global__ __launch_bounds__(1024) void scaled_match_small_kernel(int n, const T
   if (threadIdx.x == 0) {
     int any = 0;
     for (int w = 0; w < 16; ++w) any |= s_bad[w];
-    result[0] = scale;
+    if constexpr (PARTS) {
+      parts[3 * blockIdx.x] = sd;
+      parts[3 * blockIdx.x + 1] = s_val[0];
+      parts[3 * blockIdx.x + 2] = double(any);
+    } else {
+      result[0] = scale;
+      result[1] = any ? T(0) : T(1);
+      if (host_flag) __hip_atomic_store(host_flag, any ? 0 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// the verdict of many blocks: the scale of the block that holds the largest |q| (the first such block), every block's own check
+// passed, and every other block's scale equal to it within 4 ulp -- |g - s q| <= ~12 ulp |s q| overall (one block: 8)
+template <typename T>
+__global__ __launch_bounds__(256) void scaled_match_combine_kernel(int n_blocks, const double* __restrict__ parts,
+                                                                   T* __restrict__ result, int* __restrict__ host_flag) {
+  __shared__ double s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ int s_bad[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best = -1.0;
+  int bi = 0;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    const double v = parts[3 * b + 1];
+    if (v > best) {
+      best = v;
+      bi = b;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_val[w] > s_val[0] || (s_val[w] == s_val[0] && s_idx[w] < s_idx[0])) { s_val[0] = s_val[w]; s_idx[0] = s_idx[w]; }
+  }
+  __syncthreads();
+  const bool usable = s_val[0] > 0.0;
+  const double sd = usable ? parts[3 * s_idx[0]] : 0.0;
+  const double tol = 4.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
+  int bad = (usable && isfinite(sd)) ? 0 : 1;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    if (parts[3 * b + 2] != 0.0) bad = 1;
+    if (parts[3 * b + 1] > 0.0 && !(fabs(parts[3 * b] - sd) <= tol * fabs(sd))) bad = 1;
+  }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) s_bad[wave] = bad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int any = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+    result[0] = T(sd);
     result[1] = any ? T(0) : T(1);
     if (host_flag) __hip_atomic_store(host_flag, any ? 0 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -712,6 +775,17 @@ static int md_step_t(const mipme_md_args_t& a) {
   return MIPME_OK;
 }
 
+
+template <typename T>
+static int scaled_match_wide_t(hipStream_t st, int64_t n, const void* g, const void* q, void* result, void* host_flag, void* work) {
+  const int64_t nb = (n + 1024 * kMatchRegs - 1) / (1024 * kMatchRegs);
+  MIPME_REQUIRE(nb < (int64_t(1) << 24), "mipme_scaled_match_wide: too many values");
+  scaled_match_small_kernel<T, true><<<unsigned(nb), 1024, 0, st>>>(n, (const T*)g, (const T*)q, nullptr, nullptr, (double*)work);
+  MIPME_LAUNCH_CHECK();
+  scaled_match_combine_kernel<T><<<1, 256, 0, st>>>(int(nb), (const double*)work, (T*)result, (int*)host_flag);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
 
 extern "C" {
 
@@ -1075,15 +1149,29 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
   return MIPME_OK;
 }
 
+int64_t mipme_scaled_match_work(int64_t n) {
+  return n <= 1024 * kMatchRegs ? 0 : 3 * ((n + 1024 * kMatchRegs - 1) / (1024 * kMatchRegs));
+}
+
+int mipme_scaled_match_wide(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag,
+                            void* work) {
+  MIPME_REQUIRE(n > 0 && g && q && result, "invalid arguments to mipme_scaled_match_wide");
+  MIPME_REQUIRE(dtype == MIPME_F32 || dtype == MIPME_F64, "invalid dtype %d", dtype);
+  if (!work || n <= 1024 * kMatchRegs) return mipme_scaled_match(stream, dtype, n, g, q, result, host_flag);
+  return dtype == MIPME_F32 ? scaled_match_wide_t<float>((hipStream_t)stream, n, g, q, result, host_flag, work)
+                            : scaled_match_wide_t<double>((hipStream_t)stream, n, g, q, result, host_flag, work);
+}
+
 int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag) {
   MIPME_REQUIRE(n > 0 && g && q && result, "invalid arguments to mipme_scaled_match");
   hipStream_t st = (hipStream_t)stream;
   const bool small = n <= 1024 * kMatchRegs;
   if (dtype == MIPME_F32 && small)
-    scaled_match_small_kernel<float><<<1, 1024, 0, st>>>(int(n), (const float*)g, (const float*)q, (float*)result, (int*)host_flag);
+    scaled_match_small_kernel<float, false><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result, (int*)host_flag,
+                                                                nullptr);
   else if (dtype == MIPME_F64 && small)
-    scaled_match_small_kernel<double><<<1, 1024, 0, st>>>(int(n), (const double*)g, (const double*)q, (double*)result,
-                                                          (int*)host_flag);
+    scaled_match_small_kernel<double, false><<<1, 1024, 0, st>>>(n, (const double*)g, (const double*)q, (double*)result,
+                                                                 (int*)host_flag, nullptr);
   else if (dtype == MIPME_F32)
     scaled_match_kernel<float><<<1, 1024, 0, st>>>(n, (const float*)g, (const float*)q, (float*)result, (int*)host_flag);
   else if (dtype == MIPME_F64)

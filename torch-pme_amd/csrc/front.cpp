@@ -61,6 +61,8 @@ struct Api {
   decltype(&mipme_pair_distance_forward_packed) pair_distance_forward_packed = nullptr;
   decltype(&mipme_pair_distance_backward_rows) pair_distance_backward_rows = nullptr;
   decltype(&mipme_scaled_match) scaled_match = nullptr;
+  decltype(&mipme_scaled_match_work) scaled_match_work = nullptr;
+  decltype(&mipme_scaled_match_wide) scaled_match_wide = nullptr;
   decltype(&mipme_sr_rows_finalize) sr_rows_finalize = nullptr;
   decltype(&mipme_sr_rows_fused) sr_rows_fused = nullptr;
   decltype(&mipme_rspace_backward) rspace_backward = nullptr;
@@ -87,6 +89,8 @@ void load_library(const std::string& path) {
   bind(g_api.pair_distance_forward_packed, "mipme_pair_distance_forward_packed");
   bind(g_api.pair_distance_backward_rows, "mipme_pair_distance_backward_rows");
   bind(g_api.scaled_match, "mipme_scaled_match");
+  bind(g_api.scaled_match_work, "mipme_scaled_match_work");
+  bind(g_api.scaled_match_wide, "mipme_scaled_match_wide");
   bind(g_api.sr_rows_finalize, "mipme_sr_rows_finalize");
   bind(g_api.sr_rows_fused, "mipme_sr_rows_fused");
   bind(g_api.rspace_backward, "mipme_rspace_backward");
@@ -365,6 +369,14 @@ struct CalcNode : public Node {
             "rspace_backward");
     };
     const bool capturing = stream_is_capturing(stream);
+    // g == gE * charges?  (many blocks beyond 32 768 values: one workgroup needs 87 us for 262 144 of them)
+    at::Tensor match_work;
+    auto run_match = [&](void* flag) {
+      const int64_t nw = g_api.scaled_match_work(N);
+      if (nw > 0) match_work = at::empty({nw}, opts.dtype(at::kDouble));
+      return g_api.scaled_match_wide(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag,
+                                     nw > 0 ? match_work.data_ptr() : nullptr);
+    };
 
     if (need_pos && !real_dd && !capturing && g_device_select) {
       // Energy mode (g == gE * charges: the gradient of (charges * V).sum()) decided ON THE DEVICE and acted on there: the general
@@ -373,7 +385,7 @@ struct CalcNode : public Node {
       // host never waits: polling the verdict instead (below) makes it wait for everything queued before, and the GPU then
       // idles while the host prepares the next step.
       at::Tensor flag = at::empty({1}, opts.dtype(at::kInt));
-      check(g_api.scaled_match(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag.data_ptr()), "scaled_match");
+      check(run_match(flag.data_ptr()), "scaled_match");
       struct SkipGuard {
         ~SkipGuard() { g_api.set_skip_flag(nullptr); }
       };
@@ -394,7 +406,7 @@ struct CalcNode : public Node {
         if (!t_match_flag.defined()) t_match_flag = at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
         volatile int* flag = static_cast<volatile int*>(t_match_flag.data_ptr());
         *flag = -1;
-        check(g_api.scaled_match(stream, dt, N, g.data_ptr(), q.data_ptr(), res.data_ptr(), const_cast<int*>(flag)), "scaled_match");
+        check(run_match(const_cast<int*>(flag)), "scaled_match");
         int64_t spins = 0;
         while (*flag == -1) {
           if (++spins > 200000000) {  // never seen; a synchronisation is the fallback

@@ -583,6 +583,17 @@ class LazyPairGradient(torch.Tensor):
         return func(*tree_map(plain, args), **tree_map(plain, kwargs or {}))
 
 
+def _scaled_match(lib, st, dt, n, g, q, res, flag_ptr):
+    """``mipme_scaled_match`` (is g == s * q for one scalar s?), in its many-block form beyond 32 768 values."""
+    nw = lib.mipme_scaled_match_work(n) if n > 32768 else 0
+    if nw == 0:
+        _call("scaled_match", lib.mipme_scaled_match, st, dt, n, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag_ptr)
+    else:
+        work = torch.empty((nw,), dtype=torch.float64, device=g.device)
+        _call("scaled_match", lib.mipme_scaled_match_wide, st, dt, n, g.data_ptr(), q.data_ptr(), res.data_ptr(), flag_ptr,
+              work.data_ptr())
+
+
 class _SkipGuard:
     """Clears the library's per-thread skip flag (``mipme_set_skip_flag``) on the way out of a backward pass, whatever happened in
     between: the flag points at a tensor that dies with the pass."""
@@ -853,15 +864,13 @@ class _PMEFunction(torch.autograd.Function):
                     # once when the verdict is a match, then let one kernel replace its outputs by the energy-mode expressions
                     # in that case -- no host read, the host keeps running ahead of the GPU
                     select = dict(res=res, flag=torch.empty((1,), dtype=torch.int32, device=device))
-                    _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
-                          select["flag"].data_ptr())
+                    _scaled_match(lib, st, dt, N * Cn, g, q, res, select["flag"].data_ptr())
                     lib.mipme_set_skip_flag(select["flag"].data_ptr())
                     guard.armed = True
                 else:
                     flag, flag_np = _match_flag(device)
                     flag_np[0] = -1
-                    _call("scaled_match", lib.mipme_scaled_match, st, dt, N * Cn, g.data_ptr(), q.data_ptr(), res.data_ptr(),
-                          flag.data_ptr())
+                    _scaled_match(lib, st, dt, N * Cn, g, q, res, flag.data_ptr())
                     # the kernel also writes its verdict to pinned host memory: poll that word instead of a device-to-host copy
                     # (hipMemcpy of 4 bytes costs 20-30 us on this stack; the poll ends a few us after the kernel does)
                     spins = 0
