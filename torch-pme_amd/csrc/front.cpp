@@ -31,6 +31,7 @@
 #include <atomic>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -118,10 +119,33 @@ struct FrontTopo {
   uint32_t pairs_version = 0;
   at::Tensor shifts;                         // (P,3) cell shifts in the working dtype
   at::Tensor pairs32, pair_packed;           // list order: the distance kernel
-  at::Tensor row_ptr, entries, row_packed;   // rows: the distance adjoint
-  at::Tensor ent_sh, ent32;                  // rows with shift codes: the fused pair kernels (8-byte and 4-byte entries)
+  at::Tensor row_ptr, entries;               // rows
+  at::Tensor ent32;                          // rows with shift codes, 4-byte entries: the co-scheduled pair sum of the forward
   int64_t n_atoms = 0, n_pairs = 0;
-  int ent_sh_format = 1;
+  // Two more streams are only read by adjoints that the energy mode never launches on a match -- the general pair adjoint
+  // (8-byte entries with shift codes) and the distance adjoint (packed row shifts): made on first use by the Python layer
+  // (`lazy(kind) -> tensor`), so that a list that is new every call does not pay 0.2 ms for them (cold_list_ms).
+  py::object lazy;
+  std::mutex lazy_mutex;
+  at::Tensor row_packed_, ent_sh_;
+  const at::Tensor& stream_of(at::Tensor& slot, const char* kind) {
+    std::lock_guard<std::mutex> lock(lazy_mutex);
+    if (!slot.defined()) {
+      py::gil_scoped_acquire gil;
+      slot = lazy(kind).cast<at::Tensor>();
+    }
+    return slot;
+  }
+  const at::Tensor& row_packed() { return stream_of(row_packed_, "row_packed"); }
+  const at::Tensor& ent_sh() { return stream_of(ent_sh_, "ent_sh"); }
+  ~FrontTopo() {
+    if (lazy && Py_IsInitialized()) {
+      py::gil_scoped_acquire gil;
+      lazy = py::object();
+    } else {
+      lazy.release();
+    }
+  }
 };
 
 bool is_list_of(const at::Tensor& pairs, const FrontTopo& topo) {
@@ -209,7 +233,7 @@ struct DistNode : public Node {
     at::Tensor gc = g.contiguous();
     at::Tensor grad_pos = at::empty_like(pos);
     check(g_api.pair_distance_backward_rows(stream, dtype_code(pos), topo->n_atoms, topo->row_ptr.data_ptr(),
-                                            topo->entries.data_ptr(), topo->row_packed.data_ptr(), pos.data_ptr(),
+                                            topo->entries.data_ptr(), topo->row_packed().data_ptr(), pos.data_ptr(),
                                             cell.data_ptr(), nullptr, gc.data_ptr(), nullptr, grad_pos.data_ptr(), nullptr),
           "pair_distance_backward");
     out[0] = grad_pos;
@@ -355,9 +379,9 @@ struct CalcNode : public Node {
     // ... pair part, straight to the positions with the fused adjoint kernel
     auto pair_adjoint = [&](at::Tensor& out_pos) {
       out_pos = at::empty_like(pos);
-      check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh.data_ptr(), topo->entries.data_ptr(), nullptr,
+      check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh().data_ptr(), topo->entries.data_ptr(), nullptr,
                                 pos.data_ptr(), cell.data_ptr(), q.data_ptr(), nullptr, g.data_ptr(), 0, calc->full_list, &calc->pot,
-                                0, topo->ent_sh_format, slab(off_rec), 1 /* the forward's records: same positions and charges */, nullptr,
+                                0, 1 /* table codes */, slab(off_rec), 1 /* the forward's records: same positions and charges */, nullptr,
                                 out_pos.data_ptr(), nullptr, nullptr, nullptr),
             "rspace_backward");
     };
@@ -492,7 +516,7 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
     return std::nullopt;
   // ... and the geometry / G(k) are those of this cell
   if (!same_tensor(cell, calc->cell) || cell._version() != calc->cell_version) return std::nullopt;
-  if (!topo->ent32.defined() || !topo->ent_sh.defined() || topo->ent_sh_format != 1) return std::nullopt;
+  if (!topo->ent32.defined()) return std::nullopt;
 
   c10::hip::HIPGuardMasqueradingAsCUDA guard(positions.device());
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(positions.device().index()).stream();
@@ -596,8 +620,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_device_select", &set_device_select);
   m.def("set_second_order_hint", &set_second_order_hint);
   py::class_<FrontTopo, std::shared_ptr<FrontTopo>>(m, "Topology")
-      .def(py::init([](at::Tensor pairs, at::Tensor shifts, at::Tensor pairs32, at::Tensor pair_packed, at::Tensor row_ptr, at::Tensor entries,
-                       at::Tensor row_packed, at::Tensor ent_sh, int ent_sh_format, std::optional<at::Tensor> ent32, int64_t n_atoms) {
+      .def(py::init([](at::Tensor pairs, at::Tensor shifts, at::Tensor pairs32, at::Tensor pair_packed, at::Tensor row_ptr,
+                       at::Tensor entries, at::Tensor ent32, int64_t n_atoms, py::object lazy) {
         auto t = std::make_shared<FrontTopo>();
         t->pairs = c10::weak_intrusive_ptr<c10::TensorImpl>(pairs.getIntrusivePtr());
         t->pairs_version = pairs._version();
@@ -606,12 +630,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         t->pair_packed = pair_packed;
         t->row_ptr = row_ptr;
         t->entries = entries;
-        t->row_packed = row_packed;
-        t->ent_sh = ent_sh;
-        t->ent_sh_format = ent_sh_format;
-        if (ent32) t->ent32 = *ent32;
+        t->ent32 = ent32;
         t->n_atoms = n_atoms;
         t->n_pairs = pairs.size(0);
+        t->lazy = std::move(lazy);
         return t;
       }));
   py::class_<FrontCalc, std::shared_ptr<FrontCalc>>(m, "Calculator")

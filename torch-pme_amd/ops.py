@@ -234,6 +234,40 @@ def _side_stream(device):
     return entry
 
 
+def _pack_row_shifts(entries, shifts, n_pairs):
+    """int32 (2P + 1,) with the 3 cell shifts of every row entry as int8, or None if they are not small integers."""
+    lib = _lib.load()
+    device = shifts.device
+    packed = torch.zeros((2 * n_pairs + 1,), dtype=torch.int32, device=device)
+    flag = torch.empty((1,), dtype=torch.int32, device=device)
+    with _lib.on_device(device):
+        _lib.check(lib.mipme_topology_pack_shifts(_lib.current_stream(device), _lib.dtype_code(shifts.dtype), n_pairs,
+                                                  entries.data_ptr(), shifts.data_ptr(), packed.data_ptr(), flag.data_ptr()))
+    return None if int(flag.item()) != 0 else packed
+
+
+def _pack_entries(row_ptr, entries, shifts, n_pairs, n_atoms, table=True):
+    """``(ent_sh, shift_format)``: int32 (2P + 1, 2) {other atom, role-adjusted cell-shift code}, table codes (format 1) if asked
+    for and possible, else 3 x int8 (format 0); ``(None, 0)`` if the shifts are not small integers."""
+    lib = _lib.load()
+    device = entries.device
+    ent_sh = torch.zeros((2 * n_pairs + 1, 2), dtype=torch.int32, device=device)
+    flag = torch.empty((1,), dtype=torch.int32, device=device)
+    fmt = 1 if table else 0
+    while True:
+        with _lib.on_device(device):
+            _lib.check(lib.mipme_topology_pack_entries(
+                _lib.current_stream(device), _lib.dtype_code(shifts.dtype) if shifts is not None else _lib.F32, n_pairs, n_atoms,
+                row_ptr.data_ptr(), entries.data_ptr(), _lib.ptr(shifts), fmt, ent_sh.data_ptr(), flag.data_ptr()))
+        bits = int(flag.item()) if shifts is not None else 0
+        if bits & 1:
+            return None, 0
+        if fmt == 1 and bits & 2:
+            fmt = 0  # shifts beyond the table range: repack as 3 x int8
+            continue
+        return ent_sh, fmt
+
+
 class PairTopology:
     """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
 
@@ -247,7 +281,8 @@ class PairTopology:
         self.n_atoms, self.n_pairs = n_atoms, P
         self.row_ptr = torch.empty((2 * n_atoms + 1,), dtype=torch.int32, device=device)
         # one slot more than 2P: the row kernels prefetch entry `row begin` even for an empty last row (index 2P), never used
-        self.entries = torch.zeros((2 * P + 1, 2), dtype=torch.int32, device=device)
+        self.entries = torch.empty((2 * P + 1, 2), dtype=torch.int32, device=device)
+        self.entries[2 * P].zero_()  # (the build writes 2P entries: a 76 MB memset per list at cfg3 for one slot otherwise)
         self._packed = None  # (weakref(shifts), version, tensor|None)
         self._ent_sh = None  # (weakref(shifts)|None, version, tensor|None)
         self._pair_sh = None  # (weakref(shifts), version, tensor|None)
@@ -276,12 +311,24 @@ class PairTopology:
         mod = _front.module()
         if mod is not None and self.fmt_flags == 0 and self.n_pairs > 0:
             pair_packed = self.pair_packed_shifts(shifts, key)
-            row_packed = self.packed_shifts(shifts, key)
-            ent_sh, fmt = self.entries_with_shifts(shifts, key, table=True)
-            ent32 = self.compact_entries(shifts, key)
-            if pair_packed is not None and row_packed is not None and ent_sh is not None and fmt == 1 and ent32 is not None:
-                handle = mod.Topology(pairs, shifts, self.pairs32, pair_packed, self.row_ptr, self.entries, row_packed, ent_sh, fmt,
-                                      ent32, self.n_atoms)
+            ent32 = self.compact_entries(shifts, key)  # exists <=> integer shifts within the table range
+            if pair_packed is not None and ent32 is not None:
+                # the two streams only the general adjoints read are made on first use (a closure over tensors, not over this
+                # object: the handle may outlive it inside an autograd graph, and must not keep it alive in a cycle)
+                row_ptr, entries, n_pairs, n_atoms = self.row_ptr, self.entries, self.n_pairs, self.n_atoms
+
+                def lazy(kind, shifts=shifts):
+                    if kind == "row_packed":
+                        packed = _pack_row_shifts(entries, shifts, n_pairs)
+                    else:
+                        packed, fmt = _pack_entries(row_ptr, entries, shifts, n_pairs, n_atoms, table=True)
+                        packed = packed if fmt == 1 else None
+                    if packed is None:  # cannot happen when the 4-byte stream exists
+                        raise RuntimeError(f"no {kind} stream for this list")
+                    return packed
+
+                handle = mod.Topology(pairs, shifts, self.pairs32, pair_packed, self.row_ptr, self.entries, ent32, self.n_atoms,
+                                      lazy)
         self._front = (weakref.ref(key), key._version, shifts.dtype, handle)
         return handle
 
@@ -349,7 +396,8 @@ class PairTopology:
             return c[2]
         lib = _lib.load()
         device = self.entries.device
-        ent32 = torch.zeros((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
+        ent32 = torch.empty((2 * self.n_pairs + 1,), dtype=torch.int32, device=device)
+        ent32[2 * self.n_pairs :].zero_()
         flag = torch.empty((1,), dtype=torch.int32, device=device)
         with _lib.on_device(device):
             _lib.check(
