@@ -895,6 +895,23 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     const int x = idx >> kzs, z = idx & (KZ - 1);
     tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
   }
+  // the filter values this thread will need after the forward transform: fetched now, behind the tile's own loads, instead of
+  // after it (one more exposed round trip in a kernel that is one tile per CU at 64^3: a chain of latencies)
+  constexpr int kGPrefetch = 8;
+  T gpre[kGPrefetch];
+  const bool g_prefetched = n_el <= kGPrefetch * nthr;
+  if (g_prefetched) {
+#pragma unroll
+    for (int u = 0; u < kGPrefetch; ++u) {
+      const int idx = tid + u * nthr;
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      gpre[u] = T(0);
+      if (idx < n_el && z < kzn) {
+        const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+        gpre[u] = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
+      }
+    }
+  }
   __syncthreads();
   // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
   //      tile[(x << kzs) + z] ----
@@ -946,11 +963,19 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   // the half grid) -- the mesh part of the energy, assembled by the gather's tail (bricks.hip GatherTail)
   double esum = 0.0;
   const int nz_full = 2 * (nzh - 1);
-  for (int idx = tid; idx < n_el; idx += nthr) {
+  int u_pre = 0;
+  for (int idx = tid; idx < n_el; idx += nthr, ++u_pre) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
     if (z < kzn) {
       const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
-      const T gk = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];  // G_stride: one filter table per batch entry, or 0
+      T gk;  // G_stride: one filter table per batch entry, or 0
+      if (g_prefetched) {
+        gk = T(0);
+#pragma unroll
+        for (int u = 0; u < kGPrefetch; ++u) gk = u == u_pre ? gpre[u] : gk;
+      } else {
+        gk = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
+      }
       Cplx<T> v = tile[idx];
       if (epart) {
         const int iz = kz0 + z;
