@@ -887,19 +887,39 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       sr1 += sr_part[2 * i + 1];
     }
   }
-  for (int j = tid; j < half_n; j += nthr) unit_root(j, nx, tw[j].re, tw[j].im);
   Cplx<T>* col = hat + (int64_t(c) * nx * ny + ky) * nzh + kz0;  // element (x, z): col[x * ny * nzh + z]
   const int64_t xs = int64_t(ny) * nzh;
   const int n_el = nx << kzs;
-  for (int idx = tid; idx < n_el; idx += nthr) {
-    const int x = idx >> kzs, z = idx & (KZ - 1);
-    tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+  // The tile's loads are issued FIRST, into registers, and the twiddle table is computed while they are in flight: at 64^3 the
+  // kernel is one tile per CU, a chain of latencies in which the sincos sequence used to sit in front of loads that the plane
+  // kernel has just written on other XCDs (9.3 -> 8.6 us; the same reordering in the plane kernels changed nothing).
+  constexpr int kGPrefetch = 8;
+  const bool g_prefetched = n_el <= kGPrefetch * nthr;
+  Cplx<T> tpre[kGPrefetch];
+  if (g_prefetched) {
+#pragma unroll
+    for (int u = 0; u < kGPrefetch; ++u) {
+      const int idx = tid + u * nthr;
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      tpre[u] = (active && idx < n_el && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+    }
+  }
+  for (int j = tid; j < half_n; j += nthr) unit_root(j, nx, tw[j].re, tw[j].im);
+  if (g_prefetched) {
+#pragma unroll
+    for (int u = 0; u < kGPrefetch; ++u) {
+      const int idx = tid + u * nthr;
+      if (idx < n_el) tile[idx] = tpre[u];
+    }
+  } else {
+    for (int idx = tid; idx < n_el; idx += nthr) {
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+    }
   }
   // the filter values this thread will need after the forward transform: fetched now, behind the tile's own loads, instead of
   // after it (one more exposed round trip in a kernel that is one tile per CU at 64^3: a chain of latencies)
-  constexpr int kGPrefetch = 8;
   T gpre[kGPrefetch];
-  const bool g_prefetched = n_el <= kGPrefetch * nthr;
   if (g_prefetched) {
 #pragma unroll
     for (int u = 0; u < kGPrefetch; ++u) {
