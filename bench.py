@@ -21,7 +21,7 @@ region); ``ms_per_step_median`` is the median over the blocks.
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
-  roofline_valu -- the same launch against the VALU issue rate (pair-row instruction-lanes / peak); fp32 Coulomb rows only
+  roofline_valu -- the same launch against the VALU issue rate (pair-row instruction-lanes / peak)
   cpu_baseline -- the PyTorch-CPU oracle ("port" of the reference's ATen op sequence) timed on this host's cores
                   on a bounded sample, swept over thread counts (rank 0, N = 1 only)
   drop_in      -- the same frame through the reference's own call sequence, eager, no graph, no package-specific
@@ -262,8 +262,10 @@ class StubFrame:
 # VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes, one instruction-lane per clock at the 2.4 GHz peak engine clock (a v_pk_*
 # instruction counts once, as it issues once) -- /opt/skills/guides/MI355X_MICROARCH.md's CU model
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-# hot-loop ISA counts of the pair-row bodies: (VALU instructions per entry, of which quarter-rate)
-PAIR_BODY_VALU = {("f32", 1): (37, 3)}
+# hot-loop ISA counts of the pair-row bodies, per entry (a loop iteration handles two): (VALU instructions, of which quarter-rate),
+# counted in the disassembly of spread_rows_kernel<5, T, P, true> at the end of round 3 (llvm-objdump; loop control and masks
+# included, the fp64 body's rare y >= 6.5 branch excluded) -- round 2 quoted 37 for the arithmetic of the fp32 Coulomb body alone
+PAIR_BODY_VALU = {("f32", 1): (44.5, 3), ("f32", 6): (43.5, 2), ("f64", 1): (91, 1)}
 
 
 def valu_roofline(w, kernel: str, kernel_ms: float):
