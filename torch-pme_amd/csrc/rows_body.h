@@ -633,7 +633,10 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   if (!valid) a = unsigned(N - 1);
   const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
   const int r0 = rp[0], mid = rp[1], r2 = rp[2];
-  const int n_entries = row_ptr[int64_t(args.row_stride) * N];
+  // (uniform by construction; said so explicitly, or the buffer descriptor built from it lives in vector registers and every
+  // entry load of the loop becomes a WATERFALL loop -- readfirstlane x 4, compares, a branch: 24 of the loop's 117 instructions,
+  // which is what round 3's variable row stride had silently done to this body)
+  const int n_entries = __builtin_amdgcn_readfirstlane(row_ptr[int64_t(args.row_stride) * N]);
   f2v axy;
   float az, qa;
   if (pos) {
@@ -660,8 +663,8 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   }
   const int pot_end = args.full ? mid : 0x7fffffff;  // a full list feeds the potential from role i only
   const int beg = r0, end = valid ? r2 : r0;
-  const i4v ent_rs = raw_buffer(args.ent_sh, unsigned(n_entries) * 4u);
-  const i4v rec_rs = raw_buffer(args.rec, unsigned(N) * 16u);
+  const i4v ent_rs = uniform_rsrc(raw_buffer(args.ent_sh, unsigned(n_entries) * 4u));
+  const i4v rec_rs = uniform_rsrc(raw_buffer(args.rec, unsigned(N) * 16u));
   constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
   // entry words one iteration ahead, partner records fetched where they are used (62 VGPRs).  Fetching the records one
   // iteration ahead as well (two register sets alternating, +10 VGPRs) changed nothing measurable: 18.3 vs 18.1 us alone,
