@@ -264,8 +264,8 @@ class StubFrame:
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # hot-loop ISA counts of the pair-row bodies, per entry (a loop iteration handles two): (VALU instructions, of which quarter-rate),
 # counted in the disassembly of spread_rows_kernel<5, T, P, true> at the end of round 3 (llvm-objdump; loop control and masks
-# included, the fp64 body's rare y >= 6.5 branch excluded) -- round 2 quoted 37 for the arithmetic of the fp32 Coulomb body alone
-PAIR_BODY_VALU = {("f32", 1): (44.5, 3), ("f32", 6): (43.5, 2), ("f64", 1): (91, 1)}
+# included, the fp64 body's rare y >= 6.5 branch excluded; 44.5 and 43.5 for the fp32 bodies while their entry loads were waterfall loops)
+PAIR_BODY_VALU = {("f32", 1): (38, 3), ("f32", 6): (37, 2), ("f64", 1): (91, 1)}
 
 
 def valu_roofline(w, kernel: str, kernel_ms: float):
