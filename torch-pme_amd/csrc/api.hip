@@ -406,7 +406,7 @@ static constexpr int kMatchUnroll = 8;
 // n <= 1024 * kMatchRegs: every thread loads ALL its elements of q and g at once and keeps them in registers -- one memory
 // round trip for the whole kernel (the reference element's g and q reach the other threads through LDS, not through a second
 // trip).  The looped version below needs ~9 dependent trips to data other kernels have just written on other XCDs: 24 us at
-// 32 000 values in the kernel trace of the reference call sequence, this one 8.9 (profiles/r03_h_kernel_stats_dropin.txt).
+// 32 000 values in the kernel trace of the reference call sequence, this one 8.9 (profiles/r03_j_kernel_stats_dropin.txt).
 static constexpr int kMatchRegs = 32;
 // PARTS: block b of many does this for ITS 32 768 values and leaves {scale_b, max |q|_b, bad_b} in parts[3 b ..] for
 // scaled_match_combine_kernel (a block without a non-zero q demands g == 0 of its values and lets the others name the scale).
