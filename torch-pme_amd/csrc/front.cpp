@@ -128,16 +128,21 @@ struct FrontTopo {
   py::object lazy;
   std::mutex lazy_mutex;
   at::Tensor row_packed_, ent_sh_;
-  const at::Tensor& stream_of(at::Tensor& slot, const char* kind) {
+  std::atomic<bool> row_packed_ready_{false}, ent_sh_ready_{false};
+  // (lock order: the GIL first, then the mutex -- a thread that already holds the GIL may arrive here through a re-entrant
+  // backward pass, and must not meet one that holds the mutex and waits for the GIL)
+  const at::Tensor& stream_of(at::Tensor& slot, std::atomic<bool>& ready, const char* kind) {
+    if (ready.load(std::memory_order_acquire)) return slot;
+    py::gil_scoped_acquire gil;
     std::lock_guard<std::mutex> lock(lazy_mutex);
-    if (!slot.defined()) {
-      py::gil_scoped_acquire gil;
+    if (!ready.load(std::memory_order_relaxed)) {
       slot = lazy(kind).cast<at::Tensor>();
+      ready.store(true, std::memory_order_release);
     }
     return slot;
   }
-  const at::Tensor& row_packed() { return stream_of(row_packed_, "row_packed"); }
-  const at::Tensor& ent_sh() { return stream_of(ent_sh_, "ent_sh"); }
+  const at::Tensor& row_packed() { return stream_of(row_packed_, row_packed_ready_, "row_packed"); }
+  const at::Tensor& ent_sh() { return stream_of(ent_sh_, ent_sh_ready_, "ent_sh"); }
   ~FrontTopo() {
     if (lazy && Py_IsInitialized()) {
       py::gil_scoped_acquire gil;
