@@ -27,6 +27,8 @@ torch.cuda.synchronize()
 print({k: round(ms / calls * 1000, 1) for k, (calls, ms) in _lib.profile_report().items()})
 print({k: round(sum(a.elapsed_time(b) for a, b in v) / len(v) * 1000, 1) for k, v in ops.PROFILE.items()})
 
+_lib.profile_enable(False)
+ops.PROFILE = None
 # the same step replayed as a HIP graph (GraphedEnergyForces), without and with the cell gradient
 for with_cell in (False, True):
     g = tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos.detach(), f.pairs, f.shifts, cell_gradient=with_cell)
