@@ -13,7 +13,10 @@ from torchpme_amd import workloads  # noqa: E402
 
 dev = torch.device("cuda", 0)
 print(f"{'atoms':>9} {'pairs':>11} {'mesh':>5} {'ms/step':>9} {'atom-steps/s':>13} {'pairs/s':>10}")
-for n_side, n_mesh in ((9, 32), (14, 32), (22, 64), (35, 128), (44, 128), (56, 256), (70, 256)):
+SIZES = ((9, 32), (14, 32), (22, 64), (35, 128), (44, 128), (56, 256), (70, 256))
+if len(sys.argv) > 1:  # e.g. 22:64 56:256
+    SIZES = tuple(tuple(int(v) for v in a.split(":")) for a in sys.argv[1:])
+for n_side, n_mesh in SIZES:
     t0 = time.time()
     w = workloads.water_box(n_side=n_side, n_mesh=n_mesh)
     f = bench.Frame(w, dev)

@@ -745,6 +745,15 @@ __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int log
 // (x, kz0 .. kz0 + KZ) along y in LDS as tile[y][z] -- forward: decimation in frequency, stored back through the bit reversal;
 // inverse: loaded through the bit reversal, decimation in time, conjugate twiddles -- in place, natural order in memory both
 // ways, un-normalised.  Segments of KZ complex values (>= 64 B) keep the strided accesses coalesced.
+// Workgroups go to the 8 XCDs round robin by their linear index, and each XCD has its own L2.  The tiles of the strided stages
+// are segments of KZ complex values of rows whose pitch (nzh elements) is not a multiple of the cache line, so neighbouring
+// chunks share lines: give every XCD a CONTIGUOUS range of tiles (b -> the (b / 8)-th tile of XCD b % 8's range) and the
+// shared lines are fetched once per L2 instead of once per neighbour.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n) {
+  const unsigned x = b & 7u, per = n >> 3, rem = n & 7u;
+  return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+
 template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, int kzs, int nchunk, Cplx<T>* __restrict__ hat,
                                                    const int* __restrict__ skip) {
@@ -754,8 +763,9 @@ __global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, 
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_yc);  // even row length would put a wave's 64 accesses on the same banks
   Cplx<T>* tw = tile + size_t(ny) * KP;                 // exp(-2 pi i j / ny), j < ny / 2
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int chunk = blockIdx.x % nchunk;
-  const int64_t plane = blockIdx.x / nchunk;  // (channel, x)
+  const unsigned tile_id = xcd_tile(blockIdx.x, gridDim.x);
+  const int chunk = tile_id % nchunk;
+  const int64_t plane = tile_id / nchunk;  // (channel, x)
   const int kz0 = chunk << kzs, kzn = min(KZ, nzh - kz0);
   for (int j = tid; j < (ny >> 1); j += nthr) unit_root(j, ny, tw[j].re, tw[j].im);
   Cplx<T>* col = hat + plane * int64_t(ny) * nzh + kz0;  // element (y, z): col[y * nzh + z]
@@ -1058,7 +1068,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
   MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   xconv_tile_body<T, CELLSUMS>(nx, ny, nzh, log2nx, kzs, nchunk, hat, G, G_stride, dc, kg, kp, partials, epart, sr_part,
-                               n_sr_part, blockIdx.x, gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x);
+                               n_sr_part, xcd_tile(blockIdx.x, gridDim.x), gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x);
 }
 
 // ---- the convolution as ONE persistent launch ----------------------------------------------------------------------------
