@@ -884,9 +884,11 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
                                                 double* __restrict__ partials, double* __restrict__ epart,
                                                 const double* __restrict__ sr_part, int n_sr_part, unsigned tile_id,
                                                 unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x) {
-  const int KZ = 1 << kzs;
-  Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KZ]
-  Cplx<T>* tw = tile + size_t(nx) * KZ;                 // [nx/2]: exp(-2 pi i j / nx)
+  // rows padded by one element (as in the y-column stage): the passes give consecutive lanes consecutive groups of x, i.e. a
+  // stride of whole rows -- with KZ = 8 complex floats (64 bytes) per row that is 4 distinct bank groups for 32 lanes
+  const int KZ = 1 << kzs, KP = KZ + 1;
+  Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KP]
+  Cplx<T>* tw = tile + size_t(nx) * KP;                 // [nx/2]: exp(-2 pi i j / nx)
   const int chunk = tile_id % nchunk;
   const int ky = (tile_id / nchunk) % ny;
   const int c = tile_id / (nchunk * ny);
@@ -927,12 +929,12 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
 #pragma unroll
     for (int u = 0; u < kGPrefetch; ++u) {
       const int idx = tid + u * nthr;
-      if (idx < n_el) tile[idx] = tpre[u];
+      if (idx < n_el) tile[(idx >> kzs) * KP + (idx & (KZ - 1))] = tpre[u];
     }
   } else {
     for (int idx = tid; idx < n_el; idx += nthr) {
       const int x = idx >> kzs, z = idx & (KZ - 1);
-      tile[idx] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+      tile[x * KP + z] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
     }
   }
   // the filter values this thread will need after the forward transform: fetched now, behind the tile's own loads, instead of
@@ -952,8 +954,8 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   }
   __syncthreads();
   // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
-  //      tile[(x << kzs) + z] ----
-  lds_fft_radix2<T, false, false>(tile, log2nx, KZ, 1, KZ, tw, nx, tid, nthr);
+  //      tile[x * KP + z] ----
+  lds_fft_radix2<T, false, false>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
   if constexpr (CELLSUMS) {
     double acc[12];
@@ -964,7 +966,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       if (z < kzn) {
         const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
         const int iz = kz0 + z;
-        const Cplx<T> v = tile[idx];
+        const Cplx<T> v = tile[x * KP + z];
         const bool edge = (iz == 0) || ((kg.nz % 2 == 0) && (iz == kg.nz / 2));
         const double dLdG = (double(v.re) * double(v.re) + double(v.im) * double(v.im)) * (edge ? 1.0 : 2.0);
         KPoint p;
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       } else {
         gk = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
       }
-      Cplx<T> v = tile[idx];
+      Cplx<T> v = tile[x * KP + z];
       if (epart) {
         const int iz = kz0 + z;
         const bool edge = iz == 0 || iz == nz_full / 2;
@@ -1022,7 +1024,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       }
       v.re *= gk;
       v.im *= gk;
-      tile[idx] = v;
+      tile[x * KP + z] = v;
     }
   }
   if (epart) {  // uniform
@@ -1052,10 +1054,10 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   __syncthreads();
   // ---- inverse, decimation in time (bit-reversed in, natural out); conjugate twiddles, no normalisation
   //      (kspace_filter.py:169-187: norm="backward" forward, norm="forward" inverse) ----
-  lds_fft_radix2<T, true, true>(tile, log2nx, KZ, 1, KZ, tw, nx, tid, nthr);
+  lds_fft_radix2<T, true, true>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
-    if (active && z < kzn) col[x * xs + z] = tile[idx];
+    if (active && z < kzn) col[x * xs + z] = tile[x * KP + z];
   }
 }
 
@@ -1200,7 +1202,7 @@ static int convolve_persistent_t(mipme_fft_plan* p, hipStream_t st, const void* 
   a.x_threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
   a.n_conv = unsigned(p->nx);
   a.n_tiles = unsigned(a.nchunk) * unsigned(p->ny);
-  a.x_group_lds = (cs * ((size_t(p->nx) << a.kzs) + size_t(p->nx / 2)) + 15) & ~size_t(15);
+  a.x_group_lds = (cs * (size_t(p->nx) * ((size_t(1) << a.kzs) + 1) + size_t(p->nx / 2)) + 15) & ~size_t(15);
   a.mesh_in = (const T*)mesh_in; a.hat = (Cplx<T>*)hat; a.mesh_out = (T*)mesh_out; a.G = (const T*)G; a.dc = (T*)dc;
   a.epart = (double*)epart; a.sr_part = (const double*)sr_part; a.n_sr_part = int(n_sr_part);
   if (!p->conv_flags) {  // first use (not during stream capture: the callers warm up)
@@ -1251,7 +1253,7 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
   const int KZ = 1 << kzs;
   const int nchunk = (nzh + KZ - 1) / KZ;
   const unsigned grid = unsigned(nchunk) * unsigned(p->ny) * unsigned(p->batch);
-  const size_t lds = cs * ((size_t(p->nx) << kzs) + size_t(p->nx / 2));
+  const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + 1) + size_t(p->nx / 2));
   int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
   KGeom kg{};
