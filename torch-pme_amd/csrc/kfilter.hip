@@ -436,13 +436,36 @@ __device__ __forceinline__ Cplx<T> tw_at(const Cplx<T>* tw, int idx) {
   return w;
 }
 
-template <typename T, bool DIT, bool INVERSE>
+// Work item t -> (sequence b, group r of its points).  BMAP = 0: the groups of one sequence go to consecutive lanes -- right
+// for sequences that are contiguous in LDS (estride = 1: the z rows).  BMAP = 1 / 2: the SEQUENCES go to consecutive lanes
+// (1: nbatch a power of two, 2: any nbatch) -- right for column transforms (bstride = 1), where consecutive sequences are
+// consecutive addresses and the groups of one sequence sit whole rows apart, a power-of-two stride in the later passes that
+// no row padding takes off the same banks.
+#ifndef MIPME_FFT_BFAST
+#define MIPME_FFT_BFAST 1
+#endif
+template <int BMAP>
+__device__ __forceinline__ void fft_item(int t, int log_groups, int nbatch, int& b, int& r) {
+  if constexpr (BMAP == 0) {
+    b = t >> log_groups;
+    r = t & ((1 << log_groups) - 1);
+  } else if constexpr (BMAP == 1) {
+    r = t >> (31 - __clz(nbatch));
+    b = t & (nbatch - 1);
+  } else {
+    r = t / nbatch;
+    b = t - r * nbatch;
+  }
+}
+
+template <typename T, bool DIT, bool INVERSE, int BMAP = 0>
 __device__ __forceinline__ void lds_fft_single(Cplx<T>* data, int logL, int s, int nbatch, int bstride, int estride,
                                                const Cplx<T>* tw, int Ltab, int tid, int nthr) {
-  const int L = 1 << logL, half_total = nbatch << (logL - 1);
+  const int half_total = nbatch << (logL - 1);
   const int hm = 1 << (s - 1), f = Ltab >> s;
   for (int t = tid; t < half_total; t += nthr) {
-    const int b = t >> (logL - 1), r = t & ((L >> 1) - 1);
+    int b, r;
+    fft_item<BMAP>(t, logL - 1, nbatch, b, r);
     const int j = r & (hm - 1), i = ((r >> (s - 1)) << s) + j;
     Cplx<T>* p = data + b * bstride + i * estride;
     const Cplx<T> w = tw_at<T, INVERSE>(tw, j * f);
@@ -543,13 +566,12 @@ __device__ __forceinline__ void r8_dif(Cplx<T>* p, int st, Cplx<T> w8, Cplx<T> w
 #define MIPME_FFT_RADIX8 1
 #endif
 
-template <typename T, bool DIT, bool INVERSE>
+template <typename T, bool DIT, bool INVERSE, int BMAP = 0>
 __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbatch, int bstride, int estride,
                                                const Cplx<T>* tw, int Ltab, int tid = int(threadIdx.x),
                                                int nthr = int(blockDim.x)) {
-  const int L = 1 << logL;
   if (logL == 1) {
-    lds_fft_single<T, DIT, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
+    lds_fft_single<T, DIT, INVERSE, BMAP>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
     return;
   }
   const int quarter_total = nbatch << (logL - 2);
@@ -560,7 +582,7 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
   if constexpr (DIT) {
     int s = 1;  // next stage has sub-transform length 2^s
     if (odd) {
-      lds_fft_single<T, true, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
+      lds_fft_single<T, true, INVERSE, BMAP>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
       s = 2;
     }
     while (s <= logL) {
@@ -569,7 +591,8 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
         const int h = 1 << (s - 1);          // stages of length 2h then 4h
         const int f2 = Ltab >> s, f4 = Ltab >> (s + 1);
         for (int t = tid; t < quarter_total; t += nthr) {
-          const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+          int b, r;
+          fft_item<BMAP>(t, logL - 2, nbatch, b, r);
           const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 1)) + j;
           Cplx<T>* p = data + b * bstride + i * estride;
           const int st = h * estride;
@@ -588,7 +611,8 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
         const int h = 1 << (s - 1);          // stages of length 2h, 4h, 8h
         const int f2 = Ltab >> s, f4 = Ltab >> (s + 1), f8 = Ltab >> (s + 2);
         for (int t = tid; t < eighth_total; t += nthr) {
-          const int b = t >> (logL - 3), r = t & ((L >> 3) - 1);
+          int b, r;
+          fft_item<BMAP>(t, logL - 3, nbatch, b, r);
           const int j = r & (h - 1), i = ((r >> (s - 1)) << (s + 2)) + j;
           r8_dit<T, INVERSE>(data + b * bstride + i * estride, h * estride, tw_at<T, INVERSE>(tw, j * f2),
                              tw_at<T, INVERSE>(tw, j * f4), tw_at<T, INVERSE>(tw, j * f8));
@@ -606,7 +630,8 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
         const int q = 1 << (s - 3);          // stages of length 8q, 4q, 2q
         const int f8 = Ltab >> s, f4 = Ltab >> (s - 1), f2 = Ltab >> (s - 2);
         for (int t = tid; t < eighth_total; t += nthr) {
-          const int b = t >> (logL - 3), r = t & ((L >> 3) - 1);
+          int b, r;
+          fft_item<BMAP>(t, logL - 3, nbatch, b, r);
           const int j = r & (q - 1), i = ((r >> (s - 3)) << s) + j;
           r8_dif<T, INVERSE>(data + b * bstride + i * estride, q * estride, tw_at<T, INVERSE>(tw, j * f8),
                              tw_at<T, INVERSE>(tw, j * f4), tw_at<T, INVERSE>(tw, j * f2));
@@ -616,7 +641,8 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
         const int q = 1 << (s - 2);          // stages of length 4q then 2q
         const int f4 = Ltab >> s, f2 = Ltab >> (s - 1);
         for (int t = tid; t < quarter_total; t += nthr) {
-          const int b = t >> (logL - 2), r = t & ((L >> 2) - 1);
+          int b, r;
+          fft_item<BMAP>(t, logL - 2, nbatch, b, r);
           const int j = r & (q - 1), i = ((r >> (s - 2)) << s) + j;
           Cplx<T>* p = data + b * bstride + i * estride;
           const int st = q * estride;
@@ -634,7 +660,7 @@ __device__ __forceinline__ void lds_fft_radix2(Cplx<T>* data, int logL, int nbat
       }
       __syncthreads();
     }
-    if (s == 1) lds_fft_single<T, false, INVERSE>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
+    if (s == 1) lds_fft_single<T, false, INVERSE, BMAP>(data, logL, 1, nbatch, bstride, estride, tw, Ltab, tid, nthr);
   }
 }
 
@@ -681,7 +707,7 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
     }
     __syncthreads();
     // columns: DIF along y (natural in, bit-reversed out); the store undoes the bit reversal
-    if constexpr (YSTAGE) lds_fft_radix2<T, false, false>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    if constexpr (YSTAGE) lds_fft_radix2<T, false, false, MIPME_FFT_BFAST ? 2 : 0>(tile, logny, RZ, 1, RZ, tw, Ltab);
     Cplx<T>* dst = hat + plane * int64_t(ny) * RZ;
     for (int idx = tid; idx < ny * RZ; idx += nthr) {
       const int y = idx / RZ, k = idx - y * RZ;
@@ -696,7 +722,7 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
       tile[yr * RZ + k] = src[idx];
     }
     __syncthreads();
-    if constexpr (YSTAGE) lds_fft_radix2<T, true, true>(tile, logny, RZ, 1, RZ, tw, Ltab);
+    if constexpr (YSTAGE) lds_fft_radix2<T, true, true, MIPME_FFT_BFAST ? 2 : 0>(tile, logny, RZ, 1, RZ, tw, Ltab);
     // merge step (un-normalised: twice the textbook one):  C_k = (A_k + conj A_{Lz-k}) + i e^{+2 pi i k / nz} (A_k - conj A_{Lz-k})
     for (int idx = tid; idx < ny * (Lz / 2 + 1); idx += nthr) {
       const int y = idx / (Lz / 2 + 1), k = idx - y * (Lz / 2 + 1);
@@ -776,7 +802,7 @@ __global__ __launch_bounds__(256) void ycols_kernel(int ny, int nzh, int logny, 
     tile[yt * KP + z] = z < kzn ? col[int64_t(y) * nzh + z] : Cplx<T>{T(0), T(0)};
   }
   __syncthreads();
-  lds_fft_radix2<T, INVERSE, INVERSE>(tile, logny, KZ, 1, KP, tw, ny);  // forward: DIF; inverse: DIT
+  lds_fft_radix2<T, INVERSE, INVERSE, MIPME_FFT_BFAST ? 1 : 0>(tile, logny, KZ, 1, KP, tw, ny);  // forward: DIF; inverse: DIT
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int y = idx >> kzs, z = idx & (KZ - 1);
     const int ys = INVERSE ? y : int(__brev(unsigned(y)) >> (32 - logny));
@@ -877,6 +903,10 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
 // convolution kernel several side by side.  Every __syncthreads() is workgroup-wide and unconditional, so all groups of a
 // workgroup run the same number of stages (same nx); a group without a tile (`active` = false) computes on zeros and touches
 // no global memory.  tile_id / n_tiles stand for blockIdx.x / gridDim.x of the stand-alone launch.
+#ifndef MIPME_X_PAD
+#define MIPME_X_PAD 1
+#endif
+static constexpr int kXPad = MIPME_X_PAD;  // elements of padding per LDS row of the x stage
 template <typename T, bool CELLSUMS>
 __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                 Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
@@ -886,7 +916,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
                                                 unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x) {
   // rows padded by one element (as in the y-column stage): the passes give consecutive lanes consecutive groups of x, i.e. a
   // stride of whole rows -- with KZ = 8 complex floats (64 bytes) per row that is 4 distinct bank groups for 32 lanes
-  const int KZ = 1 << kzs, KP = KZ + 1;
+  const int KZ = 1 << kzs, KP = KZ + kXPad;
   Cplx<T>* tile = reinterpret_cast<Cplx<T>*>(smem_x);  // [nx][KP]
   Cplx<T>* tw = tile + size_t(nx) * KP;                 // [nx/2]: exp(-2 pi i j / nx)
   const int chunk = tile_id % nchunk;
@@ -955,7 +985,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   __syncthreads();
   // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
   //      tile[x * KP + z] ----
-  lds_fft_radix2<T, false, false>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
+  lds_fft_radix2<T, false, false, MIPME_FFT_BFAST ? 1 : 0>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
   if constexpr (CELLSUMS) {
     double acc[12];
@@ -1054,7 +1084,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   __syncthreads();
   // ---- inverse, decimation in time (bit-reversed in, natural out); conjugate twiddles, no normalisation
   //      (kspace_filter.py:169-187: norm="backward" forward, norm="forward" inverse) ----
-  lds_fft_radix2<T, true, true>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
+  lds_fft_radix2<T, true, true, MIPME_FFT_BFAST ? 1 : 0>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   for (int idx = tid; idx < n_el; idx += nthr) {
     const int x = idx >> kzs, z = idx & (KZ - 1);
     if (active && z < kzn) col[x * xs + z] = tile[x * KP + z];
@@ -1202,7 +1232,7 @@ static int convolve_persistent_t(mipme_fft_plan* p, hipStream_t st, const void* 
   a.x_threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
   a.n_conv = unsigned(p->nx);
   a.n_tiles = unsigned(a.nchunk) * unsigned(p->ny);
-  a.x_group_lds = (cs * (size_t(p->nx) * ((size_t(1) << a.kzs) + 1) + size_t(p->nx / 2)) + 15) & ~size_t(15);
+  a.x_group_lds = (cs * (size_t(p->nx) * ((size_t(1) << a.kzs) + kXPad) + size_t(p->nx / 2)) + 15) & ~size_t(15);
   a.mesh_in = (const T*)mesh_in; a.hat = (Cplx<T>*)hat; a.mesh_out = (T*)mesh_out; a.G = (const T*)G; a.dc = (T*)dc;
   a.epart = (double*)epart; a.sr_part = (const double*)sr_part; a.n_sr_part = int(n_sr_part);
   if (!p->conv_flags) {  // first use (not during stream capture: the callers warm up)
@@ -1253,7 +1283,7 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
   const int KZ = 1 << kzs;
   const int nchunk = (nzh + KZ - 1) / KZ;
   const unsigned grid = unsigned(nchunk) * unsigned(p->ny) * unsigned(p->batch);
-  const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + 1) + size_t(p->nx / 2));
+  const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + kXPad) + size_t(p->nx / 2));
   int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
   KGeom kg{};
