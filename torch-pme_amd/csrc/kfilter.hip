@@ -444,6 +444,9 @@ __device__ __forceinline__ Cplx<T> tw_at(const Cplx<T>* tw, int idx) {
 #ifndef MIPME_FFT_BFAST
 #define MIPME_FFT_BFAST 1
 #endif
+#ifndef MIPME_FFT_ZROWS
+#define MIPME_FFT_ZROWS 1  // the z rows too: their pitch (nz / 2 + 1 elements) is odd, so rows on consecutive lanes are conflict free in every pass
+#endif
 template <int BMAP>
 __device__ __forceinline__ void fft_item(int t, int log_groups, int nbatch, int& b, int& r) {
   if constexpr (BMAP == 0) {
@@ -687,7 +690,7 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
       tile[y * RZ + jr] = reinterpret_cast<const Cplx<T>*>(src)[idx];  // (a_2j, a_2j+1): the plane as ny x Lz pairs
     }
     __syncthreads();
-    lds_fft_radix2<T, true, false>(tile, loglz, ny, RZ, 1, tw, Ltab);
+    lds_fft_radix2<T, true, false, MIPME_FFT_ZROWS>(tile, loglz, ny, RZ, 1, tw, Ltab);
     // split step, pairs (k, Lz - k):  A_k = E_k + e^{-2 pi i k / nz} O_k,  E = (C_k + conj C_{Lz-k}) / 2,  O = -i (C_k - conj C_{Lz-k}) / 2
     for (int idx = tid; idx < ny * (Lz / 2 + 1); idx += nthr) {
       const int y = idx / (Lz / 2 + 1), k = idx - y * (Lz / 2 + 1);
@@ -748,7 +751,7 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
     }
     __syncthreads();
     // rows: DIF along z (natural in, bit-reversed out), read back through the bit reversal
-    lds_fft_radix2<T, false, true>(tile, loglz, ny, RZ, 1, tw, Ltab);
+    lds_fft_radix2<T, false, true, MIPME_FFT_ZROWS>(tile, loglz, ny, RZ, 1, tw, Ltab);
     T* dst = real_out + plane * int64_t(ny) * nz;
     for (int idx = tid; idx < ny * Lz; idx += nthr) {
       const int y = idx / Lz, j = idx - y * Lz;
