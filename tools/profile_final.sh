@@ -38,3 +38,12 @@ python tools/prof_dropin.py 300 > $OUT/${TAG}_prof_dropin_front.txt 2>&1
 MIPME_FRONT=0 python tools/prof_dropin.py 300 > $OUT/${TAG}_prof_dropin_python_nodes.txt 2>&1
 python tools/prof_size.py 56 256 > /dev/null 2>&1 || true
 ls -la $OUT | grep ${TAG}
+# kernel traces of the fp64 configurations and of the reference call sequence
+for cfg in cfg2 cfg4; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_$cfg -o t -- python $ROOT/bench.py --preset $cfg --steps 100 --warmup 10 --no-drop-in --no-cpu-baseline > /dev/null 2>&1)
+  python tools/rocpd_summary.py $(find $OUT/${TAG}_$cfg -name '*.db') > $OUT/${TAG}_kernel_stats_$cfg.txt
+  rm -rf $OUT/${TAG}_$cfg
+done
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_di -o t -- python $ROOT/tools/prof_dropin_kernels.py 300 > /dev/null 2>&1)
+python tools/rocpd_summary.py $(find $OUT/${TAG}_di -name '*.db') > $OUT/${TAG}_kernel_stats_dropin.txt
+rm -rf $OUT/${TAG}_di
