@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
         }
       }
     }
-    __shared__ double red[4][12];
+    __shared__ double red[8][12];
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     }
   }
   if (epart) {  // uniform
-    __shared__ double ered[16][4];  // [group][wave of the group]
+    __shared__ double ered[16][8];  // [group][wave of the group]
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
@@ -1289,6 +1289,10 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
   const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + kXPad) + size_t(p->nx / 2));
   int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  // with the cell sums every element of the tile costs ~700 double-precision instructions (eval_point<true>): at 64^3 that was
+  // four elements per thread in ONE wave per SIMD, a serial stream with nothing to overlap its latencies -- 256 threads
+  // (0.1217 -> 0.1170 ms for energy + forces + dE/dcell as a graph; 512 threads with launch bounds to match: 0.1252)
+  if (cell_partials) threads = 256;
   KGeom kg{};
   KPot kp{};
   if (cell_partials) {
