@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 300
+#define MIPME_VERSION 400
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -193,8 +193,34 @@ typedef struct mipme_kspace_forward_args {
    * device synchronisation): nan_flag (nullable) points to ONE int32 the gather kernel sets to 1 if a long-range potential it
    * writes is NaN -- device memory, or pinned host memory the caller reads without synchronising (at the next call, ...). */
   void* nan_flag;
+  /* The rest of the autograd contract of E = sum_a q_a V_a from the same launches (each nullable; they need the gather tail
+   * above, i.e. out_energy / out_grad_positions).  The reference obtains these from one backward pass through its ATen graph
+   * (tests/calculators/test_workflow.py:164-192; tuning/tuner.py:350-369 times exactly that):
+   *   out_grad_charges (N): s dE/dq_a = 2 s V_a, written by the gather (E is a symmetric bilinear form of the charges; half
+   *     lists and the rows of mipme_nl_stream -- a "full" list is only symmetric if the caller made it so, hence refused);
+   *   out_grad_cell (27 reals): s dE/dcell at fixed Cartesian positions, [0..8] the mesh part (k-grid sums of dG/dcell, the atoms'
+   *     r (x) dE/dr term, the 1/V factors), [9..17] the pair part (through d = |r_j - r_i + S cell|), [18..26] their sum (a
+   *     caller whose calculator and distances share ONE cell tensor takes the sum, others route the parts).  Needs G_deriv = mipme_kfilter_build_deriv() of the same mesh and
+   *     potential, and cell_work = float64[mipme_cell_tail_work()] of scratch.  How: the co-scheduled pair sum also forms
+   *     sum q_a q_o v'/d sh (x) u per wave, the x stage the 12 k-grid sums from the derivative table (+ pre-reduces the pair
+   *     sums), the gather sum_a r_a (x) dE/dr_a(mesh) per brick, and ONE more launch (a single workgroup) adds everything up.
+   *     Supported: 4-byte entries (shift_format 2), fp32 1/r and 1/r^6, fp64 1/r, no dist_out in the job. */
+  void* out_grad_charges;
+  void* out_grad_cell;
+  const void* G_deriv;
+  void* cell_work;
+  /* aux_seed (device scalar, nullable = grad_seed): the factor s of out_grad_charges / out_grad_cell, when it is not the one of
+   * out_grad_positions -- an MD loop seeds the positions with -1 (forces) and wants dE/dq, dE/dcell themselves */
+  const void* aux_seed;
 } mipme_kspace_forward_args_t;
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
+/* Derivative table of G(k) for out_grad_cell: 4 reals per half-grid point, shape (nx,ny,nz/2+1,4) = {alpha, beta_x, beta_y,
+ * beta_z} with dG/dk_c = alpha k_c - beta_c h_c and dG/dh_c = -beta_c k_c (k Cartesian, h_c = |a_c| / n_c; beta = 0 for PME).
+ * Computed in double precision like G; rebuild it whenever G is rebuilt (new cell values, potential or mesh). */
+int mipme_kfilter_build_deriv(void* stream, int dtype, const mipme_mesh_t* mesh, const mipme_potential_t* pot, void* G_deriv);
+/* float64 elements of cell_work for (plan, mesh, n_atoms): k-grid sums and pair sums per x-stage tile, atom sums per brick, pair
+ * sums per wavefront of the pair kernel. */
+int64_t mipme_cell_tail_work(const mipme_fft_plan* plan, const mipme_mesh_t* mesh, int64_t n_atoms);
 /* out_cell_partials (nullable, needs rho_hat == NULL; float64[mipme_cellgrad_partials_size]): the x stage of the fused
  * convolution also forms the 12 k-grid sums of the cell gradient for the energy mode (dL/dG(k) = mu(k) |rho^(k)|^2 up to
  * gE / 2V) while rho^ is in LDS -- mipme_fft_plan_kgrid_blocks(plan) partial sums that mipme_kspace_backward takes as
@@ -597,6 +623,14 @@ typedef struct {
   const void* grad_seed;    /* device scalar, nullable (= 1) */
   void* nan_flag;           /* pinned int32, nullable (see mipme_kspace_forward) */
   void* host_flags;         /* pinned int32, nullable: bit 0 list overflow (rebin), bit 1 an atom moved beyond the margin (step) */
+  /* appended in version 400 (size-checked like every field): the rest of the autograd contract, as in
+   * mipme_kspace_forward_args_t -- grad_charges (N) = 2 s V; grad_cell (27 reals: mesh part, pair part, sum) with G_deriv and
+   * cell_work = float64[mipme_cell_tail_work()]; all nullable */
+  void* grad_charges;
+  void* grad_cell;
+  const void* G_deriv;
+  void* cell_work;
+  const void* aux_seed;     /* device scalar, nullable (= grad_seed): the factor of grad_charges / grad_cell */
 } mipme_md_args_t;
 int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype);
 int64_t mipme_md_lists_ints(const mipme_mesh_t* mesh, int64_t n_atoms);

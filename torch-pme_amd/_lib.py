@@ -35,6 +35,7 @@ EXPORTS = (
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
     "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum",
+    "mipme_kfilter_build_deriv", "mipme_cell_tail_work",
 )
 
 
@@ -145,6 +146,8 @@ class KspaceForwardArgs(_VersionedArgs):
         ("sr_job", C.POINTER(SrJob)), ("out_cell_partials", C.c_void_p),
         ("out_energy", C.c_void_p), ("out_grad_positions", C.c_void_p), ("grad_seed", C.c_void_p),
         ("nan_flag", C.c_void_p),
+        ("out_grad_charges", C.c_void_p), ("out_grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
+        ("aux_seed", C.c_void_p),
     ]
 
 
@@ -192,6 +195,8 @@ class MdArgs(_VersionedArgs):
         ("atom_bins", C.c_void_p), ("live_lists", C.c_void_p), ("row_ptr", C.c_void_p), ("words", C.c_void_p),
         ("potentials", C.c_void_p), ("pair_force", C.c_void_p), ("energy", C.c_void_p), ("grad_positions", C.c_void_p),
         ("grad_seed", C.c_void_p), ("nan_flag", C.c_void_p), ("host_flags", C.c_void_p),
+        ("grad_charges", C.c_void_p), ("grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
+        ("aux_seed", C.c_void_p),
     ]
 
     def __init__(self, **fields):
@@ -220,6 +225,7 @@ def _declare(lib):
         "mipme_fft_plan_create": [ci, ci, ci, ci, ci, C.POINTER(vp)],
         "mipme_fft_plan_destroy": [vp],
         "mipme_kfilter_build": [vp, ci, MP, PP, vp],
+        "mipme_kfilter_build_deriv": [vp, ci, MP, PP, vp],
         "mipme_convolve": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_spread": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
@@ -283,6 +289,8 @@ def _declare(lib):
     lib.mipme_md_lists_ints.argtypes = [MP, i64]
     lib.mipme_nl_workspace_bytes.restype = i64
     lib.mipme_nl_workspace_bytes.argtypes = [C.POINTER(NlDesc), i64]
+    lib.mipme_cell_tail_work.restype = i64
+    lib.mipme_cell_tail_work.argtypes = [vp, MP, i64]
     lib.mipme_fft_plan_xfused.restype = ci
     lib.mipme_fft_plan_xfused.argtypes = [vp]
     lib.mipme_fft_plan_kgrid_blocks.restype = i64

@@ -37,7 +37,7 @@ int fft_forward(mipme_fft_plan*, hipStream_t, const void*, void*);
 int fft_inverse(mipme_fft_plan*, hipStream_t, void*, void*);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*, const ConvCell*);
 const void* bins_epart(const mipme_mesh_t*, int64_t, int, void*, int64_t*);
 template <typename T, typename I> int rspace_forward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, int, void*);
 template <typename T, typename I> int rspace_backward_impl(hipStream_t, int64_t, int64_t, int, const void*, const void*, const void*, const void*, int, const mipme_potential_t*, const void*, const void*, void*, void*);
@@ -54,7 +54,10 @@ bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                        const mipme_sr_job_t*, bool);
+                                        const mipme_sr_job_t*, bool, double*);
+template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template <typename T> int cell_tail_finalize_impl(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
+                                                  const void*, const void*, const void*, const void*, const void*, void*);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
@@ -119,13 +122,36 @@ static int check_plan(const mipme_fft_plan* plan, int dtype, const mipme_mesh_t*
   return MIPME_OK;
 }
 
+// cell_work of an energy step's cell gradient (mipme_cell_tail_work): [kpart 12 t][ctile 9 t][rpart 9 b][cwave 9 w]
+struct CellWork {
+  int64_t n_tiles, n_bricks, n_waves;
+  double *kpart, *ctile, *rpart, *cwave;
+  int64_t total;
+};
+static CellWork cell_work_layout(const mipme_fft_plan* plan, const mipme_mesh_t* m, int64_t N, void* base) {
+  CellWork w;
+  w.n_tiles = xconv_blocks(plan);
+  w.n_bricks = int64_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8);
+  w.n_waves = (N + 3) / 4;  // 16 lanes per row: 4 rows per wavefront (rows_body.h)
+  double* b = (double*)base;
+  w.kpart = b;
+  w.ctile = w.kpart + 12 * w.n_tiles;
+  w.rpart = w.ctile + 9 * w.n_tiles;
+  w.cwave = w.rpart + 9 * w.n_bricks;
+  w.total = 21 * w.n_tiles + 9 * w.n_bricks + 9 * w.n_waves;
+  return w;
+}
+
 template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
                             void* wait_event, int accumulate, void* out_field, void* out_records,
-                            const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail, void* nan_flag) {
+                            const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail, void* nan_flag,
+                            void* out_grad_cell = nullptr, const void* G_deriv = nullptr, void* cell_work = nullptr) {
   int rc;
+  CellWork cw{};
+  if (out_grad_cell) cw = cell_work_layout(plan, m, N, cell_work);
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
@@ -151,7 +177,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
       const int reps = (g_prof_on && co) ? kProfRepeat : 1;
       ProfScope _ps(st, co ? "spread+rspace_forward" : "spread", reps);
       for (int r = 0; r < reps; ++r)
-        if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr))) return rc;
+        if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr,
+                                   out_grad_cell ? cw.cwave : nullptr))) return rc;
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",
@@ -166,9 +193,12 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
     int64_t n_sr_part = 0;
     const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
+    ConvCell cc{G_deriv, nullptr, nullptr, 1};
+    if (out_grad_cell) cc = ConvCell{G_deriv, cw.cwave, cw.ctile, 0};
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot,
+                                                 out_grad_cell ? (void*)cw.kpart : cell_partials,
                                                  tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part,
-                                                 nullptr, nan_flag));
+                                                 nullptr, nan_flag, (G_deriv || out_grad_cell) ? &cc : nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -184,6 +214,10 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     STAGE(st, "gather", gather_epilogue_impl<T>(st, m, N, pos, phi_mesh, q, dc, self_c, bg_c, out_lr, out_phi, accumulate, nan_flag));
   guard.armed = N == 0 && bins;  // the gather has zeroed the counters (it does not run without atoms: nothing was counted either)
   guard.armed = false;
+  if (out_grad_cell)
+    STAGE(st, "cell_finalize",
+          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5 * tail->force_scale, cw.n_tiles, cw.n_bricks, cw.kpart, cw.ctile,
+                                     tail->epart_k, cw.rpart, dc, tail->aux_seed ? tail->aux_seed : tail->seed, out_grad_cell));
   return MIPME_OK;
 }
 
@@ -228,13 +262,13 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   }
   // psi = spread(g / 2V); chi = F psi
   if (bins)
-    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr, nullptr, false));
+    STAGE(st, "spread", spread_bricks<T>(st, m, N, bins, gout, 0.5 / m->volume, psi_mesh, nullptr, nullptr, false, nullptr));
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, psi_mesh, psi_hat));
   }
@@ -713,7 +747,7 @@ namespace mipme {
 bool live_supported(const mipme_mesh_t*, int64_t, int);
 int64_t live_lists_ints(const mipme_mesh_t*, int64_t);
 template <typename T> int live_rebin(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
-template <typename T> int live_spread(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*, void*);
+template <typename T> int live_spread(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*, void*, double*);
 template <typename T> int live_gather(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
                                       double, double, void*, void*, const GatherTailHost*, void*);
 }  // namespace mipme
@@ -764,14 +798,28 @@ static int md_step_t(const mipme_md_args_t& a) {
   tail.sr_reduced = 1;
   MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream capture: run "
                               "one evaluation before capturing)");
-  STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job, a.host_flags));
+  CellWork cw{};
+  if (a.grad_cell) {
+    cw = cell_work_layout(a.plan, m, a.n_atoms, a.cell_work);
+    tail.rpart = cw.rpart;
+  }
+  tail.grad_q = a.grad_charges;
+  tail.aux_seed = a.aux_seed;
+  STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job, a.host_flags,
+                                                     a.grad_cell ? cw.cwave : nullptr));
   int64_t n_sr_part = 0;
   const void* sr_part = bins_epart(m, a.n_atoms, a.dtype, a.atom_bins, &n_sr_part);
-  STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot, nullptr,
-                                               const_cast<void*>(tail.epart_k), sr_part, n_sr_part, nullptr, a.nan_flag));
+  ConvCell cc{a.G_deriv, cw.cwave, cw.ctile, 0};
+  STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot,
+                                               a.grad_cell ? (void*)cw.kpart : nullptr, const_cast<void*>(tail.epart_k), sr_part,
+                                               n_sr_part, nullptr, a.nan_flag, a.grad_cell ? &cc : nullptr));
   STAGE(st, "gather+energy+forces",
         live_gather<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.phi_mesh, a.dc, self_c, bg_c, a.potentials, nullptr,
                        &tail, a.nan_flag));
+  if (a.grad_cell)
+    STAGE(st, "cell_finalize",
+          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5, cw.n_tiles, cw.n_bricks, cw.kpart, cw.ctile, tail.epart_k, cw.rpart, a.dc,
+                                     a.aux_seed ? a.aux_seed : a.grad_seed, a.grad_cell));
   return MIPME_OK;
 }
 
@@ -803,6 +851,19 @@ int mipme_kfilter_build(void* stream, int dtype, const mipme_mesh_t* mesh, const
   MIPME_REQUIRE(G != nullptr, "G is NULL");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype, kfilter_build_impl<float>(st, mesh, pot, G), kfilter_build_impl<double>(st, mesh, pot, G));
+}
+
+int mipme_kfilter_build_deriv(void* stream, int dtype, const mipme_mesh_t* mesh, const mipme_potential_t* pot, void* G_deriv) {
+  int rc = validate_mesh(mesh);
+  if (rc) return rc;
+  MIPME_REQUIRE(G_deriv != nullptr, "G_deriv is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, kfilter_deriv_impl<float>(st, mesh, pot, G_deriv), kfilter_deriv_impl<double>(st, mesh, pot, G_deriv));
+}
+
+int64_t mipme_cell_tail_work(const mipme_fft_plan* plan, const mipme_mesh_t* mesh, int64_t n_atoms) {
+  if (!plan || !mesh || validate_mesh(mesh) || n_atoms < 0) return 0;
+  return cell_work_layout(plan, mesh, n_atoms, nullptr).total;
 }
 
 int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, const void* G, void* hat_out, void* hat_work,
@@ -883,14 +944,32 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
                                 "capture: run one evaluation before capturing)");
     tp = &tail;
   }
+  if (a.out_grad_charges || a.out_grad_cell) {
+    MIPME_REQUIRE(tp, "out_grad_charges / out_grad_cell ride on the gather tail (out_energy, out_grad_positions)");
+    MIPME_REQUIRE(!a.out_grad_charges || !a.sr_job->full_list || (a.sr_job->shift_format & MIPME_ROWS_PADDED),
+                  "out_grad_charges = 2 s V needs a half list (a full list need not be symmetric)");
+    tail.grad_q = a.out_grad_charges;
+    tail.aux_seed = a.aux_seed;
+    if (a.out_grad_cell) {
+      const int p = a.pot->kind == MIPME_COULOMB ? 1 : a.pot->exponent;
+      MIPME_REQUIRE(a.G_deriv && a.cell_work, "out_grad_cell needs G_deriv (mipme_kfilter_build_deriv) and cell_work");
+      MIPME_REQUIRE((a.sr_job->shift_format & 0xff) == 2 && !a.sr_job->dist_out && (p == 1 || a.dtype == MIPME_F32),
+                    "out_grad_cell needs 4-byte entries (shift_format 2), no dist_out, and 1/r (or fp32 1/r^6)");
+      MIPME_REQUIRE(!a.out_cell_partials, "out_grad_cell replaces out_cell_partials");
+      tail.rpart = cell_work_layout(a.plan, mesh, a.n_atoms, a.cell_work).rpart;
+      tail.records = a.out_records;
+    }
+  }
   hipStream_t st = (hipStream_t)a.stream;
   DT_SWITCH(a.dtype,
             kspace_forward_t<float>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                     a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
-                                    a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag),
+                                    a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
+                                    a.out_grad_cell, a.G_deriv, a.cell_work),
             kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                      a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
-                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag));
+                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
+                                     a.out_grad_cell, a.G_deriv, a.cell_work));
 }
 
 int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype) {
@@ -925,6 +1004,11 @@ int mipme_md_step(const mipme_md_args_t* args_in) {
   MIPME_REQUIRE(a.cell && a.G && a.rho_mesh && a.hat_work && a.phi_mesh && a.dc && a.row_ptr && a.words && a.potentials &&
                     a.pair_force && a.energy && a.grad_positions, "NULL buffer passed to mipme_md_step");
   MIPME_REQUIRE((a.shift_format & 0xff) == 2, "mipme_md_step reads 4-byte entries (shift_format 2, with or without MIPME_ROWS_PADDED)");
+  if (a.grad_cell) {
+    const int p = a.pot->kind == MIPME_COULOMB ? 1 : a.pot->exponent;
+    MIPME_REQUIRE(a.G_deriv && a.cell_work, "grad_cell needs G_deriv (mipme_kfilter_build_deriv) and cell_work");
+    MIPME_REQUIRE(p == 1 || a.dtype == MIPME_F32, "grad_cell: the fp64 pair kernel forms the cell sums for 1/r only");
+  }
   DT_SWITCH(a.dtype, md_step_t<float>(a), md_step_t<double>(a));
 }
 

@@ -789,7 +789,9 @@ __device__ long long g_wg_phase[8 * 1024];
 // Register budget of the co-scheduled kernel: 6 waves per SIMD = 3 workgroups per CU (what its LDS allows too) needs <= 80
 // VGPRs -- the allocation granule turns 82 into 88 = 2 workgroups per CU, measured 10 % slower at cfg5; asked for 6 waves the
 // compiler fits the fp32 / 4-byte-entry kernels into 68-73 without spilling.  Other instantiations are left alone.
-template <int N, typename T, int PFAST, bool COMPACT>
+// CELL: the row workgroups also form the per-wave cell-gradient sums of the energy step (FusedRowsArgs::cpart; packed fp32 body
+// and fp64 Coulomb body only: rows_cell_supported below)
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                               unsigned n_spread) {
   MIPME_WG_STAMP(0);
@@ -807,20 +809,22 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
       bool done = false;
       if constexpr (COMPACT && std::is_same<T, float>::value) {
-        if (!ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-          sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, r, tab);
+        if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
+          sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
           done = true;
         }
       }
 #if MIPME_ROW_LANES == 16
       if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
-        if (!ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
-          sr_rows_f64_body<SPREAD_THREADS>(ra, r, smem_rows);
+        if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
+          sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
           done = true;
         }
       }
 #endif
-      if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
+      if constexpr (!CELL) {
+        if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
+      }
     }
   }
 #ifdef MIPME_WG_TIMELINE
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
 
 // The pair sum alone (sparse-brick path: the bricks ran in a launch of their own): 256-thread workgroups with nothing but the
 // shift table in LDS and no register bound, i.e. full occupancy -- the same bodies, the same per-wave energy partial sums.
-template <typename T, int PFAST, bool COMPACT>
+template <typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int xcd) {
   constexpr bool F64_BODY = COMPACT && std::is_same<T, double>::value && PFAST == 1 && kRowLanes == 16;
   __shared__ __attribute__((aligned(16))) char tab_raw[F64_BODY ? kRowsF64LdsBytes : sizeof(AtomRecord<T>) * kShiftTableSize];
@@ -841,20 +845,27 @@ __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int
   const unsigned r = xcd ? xcd_contiguous(blockIdx.x, n_row_blocks) : blockIdx.x;
   if (r >= n_row_blocks) return;
   if constexpr (COMPACT && std::is_same<T, float>::value) {
-    if (!ra.dist_out) {
-      sr_rows_pk_body<PFAST, BS>(ra, r, tab);
+    if (CELL || !ra.dist_out) {
+      sr_rows_pk_body<PFAST, BS, CELL>(ra, r, tab);
       return;
     }
   }
 #if MIPME_ROW_LANES == 16
   if constexpr (F64_BODY) {
-    if (!ra.dist_out) {
-      sr_rows_f64_body<BS>(ra, r, tab_raw);
+    if (CELL || !ra.dist_out) {
+      sr_rows_f64_body<BS, CELL>(ra, r, tab_raw);
       return;
     }
   }
 #endif
-  sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, BS, 0, COMPACT>(ra, r, tab);
+  if constexpr (!CELL) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, BS, 0, COMPACT>(ra, r, tab);
+}
+
+// the pair bodies that can form the cell sums: 4-byte entries, fp32 (1/r, 1/r^6) or fp64 Coulomb, no distance by-product
+template <typename T>
+static inline bool rows_cell_supported(int pfast, int shift_format, const void* dist_out) {
+  if ((shift_format & kShiftFormatMask) != kShiftTable32 || dist_out || kRowLanes != 16) return false;
+  return sizeof(T) == 4 ? (pfast == 1 || pfast == 6) : pfast == 1;
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -924,7 +935,35 @@ struct GatherTail {
   const double* epart_sr;  // [2 * n_sr]
   const double* epart_k;   // [n_k]
   int n_sr, n_k;
+  // the rest of the autograd contract of E = sum q V (nullable): s dE/dq_a = 2 s V_a (V is a symmetric bilinear form of the
+  // charges), and per brick the nine sums  R[c][e] = sum_a r_{a,c} (s q_a field_{a,e})  of the cell gradient's atom part
+  T* grad_q;
+  double* rpart;               // [9 * bricks]
+  const AtomRecord<T>* rec4;   // (x, y, z, q) per atom: positions for rpart
+  const T* aux_seed;           // factor of grad_q and rpart (nullable: the seed of the positions)
 };
+
+// R sums of a workgroup -> rpart[9 * block ...].  r3: lanes 0..2 of every 8-lane atom group hold r_c * gp_l for c = 0..2 (l = the
+// lane's Cartesian component of the gradient), zero elsewhere.  Uniform call (barrier inside).
+template <int THREADS>
+__device__ __forceinline__ void tail_rpart(double (&r3)[3], double* __restrict__ rpart, unsigned block) {
+  __shared__ double rred[THREADS / 64][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double v = r3[c];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 3) rred[wave][3 * c + lane] = v;  // lane = e
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    double v = 0.0;
+    for (int w = 0; w < THREADS / 64; ++w) v += rred[w][threadIdx.x];
+    rpart[9 * int64_t(block) + threadIdx.x] = v;
+  }
+}
 
 template <typename T, int THREADS>
 __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* __restrict__ qsum, T inv_vol, T self_c,
@@ -978,12 +1017,19 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
     bins.live[block] = 0;
     if (block == 0) bins.live[bins.nb] = 0;
   }
-  T seed = T(1);
+  T seed = T(1), seed_aux = T(1);
   if constexpr (TAIL) {
     if (tail->seed) seed = tail->seed[0];
+    seed_aux = tail->aux_seed ? tail->aux_seed[0] : seed;
     if (block == 0) tail_energy<T, THREADS>(*tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
   }
-  if (beg == end && n_over == 0) return;
+  double r3[3] = {0.0, 0.0, 0.0};
+  if (beg == end && n_over == 0) {
+    if constexpr (TAIL) {
+      if (tail->rpart && threadIdx.x < 9) tail->rpart[9 * int64_t(block) + threadIdx.x] = 0.0;
+    }
+    return;
+  }
   const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
   const int64_t M = int64_t(g.nx) * g.ny * g.nz;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
@@ -1035,7 +1081,11 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
         if (accumulate) out_early = out[o_early];
       }
       T f_early = T(0);  // TAIL: lanes 0..2 hold the x, y, z components of the atom's pair force sum
-      if constexpr (TAIL) f_early = tail->force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
+      AtomRecord<T> r_early{T(0), T(0), T(0), T(0)};
+      if constexpr (TAIL) {
+        f_early = tail->force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
+        if (tail->rpart) r_early = tail->rec4[a.w];
+      }
       if (it == 0) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
       const int rx = a.x - ox, ry = a.y - oy, rz = a.z - oz;
       const T* tp = tile + ry * TL + (rz + tz);
@@ -1068,6 +1118,12 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
             const int64_t o = int64_t(a.w);
             field[3 * o + l] = fc;
             tail->grad_pos[3 * o + l] = seed * q_early * (tail->force_scale * f_early + fc);
+            if (tail->rpart) {
+              const double gp = double(seed_aux * q_early * fc);
+              r3[0] += double(r_early.x) * gp;
+              r3[1] += double(r_early.y) * gp;
+              r3[2] += double(r_early.z) * gp;
+            }
           }
         } else if (l == 0 && valid) {
           const int64_t o = int64_t(a.w);
@@ -1084,6 +1140,9 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
           const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[c]);
           const T v_final = accumulate ? out_early + lr : lr;
           out[o] = v_final;
+          if constexpr (TAIL) {
+            if (tail->grad_q) tail->grad_q[o] = T(2) * seed_aux * v_final;
+          }
           if (nan_flag && lr != lr) *nan_flag = 1;  // NaN guard of kspace_filter.py:189-195 (see mipme.h, nan_flag)
           if (raw) raw[o] = phi;
         } else {
@@ -1091,6 +1150,9 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
         }
       }
     }
+  }
+  if constexpr (TAIL) {
+    if (tail->rpart) tail_rpart<THREADS>(r3, tail->rpart, block);  // uniform
   }
 }
 
@@ -1338,7 +1400,7 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
 
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
-                  int* clear_count, const mipme_sr_job_t* job, bool want_epart) {
+                  int* clear_count, const mipme_sr_job_t* job, bool want_epart, double* cpart) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
@@ -1377,6 +1439,9 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     static_assert(kRowsPerSpreadBlock == SPREAD_THREADS / kRowLanes, "epart layout");
     FusedRowsArgs<T> ra_e = ra;
     ra_e.epart = want_epart ? v.epart : nullptr;
+    ra_e.cpart = cpart;
+    MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
+                  "the cell sums of the pair kernel need 4-byte entries, 1/r (or fp32 1/r^6) and no distance by-product");
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned n_spread = unsigned(bg.nb);
@@ -1388,7 +1453,11 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       const unsigned nrb = unsigned((job->n_atoms + 256 / kRowLanes - 1) / (256 / kRowLanes));
       const unsigned rgrid = bg.xcd ? pad8(nrb) : nrb;
       const bool compact_r = (job->shift_format & kShiftFormatMask) == kShiftTable32;
-      if (pfast == 1 && compact_r)
+      if (cpart && pfast == 1)
+        rows_only_kernel<T, 1, true, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      else if (cpart) {
+        if constexpr (sizeof(T) == 4) rows_only_kernel<T, 6, true, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+      } else if (pfast == 1 && compact_r)
         rows_only_kernel<T, 1, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
       else if (pfast == 1)
         rows_only_kernel<T, 1, false><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
@@ -1401,7 +1470,14 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     }
     const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_rows_blocks) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
-    if (pfast == 1 && compact)
+    if (cpart && pfast == 1)
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                               ((void)S, spread_rows_kernel<N, T, 1, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+    else if (cpart) {
+      if constexpr (sizeof(T) == 4)
+        MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                                 ((void)S, spread_rows_kernel<N, T, 6, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+    } else if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
     else if (pfast == 1)
@@ -1467,6 +1543,11 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       tail.epart_sr = tail.epart_k + tail.n_k;
       tail.n_sr = tail.n_k;
     }
+    tail.grad_q = (T*)th->grad_q;
+    tail.rpart = th->rpart;
+    tail.rec4 = (const AtomRecord<T>*)th->records;
+    tail.aux_seed = (const T*)th->aux_seed;
+    MIPME_REQUIRE(!tail.rpart || tail.rec4, "the cell sums of the gather need the atom records");
     if (sparse_bricks(N, bg.nb))
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, gather_tail_kernel<N, T, GATHER_THREADS_SPARSE><<<brick_grid(bg), GATHER_THREADS_SPARSE, 0, st>>>(
@@ -1736,6 +1817,10 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.tail.n_sr = int((f.n_atoms + 64 / kRowLanes - 1) / (64 / kRowLanes));
     d.tail.epart_k = nullptr;  // per batch entry: set by frames_forward (plan scratch)
     d.tail.n_k = 0;
+    d.tail.grad_q = nullptr;   // (the frames path forms energy + forces only)
+    d.tail.rpart = nullptr;
+    d.tail.rec4 = nullptr;
+    d.tail.aux_seed = nullptr;
     d.use_tail = f.use_tail != 0;
     d.rows.epart = f.use_tail ? v.epart : nullptr;
     out[k] = d;
@@ -1744,7 +1829,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
 }
 
 int convolve_xfused(mipme_fft_plan*, hipStream_t, const void*, const void*, void*, void*, void*, int64_t, const mipme_mesh_t*,
-                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*);
+                    const mipme_potential_t*, void*, void*, const void*, int64_t, const RowRideHost*, void*, const ConvCell*);
 int64_t xconv_blocks(const mipme_fft_plan*);
 void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 bool fft_plan_xfused(const mipme_fft_plan*);
@@ -1787,7 +1872,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   double* epart_k = all_tail ? (double*)fft_plan_tail_scratch(plan, int64_t(sizeof(double)) * n_k * n_frames) : nullptr;
   MIPME_REQUIRE(!all_tail || epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
                                       "capture: run one evaluation before capturing)");
-  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k, nullptr, 0, nullptr, nullptr);
+  int rc = convolve_xfused(plan, st, rho_all, G, hat_all, phi_all, dc_all, G_stride, nullptr, nullptr, nullptr, epart_k, nullptr, 0, nullptr, nullptr, nullptr);
   if (rc) return rc;
   if (all_tail) {  // energy + forces of every frame in the gather launch
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
@@ -2159,7 +2244,7 @@ __host__ __device__ inline unsigned live_home_blocks(int64_t n_atoms, bool xcd) 
   const unsigned n = unsigned((n_atoms + SPREAD_THREADS - 1) / SPREAD_THREADS);
   return xcd ? (n + 7u) / 8u * 8u : n;  // a multiple of 8 keeps blockIdx % 8 (the XCD) of everything behind them
 }
-template <int N, typename T, int PFAST>
+template <int N, typename T, int PFAST, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                         unsigned n_spread) {
   const unsigned n_home = live_home_blocks(sa.n_atoms, sa.bg.xcd), n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
@@ -2175,12 +2260,12 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_s
       extern __shared__ __attribute__((aligned(16))) char smem_rows[];
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
       if constexpr (std::is_same<T, float>::value)
-        sr_rows_pk_body<PFAST, SPREAD_THREADS>(ra, r, tab);
+        sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
 #if MIPME_ROW_LANES == 16
       else if constexpr (PFAST == 1)
-        sr_rows_f64_body<SPREAD_THREADS>(ra, r, smem_rows);
+        sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
 #endif
-      else
+      else if constexpr (!CELL)
         sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, true>(ra, r, tab);
     }
   }
@@ -2214,8 +2299,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
   const int n_over = bins.snap[bins.nb];
   T seed = T(1);
   if (tail.seed) seed = tail.seed[0];
+  const T seed_aux = tail.aux_seed ? tail.aux_seed[0] : seed;
   if (block == 0) tail_energy<T, THREADS>(tail, qsum, inv_vol, self_c, bg_c);  // uniform per workgroup
-  if (beg == end && n_over == 0) return;
+  double r3[3] = {0.0, 0.0, 0.0};
+  if (beg == end && n_over == 0) {
+    if (tail.rpart && threadIdx.x < 9) tail.rpart[9 * int64_t(block) + threadIdx.x] = 0.0;
+    return;
+  }
   const int main_iters = (end - beg + GROUPS - 1) / GROUPS, over_iters = (n_over + GROUPS - 1) / GROUPS;
   const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
   const bool lane_active = l < N;
@@ -2256,7 +2346,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
       }
       staged = true;
     }
-    const T q_early = rec4[a.w].w;
+    const AtomRecord<T> r_early = rec4[a.w];
+    const T q_early = r_early.w;
     const T out_early = out[a.w];
     const T f_early = tail.force[3 * int64_t(a.w) + (l < 3 ? l : 0)];
     if (it == 0) __syncthreads();  // tile staged (uniform: every thread runs the first pass)
@@ -2296,15 +2387,23 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
       const int64_t o = int64_t(a.w);
       if (field) field[3 * o + l] = fc;
       tail.grad_pos[3 * o + l] = seed * q_early * (tail.force_scale * f_early + fc);
+      if (tail.rpart) {
+        const double gp = double(seed_aux * q_early * fc);
+        r3[0] += double(r_early.x) * gp;
+        r3[1] += double(r_early.y) * gp;
+        r3[2] += double(r_early.z) * gp;
+      }
     }
     const T acc = group_sum_b<LANES, T>(sA * wzv);
     if (l == 0 && valid) {
       const T phi = acc * inv_vol;
       const T lr = T(0.5) * (phi - self_c * q_early - T(2) * bg_c * inv_vol * qsum[0]);
       out[a.w] = out_early + lr;
+      if (tail.grad_q) tail.grad_q[a.w] = T(2) * seed_aux * (out_early + lr);
       if (nan_flag && lr != lr) *nan_flag = 1;
     }
   }
+  if (tail.rpart) tail_rpart<THREADS>(r3, tail.rpart, block);  // uniform
 #ifdef MIPME_WG_TIMELINE
   __syncthreads();
 #endif
@@ -2356,7 +2455,7 @@ int live_rebin(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec
 
 template <typename T>
 int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* rec4, void* bins, void* lists, void* mesh,
-                const mipme_sr_job_t* job, void* host_flags) {
+                const mipme_sr_job_t* job, void* host_flags, double* cpart) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
@@ -2390,10 +2489,18 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
                                                 job->full_list ? 0 : 1, job->full_list, 0, job->out, job->force, nullptr, nullptr,
                                                 job->shift_format);
   ra.epart = v.epart;
+  ra.cpart = cpart;
+  MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
+                "the cell sums of the pair kernel need 4-byte entries and 1/r (or fp32 1/r^6)");
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
   const unsigned grid = live_home_blocks(N, bg.xcd) + (bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks);
-  if (pfast == 1)
+  if (cpart && pfast == 1)
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+  else if (cpart) {
+    if constexpr (sizeof(T) == 4)
+      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+  } else if (pfast == 1)
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   else
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
@@ -2420,6 +2527,10 @@ int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   tail.n_k = int(th->n_k);
   tail.epart_sr = tail.epart_k + tail.n_k;  // pre-reduced by the x stage of the convolution
   tail.n_sr = tail.n_k;
+  tail.grad_q = (T*)th->grad_q;
+  tail.rpart = th->rpart;
+  tail.rec4 = (const AtomRecord<T>*)rec4;
+  tail.aux_seed = (const T*)th->aux_seed;
   MIPME_DISPATCH_ORDER(m->order, (live_gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                      g, bg, v.idx, ll.rec_now, (const T*)v.wts, (const AtomRecord<T>*)rec4, (const T*)mesh,
                                      (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail,
@@ -2431,9 +2542,9 @@ int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
 template int live_rebin<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
 template int live_rebin<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*);
 template int live_spread<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*,
-                                void*);
+                                void*, double*);
 template int live_spread<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, void*, const mipme_sr_job_t*,
-                                 void*);
+                                 void*, double*);
 template int live_gather<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
                                 double, double, void*, void*, const GatherTailHost*, void*);
 template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
@@ -2442,9 +2553,9 @@ template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, cons
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                  const mipme_sr_job_t*, bool);
+                                  const mipme_sr_job_t*, bool, double*);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                   const mipme_sr_job_t*, bool);
+                                   const mipme_sr_job_t*, bool, double*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                   double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,

@@ -226,6 +226,19 @@ struct GatherTailHost {
   // rows that ride on the convolution launch finish after its x stage: their per-wave partial sums (waves sr2_first ..
   // sr2_first + sr2_count of the bins buffer's epart array) are added up by the gather itself
   int64_t sr2_first, sr2_count;
+  // the rest of the autograd contract of E = sum q V from the same launch (all nullable; see mipme_kspace_forward_args_t)
+  void* grad_q;        // (N): seed * dE/dq = 2 seed V
+  double* rpart;       // fp64[9 * bricks]: per-brick sums r_a (x) (seed q_a field_a) for the cell gradient
+  const void* records; // (N,4) reals x, y, z, q: the atoms' positions for rpart
+  const void* aux_seed; // device scalar, nullable (= seed): the factor of grad_q and of the cell gradient
+};
+
+// What the x stage of the fused convolution adds for the cell gradient of an energy step (kfilter.hip, convolve_xfused)
+struct ConvCell {
+  const void* G_deriv;    // kfilter_deriv_kernel table: with it the k-grid sums come from the table, else evaluated in place
+  const double* cpart_in; // per-wave cell partial sums of the co-scheduled pair kernel (9 per wave), nullable
+  double* cpart_out;      // their per-tile pre-reduction (9 per tile)
+  int legacy_ticket;      // the partials are read by cellgrad_finalize_kernel: clear its ticket counter behind them
 };
 
 // Row workgroups of the co-scheduled pair sum that ride on the persistent convolution launch instead of the spread launch:

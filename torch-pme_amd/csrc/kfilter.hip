@@ -48,6 +48,8 @@ struct KPoint {
   double k[3];
   int f[3];
   double G, dGdk[3], dGdh[3];
+  // dG/dk_c = alpha k_c - beta_c h_c,  dG/dh_c = -beta_c k_c: the four values per k-point the derivative table keeps
+  double alpha, beta[3];
 };
 
 template <bool DERIV>
@@ -66,10 +68,12 @@ __device__ inline void eval_point(const KGeom& g, const KPot& kp, int ix, int iy
   if (g.scheme == MIPME_LAGRANGE) {
     o.G = v;
     if constexpr (DERIV) {
+      o.alpha = 2.0 * dv;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         o.dGdk[c] = 2.0 * o.k[c] * dv;
         o.dGdh[c] = 0.0;
+        o.beta[c] = 0.0;
       }
     }
     return;
@@ -94,14 +98,16 @@ __device__ inline void eval_point(const KGeom& g, const KPot& kp, int ix, int iy
   if (U2 == 0.0) {
     o.G = 0.0;
     if constexpr (DERIV) {
+      o.alpha = 0.0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o.dGdk[c] = o.dGdh[c] = 0.0;
+      for (int c = 0; c < 3; ++c) o.dGdk[c] = o.dGdh[c] = o.beta[c] = 0.0;
     }
     return;
   }
   const double inv = 1.0 / U2;
   o.G = v * inv;
   if constexpr (DERIV) {
+    o.alpha = 2.0 * dv * inv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tc = t[c];
@@ -110,6 +116,7 @@ __device__ inline void eval_point(const KGeom& g, const KPot& kp, int ix, int iy
       const double w = o.G * double(2 * g.order) * L;
       o.dGdk[c] = 2.0 * o.k[c] * dv * inv - w * 0.5 * g.h[c];
       o.dGdh[c] = -w * 0.5 * o.k[c];
+      o.beta[c] = 0.5 * w;
     }
   }
 }
@@ -126,6 +133,29 @@ __global__ __launch_bounds__(256) void kfilter_kernel(KGeom g, KPot kp, T* __res
   KPoint o;
   eval_point<false>(g, kp, ix, iy, iz, o);
   G[t] = T(o.G);
+}
+
+// Derivative table of the filter, 4 reals per half-grid point {alpha, beta_x, beta_y, beta_z}:
+//   dG/dk_c = alpha k_c - beta_c h_c,   dG/dh_c = -beta_c k_c     (k Cartesian, h_c = |a_c| / n_c; beta = 0 for PME)
+// with alpha = 2 v_LR^'(k^2) / U^2 and beta_c = G n (cot t_c - 1/t_c), t_c = k_c h_c / 2.  Built once per (cell, potential) like
+// G itself; the x stage of the fused convolution forms the k-grid sums of the cell gradient from it with a dozen FMAs per
+// k-point instead of evaluating the influence function's derivatives in double precision for every k-point of every step
+// (~700 instructions each: 7.8 -> 15 us at 64^3).
+template <typename T>
+__global__ __launch_bounds__(256) void kfilter_deriv_kernel(KGeom g, KPot kp, T* __restrict__ D) {
+  const int64_t Mh = int64_t(g.nx) * g.ny * g.nzh;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= Mh) return;
+  const int iz = int(t % g.nzh);
+  const int64_t r = t / g.nzh;
+  const int iy = int(r % g.ny);
+  const int ix = int(r / g.ny);
+  KPoint o;
+  eval_point<true>(g, kp, ix, iy, iz, o);
+  D[4 * t + 0] = T(o.alpha);
+  D[4 * t + 1] = T(o.beta[0]);
+  D[4 * t + 2] = T(o.beta[1]);
+  D[4 * t + 3] = T(o.beta[2]);
 }
 
 // hat_work = hat * G ; dc[c] = Re hat[c, 0]
@@ -910,13 +940,24 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
 #define MIPME_X_PAD 1
 #endif
 static constexpr int kXPad = MIPME_X_PAD;  // elements of padding per LDS row of the x stage
-template <typename T, bool CELLSUMS>
+// CELLSUMS: 0 = none; 1 = the 12 k-grid sums of the cell gradient with the filter's derivatives evaluated in place (double
+// precision, eval_point<true>); 2 = the same sums from the derivative table `dG4` (kfilter_deriv_kernel), in the working precision
+// per thread and in double across threads.  cpart_in / cpart_out (mode 2, nullable): the per-wave cell-gradient partial sums of the
+// co-scheduled pair kernel (9 doubles per wave, n_sr_part waves), pre-reduced per tile like sr_part.
+struct XCellExtra {
+  const void* dG4;
+  const double* cpart_in;
+  double* cpart_out;
+  int* ticket;  // nullable: the ticket counter of cellgrad_finalize_kernel (behind the partials it will read), cleared here
+};
+template <typename T, int CELLSUMS>
 __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                 Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
                                                 T* __restrict__ dc, const KGeom& kg, const KPot& kp,
                                                 double* __restrict__ partials, double* __restrict__ epart,
                                                 const double* __restrict__ sr_part, int n_sr_part, unsigned tile_id,
-                                                unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x) {
+                                                unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x,
+                                                const XCellExtra& xc = XCellExtra{nullptr, nullptr, nullptr, nullptr}) {
   // rows padded by one element (as in the y-column stage): the passes give consecutive lanes consecutive groups of x, i.e. a
   // stride of whole rows -- with KZ = 8 complex floats (64 bytes) per row that is 4 distinct bank groups for 32 lanes
   const int KZ = 1 << kzs, KP = KZ + kXPad;
@@ -938,6 +979,26 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     for (int i = lo + tid; i < hi; i += 64) {
       sr0 += sr_part[2 * i];
       sr1 += sr_part[2 * i + 1];
+    }
+  }
+  if constexpr (CELLSUMS == 2) {
+    if (xc.cpart_in && xc.cpart_out && active && tid < 64) {  // uniform per wave
+      const int per = (n_sr_part + int(n_tiles) - 1) / int(n_tiles);
+      const int lo = int(tile_id) * per, hi = min(lo + per, n_sr_part);
+      double cp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cp[k] = 0.0;
+      for (int i = lo + tid; i < hi; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cp[k] += xc.cpart_in[9 * int64_t(i) + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        double v = cp[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (tid == 0) xc.cpart_out[9 * int64_t(tile_id) + k] = v;
+      }
     }
   }
   Cplx<T>* col = hat + (int64_t(c) * nx * ny + ky) * nzh + kz0;  // element (x, z): col[x * ny * nzh + z]
@@ -985,12 +1046,109 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       }
     }
   }
+  typedef T T4v __attribute__((ext_vector_type(4)));
+  const T4v* __restrict__ dG4 = reinterpret_cast<const T4v*>(xc.dG4);
+  T4v dpre[CELLSUMS == 2 ? kGPrefetch : 1];
+  if constexpr (CELLSUMS == 2) {
+    if (g_prefetched) {
+#pragma unroll
+      for (int u = 0; u < kGPrefetch; ++u) {
+        const int idx = tid + u * nthr;
+        const int x = idx >> kzs, z = idx & (KZ - 1);
+        dpre[u] = T4v{T(0), T(0), T(0), T(0)};
+        if (idx < n_el && z < kzn) {
+          const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+          dpre[u] = dG4[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
+        }
+      }
+    }
+  }
   __syncthreads();
   // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
   //      tile[x * KP + z] ----
   lds_fft_radix2<T, false, false, MIPME_FFT_BFAST ? 1 : 0>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
-  if constexpr (CELLSUMS) {
+  if constexpr (CELLSUMS == 2) {
+    // moments of w = mu |rho^|^2 against the table: M1[e][d] = sum w alpha f_e f_d (symmetric), M2[c][d] = sum w beta_c f_d, from
+    // which   K[c][d] = 2 pi sum_k w dG/dk_c f_d = 2 pi (2 pi sum_e inv[c][e] M1[e][d] - h_c M2[c][d]),
+    //         H[c]    = sum_k w dG/dh_c        = -2 pi sum_e inv[c][e] M2[c][e]
+    T m1[6], m2[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m1[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m2[i] = T(0);
+    const T fy = T(fft_freq(ky, ny));
+    int u_c = 0;
+    for (int idx = tid; idx < n_el; idx += nthr, ++u_c) {
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      if (z < kzn) {
+        const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+        const int iz = kz0 + z;
+        T4v d4;
+        if (g_prefetched) {
+          d4 = T4v{T(0), T(0), T(0), T(0)};
+#pragma unroll
+          for (int u = 0; u < kGPrefetch; ++u) d4 = u == u_c ? dpre[u] : d4;
+        } else {
+          d4 = dG4[c * G_stride + (int64_t(kx) * ny + ky) * nzh + iz];
+        }
+        const Cplx<T> v = tile[x * KP + z];
+        const bool edge = (iz == 0) || ((kg.nz % 2 == 0) && (iz == kg.nz / 2));
+        const T w = (v.re * v.re + v.im * v.im) * (edge ? T(1) : T(2));
+        const T fx = T(fft_freq(kx, nx)), fz = T(iz);
+        const T wa = w * d4.x;
+        const T wax = wa * fx, way = wa * fy, waz = wa * fz;
+        m1[0] += wax * fx; m1[1] += wax * fy; m1[2] += wax * fz;
+        m1[3] += way * fy; m1[4] += way * fz; m1[5] += waz * fz;
+        const T wb0 = w * d4.y, wb1 = w * d4.z, wb2 = w * d4.w;
+        m2[0] += wb0 * fx; m2[1] += wb0 * fy; m2[2] += wb0 * fz;
+        m2[3] += wb1 * fx; m2[4] += wb1 * fy; m2[5] += wb1 * fz;
+        m2[6] += wb2 * fx; m2[7] += wb2 * fy; m2[8] += wb2 * fz;
+      }
+    }
+    __shared__ double mred[8][15];
+    __shared__ double msum[15 + 12];  // the 15 block sums, then inv[9] and h[3] (LDS: indexed by thread below)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      double v = double(i < 6 ? m1[i < 6 ? i : 0] : m2[i >= 6 ? i - 6 : 0]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) mred[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 15) {
+      double v = 0.0;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) v += mred[w][tid];
+      msum[tid] = v;
+    } else if (tid == 15) {  // (static indices: scalar loads of the by-value argument)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) msum[15 + i] = kg.inv[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) msum[24 + i] = kg.h[i];
+    }
+    __syncthreads();
+    if (tid < 12 && active) {
+      double out;
+      if (tid < 9) {
+        const int cc = tid / 3, d = tid % 3;
+        double a = 0.0;
+        for (int e = 0; e < 3; ++e) {
+          const int lo = e < d ? e : d, hi = e < d ? d : e;
+          a += msum[15 + 3 * cc + e] * msum[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];  // symmetric M1: 00 01 02 11 12 22
+        }
+        out = 2.0 * kPi * (2.0 * kPi * a - msum[24 + cc] * msum[6 + 3 * cc + d]);
+      } else {
+        const int cc = tid - 9;
+        double a = 0.0;
+        for (int e = 0; e < 3; ++e) a += msum[15 + 3 * cc + e] * msum[6 + 3 * cc + e];
+        out = -2.0 * kPi * a;
+      }
+      partials[int64_t(tile_id) * 12 + tid] = out;
+    }
+    if (xc.ticket && tile_id == 0 && tid == 0) *xc.ticket = 0;
+  }
+  if constexpr (CELLSUMS == 1) {
     double acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.0;
@@ -1094,16 +1252,17 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   }
 }
 
-template <typename T, bool CELLSUMS>
+template <typename T, int CELLSUMS>
 __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
                                                    Cplx<T>* __restrict__ hat, const T* __restrict__ G, int64_t G_stride,
                                                    T* __restrict__ dc, KGeom kg, KPot kp, double* __restrict__ partials,
                                                    double* __restrict__ epart, const double* __restrict__ sr_part,
-                                                   int n_sr_part, const int* __restrict__ skip) {
+                                                   int n_sr_part, const int* __restrict__ skip, XCellExtra xc) {
   MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   xconv_tile_body<T, CELLSUMS>(nx, ny, nzh, log2nx, kzs, nchunk, hat, G, G_stride, dc, kg, kp, partials, epart, sr_part,
-                               n_sr_part, xcd_tile(blockIdx.x, gridDim.x), gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x);
+                               n_sr_part, xcd_tile(blockIdx.x, gridDim.x), gridDim.x, true, int(threadIdx.x), int(blockDim.x), 0, smem_x,
+                               xc);
 }
 
 // ---- the convolution as ONE persistent launch ----------------------------------------------------------------------------
@@ -1169,7 +1328,7 @@ __global__ __launch_bounds__(1024) void conv_persistent_kernel(ConvArgs<T> a) {
     KPot kp{};
     for (unsigned base = 0; base < a.n_tiles; base += a.n_conv * unsigned(G)) {
       const unsigned tile = base + w * unsigned(G) + unsigned(grp);
-      xconv_tile_body<T, false>(a.nx, a.ny, a.nzh, a.log2nx, a.kzs, a.nchunk, a.hat, a.G, 0, a.dc, kg, kp, nullptr, a.epart,
+      xconv_tile_body<T, 0>(a.nx, a.ny, a.nzh, a.log2nx, a.kzs, a.nchunk, a.hat, a.G, 0, a.dc, kg, kp, nullptr, a.epart,
                                 a.sr_part, a.n_sr_part, tile < a.n_tiles ? tile : 0u, a.n_tiles, tile < a.n_tiles, gtid,
                                 a.x_threads, grp, smem_c + size_t(grp) * a.x_group_lds);
       __syncthreads();  // the groups' LDS regions are reused by the next round
@@ -1262,10 +1421,80 @@ static int convolve_persistent_t(mipme_fft_plan* p, hipStream_t st, const void* 
   return MIPME_OK;
 }
 
+template <typename T>
+static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
+                             void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
+                             void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part, const ConvCell* cc) {
+  const int nzh = p->nz / 2 + 1;
+  int log2nx = 0;
+  while ((1 << log2nx) < p->nx) ++log2nx;
+  const size_t cs = sizeof(Cplx<T>);
+  // columns per block: a power of two giving >= 64-byte segments (8 complex floats / 4 complex doubles), tile <= 32 KiB
+  int kzs = sizeof(T) == 4 ? 3 : 2;
+  while (kzs > 0 && cs * (size_t(p->nx) << kzs) > 32768) --kzs;
+  const int KZ = 1 << kzs;
+  const int nchunk = (nzh + KZ - 1) / KZ;
+  const unsigned grid = unsigned(nchunk) * unsigned(p->ny) * unsigned(p->batch);
+  const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + kXPad) + size_t(p->nx / 2));
+  int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  const bool table = cell_partials && cc && cc->G_deriv;
+  // with the cell sums evaluated in place every element of the tile costs ~700 double-precision instructions
+  // (eval_point<true>): at 64^3 that was four elements per thread in ONE wave per SIMD, a serial stream with nothing to overlap
+  // its latencies -- 256 threads (0.1217 -> 0.1170 ms for energy + forces + dE/dcell as a graph; 512 threads with launch bounds
+  // to match: 0.1252).  From the table they are a dozen FMAs per element and the launch keeps its shape.
+  if (cell_partials && !table) threads = 256;
+  KGeom kg{};
+  KPot kp{};
+  if (cell_partials) {
+    MIPME_REQUIRE(cell_mesh && cell_pot, "the cell sums of the x stage need the mesh and potential descriptors");
+    int rc = make_kpot(cell_pot, kp);
+    if (rc) return rc;
+    kg = make_kgeom(cell_mesh);
+  }
+  XCellExtra xc{nullptr, nullptr, nullptr, nullptr};
+  if (table) {
+    xc.dG4 = cc->G_deriv;
+    xc.cpart_in = cc->cpart_in;
+    xc.cpart_out = cc->cpart_out;
+    if (cc->legacy_ticket)
+      xc.ticket = reinterpret_cast<int*>((double*)cell_partials + int64_t(grid) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl);
+  }
+  if (p->own_yz) {
+    int rc = yz_planes<T>(p, st, false, mesh_in, hat, nullptr);
+    if (rc) return rc;
+  } else if (sizeof(T) == 4) {
+    MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
+  } else {
+    MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
+  }
+#define MIPME_XCONV_LAUNCH(MODE)                                                                                              \
+  xconv_kernel<T, MODE><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<T>*)hat, (const T*)G,      \
+                                                    G_stride, (T*)dc, kg, kp, (double*)cell_partials, (double*)epart,        \
+                                                    (const double*)sr_part, int(n_sr_part), skip_flag_slot(), xc)
+  if (table)
+    MIPME_XCONV_LAUNCH(2);
+  else if (cell_partials)
+    MIPME_XCONV_LAUNCH(1);
+  else
+    MIPME_XCONV_LAUNCH(0);
+#undef MIPME_XCONV_LAUNCH
+  MIPME_LAUNCH_CHECK();
+  if (p->own_yz) {
+    int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out);
+    if (rc) return rc;
+  } else if (sizeof(T) == 4) {
+    MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
+  } else {
+    MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
+  }
+  return MIPME_OK;
+}
+
 int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
                     void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part, const RowRideHost* rh,
-                    void* err_flag) {
+                    void* err_flag, const ConvCell* cc) {
   if (!cell_partials && G_stride == 0 && conv_persistent_ok(p)) {
     if (p->dtype == MIPME_F32)
       return convolve_persistent_t<float>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
@@ -1276,75 +1505,11 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
     MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
     MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
   }
-  const int nzh = p->nz / 2 + 1;
-  int log2nx = 0;
-  while ((1 << log2nx) < p->nx) ++log2nx;
-  const size_t cs = p->dtype == MIPME_F32 ? 8 : 16;
-  // columns per block: a power of two giving >= 64-byte segments (8 complex floats / 4 complex doubles), tile <= 32 KiB
-  int kzs = p->dtype == MIPME_F32 ? 3 : 2;
-  while (kzs > 0 && cs * (size_t(p->nx) << kzs) > 32768) --kzs;
-  const int KZ = 1 << kzs;
-  const int nchunk = (nzh + KZ - 1) / KZ;
-  const unsigned grid = unsigned(nchunk) * unsigned(p->ny) * unsigned(p->batch);
-  const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + kXPad) + size_t(p->nx / 2));
-  int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
-  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
-  // with the cell sums every element of the tile costs ~700 double-precision instructions (eval_point<true>): at 64^3 that was
-  // four elements per thread in ONE wave per SIMD, a serial stream with nothing to overlap its latencies -- 256 threads
-  // (0.1217 -> 0.1170 ms for energy + forces + dE/dcell as a graph; 512 threads with launch bounds to match: 0.1252)
-  if (cell_partials) threads = 256;
-  KGeom kg{};
-  KPot kp{};
-  if (cell_partials) {
-    MIPME_REQUIRE(cell_mesh && cell_pot, "the cell sums of the x stage need the mesh and potential descriptors");
-    int rc = make_kpot(cell_pot, kp);
-    if (rc) return rc;
-    kg = make_kgeom(cell_mesh);
-  }
-  if (p->dtype == MIPME_F32) {
-    if (p->own_yz) {
-      int rc = yz_planes<float>(p, st, false, mesh_in, hat, nullptr);
-      if (rc) return rc;
-    } else {
-      MIPME_CHECK_FFT(hipfftExecR2C(p->fwd2d, (hipfftReal*)mesh_in, (hipfftComplex*)hat));
-    }
-    if (cell_partials)
-      xconv_kernel<float, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
-                                                            (const float*)G, G_stride, (float*)dc, kg, kp,
-                                                            (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
-    else
-      xconv_kernel<float, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<float>*)hat,
-                                                             (const float*)G, G_stride, (float*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
-    MIPME_LAUNCH_CHECK();
-    if (p->own_yz) {
-      int rc = yz_planes<float>(p, st, true, nullptr, hat, mesh_out);
-      if (rc) return rc;
-    } else {
-      MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
-    }
-  } else {
-    if (p->own_yz) {
-      int rc = yz_planes<double>(p, st, false, mesh_in, hat, nullptr);
-      if (rc) return rc;
-    } else {
-      MIPME_CHECK_FFT(hipfftExecD2Z(p->fwd2d, (hipfftDoubleReal*)mesh_in, (hipfftDoubleComplex*)hat));
-    }
-    if (cell_partials)
-      xconv_kernel<double, true><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                             (const double*)G, G_stride, (double*)dc, kg, kp,
-                                                             (double*)cell_partials, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
-    else
-      xconv_kernel<double, false><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<double>*)hat,
-                                                              (const double*)G, G_stride, (double*)dc, kg, kp, nullptr, (double*)epart, (const double*)sr_part, int(n_sr_part), skip_flag_slot());
-    MIPME_LAUNCH_CHECK();
-    if (p->own_yz) {
-      int rc = yz_planes<double>(p, st, true, nullptr, hat, mesh_out);
-      if (rc) return rc;
-    } else {
-      MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
-    }
-  }
-  return MIPME_OK;
+  if (p->dtype == MIPME_F32)
+    return convolve_xfused_t<float>(p, st, mesh_in, G, hat, mesh_out, dc, G_stride, cell_mesh, cell_pot, cell_partials, epart,
+                                    sr_part, n_sr_part, cc);
+  return convolve_xfused_t<double>(p, st, mesh_in, G, hat, mesh_out, dc, G_stride, cell_mesh, cell_pot, cell_partials, epart,
+                                   sr_part, n_sr_part, cc);
 }
 
 int fft_forward(mipme_fft_plan* p, hipStream_t st, const void* in, void* out);
@@ -1677,6 +1842,114 @@ int cellgrad_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, int
   return MIPME_OK;
 }
 
+template <typename T>
+int kfilter_deriv_impl(hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot, void* D) {
+  KPot kp;
+  int rc = make_kpot(pot, kp);
+  if (rc) return rc;
+  const KGeom g = make_kgeom(m);
+  const int64_t Mh = int64_t(g.nx) * g.ny * g.nzh;
+  kfilter_deriv_kernel<T><<<unsigned((Mh + 255) / 256), 256, 0, st>>>(g, kp, (T*)D);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+// ---- dE/dcell of an energy step (E = sum q V, seed s), assembled by ONE workgroup from partial sums the step's kernels left
+// behind (SURVEY.md Appendix A.5 with g = s q, i.e. psi = (s / 2V) rho):
+//   kpart[t][12]   x stage:  K[c][d] = 2 pi sum_k mu |rho^|^2 dG/dk_c f_d,  H[c] = sum_k mu |rho^|^2 dG/dh_c      (per tile)
+//   ctile[t][9]    x stage's pre-reduction of the pair kernel's per-wave sums  C[i][c] = sum_rows q_a sum_e w_e v'/d sh_i u_c
+//   epart_k[t]     x stage:  sum_k mu G |rho^|^2  (= V sum_a q_a Phi_a: the gather is the adjoint of the spread)
+//   rpart[b][9]    gather:   R[c][e] = sum_a r_{a,c} (s q_a field_{a,e})                                           (per brick)
+// mesh part  gA[a][b] = -sum_c Ai[c][a] R[c][b] - (s/2V) sum_cd Ai[c][a] K[c][d] Ai[b][d] + dLdV V Ai[b][a]
+//                       + (s/2V) H[a] / (|a_a| n_a) A[a][b],      dLdV = -s E_k / (2 V^2) + s bg Q^2 / V^2
+// pair part  gP[m][c] = s f/2 sum_i Ai[i][m] C[i][c]   (every pair sits in two rows; f = 1/2 for a full list)
+// out: 27 reals: mesh part, pair part, their sum.  31 column sums by 31 groups of 32 lanes, then 18 threads for the 3x3 algebra.
+template <typename T>
+__global__ __launch_bounds__(1024) void cell_tail_finalize_kernel(mipme_mesh_t m, double bg, double pair_scale, int n_tiles,
+                                                                 int n_bricks, const double* __restrict__ kpart,
+                                                                 const double* __restrict__ ctile,
+                                                                 const double* __restrict__ epart_k,
+                                                                 const double* __restrict__ rpart, const T* __restrict__ dc,
+                                                                 const T* __restrict__ seed, T* __restrict__ out) {
+  __shared__ double s[32], geo[18];
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+  if (grp < 31) {
+    const double* base;
+    int n, stride;
+    if (grp < 12) {
+      base = kpart + grp, n = n_tiles, stride = 12;
+    } else if (grp < 21) {
+      base = ctile ? ctile + (grp - 12) : nullptr, n = n_tiles, stride = 9;
+    } else if (grp < 30) {
+      base = rpart + (grp - 21), n = n_bricks, stride = 9;
+    } else {
+      base = epart_k, n = n_tiles, stride = 1;
+    }
+    double v = 0.0;
+    if (base)
+      for (int i = l; i < n; i += 32) v += base[int64_t(i) * stride];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    if (l == 0) s[grp] = v;
+  } else if (l == 0) {  // the idle 32nd group: cell and inverse cell to LDS with static indices (scalar loads of the by-value
+                        // argument; the 18 threads below index them by thread)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      geo[i] = m.cell[i];
+      geo[9 + i] = m.inv_cell[i];
+    }
+  }
+  __syncthreads();
+  __shared__ double res[18];
+  if (threadIdx.x < 18) {
+  const double sd = seed ? double(seed[0]) : 1.0;
+  const double V = m.volume, es = 0.5 * sd / V;
+  const double* A = geo;
+  const double* Ai = geo + 9;
+  if (threadIdx.x < 9) {
+    const int a = threadIdx.x / 3, b = threadIdx.x % 3;
+    const int nsa = a == 0 ? m.nx : (a == 1 ? m.ny : m.nz);
+    const double Q = double(dc[0]);
+    const double dLdV = -sd * s[30] / (2.0 * V * V) + sd * bg * Q * Q / (V * V);
+    double v = 0.0;
+    for (int c = 0; c < 3; ++c) {
+      v -= Ai[3 * c + a] * s[21 + 3 * c + b];
+      for (int d = 0; d < 3; ++d) v -= es * Ai[3 * c + a] * s[3 * c + d] * Ai[3 * b + d];
+    }
+    const double norm = sqrt(A[3 * a] * A[3 * a] + A[3 * a + 1] * A[3 * a + 1] + A[3 * a + 2] * A[3 * a + 2]);
+    v += dLdV * V * Ai[3 * b + a] + es * s[9 + a] / (norm * double(nsa)) * A[3 * a + b];
+    out[threadIdx.x] = T(v);
+    res[threadIdx.x] = v;
+  } else {
+    const int mm = (threadIdx.x - 9) / 3, c = (threadIdx.x - 9) % 3;
+    double v = 0.0;
+    for (int i = 0; i < 3; ++i) v += Ai[3 * i + mm] * s[12 + 3 * i + c];
+    v *= sd * pair_scale;
+    out[threadIdx.x] = T(v);
+    res[threadIdx.x] = v;
+  }
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) out[18 + threadIdx.x] = T(res[threadIdx.x] + res[9 + threadIdx.x]);  // the sum, for callers with ONE cell tensor
+}
+
+template <typename T>
+int cell_tail_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, double pair_scale, int64_t n_tiles,
+                            int64_t n_bricks, const void* kpart, const void* ctile, const void* epart_k, const void* rpart,
+                            const void* dc, const void* seed, void* out) {
+  cell_tail_finalize_kernel<T><<<1, 1024, 0, st>>>(*m, bg, pair_scale, int(n_tiles), int(n_bricks), (const double*)kpart,
+                                                  (const double*)ctile, (const double*)epart_k, (const double*)rpart,
+                                                  (const T*)dc, (const T*)seed, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template int kfilter_deriv_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template int kfilter_deriv_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
+template int cell_tail_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
+                                            const void*, const void*, const void*, const void*, const void*, void*);
+template int cell_tail_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
+                                             const void*, const void*, const void*, const void*, const void*, void*);
 template int kfilter_build_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int kfilter_build_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int apply_filter_impl<float>(hipStream_t, int64_t, int, const void*, const void*, void*, void*);

@@ -99,6 +99,11 @@ struct FusedRowsArgs {
   // w of workgroup b at index b * BS/64 + w) -- the pair part of the energy and the self-term sum, reduced later by the
   // gather's tail (bricks.hip)
   double* epart;
+  // packed / fp64 bodies with CELL only: per-WAVE sums (fp64[9] per wave, indexed like epart) of
+  //   C[i][c] = sum_rows q_a sum_e w_e v_SR'(d_e)/d_e sh_i u_c      (sh = S' A: the entry's Cartesian cell shift, u = pair vector)
+  // -- the pair part of dE/dcell is  f/2 * inv(A)^T-contracted C (every pair sits in two rows; kfilter.hip
+  // cell_tail_finalize_kernel)
+  double* cpart;
   const int* skip;  // nullable: the stand-alone kernels return at once if *skip == 1 (mipme_set_skip_flag)
   int row_stride;  // words of row_ptr per atom: 2 (rows share their boundaries) or 3 (kRowsPadded)
   bool symmetric;  // kRowsPadded: every pair appears in both of its rows as a "role i" entry
@@ -133,6 +138,7 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
   a.partials = (double*)partials;
   a.dist_out = (T*)dist_out;
   a.epart = nullptr;
+  a.cpart = nullptr;
   a.skip = nullptr;
   a.symmetric = (shift_format & kRowsPadded) != 0;
   a.row_stride = a.symmetric ? 3 : 2;
@@ -486,7 +492,7 @@ static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(Atom
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ d2v llvm_raw_buffer_load_d2(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f64");
 
-template <int BS>
+template <int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
   static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
   AtomRecord<double>* __restrict__ shift_tab = reinterpret_cast<AtomRecord<double>*>(lds);
@@ -543,6 +549,9 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
   __syncthreads();  // shift table + erfcx table
   double pot = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+  double cg[CELL ? 9 : 1];
+#pragma unroll
+  for (int k = 0; k < (CELL ? 9 : 1); ++k) cg[k] = 0.0;
   for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
     const int eB = eA + kRowLanes;
     const int oA = int((wA & kAtomMask) << 5), oB = int((wB & kAtomMask) << 5);
@@ -587,6 +596,23 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       fx = __builtin_fma(sc, vx[u], fx);
       fy = __builtin_fma(sc, vy[u], fy);
       fz = __builtin_fma(sc, vz[u], fz);
+      if constexpr (CELL) {  // (sc = -w v'/d here: the sign is restored below)
+        const AtomRecord<double>& sh = u == 0 ? sA : sB;
+        const double tx = sc * vx[u], ty = sc * vy[u], tz = sc * vz[u];
+        cg[0] = __builtin_fma(sh.x, tx, cg[0]); cg[1] = __builtin_fma(sh.x, ty, cg[1]); cg[2] = __builtin_fma(sh.x, tz, cg[2]);
+        cg[3] = __builtin_fma(sh.y, tx, cg[3]); cg[4] = __builtin_fma(sh.y, ty, cg[4]); cg[5] = __builtin_fma(sh.y, tz, cg[5]);
+        cg[6] = __builtin_fma(sh.z, tx, cg[6]); cg[7] = __builtin_fma(sh.z, ty, cg[7]); cg[8] = __builtin_fma(sh.z, tz, cg[8]);
+      }
+    }
+  }
+  if constexpr (CELL) {
+    if (args.cpart) {
+      const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const double v = wave_sum(valid ? -qa * cg[k] : 0.0);
+        if ((threadIdx.x & 63) == 0) args.cpart[9 * w + k] = v;
+      }
     }
   }
   pot = row_sum(pot);
@@ -612,7 +638,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
 }
 
 #if MIPME_ROW_LANES == 16
-template <int PFAST, int BS>
+template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
                                                 AtomRecord<float>* __restrict__ shift_tab) {
   static_assert(kRowLanes == 16, "the packed body walks 2 x 16 entries per row and iteration");
@@ -675,6 +701,14 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   __syncthreads();  // shift table
   f2v pot2 = f2v{0.f, 0.f}, fxy = f2v{0.f, 0.f};
   float fz = 0.f;
+  // CELL: C[i][(x,y)] and C[i][z] for i = x, y, z of the entry's Cartesian shift (9 sums: 3 packed + 3 scalar)
+  f2v cxy[CELL ? 3 : 1];
+  float cz[CELL ? 3 : 1];
+#pragma unroll
+  for (int k = 0; k < (CELL ? 3 : 1); ++k) {
+    cxy[k] = f2v{0.f, 0.f};
+    cz[k] = 0.f;
+  }
   for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
     const int eB = eA + kRowLanes;
     const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
@@ -695,10 +729,40 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
     pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
     const f2v sc = sv * dvd;
-    fxy -= sc.x * vA;
-    fz -= sc.x * zA;
-    fxy -= sc.y * vB;
-    fz -= sc.y * zB;
+    if constexpr (CELL) {
+      const f2v tA = sc.x * vA, tB = sc.y * vB;
+      const float tzA = sc.x * zA, tzB = sc.y * zB;
+      fxy -= tA;
+      fz -= tzA;
+      fxy -= tB;
+      fz -= tzB;
+      cxy[0] += sA.x * tA; cz[0] += sA.x * tzA;
+      cxy[1] += sA.y * tA; cz[1] += sA.y * tzA;
+      cxy[2] += sA.z * tA; cz[2] += sA.z * tzA;
+      cxy[0] += sB.x * tB; cz[0] += sB.x * tzB;
+      cxy[1] += sB.y * tB; cz[1] += sB.y * tzB;
+      cxy[2] += sB.z * tB; cz[2] += sB.z * tzB;
+    } else {
+      fxy -= sc.x * vA;
+      fz -= sc.x * zA;
+      fxy -= sc.y * vB;
+      fz -= sc.y * zB;
+    }
+  }
+  if constexpr (CELL) {
+    if (args.cpart) {  // uniform
+      const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
+      const float qv = valid ? qa : 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float vx = wave_sum(qv * cxy[i].x), vy = wave_sum(qv * cxy[i].y), vz = wave_sum(qv * cz[i]);
+        if ((threadIdx.x & 63) == 0) {
+          args.cpart[9 * w + 3 * i] = double(vx);
+          args.cpart[9 * w + 3 * i + 1] = double(vy);
+          args.cpart[9 * w + 3 * i + 2] = double(vz);
+        }
+      }
+    }
   }
   const float pot = row_sum(pot2.x + pot2.y);
   if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.f) + 0.5f * pot;
@@ -723,9 +787,10 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
 
 #else
 // experiment builds with another row width (tools/build_variant.sh ... -DMIPME_ROW_LANES=32): no packed body, the generic one
-template <int PFAST, int BS>
+template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
                                                 AtomRecord<float>* __restrict__ shift_tab) {
+  static_assert(!CELL, "the cell sums of the energy step need the packed body (MIPME_ROW_LANES == 16)");
   sr_fused_rows_body<float, kPotForce, false, PFAST, false, true, BS, 0, true>(args, block, shift_tab);
 }
 #endif

@@ -23,7 +23,7 @@ class _LiveStep:
     every kernel of the step reads; the atom -> mesh-brick bookkeeping (bins, per-brick atom lists) is rebuilt only when the
     neighbour list is (``rebin``), while every weight is evaluated from the current positions in every step."""
 
-    def __init__(self, calculator, charges, cell, positions):
+    def __init__(self, calculator, charges, cell, positions, charge_gradient=False, cell_gradient=False):
         lib = self.lib = _lib.load()
         device, dtype = positions.device, positions.dtype
         N = positions.shape[0]
@@ -54,6 +54,17 @@ class _LiveStep:
         self.energy = torch.empty((), dtype=dtype, device=device)
         self.grad = torch.empty((N, 3), dtype=dtype, device=device)
         self.minus_one = torch.tensor(-1.0, dtype=dtype, device=device)
+        self.one = torch.tensor(1.0, dtype=dtype, device=device)
+        # the rest of the autograd contract from the same five launches (+ one single-workgroup launch for the cell)
+        self.grad_q = torch.empty((N, 1), dtype=dtype, device=device) if charge_gradient else None
+        self.grad_cell = self.G_deriv = self.cell_work = None
+        if cell_gradient:
+            if dtype != torch.float32 and not (self.pot.kind == _lib.COULOMB or self.pot.exponent == 1):
+                raise NotImplementedError("the fp64 pair kernel forms the cell sums for 1/r only")
+            self.grad_cell = torch.empty((27,), dtype=dtype, device=device)
+            self.G_deriv = ops.filter_derivative(geom, self.pot, dtype, device)
+            self.cell_work = torch.empty((lib.mipme_cell_tail_work(self.plan.handle, C.byref(self.md), N),),
+                                         dtype=torch.float64, device=device)
         self.flags = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.flags_np = self.flags.numpy()
         self.nan_flag = calculator._nan_flag_ptr()
@@ -70,7 +81,8 @@ class _LiveStep:
             live_lists=self.lists.data_ptr(), row_ptr=row_ptr.data_ptr(), words=words.data_ptr(),
             potentials=self.potentials.data_ptr(), pair_force=self.pair_force.data_ptr(), energy=self.energy.data_ptr(),
             grad_positions=self.grad.data_ptr(), grad_seed=self.minus_one.data_ptr(), nan_flag=self.nan_flag,
-            host_flags=self.flags.data_ptr())
+            host_flags=self.flags.data_ptr(), grad_charges=_lib.ptr(self.grad_q), grad_cell=_lib.ptr(self.grad_cell),
+            G_deriv=_lib.ptr(self.G_deriv), cell_work=_lib.ptr(self.cell_work), aux_seed=self.one.data_ptr())
 
     def rebin(self):
         with _lib.on_device(self.device):
@@ -99,7 +111,13 @@ class GraphedEnergyForces:
     :param calculator: a :class:`PMECalculator` / :class:`P3MCalculator`
     :param charges, cell, positions, neighbor_indices, neighbor_shifts: tensors on the GPU; ``positions`` only
         provides the shape/dtype and the values for the warm-up.
-    :param cell_gradient: also return ``dE/dcell`` (stress) from every call
+    :param cell_gradient: also return ``dE/dcell`` (3,3) from every call (the virial is ``-cell.T @ dE/dcell``): the co-scheduled
+        pair sum, the x stage of the convolution and the gather leave partial sums behind and ONE more single-workgroup launch
+        assembles them (``mipme_kspace_forward_args_t.out_grad_cell``); cases those kernels do not cover (fp64 1/r^6, stored
+        distances, non-integer shifts) go through the calculator's general autograd nodes instead -- same numbers
+    :param charge_gradient: also return ``dE/dcharges`` (N,1) from every call (``= 2 V``, written by the gather launch).  With
+        both flags a call returns ``E, F, dE/dq, dE/dcell`` -- the whole first-order autograd contract of the reference
+        (``tests/calculators/test_workflow.py:164-192``) from one graph replay
     :param store_distances: keep the pair distances of the last evaluation in ``self.distances`` (P,) -- written by the pair
         kernel as a by-product; off by default: the kernel then forms them in registers only (19 MB less per step at 4.76 M
         pairs, and the packed fp32 body of the pair sum applies)
@@ -118,9 +136,10 @@ class GraphedEnergyForces:
 
     def __init__(self, calculator, charges, cell, positions, neighbor_indices=None, neighbor_shifts=None, warmup: int = 3,
                  cell_gradient: bool = False, store_distances: bool = False, neighbors=None,
-                 periodic=(True, True, True), live_bins: bool | None = None):
+                 periodic=(True, True, True), live_bins: bool | None = None, charge_gradient: bool = False):
         self.calc = calculator
         self.store_distances = bool(store_distances)
+        self.charge_gradient = bool(charge_gradient)
         self.stream = None
         if neighbors is not None:
             if neighbor_indices is not None or neighbor_shifts is not None:
@@ -131,19 +150,23 @@ class GraphedEnergyForces:
             raise ValueError("`neighbor_indices` and `neighbor_shifts` (or `neighbors`) are required")
         self.q = charges.detach()
         #: with ``cell_gradient=True`` every call also returns dE/dcell (3,3) -- the virial is ``-cell.T @ dE/dcell``
-        self.cell_gradient = cell_gradient
-        self.cell = cell.detach().clone().requires_grad_(True) if cell_gradient else cell.detach()
+        self.cell_gradient = bool(cell_gradient)
+        self.cell = cell.detach().clone() if cell_gradient else cell.detach()
         self.pos = positions.detach().clone().requires_grad_(True)
         device = positions.device
-        # seeding the backward pass with -1 makes ``pos.grad`` the forces directly (no fill and no negation kernel)
+        # seeding the backward pass with -1 makes ``pos.grad`` the forces directly (no fill and no negation kernel); the
+        # derivatives w.r.t. charges and cell are asked of the same gather tail with a seed of their own (+1)
         self._minus_one = torch.tensor(-1.0, dtype=positions.dtype, device=device)
+        self._one = torch.tensor(1.0, dtype=positions.dtype, device=device)
+        self._fused_contract = True  # False: charges / cell gradients through the general autograd nodes (see _capture)
+        self.charge_grad = self.cell_grad = None
         self._warmup = max(1, warmup)
         self.refresh_graph = None
         self._live = None
-        if neighbors is not None and live_bins is not False and not cell_gradient and hasattr(calculator, "_kspace_setup") \
+        if neighbors is not None and live_bins is not False and hasattr(calculator, "_kspace_setup") \
                 and calculator.potential.smearing is not None:
             try:
-                live = _LiveStep(calculator, self.q, self.cell, self.pos)
+                live = _LiveStep(calculator, self.q, self.cell, self.pos, self.charge_gradient, self.cell_gradient)
                 live.rebin()  # trial: a very non-uniform system overflows the per-brick lists -> keep the binned step
                 torch.cuda.current_stream(device).synchronize()
                 live.check()
@@ -244,26 +267,38 @@ class GraphedEnergyForces:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._live.step()
-        self.energy, self.forces, self.cell_grad, self.distances = self._live.energy, self._live.grad, None, None
+        self.energy, self.forces, self.distances = self._live.energy, self._live.grad, None
+        self.charge_grad = self._live.grad_q
+        self.cell_grad = None if self._live.grad_cell is None else self._live.grad_cell[18:27].view(3, 3)
         self.pairs, self.shifts = self.stream.indices, None
 
     def _capture(self, neighbor_indices, neighbor_shifts):
         if self._live is not None:
             return self._capture_live()
-        calculator, cell_gradient, device, warmup = self.calc, self.cell_gradient, self.pos.device, self._warmup
+        calculator, device, warmup = self.calc, self.pos.device, self._warmup
         self.pairs = neighbor_indices
         self.shifts = None if neighbor_shifts is None else neighbor_shifts.to(self.pos.dtype).contiguous()
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):  # warm-up off the default stream: plans, topology, filter caches get built
-            for _ in range(max(1, warmup)):
-                self.pos.grad = None
-                self.cell.grad = None
+            for it in range(max(1, warmup) + 1):
+                self.pos.grad = self.cell.grad = self.q.grad = None
                 self._eval()
+                if it == 0 and (self.charge_gradient or self.cell_gradient) and self._fused_contract:
+                    # did the gather tail take the request (seed_promise(charges=, cell=))?  Otherwise the general nodes:
+                    # charges / cell become leaves and autograd differentiates w.r.t. them
+                    t = self._tail
+                    ok = t is not None and (t["grad_q"] is not None or not self.charge_gradient) and (
+                        t["grad_cell"] is not None or not self.cell_gradient)
+                    if not ok:
+                        self._fused_contract = False
+                        if self.charge_gradient:
+                            self.q = self.q.clone().requires_grad_(True)
+                        if self.cell_gradient:
+                            self.cell.requires_grad_(True)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        self.pos.grad = None
-        self.cell.grad = None
+        self.pos.grad = self.cell.grad = self.q.grad = None
         # The captured graph holds raw pointers into buffers that were built during the warm-up and live in caches: the
         # transposed pair list (+ packed shifts), the calculator's filter table, the reduction scratch.  Keep them alive
         # for the lifetime of the graph, whatever the caches evict later.
@@ -283,8 +318,15 @@ class GraphedEnergyForces:
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
             self.forces = self.pos.grad
-            # the backward pass is seeded with -1 (so that pos.grad is the force): undo the sign for the cell
-            self.cell_grad = -self.cell.grad if cell_gradient else None
+            if self._fused_contract:
+                t = self._tail
+                self._keepalive.append(t)  # (G_deriv, cell_work, the output buffers)
+                self.charge_grad = t["grad_q"] if self.charge_gradient else None
+                self.cell_grad = t["grad_cell"][18:27].view(3, 3) if self.cell_gradient else None
+            else:
+                # the backward pass is seeded with -1 (so that pos.grad is the force): undo the sign for charges and cell
+                self.charge_grad = -self.q.grad if self.charge_gradient else None
+                self.cell_grad = -self.cell.grad if self.cell_gradient else None
 
     def _eval(self):
         # the pair kernel of the calculator forms the distances itself (no separate pass over the list); "virtual": in
@@ -297,23 +339,32 @@ class GraphedEnergyForces:
         #: the pair distances of the last evaluation (P,) with ``store_distances=True``, else None
         self.distances = d.detach() if self.store_distances else None
         # the backward pass below is seeded with self._minus_one: promise that to the forward, whose gather then writes the
-        # forces themselves (energy reduction and force assembly ride in the gather launch, see ops.SEED_PROMISE)
-        with ops.seed_promise(None if self.cell_gradient else self._minus_one):
+        # forces themselves (energy reduction and force assembly ride in the gather launch, see ops.SEED_PROMISE) -- and, on
+        # request, dE/dcharges and dE/dcell with a seed of +1
+        fused = self._fused_contract
+        with ops.seed_promise(self._minus_one, charges=fused and self.charge_gradient, cell=fused and self.cell_gradient,
+                              aux_seed=self._one):
             V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
+        self._tail = getattr(V.grad_fn, "tail", None)
         E = ops.weighted_sum(V, self.q)
         E.backward(self._minus_one)
         return E.detach()
 
     def __call__(self, positions: torch.Tensor | None = None):
+        """``E, F`` (+ ``dE/dcharges`` with ``charge_gradient``, + ``dE/dcell`` with ``cell_gradient``, in that order) of the
+        current -- or the given -- positions: one graph replay.  The returned tensors are the graph's own buffers."""
         self._deferred_check()
         self.calc.check()  # a NaN a previous replay met (pinned word, no synchronisation)
         if positions is not None:
             with torch.no_grad():
                 self.pos.copy_(positions)
         self.graph.replay()
+        out = (self.energy, self.forces)
+        if self.charge_gradient:
+            out += (self.charge_grad,)
         if self.cell_gradient:
-            return self.energy, self.forces, self.cell_grad
-        return self.energy, self.forces
+            out += (self.cell_grad,)
+        return out
 
 
 class _FramesFunction(torch.autograd.Function):

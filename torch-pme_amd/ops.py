@@ -144,6 +144,23 @@ def build_filter(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device
     return G
 
 
+def filter_derivative(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, device) -> torch.Tensor:
+    """Derivative table of G(k) (``mipme_kfilter_build_deriv``: 4 reals per half-grid point) for the cell gradient of an energy
+    step, built on first use and kept with the geometry it belongs to (a new cell makes a new geometry, hence a new table)."""
+    key = (pot_desc.kind, pot_desc.exponent, pot_desc.smearing, pot_desc.prefactor, dtype, str(device))
+    cache = geom.__dict__.setdefault("_deriv_cache", {})
+    D = cache.get(key)
+    if D is None:
+        D = torch.empty((geom.ns[0], geom.ns[1], geom.ns[2] // 2 + 1, 4), dtype=dtype, device=device)
+        md = geom.desc(1)
+        with _lib.on_device(device):
+            _lib.check(_lib.load().mipme_kfilter_build_deriv(_lib.current_stream(device), _lib.dtype_code(dtype), C.byref(md),
+                                                             C.byref(pot_desc), D.data_ptr()))
+        cache.clear()
+        cache[key] = D
+    return D
+
+
 # How the pair kernels accumulate per-atom results:
 #   "rows"   (default) owner-computes sums over a transposed pair list (csrc/topology.hip); needs a
 #            one-off build per neighbour-list tensor, no atomics, deterministic.
@@ -171,25 +188,34 @@ TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
 #: a device scalar the caller promises to seed the next backward pass with (set by GraphedEnergyForces around its
 #: evaluation): the gather's tail then writes seed * dE/dpositions and the backward pass launches nothing
 SEED_PROMISE = None
+#: (charges, cell, aux_seed) asked of the gather's tail irrespective of requires_grad (see seed_promise)
+TAIL_REQUEST = (False, False, None)
 
 
 class seed_promise:
     """``with seed_promise(seed): V = calculator(...)`` -- the caller promises to seed the backward pass of ``weighted_sum(V,
     charges)`` with the device scalar ``seed`` (unchanged until then), e.g. ``E.backward(seed)`` with ``seed = -1`` to get the
     forces.  The gather's tail then writes ``seed * dE/dpositions`` in the forward pass and the backward launches nothing; any
-    other seed still gives the right gradient through the ordinary backward kernels."""
+    other seed still gives the right gradient through the ordinary backward kernels.
 
-    def __init__(self, seed):
-        self.seed = seed
+    ``charges=True`` / ``cell=True`` ask the same tail for ``aux_seed * dE/dcharges`` and ``aux_seed * dE/dcell`` as well, whether or
+    not those tensors require a gradient (``aux_seed``: device scalar, default = ``seed``): a caller that reads the buffers of the
+    node's ``tail`` itself -- :class:`~torchpme_amd.graphed.GraphedEnergyForces` -- gets forces (seed -1) and the derivatives
+    w.r.t. charges and cell (aux seed +1) from one forward pass without a sign-flip launch."""
+
+    def __init__(self, seed, charges: bool = False, cell: bool = False, aux_seed=None):
+        self.seed, self.want_q, self.want_cell, self.aux_seed = seed, bool(charges), bool(cell), aux_seed
 
     def __enter__(self):
-        global SEED_PROMISE
+        global SEED_PROMISE, TAIL_REQUEST
         self._prev, SEED_PROMISE = SEED_PROMISE, self.seed
+        self._prev_req, TAIL_REQUEST = TAIL_REQUEST, (self.want_q, self.want_cell, self.aux_seed)
         return self
 
     def __exit__(self, *exc):
-        global SEED_PROMISE
+        global SEED_PROMISE, TAIL_REQUEST
         SEED_PROMISE = self._prev
+        TAIL_REQUEST = self._prev_req
         return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
@@ -771,7 +797,7 @@ class _PMEFunction(torch.autograd.Function):
                     records_out = fused["records"]
                 # co-scheduled pair sum: the spread launch also carries the row workgroups of the fused distance + pair kernel
                 # (mipme_sr_job_t); the gather then adds the mesh part to the potentials the pair sum wrote
-                job = None
+                job = ent32 = None
                 if (COSCHEDULE and records_out is not None and mask is None and (fused["fmt"] & 0xFF) == 1
                         and fused["partials"] is None and N > 0):
                     # the 4-byte entry stream is read by the co-scheduled kernel only (mipme.h, shift_format 2): use it when the
@@ -805,14 +831,32 @@ class _PMEFunction(torch.autograd.Function):
                 # nor the force assembly is launched.
                 ni = ctx.needs_input_grad
                 p_eff = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+                # ... and the rest of the contract rides along (mipme.h, out_grad_charges / out_grad_cell): dE/dq = 2 V for a
+                # half list, dE/dcell from partial sums of the same launches + one single-workgroup launch
+                symmetric = (not full_list) or bool(topo is not None and topo.fmt_flags)
+                want_q, want_cell, aux_seed = TAIL_REQUEST
+                tail_q = bool(ni[0] or want_q) and symmetric
+                tail_cell = bool(ni[1] or ni[12] or want_cell) and ent32 is not None and not write_dist and slab_axis is None and (
+                    p_eff == 1 or dtype == torch.float32) and src_cell is not None
                 if (TAIL_FUSION and job is not None and field is not None and fused["force"] is not None and not lazy
-                        and ENERGY_FAST_PATH and not (ni[0] or ni[1] or ni[3] or ni[12]) and rho_hat is None
-                        and p_eff in (1, 6) and pot_desc.exclusion_radius <= 0):
+                        and ENERGY_FAST_PATH and not ni[3] and (tail_q or not ni[0]) and (tail_cell or not (ni[1] or ni[12]))
+                        and rho_hat is None and p_eff in (1, 6) and pot_desc.exclusion_radius <= 0):
                     seed = SEED_PROMISE
                     if seed is not None and (seed.dtype != dtype or seed.device != device or seed.numel() != 1):
                         seed = None
+                    if aux_seed is not None and (aux_seed.dtype != dtype or aux_seed.device != device or aux_seed.numel() != 1):
+                        aux_seed = None
                     tail = dict(energy=torch.empty((), dtype=dtype, device=device),
-                                grad=torch.empty((N, 3), dtype=dtype, device=device), seed=seed)
+                                grad=torch.empty((N, 3), dtype=dtype, device=device), seed=seed, grad_q=None, grad_cell=None,
+                                aux_seed=aux_seed)
+                    if tail_q:
+                        tail["grad_q"] = torch.empty((N, 1), dtype=dtype, device=device)
+                    if tail_cell:
+                        tail["grad_cell"] = torch.empty((27,), dtype=dtype, device=device)
+                        tail["G_deriv"] = filter_derivative(geom, pot_desc, dtype, device)
+                        tail["cell_work"] = torch.empty((lib.mipme_cell_tail_work(plan.handle, C.byref(md), N),),
+                                                        dtype=torch.float64, device=device)
+                        cell_partials = None  # (the k-grid sums go to cell_work)
                 args = _lib.KspaceForwardArgs(
                     plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if (overlap or job is not None) else 0,
                     mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N, positions=pos.data_ptr(), charges=q.data_ptr(),
@@ -824,6 +868,11 @@ class _PMEFunction(torch.autograd.Function):
                     out_energy=None if tail is None else tail["energy"].data_ptr(),
                     out_grad_positions=None if tail is None else tail["grad"].data_ptr(),
                     grad_seed=None if tail is None else _lib.ptr(tail["seed"]), nan_flag=nan_flag,
+                    out_grad_charges=None if tail is None else _lib.ptr(tail["grad_q"]),
+                    out_grad_cell=None if tail is None else _lib.ptr(tail["grad_cell"]),
+                    G_deriv=None if tail is None else _lib.ptr(tail.get("G_deriv")),
+                    cell_work=None if tail is None else _lib.ptr(tail.get("cell_work")),
+                    aux_seed=None if tail is None else _lib.ptr(tail["aux_seed"]),
                 )
                 _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
@@ -856,11 +905,14 @@ class _PMEFunction(torch.autograd.Function):
         # E = weighted_sum(out, charges) can be differentiated without this node (see _EnergyDirectSum) when its gradient is
         # gE q_a (f F_a + field_a) with both per-atom sums already formed above and nothing else asks for a gradient
         ni = ctx.needs_input_grad
+        covered = tail is not None and (tail["grad_q"] is not None or not ni[0]) and (
+            tail["grad_cell"] is not None or not (ni[1] or ni[12]))
         ctx.energy_direct = bool(
             ENERGY_FAST_PATH and Cn == 1 and fused is not None and fused["force"] is not None and src_positions is positions
-            and not (ni[0] or ni[1] or ni[3] or ni[12]) and slab_axis is None and (geom is None or field is not None)
-            and not lazy
+            and (covered or not (ni[0] or ni[1] or ni[12])) and not ni[3] and slab_axis is None
+            and (geom is None or field is not None) and not lazy
         )
+        ctx.src_cell_is_cell = src_cell is cell
         return out
 
     @staticmethod
@@ -1163,7 +1215,7 @@ def pme_potential(charges, cell, positions, neighbor_indices, neighbor_distances
                                  G, pot_desc, full_list, slab_axis, src.positions, src.cell, src, False, nan_flag)
         node = out.grad_fn
         if node is not None and getattr(node, "energy_direct", False):
-            out._mipme_energy = (node, positions, charges, charges._version)
+            out._mipme_energy = (node, positions, charges, charges._version, cell, src.cell)
         return out
     if src is not None and src.pending:
         src.materialize()
@@ -1488,8 +1540,10 @@ def weighted_sum(potentials: torch.Tensor, charges: torch.Tensor) -> torch.Tenso
     _lib.require_device(potentials, "potentials")
     hook = getattr(potentials, "_mipme_energy", None)
     if (hook is not None and ENERGY_FAST_PATH and torch.is_grad_enabled() and potentials.grad_fn is hook[0]
-            and charges is hook[2] and charges._version == hook[3] and not charges.requires_grad):
-        return _EnergyDirectSum.apply(potentials.detach(), charges, hook[1], hook[0])
+            and charges is hook[2] and charges._version == hook[3]):
+        # (a node that is `energy_direct` with charges / cell that want a gradient has them in its gather tail)
+        return _EnergyDirectSum.apply(potentials.detach(), charges, hook[1], hook[0], hook[4],
+                                      None if hook[5] is hook[4] else hook[5])
     return _WeightedSum.apply(potentials, charges)
 
 
@@ -1503,7 +1557,7 @@ class _EnergyDirectSum(torch.autograd.Function):
     of the potentials still differentiates through their node as usual -- the contributions add."""
 
     @staticmethod
-    def forward(ctx, V, q, positions, node):
+    def forward(ctx, V, q, positions, node, cell=None, src_cell=None):
         lib = _lib.load()
         q_c = q.detach().contiguous()
         ctx.tail = tail = getattr(node, "tail", None)
@@ -1525,17 +1579,39 @@ class _EnergyDirectSum(torch.autograd.Function):
         lib = _lib.load()
         q = ctx.q
         tail = ctx.tail
-        if tail is not None and tail["seed"] is not None and g.data_ptr() == tail["seed"].data_ptr() and g.numel() == 1:
+        need_q, need_pos, need_cell, need_src_cell = (ctx.needs_input_grad[k] for k in (1, 2, 4, 5))
+        promised = (tail is not None and tail["seed"] is not None and g.data_ptr() == tail["seed"].data_ptr()
+                    and g.numel() == 1)
+        grad_q = grad_cell = grad_src_cell = None
+        if tail is not None and (need_q or need_cell or need_src_cell):
+            # the rest of the contract, from the same gather tail (seed * dE/dq = 2 seed V; seed * dE/dcell: mesh part, pair part,
+            # their sum); the tail was written with the promised seed, or with 1
+            base = tail["aux_seed"] if tail["aux_seed"] is not None else tail["seed"]
+            scale = None if (promised and tail["aux_seed"] is None) else (g if base is None else g / base)
+            if need_q:
+                grad_q = tail["grad_q"].detach() if scale is None else tail["grad_q"] * scale
+            gc = tail["grad_cell"]
+            if gc is not None:
+                gc = gc.detach() if scale is None else gc * scale
+                if need_cell and need_src_cell:
+                    grad_cell, grad_src_cell = gc[0:9].view(3, 3), gc[9:18].view(3, 3)
+                elif need_cell:  # (cell and the distances' cell are the same tensor: the sum)
+                    grad_cell = gc[18:27].view(3, 3)
+                elif need_src_cell:
+                    grad_src_cell = gc[9:18].view(3, 3)
+        if not need_pos:
+            return None, grad_q, None, None, grad_cell, grad_src_cell
+        if promised:
             # the promised seed: the gather's tail has already written seed * dE/dpositions (a fresh alias, so that the
             # accumulation into positions.grad takes the buffer instead of copying it)
-            return None, None, tail["grad"].detach(), None
+            return None, grad_q, tail["grad"].detach(), None, grad_cell, grad_src_cell
         grad_pos = torch.empty((q.shape[0], 3), dtype=q.dtype, device=q.device)
         g = g.contiguous()
         with _lib.on_device(q.device):
             _call("forces_finalize", lib.mipme_sr_rows_finalize, _lib.current_stream(q.device), _lib.dtype_code(q.dtype),
                   q.shape[0], _lib.ptr(ctx.force), _lib.ptr(ctx.field), q.data_ptr(), g.data_ptr(), ctx.full, None,
                   grad_pos.data_ptr(), None)
-        return None, None, grad_pos, None
+        return None, grad_q, grad_pos, None, grad_cell, grad_src_cell
 
 
 class _EwaldKSpace(torch.autograd.Function):
