@@ -57,7 +57,7 @@ template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_
                                         const mipme_sr_job_t*, bool, double*);
 template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int cell_tail_finalize_impl(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
-                                                  const void*, const void*, const void*, const void*, const void*, void*);
+                                                  const void*, const void*, const void*, void*);
 bool sr_job_fusable(const mipme_sr_job_t*);
 int* fft_plan_brick_count(const mipme_fft_plan*);
 template <typename T> int gather_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*, double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
@@ -122,23 +122,26 @@ static int check_plan(const mipme_fft_plan* plan, int dtype, const mipme_mesh_t*
   return MIPME_OK;
 }
 
-// cell_work of an energy step's cell gradient (mipme_cell_tail_work): [kpart 12 t][ctile 9 t][rpart 9 b][cwave 9 w]
+// cell_work of an energy step's cell gradient (mipme_cell_tail_work), in doubles:
+// [rows 25 per rider][rpart 9 per brick][cwave 9 per wavefront of the pair kernel][wbuf: one real per half-grid point]
 struct CellWork {
-  int64_t n_tiles, n_bricks, n_waves;
-  double *kpart, *ctile, *rpart, *cwave;
+  int64_t n_riders, n_bricks, n_waves;
+  double *rows, *rpart, *cwave;
+  void* wbuf;
   int64_t total;
 };
-static CellWork cell_work_layout(const mipme_fft_plan* plan, const mipme_mesh_t* m, int64_t N, void* base) {
+static CellWork cell_work_layout(const mipme_mesh_t* m, int64_t N, void* base) {
   CellWork w;
-  w.n_tiles = xconv_blocks(plan);
+  const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+  w.n_riders = std::min<int64_t>(256, std::max<int64_t>(8, Mh / 2048));  // ~2 k-points per rider thread (1024 threads)
   w.n_bricks = int64_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8);
   w.n_waves = (N + 3) / 4;  // 16 lanes per row: 4 rows per wavefront (rows_body.h)
   double* b = (double*)base;
-  w.kpart = b;
-  w.ctile = w.kpart + 12 * w.n_tiles;
-  w.rpart = w.ctile + 9 * w.n_tiles;
+  w.rows = b;
+  w.rpart = w.rows + 25 * w.n_riders;
   w.cwave = w.rpart + 9 * w.n_bricks;
-  w.total = 21 * w.n_tiles + 9 * w.n_bricks + 9 * w.n_waves;
+  w.wbuf = w.cwave + 9 * w.n_waves;
+  w.total = 25 * w.n_riders + 9 * w.n_bricks + 9 * w.n_waves + Mh;  // (wbuf: Mh reals of <= 8 bytes)
   return w;
 }
 
@@ -151,7 +154,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             void* out_grad_cell = nullptr, const void* G_deriv = nullptr, void* cell_work = nullptr) {
   int rc;
   CellWork cw{};
-  if (out_grad_cell) cw = cell_work_layout(plan, m, N, cell_work);
+  if (out_grad_cell) cw = cell_work_layout(m, N, cell_work);
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
@@ -193,12 +196,10 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
     int64_t n_sr_part = 0;
     const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
-    ConvCell cc{G_deriv, nullptr, nullptr, 1};
-    if (out_grad_cell) cc = ConvCell{G_deriv, cw.cwave, cw.ctile, 0};
-    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot,
-                                                 out_grad_cell ? (void*)cw.kpart : cell_partials,
+    const ConvCell cc{G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders)};
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
                                                  tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part,
-                                                 nullptr, nan_flag, (G_deriv || out_grad_cell) ? &cc : nullptr));
+                                                 nullptr, nan_flag, out_grad_cell ? &cc : nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -216,8 +217,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   guard.armed = false;
   if (out_grad_cell)
     STAGE(st, "cell_finalize",
-          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5 * tail->force_scale, cw.n_tiles, cw.n_bricks, cw.kpart, cw.ctile,
-                                     tail->epart_k, cw.rpart, dc, tail->aux_seed ? tail->aux_seed : tail->seed, out_grad_cell));
+          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5 * tail->force_scale, cw.n_riders, cw.n_bricks, cw.rows, cw.rpart, dc,
+                                     tail->aux_seed ? tail->aux_seed : tail->seed, out_grad_cell));
   return MIPME_OK;
 }
 
@@ -800,7 +801,7 @@ static int md_step_t(const mipme_md_args_t& a) {
                               "one evaluation before capturing)");
   CellWork cw{};
   if (a.grad_cell) {
-    cw = cell_work_layout(a.plan, m, a.n_atoms, a.cell_work);
+    cw = cell_work_layout(m, a.n_atoms, a.cell_work);
     tail.rpart = cw.rpart;
   }
   tail.grad_q = a.grad_charges;
@@ -809,16 +810,16 @@ static int md_step_t(const mipme_md_args_t& a) {
                                                      a.grad_cell ? cw.cwave : nullptr));
   int64_t n_sr_part = 0;
   const void* sr_part = bins_epart(m, a.n_atoms, a.dtype, a.atom_bins, &n_sr_part);
-  ConvCell cc{a.G_deriv, cw.cwave, cw.ctile, 0};
-  STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot,
-                                               a.grad_cell ? (void*)cw.kpart : nullptr, const_cast<void*>(tail.epart_k), sr_part,
-                                               n_sr_part, nullptr, a.nan_flag, a.grad_cell ? &cc : nullptr));
+  const ConvCell cc{a.G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders)};
+  STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot, nullptr,
+                                               const_cast<void*>(tail.epart_k), sr_part, n_sr_part, nullptr, a.nan_flag,
+                                               a.grad_cell ? &cc : nullptr));
   STAGE(st, "gather+energy+forces",
         live_gather<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.phi_mesh, a.dc, self_c, bg_c, a.potentials, nullptr,
                        &tail, a.nan_flag));
   if (a.grad_cell)
     STAGE(st, "cell_finalize",
-          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5, cw.n_tiles, cw.n_bricks, cw.kpart, cw.ctile, tail.epart_k, cw.rpart, a.dc,
+          cell_tail_finalize_impl<T>(st, m, bg_c, 0.5, cw.n_riders, cw.n_bricks, cw.rows, cw.rpart, a.dc,
                                      a.aux_seed ? a.aux_seed : a.grad_seed, a.grad_cell));
   return MIPME_OK;
 }
@@ -863,7 +864,7 @@ int mipme_kfilter_build_deriv(void* stream, int dtype, const mipme_mesh_t* mesh,
 
 int64_t mipme_cell_tail_work(const mipme_fft_plan* plan, const mipme_mesh_t* mesh, int64_t n_atoms) {
   if (!plan || !mesh || validate_mesh(mesh) || n_atoms < 0) return 0;
-  return cell_work_layout(plan, mesh, n_atoms, nullptr).total;
+  return cell_work_layout(mesh, n_atoms, nullptr).total;
 }
 
 int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, const void* G, void* hat_out, void* hat_work,
@@ -956,7 +957,7 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
       MIPME_REQUIRE((a.sr_job->shift_format & 0xff) == 2 && !a.sr_job->dist_out && (p == 1 || a.dtype == MIPME_F32),
                     "out_grad_cell needs 4-byte entries (shift_format 2), no dist_out, and 1/r (or fp32 1/r^6)");
       MIPME_REQUIRE(!a.out_cell_partials, "out_grad_cell replaces out_cell_partials");
-      tail.rpart = cell_work_layout(a.plan, mesh, a.n_atoms, a.cell_work).rpart;
+      tail.rpart = cell_work_layout(mesh, a.n_atoms, a.cell_work).rpart;
       tail.records = a.out_records;
     }
   }

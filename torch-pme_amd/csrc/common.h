@@ -233,12 +233,16 @@ struct GatherTailHost {
   const void* aux_seed; // device scalar, nullable (= seed): the factor of grad_q and of the cell gradient
 };
 
-// What the x stage of the fused convolution adds for the cell gradient of an energy step (kfilter.hip, convolve_xfused)
+// The cell gradient of an energy step inside the fused convolution (kfilter.hip, convolve_xfused): the x stage stores
+// w = mu |rho^|^2 per k-point, and rider workgroups of the launch behind it form the sums against the filter's derivative table
+// (+ slices of the pair kernel's cell sums and of the x stage's energy sums): one row of 25 doubles per rider
 struct ConvCell {
-  const void* G_deriv;    // kfilter_deriv_kernel table: with it the k-grid sums come from the table, else evaluated in place
-  const double* cpart_in; // per-wave cell partial sums of the co-scheduled pair kernel (9 per wave), nullable
-  double* cpart_out;      // their per-tile pre-reduction (9 per tile)
-  int legacy_ticket;      // the partials are read by cellgrad_finalize_kernel: clear its ticket counter behind them
+  const void* G_deriv;  // kfilter_deriv_kernel table
+  const double* cwave;  // per-wave cell partial sums of the co-scheduled pair kernel (9 per wave), nullable
+  int64_t n_waves;
+  void* wbuf;           // (nx, ny, nz/2+1) reals
+  double* rows;         // [n_riders][25]
+  int n_riders;
 };
 
 // Row workgroups of the co-scheduled pair sum that ride on the persistent convolution launch instead of the spread launch:
@@ -278,6 +282,40 @@ inline const int*& skip_flag_slot() {
 inline bool env_flag(const char* name, bool dflt) {
   const char* e = getenv(name);
   return e ? (e[0] != '0') : dflt;
+}
+
+// Wave-wide sums without LDS traffic: four DPP steps inside every row of 16 lanes (quad permutes, then the half-row and row
+// mirrors -- after the quad steps the lanes of a quad agree, so a mirror serves as the xor exchange), then the four row sums
+// through v_readlane.  `__shfl_xor` is ds_bpermute: six LDS operations per value (twelve for a double), which for the 25-value
+// rows of the cell riders was most of an 18 us launch.  Result in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <typename T>
+__device__ __forceinline__ T row16_sum_dpp(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v = row16_sum_dpp(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
 template <typename T>

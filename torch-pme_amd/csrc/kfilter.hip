@@ -791,12 +791,111 @@ __device__ __forceinline__ void yz_plane_body(int ny, int nz, int logny, int log
   }
 }
 
+// ---- cell-gradient riders of an energy step ------------------------------------------------------------------------------
+// Workgroups appended to the launch that FOLLOWS the x stage (the inverse (y,z) planes: 64 workgroups on 256 CUs at 64^3, so the
+// riders run on idle CUs and end before the planes do).  Each takes a slice of the half grid and forms the 15 moments of
+// w = mu |rho^|^2 (written by the x stage) against the filter's derivative table {alpha, beta_x, beta_y, beta_z},
+//     M1[e][d] = sum w alpha f_e f_d  (00 01 02 11 12 22),      M2[c][d] = sum w beta_c f_d,          f = integer frequencies,
+// a slice of the pair kernel's per-wave cell sums (9 doubles per wavefront), and a slice of the x stage's energy sums; one row
+// of kCellRow doubles per rider: {15 moments, 9 pair sums, E_k}.  cell_tail_finalize_kernel turns the column sums into dE/dcell.
+static constexpr int kCellRow = 25;
+struct CellRider {
+  int n_riders;  // 0: none
+  int nx, ny, nzh;
+  const void* wbuf;   // (nx, ny, nzh) reals
+  const void* dG4;    // (nx, ny, nzh, 4) reals
+  const double* cwave;    // nullable
+  int n_waves;
+  const double* epart_k;  // nullable
+  int n_tiles;
+  double* rows;  // [n_riders][kCellRow]
+};
+
+template <typename T>
+__device__ __forceinline__ void cell_rider_body(const CellRider& r, unsigned rider, int nthr, double* red /* [16][kCellRow] LDS */) {
+  typedef T T4v __attribute__((ext_vector_type(4)));
+  const T* __restrict__ wbuf = static_cast<const T*>(r.wbuf);
+  const T4v* __restrict__ dG4 = static_cast<const T4v*>(r.dG4);
+  const int tid = threadIdx.x;
+  // (32-bit index arithmetic: the host side refuses half grids of 2^31 points)
+  const unsigned Mh = unsigned(r.nx) * unsigned(r.ny) * unsigned(r.nzh);
+  const unsigned gid = rider * unsigned(nthr) + unsigned(tid), TT = unsigned(r.n_riders) * unsigned(nthr);
+  T m[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) m[i] = T(0);
+  constexpr int U = 4;  // points in flight per thread (all loads of a batch issued before the first use)
+  for (unsigned i0 = gid; i0 < Mh; i0 += U * TT) {
+    T w[U];
+    T4v d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = i0 + unsigned(u) * TT;
+      const bool ok = i < Mh;
+      w[u] = ok ? wbuf[i] : T(0);
+      d[u] = dG4[ok ? i : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = i0 + unsigned(u) * TT;
+      const unsigned q = i / unsigned(r.nzh), iz = i - q * unsigned(r.nzh);
+      const unsigned ix = q / unsigned(r.ny), iy = q - ix * unsigned(r.ny);
+      const T fx = T(fft_freq(int(ix), r.nx)), fy = T(fft_freq(int(iy), r.ny)), fz = T(int(iz));
+      const T wa = w[u] * d[u].x;
+      const T wax = wa * fx, way = wa * fy, waz = wa * fz;
+      m[0] += wax * fx; m[1] += wax * fy; m[2] += wax * fz;
+      m[3] += way * fy; m[4] += way * fz; m[5] += waz * fz;
+      const T wb0 = w[u] * d[u].y, wb1 = w[u] * d[u].z, wb2 = w[u] * d[u].w;
+      m[6] += wb0 * fx; m[7] += wb0 * fy; m[8] += wb0 * fz;
+      m[9] += wb1 * fx; m[10] += wb1 * fy; m[11] += wb1 * fz;
+      m[12] += wb2 * fx; m[13] += wb2 * fy; m[14] += wb2 * fz;
+    }
+  }
+  // the pair kernel's per-wave sums: a wavefront of the rider takes 64 / 9 ... simply one pair-kernel wave per thread and round
+  double cp[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cp[k] = 0.0;
+  if (r.cwave)
+    for (unsigned i = gid; i < unsigned(r.n_waves); i += TT) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cp[k] += r.cwave[9 * size_t(i) + k];
+    }
+  double ek = 0.0;
+  if (r.epart_k)
+    for (unsigned i = gid; i < unsigned(r.n_tiles); i += TT) ek += r.epart_k[i];
+  // wave sums in the working precision (DPP + readlane: no LDS traffic), waves added in double
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < kCellRow; ++i) {
+    const T mine = i < 15 ? m[i < 15 ? i : 0] : (i < 24 ? T(cp[(i >= 15 && i < 24) ? i - 15 : 0]) : T(ek));
+    const T v = wave_sum_dpp(mine);
+    if (lane == 0) red[wave * kCellRow + i] = double(v);
+  }
+  __syncthreads();
+  if (tid < kCellRow) {
+    double v = 0.0;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) v += red[w * kCellRow + tid];
+    r.rows[size_t(rider) * kCellRow + tid] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void cell_rider_kernel(CellRider r) {
+  __shared__ double red[16 * kCellRow];
+  cell_rider_body<T>(r, blockIdx.x, int(blockDim.x), red);
+}
+
 template <typename T, bool INVERSE, bool YSTAGE = true>
 __global__ __launch_bounds__(1024) void yz_planes_kernel(int ny, int nz, int logny, int loglz, const T* __restrict__ real_in,
                                                        Cplx<T>* __restrict__ hat, T* __restrict__ real_out,
-                                                       const int* __restrict__ skip) {
+                                                       const int* __restrict__ skip, unsigned n_planes, CellRider rider) {
   MIPME_SKIP_IF_SET(skip);
   extern __shared__ __attribute__((aligned(16))) char smem_yz[];
+  if constexpr (INVERSE && YSTAGE) {
+    if (blockIdx.x >= n_planes) {  // (uniform; rider.n_riders workgroups behind the planes)
+      cell_rider_body<T>(rider, blockIdx.x - n_planes, int(blockDim.x), reinterpret_cast<double*>(smem_yz));
+      return;
+    }
+  }
   yz_plane_body<T, INVERSE, YSTAGE>(ny, nz, logny, loglz, real_in, hat, real_out, blockIdx.x, smem_yz);  // plane = (channel, x)
 }
 
@@ -880,21 +979,32 @@ static int zrows(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* re
   const int work = R * (Lz + 1);
   const int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
   if (inverse)
-    yz_planes_kernel<T, true, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out, skip_flag_slot());
+    yz_planes_kernel<T, true, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out, skip_flag_slot(), grid, CellRider{});
   else
-    yz_planes_kernel<T, false, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr, skip_flag_slot());
+    yz_planes_kernel<T, false, false><<<grid, threads, lds, st>>>(R, p->nz, 0, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr, skip_flag_slot(), grid, CellRider{});
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
 
 template <typename T>
-static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* real_in, void* hat, void* real_out) {
+static int cell_riders_alone(hipStream_t st, const CellRider& r) {
+  cell_rider_kernel<T><<<unsigned(r.n_riders), 1024, 0, st>>>(r);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+// rider (inverse only, nullable): the cell-gradient riders of an energy step, appended to the launch where there is ONE launch
+// per direction, a launch of their own otherwise
+template <typename T>
+static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void* real_in, void* hat, void* real_out,
+                     const CellRider* rider = nullptr) {
   if (p->split_yz) {  // planes beyond one workgroup's LDS: z rows and y columns as two launches
     int rc;
     if (!inverse) {
       if ((rc = zrows<T>(p, st, false, real_in, hat, nullptr))) return rc;
       return ycols<T>(p, st, false, hat);
     }
+    if (rider && rider->n_riders > 0 && (rc = cell_riders_alone<T>(st, *rider))) return rc;
     if ((rc = ycols<T>(p, st, true, hat))) return rc;
     return zrows<T>(p, st, true, nullptr, hat, real_out);
   }
@@ -902,8 +1012,10 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
   while ((1 << logny) < p->ny) ++logny;
   while ((1 << loglz) < p->nz / 2) ++loglz;
   const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
-  const size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
+  size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
   const unsigned grid = unsigned(p->nx) * unsigned(p->batch);
+  const unsigned n_riders = (inverse && rider) ? unsigned(rider->n_riders) : 0u;
+  if (n_riders && lds < sizeof(double) * 16 * kCellRow) lds = sizeof(double) * 16 * kCellRow;  // the riders' reduction scratch
   const int work = p->ny * (Lz + 1);
   // latency-bound, one workgroup per plane: the widest workgroup wins (1024 threads 24.0 us per convolution at 64^3 fp32,
   // 512 threads 25.6, 256 threads 30.9; the two hipFFT plans it replaces 25.3)
@@ -917,9 +1029,11 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
     }
   }
   if (inverse)
-    yz_planes_kernel<T, true><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out, skip_flag_slot());
+    yz_planes_kernel<T, true><<<grid + n_riders, threads, lds, st>>>(p->ny, p->nz, logny, loglz, nullptr, (Cplx<T>*)hat, (T*)real_out,
+                                                                     skip_flag_slot(), grid, n_riders ? *rider : CellRider{});
   else
-    yz_planes_kernel<T, false><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr, skip_flag_slot());
+    yz_planes_kernel<T, false><<<grid, threads, lds, st>>>(p->ny, p->nz, logny, loglz, (const T*)real_in, (Cplx<T>*)hat, nullptr,
+                                                           skip_flag_slot(), grid, CellRider{});
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -941,14 +1055,13 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
 #endif
 static constexpr int kXPad = MIPME_X_PAD;  // elements of padding per LDS row of the x stage
 // CELLSUMS: 0 = none; 1 = the 12 k-grid sums of the cell gradient with the filter's derivatives evaluated in place (double
-// precision, eval_point<true>); 2 = the same sums from the derivative table `dG4` (kfilter_deriv_kernel), in the working precision
-// per thread and in double across threads.  cpart_in / cpart_out (mode 2, nullable): the per-wave cell-gradient partial sums of the
-// co-scheduled pair kernel (9 doubles per wave, n_sr_part waves), pre-reduced per tile like sr_part.
+// precision, eval_point<true>), one 12-value row per tile (general autograd nodes).
+// The ENERGY STEP's cell gradient takes nothing but one store per k-point from this kernel: wbuf (nullable) receives
+// w = mu |rho^|^2 on the half grid, and the sums against the filter's derivative table are formed by rider workgroups of the
+// NEXT launch (cell_rider_body below) -- the x stage is one tile per CU at 64^3, a chain of latencies, and whatever is put on
+// that chain is paid in full (sums formed here, in the middle or behind the stores, cost 7 us of a 7.8 us kernel).
 struct XCellExtra {
-  const void* dG4;
-  const double* cpart_in;
-  double* cpart_out;
-  int* ticket;  // nullable: the ticket counter of cellgrad_finalize_kernel (behind the partials it will read), cleared here
+  void* wbuf;
 };
 template <typename T, int CELLSUMS>
 __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
@@ -957,7 +1070,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
                                                 double* __restrict__ partials, double* __restrict__ epart,
                                                 const double* __restrict__ sr_part, int n_sr_part, unsigned tile_id,
                                                 unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x,
-                                                const XCellExtra& xc = XCellExtra{nullptr, nullptr, nullptr, nullptr}) {
+                                                const XCellExtra& xc = XCellExtra{nullptr}) {
   // rows padded by one element (as in the y-column stage): the passes give consecutive lanes consecutive groups of x, i.e. a
   // stride of whole rows -- with KZ = 8 complex floats (64 bytes) per row that is 4 distinct bank groups for 32 lanes
   const int KZ = 1 << kzs, KP = KZ + kXPad;
@@ -979,26 +1092,6 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
     for (int i = lo + tid; i < hi; i += 64) {
       sr0 += sr_part[2 * i];
       sr1 += sr_part[2 * i + 1];
-    }
-  }
-  if constexpr (CELLSUMS == 2) {
-    if (xc.cpart_in && xc.cpart_out && active && tid < 64) {  // uniform per wave
-      const int per = (n_sr_part + int(n_tiles) - 1) / int(n_tiles);
-      const int lo = int(tile_id) * per, hi = min(lo + per, n_sr_part);
-      double cp[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) cp[k] = 0.0;
-      for (int i = lo + tid; i < hi; i += 64) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cp[k] += xc.cpart_in[9 * int64_t(i) + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        double v = cp[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (tid == 0) xc.cpart_out[9 * int64_t(tile_id) + k] = v;
-      }
     }
   }
   Cplx<T>* col = hat + (int64_t(c) * nx * ny + ky) * nzh + kz0;  // element (x, z): col[x * ny * nzh + z]
@@ -1046,108 +1139,11 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       }
     }
   }
-  typedef T T4v __attribute__((ext_vector_type(4)));
-  const T4v* __restrict__ dG4 = reinterpret_cast<const T4v*>(xc.dG4);
-  T4v dpre[CELLSUMS == 2 ? kGPrefetch : 1];
-  if constexpr (CELLSUMS == 2) {
-    if (g_prefetched) {
-#pragma unroll
-      for (int u = 0; u < kGPrefetch; ++u) {
-        const int idx = tid + u * nthr;
-        const int x = idx >> kzs, z = idx & (KZ - 1);
-        dpre[u] = T4v{T(0), T(0), T(0), T(0)};
-        if (idx < n_el && z < kzn) {
-          const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
-          dpre[u] = dG4[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
-        }
-      }
-    }
-  }
   __syncthreads();
   // ---- forward, decimation in frequency (natural in, bit-reversed out): KZ sequences of length nx, element x of column z at
   //      tile[x * KP + z] ----
   lds_fft_radix2<T, false, false, MIPME_FFT_BFAST ? 1 : 0>(tile, log2nx, KZ, 1, KP, tw, nx, tid, nthr);
   if (dc && active && ky == 0 && kz0 == 0 && tid == 0) dc[c] = tile[0].re;  // k = 0 (bit reversal maps 0 to 0)
-  if constexpr (CELLSUMS == 2) {
-    // moments of w = mu |rho^|^2 against the table: M1[e][d] = sum w alpha f_e f_d (symmetric), M2[c][d] = sum w beta_c f_d, from
-    // which   K[c][d] = 2 pi sum_k w dG/dk_c f_d = 2 pi (2 pi sum_e inv[c][e] M1[e][d] - h_c M2[c][d]),
-    //         H[c]    = sum_k w dG/dh_c        = -2 pi sum_e inv[c][e] M2[c][e]
-    T m1[6], m2[9];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) m1[i] = T(0);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) m2[i] = T(0);
-    const T fy = T(fft_freq(ky, ny));
-    int u_c = 0;
-    for (int idx = tid; idx < n_el; idx += nthr, ++u_c) {
-      const int x = idx >> kzs, z = idx & (KZ - 1);
-      if (z < kzn) {
-        const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
-        const int iz = kz0 + z;
-        T4v d4;
-        if (g_prefetched) {
-          d4 = T4v{T(0), T(0), T(0), T(0)};
-#pragma unroll
-          for (int u = 0; u < kGPrefetch; ++u) d4 = u == u_c ? dpre[u] : d4;
-        } else {
-          d4 = dG4[c * G_stride + (int64_t(kx) * ny + ky) * nzh + iz];
-        }
-        const Cplx<T> v = tile[x * KP + z];
-        const bool edge = (iz == 0) || ((kg.nz % 2 == 0) && (iz == kg.nz / 2));
-        const T w = (v.re * v.re + v.im * v.im) * (edge ? T(1) : T(2));
-        const T fx = T(fft_freq(kx, nx)), fz = T(iz);
-        const T wa = w * d4.x;
-        const T wax = wa * fx, way = wa * fy, waz = wa * fz;
-        m1[0] += wax * fx; m1[1] += wax * fy; m1[2] += wax * fz;
-        m1[3] += way * fy; m1[4] += way * fz; m1[5] += waz * fz;
-        const T wb0 = w * d4.y, wb1 = w * d4.z, wb2 = w * d4.w;
-        m2[0] += wb0 * fx; m2[1] += wb0 * fy; m2[2] += wb0 * fz;
-        m2[3] += wb1 * fx; m2[4] += wb1 * fy; m2[5] += wb1 * fz;
-        m2[6] += wb2 * fx; m2[7] += wb2 * fy; m2[8] += wb2 * fz;
-      }
-    }
-    __shared__ double mred[8][15];
-    __shared__ double msum[15 + 12];  // the 15 block sums, then inv[9] and h[3] (LDS: indexed by thread below)
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < 15; ++i) {
-      double v = double(i < 6 ? m1[i < 6 ? i : 0] : m2[i >= 6 ? i - 6 : 0]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) mred[wave][i] = v;
-    }
-    __syncthreads();
-    if (tid < 15) {
-      double v = 0.0;
-      for (int w = 0; w < (nthr + 63) / 64; ++w) v += mred[w][tid];
-      msum[tid] = v;
-    } else if (tid == 15) {  // (static indices: scalar loads of the by-value argument)
-#pragma unroll
-      for (int i = 0; i < 9; ++i) msum[15 + i] = kg.inv[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) msum[24 + i] = kg.h[i];
-    }
-    __syncthreads();
-    if (tid < 12 && active) {
-      double out;
-      if (tid < 9) {
-        const int cc = tid / 3, d = tid % 3;
-        double a = 0.0;
-        for (int e = 0; e < 3; ++e) {
-          const int lo = e < d ? e : d, hi = e < d ? d : e;
-          a += msum[15 + 3 * cc + e] * msum[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];  // symmetric M1: 00 01 02 11 12 22
-        }
-        out = 2.0 * kPi * (2.0 * kPi * a - msum[24 + cc] * msum[6 + 3 * cc + d]);
-      } else {
-        const int cc = tid - 9;
-        double a = 0.0;
-        for (int e = 0; e < 3; ++e) a += msum[15 + 3 * cc + e] * msum[6 + 3 * cc + e];
-        out = -2.0 * kPi * a;
-      }
-      partials[int64_t(tile_id) * 12 + tid] = out;
-    }
-    if (xc.ticket && tile_id == 0 && tid == 0) *xc.ticket = 0;
-  }
   if constexpr (CELLSUMS == 1) {
     double acc[12];
 #pragma unroll
@@ -1212,6 +1208,12 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
         const int iz = kz0 + z;
         const bool edge = iz == 0 || iz == nz_full / 2;
         esum += (edge ? 1.0 : 2.0) * double(gk) * (double(v.re) * double(v.re) + double(v.im) * double(v.im));
+      }
+      if (xc.wbuf) {  // uniform
+        const int iz = kz0 + z;
+        const bool edge = iz == 0 || iz == nz_full / 2;
+        static_cast<T*>(xc.wbuf)[(int64_t(c) * nx + kx) * ny * nzh + int64_t(ky) * nzh + iz] =
+            (edge ? T(1) : T(2)) * (v.re * v.re + v.im * v.im);
       }
       v.re *= gk;
       v.im *= gk;
@@ -1363,6 +1365,16 @@ int64_t xconv_blocks(const mipme_fft_plan* p) {
   return int64_t((nzh + KZ - 1) / KZ) * p->ny * p->batch;
 }
 
+// wavefronts per tile of the x stage in its default shape (rows per tile of the energy step's cell sums, XCellExtra)
+int64_t xconv_waves(const mipme_fft_plan* p) {
+  const size_t cs = p->dtype == MIPME_F32 ? 8 : 16;
+  int kzs = p->dtype == MIPME_F32 ? 3 : 2;
+  while (kzs > 0 && cs * (size_t(p->nx) << kzs) > 32768) --kzs;
+  int threads = (p->nx >> 2) << kzs;
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  return (threads + 63) / 64;
+}
+
 // cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
 // One persistent launch for the whole convolution (+ riding row workgroups of the pair sum), when the plan allows it
 static bool conv_persistent_ok(const mipme_fft_plan* p);
@@ -1438,12 +1450,11 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
   const size_t lds = cs * (size_t(p->nx) * (size_t(KZ) + kXPad) + size_t(p->nx / 2));
   int threads = (p->nx >> 2) << kzs;  // one 4-point group per thread and pass
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
-  const bool table = cell_partials && cc && cc->G_deriv;
   // with the cell sums evaluated in place every element of the tile costs ~700 double-precision instructions
   // (eval_point<true>): at 64^3 that was four elements per thread in ONE wave per SIMD, a serial stream with nothing to overlap
   // its latencies -- 256 threads (0.1217 -> 0.1170 ms for energy + forces + dE/dcell as a graph; 512 threads with launch bounds
-  // to match: 0.1252).  From the table they are a dozen FMAs per element and the launch keeps its shape.
-  if (cell_partials && !table) threads = 256;
+  // to match: 0.1252).  The energy step (cc) leaves them to the riders of the next launch.
+  if (cell_partials) threads = 256;
   KGeom kg{};
   KPot kp{};
   if (cell_partials) {
@@ -1452,13 +1463,23 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     if (rc) return rc;
     kg = make_kgeom(cell_mesh);
   }
-  XCellExtra xc{nullptr, nullptr, nullptr, nullptr};
-  if (table) {
-    xc.dG4 = cc->G_deriv;
-    xc.cpart_in = cc->cpart_in;
-    xc.cpart_out = cc->cpart_out;
-    if (cc->legacy_ticket)
-      xc.ticket = reinterpret_cast<int*>((double*)cell_partials + int64_t(grid) * 12 + int64_t(kFinalizeBlocksDecl) * kFinalizeNVDecl);
+  XCellExtra xc{cc ? cc->wbuf : nullptr};
+  CellRider rider{};
+  if (cc) {
+    MIPME_REQUIRE(p->batch == 1 && cc->G_deriv && cc->wbuf && cc->rows && cc->n_riders > 0,
+                  "the cell riders serve a single mesh and need the derivative table and their buffers");
+    MIPME_REQUIRE(int64_t(p->nx) * p->ny * nzh < (int64_t(1) << 31), "mesh too large for the cell riders' 32-bit indices");
+    rider.n_riders = cc->n_riders;
+    rider.nx = p->nx;
+    rider.ny = p->ny;
+    rider.nzh = nzh;
+    rider.wbuf = cc->wbuf;
+    rider.dG4 = cc->G_deriv;
+    rider.cwave = cc->cwave;
+    rider.n_waves = int(cc->n_waves);
+    rider.epart_k = (const double*)epart;
+    rider.n_tiles = int(grid);
+    rider.rows = cc->rows;
   }
   if (p->own_yz) {
     int rc = yz_planes<T>(p, st, false, mesh_in, hat, nullptr);
@@ -1472,21 +1493,24 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
   xconv_kernel<T, MODE><<<grid, threads, lds, st>>>(p->nx, p->ny, nzh, log2nx, kzs, nchunk, (Cplx<T>*)hat, (const T*)G,      \
                                                     G_stride, (T*)dc, kg, kp, (double*)cell_partials, (double*)epart,        \
                                                     (const double*)sr_part, int(n_sr_part), skip_flag_slot(), xc)
-  if (table)
-    MIPME_XCONV_LAUNCH(2);
-  else if (cell_partials)
+  if (cell_partials)
     MIPME_XCONV_LAUNCH(1);
   else
     MIPME_XCONV_LAUNCH(0);
 #undef MIPME_XCONV_LAUNCH
   MIPME_LAUNCH_CHECK();
   if (p->own_yz) {
-    int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out);
+    int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out, cc ? &rider : nullptr);
     if (rc) return rc;
-  } else if (sizeof(T) == 4) {
-    MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
   } else {
-    MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
+    if (cc) {
+      int rc = cell_riders_alone<T>(st, rider);
+      if (rc) return rc;
+    }
+    if (sizeof(T) == 4)
+      MIPME_CHECK_FFT(hipfftExecC2R(p->inv2d, (hipfftComplex*)hat, (hipfftReal*)mesh_out));
+    else
+      MIPME_CHECK_FFT(hipfftExecZ2D(p->inv2d, (hipfftDoubleComplex*)hat, (hipfftDoubleReal*)mesh_out));
   }
   return MIPME_OK;
 }
@@ -1856,90 +1880,134 @@ int kfilter_deriv_impl(hipStream_t st, const mipme_mesh_t* m, const mipme_potent
 
 // ---- dE/dcell of an energy step (E = sum q V, seed s), assembled by ONE workgroup from partial sums the step's kernels left
 // behind (SURVEY.md Appendix A.5 with g = s q, i.e. psi = (s / 2V) rho):
-//   kpart[t][12]   x stage:  K[c][d] = 2 pi sum_k mu |rho^|^2 dG/dk_c f_d,  H[c] = sum_k mu |rho^|^2 dG/dh_c      (per tile)
-//   ctile[t][9]    x stage's pre-reduction of the pair kernel's per-wave sums  C[i][c] = sum_rows q_a sum_e w_e v'/d sh_i u_c
-//   epart_k[t]     x stage:  sum_k mu G |rho^|^2  (= V sum_a q_a Phi_a: the gather is the adjoint of the spread)
+//   rows[r][25]    cell riders (cell_rider_body): 15 moments of mu |rho^|^2 against the filter's derivative table
+//                    M1[e][d] = sum w alpha f_e f_d (00 01 02 11 12 22),  M2[c][d] = sum w beta_c f_d
+//                  => K[c][d] = 2 pi sum_k w dG/dk_c f_d = 2 pi (2 pi sum_e Ai[c][e] M1[e][d] - h_c M2[c][d]),
+//                     H[c]    = sum_k w dG/dh_c = -2 pi sum_e Ai[c][e] M2[c][e],           h_c = |a_c| / n_c
+//                  then 9 sums of the pair kernel  C[i][c] = sum_rows q_a sum_e w_e v'/d sh_i u_c,
+//                  then E_k = sum_k mu G |rho^|^2  (= V sum_a q_a Phi_a: the gather is the adjoint of the spread)
 //   rpart[b][9]    gather:   R[c][e] = sum_a r_{a,c} (s q_a field_{a,e})                                           (per brick)
 // mesh part  gA[a][b] = -sum_c Ai[c][a] R[c][b] - (s/2V) sum_cd Ai[c][a] K[c][d] Ai[b][d] + dLdV V Ai[b][a]
 //                       + (s/2V) H[a] / (|a_a| n_a) A[a][b],      dLdV = -s E_k / (2 V^2) + s bg Q^2 / V^2
 // pair part  gP[m][c] = s f/2 sum_i Ai[i][m] C[i][c]   (every pair sits in two rows; f = 1/2 for a full list)
-// out: 27 reals: mesh part, pair part, their sum.  31 column sums by 31 groups of 32 lanes, then 18 threads for the 3x3 algebra.
+// out: 27 reals: mesh part, pair part, their sum.  Column sums: 25 groups of 16 lanes (rider rows) and 9 groups of 32 lanes
+// (brick rows), sixteen loads in flight per lane -- a plain accumulation loop is a chain of dependent cold loads (the inputs
+// were written by other XCDs a moment ago): 6.7 us for this kernel --, then 18 threads for the 3x3 algebra.
 template <typename T>
-__global__ __launch_bounds__(1024) void cell_tail_finalize_kernel(mipme_mesh_t m, double bg, double pair_scale, int n_tiles,
-                                                                 int n_bricks, const double* __restrict__ kpart,
-                                                                 const double* __restrict__ ctile,
-                                                                 const double* __restrict__ epart_k,
+__global__ __launch_bounds__(1024) void cell_tail_finalize_kernel(mipme_mesh_t m, double bg, double pair_scale, int n_rows,
+                                                                 int n_bricks, const double* __restrict__ rows,
                                                                  const double* __restrict__ rpart, const T* __restrict__ dc,
                                                                  const T* __restrict__ seed, T* __restrict__ out) {
-  __shared__ double s[32], geo[18];
-  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
-  if (grp < 31) {
-    const double* base;
-    int n, stride;
-    if (grp < 12) {
-      base = kpart + grp, n = n_tiles, stride = 12;
-    } else if (grp < 21) {
-      base = ctile ? ctile + (grp - 12) : nullptr, n = n_tiles, stride = 9;
-    } else if (grp < 30) {
-      base = rpart + (grp - 21), n = n_bricks, stride = 9;
-    } else {
-      base = epart_k, n = n_tiles, stride = 1;
+  __shared__ double gs[34], geo[18], s[31], res[18];
+  {
+    const int t = threadIdx.x;
+    const double* base = nullptr;
+    int n = 0, stride = 1, lanes = 16, l = 0, g = -1;
+    if (t < 16 * kCellRow) {
+      g = t >> 4, l = t & 15, lanes = 16;
+      base = rows + g, n = n_rows, stride = kCellRow;
+    } else if (t < 16 * kCellRow + 32 * 9) {
+      const int u = t - 16 * kCellRow;
+      g = kCellRow + (u >> 5), l = u & 31, lanes = 32;
+      base = rpart + (u >> 5), n = n_bricks, stride = 9;
     }
     double v = 0.0;
-    if (base)
-      for (int i = l; i < n; i += 32) v += base[int64_t(i) * stride];
+    constexpr int B = 16;
+    for (int i0 = l; i0 < n; i0 += lanes * B) {
+      double tmp[B];
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-    if (l == 0) s[grp] = v;
-  } else if (l == 0) {  // the idle 32nd group: cell and inverse cell to LDS with static indices (scalar loads of the by-value
-                        // argument; the 18 threads below index them by thread)
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + lanes * u;
+        tmp[u] = i < n ? base[int64_t(i) * stride] : 0.0;
+      }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      geo[i] = m.cell[i];
-      geo[9 + i] = m.inv_cell[i];
+      for (int u = 0; u < B; ++u) v += tmp[u];
     }
+    // (16-lane groups are aligned to 16, 32-lane groups to 32 -- 16 * 25 = 400 is a multiple of 16 but not of 32: reduce both
+    // with xor steps inside aligned 16-lane halves and combine the halves of a 32-lane group through LDS atomics-free adds)
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    if (g >= 0 && g < kCellRow && l == 0) gs[g] = v;
+    __shared__ double half[9][2];
+    if (g >= kCellRow && (l & 15) == 0) half[g - kCellRow][l >> 4] = v;
+    if (threadIdx.x == 1023) {  // cell and inverse cell to LDS with static indices (scalar loads of the by-value argument; the
+                                // threads below index them by thread)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        geo[i] = m.cell[i];
+        geo[9 + i] = m.inv_cell[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) gs[kCellRow + threadIdx.x] = half[threadIdx.x][0] + half[threadIdx.x][1];
   }
   __syncthreads();
-  __shared__ double res[18];
-  if (threadIdx.x < 18) {
-  const double sd = seed ? double(seed[0]) : 1.0;
-  const double V = m.volume, es = 0.5 * sd / V;
   const double* A = geo;
   const double* Ai = geo + 9;
-  if (threadIdx.x < 9) {
-    const int a = threadIdx.x / 3, b = threadIdx.x % 3;
-    const int nsa = a == 0 ? m.nx : (a == 1 ? m.ny : m.nz);
-    const double Q = double(dc[0]);
-    const double dLdV = -sd * s[30] / (2.0 * V * V) + sd * bg * Q * Q / (V * V);
-    double v = 0.0;
-    for (int c = 0; c < 3; ++c) {
-      v -= Ai[3 * c + a] * s[21 + 3 * c + b];
-      for (int d = 0; d < 3; ++d) v -= es * Ai[3 * c + a] * s[3 * c + d] * Ai[3 * b + d];
+  // s[0..8] = K, s[9..11] = H, s[12..20] = C, s[21..29] = R, s[30] = E_k
+  if (threadIdx.x < 31) {
+    const int t = threadIdx.x;
+    double v;
+    if (t < 9) {
+      const int cc = t / 3, d = t % 3;
+      double a = 0.0;
+      for (int e = 0; e < 3; ++e) {
+        const int lo = e < d ? e : d, hi = e < d ? d : e;
+        a += Ai[3 * cc + e] * gs[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];
+      }
+      const double hc = sqrt(A[3 * cc] * A[3 * cc] + A[3 * cc + 1] * A[3 * cc + 1] + A[3 * cc + 2] * A[3 * cc + 2]) /
+                        double(cc == 0 ? m.nx : (cc == 1 ? m.ny : m.nz));
+      v = 2.0 * kPi * (2.0 * kPi * a - hc * gs[6 + 3 * cc + d]);
+    } else if (t < 12) {
+      const int cc = t - 9;
+      double a = 0.0;
+      for (int e = 0; e < 3; ++e) a += Ai[3 * cc + e] * gs[6 + 3 * cc + e];
+      v = -2.0 * kPi * a;
+    } else if (t < 21) {
+      v = gs[15 + (t - 12)];
+    } else if (t < 30) {
+      v = gs[kCellRow + (t - 21)];
+    } else {
+      v = gs[24];
     }
-    const double norm = sqrt(A[3 * a] * A[3 * a] + A[3 * a + 1] * A[3 * a + 1] + A[3 * a + 2] * A[3 * a + 2]);
-    v += dLdV * V * Ai[3 * b + a] + es * s[9 + a] / (norm * double(nsa)) * A[3 * a + b];
-    out[threadIdx.x] = T(v);
-    res[threadIdx.x] = v;
-  } else {
-    const int mm = (threadIdx.x - 9) / 3, c = (threadIdx.x - 9) % 3;
-    double v = 0.0;
-    for (int i = 0; i < 3; ++i) v += Ai[3 * i + mm] * s[12 + 3 * i + c];
-    v *= sd * pair_scale;
-    out[threadIdx.x] = T(v);
-    res[threadIdx.x] = v;
+    s[t] = v;
   }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const double sd = seed ? double(seed[0]) : 1.0;
+    const double V = m.volume, es = 0.5 * sd / V;
+    if (threadIdx.x < 9) {
+      const int a = threadIdx.x / 3, b = threadIdx.x % 3;
+      const int nsa = a == 0 ? m.nx : (a == 1 ? m.ny : m.nz);
+      const double Q = double(dc[0]);
+      const double dLdV = -sd * s[30] / (2.0 * V * V) + sd * bg * Q * Q / (V * V);
+      double v = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        v -= Ai[3 * c + a] * s[21 + 3 * c + b];
+        for (int d = 0; d < 3; ++d) v -= es * Ai[3 * c + a] * s[3 * c + d] * Ai[3 * b + d];
+      }
+      const double norm = sqrt(A[3 * a] * A[3 * a] + A[3 * a + 1] * A[3 * a + 1] + A[3 * a + 2] * A[3 * a + 2]);
+      v += dLdV * V * Ai[3 * b + a] + es * s[9 + a] / (norm * double(nsa)) * A[3 * a + b];
+      out[threadIdx.x] = T(v);
+      res[threadIdx.x] = v;
+    } else {
+      const int mm = (threadIdx.x - 9) / 3, c = (threadIdx.x - 9) % 3;
+      double v = 0.0;
+      for (int i = 0; i < 3; ++i) v += Ai[3 * i + mm] * s[12 + 3 * i + c];
+      v *= sd * pair_scale;
+      out[threadIdx.x] = T(v);
+      res[threadIdx.x] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x < 9) out[18 + threadIdx.x] = T(res[threadIdx.x] + res[9 + threadIdx.x]);  // the sum, for callers with ONE cell tensor
 }
 
 template <typename T>
-int cell_tail_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, double pair_scale, int64_t n_tiles,
-                            int64_t n_bricks, const void* kpart, const void* ctile, const void* epart_k, const void* rpart,
-                            const void* dc, const void* seed, void* out) {
-  cell_tail_finalize_kernel<T><<<1, 1024, 0, st>>>(*m, bg, pair_scale, int(n_tiles), int(n_bricks), (const double*)kpart,
-                                                  (const double*)ctile, (const double*)epart_k, (const double*)rpart,
-                                                  (const T*)dc, (const T*)seed, (T*)out);
+int cell_tail_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, double pair_scale, int64_t n_rows,
+                            int64_t n_bricks, const void* rows, const void* rpart, const void* dc, const void* seed, void* out) {
+  cell_tail_finalize_kernel<T><<<1, 1024, 0, st>>>(*m, bg, pair_scale, int(n_rows), int(n_bricks), (const double*)rows,
+                                                  (const double*)rpart, (const T*)dc, (const T*)seed, (T*)out);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -1947,9 +2015,9 @@ int cell_tail_finalize_impl(hipStream_t st, const mipme_mesh_t* m, double bg, do
 template int kfilter_deriv_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int kfilter_deriv_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int cell_tail_finalize_impl<float>(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
-                                            const void*, const void*, const void*, const void*, const void*, void*);
+                                            const void*, const void*, const void*, void*);
 template int cell_tail_finalize_impl<double>(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
-                                             const void*, const void*, const void*, const void*, const void*, void*);
+                                             const void*, const void*, const void*, void*);
 template int kfilter_build_impl<float>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int kfilter_build_impl<double>(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template int apply_filter_impl<float>(hipStream_t, int64_t, int, const void*, const void*, void*, void*);

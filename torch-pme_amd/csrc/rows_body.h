@@ -558,6 +558,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     const d2v pAxy = llvm_raw_buffer_load_d2(rec_rs, oA, 0, 0), pAzq = llvm_raw_buffer_load_d2(rec_rs, oA + 16, 0, 0);
     const d2v pBxy = llvm_raw_buffer_load_d2(rec_rs, oB, 0, 0), pBzq = llvm_raw_buffer_load_d2(rec_rs, oB + 16, 0, 0);
     const AtomRecord<double> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
+    const unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
     off += 8 * kRowLanes;
     wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
     wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
@@ -585,6 +586,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       y[u] = c1 * (d2[u] * inv[u]);
     }
     exp_neg_fast2(x, e);
+    constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
+    const bool any_cross = CELL && __builtin_amdgcn_ballot_w64((eA < end && codeA != kCentre) || (eB < end && codeB != kCentre)) != 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
 #pragma unroll
@@ -596,7 +599,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       fx = __builtin_fma(sc, vx[u], fx);
       fy = __builtin_fma(sc, vy[u], fy);
       fz = __builtin_fma(sc, vz[u], fz);
-      if constexpr (CELL) {  // (sc = -w v'/d here: the sign is restored below)
+      if (CELL && any_cross) {  // (wave-uniform: see the packed body; sc = -w v'/d here: the sign is restored below)
         const AtomRecord<double>& sh = u == 0 ? sA : sB;
         const double tx = sc * vx[u], ty = sc * vy[u], tz = sc * vz[u];
         cg[0] = __builtin_fma(sh.x, tx, cg[0]); cg[1] = __builtin_fma(sh.x, ty, cg[1]); cg[2] = __builtin_fma(sh.x, tz, cg[2]);
@@ -610,7 +613,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const double v = wave_sum(valid ? -qa * cg[k] : 0.0);
+        const double v = wave_sum_dpp(valid ? -qa * cg[k] : 0.0);
         if ((threadIdx.x & 63) == 0) args.cpart[9 * w + k] = v;
       }
     }
@@ -714,6 +717,7 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
     const f4v cRB = llvm_raw_buffer_load_f4(rec_rs, int((wB & kAtomMask) << 4), 0, 0);
     const AtomRecord<float> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
+    const unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
     off += 8 * kRowLanes;
     wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
     wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
@@ -736,12 +740,17 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
       fz -= tzA;
       fxy -= tB;
       fz -= tzB;
-      cxy[0] += sA.x * tA; cz[0] += sA.x * tzA;
-      cxy[1] += sA.y * tA; cz[1] += sA.y * tzA;
-      cxy[2] += sA.z * tA; cz[2] += sA.z * tzA;
-      cxy[0] += sB.x * tB; cz[0] += sB.x * tzB;
-      cxy[1] += sB.y * tB; cz[1] += sB.y * tzB;
-      cxy[2] += sB.z * tB; cz[2] += sB.z * tzB;
+      // only pairs that cross a cell boundary contribute (sh = 0 otherwise), and at 9 A in a 68 A box that is no entry at all in
+      // most iterations of most wavefronts: a wave-uniform branch around the twelve instructions
+      constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
+      if (__builtin_amdgcn_ballot_w64((okA && codeA != kCentre) || (okB && codeB != kCentre)) != 0) {
+        cxy[0] += sA.x * tA; cz[0] += sA.x * tzA;
+        cxy[1] += sA.y * tA; cz[1] += sA.y * tzA;
+        cxy[2] += sA.z * tA; cz[2] += sA.z * tzA;
+        cxy[0] += sB.x * tB; cz[0] += sB.x * tzB;
+        cxy[1] += sB.y * tB; cz[1] += sB.y * tzB;
+        cxy[2] += sB.z * tB; cz[2] += sB.z * tzB;
+      }
     } else {
       fxy -= sc.x * vA;
       fz -= sc.x * zA;
@@ -755,7 +764,7 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
       const float qv = valid ? qa : 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const float vx = wave_sum(qv * cxy[i].x), vy = wave_sum(qv * cxy[i].y), vz = wave_sum(qv * cz[i]);
+        const float vx = wave_sum_dpp(qv * cxy[i].x), vy = wave_sum_dpp(qv * cxy[i].y), vz = wave_sum_dpp(qv * cz[i]);
         if ((threadIdx.x & 63) == 0) {
           args.cpart[9 * w + 3 * i] = double(vx);
           args.cpart[9 * w + 3 * i + 1] = double(vy);
