@@ -74,6 +74,8 @@ def parse_args(argv=None):
                     help="independent frames evaluated per rank and step (BASELINE.json configs[3]: --preset cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
+    ap.add_argument("--no-contract", action="store_true",
+                    help="skip the `contract` block (E+F, +dE/dq, +dE/dcell as graphs and eagerly; the TuningTimings protocol)")
     ap.add_argument("--store-distances", action="store_true",
                     help="also store the pair distances the fused pair kernel forms (a by-product nobody reads in an energy + "
                          "forces step; off: they stay in registers)")
@@ -481,6 +483,136 @@ def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
     out["cold_list_note"] = ("cold_list_ms: fresh neighbor_indices / shifts tensors every call (per-list work: radix-sort "
                              "transposition + entry streams, then the same kernels); cold_stream_ms: NeighborStream.update() "
                              "(device cell list writes the pair kernels' rows in place) + the same calculator call")
+    return out
+
+
+def contract_timing(frame, name: str):
+    """The whole first-order autograd contract of the reference on the headline box (rank 0, one GPU): ms per evaluation of
+    {E, F}, {E, F, dE/dq}, {E, F, dE/dq, dE/dcell} as a replayed HIP graph (binned step and live-bin step) and eagerly, and the
+    reference's own timing protocol literally (``tuning/tuner.py:337-373``: clones with ``requires_grad`` on positions, cell,
+    charges; constant ``neighbor_distances``; ``result.sum().backward()``) -- each result against the committed oracle numbers
+    of this box (``tests/golden/workloads.npz``; nothing under oracle/ runs here).  Reference for the contract:
+    ``tests/calculators/test_workflow.py:164-192``."""
+    tpa, w = frame._tpa, frame.w
+    out = {"reference": "tests/calculators/test_workflow.py:164-192 (gradients w.r.t. positions, charges, cell from one backward "
+                        "pass); tuning/tuner.py:337-373 (TuningTimings protocol)"}
+    z = None
+    path = os.path.join(ROOT, "tests", "golden", "workloads.npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        if f"{name}_cell_grad" not in z.files or int(z[f"{name}_n_pairs"]) != w.n_pairs:
+            z = None
+    rng = np.random.default_rng(4242)
+    rng.normal(size=(w.n_atoms, 3))
+    s_vec = rng.normal(size=(w.n_atoms, 1))  # (the checksum vectors of tests/golden/make_workloads_golden.py)
+
+    def errors(E, F, dq=None, dc=None):
+        if z is None:
+            return {"oracle": "no committed contract numbers for this box"}
+        sample = z[f"{name}_sample"]
+        e = {"rel_energy": abs(float(E) - float(z[f"{name}_energy"])) / abs(float(z[f"{name}_energy"]))}
+        Fs = z[f"{name}_force_sample"]
+        e["force_rel_l2_256_atoms"] = float(np.linalg.norm(F.detach().cpu().double().numpy()[sample] - Fs) / np.linalg.norm(Fs))
+        if dq is not None:
+            q_ = dq.detach().cpu().double().numpy()
+            ref = z[f"{name}_charge_grad_sample"]
+            e["charge_grad_rel_l2_256_atoms"] = float(np.linalg.norm(q_[sample, 0] - ref) / np.linalg.norm(ref))
+            e["charge_grad_checksum_rel"] = abs(float((s_vec * q_).sum()) - float(z[f"{name}_charge_grad_dot"])) / (
+                np.linalg.norm(s_vec) * np.linalg.norm(q_))
+        if dc is not None:
+            ref = z[f"{name}_cell_grad"]
+            e["cell_grad_rel_max"] = float(np.abs(dc.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max())
+        return e
+
+    graph = {}
+    for label, kw in (("E+F", {}), ("E+F+dq", dict(charge_gradient=True)),
+                      ("E+F+dq+dcell", dict(charge_gradient=True, cell_gradient=True))):
+        for mode in ("binned", "live"):
+            try:
+                if mode == "binned":
+                    step = tpa.GraphedEnergyForces(frame.calc, frame.q, frame.cell, frame.pos.detach(), frame.pairs, frame.shifts, **kw)
+                else:
+                    step = tpa.GraphedEnergyForces(frame.calc, frame.q, frame.cell, frame.pos.detach(), neighbors=w.cutoff, **kw)
+                res = step()
+                torch.cuda.synchronize()
+                entry = {"ms_per_step": round(min(_event_ms(step.graph.replay, 300, 30) for _ in range(3)), 6),
+                         "fused_in_the_step": bool(step._fused_contract), "live_bins": step._live is not None}
+                entry["vs_oracle"] = errors(res[0], res[1], res[2] if "dq" in label else None,
+                                            res[-1] if "dcell" in label else None)
+                graph[f"{label} ({mode})"] = entry
+                del step
+            except Exception as exc:  # noqa: BLE001
+                graph[f"{label} ({mode})"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    out["graph"] = graph
+
+    # ---- eager: the reference call sequence with more leaves
+    def eager(leaves, weighted, n=60, warm=10):
+        pos = frame.pos.detach().clone().requires_grad_(True)
+        q = frame.q.clone().requires_grad_("q" in leaves)
+        cell = frame.cell.clone().requires_grad_("cell" in leaves)
+
+        def step():
+            pos.grad = q.grad = cell.grad = None
+            d = tpa.pair_distances(pos, frame.pairs, cell, frame.shifts)
+            V = frame.calc(q, cell, pos, frame.pairs, d)
+            E = tpa.weighted_sum(V, q) if weighted else (q * V).sum()
+            E.backward()
+            return E
+
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            E = step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        return {"ms_per_step": round(ms, 5), "vs_oracle": errors(E, -pos.grad, q.grad, cell.grad)}
+
+    out["eager"] = {}
+    for label, leaves in (("E+F", ()), ("E+F+dq", ("q",)), ("E+F+dq+dcell", ("q", "cell"))):
+        out["eager"][f"{label}: (q*V).sum()"] = eager(leaves, False)
+        out["eager"][f"{label}: weighted_sum"] = eager(leaves, True)
+
+    # ---- the reference's TuningTimings protocol, literally
+    d_fixed = tpa.pair_distances(frame.pos.detach(), frame.pairs, frame.cell, frame.shifts).detach().clone()
+    p0, c0, q0 = frame.pos.detach(), frame.cell, frame.q
+
+    def protocol():
+        positions, cell, charges = p0.clone(), c0.clone(), q0.clone()
+        for t in (positions, cell, charges):
+            t.requires_grad_(True)
+        result = frame.calc.forward(positions=positions, charges=charges, cell=cell, neighbor_indices=frame.pairs,
+                                    neighbor_distances=d_fixed)
+        value = result.sum()
+        value.backward(retain_graph=True)
+        return value, positions.grad, charges.grad, cell.grad
+
+    for _ in range(10):
+        protocol()
+    torch.cuda.synchronize()
+    n = 60
+    t0 = time.perf_counter()
+    for _ in range(n):
+        val, gp, gq, gc = protocol()
+    torch.cuda.synchronize()
+    tt = {"ms_per_call": round(1e3 * (time.perf_counter() - t0) / n, 5),
+          "protocol": "positions, cell, charges cloned with requires_grad; constant neighbor_distances; "
+                      "calculator.forward(...).sum().backward(retain_graph=True) -- tuning/tuner.py:350-369"}
+    timer = tpa.tuning.TuningTimings(q0, c0, p0, frame.pairs, d_fixed, n_repeat=20, n_warmup=4)
+    tt["TuningTimings_median_ms"] = round(1e3 * float(timer(frame.calc)), 5)
+    if z is not None and f"{name}_sumseed_cell" in z.files:
+        sample = z[f"{name}_sample"]
+        rp = z[f"{name}_sumseed_pos_sample"]
+        rq = z[f"{name}_sumseed_charge_sample"]
+        rc = z[f"{name}_sumseed_cell"]
+        tt["vs_oracle"] = {
+            "rel_value": abs(float(val) - float(z[f"{name}_sumseed_value"])) / abs(float(z[f"{name}_sumseed_value"])),
+            "positions_grad_rel_l2_256_atoms": float(np.linalg.norm(gp.cpu().double().numpy()[sample] - rp) / np.linalg.norm(rp)),
+            "charges_grad_rel_l2_256_atoms": float(np.linalg.norm(gq.cpu().double().numpy()[sample, 0] - rq) / np.linalg.norm(rq)),
+            "cell_grad_rel_max": float(np.abs(gc.cpu().double().numpy() - rc).max() / np.abs(rc).max()),
+        }
+    out["tuning_protocol"] = tt
     return out
 
 
@@ -997,6 +1129,11 @@ def main(argv=None):
                 out["list_refresh"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_drop_in:
             out["drop_in"] = drop_in_timing(frame)
+        if world == 1 and n_frames == 1 and not args.no_contract and not args.no_drop_in:
+            try:
+                out["contract"] = contract_timing(frame, args.workload)
+            except Exception as exc:  # noqa: BLE001  (keep the line)
+                out["contract"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -401,6 +401,14 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 int64_t mipme_scaled_match_work(int64_t n);
 int mipme_scaled_match_wide(void* stream, int dtype, int64_t n, const void* g, const void* q, void* result, void* host_flag,
                             void* work);
+/* host_flag[0] = 1 if a[i] == b[i] for all i < n (bitwise equal reals of `dtype`, n <= 1024), else 0; host_flag: ONE int32 of
+ * pinned host memory the caller presets to -1 and polls.  For callers that receive a NEW cell tensor every call
+ * (tuning/tuner.py:350-352 clones its inputs; data loaders do the same): the library's host layer then launches the step with
+ * the mesh geometry and filter it cached for the previous cell, this kernel FIRST in the queue, and looks at the verdict after
+ * its last launch -- the 9-value device-to-host copy the reference pays before it can size the mesh
+ * (lib/kvectors.py:17-21) would make the host wait for everything queued before it, every call. */
+int mipme_values_equal(void* stream, int dtype, int64_t n, const void* a, const void* b, void* host_flag);
+
 /* The same decision WITHOUT a host round trip (the poll above makes the host wait for everything queued before it: the eager
  * reference call sequence then runs GPU and host one after the other).  The caller launches mipme_scaled_match with a DEVICE
  * int32 as `host_flag`, announces it with mipme_set_skip_flag(flag) -- kernels launched by THIS THREAD through

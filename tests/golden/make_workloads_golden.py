@@ -7,7 +7,10 @@ these numbers -- the 39 M-pair cfg5 evaluation takes minutes of NumPy and tens o
 
 Per workload `k`: k_energy, k_force_sample (256 atoms, indices k_sample), k_force_sq (sum |F|^2), k_force_dot (sum_a r_a . F_a
 with r = default_rng(4242).normal((N, 3)): a checksum of the whole array), k_potential_dot (sum_a s_a V_a, s likewise),
-k_n_pairs, k_pos_checksum (sum of positions, sum of squares: the synthetic box is the one the numbers belong to)."""
+k_n_pairs, k_pos_checksum (sum of positions, sum of squares: the synthetic box is the one the numbers belong to).  Round 4: the
+whole autograd contract -- k_charge_grad_sample / k_charge_grad_dot (dE/dq), k_cell_grad (dE/dcell, 3x3) -- and the gradients of
+the reference's timing protocol L = V.sum() with constant distances: k_sumseed_{value, pos_sample, pos_dot, charge_sample,
+charge_dot, cell}."""
 import os
 import sys
 import time
@@ -28,8 +31,15 @@ def summarise(w):
     V, cache = O.forward(spec, w.scheme, w.order, w.mesh_spacing, w.charges, w.cell, w.positions, w.pairs, dist,
                          return_cache=True)
     gr = O.backward(cache, w.charges)
-    gpos_d, _ = O.pair_distances_backward(w.positions, w.cell, w.pairs, w.shifts, gr["dist"])
+    gpos_d, gcell_d = O.pair_distances_backward(w.positions, w.cell, w.pairs, w.shifts, gr["dist"])
     F = -(gr["positions"] + gpos_d)
+    # the rest of the autograd contract of E = sum q V (reference: tests/calculators/test_workflow.py:164-192): dE/dq = V + the
+    # adjoint's charge part, dE/dcell = mesh part + the pair part chained through the distances
+    dEdq = gr["charges"] + V
+    dEdcell = gr["cell"] + gcell_d
+    # ... and of the reference's own timing protocol (tuning/tuner.py:350-369): L = V.sum() with the distances a CONSTANT input
+    # (gradients w.r.t. positions and cell come from the mesh part alone)
+    gs = O.backward(cache, np.ones_like(w.charges))
     rng = np.random.default_rng(4242)
     r = rng.normal(size=(w.n_atoms, 3))
     s = rng.normal(size=(w.n_atoms, 1))
@@ -42,6 +52,15 @@ def summarise(w):
         "force_sq": float((F * F).sum()),
         "force_dot": float((r * F).sum()),
         "potential_dot": float((s * V).sum()),
+        "charge_grad_sample": dEdq[sample, 0],
+        "charge_grad_dot": float((s * dEdq).sum()),
+        "cell_grad": dEdcell,
+        "sumseed_value": float(V.sum()),
+        "sumseed_pos_sample": gs["positions"][sample],
+        "sumseed_pos_dot": float((r * gs["positions"]).sum()),
+        "sumseed_charge_sample": gs["charges"][sample, 0],
+        "sumseed_charge_dot": float((s * gs["charges"]).sum()),
+        "sumseed_cell": gs["cell"],
         "n_pairs": w.n_pairs,
         "pos_checksum": np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()]),
     }

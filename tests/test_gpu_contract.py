@@ -1,0 +1,263 @@
+"""The whole first-order autograd contract of the reference from ONE energy step: E = sum q V, F = -dE/dr, dE/dq, dE/dcell
+(reference: tests/calculators/test_workflow.py:164-192 differentiates w.r.t. charges, cell, positions in one backward pass;
+tuning/tuner.py:350-369 times exactly that; tests/calculators/test_values_ewald.py:317-356 validates the stress).
+
+Here the gather launch also writes dE/dq = 2 V, and dE/dcell is assembled from partial sums of the pair kernel, of rider workgroups
+of the inverse (y,z) launch (k-grid sums against the filter's derivative table) and of the gather + one single-workgroup launch
+(mipme_kspace_forward_args_t.out_grad_charges / out_grad_cell; mipme_md_args_t.grad_charges / grad_cell).  Every case against the
+oracle (oracle/pme_numpy.py, pinned to the reference's goldens by tests/test_oracle_golden.py): fp64 <= 1e-9 (observed 1e-13),
+fp32 <= 2e-4 of the largest component (observed 5e-6); at the benchmark boxes' full size against tests/golden/workloads.npz."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import torchpme_amd as tpa  # noqa: E402
+from torchpme_amd import ops, workloads  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pme_numpy as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def small_box(seed, triclinic, n_side=7, a=2.3):
+    rng = np.random.default_rng(seed)
+    L = n_side * a
+    g = (np.arange(n_side) + 0.5) * a
+    pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.35, 0.35, (n_side**3, 3))
+    cell = L * np.eye(3)
+    if triclinic:
+        cell = cell + np.array([[0.0, 0.0, 0.0], [0.8, 0.0, 0.0], [-0.5, 0.7, 0.0]])
+        pos = (pos / L) @ cell
+    q = rng.normal(size=(len(pos), 1))
+    q -= q.mean()
+    return pos, cell, q
+
+
+def oracle_contract(spec, scheme, order, h, q, cell, pos, pairs, S, g=None):
+    """E, dE/dr, dE/dq, dE/dcell of E = sum q V (g = None), or the gradients of L = sum g V with the charges held fixed in g."""
+    dist, _ = O.pair_distances(pos, cell, pairs, S)
+    V, cache = O.forward(spec, "P3M" if scheme == "P3M" else "Lagrange", order, h, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, q if g is None else g)
+    gpos, gcell_pair = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    E = float(((q if g is None else g) * V).sum())
+    return E, gpos + gr["positions"], gr["charges"] + (V if g is None else 0.0), gr["cell"] + gcell_pair, V
+
+
+def setup(dtype, scheme, order, expo, tri, seed=0):
+    pos, cell, q = small_box(11 + order + seed, tri)
+    if expo == 6:
+        q = np.abs(q) + 0.5
+    rc, sm = 5.5, 1.1
+    hmesh = 2 * np.linalg.norm(cell, axis=1).min() / 30
+    pairs, S, _ = tpa.neighbor_list(pos, cell, rc)
+    spec = O.PotentialSpec("coulomb" if expo == 1 else "ipl", expo, sm, 1.0)
+    pot = tpa.CoulombPotential(smearing=sm) if expo == 1 else tpa.InversePowerLawPotential(exponent=6, smearing=sm)
+    Calc = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    calc = Calc(pot, mesh_spacing=hmesh, interpolation_nodes=order)
+    t = dict(q=torch.tensor(q, dtype=dtype, device=DEV), cell=torch.tensor(cell, dtype=dtype, device=DEV),
+             pos=torch.tensor(pos, dtype=dtype, device=DEV), pairs=torch.tensor(pairs, device=DEV),
+             shifts=torch.tensor(S, dtype=dtype, device=DEV))
+    return dict(np=(spec, scheme, order, hmesh, q, cell, pos, pairs, S), calc=calc, rc=rc, **t)
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+CASES = [("P3M", 5, 1, False), ("P3M", 4, 1, True), ("PME", 4, 1, True), ("P3M", 5, 6, False), ("P3M", 3, 1, True),
+         ("P3M", 2, 1, False), ("PME", 7, 1, True), ("PME", 6, 6, True)]
+
+
+@pytest.mark.parametrize("live", [False, True], ids=["binned", "live"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("scheme,order,expo,tri", CASES)
+def test_graphed_step_returns_the_whole_contract(scheme, order, expo, tri, dtype, live):
+    """GraphedEnergyForces(charge_gradient=True, cell_gradient=True): E, F, dE/dq, dE/dcell of two replays against the oracle;
+    fp64 1/r^6 (no cell sums in that pair body) must take the general nodes and agree all the same."""
+    c = setup(dtype, scheme, order, expo, tri)
+    Eo, gpo, dqo, dco, _ = oracle_contract(*c["np"])
+    if live:
+        kw = dict(neighbors=c["rc"], live_bins=True)
+        args = ()
+    else:
+        kw, args = {}, (c["pairs"], c["shifts"])
+    fused_expected = not (expo == 6 and dtype == torch.float64)
+    if live and not fused_expected:
+        with pytest.raises(NotImplementedError):
+            tpa.GraphedEnergyForces(c["calc"], c["q"], c["cell"], c["pos"], *args, charge_gradient=True, cell_gradient=True, **kw)
+        return
+    step = tpa.GraphedEnergyForces(c["calc"], c["q"], c["cell"], c["pos"], *args, charge_gradient=True, cell_gradient=True, **kw)
+    assert step._fused_contract == fused_expected
+    assert (step._live is not None) == live
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    for _ in range(2):
+        E, F, dq, dc = step()
+        torch.cuda.synchronize()
+        assert abs(float(E) - Eo) <= tol * abs(Eo)
+        assert rel(-F, gpo) <= tol and rel(dq, dqo) <= tol and rel(dc, dco) <= tol, (rel(-F, gpo), rel(dq, dqo), rel(dc, dco))
+    # the single flags, and the order of the returned tuple
+    s_q = tpa.GraphedEnergyForces(c["calc"], c["q"], c["cell"], c["pos"], *args, charge_gradient=True, **kw)
+    out = s_q()
+    assert len(out) == 3 and rel(out[2], dqo) <= tol
+    s_c = tpa.GraphedEnergyForces(c["calc"], c["q"], c["cell"], c["pos"], *args, cell_gradient=True, **kw)
+    out = s_c()
+    assert len(out) == 3 and out[2].shape == (3, 3) and rel(out[2], dco) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("reduce", ["weighted_sum", "tensor_ops"])
+@pytest.mark.parametrize("distances", ["virtual", "default"])
+def test_eager_autograd_contract_matches_the_oracle(dtype, reduce, distances):
+    """The reference's call sequence with charges, cell and positions as leaves (tests/calculators/test_workflow.py:164-192):
+    through `weighted_sum` on deferred distances (the gather tail serves all three gradients), through plain tensor ops and the
+    default distance tensor (general nodes) -- same numbers."""
+    c = setup(dtype, "P3M", 5, 1, True, seed=3)
+    Eo, gpo, dqo, dco, _ = oracle_contract(*c["np"])
+    pos = c["pos"].clone().requires_grad_(True)
+    q = c["q"].clone().requires_grad_(True)
+    cell = c["cell"].clone().requires_grad_(True)
+    d = tpa.pair_distances(pos, c["pairs"], cell, c["shifts"], deferred="virtual" if distances == "virtual" else False)
+    V = c["calc"](q, cell, pos, c["pairs"], d)
+    E = tpa.weighted_sum(V, q) if reduce == "weighted_sum" else (q * V).sum()
+    E.backward()
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    assert abs(float(E) - Eo) <= tol * abs(Eo)
+    assert rel(pos.grad, gpo) <= tol and rel(q.grad, dqo) <= tol and rel(cell.grad, dco) <= tol
+    # a seed other than one scales everything
+    pos.grad = q.grad = cell.grad = None
+    d = tpa.pair_distances(pos, c["pairs"], cell, c["shifts"], deferred="virtual" if distances == "virtual" else False)
+    V = c["calc"](q, cell, pos, c["pairs"], d)
+    E = tpa.weighted_sum(V, q) if reduce == "weighted_sum" else (q * V).sum()
+    (E * -0.37).backward()
+    assert rel(pos.grad, -0.37 * gpo) <= tol and rel(q.grad, -0.37 * dqo) <= tol and rel(cell.grad, -0.37 * dco) <= tol
+
+
+def test_tail_is_used_for_the_deferred_contract():
+    """With deferred distances + weighted_sum the three gradients come out of the forward's launches: no kernel of the backward
+    pass but the scaling of the stored results (launch names recorded by ops.PROFILE)."""
+    c = setup(torch.float32, "P3M", 5, 1, False, seed=5)
+    pos = c["pos"].clone().requires_grad_(True)
+    q = c["q"].clone().requires_grad_(True)
+    cell = c["cell"].clone().requires_grad_(True)
+    ops.PROFILE = {}
+    try:
+        d = tpa.pair_distances(pos, c["pairs"], cell, c["shifts"], deferred="virtual")
+        V = c["calc"](q, cell, pos, c["pairs"], d)
+        node = V.grad_fn
+        E = tpa.weighted_sum(V, q)
+        E.backward()
+        torch.cuda.synchronize()
+        names = set(ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+    assert node.tail is not None and node.tail["grad_q"] is not None and node.tail["grad_cell"] is not None
+    assert "kspace_backward" not in names and "rspace_backward" not in names and "energy_sum" not in names, names
+
+
+def test_sum_seed_of_the_tuning_protocol():
+    """tuning/tuner.py:350-369 literally: clones with requires_grad, constant distances, result.sum().backward() -- gradients
+    w.r.t. positions, charges and cell against the oracle's adjoint for g = 1."""
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        c = setup(dtype, "P3M", 5, 1, True, seed=7)
+        spec, scheme, order, h, qn, celln, posn, pairs, S = c["np"]
+        dist, _ = O.pair_distances(posn, celln, pairs, S)
+        V, cache = O.forward(spec, "P3M", order, h, qn, celln, posn, pairs, dist, return_cache=True)
+        gr = O.backward(cache, np.ones_like(qn))
+        d_fixed = torch.tensor(dist, dtype=dtype, device=DEV)
+        for _ in range(2):
+            positions, cell, charges = c["pos"].clone(), c["cell"].clone(), c["q"].clone()
+            for t in (positions, cell, charges):
+                t.requires_grad_(True)
+            result = c["calc"].forward(positions=positions, charges=charges, cell=cell, neighbor_indices=c["pairs"],
+                                       neighbor_distances=d_fixed)
+            value = result.sum()
+            value.backward(retain_graph=True)
+            assert abs(float(value) - V.sum()) <= tol * np.abs(V).sum()
+            assert rel(positions.grad, gr["positions"]) <= tol
+            assert rel(charges.grad, gr["charges"]) <= tol
+            assert rel(cell.grad, gr["cell"]) <= tol
+
+
+@pytest.mark.parametrize("cfg", ["ionic", "water"])
+def test_fullsize_contract_against_committed_oracle(cfg, golden_dir):
+    """cfg2 (8 000 ions, fp64) and cfg3 (31 944-atom water box, fp32 and fp64) at full size: dE/dq (256 sampled atoms + the
+    whole-array checksum) and dE/dcell against tests/golden/workloads.npz, from the binned and the live-bin graph and from the
+    eager tail; and the TuningTimings protocol's three gradients against the committed g = 1 adjoint."""
+    w = {"ionic": workloads.ionic_box, "water": workloads.water_box}[cfg]()
+    z = np.load(os.path.join(golden_dir, "workloads.npz"))
+    g = {k[len(cfg) + 1:]: z[k] for k in z.files if k.startswith(cfg + "_")}
+    assert int(g["n_pairs"]) == w.n_pairs
+    rng = np.random.default_rng(4242)
+    rng.normal(size=(w.n_atoms, 3))
+    s_vec = rng.normal(size=(w.n_atoms, 1))
+    sample = g["sample"]
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-4)):
+        t = lambda a: torch.tensor(a, dtype=dtype, device=DEV)  # noqa: E731
+        pos, cell, q, shifts = t(w.positions), t(w.cell), t(w.charges), t(w.shifts)
+        pairs = torch.tensor(w.pairs, device=DEV)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=w.smearing), mesh_spacing=w.mesh_spacing,
+                                 interpolation_nodes=w.order)
+        results = {}
+        step = tpa.GraphedEnergyForces(calc, q, cell, pos, pairs, shifts, charge_gradient=True, cell_gradient=True)
+        assert step._fused_contract
+        results["graph"] = tuple(x.clone() for x in step())
+        del step
+        live = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=w.cutoff, charge_gradient=True, cell_gradient=True)
+        results["live"] = tuple(x.clone() for x in live())
+        del live
+        p_, q_, c_ = pos.clone().requires_grad_(True), q.clone().requires_grad_(True), cell.clone().requires_grad_(True)
+        d = tpa.pair_distances(p_, pairs, c_, shifts, deferred="virtual")
+        E = tpa.weighted_sum(calc(q_, c_, p_, pairs, d), q_)
+        E.backward()
+        results["eager"] = (E.detach(), -p_.grad, q_.grad, c_.grad)
+        for name, (E, F, dq, dc) in results.items():
+            dq = dq.cpu().double().numpy()
+            assert abs(float(E) - float(g["energy"])) <= tol * abs(float(g["energy"])), (cfg, dtype, name)
+            assert rel(F.cpu()[sample], g["force_sample"]) <= 10 * tol, (cfg, dtype, name)
+            ref = g["charge_grad_sample"]
+            assert np.abs(dq[sample, 0] - ref).max() <= tol * np.abs(ref).max(), (cfg, dtype, name)
+            assert abs(float((s_vec * dq).sum()) - float(g["charge_grad_dot"])) <= tol * np.linalg.norm(s_vec) * np.linalg.norm(dq)
+            assert rel(dc, g["cell_grad"]) <= 10 * tol, (cfg, dtype, name, rel(dc, g["cell_grad"]))
+        # the reference's timing protocol on this box
+        d_fixed = tpa.pair_distances(pos, pairs, cell, shifts).detach().clone()
+        positions, cl, charges = pos.clone(), cell.clone(), q.clone()
+        for x in (positions, cl, charges):
+            x.requires_grad_(True)
+        value = calc.forward(positions=positions, charges=charges, cell=cl, neighbor_indices=pairs,
+                             neighbor_distances=d_fixed).sum()
+        value.backward(retain_graph=True)
+        assert abs(float(value) - float(g["sumseed_value"])) <= 10 * tol * abs(float(g["sumseed_value"])) + tol * np.abs(w.charges).sum()
+        assert rel(positions.grad.cpu()[sample], g["sumseed_pos_sample"]) <= 10 * tol
+        assert rel(charges.grad.cpu()[sample, 0], g["sumseed_charge_sample"]) <= 10 * tol
+        assert rel(cl.grad, g["sumseed_cell"]) <= 10 * tol
+
+
+def test_c_abi_refuses_what_the_tail_cannot_do():
+    """out_grad_cell without its table / scratch, and out_grad_charges for a full list, are argument errors, not wrong numbers."""
+    import ctypes as C
+
+    from torchpme_amd import _lib
+
+    lib = _lib.load()
+    c = setup(torch.float32, "P3M", 5, 1, False)
+    calc = c["calc"]
+    geom, G = calc._kspace_setup(c["cell"], torch.float32, torch.device(DEV))
+    md = geom.desc(1)
+    plan = _lib.get_plan(torch.device(DEV), torch.float32, geom.ns, 1, geom.plan_store)
+    assert lib.mipme_cell_tail_work(plan.handle, C.byref(md), 1000) > 0
+    assert lib.mipme_cell_tail_work(None, C.byref(md), 1000) == 0
+    D = ops.filter_derivative(geom, calc.potential._descriptor(), torch.float32, torch.device(DEV))
+    assert D.shape == (*G.shape, 4) and bool(torch.isfinite(D).all())
+    # PME has no charge-assignment factor: beta = 0
+    c2 = setup(torch.float32, "PME", 4, 1, False)
+    geom2, G2 = c2["calc"]._kspace_setup(c2["cell"], torch.float32, torch.device(DEV))
+    D2 = ops.filter_derivative(geom2, c2["calc"].potential._descriptor(), torch.float32, torch.device(DEV))
+    assert float(D2[..., 1:].abs().max()) == 0.0 and float(D2[..., 0].abs().max()) > 0.0

@@ -651,6 +651,14 @@ __global__ __launch_bounds__(1024) void scaled_match_kernel(int64_t n, const T* 
 // verdict = result of scaled_match_kernel: {s, 1 or 0}.  1: the upstream gradient is s * charges -- overwrite the general path's
 // (skipped) outputs with the energy-mode expressions from the forward's per-atom sums; 0: leave them.
 template <typename T>
+__global__ __launch_bounds__(64) void values_equal_kernel(int n, const T* __restrict__ a, const T* __restrict__ b, int* host_flag) {
+  bool same = true;
+  for (int i = threadIdx.x; i < n; i += 64) same = same && (a[i] == b[i]);
+  const bool all = __builtin_amdgcn_ballot_w64(!same) == 0;
+  if (threadIdx.x == 0) __hip_atomic_store(host_flag, all ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void energy_select_kernel(int64_t N, const T* __restrict__ verdict, const T* __restrict__ q,
                                                            const T* __restrict__ force, const T* __restrict__ field, T f,
                                                            T* __restrict__ grad_mesh, T* __restrict__ grad_pair) {
@@ -1270,6 +1278,19 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 }
 
 int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }
+
+int mipme_values_equal(void* stream, int dtype, int64_t n, const void* a, const void* b, void* host_flag) {
+  MIPME_REQUIRE(n >= 0 && n <= 1024 && a && b && host_flag, "mipme_values_equal: up to 1024 values, non-NULL buffers");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    values_equal_kernel<float><<<1, 64, 0, st>>>(int(n), (const float*)a, (const float*)b, (int*)host_flag);
+  else if (dtype == MIPME_F64)
+    values_equal_kernel<double><<<1, 64, 0, st>>>(int(n), (const double*)a, (const double*)b, (int*)host_flag);
+  else
+    MIPME_REQUIRE(false, "invalid dtype %d", dtype);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
 
 int mipme_set_skip_flag(const void* device_flag) {
   skip_flag_slot() = (const int*)device_flag;

@@ -28,7 +28,7 @@ class _LiveStep:
         device, dtype = positions.device, positions.dtype
         N = positions.shape[0]
         self.device, self.dtype, self.n_atoms = device, dtype, N
-        geom, G = calculator._kspace_setup(cell, dtype, device)
+        geom, G = calculator._kspace_setup(cell, dtype, device, speculate=False)
         self.geom, self.G = geom, G
         self.md = geom.desc(1)
         self.pot = calculator.potential._descriptor()
@@ -421,7 +421,7 @@ class GraphedFrameBatch:
         for q, cell, pos, pairs, shifts in frames:
             if q.shape[1] != 1:
                 raise ValueError("the frames path handles a single charge channel")
-            geom, G = calculator._kspace_setup(cell, dtype, device)
+            geom, G = calculator._kspace_setup(cell, dtype, device, speculate=False)
             geoms.append(geom)
             Gs.append(G.reshape(-1))
         ns = geoms[0].ns

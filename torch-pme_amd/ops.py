@@ -720,12 +720,10 @@ class _PMEFunction(torch.autograd.Function):
                         cell=None if src_cell is None else src_cell.detach().contiguous(), force=None, partials=None,
                         records=torch.empty((N, 4), dtype=dtype, device=device),
                     )
-                    # speculative force sums: if the backward turns out to be in energy mode they ARE the SR forces
+                    # speculative force sums: if the backward turns out to be in energy mode they ARE the SR forces (the
+                    # matching cell sums: decided below, once it is known whether the gather tail covers the cell gradient)
                     if ENERGY_FAST_PATH and ctx.needs_input_grad[11]:
                         fused["force"] = torch.empty((N, 3), dtype=dtype, device=device)
-                        if src_cell is not None and ctx.needs_input_grad[12]:
-                            fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64,
-                                                            device=device)
             # deferred distances (``pair_distances(..., deferred=True)``): the fused kernel writes them as a by-product
             write_dist = False
             if src is not None and src.pending:
@@ -735,6 +733,11 @@ class _PMEFunction(torch.autograd.Function):
                     write_dist = fused is not None and mask is None and P > 0 and topo.sorted_by_first
                     if not write_dist:
                         src.materialize()
+
+            want_pair_partials = bool(fused is not None and fused["force"] is not None and src_cell is not None
+                                      and ctx.needs_input_grad[12])
+            if want_pair_partials and geom is None:
+                fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
 
             def run_rspace(accumulate):
                 stream = _lib.current_stream(device)
@@ -772,12 +775,6 @@ class _PMEFunction(torch.autograd.Function):
                 rho_hat = cell_partials = None
                 if not plan.xfused or not XFUSED:
                     rho_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
-                elif need_cell:
-                    # speculative, like the force sums: the k-grid sums of the cell gradient for the energy mode, formed by the
-                    # x stage of the fused convolution while rfftn(rho) is in LDS (the backward then needs neither rho^ nor
-                    # the 3-D plans; a general upstream gradient recomputes rho^ from the saved charge mesh)
-                    cell_partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
-                                                device=device)
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
                 phi_atoms = torch.empty((N, Cn), dtype=dtype, device=device) if need_cell else None
@@ -797,16 +794,46 @@ class _PMEFunction(torch.autograd.Function):
                     records_out = fused["records"]
                 # co-scheduled pair sum: the spread launch also carries the row workgroups of the fused distance + pair kernel
                 # (mipme_sr_job_t); the gather then adds the mesh part to the potentials the pair sum wrote
-                job = ent32 = None
-                if (COSCHEDULE and records_out is not None and mask is None and (fused["fmt"] & 0xFF) == 1
-                        and fused["partials"] is None and N > 0):
-                    # the 4-byte entry stream is read by the co-scheduled kernel only (mipme.h, shift_format 2): use it when the
-                    # library will co-schedule -- force sums wanted, 1/r or 1/r^6 with a smearing and no exclusion radius
-                    p_job = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
-                    ent32 = None
-                    if (fused["force"] is not None and p_job in (1, 6) and pot_desc.smearing > 0
-                            and pot_desc.exclusion_radius <= 0):
-                        ent32 = topo.compact_entries(src.shifts, src.shifts_key)
+                ni = ctx.needs_input_grad
+                p_eff = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
+                cosched = bool(COSCHEDULE and records_out is not None and mask is None and (fused["fmt"] & 0xFF) == 1 and N > 0)
+                # the 4-byte entry stream is read by the co-scheduled kernel only (mipme.h, shift_format 2): use it when the
+                # library will co-schedule -- force sums wanted, 1/r or 1/r^6 with a smearing and no exclusion radius
+                ent32 = None
+                if (cosched and fused["force"] is not None and p_eff in (1, 6) and pot_desc.smearing > 0
+                        and pot_desc.exclusion_radius <= 0):
+                    ent32 = topo.compact_entries(src.shifts, src.shifts_key)
+                # Tail of an energy step in the gather launch (mipme_kspace_forward_args_t.out_energy ...): speculative like the
+                # force sums.  If the caller reduces with weighted_sum(V, charges) (see energy_direct below), E and the assembled
+                # position gradient are already there and neither the energy reduction nor the force assembly is launched; and
+                # the rest of the contract rides along (out_grad_charges / out_grad_cell): dE/dq = 2 V for a half list, dE/dcell
+                # from partial sums of the same launches + one single-workgroup launch -- those two also serve the energy mode
+                # of THIS node's backward (lazy distances, plain tensor reductions).
+                symmetric = (not full_list) or bool(topo is not None and topo.fmt_flags)
+                want_q, want_cell, aux_seed = TAIL_REQUEST
+                tail_q = bool(ni[0] or want_q) and symmetric
+                tail_cell = bool(ni[1] or ni[12] or want_cell) and ent32 is not None and not write_dist and slab_axis is None and (
+                    p_eff == 1 or dtype == torch.float32) and src_cell is not None
+                tail_ok = bool(
+                    TAIL_FUSION and cosched and field is not None and fused["force"] is not None and ENERGY_FAST_PATH
+                    and not ni[3] and (tail_q or not ni[0]) and (tail_cell or not (ni[1] or ni[12])) and rho_hat is None
+                    and p_eff in (1, 6) and pot_desc.exclusion_radius <= 0
+                    and (not lazy or tail_q or tail_cell))  # (lazy distances: only for what the tail adds to this node)
+                if not tail_ok:
+                    tail_q = tail_cell = False
+                if not tail_cell:
+                    if want_pair_partials:
+                        # the pair part's cell sums from the generic pair body (no co-scheduled launch with them)
+                        fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
+                        cosched = False
+                    if need_cell and rho_hat is None:
+                        # speculative, like the force sums: the k-grid sums of the cell gradient for the energy mode, formed by
+                        # the x stage of the fused convolution while rfftn(rho) is in LDS (the backward then needs neither rho^
+                        # nor the 3-D plans; a general upstream gradient recomputes rho^ from the saved charge mesh)
+                        cell_partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
+                                                    device=device)
+                job = None
+                if cosched:
                     job = _lib.SrJob(
                         n_atoms=N, row_ptr=topo.row_ptr.data_ptr(),
                         entries_shift=(fused["ent_sh"] if ent32 is None else ent32).data_ptr(),
@@ -825,22 +852,7 @@ class _PMEFunction(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         run_rspace(0)
                         join.record()
-                # Tail of an energy + forces step in the gather launch (mipme_kspace_forward_args_t.out_energy): speculative like
-                # the force sums -- if the caller reduces with weighted_sum(V, charges) and asks for nothing but dE/dpositions
-                # (see energy_direct below), E and the assembled gradient are already there and neither the energy reduction
-                # nor the force assembly is launched.
-                ni = ctx.needs_input_grad
-                p_eff = 1 if pot_desc.kind == _lib.COULOMB else pot_desc.exponent
-                # ... and the rest of the contract rides along (mipme.h, out_grad_charges / out_grad_cell): dE/dq = 2 V for a
-                # half list, dE/dcell from partial sums of the same launches + one single-workgroup launch
-                symmetric = (not full_list) or bool(topo is not None and topo.fmt_flags)
-                want_q, want_cell, aux_seed = TAIL_REQUEST
-                tail_q = bool(ni[0] or want_q) and symmetric
-                tail_cell = bool(ni[1] or ni[12] or want_cell) and ent32 is not None and not write_dist and slab_axis is None and (
-                    p_eff == 1 or dtype == torch.float32) and src_cell is not None
-                if (TAIL_FUSION and job is not None and field is not None and fused["force"] is not None and not lazy
-                        and ENERGY_FAST_PATH and not ni[3] and (tail_q or not ni[0]) and (tail_cell or not (ni[1] or ni[12]))
-                        and rho_hat is None and p_eff in (1, 6) and pot_desc.exclusion_radius <= 0):
+                if tail_ok:
                     seed = SEED_PROMISE
                     if seed is not None and (seed.dtype != dtype or seed.device != device or seed.numel() != 1):
                         seed = None
@@ -856,7 +868,6 @@ class _PMEFunction(torch.autograd.Function):
                         tail["G_deriv"] = filter_derivative(geom, pot_desc, dtype, device)
                         tail["cell_work"] = torch.empty((lib.mipme_cell_tail_work(plan.handle, C.byref(md), N),),
                                                         dtype=torch.float64, device=device)
-                        cell_partials = None  # (the k-grid sums go to cell_work)
                 args = _lib.KspaceForwardArgs(
                     plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if (overlap or job is not None) else 0,
                     mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N, positions=pos.data_ptr(), charges=q.data_ptr(),
@@ -886,7 +897,7 @@ class _PMEFunction(torch.autograd.Function):
                         pos.data_ptr(), q.data_ptr(), moments.data_ptr(), out.data_ptr(),
                     )
                 saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
-                             bins=bins, rho_mesh=rho_mesh if cell_partials is not None else None,
+                             bins=bins, rho_mesh=rho_mesh if (cell_partials is not None or tail_cell) else None,
                              cell_partials=cell_partials)
                 if not overlap and job is None:
                     run_rspace(1)
@@ -983,6 +994,24 @@ class _PMEFunction(torch.autograd.Function):
                         sr_scale = res[:1]
             if sr_scale is not None and ctx.slab_axis is None:
                 gscale = sr_scale
+            # what the forward's gather tail already holds for exactly this upstream gradient (mipme.h, out_grad_charges /
+            # out_grad_cell): dE/dq = 2 V and dE/dcell (mesh part, pair part) per unit of the tail's seed
+            tail = ctx.tail
+            if gscale is not None and tail is not None and (tail["grad_q"] is not None or tail["grad_cell"] is not None):
+                base = tail["aux_seed"] if tail["aux_seed"] is not None else tail["seed"]
+                tscale = sr_scale if base is None else sr_scale / base
+                if need_q and tail["grad_q"] is not None:
+                    grad_q = tail["grad_q"] * tscale
+                    need_q = False
+                if tail["grad_cell"] is not None and (need_cell or need_src_cell):
+                    gc = tail["grad_cell"] * tscale
+                    if need_cell:
+                        grad_cell = gc[0:9].view(3, 3)
+                        need_cell = False
+                    if need_src_cell:
+                        grad_src_cell = gc[9:18].view(3, 3)
+                        need_src_cell = False
+                do_kspace = geom is not None and (need_q or need_cell or need_pos)
             # the mesh force field of the forward gather serves the forces AND (through cellgrad_finalize) the cell gradient
             field = ctx.field if gscale is not None else None
             cell_partials = ctx.cell_partials
@@ -1113,7 +1142,7 @@ class _PMEFunction(torch.autograd.Function):
             if sr_done and mesh_done and ctx.same_positions and need_src_pos and not lazy:
                 # both parts differentiate the same ``positions`` tensor: one kernel, one gradient
                 grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
-                finalize(fused["force"], field, fused["partials"], grad_pos, grad_src_cell)
+                finalize(fused["force"], field, fused["partials"], grad_pos, grad_src_cell if need_src_cell else None)
             else:
                 if mesh_done:
                     grad_pos = torch.empty((N, 3), dtype=dtype, device=device)
@@ -1121,7 +1150,7 @@ class _PMEFunction(torch.autograd.Function):
                 if sr_done:
                     if need_src_pos:
                         grad_src_pos = torch.empty((N, 3), dtype=dtype, device=device)
-                    finalize(fused["force"], None, fused["partials"], grad_src_pos, grad_src_cell)
+                    finalize(fused["force"], None, fused["partials"], grad_src_pos, grad_src_cell if need_src_cell else None)
             if (need_src_pos or need_src_cell) and not sr_done:
                 grad_src_pos = torch.empty((N, 3), dtype=dtype, device=device)
                 partials = None
