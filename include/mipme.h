@@ -212,6 +212,10 @@ typedef struct mipme_kspace_forward_args {
   /* aux_seed (device scalar, nullable = grad_seed): the factor s of out_grad_charges / out_grad_cell, when it is not the one of
    * out_grad_positions -- an MD loop seeds the positions with -1 (forces) and wants dE/dq, dE/dcell themselves */
   const void* aux_seed;
+  /* out_rho_hat (nullable, with rho_hat == NULL: the fused convolution): rfftn(rho) (C,nx,ny,nz/2+1 complex), stored by the x
+   * stage while it holds the values -- what a later mipme_kspace_backward with a cell gradient takes as `rho_hat` (general
+   * upstream gradient: fused convolution with G_deriv; energy mode: the k-grid sums) without a 3-D transform of its own. */
+  void* out_rho_hat;
 } mipme_kspace_forward_args_t;
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
 /* Derivative table of G(k) for out_grad_cell: 4 reals per half-grid point, shape (nx,ny,nz/2+1,4) = {alpha, beta_x, beta_y,
@@ -327,6 +331,11 @@ typedef struct mipme_kspace_backward_args {
   const void* grad_scale;
   const void* mesh_field;
   int64_t kgrid_blocks_ready;
+  /* G_deriv (nullable; mipme_kfilter_build_deriv): with it a general upstream gradient WITH a cell gradient runs the fused
+   * convolution too (psi_hat == NULL allowed; single channel, plans with mipme_fft_plan_xfused): the x stage contracts psi^ with
+   * the saved rho_hat, rider workgroups of the inverse (y,z) launch form the k-grid sums against the table -- no 3-D hipFFT
+   * plans, no influence-function derivatives evaluated per k-point. */
+  const void* G_deriv;
 } mipme_kspace_backward_args_t;
 int mipme_kspace_backward(const mipme_kspace_backward_args_t* args);
 /* Energy mode extras (grad_scale != NULL): mesh_field (nullable; out_field of the forward call) with grad_positions ==

@@ -147,7 +147,7 @@ class KspaceForwardArgs(_VersionedArgs):
         ("out_energy", C.c_void_p), ("out_grad_positions", C.c_void_p), ("grad_seed", C.c_void_p),
         ("nan_flag", C.c_void_p),
         ("out_grad_charges", C.c_void_p), ("out_grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
-        ("aux_seed", C.c_void_p),
+        ("aux_seed", C.c_void_p), ("out_rho_hat", C.c_void_p),
     ]
 
 
@@ -163,7 +163,7 @@ class KspaceBackwardArgs(_VersionedArgs):
         ("psi_mesh", C.c_void_p), ("psi_hat", C.c_void_p), ("hat_work", C.c_void_p), ("chi_mesh", C.c_void_p),
         ("dc", C.c_void_p), ("partials", C.c_void_p), ("grad_positions", C.c_void_p), ("grad_charges", C.c_void_p),
         ("grad_cell", C.c_void_p), ("atom_bins", C.c_void_p), ("grad_scale", C.c_void_p), ("mesh_field", C.c_void_p),
-        ("kgrid_blocks_ready", C.c_int64),
+        ("kgrid_blocks_ready", C.c_int64), ("G_deriv", C.c_void_p),
     ]
 
 

@@ -223,7 +223,7 @@ class Calculator(torch.nn.Module):
             slab_axis = ops._slab_axis(periodic.tolist())
         nan_flag = self._nan_flag_ptr() if geom is not None else None
         if nan_flag is not None:
-            self._nan_shape = [charges.shape[1], *geom.ns]
+            self.__dict__["_nan_shape"] = [charges.shape[1], *geom.ns]
         out = ops.pme_potential(
             charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
             bool(self.full_neighbor_list), slab_axis, nan_flag,
@@ -234,7 +234,7 @@ class Calculator(torch.nn.Module):
             if not self._speculation_held():
                 geom, G = self._kspace_setup(cell, positions.dtype, positions.device, speculate=False)
                 if nan_flag is not None:
-                    self._nan_shape = [charges.shape[1], *geom.ns]
+                    self.__dict__["_nan_shape"] = [charges.shape[1], *geom.ns]
                 out = ops.pme_potential(
                     charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
                     bool(self.full_neighbor_list), slab_axis, nan_flag,
@@ -298,7 +298,8 @@ class PMECalculator(Calculator):
         pot_desc = self.potential._descriptor()
         pkey = (pot_desc.kind, pot_desc.exponent, pot_desc.smearing, pot_desc.prefactor)
         c = self._cache
-        self._speculated = None
+        d = self.__dict__  # (plain attributes: nn.Module.__setattr__ costs ~3 us a time, several times per call)
+        d["_speculated"] = None
         if (
             c is not None
             and c[2] == dtype
@@ -312,28 +313,29 @@ class PMECalculator(Calculator):
                     and tuple(cell.shape) == (3, 3) and not torch.cuda.is_current_stream_capturing()):
                 flag = self._bet_flag
                 if flag is None:
-                    flag = self._bet_flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
-                    self._bet_flag_np = flag.numpy()
+                    flag = d["_bet_flag"] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+                    d["_bet_flag_np"] = flag.numpy()
                 self._bet_flag_np[0] = -1
                 with _lib.on_device(device):
                     _lib.check(_lib.load().mipme_values_equal(_lib.current_stream(device), _lib.dtype_code(dtype), 9,
                                                               cell.data_ptr(), c[8].data_ptr(), flag.data_ptr()))
-                self._speculated = cell
+                d["_speculated"] = cell
                 return c[6], c[7]
         cell_host = cell.detach().to("cpu", torch.float64).numpy()
         ns = ops.ns_mesh_from_cell(cell_host, self.mesh_spacing)
         geom = ops.MeshGeometry(cell_host, ns, self._scheme, self.interpolation_nodes)
         geom.plan_store = self._plan_store
         G = ops.build_filter(geom, pot_desc, dtype, device)
-        self._cache = (weakref.ref(cell), cell._version, dtype, device, pkey, (self.mesh_spacing, self.interpolation_nodes),
+        d["_cache"] = (weakref.ref(cell), cell._version, dtype, device, pkey, (self.mesh_spacing, self.interpolation_nodes),
                        geom, G, cell.detach().to(dtype).clone())
-        self._bet_won = True
+        d["_bet_won"] = True
         return geom, G
 
     def _speculation_held(self) -> bool:
         """Verdict of the comparison ``_kspace_setup`` queued for a new cell tensor (pinned word, polled).  True: the cached
         geometry was the right one, and the cache now answers to the new tensor's identity as well."""
-        cell, self._speculated = self._speculated, None
+        d = self.__dict__
+        cell, d["_speculated"] = self._speculated, None
         flag = self._bet_flag_np
         spins = 0
         while flag[0] == -1:
@@ -343,9 +345,9 @@ class PMECalculator(Calculator):
                 break
         if flag[0] == 1:
             c = self._cache
-            self._cache = (weakref.ref(cell), cell._version) + c[2:]
+            d["_cache"] = (weakref.ref(cell), cell._version) + c[2:]
             return True
-        self._bet_won = False  # (cells that change from call to call: stop betting until a cell is seen twice)
+        d["_bet_won"] = False  # (cells that change from call to call: stop betting until a cell is seen twice)
         return False
 
 
@@ -378,7 +380,7 @@ class PMECalculator(Calculator):
             self.check()  # a NaN seen by an earlier call surfaces here
         out = mod.calc_forward(c[1], charges, cell, positions, neighbor_indices, neighbor_distances)
         if out is not None and self._nan_flag is not None:
-            self._nan_shape = [1, *geom.ns]
+            self.__dict__["_nan_shape"] = [1, *geom.ns]
         return out
 
 

@@ -151,7 +151,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             void* hat_work, void* phi_mesh, void* dc, void* out_lr, void* out_phi, void* bins,
                             void* wait_event, int accumulate, void* out_field, void* out_records,
                             const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail, void* nan_flag,
-                            void* out_grad_cell = nullptr, const void* G_deriv = nullptr, void* cell_work = nullptr) {
+                            void* out_grad_cell = nullptr, const void* G_deriv = nullptr, void* cell_work = nullptr,
+                            void* out_rho_hat = nullptr) {
   int rc;
   CellWork cw{};
   if (out_grad_cell) cw = cell_work_layout(m, N, cell_work);
@@ -196,10 +197,12 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
     int64_t n_sr_part = 0;
     const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
-    const ConvCell cc{G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders)};
+    ConvCell cc{};
+    if (out_grad_cell) cc = ConvCell{G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders), nullptr, nullptr, nullptr, nullptr};
+    cc.rho_hat_out = out_rho_hat;
     STAGE(st, "convolve_xfused", convolve_xfused(plan, st, rho_mesh, G, hat_work, phi_mesh, dc, 0, m, pot, cell_partials,
                                                  tail ? const_cast<void*>(tail->epart_k) : nullptr, sr_part, n_sr_part,
-                                                 nullptr, nan_flag, out_grad_cell ? &cc : nullptr));
+                                                 nullptr, nan_flag, (out_grad_cell || out_rho_hat) ? &cc : nullptr));
   } else {
     STAGE(st, "fft_r2c", fft_forward(plan, st, rho_mesh, rho_hat));
     STAGE(st, "apply_filter", apply_filter_impl<T>(st, Mh, m->n_channels, rho_hat, G, hat_work, dc));
@@ -228,7 +231,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
                              const void* phi_mesh, const void* rho_hat, const void* rho_dc, const void* phi_atoms,
                              void* psi_mesh, void* psi_hat, void* hat_work, void* chi_mesh, void* dc, void* partials,
                              void* grad_pos, void* grad_q, void* grad_cell, void* bins, const void* grad_scale,
-                             const void* mesh_field, int64_t kgrid_blocks_ready) {
+                             const void* mesh_field, int64_t kgrid_blocks_ready, const void* G_deriv) {
   int rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
@@ -267,6 +270,28 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   else
     STAGE(st, "spread", spread_impl<T>(st, m, N, pos, gout, 0.5 / m->volume, psi_mesh));
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+  if (grad_cell && !psi_hat) {
+    // the fused convolution with the cell sums: psi^ is contracted with the saved rho^ by the x stage, the k-grid sums against
+    // the derivative table are formed by the riders of the inverse (y,z) launch -- as 12-value rows for cellgrad_finalize_kernel
+    MIPME_REQUIRE(G_deriv && rho_hat && rho_dc && phi_atoms && partials && grad_pos && m->n_channels == 1,
+                  "fused cell gradient needs G_deriv, rho_hat, rho_dc, phi_atoms, partials, grad_positions and one channel");
+    const int64_t n_riders = std::min<int64_t>(256, std::max<int64_t>(8, Mh / 2048));
+    double* kh = (double*)partials;
+    double* rows = kh + 12 * n_riders + cellgrad_scratch_doubles();
+    void* wbuf = rows + 25 * n_riders;
+    ConvCell cc{G_deriv, nullptr, 0, wbuf, rows, int(n_riders), nullptr, rho_hat, kh,
+                reinterpret_cast<int*>(kh + 12 * n_riders + cellgrad_scratch_doubles() - 1)};
+    STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, m, pot, nullptr, nullptr,
+                                                 nullptr, 0, nullptr, nullptr, &cc));
+    if (bins)
+      STAGE(st, "gather_grad", gather_grad_bricks<T>(st, m, N, bins, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
+    else
+      STAGE(st, "gather_grad", gather_grad_impl<T>(st, m, N, pos, q, gout, phi_mesh, chi_mesh, dc, nullptr, self_c, bg_c, grad_pos, grad_q));
+    STAGE(st, "cellgrad_finalize",
+          cellgrad_finalize_impl<T>(st, m, bg_c, N, partials, pos, grad_pos, gout, phi_atoms, rho_dc, dc, nullptr, grad_cell,
+                                    n_riders, nullptr, nullptr));
+    return MIPME_OK;
+  }
   const bool xfused = !grad_cell && !psi_hat;
   if (xfused) {
     STAGE(st, "convolve_xfused", convolve_xfused(plan, st, psi_mesh, G, hat_work, chi_mesh, dc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));
@@ -818,7 +843,7 @@ static int md_step_t(const mipme_md_args_t& a) {
                                                      a.grad_cell ? cw.cwave : nullptr));
   int64_t n_sr_part = 0;
   const void* sr_part = bins_epart(m, a.n_atoms, a.dtype, a.atom_bins, &n_sr_part);
-  const ConvCell cc{a.G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders)};
+  const ConvCell cc{a.G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders), nullptr, nullptr, nullptr, nullptr};
   STAGE(st, "convolve_xfused", convolve_xfused(a.plan, st, a.rho_mesh, a.G, a.hat_work, a.phi_mesh, a.dc, 0, m, a.pot, nullptr,
                                                const_cast<void*>(tail.epart_k), sr_part, n_sr_part, nullptr, a.nan_flag,
                                                a.grad_cell ? &cc : nullptr));
@@ -923,6 +948,8 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
   MIPME_REQUIRE(a.G && a.rho_mesh && a.hat_work && a.phi_mesh && a.dc, "NULL work buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(a.rho_hat || fft_plan_xfused(a.plan), "rho_hat may only be NULL for plans with a power-of-two nx");
   MIPME_REQUIRE(!a.out_cell_partials || !a.rho_hat, "out_cell_partials is produced by the fused convolution (rho_hat == NULL)");
+  MIPME_REQUIRE(!a.out_rho_hat || (!a.rho_hat && mesh->n_channels == 1),
+                "out_rho_hat is written by the fused convolution (rho_hat == NULL) of a single-channel mesh");
   MIPME_REQUIRE(a.n_atoms == 0 || (a.positions && a.charges && a.out_lr), "NULL atom buffer passed to mipme_kspace_forward");
   MIPME_REQUIRE(!a.atom_bins || bricks_supported(mesh, a.dtype), "atom bins passed for a mesh the brick kernels do not support");
   MIPME_REQUIRE(!a.out_field || (a.atom_bins && mesh->n_channels == 1), "out_field needs atom bins and a single channel");
@@ -974,11 +1001,11 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
             kspace_forward_t<float>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                     a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
-                                    a.out_grad_cell, a.G_deriv, a.cell_work),
+                                    a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat),
             kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                      a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
                                      a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
-                                     a.out_grad_cell, a.G_deriv, a.cell_work));
+                                     a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat));
 }
 
 int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype) {
@@ -1030,8 +1057,8 @@ int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {
   MIPME_REQUIRE(a.pot && a.pot->smearing > 0, "Must specify smearing to use a potential with PMECalculator");
   MIPME_REQUIRE(a.G && a.phi_mesh && (a.grad_scale || (a.psi_mesh && a.hat_work && a.chi_mesh && a.dc)),
                 "NULL work buffer passed to mipme_kspace_backward");
-  MIPME_REQUIRE(a.grad_scale || a.psi_hat || (!a.grad_cell && fft_plan_xfused(a.plan)),
-                "psi_hat may only be NULL without a cell gradient and for plans with a power-of-two nx");
+  MIPME_REQUIRE(a.grad_scale || a.psi_hat || ((!a.grad_cell || a.G_deriv) && fft_plan_xfused(a.plan)),
+                "psi_hat may only be NULL for plans with a power-of-two nx, and with a cell gradient only together with G_deriv");
   MIPME_REQUIRE(a.n_atoms == 0 || (a.positions && a.charges && a.grad_out), "NULL atom buffer passed to mipme_kspace_backward");
   MIPME_REQUIRE(!a.atom_bins || bricks_supported(a.mesh, a.dtype), "atom bins passed for a mesh the brick kernels do not support");
   hipStream_t st = (hipStream_t)a.stream;
@@ -1039,11 +1066,11 @@ int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {
             kspace_backward_t<float>(a.plan, st, a.mesh, a.pot, a.n_atoms, a.positions, a.charges, a.grad_out, a.G, a.phi_mesh,
                                      a.rho_hat, a.rho_dc, a.phi_atoms, a.psi_mesh, a.psi_hat, a.hat_work, a.chi_mesh, a.dc,
                                      a.partials, a.grad_positions, a.grad_charges, a.grad_cell, a.atom_bins, a.grad_scale,
-                                     a.mesh_field, a.kgrid_blocks_ready),
+                                     a.mesh_field, a.kgrid_blocks_ready, a.G_deriv),
             kspace_backward_t<double>(a.plan, st, a.mesh, a.pot, a.n_atoms, a.positions, a.charges, a.grad_out, a.G, a.phi_mesh,
                                       a.rho_hat, a.rho_dc, a.phi_atoms, a.psi_mesh, a.psi_hat, a.hat_work, a.chi_mesh, a.dc,
                                       a.partials, a.grad_positions, a.grad_charges, a.grad_cell, a.atom_bins, a.grad_scale,
-                                      a.mesh_field, a.kgrid_blocks_ready));
+                                      a.mesh_field, a.kgrid_blocks_ready, a.G_deriv));
 }
 
 int mipme_fft_plan_xfused(const mipme_fft_plan* plan) { return plan && fft_plan_xfused(plan) ? 1 : 0; }
@@ -1106,7 +1133,10 @@ int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms) 
   // k-grid partial sums come either from apply_filter_cellgrad (one block per 256 half-grid points) or from the x stage of
   // the fused convolution (at most one block per (ky, kz) column and channel)
   const int64_t xmax = int64_t(mesh->ny) * (mesh->nz / 2 + 1) * mesh->n_channels;
-  return 12 * std::max<int64_t>(cellgrad_blocks(mesh), xmax) + cellgrad_scratch_doubles();
+  // ... or from the riders of the fused general adjoint (G_deriv): 12 + 25 doubles per rider and one real per half-grid point
+  const int64_t Mh = int64_t(mesh->nx) * mesh->ny * (mesh->nz / 2 + 1);
+  const int64_t fused = 37 * 256 + Mh;
+  return std::max<int64_t>(12 * std::max<int64_t>(cellgrad_blocks(mesh), xmax), fused) + cellgrad_scratch_doubles();
 }
 
 int mipme_slab_forward(void* stream, int dtype, int axis, const mipme_mesh_t* mesh, double prefactor, int64_t n_atoms,

@@ -242,7 +242,11 @@ struct ConvCell {
   int64_t n_waves;
   void* wbuf;           // (nx, ny, nz/2+1) reals
   double* rows;         // [n_riders][25]
-  int n_riders;
+  int n_riders;         // 0: no riders (only rho_hat_out)
+  void* rho_hat_out;    // nullable: rfftn(mesh_in), natural layout, stored by the x stage (forward pass, for a later backward)
+  const void* rho_hat_in;  // nullable: the general adjoint -- w = mu Re[rho^ conj psi^] instead of mu |rho^|^2
+  double* kh_rows;      // nullable: 12 sums K[c][d], H[c] per rider, the rows cellgrad_finalize_kernel reads
+  int* ticket;          // ... and its ticket counter, cleared by the first rider
 };
 
 // Row workgroups of the co-scheduled pair sum that ride on the persistent convolution launch instead of the spread launch:

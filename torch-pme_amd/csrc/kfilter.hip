@@ -809,6 +809,11 @@ struct CellRider {
   const double* epart_k;  // nullable
   int n_tiles;
   double* rows;  // [n_riders][kCellRow]
+  // general adjoint (nullable): also the 12 sums K[c][d], H[c] of this rider's moments, as cellgrad_finalize_kernel reads them
+  // (one 12-value row per rider), and its ticket counter cleared
+  double* kh_rows;
+  int* ticket;
+  double inv[9], h[3];
 };
 
 template <typename T>
@@ -871,10 +876,43 @@ __device__ __forceinline__ void cell_rider_body(const CellRider& r, unsigned rid
     if (lane == 0) red[wave * kCellRow + i] = double(v);
   }
   __syncthreads();
+  double total = 0.0;
   if (tid < kCellRow) {
-    double v = 0.0;
-    for (int w = 0; w < (nthr + 63) / 64; ++w) v += red[w * kCellRow + tid];
-    r.rows[size_t(rider) * kCellRow + tid] = v;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) total += red[w * kCellRow + tid];
+    r.rows[size_t(rider) * kCellRow + tid] = total;
+  }
+  if (r.kh_rows) {  // uniform
+    __syncthreads();
+    if (tid < 15) red[tid] = total;
+    __syncthreads();
+    if (tid < 12) {
+      double out;
+      if (tid < 9) {
+        const int cc = tid / 3, d = tid % 3;
+        double a = 0.0;
+        for (int e = 0; e < 3; ++e) {
+          const int lo = e < d ? e : d, hi = e < d ? d : e;
+          const double inv_ce = cc == 0 ? (e == 0 ? r.inv[0] : e == 1 ? r.inv[1] : r.inv[2])
+                                        : cc == 1 ? (e == 0 ? r.inv[3] : e == 1 ? r.inv[4] : r.inv[5])
+                                                  : (e == 0 ? r.inv[6] : e == 1 ? r.inv[7] : r.inv[8]);
+          a += inv_ce * red[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];
+        }
+        const double hc = cc == 0 ? r.h[0] : (cc == 1 ? r.h[1] : r.h[2]);
+        out = 2.0 * kPi * (2.0 * kPi * a - hc * red[6 + 3 * cc + d]);
+      } else {
+        const int cc = tid - 9;
+        double a = 0.0;
+        for (int e = 0; e < 3; ++e) {
+          const double inv_ce = cc == 0 ? (e == 0 ? r.inv[0] : e == 1 ? r.inv[1] : r.inv[2])
+                                        : cc == 1 ? (e == 0 ? r.inv[3] : e == 1 ? r.inv[4] : r.inv[5])
+                                                  : (e == 0 ? r.inv[6] : e == 1 ? r.inv[7] : r.inv[8]);
+          a += inv_ce * red[6 + 3 * cc + e];
+        }
+        out = -2.0 * kPi * a;
+      }
+      r.kh_rows[size_t(rider) * 12 + tid] = out;
+    }
+    if (r.ticket && rider == 0 && tid == 0) *r.ticket = 0;
   }
 }
 
@@ -1060,8 +1098,13 @@ static constexpr int kXPad = MIPME_X_PAD;  // elements of padding per LDS row of
 // w = mu |rho^|^2 on the half grid, and the sums against the filter's derivative table are formed by rider workgroups of the
 // NEXT launch (cell_rider_body below) -- the x stage is one tile per CU at 64^3, a chain of latencies, and whatever is put on
 // that chain is paid in full (sums formed here, in the middle or behind the stores, cost 7 us of a 7.8 us kernel).
+// rho_hat_out (nullable): the tile before the product, i.e. rfftn(mesh_in) in its natural (kx, ky, kz) layout -- kept by a forward
+// pass whose backward may need it; rho_hat_in (nullable, backward pass): w = mu Re[rho^ conj psi^] instead (the general adjoint's
+// dL/dG), rho^ prefetched with the tile.
 struct XCellExtra {
   void* wbuf;
+  void* rho_hat_out;
+  const void* rho_hat_in;
 };
 template <typename T, int CELLSUMS>
 __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
@@ -1070,7 +1113,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
                                                 double* __restrict__ partials, double* __restrict__ epart,
                                                 const double* __restrict__ sr_part, int n_sr_part, unsigned tile_id,
                                                 unsigned n_tiles, bool active, int tid, int nthr, int grp, char* smem_x,
-                                                const XCellExtra& xc = XCellExtra{nullptr}) {
+                                                const XCellExtra& xc = XCellExtra{nullptr, nullptr, nullptr}) {
   // rows padded by one element (as in the y-column stage): the passes give consecutive lanes consecutive groups of x, i.e. a
   // stride of whole rows -- with KZ = 8 complex floats (64 bytes) per row that is 4 distinct bank groups for 32 lanes
   const int KZ = 1 << kzs, KP = KZ + kXPad;
@@ -1136,6 +1179,20 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       if (idx < n_el && z < kzn) {
         const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
         gpre[u] = G[c * G_stride + (int64_t(kx) * ny + ky) * nzh + kz0 + z];
+      }
+    }
+  }
+  Cplx<T> rpre[kGPrefetch];
+  const Cplx<T>* __restrict__ rho_in = static_cast<const Cplx<T>*>(xc.rho_hat_in);
+  if (rho_in && g_prefetched) {  // uniform
+#pragma unroll
+    for (int u = 0; u < kGPrefetch; ++u) {
+      const int idx = tid + u * nthr;
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      rpre[u] = Cplx<T>{T(0), T(0)};
+      if (idx < n_el && z < kzn) {
+        const int kx = int(__brev(unsigned(x)) >> (32 - log2nx));
+        rpre[u] = rho_in[(int64_t(c) * nx + kx) * ny * nzh + int64_t(ky) * nzh + kz0 + z];
       }
     }
   }
@@ -1209,11 +1266,24 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
         const bool edge = iz == 0 || iz == nz_full / 2;
         esum += (edge ? 1.0 : 2.0) * double(gk) * (double(v.re) * double(v.re) + double(v.im) * double(v.im));
       }
-      if (xc.wbuf) {  // uniform
+      if (xc.wbuf || xc.rho_hat_out) {  // uniform
         const int iz = kz0 + z;
-        const bool edge = iz == 0 || iz == nz_full / 2;
-        static_cast<T*>(xc.wbuf)[(int64_t(c) * nx + kx) * ny * nzh + int64_t(ky) * nzh + iz] =
-            (edge ? T(1) : T(2)) * (v.re * v.re + v.im * v.im);
+        const int64_t at = (int64_t(c) * nx + kx) * ny * nzh + int64_t(ky) * nzh + iz;
+        if (xc.rho_hat_out) static_cast<Cplx<T>*>(xc.rho_hat_out)[at] = v;
+        if (xc.wbuf) {
+          const bool edge = iz == 0 || iz == nz_full / 2;
+          Cplx<T> r = v;
+          if (rho_in) {
+            if (g_prefetched) {
+              r = Cplx<T>{T(0), T(0)};
+#pragma unroll
+              for (int u = 0; u < kGPrefetch; ++u) r = u == u_pre ? rpre[u] : r;
+            } else {
+              r = rho_in[at];
+            }
+          }
+          static_cast<T*>(xc.wbuf)[at] = (edge ? T(1) : T(2)) * (r.re * v.re + r.im * v.im);
+        }
       }
       v.re *= gk;
       v.im *= gk;
@@ -1463,12 +1533,21 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     if (rc) return rc;
     kg = make_kgeom(cell_mesh);
   }
-  XCellExtra xc{cc ? cc->wbuf : nullptr};
+  XCellExtra xc{cc ? cc->wbuf : nullptr, cc ? cc->rho_hat_out : nullptr, cc ? cc->rho_hat_in : nullptr};
   CellRider rider{};
-  if (cc) {
-    MIPME_REQUIRE(p->batch == 1 && cc->G_deriv && cc->wbuf && cc->rows && cc->n_riders > 0,
+  const bool riders = cc && cc->n_riders > 0;
+  if (riders) {
+    MIPME_REQUIRE(p->batch == 1 && cc->G_deriv && cc->wbuf && cc->rows,
                   "the cell riders serve a single mesh and need the derivative table and their buffers");
     MIPME_REQUIRE(int64_t(p->nx) * p->ny * nzh < (int64_t(1) << 31), "mesh too large for the cell riders' 32-bit indices");
+    if (cc->kh_rows) {
+      MIPME_REQUIRE(cell_mesh, "the K / H sums of the riders need the mesh descriptor");
+      const KGeom kg2 = make_kgeom(cell_mesh);
+      for (int i = 0; i < 9; ++i) rider.inv[i] = kg2.inv[i];
+      for (int i = 0; i < 3; ++i) rider.h[i] = kg2.h[i];
+      rider.kh_rows = cc->kh_rows;
+      rider.ticket = cc->ticket;
+    }
     rider.n_riders = cc->n_riders;
     rider.nx = p->nx;
     rider.ny = p->ny;
@@ -1500,10 +1579,10 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
 #undef MIPME_XCONV_LAUNCH
   MIPME_LAUNCH_CHECK();
   if (p->own_yz) {
-    int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out, cc ? &rider : nullptr);
+    int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out, riders ? &rider : nullptr);
     if (rc) return rc;
   } else {
-    if (cc) {
+    if (riders) {
       int rc = cell_riders_alone<T>(st, rider);
       if (rc) return rc;
     }

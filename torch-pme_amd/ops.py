@@ -826,12 +826,17 @@ class _PMEFunction(torch.autograd.Function):
                         # the pair part's cell sums from the generic pair body (no co-scheduled launch with them)
                         fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
                         cosched = False
-                    if need_cell and rho_hat is None:
+                    if need_cell and rho_hat is None and Cn > 1:
                         # speculative, like the force sums: the k-grid sums of the cell gradient for the energy mode, formed by
                         # the x stage of the fused convolution while rfftn(rho) is in LDS (the backward then needs neither rho^
                         # nor the 3-D plans; a general upstream gradient recomputes rho^ from the saved charge mesh)
                         cell_partials = torch.empty((lib.mipme_cellgrad_partials_size(C.byref(md), N),), dtype=torch.float64,
                                                     device=device)
+                # one channel: the x stage keeps rfftn(rho) itself (a 1 MB store at 64^3) -- the backward pass forms the k-grid
+                # sums from it in either mode, the general one with the fused convolution (mipme.h, G_deriv)
+                rho_keep = None
+                if need_cell and rho_hat is None and Cn == 1:
+                    rho_keep = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 job = None
                 if cosched:
                     job = _lib.SrJob(
@@ -883,7 +888,7 @@ class _PMEFunction(torch.autograd.Function):
                     out_grad_cell=None if tail is None else _lib.ptr(tail["grad_cell"]),
                     G_deriv=None if tail is None else _lib.ptr(tail.get("G_deriv")),
                     cell_work=None if tail is None else _lib.ptr(tail.get("cell_work")),
-                    aux_seed=None if tail is None else _lib.ptr(tail["aux_seed"]),
+                    aux_seed=None if tail is None else _lib.ptr(tail["aux_seed"]), out_rho_hat=_lib.ptr(rho_keep),
                 )
                 _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
@@ -896,7 +901,9 @@ class _PMEFunction(torch.autograd.Function):
                         "slab_forward", lib.mipme_slab_forward, st, dt, slab_axis, C.byref(md), pot_desc.prefactor, N,
                         pos.data_ptr(), q.data_ptr(), moments.data_ptr(), out.data_ptr(),
                     )
-                saved = dict(phi_mesh=phi_mesh, rho_hat=rho_hat if need_cell else None, rho_dc=dc, phi_atoms=phi_atoms,
+                ctx.rho_kept = rho_keep is not None
+                saved = dict(phi_mesh=phi_mesh, rho_hat=(rho_hat if rho_keep is None else rho_keep) if need_cell else None,
+                             rho_dc=dc, phi_atoms=phi_atoms,
                              bins=bins, rho_mesh=rho_mesh if (cell_partials is not None or tail_cell) else None,
                              cell_partials=cell_partials)
                 if not overlap and job is None:
@@ -958,6 +965,7 @@ class _PMEFunction(torch.autograd.Function):
             if tag is not None and tag[0] == q.data_ptr() and tag[1] == tuple(q.shape) and tag[2] == q._version:
                 sr_scale = tag[3]  # enough for the pair part
             elif (ENERGY_FAST_PATH and ENERGY_DETECT and tag is None and N > 0 and (fused is not None or do_kspace)
+                  and not (N > 1 and grad_out.stride(0) == 0)  # an expanded scalar (``V.sum().backward()``): not gE * charges
                   and not torch.cuda.is_current_stream_capturing()):
                 # no tag: the caller reduced with plain tensor ops, ``(charges * V).sum()`` (README.rst:112-114) -- ask the
                 # device whether the gradient is a multiple of the charges (one small kernel + a 2-value read; the general
@@ -1001,7 +1009,9 @@ class _PMEFunction(torch.autograd.Function):
                 base = tail["aux_seed"] if tail["aux_seed"] is not None else tail["seed"]
                 tscale = sr_scale if base is None else sr_scale / base
                 if need_q and tail["grad_q"] is not None:
-                    grad_q = tail["grad_q"] * tscale
+                    # (the tail holds the TOTAL dE/dq = 2 V of E = sum q V; through this node flows the half that comes from
+                    # V's dependence on the charges, the other half is the reduction's own)
+                    grad_q = tail["grad_q"] * (0.5 * tscale)
                     need_q = False
                 if tail["grad_cell"] is not None and (need_cell or need_src_cell):
                     gc = tail["grad_cell"] * tscale
@@ -1086,7 +1096,8 @@ class _PMEFunction(torch.autograd.Function):
                 psi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 chi_mesh = torch.empty((Cn,) + geom.ns, dtype=dtype, device=device)
                 psi_hat = None
-                if need_cell or not plan.xfused or not XFUSED:
+                fused_cell = bool(need_cell and getattr(ctx, "rho_kept", False) and plan.xfused and XFUSED and Cn == 1)
+                if (need_cell and not fused_cell) or not plan.xfused or not XFUSED:
                     psi_hat = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 hat_work = torch.empty((Cn, geom.n_half), dtype=cdtype, device=device)
                 dc = torch.empty((Cn,), dtype=dtype, device=device)
@@ -1106,6 +1117,7 @@ class _PMEFunction(torch.autograd.Function):
                     hat_work=hat_work.data_ptr(), chi_mesh=chi_mesh.data_ptr(), dc=dc.data_ptr(),
                     partials=_lib.ptr(partials), grad_positions=_lib.ptr(grad_pos), grad_charges=_lib.ptr(grad_q),
                     grad_cell=_lib.ptr(grad_cell), atom_bins=_lib.ptr(bins),
+                    G_deriv=filter_derivative(geom, pot_desc, dtype, device).data_ptr() if fused_cell else None,
                 )
                 _call("kspace_backward", lib.mipme_kspace_backward, C.byref(args))
                 if ctx.slab_axis is not None:
