@@ -612,7 +612,8 @@ int mipme_nl_stream(void* stream, int dtype, const mipme_nl_t* nl, int64_t n_ato
  * sum over the rows of mipme_nl_stream (co-scheduled), (y,z) transforms, x stage * G, (y,z) transforms, gather + energy +
  * forces -- with every weight evaluated on the fly from the current positions; only the atom -> brick bookkeeping is reused.
  * An atom that has moved more than one mesh point since the rebin sets bit 1 of host_flags (the step's results are invalid:
- * rebin sooner); bit 0: a brick list overflowed at the rebin.  P3M / PME with 1/r or 1/r^6, one channel, meshes the brick
+ * rebin sooner) AND makes the step write NaN as its energy, so that the offending step says so in what it returns; bit 0: a
+ * brick list overflowed at the rebin.  P3M / PME with 1/r or 1/r^6, one channel, meshes the brick
  * kernels cover (mipme_md_supported). */
 typedef struct {
   uint32_t size, version;   /* sizeof(mipme_md_args_t), 1 */

@@ -74,7 +74,7 @@ def test_stream_pair_set_matches_host_builder(triclinic, dtype):
     np.testing.assert_array_equal(canon5(np.concatenate([p2.cpu().numpy(), np.rint(S2.cpu().numpy()).astype(np.int64)], axis=1)), want)
 
 
-@pytest.mark.parametrize("case", ["cscl", "long_cutoff", "one_cell", "slab"])
+@pytest.mark.parametrize("case", ["cscl", "long_cutoff", "one_cell", "slab", "planar", "thin_slab"])
 def test_device_list_small_boxes(case):
     """Boxes smaller than three cutoffs -- down to a cutoff of several box lengths -- on the device (round 2 sent them to the
     host): same pairs, shifts and distances as the host builder; CsCl at rc = 2 has the survey's 58 half pairs."""
@@ -86,8 +86,15 @@ def test_device_list_small_boxes(case):
         cell, pos, rc = np.array([[3.0, 0, 0], [0.4, 3.3, 0], [0.2, -0.3, 2.9]]), rng.uniform(0, 3, (7, 3)), 7.5
     elif case == "one_cell":
         cell, pos, rc = np.diag([5.0, 6.0, 5.5]), rng.uniform(-2, 7, (40, 3)), 4.9
-    else:
+    elif case == "slab":
         cell, pos, rc, periodic = np.diag([4.0, 4.5, 30.0]), rng.uniform(0, 4, (60, 3)) * [1, 1, 5], 5.0, (True, True, False)
+    elif case == "planar":  # a sheet: every atom at one height of a non-periodic axis (round-3 advice: the reach along it exploded)
+        pos = rng.uniform(0, 20, (80, 3))
+        pos[:, 2] = 11.0
+        cell, rc, periodic = np.diag([20.0, 20.0, 30.0]), 5.0, (True, True, False)
+    else:  # a slab a hundred times thinner than the cutoff
+        pos = rng.uniform(0, 12, (50, 3)) * [1, 1, 0.02 / 12]
+        cell, rc, periodic = np.diag([12.0, 12.0, 30.0]), 5.0, (True, True, False)
     for full in (False, True):
         hp, hS, hd = tpa.neighbor_list(pos, cell, rc, full_list=full, periodic=periodic)
         gp, gS, gd = tpa.neighbor_list_device(t(pos), t(cell), rc, full_list=full, periodic=periodic)
@@ -100,6 +107,30 @@ def test_device_list_small_boxes(case):
         ka = np.lexsort(np.concatenate([hp, hS], axis=1).T[::-1])
         kb = np.lexsort(np.concatenate([gp.cpu().numpy(), np.rint(gS.cpu().numpy()).astype(np.int64)], axis=1).T[::-1])
         np.testing.assert_allclose(gd.cpu().numpy()[kb], hd[ka], rtol=1e-12)
+
+
+def test_device_list_of_one_atom_or_none():
+    """N = 0 and N = 1 with a non-periodic axis (the cell grid spans the atoms' extent: a zero span must not turn into a reach
+    of millions of cells), and N = 1 fully periodic with images within the cutoff."""
+    cell = np.diag([6.0, 6.0, 30.0])
+    for periodic in ((True, True, False), (True, True, True)):
+        for n in (0, 1):
+            pos = np.full((n, 3), 1.5)
+            hp, hS, hd = tpa.neighbor_list(pos, cell, 7.0, periodic=periodic)
+            gp, gS, gd = tpa.neighbor_list_device(t(pos.reshape(n, 3)), t(cell), 7.0, periodic=periodic)
+            assert len(gp) == len(hp)
+            if len(hp):
+                a = canon5(np.concatenate([hp, hS], axis=1))
+                b = canon5(np.concatenate([gp.cpu().numpy(), np.rint(gS.cpu().numpy()).astype(np.int64)], axis=1))
+                np.testing.assert_array_equal(a, b)
+    # the stream form of a planar system
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(0, 20, (90, 3))
+    pos[:, 2] = 3.0
+    nl = tpa.NeighborStream(t(pos), t(np.diag([20.0, 20.0, 30.0])), 5.0, periodic=(True, True, False))
+    nl.check(synchronize=True)
+    hp, _, _ = tpa.neighbor_list(pos, np.diag([20.0, 20.0, 30.0]), 5.0, full_list=True, periodic=(True, True, False))
+    assert nl.n_entries == len(hp)
 
 
 def _small_water(n_side=6, dtype="f64"):
@@ -195,6 +226,26 @@ def test_far_atoms_are_reported():
         nl.check(synchronize=True)
 
 
+def test_reference_format_list_refuses_atoms_beyond_the_wrap_range():
+    """neighbor_list_device: an atom more than 400 grid cells outside the unit cell (its wrap integer is clamped in the binning
+    pass) is an error, not a list with wrong shifts (round-3 advice); a merely distant atom gives the host builder's list."""
+    cell = np.diag([10.0, 10.0, 10.0])
+    pos = np.random.default_rng(1).uniform(0, 10, (50, 3))
+    far = pos.copy()
+    far[7] += [5000.0, 0, 0]  # 500 box lengths
+    with pytest.raises(ValueError, match="more than 400 cells"):
+        tpa.neighbor_list_device(t(far), t(cell), 3.0)
+    near = pos.copy()
+    near[7] += [50.0, 0, 0]
+    gp, gS, _ = tpa.neighbor_list_device(t(near), t(cell), 3.0)
+    hp, hS, _ = tpa.neighbor_list(near, cell, 3.0)
+    np.testing.assert_array_equal(canon5(np.concatenate([hp, hS], axis=1)),
+                                  canon5(np.concatenate([gp.cpu().numpy(), np.rint(gS.cpu().numpy()).astype(np.int64)], axis=1)))
+    # and a later call with well-behaved atoms is not haunted by the stale flag
+    gp, _, _ = tpa.neighbor_list_device(t(pos), t(cell), 3.0)
+    assert len(gp) == len(tpa.neighbor_list(pos, cell, 3.0)[0])
+
+
 def _close(E, F, E0, F0, tol_e, tol_f):
     eE = abs(E.item() - E0) / abs(E0)
     eF = np.linalg.norm(F.cpu().numpy() - F0) / np.linalg.norm(F0)
@@ -233,7 +284,8 @@ def test_graphed_refresh_in_place(dtype):
     E, F = step()
     assert step.graph is graph and step.stream.words.data_ptr() == words_ptr  # nothing was captured or allocated again
     _close(E, F, E1, F1, tol_e, tol_f)
-    assert stale_err > 2 * tol_e  # the test moved the atoms far enough to matter
+    # the test moved the atoms far enough to matter (the live-bin step says so itself: NaN instead of a stale energy)
+    assert np.isnan(stale_err) if step._live is not None else stale_err > 2 * tol_e
     assert step.stream.n_entries == 2 * len(p2)
 
 
@@ -254,15 +306,60 @@ def test_live_bins_match_the_binned_step(dtype, scheme, order, p):
     h = float(w.cell[0, 0]) / w.n_mesh
     rng = np.random.default_rng(12)
     moved = w.positions + rng.uniform(-0.45 * h, 0.45 * h, w.positions.shape) / np.sqrt(3.0)
+    # the oracle on the SAME pair set (the list of the positions the stream was built from, skin included), at both positions
+    hp, hS, _ = tpa.neighbor_list(w.positions, w.cell, w.cutoff + 1.0)
+    spec = O.PotentialSpec("coulomb" if p == 1 else "ipl", p, w.smearing, 1.0)
     for x in (w.positions, moved):
         E1, F1 = live(t(x, dtype))
         E2, F2 = ref(t(x, dtype))
         tol = 1e-11 if dtype == torch.float64 else 2e-5
         assert abs(E1.item() - E2.item()) <= tol * abs(E2.item()), (E1.item(), E2.item())
         assert float((F1 - F2).norm() / F2.norm()) <= (1e-10 if dtype == torch.float64 else 5e-5)
+        dist, _ = O.pair_distances(x, w.cell, hp, hS)
+        V, cache = O.forward(spec, "P3M" if scheme == "P3M" else "Lagrange", order, w.mesh_spacing, w.charges, w.cell, x, hp, dist,
+                             return_cache=True)
+        gr = O.backward(cache, w.charges)
+        gpos, _ = O.pair_distances_backward(x, w.cell, hp, hS, gr["dist"])
+        Eo, Fo = float((V * w.charges).sum()), -(gpos + gr["positions"])
+        tol_e, tol_f = (1e-10, 1e-9) if dtype == torch.float64 else (2e-5, 1e-4)
+        assert abs(E1.item() - Eo) <= tol_e * abs(Eo), (E1.item(), Eo)
+        assert float(np.abs(F1.cpu().double().numpy() - Fo).max()) <= tol_f * np.abs(Fo).max()
     live._deferred_check()
     torch.cuda.synchronize()
     live._live.check()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_live_margin_violation_is_loud_and_check_heals_it(dtype):
+    """An atom that moves more than one mesh point between refreshes: the offending step returns NaN as its energy (not a
+    plausible wrong number), the next plain use raises, and ``step(positions, check=True)`` refreshes and re-evaluates before
+    it returns -- the oracle's energy and forces of a list built from scratch at the new positions.  ``max_displacement`` is
+    the mesh spacing of a cubic cell."""
+    w = _small_water()
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=w.smearing), mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order)
+    pos, cell, q = t(w.positions, dtype), t(w.cell, dtype), t(w.charges, dtype)
+    step = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=w.cutoff + 0.5, live_bins=True)
+    assert step._live is not None
+    h = float(w.cell[0, 0]) / w.n_mesh
+    assert abs(step.max_displacement - h) < 1e-6 * h
+    rng = np.random.default_rng(4)
+    shift = np.repeat(rng.uniform(-1.2, 1.2, (w.n_atoms // 3, 3)), 3, axis=0)  # up to 2 mesh points
+    new_pos = w.positions + shift
+    E_bad, _ = step(t(new_pos, dtype))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(E_bad))
+    with pytest.raises(RuntimeError, match="moved more than one mesh point"):
+        step()
+    p2, S2, _ = tpa.neighbor_list(new_pos, w.cell, w.cutoff + 0.5)
+    w2 = workloads.Workload(w.name, new_pos, w.charges, w.cell, p2, S2, w.cutoff, w.smearing, w.mesh_spacing, w.n_mesh,
+                            w.scheme, w.order, w.exponent, w.dtype)
+    E1, F1, _, _ = _oracle_energy_forces(w2)
+    E, F = step(t(w.positions, dtype), check=True)  # back home first: a valid step
+    E, F = step(t(new_pos, dtype), check=True)      # ... then the jump, healed inside the call
+    tol_e, tol_f = (1e-10, 1e-9) if dtype == torch.float64 else (1e-5, 5e-5)
+    _close(E, F, E1, F1, tol_e, tol_f)
+    E, F = step()  # and the object is usable afterwards
+    _close(E, F, E1, F1, tol_e, tol_f)
 
 
 def test_nve_with_list_refresh_conserves_energy():

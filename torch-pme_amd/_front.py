@@ -30,10 +30,15 @@ def module():
                       "path", RuntimeWarning, stacklevel=2)
         return None
     _lib.load()
-    spec = importlib.util.spec_from_file_location("_mipme_front", PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    mod.load_library(_lib.LIB_PATH)
+    try:
+        spec = importlib.util.spec_from_file_location("_mipme_front", PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.load_library(_lib.LIB_PATH)
+    except Exception as exc:  # noqa: BLE001  an ABI / torch-version mismatch: the Python path serves every call, as without it
+        warnings.warn(f"{PATH} cannot be used ({type(exc).__name__}: {exc}); eager calculator calls keep their Python host "
+                      "path -- rebuild it with `make -C torch-pme_amd/csrc front`", RuntimeWarning, stacklevel=2)
+        return None
     from . import ops
 
     def unwrap(g):

@@ -839,6 +839,7 @@ static int md_step_t(const mipme_md_args_t& a) {
   }
   tail.grad_q = a.grad_charges;
   tail.aux_seed = a.aux_seed;
+  tail.live_flags = a.host_flags;
   STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job, a.host_flags,
                                                      a.grad_cell ? cw.cwave : nullptr));
   int64_t n_sr_part = 0;

@@ -941,6 +941,9 @@ struct GatherTail {
   double* rpart;               // [9 * bricks]
   const AtomRecord<T>* rec4;   // (x, y, z, q) per atom: positions for rpart
   const T* aux_seed;           // factor of grad_q and rpart (nullable: the seed of the positions)
+  // live-bin step (nullable): the pinned flag word of the step; if the spread of THIS step has flagged an atom beyond the margin
+  // (bit 1) the energy is written as NaN -- a step whose results are invalid says so in what it returns, not only at the next call
+  const int* live_flags;
 };
 
 // R sums of a workgroup -> rpart[9 * block ...].  r3: lanes 0..2 of every 8-lane atom group hold r_c * gp_l for c = 0..2 (l = the
@@ -989,7 +992,9 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
     for (int w = 0; w < THREADS / 64; ++w)
       for (int k = 0; k < 3; ++k) t[k] += tred[w][k];
     const double Q = double(qsum[0]);
-    tail.energy[0] = T(t[0] + 0.5 * double(inv_vol) * t[2] - 0.5 * double(self_c) * t[1] - double(bg_c) * double(inv_vol) * Q * Q);
+    double e = t[0] + 0.5 * double(inv_vol) * t[2] - 0.5 * double(self_c) * t[1] - double(bg_c) * double(inv_vol) * Q * Q;
+    if (tail.live_flags && (__hip_atomic_load(tail.live_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & 2)) e = __builtin_nan("");
+    tail.energy[0] = T(e);
   }
 }
 
@@ -1547,6 +1552,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     tail.rpart = th->rpart;
     tail.rec4 = (const AtomRecord<T>*)th->records;
     tail.aux_seed = (const T*)th->aux_seed;
+    tail.live_flags = nullptr;
     MIPME_REQUIRE(!tail.rpart || tail.rec4, "the cell sums of the gather need the atom records");
     if (sparse_bricks(N, bg.nb))
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
@@ -1821,6 +1827,7 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.tail.rpart = nullptr;
     d.tail.rec4 = nullptr;
     d.tail.aux_seed = nullptr;
+    d.tail.live_flags = nullptr;
     d.use_tail = f.use_tail != 0;
     d.rows.epart = f.use_tail ? v.epart : nullptr;
     out[k] = d;
@@ -2531,6 +2538,7 @@ int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   tail.rpart = th->rpart;
   tail.rec4 = (const AtomRecord<T>*)rec4;
   tail.aux_seed = (const T*)th->aux_seed;
+  tail.live_flags = (const int*)th->live_flags;
   MIPME_DISPATCH_ORDER(m->order, (live_gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                      g, bg, v.idx, ll.rec_now, (const T*)v.wts, (const AtomRecord<T>*)rec4, (const T*)mesh,
                                      (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail,

@@ -231,6 +231,7 @@ struct GatherTailHost {
   double* rpart;       // fp64[9 * bricks]: per-brick sums r_a (x) (seed q_a field_a) for the cell gradient
   const void* records; // (N,4) reals x, y, z, q: the atoms' positions for rpart
   const void* aux_seed; // device scalar, nullable (= seed): the factor of grad_q and of the cell gradient
+  const void* live_flags; // live-bin step: its pinned flag word (bit 1 = an atom beyond the margin -> the energy becomes NaN)
 };
 
 // The cell gradient of an energy step inside the fused convolution (kfilter.hip, convolve_xfused): the x stage stores

@@ -94,13 +94,29 @@ class _LiveStep:
             a = self._args()
             _lib.check(self.lib.mipme_md_step(C.byref(a)))
 
+    @property
+    def max_displacement(self) -> float:
+        """A displacement (same units as the cell) every atom may make since the last rebin without leaving the margin of ONE mesh
+        point: ``min_d 1 / (n_d |column d of inv(cell)|)`` (u_d = n_d r . inv(cell)[:, d] changes by at most n_d |dr| |column d|)."""
+        inv = np.asarray(self.geom.inv_cell)
+        return float(min(1.0 / (self.geom.ns[d] * np.linalg.norm(inv[:, d])) for d in range(3)))
+
+    def moved(self) -> bool:
+        """True if a step since the last look flagged an atom beyond the margin (clears the bit)."""
+        f = int(self.flags_np[0])
+        if f & 2:
+            self.flags_np[0] = f & ~2
+            return True
+        return False
+
     def check(self):
         f = int(self.flags_np[0])
         if f:
             self.flags_np[0] = 0
             if f & 2:
                 raise RuntimeError("GraphedEnergyForces: an atom has moved more than one mesh point since the last refresh(); "
-                                   "the results of that step are invalid -- refresh the neighbour structures sooner")
+                                   "the results of that step are invalid (its energy was returned as NaN) -- refresh the "
+                                   "neighbour structures sooner, or call the object with check=True")
             raise RuntimeError("GraphedEnergyForces: a brick's atom list overflowed at the last refresh (very non-uniform "
                                "system); construct with live_bins=False")
 
@@ -130,8 +146,13 @@ class GraphedEnergyForces:
     :param live_bins: (``neighbors=`` form) also keep the atom -> mesh-brick bookkeeping across steps and rebuild it in
         :meth:`refresh`, evaluating every mesh weight on the fly from the current positions (``mipme_md_step``: five launches
         per step instead of six, no per-step binning pass, no per-brick candidate scan).  Valid while no atom has moved more
-        than ONE MESH POINT since the last refresh -- checked in every step, reported like a row overflow.  Default: on where
-        the kernels cover the case (mesh calculators with 1/r or 1/r^6, no cell gradient).
+        than ONE MESH POINT since the last refresh -- :attr:`max_displacement` is that distance in the units of the cell;
+        compare it with the skin in ``neighbors`` (a refresh criterion of skin / 2 can exceed it on a fine mesh).  Every step
+        checks the margin on the device.  A step that violates it returns ``NaN`` as its energy (its other results are
+        invalid too) and the next use of the object raises; ``step(positions, check=True)`` looks at the flag before it
+        returns -- one stream synchronisation -- and, on a violation, refreshes the neighbour structures and evaluates again,
+        so that what it returns is always valid.  In this mode the charges live in the object's records: change them with
+        :meth:`set_charges`.  Default: on where the kernels cover the case (mesh calculators with 1/r or 1/r^6).
     """
 
     def __init__(self, calculator, charges, cell, positions, neighbor_indices=None, neighbor_shifts=None, warmup: int = 3,
@@ -350,15 +371,40 @@ class GraphedEnergyForces:
         E.backward(self._minus_one)
         return E.detach()
 
-    def __call__(self, positions: torch.Tensor | None = None):
+    @property
+    def max_displacement(self):
+        """How far an atom may move between two :meth:`refresh` calls of the live-bin step (one mesh point, in the units of the
+        cell); ``None`` for the binned step, which re-bins every call."""
+        return None if self._live is None else self._live.max_displacement
+
+    def set_charges(self, charges: torch.Tensor) -> None:
+        """New charge values (same shape) for the following steps.  The binned step reads the tensor given at construction, so
+        writing into that tensor has the same effect there; the live-bin step keeps the charges in its atom records."""
+        with torch.no_grad():
+            if self._live is not None:
+                self._live.rec[:, 3] = charges.detach()[:, 0]
+            self.q.copy_(charges.detach())
+
+    def __call__(self, positions: torch.Tensor | None = None, check: bool = False):
         """``E, F`` (+ ``dE/dcharges`` with ``charge_gradient``, + ``dE/dcell`` with ``cell_gradient``, in that order) of the
-        current -- or the given -- positions: one graph replay.  The returned tensors are the graph's own buffers."""
+        current -- or the given -- positions: one graph replay.  The returned tensors are the graph's own buffers.
+
+        ``check=True`` (live-bin step): wait for the step and look at its margin flag; if an atom had moved more than one mesh
+        point since the last refresh, :meth:`refresh` (neighbour list and bins from the current positions) and evaluate again
+        before returning -- the results are then valid whatever the atoms did, at the price of one synchronisation per call."""
         self._deferred_check()
         self.calc.check()  # a NaN a previous replay met (pinned word, no synchronisation)
         if positions is not None:
             with torch.no_grad():
                 self.pos.copy_(positions)
         self.graph.replay()
+        if check and self._live is not None:
+            torch.cuda.current_stream(self.pos.device).synchronize()
+            if self._live.moved():
+                self.refresh(check=True)
+                self.graph.replay()
+                torch.cuda.current_stream(self.pos.device).synchronize()
+                self._deferred_check()
         out = (self.energy, self.forces)
         if self.charge_gradient:
             out += (self.charge_grad,)

@@ -39,6 +39,8 @@ def neighbor_list(positions, cell, cutoff: float, full_list: bool = False, perio
     A = np.ascontiguousarray(np.asarray(cell, dtype=np.float64))
     periodic = np.asarray(periodic, dtype=bool)
     N = pos.shape[0]
+    if N == 0:
+        return np.zeros((0, 2), dtype=np.int64), np.zeros((0, 3), dtype=np.int64), np.zeros((0,))
     Ainv = np.linalg.inv(A)
     frac = pos @ Ainv
     wrap = np.where(periodic, np.floor(frac), 0.0).astype(np.int64)
@@ -151,6 +153,10 @@ def _cell_grid(A: np.ndarray, cutoff: float, periodic, n_atoms: int, lo=None, hi
         f = (limit / (nc[0] * nc[1] * nc[2])) ** (1.0 / 3.0)
         nc = [max(1, min(n - 1, int(np.floor(n * f)))) if n > 1 else 1 for n in nc]
     reach = [int(np.ceil(cutoff / (w / n))) for w, n in zip(widths, nc)]
+    # a non-periodic axis has no images: cells beyond [0, n) do not exist, so the walk never needs more than n - 1 cells to
+    # either side -- a planar system (all atoms at one height), a slab much thinner than the cutoff, or one atom would
+    # otherwise ask for millions of cells of reach along that axis (and be refused as "more than 100 images")
+    reach = [r if periodic[d] else min(r, nc[d] - 1) for d, r in enumerate(reach)]
     return nc, reach, frac_off, frac_scale
 
 
@@ -216,7 +222,14 @@ def neighbor_list_device(positions, cell, cutoff: float, full_list: bool = False
         _lib.check(lib.mipme_nl_count(st, dt, C.byref(desc), N, ws.data_ptr(), counts.data_ptr()))
         offsets = torch.zeros((N + 1,), dtype=torch.int64, device=device)
         torch.cumsum(counts, dim=0, out=offsets[1:])
-        P = int(offsets[-1].item())  # the one host synchronisation: the size of the list
+        # the one host synchronisation: the size of the list -- and, with it, the status word of the binning pass (the last
+        # 256-byte block of the workspace holds the status words, csrc/neighbors.hip nl_layout): an atom more than 400 cells
+        # outside the unit cell has its wrap integer clamped, i.e. its shifts would be wrong -- an error, not a result
+        tail = torch.cat([offsets[-1:].to(torch.int64), ws[-256:-248].view(torch.int32)[1:2].to(torch.int64)]).cpu()
+        P = int(tail[0])
+        if int(tail[1]) & 4:
+            raise ValueError("an atom lies more than 400 cells of the neighbour grid outside the unit cell: wrap the positions "
+                             "into the cell (the shifts of the list would be wrong)")
         pairs = torch.empty((P, 2), dtype=torch.int64, device=device)
         shifts = torch.empty((P, 3), dtype=dtype, device=device)
         dist = torch.empty((P,), dtype=dtype, device=device)
