@@ -56,6 +56,19 @@ def test_exchange_modes_gather_the_same_energies():
     assert out["parallelism"]["exchange"] == "per-step"  # the default with more than one rank
 
 
+def test_eight_ranks_cfg4_preset():
+    """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node -- ``bench.py --gpus 8 --preset cfg4`` -- on eight CPU
+    ranks (gloo, stub evaluator): rank binding, the per-step exchange of 8 x 8 frame energies inside the timed loop and
+    ``weak_efficiency`` are all exercised; only the evaluator and the fabric differ from the real run."""
+    out = _run("--gpus", "8", "--preset", "cfg4", "--steps", "2", "--warmup", "1", "--blocks", "1")
+    assert out["n_gpus"] == 8 and out["parallelism"]["n_ranks"] == 8
+    assert out["energies_gathered"] == 64 and out["config"]["frames_per_gpu"] == 8
+    assert out["parallelism"]["exchange"] == "per-step"
+    assert len(out["parallelism"]["per_rank_ms_per_step"]) == 8
+    assert sorted(r["rank"] for r in out["parallelism"]["ranks"]) == list(range(8))
+    assert out["weak_efficiency"]["value"] > 0
+
+
 def test_single_rank_default():
     out = _run("--steps", "2", "--warmup", "1")
     assert out["n_gpus"] == 1 and out["parallelism"]["n_ranks"] == 1

@@ -66,3 +66,40 @@ def test_farm_two_ranks_gloo(tmp_path, n_frames):
     serial = farm.farm_energies(n_frames, _frame_energy).numpy()
     np.testing.assert_array_equal(e0, e1)
     np.testing.assert_allclose(e0, serial, rtol=0, atol=0)
+
+
+def _frame_energy_forces(f: int):
+    """(energy, (N_f, 4) potentials | pseudo-forces) of a frame whose size depends on the index."""
+    n = 5 + (f % 3)
+    g = torch.Generator().manual_seed(1000 + f)
+    arr = torch.rand((n, 4), generator=g, dtype=torch.float64)
+    return arr.sum(), arr
+
+
+def _worker_forces(rank, world, port, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [5 + (f % 3) for f in range(n_frames)]
+        e, arrays = farm.farm_energies_forces(sizes, _frame_energy_forces)
+        np.save(os.path.join(out_dir, f"e{rank}.npy"), e.numpy())
+        np.save(os.path.join(out_dir, f"f{rank}.npy"), torch.cat(arrays).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,world", [(5, 2), (2, 3)])
+def test_farm_gathers_per_atom_results(tmp_path, n_frames, world):
+    """the optional gather of per-atom potentials + forces -- frames of different sizes, a rank without frames."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_forces, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    sizes = [5 + (f % 3) for f in range(n_frames)]
+    e_ser, arr_ser = farm.farm_energies_forces(sizes, _frame_energy_forces)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"e{r}.npy"), e_ser.numpy())
+        np.testing.assert_array_equal(np.load(tmp_path / f"f{r}.npy"), torch.cat(arr_ser).numpy())
+    for f, a in enumerate(arr_ser):
+        assert a.shape == (sizes[f], 4)
