@@ -261,3 +261,61 @@ def test_c_abi_refuses_what_the_tail_cannot_do():
     geom2, G2 = c2["calc"]._kspace_setup(c2["cell"], torch.float32, torch.device(DEV))
     D2 = ops.filter_derivative(geom2, c2["calc"].potential._descriptor(), torch.float32, torch.device(DEV))
     assert float(D2[..., 1:].abs().max()) == 0.0 and float(D2[..., 0].abs().max()) > 0.0
+
+
+def test_new_list_tensors_with_old_values_reuse_the_structures(monkeypatch):
+    """The reference's users hand a fresh neighbour list to every call (examples/02-neighbor-lists-usage.py:97-164).  A NEW
+    `neighbor_indices` / shifts tensor with the values of the previous one reuses the transposed list and the entry streams on a
+    bet that is verified on the device (ops.SPECULATE_LISTS, mipme_checksum); a tensor of the same shape with OTHER values loses
+    the bet and gets freshly built structures -- the results are right either way."""
+    c = setup(torch.float64, "P3M", 5, 1, True, seed=9)
+    Eo, gpo, _, _, _ = oracle_contract(*c["np"])
+    built = []
+    orig = ops.PairTopology.__init__
+
+    def counting(self, pairs, n_atoms):
+        built.append(pairs.shape[0])
+        orig(self, pairs, n_atoms)
+
+    monkeypatch.setattr(ops.PairTopology, "__init__", counting)
+    ops._TOPOLOGIES.clear()
+    ops._BET_PAUSE[0] = 0
+
+    def energy_forces(pairs, shifts, plain_distances=False):
+        pos = c["pos"].clone().requires_grad_(True)
+        d = tpa.pair_distances(pos, pairs, c["cell"], shifts)
+        if plain_distances:
+            d = d.detach().clone()
+        V = c["calc"](c["q"], c["cell"], pos, pairs, d)
+        E = (c["q"] * V).sum()
+        E.backward()
+        return float(E), pos.grad
+
+    E, g = energy_forces(c["pairs"], c["shifts"])
+    assert len(built) == 1 and abs(E - Eo) <= 1e-9 * abs(Eo) and rel(g, gpo) <= 1e-9
+    for _ in range(3):  # clones: same values, new tensors -> no rebuild
+        E, g = energy_forces(c["pairs"].clone(), c["shifts"].clone())
+        assert abs(E - Eo) <= 1e-9 * abs(Eo) and rel(g, gpo) <= 1e-9
+    assert len(built) == 1
+    # other values in the same shape: reverse the list (i <-> j, shifts negated): another list of the same pairs
+    pairs2 = c["pairs"].flip(1).contiguous()
+    shifts2 = (-c["shifts"]).contiguous()
+    E, g = energy_forces(pairs2, shifts2)
+    assert len(built) == 2 and abs(E - Eo) <= 1e-9 * abs(Eo) and rel(g, gpo) <= 1e-9
+    # the SAME pairs tensor with shifts of other values: one image moved (the energy changes, and must equal the oracle's)
+    ops._BET_PAUSE[0] = 0
+    S3 = c["np"][8].copy()
+    k = int(np.argmax(np.abs(S3).sum(1) == 0))
+    S3[k] = [1, 0, 0]
+    spec, scheme, order, h, q, cell, pos, pairs, _ = c["np"]
+    Eo3, gpo3, _, _, _ = oracle_contract(spec, scheme, order, h, q, cell, pos, pairs, S3)
+    E, g = energy_forces(c["pairs"], torch.tensor(S3, dtype=torch.float64, device=DEV))
+    assert abs(E - Eo3) <= 1e-9 * abs(Eo3) and rel(g, gpo3) <= 1e-9 and abs(Eo3 - Eo) > 1e-6 * abs(Eo)
+    # a plain distance tensor (the calculator alone looks the list up): clone again
+    ops._BET_PAUSE[0] = 0
+    n = len(built)
+    E1, _ = energy_forces(c["pairs"].clone(), c["shifts"], plain_distances=True)  # (the shifts tensor changed back: a lost bet)
+    n = len(built)
+    ops._BET_PAUSE[0] = 0
+    E2, _ = energy_forces(c["pairs"].clone(), c["shifts"], plain_distances=True)
+    assert len(built) == n and abs(E1 - Eo) <= 1e-9 * abs(Eo) and abs(E2 - Eo) <= 1e-9 * abs(Eo)

@@ -276,6 +276,38 @@ def test_fullsize_against_committed_oracle(cfg, request, golden_dir):
             assert abs(float((r * F).sum()) - float(g["force_dot"])) <= tol_c * scale, (cfg, dtype, name)
 
 
+def test_eight_headline_frames_in_one_batch(golden_dir):
+    """Eight cfg3-size frames (31 944-atom water boxes, seeds 1234 ... 1241, fp32) evaluated together -- GraphedFrameBatch: one
+    launch per kernel for all frames; and one replayed graph per frame on its own stream -- each frame's energy and forces
+    against the pinned oracle's numbers for that frame (tests/golden/frames_water.npz, made by make_frames_golden.py): energy
+    1e-5, 256 sampled forces rel-L2 1e-4, sum |F|^2 1e-4.  bench.py's `frames` block times exactly these two forms."""
+    z = np.load(os.path.join(golden_dir, "frames_water.npz"))
+    n = len(z["seeds"])
+    ws = [workloads.water_box(seed=int(sd)) for sd in z["seeds"]]
+    boxes = [Box(w, torch.float32) for w in ws]
+    for f, w in enumerate(ws):
+        assert int(z[f"f{f}_n_pairs"]) == w.n_pairs
+        assert np.allclose([w.positions.sum(), (w.positions**2).sum()], z[f"f{f}_pos_checksum"], rtol=1e-13)
+    batch = tpa.GraphedFrameBatch(boxes[0].calc, [(b.q, b.cell, b.pos, b.pairs, b.shifts) for b in boxes])
+    for _ in range(2):
+        energies, forces = batch()
+    torch.cuda.synchronize()
+    graphs = [tpa.GraphedEnergyForces(b.calc, b.q, b.cell, b.pos, b.pairs, b.shifts) for b in boxes]
+    streams = [torch.cuda.Stream() for _ in boxes]
+    for g, st in zip(graphs, streams):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            g.graph.replay()
+    torch.cuda.synchronize()
+    for f in range(n):
+        Eo, sample, Fs = float(z[f"f{f}_energy"]), z[f"f{f}_sample"], torch.tensor(z[f"f{f}_force_sample"])
+        for name, E, F in (("batch", energies[f], forces[f]), ("streams", graphs[f].energy, graphs[f].forces)):
+            F = F.cpu().double()
+            assert abs(float(E) - Eo) <= 1e-5 * abs(Eo), (f, name, float(E), Eo)
+            assert rel(F[sample], Fs) <= 1e-4, (f, name)
+            assert abs(float((F * F).sum()) - float(z[f"f{f}_force_sq"])) <= 1e-4 * float(z[f"f{f}_force_sq"]), (f, name)
+
+
 def test_nve_energy_conservation():
     """examples/nve_ions.py: 1 728 charged soft spheres (Coulomb + 1/r^6, two graphed calculators, device neighbour list),
     200 velocity-Verlet steps -- the total energy is conserved to a small fraction of the kinetic energy, and halving the

@@ -228,6 +228,13 @@ class Calculator(torch.nn.Module):
             charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
             bool(self.full_neighbor_list), slab_axis, nan_flag,
         )
+        try:
+            ops.verify_bets()  # (ops.SPECULATE_LISTS: the structures of a previous list tensor may have been reused on a bet)
+        except ops.SpeculationLost:
+            out = ops.pme_potential(
+                charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
+                bool(self.full_neighbor_list), slab_axis, nan_flag,
+            )
         if getattr(self, "_speculated", None) is not None:
             # the geometry was the one cached for the PREVIOUS cell tensor, on the bet that the new one holds the same values
             # (_kspace_setup): the comparison ran first in the queue -- look at its verdict now that everything is launched
@@ -341,6 +348,7 @@ class PMECalculator(Calculator):
         while flag[0] == -1:
             spins += 1
             if spins > 5_000_000:
+                ops.SPIN_TIMEOUTS["cell"] += 1
                 torch.cuda.current_stream(cell.device).synchronize()
                 break
         if flag[0] == 1:

@@ -683,6 +683,58 @@ __global__ __launch_bounds__(64) void values_equal_kernel(int n, const T* __rest
   if (threadIdx.x == 0) __hip_atomic_store(host_flag, all ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__ data, int64_t n_vec, const unsigned* __restrict__ tail,
+                                                       int n_tail, unsigned long long* __restrict__ sums,
+                                                       const unsigned long long* __restrict__ expect, int* host_flag) {
+  unsigned long long a = 0, b = 0;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const uint4 v = data[i];
+    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    const unsigned long long k = 0x9e3779b97f4a7c15ull * (unsigned long long)(2 * i + 1);
+    a += mix64(lo + k);
+    b += mix64(hi ^ (k << 1 | 1));
+    a += mix64(hi + 0x632be59bd9b4e019ull * (unsigned long long)(2 * i + 2));
+    b += mix64(lo ^ (k * 3));
+  }
+  if (blockIdx.x == 0 && int(threadIdx.x) < n_tail) a += mix64((unsigned long long)tail[threadIdx.x] + 0x1234567ull * (threadIdx.x + 1));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  __shared__ unsigned long long red[4][2];
+  __shared__ bool last;
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = a;
+    red[threadIdx.x >> 6][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&sums[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    __threadfence();
+    last = atomicAdd(&sums[2], 1ull) == (unsigned long long)(gridDim.x - 1);
+    if (last && host_flag) {
+      __threadfence();
+      const unsigned long long s0 = __hip_atomic_load(&sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long s1 = __hip_atomic_load(&sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int same = expect && s0 == expect[0] && s1 == expect[1];
+      __hip_atomic_store(host_flag, same ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void energy_select_kernel(int64_t N, const T* __restrict__ verdict, const T* __restrict__ q,
                                                            const T* __restrict__ force, const T* __restrict__ field, T f,
@@ -1309,6 +1361,20 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 }
 
 int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }
+
+int mipme_checksum(void* stream, const void* data, int64_t n_bytes, void* sums, const void* expect, void* host_flag) {
+  MIPME_REQUIRE(n_bytes >= 0 && (n_bytes % 4) == 0 && sums && (n_bytes == 0 || data), "mipme_checksum: a multiple of 4 bytes, non-NULL buffers");
+  MIPME_REQUIRE((reinterpret_cast<uintptr_t>(data) & 15) == 0, "mipme_checksum: the buffer must be 16-byte aligned");
+  const int64_t n_vec = n_bytes / 16;
+  const int n_tail = int((n_bytes % 16) / 4);
+  int64_t blocks = (n_vec + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  checksum_kernel<<<unsigned(blocks), 256, 0, (hipStream_t)stream>>>(
+      (const uint4*)data, n_vec, (const unsigned*)((const char*)data + 16 * n_vec), n_tail, (unsigned long long*)sums,
+      (const unsigned long long*)expect, (int*)host_flag);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
 
 int mipme_values_equal(void* stream, int dtype, int64_t n, const void* a, const void* b, void* host_flag) {
   MIPME_REQUIRE(n >= 0 && n <= 1024 && a && b && host_flag, "mipme_values_equal: up to 1024 values, non-NULL buffers");

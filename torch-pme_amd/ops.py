@@ -294,6 +294,79 @@ def _pack_entries(row_ptr, entries, shifts, n_pairs, n_atoms, table=True):
         return ent_sh, fmt
 
 
+# A NEW neighbour-list (or shifts) tensor is first assumed to hold the values of the previous one: the reference's users hand a
+# fresh list to every call (examples/02-neighbor-lists-usage.py:97-164), often the same values in a new tensor (a clone, a data
+# loader's copy), and the per-list structures -- radix-sort transposition, entry streams: 0.6 ms at cfg3 -- would be rebuilt for
+# nothing.  The bet: ``mipme_checksum`` hashes the new tensor on the device and compares with the hash of the tensor the cached
+# structures were built from; the verdict lands in pinned memory and is looked at (``verify_bets``) before any result that used
+# the cached structures is handed out; a lost bet repeats the evaluation with freshly built structures.  "0": always rebuild.
+SPECULATE_LISTS = os.environ.get("MIPME_SPECULATE_LISTS", "1") != "0"
+_BETS: list = []  # pending verdicts: (pinned flags numpy view, slot, undo callable)
+_BET_PAUSE = [0]  # list misses to sit out after a lost bet (lists that really change from call to call)
+_BET_FLAGS: dict = {}
+#: polls of a pinned verdict word that gave up and synchronised instead (diagnostics: should stay at zero)
+SPIN_TIMEOUTS = {"match": 0, "bets": 0, "cell": 0}
+
+
+class SpeculationLost(Exception):
+    """A bet on unchanged list values was lost: the caller repeats its work (the stale cache entries are already gone)."""
+
+
+def _bet_slot():
+    st = _BET_FLAGS.get("flags")
+    if st is None:
+        flags = torch.zeros((64,), dtype=torch.int32).pin_memory()
+        st = _BET_FLAGS["flags"] = [flags, flags.numpy(), 0]
+    st[2] = (st[2] + 1) % 64
+    st[1][st[2]] = -1
+    return st[0], st[1], st[2]
+
+
+def device_checksum(t: torch.Tensor, expect: torch.Tensor | None = None, undo=None) -> torch.Tensor:
+    """128-bit checksum of ``t`` (contiguous, 16-byte aligned storage) as a device tensor; with ``expect`` the comparison's
+    verdict is queued for :func:`verify_bets` together with ``undo`` (what to forget if the bet is lost)."""
+    lib = _lib.load()
+    sums = torch.zeros((3,), dtype=torch.int64, device=t.device)
+    flag_ptr = None
+    if expect is not None:
+        flags, view, slot = _bet_slot()
+        flag_ptr = flags.data_ptr() + 4 * slot
+        _BETS.append((view, slot, undo))
+    with _lib.on_device(t.device):
+        _lib.check(lib.mipme_checksum(_lib.current_stream(t.device), t.data_ptr(), t.numel() * t.element_size(), sums.data_ptr(),
+                                      _lib.ptr(expect), flag_ptr))
+    return sums
+
+
+def verify_bets() -> None:
+    """Look at the verdicts of the bets made since the last call (polling pinned words: the comparisons were queued before the
+    kernels that used the cached structures); raise :class:`SpeculationLost` after undoing every lost one."""
+    if not _BETS:
+        return
+    lost = False
+    for view, slot, undo in _BETS:
+        spins = 0
+        while view[slot] == -1:
+            spins += 1
+            if spins > 5_000_000:
+                SPIN_TIMEOUTS["bets"] += 1
+                torch.cuda.synchronize()
+                break
+        if view[slot] != 1:
+            lost = True
+            if undo is not None:
+                undo()
+    _BETS.clear()
+    if lost:
+        _BET_PAUSE[0] = 16
+        raise SpeculationLost()
+
+
+def _can_bet(t: torch.Tensor) -> bool:
+    return (SPECULATE_LISTS and _BET_PAUSE[0] == 0 and len(_BETS) < 32 and t.is_contiguous() and t.data_ptr() % 16 == 0
+            and (t.numel() * t.element_size()) % 4 == 0 and not torch.cuda.is_current_stream_capturing())
+
+
 class PairTopology:
     """Transposed pair list of one ``neighbor_indices`` tensor (see ``include/mipme.h``)."""
 
@@ -314,6 +387,11 @@ class PairTopology:
         self._pair_sh = None  # (weakref(shifts), version, tensor|None)
         self._ent32 = None  # (weakref(shifts)|None, version, tensor|None)
         self._sorted = None
+        # what the structures were built from, for the bet on a new tensor with the same values (see SPECULATE_LISTS)
+        self.src_dtype = pairs.dtype
+        self._sum = device_checksum(pairs) if (SPECULATE_LISTS and pairs.is_contiguous() and pairs.data_ptr() % 16 == 0
+                                               and not torch.cuda.is_current_stream_capturing()) else None
+        self._shift_key = self._shift_sum = self._shift_meta = None
         # 8-byte (i, j) copy of an int64 list for the two kernels that stream the list in pair order
         self.pairs32 = pairs if pairs.dtype == torch.int32 else pairs.to(torch.int32)
         with _lib.on_device(device):
@@ -325,6 +403,42 @@ class PairTopology:
                     ws.data_ptr(), nbytes, self.row_ptr.data_ptr(), self.entries.data_ptr(),
                 )
             )
+
+    def adopt_shifts(self, shifts: torch.Tensor, key: torch.Tensor | None = None) -> None:
+        """Called with the shifts of an evaluation before the shift-keyed streams are asked for.  If they were built for ANOTHER
+        tensor of the same shape and dtype, bet that it held the same values (SPECULATE_LISTS): re-key the streams to the new
+        tensor and queue the checksum comparison; otherwise remember this tensor's checksum for the next such bet."""
+        key = shifts if key is None else key
+        cur = self._shift_key
+        if cur is not None and cur[0]() is key and cur[1] == key._version:
+            return
+        meta = (tuple(shifts.shape), shifts.dtype)
+        if self._shift_sum is not None and self._shift_meta == meta and _can_bet(shifts):
+            def undo(self=self):
+                self._packed = self._ent_sh = self._pair_sh = self._ent32 = None
+                self.__dict__.pop("_front", None)
+                self._shift_key = self._shift_sum = None
+
+            device_checksum(shifts, self._shift_sum, undo)
+            wr, ver = weakref.ref(key), key._version
+            if self._packed is not None:
+                self._packed = (wr, ver) + tuple(self._packed[2:])
+            if self._pair_sh is not None:
+                self._pair_sh = (wr, ver) + tuple(self._pair_sh[2:])
+            if self._ent32 is not None and self._ent32[0] is not None:
+                self._ent32 = (wr, ver) + tuple(self._ent32[2:])
+            if isinstance(self._ent_sh, dict):
+                self._ent_sh = {k: ((wr, ver) + tuple(v[2:]) if v[0] is not None else v) for k, v in self._ent_sh.items()}
+            self.__dict__.pop("_front", None)  # (the handle holds the old tensors; rebuilt from the cached streams)
+            self._shift_key = (wr, ver)
+            return
+        self._packed = self._pair_sh = self._ent32 = None
+        self._ent_sh = None
+        self.__dict__.pop("_front", None)
+        self._shift_key = (weakref.ref(key), key._version)
+        self._shift_meta = meta
+        self._shift_sum = device_checksum(shifts) if (SPECULATE_LISTS and shifts.is_contiguous() and shifts.data_ptr() % 16 == 0
+                                                      and not torch.cuda.is_current_stream_capturing()) else None
 
     def front(self, pairs: torch.Tensor, shifts: torch.Tensor, key: torch.Tensor):
         """Handle of this list (with the shift streams of ``key``) for the compiled front end (``_front.py``), or ``None``
@@ -595,6 +709,18 @@ def get_topology(pairs: torch.Tensor, n_atoms: int) -> PairTopology:
     if hit is not None and hit[0]() is pairs and hit[1] == pairs._version:
         _TOPOLOGIES.move_to_end(key)
         return hit[2]
+    if _BET_PAUSE[0] > 0:
+        _BET_PAUSE[0] -= 1
+    elif _can_bet(pairs):
+        # a new tensor: bet that it holds the values of the list the most recent matching topology was built from
+        for k_old in reversed(_TOPOLOGIES):
+            t_old = _TOPOLOGIES[k_old][2]
+            if (k_old[1:] == key[1:] and isinstance(t_old, PairTopology) and t_old._sum is not None
+                    and t_old.src_dtype == pairs.dtype):
+                device_checksum(pairs, t_old._sum, lambda key=key: _TOPOLOGIES.pop(key, None))
+                _TOPOLOGIES[key] = (weakref.ref(pairs), pairs._version, t_old)
+                t_old.__dict__.pop("_front", None)  # (the compiled front end's handle names the old list tensor)
+                return t_old
     topo = PairTopology(pairs, n_atoms)
     _TOPOLOGIES[key] = (weakref.ref(pairs), pairs._version, topo)
     while len(_TOPOLOGIES) > 16:
@@ -713,6 +839,8 @@ class _PMEFunction(torch.autograd.Function):
                 full_list = False  # rows of a NeighborStream hold every neighbour once: a half list whatever the calculator says
             fused = None
             if src is not None:
+                if isinstance(topo, PairTopology) and src.shifts is not None:
+                    topo.adopt_shifts(src.shifts, src.shifts_key)
                 ent_sh, shift_fmt = topo.entries_with_shifts(src.shifts, src.shifts_key, table=mask is None)
                 if ent_sh is not None:
                     fused = dict(
@@ -996,6 +1124,7 @@ class _PMEFunction(torch.autograd.Function):
                     while flag_np[0] == -1:
                         spins += 1
                         if spins > 2_000_000:  # never seen; a stream synchronisation is the fallback
+                            SPIN_TIMEOUTS["match"] += 1
                             torch.cuda.current_stream(device).synchronize()
                             break
                     if flag_np[0] == 1:
@@ -1270,6 +1399,8 @@ def _launch_pair_distances(pos, cl, pairs, sh, shifts_key, out):
     device, dtype = pos.device, pos.dtype
     P = pairs.shape[0]
     topo = get_topology(pairs, pos.shape[0]) if PAIR_MODE == "rows" else None
+    if isinstance(topo, PairTopology) and sh is not None:
+        topo.adopt_shifts(sh, shifts_key)
     pl = pairs if topo is None else topo.pairs32
     packed = topo.pair_packed_shifts(sh, shifts_key) if (topo is not None and sh is not None) else None
     with _lib.on_device(device):
@@ -1400,6 +1531,15 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None,
 
 @torch.compiler.disable
 def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, deferred):
+    try:
+        dist = _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, deferred)
+        verify_bets()  # (SPECULATE_LISTS: the structures of a previous list tensor may have been reused on a bet)
+        return dist
+    except SpeculationLost:
+        return _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, deferred)
+
+
+def _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, deferred):
     if cell is not None and neighbor_shifts is None:
         raise ValueError("Provided `cell` but no `neighbor_shifts`.")
     if cell is None and neighbor_shifts is not None:
@@ -1419,7 +1559,9 @@ def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, de
         # compiled front end (csrc/front.cpp): the same kernel, a C++ autograd node, ~8 us of host time instead of ~50
         mod = _front.module()
         if mod is not None:
-            ft = get_topology(neighbor_indices, positions.shape[0]).front(neighbor_indices, shifts_c, neighbor_shifts)
+            topo_f = get_topology(neighbor_indices, positions.shape[0])
+            topo_f.adopt_shifts(shifts_c, neighbor_shifts)
+            ft = topo_f.front(neighbor_indices, shifts_c, neighbor_shifts)
             if ft is not None:
                 dist = mod.pair_distances(ft, positions, cell, neighbor_indices)
                 if dist is not None:
