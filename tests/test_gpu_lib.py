@@ -393,3 +393,27 @@ def test_scaled_match_verdicts(dtype, n):
     q.zero_()
     assert verdict(torch.zeros_like(q), True)[0] == 0  # no reference element at all: not a match (as with one workgroup)
     assert verdict(torch.zeros_like(q), False)[0] == 0
+
+
+def test_custom_kspace_kernel_runs_the_same_convolution():
+    """lib.KSpaceFilter with a user-defined lib.KSpaceKernel (reference lib/kspace_filter.py:7-35: the customisable filter):
+    tabulated from kernel_from_k_sq on generate_kvectors_for_mesh, it gives what the built-in potential's device-built table
+    gives, and what numpy's rfftn / irfftn give with the same table."""
+    from torchpme_amd import lib
+
+    cell = torch.tensor([[9.0, 0, 0], [1.0, 10.0, 0], [0.5, -0.7, 11.0]], dtype=torch.float64, device="cuda")
+    ns = (16, 32, 16)
+    pot = tpa.CoulombPotential(smearing=1.3)
+
+    class Mine(lib.KSpaceKernel):
+        def kernel_from_k_sq(self, k_sq):
+            return pot.lr_from_k_sq(k_sq)
+
+    mesh = torch.randn((2, *ns), dtype=torch.float64, device="cuda")
+    ref = lib.KSpaceFilter(cell, ns, pot)(mesh)
+    mine = lib.KSpaceFilter(cell, ns, Mine())(mesh)
+    assert float((ref - mine).abs().max()) <= 1e-10 * float(ref.abs().max())
+    k = lib.generate_kvectors_for_mesh(cell, ns)
+    G = pot.lr_from_k_sq((k * k).sum(-1)).cpu().numpy()
+    want = np.fft.irfftn(np.fft.rfftn(mesh.cpu().numpy(), axes=(1, 2, 3)) * G, s=ns, axes=(1, 2, 3)) * np.prod(ns)
+    assert np.abs(mine.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()

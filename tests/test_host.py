@@ -483,3 +483,29 @@ def test_integration_snippets_match_the_header():
             for arg in split_args(code[m.end():i - 1]):
                 key = arg.split("=", 1)[0].strip()
                 assert key in structs[cname], (cls, key)
+
+
+def test_generate_kvectors_for_mesh_matches_the_reference_golden():
+    """lib.generate_kvectors_for_mesh (reference lib/kvectors.py:77-102): the half-grid k-vectors of the conventions fixture
+    (made by the reference: triclinic cell, ns = [8, 8, 16]), shape (nx, ny, nz/2+1, 3), and the survey's known value
+    k[1,0,0]; differentiable w.r.t. the cell; KSpaceKernel is the reference's interface class."""
+    import numpy as np
+    import torch
+
+    from torchpme_amd import lib
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "conventions.npz"))
+    cell = torch.tensor(z["cell"], dtype=torch.float64, requires_grad=True)
+    ns = torch.tensor(z["ns"])
+    k = lib.generate_kvectors_for_mesh(cell, ns)
+    assert tuple(k.shape) == (int(ns[0]), int(ns[1]), int(ns[2]) // 2 + 1, 3)
+    np.testing.assert_allclose(k.detach().numpy(), z["kvectors"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(k[1, 0, 0].detach().numpy(), [1.5707963, -0.15707963, -0.089011792], atol=1e-7)
+    (k * k).sum().backward()
+    assert cell.grad is not None and bool(torch.isfinite(cell.grad).all())
+    with pytest.raises(ValueError, match=r"cell of shape \[3\] should be of shape \(3, 3\)"):
+        lib.generate_kvectors_for_mesh(torch.zeros(3), ns)
+    with pytest.raises(ValueError, match=r"ns of shape \[2\] should be of shape \(3, \)"):
+        lib.generate_kvectors_for_mesh(cell.detach(), torch.tensor([2, 2]))
+    with pytest.raises(NotImplementedError, match="kernel_from_k_sq is not implemented for 'KSpaceKernel'"):
+        lib.KSpaceKernel().kernel_from_k_sq(torch.zeros(2))

@@ -47,3 +47,18 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_di -o t -- python $ROOT/tools/prof_dropin_kernels.py 300 > /dev/null 2>&1)
 python tools/rocpd_summary.py $(find $OUT/${TAG}_di -name '*.db') > $OUT/${TAG}_kernel_stats_dropin.txt
 rm -rf $OUT/${TAG}_di
+# round 4: the energy step with the whole autograd contract (E, F, dE/dq, dE/dcell), binned and live; the TuningTimings protocol
+python tools/check_contract.py > $OUT/${TAG}_check_contract.txt 2>&1
+for m in F Fqc; do
+  for live in 0 1; do
+    (cd /tmp && MODE=$m LIVE=$live rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_c_$m$live -o t -- python $ROOT/tools/prof_contract.py > /dev/null 2>&1)
+    python tools/rocpd_summary.py $(find $OUT/${TAG}_c_$m$live -name '*.db') > $OUT/${TAG}_kernel_stats_contract_${m}_live$live.txt
+    rm -rf $OUT/${TAG}_c_$m$live
+  done
+done
+PROFILE=1 python tools/prof_protocol.py 200 > $OUT/${TAG}_protocol_prof.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_pp -o t -- python $ROOT/tools/prof_protocol.py 200 > /dev/null 2>&1)
+python tools/rocpd_summary.py $(find $OUT/${TAG}_pp -name '*.db') > $OUT/${TAG}_kernel_stats_protocol.txt
+rm -rf $OUT/${TAG}_pp
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2>> $OUT/${TAG}_bench_default.err
+ls -la $OUT | grep ${TAG}

@@ -128,11 +128,47 @@ class MeshInterpolator:
         return out
 
 
+def generate_kvectors_for_mesh(cell: torch.Tensor, ns) -> torch.Tensor:
+    """Reciprocal-space vectors of the rfft half grid of an ``(nx, ny, nz)`` mesh, shape ``(nx, ny, nz // 2 + 1, 3)``:
+    ``k = 2 pi (f_x, f_y, f_z) A^-T`` with the integer frequencies of ``fftfreq`` along x and y and of ``rfftfreq`` along z
+    (reference ``lib/kvectors.py:77-102``).  Differentiable w.r.t. ``cell``.  The calculators never materialise this grid (their
+    kernels derive every k-vector from its index, ``csrc/kfilter.hip``); it is the inspection / custom-kernel utility."""
+    if cell.shape != (3, 3):
+        raise ValueError(f"cell of shape {list(cell.shape)} should be of shape (3, 3)")
+    if isinstance(ns, torch.Tensor):
+        if ns.shape != (3,):
+            raise ValueError(f"ns of shape {list(ns.shape)} should be of shape (3, )")
+        if ns.device != cell.device:
+            raise ValueError(f"`ns` and `cell` are not on the same device, got {ns.device} and {cell.device}.")
+    nx, ny, nz = _ns_tuple(ns)
+    recip = (2 * torch.pi) * torch.linalg.inv_ex(cell)[0].T  # rows: reciprocal lattice vectors
+
+    def freq(n, half):
+        f = torch.arange(n // 2 + 1 if half else n, device=cell.device)
+        if not half:
+            f = torch.where(f < (n + 1) // 2, f, f - n)
+        return f.to(cell.dtype)
+
+    fx, fy, fz = freq(nx, False), freq(ny, False), freq(nz, True)
+    return (fx[:, None, None, None] * recip[0] + fy[None, :, None, None] * recip[1] + fz[None, None, :, None] * recip[2])
+
+
+class KSpaceKernel(torch.nn.Module):
+    """Interface of a reciprocal-space kernel (reference ``lib/kspace_filter.py:7-35``): subclasses return the filter values
+    for a tensor of squared k-vector norms.  The built-in potentials implement it as ``lr_from_k_sq``; a :class:`KSpaceFilter`
+    given any other subclass tabulates ``kernel_from_k_sq`` once per cell with tensor operations and runs the same convolution
+    kernels on the table."""
+
+    def kernel_from_k_sq(self, k_sq: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(f"kernel_from_k_sq is not implemented for '{self.__class__.__name__}'")
+
+
 class KSpaceFilter:
     """``irfftn(rfftn(mesh) * G(k))`` with ``G = kernel(|k|^2)`` (reference ``lib/kspace_filter.py:31-222``).
 
     Only the un-normalised convention used by the calculators (``fft_norm="backward"``,
-    ``ifft_norm="forward"``) is implemented; ``kernel`` must be a built-in :class:`Potential`."""
+    ``ifft_norm="forward"``) is implemented; ``kernel`` is a built-in :class:`Potential` (G built by the device kernel) or any
+    :class:`KSpaceKernel` (G tabulated from ``kernel_from_k_sq`` on :func:`generate_kvectors_for_mesh`)."""
 
     _scheme = _lib.LAGRANGE
     _order = 3
@@ -163,7 +199,11 @@ class KSpaceFilter:
         self._geom = ops.MeshGeometry(
             self.cell.detach().to("cpu", torch.float64).numpy(), self.ns_mesh, self._scheme, self._order
         )
-        self._kfilter = ops.build_filter(self._geom, self.kernel._descriptor(), self.cell.dtype, self.cell.device)
+        if isinstance(self.kernel, Potential):
+            self._kfilter = ops.build_filter(self._geom, self.kernel._descriptor(), self.cell.dtype, self.cell.device)
+        else:  # a custom KSpaceKernel: tabulated with tensor operations, then the same convolution kernels
+            k = generate_kvectors_for_mesh(self.cell.detach(), self.ns_mesh)
+            self._kfilter = self.kernel.kernel_from_k_sq((k * k).sum(-1)).to(self.cell.dtype).contiguous()
 
     def forward(self, mesh_values: torch.Tensor) -> torch.Tensor:
         if mesh_values.dim() != 4:
