@@ -224,10 +224,11 @@ class Calculator(torch.nn.Module):
         nan_flag = self._nan_flag_ptr() if geom is not None else None
         if nan_flag is not None:
             self.__dict__["_nan_shape"] = [charges.shape[1], *geom.ns]
-        out = ops.pme_potential(
-            charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
-            bool(self.full_neighbor_list), slab_axis, nan_flag,
-        )
+        with ops.betting():
+            out = ops.pme_potential(
+                charges, cell, positions, neighbor_indices, neighbor_distances, pair_mask, geom, G, pot_desc,
+                bool(self.full_neighbor_list), slab_axis, nan_flag,
+            )
         try:
             ops.verify_bets()  # (ops.SPECULATE_LISTS: the structures of a previous list tensor may have been reused on a bet)
         except ops.SpeculationLost:

@@ -17,9 +17,6 @@
 #include "common.h"
 #include "rows_body.h"
 
-#include <mutex>
-#include <vector>
-
 namespace mipme {
 
 static constexpr int BRICK = 8;
@@ -813,12 +810,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
       bool done = false;
       if constexpr (COMPACT && std::is_same<T, float>::value) {
         if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-          if constexpr (PFAST == 1) {
-            if (ra.sr_table) sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL, true>(ra, r, tab);
-            else sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-          } else {
-            sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-          }
+          sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
           done = true;
         }
       }
@@ -846,9 +838,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
 template <typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int xcd) {
   constexpr bool F64_BODY = COMPACT && std::is_same<T, double>::value && PFAST == 1 && kRowLanes == 16;
-  __shared__ __attribute__((aligned(16))) char tab_raw[F64_BODY ? kRowsF64LdsBytes
-                                                               : sizeof(AtomRecord<T>) * kShiftTableSize +
-                                                                     ((sizeof(T) == 4 && PFAST == 1 && COMPACT) ? kSrTabLdsBytes : 0)];
+  __shared__ __attribute__((aligned(16))) char tab_raw[F64_BODY ? kRowsF64LdsBytes : sizeof(AtomRecord<T>) * kShiftTableSize];
   AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(tab_raw);
   constexpr int BS = 256;
   const unsigned n_row_blocks = unsigned((ra.N + BS / kRowLanes - 1) / (BS / kRowLanes));
@@ -856,12 +846,7 @@ __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int
   if (r >= n_row_blocks) return;
   if constexpr (COMPACT && std::is_same<T, float>::value) {
     if (CELL || !ra.dist_out) {
-      if constexpr (PFAST == 1) {
-            if (ra.sr_table) sr_rows_pk_body<PFAST, BS, CELL, true>(ra, r, tab);
-            else sr_rows_pk_body<PFAST, BS, CELL>(ra, r, tab);
-          } else {
-            sr_rows_pk_body<PFAST, BS, CELL>(ra, r, tab);
-          }
+      sr_rows_pk_body<PFAST, BS, CELL>(ra, r, tab);
       return;
     }
   }
@@ -1418,67 +1403,6 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   return MIPME_OK;
 }
 
-// ---- table of v_SR, v_SR'/d in d^2 for the packed fp32 Coulomb body (rows_body.h, kSrTab*) --------------------------------------
-__global__ __launch_bounds__(128) void sr_table_kernel(double c1, double pref, float* __restrict__ tab) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > kSrTabIntervals) return;
-  float* o = tab + 8 * j;
-  if (j == kSrTabIntervals) {  // beyond d = 8 sigma: erfc < 1e-15
-    for (int k = 0; k < 8; ++k) o[k] = 0.f;
-    return;
-  }
-  const double s_lo = 1.0 / (128.0 * c1 * c1);  // sigma^2 / 64 with 1 / sigma^2 = 2 c1^2
-  const int oct = j >> kSrTabBits, mm = j & ((1 << kSrTabBits) - 1);
-  const double base = s_lo * double(1u << oct), h = base / double(1 << kSrTabBits), s0 = base + mm * h;
-  double f[4], g[4];
-  for (int k = 0; k < 4; ++k) {
-    const double sk = s0 + h * (double(k) / 3.0), d = sqrt(sk), y = c1 * d;
-    const double ec = erfc(y);
-    f[k] = pref * ec / d;
-    g[k] = -pref * (ec / d + 1.1283791670955126 * c1 * exp(-y * y)) / sk;  // v'(d) / d
-  }
-  auto cubic = [&](const double (&v)[4], int which) {
-    const double a3 = 4.5 * (-v[0] + 3.0 * v[1] - 3.0 * v[2] + v[3]), a2 = 4.5 * (2.0 * v[0] - 5.0 * v[1] + 4.0 * v[2] - v[3]),
-                 a1 = 0.5 * (-11.0 * v[0] + 18.0 * v[1] - 9.0 * v[2] + 2.0 * v[3]), a0 = v[0];
-    o[0 + which] = float(a3);
-    o[2 + which] = float(a2);
-    o[4 + which] = float(a1);
-    o[6 + which] = float(a0);
-  };
-  cubic(f, 0);
-  cubic(g, 1);
-}
-
-// device table for (c1, pref), built on first use (a hipMalloc: not during stream capture -- the callers warm up) and kept for
-// the life of the process; NULL switches the table off (MIPME_SR_TABLE=0, or the allocation failed)
-static const float* sr_table_for(hipStream_t st, const FastRS& cf) {
-  static const bool on = env_flag("MIPME_SR_TABLE", true);
-  if (!on) return nullptr;
-  struct Entry { double c1, pref; int device; float* tab; };
-  static std::mutex mu;
-  static std::vector<Entry> cache;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lock(mu);
-  for (const Entry& e : cache)
-    if (e.c1 == cf.c1 && e.pref == cf.pref && e.device == dev) return e.tab;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return nullptr;  // first use under capture: the analytic body (same results to 1e-7)
-  }
-  float* tab = nullptr;
-  if (hipMalloc((void**)&tab, kSrTabLdsBytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  sr_table_kernel<<<(kSrTabIntervals + 128) / 128, 128, 0, st>>>(cf.c1, cf.pref, tab);
-  if (hipGetLastError() != hipSuccess) return nullptr;
-  if (cache.size() >= 64) cache.erase(cache.begin());  // (the evicted table is leaked: 12 KB, and a captured graph may still read it)
-  cache.push_back(Entry{cf.c1, cf.pref, dev, tab});
-  return tab;
-}
-
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
                   int* clear_count, const mipme_sr_job_t* job, bool want_epart, double* cpart) {
@@ -1521,16 +1445,12 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     FusedRowsArgs<T> ra_e = ra;
     ra_e.epart = want_epart ? v.epart : nullptr;
     ra_e.cpart = cpart;
-    if (sizeof(T) == 4 && pfast == 1 && (job->shift_format & kShiftFormatMask) == kShiftTable32 && !job->dist_out)
-      ra_e.sr_table = sr_table_for(st, cf);
     MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
                   "the cell sums of the pair kernel need 4-byte entries, 1/r (or fp32 1/r^6) and no distance by-product");
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned n_spread = unsigned(bg.nb);
-    // (row workgroups keep their shift table -- and the v_SR table -- in the launch's dynamic LDS)
-    const size_t lds_rows = sizeof(AtomRecord<T>) * kShiftTableSize + (ra_e.sr_table ? kSrTabLdsBytes : 0);
-    const size_t lds_k = std::max(lds, lds_rows);
+    const size_t lds_k = lds;
     if (sparse) {  // the bricks first, by themselves; then the pair sum in a launch of its own (rows_only_kernel)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
@@ -2347,12 +2267,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_s
       extern __shared__ __attribute__((aligned(16))) char smem_rows[];
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
       if constexpr (std::is_same<T, float>::value)
-        if constexpr (PFAST == 1) {
-            if (ra.sr_table) sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL, true>(ra, r, tab);
-            else sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-          } else {
-            sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-          }
+        sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
 #if MIPME_ROW_LANES == 16
       else if constexpr (PFAST == 1)
         sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
@@ -2582,22 +2497,20 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
                                                 job->shift_format);
   ra.epart = v.epart;
   ra.cpart = cpart;
-  if (sizeof(T) == 4 && pfast == 1) ra.sr_table = sr_table_for(st, cf);
-  const size_t lds_live = std::max(lds, sizeof(AtomRecord<T>) * kShiftTableSize + (ra.sr_table ? kSrTabLdsBytes : 0));
   MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
                 "the cell sums of the pair kernel need 4-byte entries and 1/r (or fp32 1/r^6)");
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
   const unsigned grid = live_home_blocks(N, bg.xcd) + (bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks);
   if (cpart && pfast == 1)
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_live, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   else if (cpart) {
     if constexpr (sizeof(T) == 4)
-      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds_live, st>>>(sa, ra, n_spread)));
+      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   } else if (pfast == 1)
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds_live, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   else
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds_live, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }

@@ -104,8 +104,6 @@ struct FusedRowsArgs {
   // -- the pair part of dE/dcell is  f/2 * inv(A)^T-contracted C (every pair sits in two rows; kfilter.hip
   // cell_tail_finalize_kernel)
   double* cpart;
-  // packed fp32 Coulomb body with TAB: v_SR and v_SR'/d from a table in d^2 (sr_table_* below), nullable
-  const float* sr_table;
   const int* skip;  // nullable: the stand-alone kernels return at once if *skip == 1 (mipme_set_skip_flag)
   int row_stride;  // words of row_ptr per atom: 2 (rows share their boundaries) or 3 (kRowsPadded)
   bool symmetric;  // kRowsPadded: every pair appears in both of its rows as a "role i" entry
@@ -141,7 +139,6 @@ static inline FusedRowsArgs<T> make_fused_rows_args(const SRPot& s, const FastRS
   a.dist_out = (T*)dist_out;
   a.epart = nullptr;
   a.cpart = nullptr;
-  a.sr_table = nullptr;
   a.skip = nullptr;
   a.symmetric = (shift_format & kRowsPadded) != 0;
   a.row_stride = a.symmetric ? 3 : 2;
@@ -643,23 +640,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   }
 }
 
-// ---- v_SR(d), v_SR'(d)/d of the Coulomb potential from a table in s = d^2 --------------------------------------------------
-// The packed body spends 6 of its ~75 vector instructions per two entries on quarter-rate transcendentals (rsq, exp2, rcp: 24
-// issue slots) and ~20 more on the erfc polynomial and the products behind them.  Both functions are smooth in s on a
-// logarithmic scale, so: x = s * 64 / sigma^2 (the table starts at d = sigma / 8), interval = exponent and top kSrTabBits
-// mantissa bits of the float x (kSrTabOctaves octaves: up to d = 8 sigma, beyond which erfc < 1e-15 and the entry is zero),
-// t = the remaining mantissa bits in [0, 1), and per interval a cubic through four equidistant nodes for BOTH functions, stored
-// as pairs (v, v'/d) so that one packed Horner scheme -- three v_pk_fma_f32 -- evaluates them together.  Relative error of the
-// cubic at 32 intervals per octave: <= 5e-4 (h/s)^4 s^4 f''''/f ~ 1e-8 where the values matter (d < 5 sigma).  x < 1 (atoms
-// closer than sigma / 8) takes the analytic path (wave-uniform branch).  Coefficients are computed in double precision once per
-// (smearing, prefactor) (bricks.hip sr_table_for) and copied to LDS by every row workgroup (12 KB).
-static constexpr int kSrTabBits = 5, kSrTabOctaves = 12;
-static constexpr int kSrTabIntervals = kSrTabOctaves << kSrTabBits;           // + one all-zero interval behind them
-static constexpr int kSrTabFloats = (kSrTabIntervals + 1) * 8;                // 4 pairs per interval
-static constexpr size_t kSrTabLdsBytes = sizeof(float) * kSrTabFloats;
-
 #if MIPME_ROW_LANES == 16
-template <int PFAST, int BS, bool CELL = false, bool TAB = false>
+template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
                                                 AtomRecord<float>* __restrict__ shift_tab) {
   static_assert(kRowLanes == 16, "the packed body walks 2 x 16 entries per row and iteration");
@@ -708,13 +690,6 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
                                        sx * A[2] + sy * A[5] + sz * A[8], 0.f};
     }
   }
-  static_assert(!TAB || PFAST == 1, "the table is the Coulomb potential's");
-  f2v* __restrict__ srt = reinterpret_cast<f2v*>(shift_tab + kShiftTableSize);  // [kSrTabIntervals + 1][4] pairs (TAB)
-  if constexpr (TAB) {
-    const f2v* __restrict__ gt = reinterpret_cast<const f2v*>(args.sr_table);
-    for (int k = threadIdx.x; k < kSrTabFloats / 2; k += BS) srt[k] = gt[k];
-  }
-  const float c_xs = 128.f * c_inv2s2;  // x = d^2 * 64 / sigma^2
   const int pot_end = args.full ? mid : 0x7fffffff;  // a full list feeds the potential from role i only
   const int beg = r0, end = valid ? r2 : r0;
   const i4v ent_rs = uniform_rsrc(raw_buffer(args.ent_sh, unsigned(n_entries) * 4u));
@@ -755,33 +730,7 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     const f2v d2 = f2v{okA ? dA : 1.f, okB ? dB : 1.f};
     const f2v sv = f2v{okA ? cRA.w : 0.f, okB ? cRB.w : 0.f};
     f2v v, dvd;
-    if constexpr (TAB) {
-      const f2v x = d2 * c_xs;
-      if (__builtin_amdgcn_ballot_w64(x.x < 1.f || x.y < 1.f) != 0) {  // (an atom pair closer than sigma / 8: analytic)
-        fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
-      } else {
-        const unsigned bA = __float_as_uint(x.x), bB = __float_as_uint(x.y);
-        constexpr int kShift = 23 - kSrTabBits;
-        int iA = int(bA >> kShift) - (127 << kSrTabBits), iB = int(bB >> kShift) - (127 << kSrTabBits);
-        iA = iA < kSrTabIntervals ? iA : kSrTabIntervals;
-        iB = iB < kSrTabIntervals ? iB : kSrTabIntervals;
-        const float tA = float(bA & ((1u << kShift) - 1u)) * (1.f / float(1u << kShift));
-        const float tB = float(bB & ((1u << kShift) - 1u)) * (1.f / float(1u << kShift));
-        const f2v* __restrict__ cA = srt + 4 * iA;
-        const f2v* __restrict__ cB = srt + 4 * iB;
-        f2v rA = cA[0], rB = cB[0];
-        rA = rA * tA + cA[1];
-        rB = rB * tB + cB[1];
-        rA = rA * tA + cA[2];
-        rB = rB * tB + cB[2];
-        rA = rA * tA + cA[3];
-        rB = rB * tB + cB[3];
-        v = f2v{rA.x, rB.x};
-        dvd = f2v{rA.y, rB.y};
-      }
-    } else {
-      fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
-    }
+    fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
     pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
     const f2v sc = sv * dvd;
     if constexpr (CELL) {
@@ -847,7 +796,7 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
 
 #else
 // experiment builds with another row width (tools/build_variant.sh ... -DMIPME_ROW_LANES=32): no packed body, the generic one
-template <int PFAST, int BS, bool CELL = false, bool TAB = false>
+template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
                                                 AtomRecord<float>* __restrict__ shift_tab) {
   static_assert(!CELL, "the cell sums of the energy step need the packed body (MIPME_ROW_LANES == 16)");

@@ -362,8 +362,26 @@ def verify_bets() -> None:
         raise SpeculationLost()
 
 
+class betting:
+    """``with betting(): ...`` -- the caller WILL call :func:`verify_bets` before it hands out anything computed inside.  Bets are
+    only placed inside such a scope (a path that looks a list up without verifying -- the Ewald and direct calculators, the graph
+    classes -- always builds or finds the structures of exactly its tensor)."""
+
+    def __enter__(self):
+        _BET_SCOPE[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _BET_SCOPE[0] -= 1
+        return False
+
+
+_BET_SCOPE = [0]
+
+
 def _can_bet(t: torch.Tensor) -> bool:
-    return (SPECULATE_LISTS and _BET_PAUSE[0] == 0 and len(_BETS) < 32 and t.is_contiguous() and t.data_ptr() % 16 == 0
+    return (SPECULATE_LISTS and _BET_SCOPE[0] > 0 and _BET_PAUSE[0] == 0 and len(_BETS) < 32 and t.is_contiguous()
+            and t.data_ptr() % 16 == 0
             and (t.numel() * t.element_size()) % 4 == 0 and not torch.cuda.is_current_stream_capturing())
 
 
@@ -1532,7 +1550,8 @@ def pair_distances(positions, neighbor_indices, cell=None, neighbor_shifts=None,
 @torch.compiler.disable
 def _pair_distances_eager(positions, neighbor_indices, cell, neighbor_shifts, deferred):
     try:
-        dist = _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, deferred)
+        with betting():
+            dist = _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, deferred)
         verify_bets()  # (SPECULATE_LISTS: the structures of a previous list tensor may have been reused on a bet)
         return dist
     except SpeculationLost:
