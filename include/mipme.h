@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 400
+#define MIPME_VERSION 401
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -442,6 +442,18 @@ int mipme_energy_select(void* stream, int dtype, int64_t n_atoms, const void* ve
  * (all (N,3); out may alias grad_mesh or grad_pair). */
 int mipme_energy_select_sum(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* charges, const void* force,
                             const void* field, int full_list, const void* grad_mesh, const void* grad_pair, void* out);
+/* ... and for the rest of the autograd contract (Calculator.forward's gradients w.r.t. charges and cell,
+ * tests/calculators/test_workflow.py:164-192) when the forward's gather tail holds them for the energy mode (out_grad_charges,
+ * out_grad_cell of mipme_kspace_forward, per unit seed):
+ *   grad_charges[a] = match ? 1/2 s tail_grad_charges[a] : grad_charges[a]            (N; in: the general adjoint's; nullable)
+ *   grad_cell[i]    = match ? s tail_grad_cell[(pair_through_distances ? 0 : 18) + i]
+ *                           : cell_mesh[i] + cell_pair[i]                             (9; cell_pair nullable; all nullable)
+ * 1/2: the tail holds the TOTAL dE/dq = 2 V of E = sum q V, of which the calculator's node owns the half that comes from V's
+ * dependence on the charges.  pair_through_distances != 0: the pair part of dE/dcell flows through neighbor_distances (its
+ * gradient is observed), so only the mesh part (tail slots 0..8) belongs to the calculator's own cell argument. */
+int mipme_energy_select_contract(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* tail_grad_charges,
+                                 void* grad_charges, const void* tail_grad_cell, int pair_through_distances,
+                                 const void* cell_mesh, const void* cell_pair, void* grad_cell);
 
 /* ---- caller side: pair distances, tests/helpers.py:278-304 ------------------------------------ */
 

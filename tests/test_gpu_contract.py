@@ -319,3 +319,75 @@ def test_new_list_tensors_with_old_values_reuse_the_structures(monkeypatch):
     ops._BET_PAUSE[0] = 0
     E2, _ = energy_forces(c["pairs"].clone(), c["shifts"], plain_distances=True)
     assert len(built) == n and abs(E1 - Eo) <= 1e-9 * abs(Eo) and abs(E2 - Eo) <= 1e-9 * abs(Eo)
+
+
+FRONT_CASES = [("P3M", 5, 1, False), ("PME", 4, 1, True), ("P3M", 4, 6, True)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("mode", ["energy", "general", "energy+observed", "general+observed", "charges-only", "cell-only"])
+@pytest.mark.parametrize("scheme,order,expo,tri", FRONT_CASES)
+def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mode, dtype):
+    """csrc/front.cpp with charges / cell as leaves (the reference's tests/calculators/test_workflow.py:164-192 through
+    `pair_distances` + calculator + plain tensor reduction): the gather tail's dE/dq, dE/dcell on a match, the general adjoint
+    otherwise, the pair part through the distances node when dE/d(neighbor_distances) is observed.  Twice through a retained
+    graph (the forward's records must survive the charge adjoint)."""
+    from torchpme_amd import _front
+
+    if _front.module() is None:
+        pytest.skip("compiled front end not built")
+    c = setup(dtype, scheme, order, expo, tri, seed=1)
+    spec, _, _, hmesh, q, cell, pos, pairs, S = c["np"]
+    w = q if not mode.startswith("general") else np.random.default_rng(5).normal(size=q.shape)
+    dist, _ = O.pair_distances(pos, cell, pairs, S)
+    Vo, cache = O.forward(spec, "P3M" if scheme == "P3M" else "Lagrange", order, hmesh, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, w)
+    gpo, gcell_pair = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    gpo, dqo, dco, ddo = gpo + gr["positions"], gr["charges"], gr["cell"] + gcell_pair, gr["dist"]
+    tp = c["pos"].clone().requires_grad_(True)
+    tq = c["q"].clone().requires_grad_(mode != "cell-only")
+    tc = c["cell"].clone().requires_grad_(mode != "charges-only")
+    d = tpa.pair_distances(tp, c["pairs"], tc, c["shifts"])
+    assert _front.module().is_front_distances(d)
+    V = c["calc"](tq, tc, tp, c["pairs"], d)
+    fp64_ipl_cell = expo == 6 and dtype == torch.float64 and tc.requires_grad  # (no fp64 1/r^6 cell sums in the tail: Python nodes)
+    assert (V.grad_fn.name() == "MipmeCalculatorBackward") != fp64_ipl_cell
+    if "observed" in mode:
+        d.retain_grad()
+    tw = tq.detach() if w is q else torch.tensor(w, dtype=dtype, device=DEV)
+    tol = 1e-9 if dtype == torch.float64 else 3e-4
+    for rep in range(2):
+        for t in (tp, tq, tc, d):
+            t.grad = None
+        (tw * V).sum().backward(retain_graph=True)
+        assert rel(V, Vo) <= tol and rel(tp.grad, gpo) <= tol
+        if tq.requires_grad:
+            assert rel(tq.grad, dqo) <= tol
+        if tc.requires_grad:
+            assert rel(tc.grad, dco) <= tol
+        if "observed" in mode:
+            assert rel(d.grad, ddo) <= tol
+
+
+def test_compiled_front_end_contract_with_the_polled_verdict():
+    """MIPME_FRONT_POLL=1 (the verdict of the energy-mode test read on the host): same numbers as the device-side select."""
+    from torchpme_amd import _front
+
+    mod = _front.module()
+    if mod is None:
+        pytest.skip("compiled front end not built")
+    c = setup(torch.float64, "P3M", 5, 1, True, seed=2)
+    Eo, gpo, dqo, dco, _ = oracle_contract(*c["np"])
+    try:
+        for device_select in (False, True):
+            mod.set_device_select(device_select)
+            tp, tq, tc = (c[k].clone().requires_grad_(True) for k in ("pos", "q", "cell"))
+            d = tpa.pair_distances(tp, c["pairs"], tc, c["shifts"])
+            V = c["calc"](tq, tc, tp, c["pairs"], d)
+            assert V.grad_fn.name() == "MipmeCalculatorBackward"
+            E = (tq * V).sum()
+            E.backward()
+            assert abs(float(E) - Eo) <= 1e-9 * abs(Eo)
+            assert rel(tp.grad, gpo) <= 1e-9 and rel(tq.grad, dqo) <= 1e-9 and rel(tc.grad, dco) <= 1e-9
+    finally:
+        mod.set_device_select(os.environ.get("MIPME_FRONT_POLL", "0") == "0")

@@ -37,10 +37,10 @@ def _tensors(cell, pos, q, pairs, S, dtype):
     return t(q), t(cell), t(pos, True), torch.tensor(pairs, device=DEV), t(S)
 
 
-def _calc(scheme="P3M", exponent=1):
+def _calc(scheme="P3M", exponent=1, full_neighbor_list=False):
     pot = tpa.CoulombPotential(smearing=1.1) if exponent == 1 else tpa.InversePowerLawPotential(exponent=exponent, smearing=1.1)
     cls = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
-    return cls(pot, mesh_spacing=0.9, interpolation_nodes=4)
+    return cls(pot, mesh_spacing=0.9, interpolation_nodes=4, full_neighbor_list=full_neighbor_list)
 
 
 def _reference_sequence(calc, tq, tc, tp, ti, tS, weights=None):
@@ -149,22 +149,46 @@ def test_calls_outside_the_case_use_the_python_nodes():
     gr = O.backward(cache, q)
     gpos_d, gcell_d = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
     calc = _calc()
-    # charges with a gradient: compiled distances node + Python calculator node (its LazyPairGradient reaches the C++ node)
+    # charges with a gradient and a FULL list (dE/dq = 2 V needs a symmetric list): compiled distances node + Python calculator
+    # node (its LazyPairGradient reaches the C++ node)
+    full = np.concatenate([pairs, pairs[:, ::-1]])
+    S_full = np.concatenate([S, -S])
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, full, S_full, torch.float64)
+    tq.requires_grad_(True)
+    calc_full = _calc(full_neighbor_list=True)
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    V = calc_full(tq, tc, tp, ti, d)
+    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() != CALC_NODE
+    (tq.detach() * V).sum().backward()
+    assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
+    assert rell2(tq.grad.cpu(), gr["charges"]) < 1e-10
+    # charges / cell with a gradient and a half list: the compiled nodes (tests/test_gpu_contract.py has the cases)
     tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
     tq.requires_grad_(True)
+    tc.requires_grad_(True)
     d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS, tq.detach())
-    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() != CALC_NODE
+    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() == CALC_NODE
     E.backward()
     assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
     assert rell2(tq.grad.cpu(), gr["charges"]) < 1e-10
-    # cell with a gradient: both nodes are the Python ones
+    assert rell2(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+    # cell with a gradient and a call outside the case (`periodic`): compiled distances node + Python calculator node, whose
+    # placeholder gradient carries the pair part of dE/dcell to the C++ node
     tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
     tc.requires_grad_(True)
-    d, V, E = _reference_sequence(calc, tq, tc, tp, ti, tS)
-    assert d.grad_fn.name() != DIST_NODE and V.grad_fn.name() != CALC_NODE
-    E.backward()
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    V = calc(tq, tc, tp, ti, d, periodic=torch.tensor([True, True, True], device=DEV))
+    assert d.grad_fn.name() == DIST_NODE and V.grad_fn.name() != CALC_NODE
+    (tq * V).sum().backward()
     assert rell2(tp.grad.cpu(), gr["positions"] + gpos_d) < 1e-10
     assert rell2(tc.grad.cpu(), gr["cell"] + gcell_d) < 1e-9
+    # ... and a plain (P,) gradient for the distances with a cell that requires one: the distance adjoint's own cell sums
+    tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
+    tc.requires_grad_(True)
+    d = tpa.pair_distances(tp, ti, tc, tS)
+    (0.5 * (d * d).sum()).backward()
+    gp_dd, gc_dd = O.pair_distances_backward(pos, cell, pairs, S, dist)
+    assert rell2(tp.grad.cpu(), gp_dd) < 1e-10 and rell2(tc.grad.cpu(), gc_dd) < 1e-10
     # a `periodic` argument, a pair mask, no gradient at all, distances from elsewhere
     tq, tc, tp, ti, tS = _tensors(cell, pos, q, pairs, S, torch.float64)
     d = tpa.pair_distances(tp, ti, tc, tS)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmipme.so does not export {name}"
     assert sorted(declared) == sorted(_lib.EXPORTS)
-    assert lib.mipme_version() == 400
+    assert lib.mipme_version() == 401
 
 
 def test_compiled_front_end_loads_and_declines_cpu_tensors():
@@ -41,9 +41,9 @@ def test_compiled_front_end_loads_and_declines_cpu_tensors():
     # descriptor sizes of the ctypes mirror and of include/mipme.h as front.cpp was compiled against it
     pot = tpa.CoulombPotential(smearing=1.0)._descriptor()
     with pytest.raises(RuntimeError, match="descriptor size mismatch"):
-        mod.Calculator(b"x", bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None)
+        mod.Calculator(b"x", bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None, None)
     md = _lib.MeshDesc()
-    fc = mod.Calculator(bytes(md), bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None)
+    fc = mod.Calculator(bytes(md), bytes(pot), 0, torch.zeros(1), torch.eye(3), False, 0, 1, None, None)
     # CPU tensors: not this file's case -> None, the Python path (which raises the reference's errors) takes over
     pos = torch.zeros((4, 3), requires_grad=True)
     assert mod.calc_forward(fc, torch.zeros((4, 1)), torch.eye(3), pos, torch.zeros((2, 2), dtype=torch.int64), torch.zeros(2)) is None

@@ -44,10 +44,10 @@ def module():
     def unwrap(g):
         """What a distances node made by the extension does with a gradient that is a tensor subclass."""
         if isinstance(g, ops.LazyPairGradient):
-            if not g.materialized and g._grad_pos is not None:
-                return g._grad_pos, None
-            return None, g.materialize()
-        return None, g
+            if not g.materialized and (g._grad_pos is not None or g._grad_cell is not None):
+                return g._grad_pos, g._grad_cell, None
+            return None, None, g.materialize()
+        return None, None, g
 
     mod.set_unwrap(unwrap)
     mod.set_second_order_hint(ops.SECOND_ORDER_HINT)

@@ -34,7 +34,7 @@ EXPORTS = (
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
-    "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum",
+    "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum", "mipme_energy_select_contract",
     "mipme_kfilter_build_deriv", "mipme_cell_tail_work", "mipme_values_equal", "mipme_checksum",
 )
 
@@ -268,6 +268,7 @@ def _declare(lib):
         "mipme_checksum": [vp, vp, i64, vp, vp, vp],
         "mipme_energy_select": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp],
         "mipme_energy_select_sum": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
+        "mipme_energy_select_contract": [vp, ci, i64, vp, vp, vp, vp, ci, vp, vp, vp],
         "mipme_md_rebin": [C.POINTER(MdArgs)],
         "mipme_md_step": [C.POINTER(MdArgs)],
     }

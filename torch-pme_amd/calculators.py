@@ -362,7 +362,7 @@ class PMECalculator(Calculator):
 
     def _front_forward(self, charges, cell, positions, neighbor_indices, neighbor_distances):
         """The call through the C++ autograd nodes of ``csrc/front.cpp`` when ``neighbor_distances`` comes from this package's
-        ``pair_distances`` (its compiled node) and only ``positions`` wants a gradient; ``None`` sends the call down the Python
+        ``pair_distances`` (its compiled node); gradients for positions, charges and cell; ``None`` sends the call down the Python
         path, which also owns every error message: nothing is validated here beyond what decides the route."""
         mod = _front.module()
         if (mod is None or type(neighbor_distances) is not torch.Tensor or not mod.is_front_distances(neighbor_distances)
@@ -370,7 +370,8 @@ class PMECalculator(Calculator):
                 or cell.dtype != positions.dtype or cell.device != positions.device):
             return None
         geom, G = self._kspace_setup(cell, positions.dtype, positions.device, speculate=False)
-        key = (bool(self.full_neighbor_list), self.check_nan)
+        want_cell = cell.requires_grad
+        key = (bool(self.full_neighbor_list), self.check_nan, want_cell)
         c = geom.__dict__.get("_front")
         if c is None or c[0] != key:
             fc = None
@@ -380,8 +381,13 @@ class PMECalculator(Calculator):
             if (p_eff in (1, 6) and pot_desc.smearing > 0 and pot_desc.exclusion_radius <= 0 and plan.xfused and ops.XFUSED
                     and ops.MESH_MODE == "bricks" and ops.PAIR_MODE == "rows" and ops.COSCHEDULE and ops.ENERGY_FAST_PATH
                     and ops.ENERGY_DETECT and ops.COMPACT_ENTRIES and ops.FUSE_DISTANCES and not ops.OVERLAP):
+                # (a cell that requires a gradient: the derivative table of G for the gather tail's dE/dcell -- 1/r in either
+                # precision, 1/r^6 in fp32 (mipme.h, out_grad_cell); without it the C++ side declines such calls)
+                deriv = None
+                if want_cell and (p_eff == 1 or positions.dtype == torch.float32):
+                    deriv = ops.filter_derivative(geom, pot_desc, positions.dtype, positions.device)
                 fc = mod.Calculator(bytes(geom.desc(1)), bytes(pot_desc), plan.handle.value, G, cell,
-                                    bool(self.full_neighbor_list), self._nan_flag_ptr() or 0, geom.n_half, plan)
+                                    bool(self.full_neighbor_list), self._nan_flag_ptr() or 0, geom.n_half, plan, deriv)
             c = geom._front = (key, fc)
         if c[1] is None:
             return None

@@ -759,6 +759,24 @@ __global__ __launch_bounds__(256) void energy_select_sum_kernel(int64_t N, const
     out[t] = match ? s * q[t / 3] * (f * force[t] + field[t]) : grad_mesh[t] + grad_pair[t];
 }
 
+// ... and for the charge / cell gradients of the same step (mipme.h, mipme_energy_select_contract)
+template <typename T>
+__global__ __launch_bounds__(256) void energy_select_contract_kernel(int64_t N, const T* __restrict__ verdict,
+                                                                    const T* __restrict__ tail_q, T* grad_q,
+                                                                    const T* __restrict__ tail_cell, int cell_off,
+                                                                    const T* cell_mesh, const T* cell_pair, T* grad_cell) {
+  const bool match = verdict[1] == T(1);
+  const T s = verdict[0];
+  if (grad_cell && blockIdx.x == 0 && threadIdx.x < 9) {
+    const int i = threadIdx.x;
+    grad_cell[i] = match ? s * tail_cell[cell_off + i] : cell_mesh[i] + (cell_pair ? cell_pair[i] : T(0));
+  }
+  if (!grad_q || !match) return;  // (the general adjoint's charge gradient is already in place)
+  const T h = T(0.5) * s;
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < N; t += int64_t(gridDim.x) * blockDim.x)
+    grad_q[t] = h * tail_q[t];
+}
+
 static double axis_length(const mipme_mesh_t* m, int axis) {
   const double* a = m->cell + 3 * axis;
   return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -1430,6 +1448,34 @@ int mipme_energy_select_sum(void* stream, int dtype, int64_t n_atoms, const void
     energy_select_sum_kernel<double><<<blocks, 256, 0, st>>>(n_atoms, (const double*)verdict, (const double*)charges,
                                                             (const double*)force, (const double*)field, full_list ? 0.5 : 1.0,
                                                             (const double*)grad_mesh, (const double*)grad_pair, (double*)out);
+  else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_energy_select_contract(void* stream, int dtype, int64_t n_atoms, const void* verdict, const void* tail_grad_charges,
+                                 void* grad_charges, const void* tail_grad_cell, int pair_through_distances,
+                                 const void* cell_mesh, const void* cell_pair, void* grad_cell) {
+  MIPME_REQUIRE(n_atoms >= 0 && verdict, "invalid arguments to mipme_energy_select_contract");
+  MIPME_REQUIRE(!grad_charges || tail_grad_charges, "grad_charges needs the tail's charge gradient");
+  MIPME_REQUIRE(!grad_cell || (tail_grad_cell && cell_mesh), "grad_cell needs the tail's cell gradient and the general mesh part");
+  if (!grad_cell && (!grad_charges || n_atoms == 0)) return MIPME_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = grad_charges ? unsigned(std::max<int64_t>(1, std::min<int64_t>((n_atoms + 255) / 256, 2048))) : 1u;
+  const int off = pair_through_distances ? 0 : 18;
+  if (dtype == MIPME_F32)
+    energy_select_contract_kernel<float><<<blocks, 256, 0, st>>>(n_atoms, (const float*)verdict, (const float*)tail_grad_charges,
+                                                                (float*)grad_charges, (const float*)tail_grad_cell, off,
+                                                                (const float*)cell_mesh, (const float*)cell_pair,
+                                                                (float*)grad_cell);
+  else if (dtype == MIPME_F64)
+    energy_select_contract_kernel<double><<<blocks, 256, 0, st>>>(n_atoms, (const double*)verdict,
+                                                                 (const double*)tail_grad_charges, (double*)grad_charges,
+                                                                 (const double*)tail_grad_cell, off, (const double*)cell_mesh,
+                                                                 (const double*)cell_pair, (double*)grad_cell);
   else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;

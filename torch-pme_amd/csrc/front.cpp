@@ -6,7 +6,8 @@
 //
 // The kernels are libmipme's (include/mipme.h); what this file replaces is the HOST side of the two autograd nodes for the
 // common case -- single-channel mesh calculator, 1/r or 1/r^6 with a smearing, fully periodic, no masks, gradients wanted for
-// the positions only -- which in Python costs ~0.3 ms per step at 32 000 atoms against ~0.12 ms of kernels (two
+// the positions and, from round 4, for the charges and the cell as well (the whole contract of
+// tests/calculators/test_workflow.py:164-192) -- which in Python costs ~0.3 ms per step at 32 000 atoms against ~0.12 ms of kernels (two
 // torch.autograd.Function round trips, a dozen torch.empty, ctypes marshalling; profiles/r03_d_prof_dropin.txt).  Here both
 // nodes are C++ autograd nodes, each direction is one function that fills the versioned argument structs and calls the C-ABI,
 // and the scratch of a call is two allocations.  Anything outside the common case returns None and the Python path
@@ -21,7 +22,11 @@
 //     the stand-alone kernel and flows through the distances node, as in the reference's graph (ops.LazyPairGradient does the
 //     same lazily in Python);
 //   * energy mode (upstream gradient == gE * charges, decided on the device by mipme_scaled_match + a pinned-word poll) uses
-//     the per-atom sums of the forward; any other upstream gradient takes the general adjoint kernels.
+//     the per-atom sums of the forward; any other upstream gradient takes the general adjoint kernels;
+//   * charges / cell that require a gradient: the forward's gather tail also leaves dE/dq = 2 V and dE/dcell of the energy
+//     mode (mipme.h: out_grad_charges, out_grad_cell), the general adjoint forms them for any other upstream gradient, and
+//     mipme_energy_select_contract picks on the device.  The pair part of dE/dcell reaches `cell` from the calculator's node
+//     directly, like the pair part of dE/dpositions -- unless dE/d(neighbor_distances) is observed.
 //
 // Build: torch-pme_amd/csrc/Makefile target `front` (g++; no device code here).  libmipme.so is dlopen'ed at the path the
 // Python layer loaded it from, so MIPME_LIB builds are honoured.
@@ -69,6 +74,10 @@ struct Api {
   decltype(&mipme_rspace_backward) rspace_backward = nullptr;
   decltype(&mipme_set_skip_flag) set_skip_flag = nullptr;
   decltype(&mipme_energy_select_sum) energy_select_sum = nullptr;
+  decltype(&mipme_energy_select_contract) energy_select_contract = nullptr;
+  decltype(&mipme_cell_tail_work) cell_tail_work = nullptr;
+  decltype(&mipme_cellgrad_partials_size) cellgrad_partials_size = nullptr;
+  decltype(&mipme_rows_partials_size) rows_partials_size = nullptr;
 };
 Api g_api;
 
@@ -97,6 +106,10 @@ void load_library(const std::string& path) {
   bind(g_api.rspace_backward, "mipme_rspace_backward");
   bind(g_api.set_skip_flag, "mipme_set_skip_flag");
   bind(g_api.energy_select_sum, "mipme_energy_select_sum");
+  bind(g_api.energy_select_contract, "mipme_energy_select_contract");
+  bind(g_api.cell_tail_work, "mipme_cell_tail_work");
+  bind(g_api.cellgrad_partials_size, "mipme_cellgrad_partials_size");
+  bind(g_api.rows_partials_size, "mipme_rows_partials_size");
   if (g_api.version() != MIPME_VERSION)
     throw std::runtime_error("libmipme version " + std::to_string(g_api.version()) + " != header " + std::to_string(MIPME_VERSION));
 }
@@ -162,6 +175,7 @@ struct FrontCalc {
   mipme_potential_t pot;
   mipme_fft_plan* plan = nullptr;
   at::Tensor G;
+  at::Tensor G_deriv;  // derivative table of G (mipme_kfilter_build_deriv); undefined: no cell gradients through this file
   at::Tensor cell;  // the cell tensor the geometry and G belong to (identity + version)
   uint32_t cell_version = 0;
   int full_list = 0;
@@ -180,7 +194,8 @@ struct FrontCalc {
 };
 
 // ops.LazyPairGradient (the Python calculator path's placeholder for dE/d(neighbor_distances)) may arrive at a distances node made
-// here, when the calculator call itself was outside this file's case: `unwrap(g) -> (grad_positions | None, plain tensor | None)`
+// here, when the calculator call itself was outside this file's case:
+// `unwrap(g) -> (grad_positions | None, grad_cell | None, plain tensor | None)`
 py::object* g_unwrap = nullptr;  // leaked on purpose (no interpreter at static destruction time)
 void set_unwrap(py::object fn) { g_unwrap = new py::object(std::move(fn)); }
 
@@ -212,15 +227,17 @@ struct DistNode : public Node {
   variable_list apply(variable_list&& grads) override {
     variable_list out(2);
     at::Tensor g = grads[0];
-    if (!g.defined() || !task_should_compute_output(0)) return out;
+    const bool want_pos = task_should_compute_output(0), want_cell = task_should_compute_output(1);
+    if (!g.defined() || (!want_pos && !want_cell)) return out;
     if (g.unsafeGetTensorImpl()->is_python_dispatch() && g_unwrap) {
       py::gil_scoped_acquire gil;
       py::tuple r = (*g_unwrap)(g);
-      if (!r[0].is_none()) {  // the fused kernels of the Python path have applied this node's Jacobian already
-        out[0] = r[0].cast<at::Tensor>();
+      if (!r[0].is_none() || !r[1].is_none()) {  // the fused kernels of the Python path have applied this node's Jacobian already
+        if (!r[0].is_none()) out[0] = r[0].cast<at::Tensor>();
+        if (!r[1].is_none()) out[1] = r[1].cast<at::Tensor>();
         return out;
       }
-      g = r[1].cast<at::Tensor>();
+      g = r[2].cast<at::Tensor>();
     }
     TORCH_CHECK(pos._version() == pos_version && cell._version() == cell_version,
                 "positions or cell of pair_distances() were modified in place before the backward pass");
@@ -230,18 +247,25 @@ struct DistNode : public Node {
       at::Tensor i = topo->pairs32.select(1, 0).to(at::kLong), j = topo->pairs32.select(1, 1).to(at::kLong);
       at::Tensor vec = pos_in.index_select(0, j) - pos_in.index_select(0, i) + topo->shifts.matmul(cell_in);
       at::Tensor gvec = (g / at::linalg_vector_norm(vec, 2, at::IntArrayRef{1})).unsqueeze(1) * vec;
-      out[0] = at::zeros_like(pos_in).index_add(0, j, gvec).index_add(0, i, -gvec);
+      if (want_pos) out[0] = at::zeros_like(pos_in).index_add(0, j, gvec).index_add(0, i, -gvec);
+      if (want_cell) out[1] = topo->shifts.t().matmul(gvec);
       return out;
     }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(pos.device());
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(pos.device().index()).stream();
     at::Tensor gc = g.contiguous();
-    at::Tensor grad_pos = at::empty_like(pos);
+    at::Tensor grad_pos = at::empty_like(pos), grad_cell, partials;
+    if (want_cell) {
+      grad_cell = at::empty_like(cell);
+      partials = at::empty({g_api.rows_partials_size(topo->n_atoms)}, pos.options().dtype(at::kDouble));
+    }
     check(g_api.pair_distance_backward_rows(stream, dtype_code(pos), topo->n_atoms, topo->row_ptr.data_ptr(),
                                             topo->entries.data_ptr(), topo->row_packed().data_ptr(), pos.data_ptr(),
-                                            cell.data_ptr(), nullptr, gc.data_ptr(), nullptr, grad_pos.data_ptr(), nullptr),
+                                            cell.data_ptr(), nullptr, gc.data_ptr(), want_cell ? partials.data_ptr() : nullptr,
+                                            grad_pos.data_ptr(), want_cell ? grad_cell.data_ptr() : nullptr),
           "pair_distance_backward");
-    out[0] = grad_pos;
+    if (want_pos) out[0] = grad_pos;
+    if (want_cell) out[1] = grad_cell;
     return out;
   }
 
@@ -269,7 +293,7 @@ std::optional<at::Tensor> pair_distances(const std::shared_ptr<FrontTopo>& topo,
                                          const at::Tensor& pairs) {
   if (!topo || !eligible_real(positions) || !eligible_real(cell) || positions.dim() != 2 || positions.size(1) != 3 ||
       positions.size(0) != topo->n_atoms || cell.dim() != 2 || cell.size(0) != 3 || cell.size(1) != 3 ||
-      cell.scalar_type() != positions.scalar_type() || cell.device() != positions.device() || cell.requires_grad() ||
+      cell.scalar_type() != positions.scalar_type() || cell.device() != positions.device() ||
       !is_list_of(pairs, *topo) || pairs._version() != topo->pairs_version || topo->n_pairs == 0 ||
       topo->pair_packed.device() != positions.device())
     return std::nullopt;
@@ -309,10 +333,15 @@ struct CalcNode : public Node {
   std::shared_ptr<Node> dist_node;  // DistNode of the distances (also reachable through next_edge(1); kept typed here)
   at::Tensor q, pos, cell, dist;    // detached aliases of the inputs
   at::Tensor pos_in;                // positions as the caller passed them (see first_order_only)
+  at::Tensor q_in, cell_in;         // ... and charges / cell, when they require a gradient
   uint32_t q_version = 0, pos_version = 0, cell_version = 0, dist_version = 0;
   at::Tensor force, field;          // per-atom sums of the forward (pair force sums, mesh force field)
   at::Tensor keep;                  // one slab: phi_mesh | rho_dc | atom bins | records
   size_t off_phi = 0, off_dc = 0, off_bins = 0, off_rec = 0;
+  // the rest of the contract, per unit of gE, from the forward's gather tail (charges / cell that require a gradient)
+  at::Tensor tail_q;                // (N)  dE/dq = 2 V
+  at::Tensor tail_cell;             // (27) dE/dcell: mesh part, pair part, sum
+  at::Tensor rho_kept, phi_atoms;   // rfftn(rho) and the per-atom mesh potential: the general adjoint's cell gradient
 
   std::string name() const override { return "MipmeCalculatorBackward"; }
 
@@ -331,10 +360,12 @@ struct CalcNode : public Node {
   }
 
   variable_list apply(variable_list&& grads) override {
-    variable_list out(2);
+    variable_list out(4);
     const at::Tensor& g_in = grads[0];
     const bool need_pos = task_should_compute_output(0), need_dist = task_should_compute_output(1);
-    if (!g_in.defined() || (!need_pos && !need_dist)) return out;
+    const bool need_q = tail_q.defined() && task_should_compute_output(2);
+    const bool need_cell = tail_cell.defined() && task_should_compute_output(3);
+    if (!g_in.defined() || (!need_pos && !need_dist && !need_q && !need_cell)) return out;
     TORCH_CHECK(q._version() == q_version && pos._version() == pos_version && cell._version() == cell_version &&
                     dist._version() == dist_version,
                 "an input of the calculator was modified in place before the backward pass");
@@ -345,10 +376,15 @@ struct CalcNode : public Node {
     at::Tensor g = g_in.contiguous();
     const auto opts = pos.options();
     const bool real_dd = need_dist && distances_observed();
+    // the mesh part of the cell gradient contains the mesh forces, the pair part the pair forces: both adjoints run for it
+    const bool mesh_pos = need_pos || need_cell;
+    // (with an observed dE/dd the pair part of every gradient travels through the distances node)
+    const bool pair_pos = !real_dd && (need_pos || need_dist || need_cell);
 
-    at::Tensor grad_pos, grad_dist;
+    at::Tensor grad_pos, grad_dist, grad_q, grad_cell;
+    at::Tensor cell_mesh, cell_pair;  // general adjoint: the two parts of dL/dcell
     at::Tensor res = at::empty({2}, opts);  // verdict of mipme_scaled_match: {gE, 1 or 0}
-    at::Tensor work;
+    at::Tensor work, cell_partials, pair_partials, q_records;
     // general upstream gradient, mesh part: second spread, convolution and gradient gather
     auto mesh_adjoint = [&](at::Tensor& out_pos) {
       const int64_t nx = calc->mesh.nx, ny = calc->mesh.ny, nz = calc->mesh.nz;
@@ -356,7 +392,7 @@ struct CalcNode : public Node {
       const size_t mesh_bytes = align256(size_t(nx) * ny * nz * s), hat_bytes = align256(size_t(calc->n_half) * 2 * s);
       work = at::empty({int64_t(2 * mesh_bytes + hat_bytes + 256)}, opts.dtype(at::kByte));
       char* w = static_cast<char*>(work.data_ptr());
-      out_pos = at::empty_like(pos);
+      if (mesh_pos) out_pos = at::empty_like(pos);
       mipme_kspace_backward_args_t a;
       std::memset(&a, 0, sizeof(a));
       a.size = sizeof(a);
@@ -377,18 +413,47 @@ struct CalcNode : public Node {
       a.chi_mesh = w + mesh_bytes;
       a.hat_work = w + 2 * mesh_bytes;
       a.dc = w + 2 * mesh_bytes + hat_bytes;
-      a.grad_positions = out_pos.data_ptr();
+      a.grad_positions = mesh_pos ? out_pos.data_ptr() : nullptr;
       a.atom_bins = slab(off_bins);
+      if (need_q) {
+        grad_q = at::empty_like(q);
+        a.grad_charges = grad_q.data_ptr();
+      }
+      if (need_cell) {
+        // the fused convolution contracts psi^ with the rfftn(rho) the forward kept (mipme.h, G_deriv)
+        cell_mesh = at::empty({3, 3}, opts);
+        cell_partials = at::empty({g_api.cellgrad_partials_size(&calc->mesh, N)}, opts.dtype(at::kDouble));
+        a.rho_hat = rho_kept.data_ptr();
+        a.phi_atoms = phi_atoms.data_ptr();
+        a.partials = cell_partials.data_ptr();
+        a.grad_cell = cell_mesh.data_ptr();
+        a.G_deriv = calc->G_deriv.data_ptr();
+      }
       check(g_api.kspace_backward(&a), "kspace_backward");
     };
-    // ... pair part, straight to the positions with the fused adjoint kernel
+    // ... pair part, straight to the positions (and the cell) with the fused adjoint kernel
     auto pair_adjoint = [&](at::Tensor& out_pos) {
       out_pos = at::empty_like(pos);
+      if (need_cell) {
+        cell_pair = at::empty({3, 3}, opts);
+        pair_partials = at::empty({g_api.rows_partials_size(N)}, opts.dtype(at::kDouble));
+      }
       check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh().data_ptr(), topo->entries.data_ptr(), nullptr,
                                 pos.data_ptr(), cell.data_ptr(), q.data_ptr(), nullptr, g.data_ptr(), 0, calc->full_list, &calc->pot,
                                 0, 1 /* table codes */, slab(off_rec), 1 /* the forward's records: same positions and charges */, nullptr,
-                                out_pos.data_ptr(), nullptr, nullptr, nullptr),
+                                out_pos.data_ptr(), need_cell ? pair_partials.data_ptr() : nullptr,
+                                need_cell ? cell_pair.data_ptr() : nullptr, nullptr),
             "rspace_backward");
+    };
+    // ... its charge gradient: the transposed pair sum over the upstream gradient, added to the mesh part's
+    auto pair_adjoint_charges = [&]() {
+      // (records of its own: the kernel repacks them with the upstream gradient in the charge slot, and the forward's must
+      // survive for a second backward pass through a retained graph)
+      q_records = at::empty({N, 4}, opts);
+      check(g_api.sr_rows_fused(stream, dt, N, topo->row_ptr.data_ptr(), topo->ent_sh().data_ptr(), topo->entries.data_ptr(), nullptr,
+                                pos.data_ptr(), cell.data_ptr(), q.data_ptr(), g.data_ptr(), nullptr, 1, calc->full_list, &calc->pot,
+                                1 /* accumulate */, 1, q_records.data_ptr(), 0, grad_q.data_ptr(), nullptr, nullptr, nullptr, nullptr),
+            "rspace_backward_charges");
     };
     // ... or as a (P,) gradient through the distances node
     auto pair_adjoint_dd = [&](const void* scale) {
@@ -396,6 +461,19 @@ struct CalcNode : public Node {
       check(g_api.rspace_backward(stream, dt, MIPME_I32, P, N, 1, topo->pairs32.data_ptr(), dist.data_ptr(), q.data_ptr(), nullptr,
                                   calc->full_list, &calc->pot, g.data_ptr(), scale, grad_dist.data_ptr(), nullptr),
             "rspace_backward");
+    };
+    // charges / cell: the tail's values on a match, the general adjoint's otherwise (decided by the kernel from the verdict)
+    auto select_contract = [&](bool matched_on_host) {
+      if (!need_q && !need_cell) return;
+      if (need_q && !grad_q.defined()) grad_q = at::empty_like(q);
+      if (need_cell) grad_cell = at::empty({3, 3}, opts);
+      // (a match known on the host: no general parts exist, and the kernel does not read them)
+      const void* cm = !need_cell ? nullptr : matched_on_host ? tail_cell.data_ptr() : cell_mesh.data_ptr();
+      const void* cp = !need_cell || matched_on_host || !cell_pair.defined() ? nullptr : cell_pair.data_ptr();
+      check(g_api.energy_select_contract(stream, dt, N, res.data_ptr(), need_q ? tail_q.data_ptr() : nullptr,
+                                         need_q ? grad_q.data_ptr() : nullptr, need_cell ? tail_cell.data_ptr() : nullptr,
+                                         real_dd ? 1 : 0, cm, cp, need_cell ? grad_cell.data_ptr() : nullptr),
+            "energy_select_contract");
     };
     const bool capturing = stream_is_capturing(stream);
     // g == gE * charges?  (many blocks beyond 32 768 values: one workgroup needs 87 us for 262 144 of them)
@@ -424,10 +502,12 @@ struct CalcNode : public Node {
         SkipGuard guard_skip;
         mesh_adjoint(grad_pos);
         pair_adjoint(pair_pos);
+        if (need_q) pair_adjoint_charges();
       }
       check(g_api.energy_select_sum(stream, dt, N, res.data_ptr(), q.data_ptr(), force.data_ptr(), field.data_ptr(), calc->full_list,
                                     grad_pos.data_ptr(), pair_pos.data_ptr(), grad_pos.data_ptr()),
             "energy_select");
+      select_contract(false);
     } else {
       // the verdict polled in pinned memory (when dE/d(neighbor_distances) itself is wanted: rare)
       bool match = false;
@@ -445,6 +525,10 @@ struct CalcNode : public Node {
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         match = *flag == 1;
+      } else {
+        TORCH_CHECK(!need_q && !need_cell,
+                    "charge / cell gradients of an eager calculator call cannot be captured into a HIP graph: use "
+                    "torchpme_amd.GraphedEnergyForces(charge_gradient=..., cell_gradient=...)");
       }
       if (match) {
         at::Tensor scale = res.narrow(0, 0, 1);
@@ -457,26 +541,33 @@ struct CalcNode : public Node {
                 "forces_finalize");
         }
         if (real_dd) pair_adjoint_dd(scale.data_ptr());
+        select_contract(true);
       } else {
-        if (need_pos) mesh_adjoint(grad_pos);
+        if (mesh_pos || need_q) mesh_adjoint(grad_pos);
         if (real_dd) {
           pair_adjoint_dd(nullptr);
-        } else if (need_pos || need_dist) {
-          at::Tensor pair_pos;
-          pair_adjoint(pair_pos);
+        } else if (pair_pos) {
+          at::Tensor pair_pos_t;
+          pair_adjoint(pair_pos_t);
           if (grad_pos.defined())
-            grad_pos.add_(pair_pos);
+            grad_pos.add_(pair_pos_t);
           else
-            grad_pos = pair_pos;
+            grad_pos = pair_pos_t;
         }
+        if (need_q) pair_adjoint_charges();
+        if (need_cell) grad_cell = cell_pair.defined() ? cell_mesh + cell_pair : cell_mesh;
       }
     }
     if (at::GradMode::is_enabled()) {
       first_order_only(grad_pos, pos_in);
       first_order_only(grad_dist, pos_in);
+      first_order_only(grad_q, q_in.defined() ? q_in : pos_in);
+      first_order_only(grad_cell, cell_in.defined() ? cell_in : pos_in);
     }
     if (need_pos) out[0] = grad_pos;
     if (grad_dist.defined()) out[1] = grad_dist;
+    if (need_q) out[2] = grad_q;
+    if (need_cell) out[3] = grad_cell;
     return out;
   }
 
@@ -484,11 +575,17 @@ struct CalcNode : public Node {
     q.reset();
     pos.reset();
     pos_in.reset();
+    q_in.reset();
+    cell_in.reset();
     cell.reset();
     dist.reset();
     force.reset();
     field.reset();
     keep.reset();
+    tail_q.reset();
+    tail_cell.reset();
+    rho_kept.reset();
+    phi_atoms.reset();
   }
 };
 
@@ -501,8 +598,12 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   if (!dn) return std::nullopt;
   const auto& topo = dn->topo;
   if (!at::GradMode::is_enabled() || !eligible_real(positions) || !positions.requires_grad() || !eligible_real(charges) ||
-      charges.requires_grad() || !eligible_real(cell) || cell.requires_grad() || !eligible_real(dist) || dist.retains_grad())
+      !eligible_real(cell) || !eligible_real(dist) || dist.retains_grad())
     return std::nullopt;
+  // charges / cell that require a gradient: served when the gather tail can carry the energy mode's values -- dE/dq = 2 V
+  // needs a half list (mipme.h, out_grad_charges), dE/dcell the derivative table of G
+  const bool want_q = charges.requires_grad(), want_cell = cell.requires_grad();
+  if ((want_q && calc->full_list) || (want_cell && !calc->G_deriv.defined())) return std::nullopt;
   const int64_t N = topo->n_atoms, P = topo->n_pairs;
   if (charges.dim() != 2 || charges.size(0) != N || charges.size(1) != 1 || positions.dim() != 2 || positions.size(0) != N ||
       positions.size(1) != 3 || dist.dim() != 1 || dist.size(0) != P || pairs.dim() != 2 || pairs.size(0) != P ||
@@ -545,6 +646,18 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   at::Tensor work = at::empty({int64_t(mesh_bytes + hat_bytes)}, opts.dtype(at::kByte));  // rho_mesh | hat_work
   at::Tensor out = at::empty({N, 1}, opts);
   at::Tensor force = at::empty({N, 3}, opts), field = at::empty({N, 3}, opts);
+  at::Tensor tail_e, tail_gp, tail_q, tail_cell, cell_work, rho_kept, phi_atoms;
+  if (want_q || want_cell) {
+    tail_e = at::empty({}, opts);  // (the tail's energy and assembled forces come with it: unit seed)
+    tail_gp = at::empty({N, 3}, opts);
+    if (want_q) tail_q = at::empty({N, 1}, opts);
+    if (want_cell) {
+      tail_cell = at::empty({27}, opts);
+      cell_work = at::empty({g_api.cell_tail_work(calc->plan, &calc->mesh, N)}, opts.dtype(at::kDouble));
+      rho_kept = at::empty({int64_t(hat_bytes)}, opts.dtype(at::kByte));
+      phi_atoms = at::empty({N, 1}, opts);
+    }
+  }
   char* kp = static_cast<char*>(keep.data_ptr());
   char* wp = static_cast<char*>(work.data_ptr());
 
@@ -590,6 +703,18 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   a.out_records = kp + node->off_rec;
   a.sr_job = &job;
   a.nan_flag = calc->nan_flag;
+  if (tail_e.defined()) {
+    a.out_energy = tail_e.data_ptr();
+    a.out_grad_positions = tail_gp.data_ptr();
+    if (want_q) a.out_grad_charges = tail_q.data_ptr();
+    if (want_cell) {
+      a.out_grad_cell = tail_cell.data_ptr();
+      a.G_deriv = calc->G_deriv.data_ptr();
+      a.cell_work = cell_work.data_ptr();
+      a.out_rho_hat = rho_kept.data_ptr();
+      a.out_phi = phi_atoms.data_ptr();
+    }
+  }
   check(g_api.kspace_forward(&a), "kspace_forward");
 
   node->calc = calc;
@@ -607,7 +732,13 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   node->force = force;
   node->field = field;
   node->keep = keep;
-  node->set_next_edges(torch::autograd::collect_next_edges(positions, dist));
+  node->tail_q = tail_q;
+  node->tail_cell = tail_cell;
+  node->rho_kept = rho_kept;
+  node->phi_atoms = phi_atoms;
+  if (want_q) node->q_in = charges;
+  if (want_cell) node->cell_in = cell;
+  node->set_next_edges(torch::autograd::collect_next_edges(positions, dist, charges, cell));
   torch::autograd::create_gradient_edge(out, node);
   return out;
 }
@@ -643,7 +774,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       }));
   py::class_<FrontCalc, std::shared_ptr<FrontCalc>>(m, "Calculator")
       .def(py::init([](py::bytes mesh, py::bytes pot, int64_t plan, at::Tensor G, at::Tensor cell, bool full_list, int64_t nan_flag,
-                       int64_t n_half, py::object keepalive) {
+                       int64_t n_half, py::object keepalive, std::optional<at::Tensor> G_deriv) {
         auto c = std::make_shared<FrontCalc>();
         const std::string mb = mesh, pb = pot;
         if (mb.size() != sizeof(mipme_mesh_t) || pb.size() != sizeof(mipme_potential_t))
@@ -652,6 +783,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         std::memcpy(&c->pot, pb.data(), sizeof(mipme_potential_t));
         c->plan = reinterpret_cast<mipme_fft_plan*>(plan);
         c->G = G;
+        if (G_deriv) c->G_deriv = *G_deriv;
         c->cell = cell;
         c->cell_version = cell._version();
         c->full_list = full_list ? 1 : 0;

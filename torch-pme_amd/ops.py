@@ -1571,7 +1571,7 @@ def _pair_distances_once(positions, neighbor_indices, cell, neighbor_shifts, def
     else:
         shifts_c = neighbor_shifts.to(positions.dtype)
     if (deferred is False and FRONT and PROFILE is None and cell is not None and PAIR_MODE == "rows" and FUSE_DISTANCES and positions.requires_grad
-            and not cell.requires_grad and torch.is_grad_enabled() and type(positions) is torch.Tensor
+            and torch.is_grad_enabled() and type(positions) is torch.Tensor and type(cell) is torch.Tensor
             and type(neighbor_indices) is torch.Tensor and neighbor_indices.is_contiguous() and neighbor_indices.dim() == 2
             and getattr(neighbor_indices, "_mipme_stream", None) is None and shifts_c.is_contiguous()
             and not inside_vmap(positions, cell, neighbor_indices, shifts_c)):
