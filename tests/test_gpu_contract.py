@@ -326,8 +326,9 @@ FRONT_CASES = [("P3M", 5, 1, False), ("PME", 4, 1, True), ("P3M", 4, 6, True)]
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("mode", ["energy", "general", "energy+observed", "general+observed", "charges-only", "cell-only"])
+@pytest.mark.parametrize("select", [1, 2], ids=["default", "on_device"])
 @pytest.mark.parametrize("scheme,order,expo,tri", FRONT_CASES)
-def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mode, dtype):
+def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mode, dtype, select):
     """csrc/front.cpp with charges / cell as leaves (the reference's tests/calculators/test_workflow.py:164-192 through
     `pair_distances` + calculator + plain tensor reduction): the gather tail's dE/dq, dE/dcell on a match, the general adjoint
     otherwise, the pair part through the distances node when dE/d(neighbor_distances) is observed.  Twice through a retained
@@ -356,21 +357,26 @@ def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mo
         d.retain_grad()
     tw = tq.detach() if w is q else torch.tensor(w, dtype=dtype, device=DEV)
     tol = 1e-9 if dtype == torch.float64 else 3e-4
-    for rep in range(2):
-        for t in (tp, tq, tc, d):
-            t.grad = None
-        (tw * V).sum().backward(retain_graph=True)
-        assert rel(V, Vo) <= tol and rel(tp.grad, gpo) <= tol
-        if tq.requires_grad:
-            assert rel(tq.grad, dqo) <= tol
-        if tc.requires_grad:
-            assert rel(tc.grad, dco) <= tol
-        if "observed" in mode:
-            assert rel(d.grad, ddo) <= tol
+    _front.module().set_device_select(select)  # (front.cpp, g_device_select: who decides the energy mode)
+    try:
+        for rep in range(2):
+            for t in (tp, tq, tc, d):
+                t.grad = None
+            (tw * V).sum().backward(retain_graph=True)
+            assert rel(V, Vo) <= tol and rel(tp.grad, gpo) <= tol
+            if tq.requires_grad:
+                assert rel(tq.grad, dqo) <= tol
+            if tc.requires_grad:
+                assert rel(tc.grad, dco) <= tol
+            if "observed" in mode:
+                assert rel(d.grad, ddo) <= tol
+    finally:
+        _front.module().set_device_select(_front.select_mode())
 
 
 def test_compiled_front_end_contract_with_the_polled_verdict():
-    """MIPME_FRONT_POLL=1 (the verdict of the energy-mode test read on the host): same numbers as the device-side select."""
+    """The verdict of the energy-mode test read on the host (MIPME_FRONT_POLL=1; the default when charges / cell want
+    gradients) or acted on by the device (MIPME_FRONT_SELECT=always): same numbers."""
     from torchpme_amd import _front
 
     mod = _front.module()
@@ -379,7 +385,7 @@ def test_compiled_front_end_contract_with_the_polled_verdict():
     c = setup(torch.float64, "P3M", 5, 1, True, seed=2)
     Eo, gpo, dqo, dco, _ = oracle_contract(*c["np"])
     try:
-        for device_select in (False, True):
+        for device_select in (0, 1, 2):  # polled; the default mix (polled here: charges and cell want gradients); on the device
             mod.set_device_select(device_select)
             tp, tq, tc = (c[k].clone().requires_grad_(True) for k in ("pos", "q", "cell"))
             d = tpa.pair_distances(tp, c["pairs"], tc, c["shifts"])
@@ -390,4 +396,4 @@ def test_compiled_front_end_contract_with_the_polled_verdict():
             assert abs(float(E) - Eo) <= 1e-9 * abs(Eo)
             assert rel(tp.grad, gpo) <= 1e-9 and rel(tq.grad, dqo) <= 1e-9 and rel(tc.grad, dco) <= 1e-9
     finally:
-        mod.set_device_select(os.environ.get("MIPME_FRONT_POLL", "0") == "0")
+        mod.set_device_select(_front.select_mode())

@@ -130,7 +130,8 @@ def loop(want_q, want_c, n, general=False):
 import gc
 
 gc.disable()
-for label, a, b in (("E+F", False, False), ("E+F+dq", True, False), ("E+F+dcell", False, True), ("E+F+dq+dcell", True, True)):
-    ms = min(loop(a, b, 200) for _ in range(3))
-    msg = min(loop(a, b, 200, general=True) for _ in range(2))
-    print(f"eager {label:14s} {ms:.4f} ms   general seed {msg:.4f} ms", flush=True)
+cases = (("E+F", False, False), ("E+F+dq", True, False), ("E+F+dcell", False, True), ("E+F+dq+dcell", True, True), ("E+F", False, False))
+for label, a, b in cases:
+    ms = [loop(a, b, 200) for _ in range(3)]
+    msg = [loop(a, b, 200, general=True) for _ in range(2)]
+    print(f"eager {label:14s} {min(ms):.4f} ms ({' '.join(f'{x:.4f}' for x in ms)})   general seed {min(msg):.4f} ms", flush=True)

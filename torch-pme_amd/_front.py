@@ -18,6 +18,14 @@ _mod = None
 _tried = False
 
 
+def select_mode() -> int:
+    """How the C++ calculator node decides the energy mode (front.cpp, g_device_select): 0 polled (``MIPME_FRONT_POLL=1``), 2 on
+    the device for every request (``MIPME_FRONT_SELECT=always``), 1 the default mix."""
+    if os.environ.get("MIPME_FRONT_POLL", "0") != "0":
+        return 0
+    return 2 if os.environ.get("MIPME_FRONT_SELECT", "") == "always" else 1
+
+
 def module():
     global _mod, _tried
     if _tried:
@@ -51,6 +59,6 @@ def module():
 
     mod.set_unwrap(unwrap)
     mod.set_second_order_hint(ops.SECOND_ORDER_HINT)
-    mod.set_device_select(os.environ.get("MIPME_FRONT_POLL", "0") == "0")
+    mod.set_device_select(select_mode())
     _mod = mod
     return mod

@@ -324,8 +324,14 @@ std::optional<at::Tensor> pair_distances(const std::shared_ptr<FrontTopo>& topo,
 
 // ---- the calculator node -----------------------------------------------------------------------------------------------------
 thread_local at::Tensor t_match_flag;  // pinned int32[1] per thread: the verdict of mipme_scaled_match
-bool g_device_select = true;           // MIPME_FRONT_POLL=1: decide the energy mode by polling instead (A/B, debugging)
-void set_device_select(bool on) { g_device_select = on; }
+// How the energy mode is decided: 0 = the verdict polled in pinned memory (MIPME_FRONT_POLL=1), 2 = on the device for every
+// request (MIPME_FRONT_SELECT=always), 1 (default) = on the device when only the positions want a gradient, polled when the
+// charges or the cell do too: the device-side decision launches the whole general adjoint as kernels that return at once, and
+// with the charge / cell adjoints on top that is ~12 launches -- more than the wait they avoid (tools/check_front_contract.py:
+// E+F+dq 0.149 polled vs 0.168 ms, E+F+dq+dcell 0.168 vs 0.196 ms; positions only 0.131 vs 0.137 on a fast host, 0.171 vs 0.157
+// on a slow one).
+int g_device_select = 1;
+void set_device_select(int mode) { g_device_select = mode; }
 
 struct CalcNode : public Node {
   std::shared_ptr<FrontCalc> calc;
@@ -485,7 +491,7 @@ struct CalcNode : public Node {
                                      nw > 0 ? match_work.data_ptr() : nullptr);
     };
 
-    if (need_pos && !real_dd && !capturing && g_device_select) {
+    if (need_pos && !real_dd && !capturing && (g_device_select == 2 || (g_device_select == 1 && !need_q && !need_cell))) {
       // Energy mode (g == gE * charges: the gradient of (charges * V).sum()) decided ON THE DEVICE and acted on there: the general
       // adjoint is launched with every kernel told to return at once on a match, then one kernel writes gE q_a (f force_a +
       // field_a) from the per-atom sums of the forward in that case, or adds up the general adjoint's two parts otherwise.  The
