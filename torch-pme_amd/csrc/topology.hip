@@ -231,6 +231,98 @@ __global__ __launch_bounds__(256) void rspace_rows_kernel(SRPot s, int64_t N, in
 }
 
 
+// ---- constant distances: v_SR(d) per row entry, computed once (mipme.h, mipme_rspace_rows_tabulate) ------------------------------
+// One record per row entry, in row order: the partner atom and the pair's potential value (zero for a masked pair) -- the
+// pair sum over them is a sparse matrix-vector product that streams 8 (fp32) / 16 (fp64) bytes per entry and gathers only the
+// partner's source value; no distance gather (64-byte sectors for the scattered role-j entries), no erfc.
+template <typename T>
+struct EntVal {
+  int other;
+  T v;
+};
+static_assert(sizeof(EntVal<float>) == 8 && sizeof(EntVal<double>) == 16, "EntVal layout");
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_tabulate_kernel(SRPot s, int64_t N, const int* __restrict__ row_ptr,
+                                                           const int2* __restrict__ entries, const T* __restrict__ dist,
+                                                           const uint8_t* __restrict__ mask, int t_lo, int t_hi,
+                                                           EntVal<T>* __restrict__ ev, T* __restrict__ row_sum_t) {
+  constexpr int U = kRowUnroll;
+  const int sub = threadIdx.x % kRowLanes;
+  int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;
+  const int beg = row_ptr[2 * a], end = valid ? row_ptr[2 * a + 2] : beg;
+  const int s_beg = row_ptr[2 * a + t_lo], s_end = row_ptr[2 * a + t_hi + 1];  // the roles of the transposed sum
+  T acc = T(0);
+  for (int base = beg; base < end; base += kRowLanes * U) {
+    int2 en[U];
+    T d[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * kRowLanes + sub;
+      ok[u] = e < end;
+      en[u] = entries[ok[u] ? e : beg];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[u] = dist[en[u].y];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * kRowLanes + sub;
+      T v, dv;
+      sr_eval<T, false>(s, d[u], v, dv);
+      if (mask && !mask[en[u].y]) v = T(0);
+      if (ok[u]) {
+        ev[e] = EntVal<T>{en[u].x, v};
+        if (e >= s_beg && e < s_end) acc += v;
+      }
+    }
+  }
+  if (row_sum_t) {
+    const T tot = row_sum(acc);
+    if (sub == 0 && valid) row_sum_t[a] = T(0.5) * tot;
+  }
+}
+
+// out[a] (+)= 1/2 sum_{entries of a in the roles} src[other] v_e
+template <typename T>
+__global__ __launch_bounds__(256) void rows_tabulated_kernel(int64_t N, const int* __restrict__ row_ptr,
+                                                            const EntVal<T>* __restrict__ ev, const T* __restrict__ src,
+                                                            int role_lo, int role_hi, bool accumulate, T* __restrict__ out) {
+  constexpr int U = 4;
+  const int sub = threadIdx.x % kRowLanes;
+  int64_t a = int64_t(blockIdx.x) * kRowsPerBlock + threadIdx.x / kRowLanes;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;
+  const int beg = row_ptr[2 * a + role_lo], end = valid ? row_ptr[2 * a + role_hi + 1] : beg;
+  T acc = T(0);
+  EntVal<T> nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = beg + u * kRowLanes + sub;
+    nxt[u] = ev[e < end ? e : beg];
+  }
+  for (int base = beg; base < end; base += kRowLanes * U) {
+    EntVal<T> cur[U];
+    T sv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sv[u] = src[cur[u].other];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + kRowLanes * U + u * kRowLanes + sub;
+      nxt[u] = ev[e < end ? e : beg];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + u * kRowLanes + sub < end) acc += sv[u] * cur[u].v;
+  }
+  const T tot = row_sum(acc);
+  if (sub == 0 && valid) out[a] = (accumulate ? out[a] : T(0)) + T(0.5) * tot;
+}
+
 // grad_pos[a] = sum_{role i} -(g_p/d_p) vec_p + sum_{role j} +(g_p/d_p) vec_p ,  vec_p = r_j - r_i + S_p A
 // grad_cell = sum_p S_p^T (g_p/d_p) vec_p, accumulated from the role-i entries (each pair once).
 template <typename T, bool CELLGRAD>
@@ -699,6 +791,53 @@ int mipme_rspace_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, 
     return rspace_rows_impl<double>(st, n_atoms, n_channels, row_ptr, entries, dist, src, pair_mask, lo, hi, pot, accumulate, out);
   set_error("invalid dtype %d", dtype);
   return MIPME_EINVAL;
+}
+
+int64_t mipme_rspace_rows_value_bytes(int dtype, int64_t n_pairs) {
+  if (n_pairs < 0 || (dtype != MIPME_F32 && dtype != MIPME_F64)) return 0;
+  return (2 * n_pairs + 1) * int64_t(dtype == MIPME_F32 ? sizeof(EntVal<float>) : sizeof(EntVal<double>));
+}
+
+int mipme_rspace_rows_tabulate(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries, const void* dist,
+                               const void* pair_mask, int full_list, const mipme_potential_t* pot, void* values,
+                               void* row_sum_transposed) {
+  MIPME_REQUIRE(n_atoms >= 0 && row_ptr && entries && values && (n_atoms == 0 || dist), "invalid arguments to mipme_rspace_rows_tabulate");
+  MIPME_REQUIRE(dtype == MIPME_F32 || dtype == MIPME_F64, "invalid dtype %d", dtype);
+  SRPot s;
+  int rc = make_srpot(pot, s);
+  if (rc) return rc;
+  if (n_atoms == 0) return MIPME_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int t_lo = full_list ? 1 : 0, t_hi = 1;  // roles of the transposed sum (mipme_rspace_rows)
+  if (dtype == MIPME_F32)
+    rows_tabulate_kernel<float><<<row_blocks(n_atoms), 256, 0, st>>>(s, n_atoms, (const int*)row_ptr, (const int2*)entries,
+                                                                    (const float*)dist, (const uint8_t*)pair_mask, t_lo, t_hi,
+                                                                    (EntVal<float>*)values, (float*)row_sum_transposed);
+  else
+    rows_tabulate_kernel<double><<<row_blocks(n_atoms), 256, 0, st>>>(s, n_atoms, (const int*)row_ptr, (const int2*)entries,
+                                                                     (const double*)dist, (const uint8_t*)pair_mask, t_lo, t_hi,
+                                                                     (EntVal<double>*)values, (double*)row_sum_transposed);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_rspace_rows_tabulated(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* values, const void* src,
+                                int transpose, int full_list, int accumulate, void* out) {
+  MIPME_REQUIRE(n_atoms >= 0 && row_ptr && values, "invalid arguments to mipme_rspace_rows_tabulated");
+  MIPME_REQUIRE(n_atoms == 0 || (out && src), "NULL buffer passed to mipme_rspace_rows_tabulated");
+  MIPME_REQUIRE(dtype == MIPME_F32 || dtype == MIPME_F64, "invalid dtype %d", dtype);
+  if (n_atoms == 0) return MIPME_OK;
+  int lo = 0, hi = 1;
+  if (full_list) lo = hi = transpose ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    rows_tabulated_kernel<float><<<row_blocks(n_atoms), 256, 0, st>>>(n_atoms, (const int*)row_ptr, (const EntVal<float>*)values,
+                                                                     (const float*)src, lo, hi, accumulate != 0, (float*)out);
+  else
+    rows_tabulated_kernel<double><<<row_blocks(n_atoms), 256, 0, st>>>(n_atoms, (const int*)row_ptr, (const EntVal<double>*)values,
+                                                                      (const double*)src, lo, hi, accumulate != 0, (double*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
 }
 
 int mipme_pair_distance_backward_rows(void* stream, int dtype, int64_t n_atoms, const void* row_ptr, const void* entries,

@@ -167,6 +167,10 @@ def filter_derivative(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, d
 #   "atomic" one pass over the list with hardware float atomics (csrc/rspace.hip); no preprocessing.
 PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
 
+#: constant ``neighbor_distances`` (the same tensor, unmodified, seen a second time by the same list): v_SR(d) per row entry is
+#: tabulated once and the pair sum becomes a sparse matrix-vector product (PairTopology.tabulated); "0" disables
+TABULATE = os.environ.get("MIPME_TABULATE", "1") != "0"
+
 # How atoms meet the mesh: "bricks" (default; atoms binned by 8^3 mesh brick, owner-computes LDS-tile spread,
 # LDS-tiled gathers -- csrc/bricks.hip) or "atomic" (global float atomics -- csrc/mesh.hip).  Meshes too small
 # for bricks always take the atomic kernels.
@@ -421,6 +425,31 @@ class PairTopology:
                     ws.data_ptr(), nbytes, self.row_ptr.data_ptr(), self.entries.data_ptr(),
                 )
             )
+
+    def tabulated(self, dist: torch.Tensor, mask, pot_desc, full_list: bool):
+        """``(values, row_sum_transposed)`` of ``mipme_rspace_rows_tabulate`` for a ``neighbor_distances`` tensor that this
+        list has ALREADY been evaluated with (same tensor, same version, same potential, same mask): a charge loop over a fixed
+        geometry, the reference tuner's timing protocol (tuning/tuner.py:337-373).  ``None`` on the first sighting -- which only
+        remembers the tensor -- so that distances that are new every call never pay for the table (76 MB and one pass over the
+        list at 4.76 M pairs)."""
+        key = (bytes(pot_desc), bool(full_list), None if mask is None else (mask.data_ptr(), mask._version))
+        c = self.__dict__.get("_tab")
+        if c is None or c[0]() is not dist or c[1] != dist._version or c[2] != key:
+            self._tab = (weakref.ref(dist), dist._version, key, None)
+            return None
+        if c[3] is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            lib = _lib.load()
+            device, dt = dist.device, _lib.dtype_code(dist.dtype)
+            values = torch.empty((lib.mipme_rspace_rows_value_bytes(dt, self.n_pairs),), dtype=torch.uint8, device=device)
+            row_sum = torch.empty((self.n_atoms, 1), dtype=dist.dtype, device=device)
+            with _lib.on_device(device):
+                _call("rspace_tabulate", lib.mipme_rspace_rows_tabulate, _lib.current_stream(device), dt, self.n_atoms,
+                      self.row_ptr.data_ptr(), self.entries.data_ptr(), dist.data_ptr(), _lib.ptr(mask), int(full_list),
+                      C.byref(pot_desc), values.data_ptr(), row_sum.data_ptr())
+            c = self._tab = c[:3] + ((values, row_sum),)
+        return c[3]
 
     def adopt_shifts(self, shifts: torch.Tensor, key: torch.Tensor | None = None) -> None:
         """Called with the shifts of an evaluation before the shift-keyed streams are asked for.  If they were built for ANOTHER
@@ -885,6 +914,13 @@ class _PMEFunction(torch.autograd.Function):
             if want_pair_partials and geom is None:
                 fused["partials"] = torch.empty((lib.mipme_rows_partials_size(N),), dtype=torch.float64, device=device)
 
+            # distances that are a plain tensor this list has been evaluated with before: the tabulated pair sum
+            tab = None
+            if (TABULATE and fused is None and topo is not None and Cn == 1 and P > 0 and not ctx.needs_input_grad[3]
+                    and type(neighbor_distances) is torch.Tensor and neighbor_distances.is_contiguous()):
+                tab = topo.tabulated(neighbor_distances, mask, pot_desc, full_list)  # (keyed on the caller's tensor object)
+            ctx.tab = tab
+
             def run_rspace(accumulate):
                 stream = _lib.current_stream(device)
                 if fused is not None:
@@ -899,6 +935,13 @@ class _PMEFunction(torch.autograd.Function):
                     if write_dist:
                         src.pending = False
                 elif topo is not None:
+                    if tab is not None:  # constant distances: v_SR(d) per row entry is already there (PairTopology.tabulated)
+                        _call(
+                            "rspace_forward", lib.mipme_rspace_rows_tabulated,
+                            stream, dt, N, topo.row_ptr.data_ptr(), tab[0].data_ptr(), q.data_ptr(), 0, int(full_list),
+                            accumulate, out.data_ptr(),
+                        )
+                        return
                     _call(
                         "rspace_forward", lib.mipme_rspace_rows,
                         stream, dt, N, Cn, topo.row_ptr.data_ptr(), topo.entries.data_ptr(), dist.data_ptr(),
@@ -1344,6 +1387,15 @@ class _PMEFunction(torch.autograd.Function):
                     1, full, C.byref(pot_desc), 1, fused["fmt"], fused["records"].data_ptr(), 0, grad_q.data_ptr(), None, None,
                     None, None,
                 )
+            elif need_q and topo is not None and getattr(ctx, "tab", None) is not None:
+                if N > 1 and grad_out.stride(0) == 0 and grad_out.stride(1) in (0, 1):
+                    # a uniform upstream gradient (``result.sum().backward()``): c times the table's row sums
+                    grad_q.addcmul_(ctx.tab[1], grad_out[:1])
+                else:
+                    _call(
+                        "rspace_backward_charges", lib.mipme_rspace_rows_tabulated,
+                        st, dt, N, topo.row_ptr.data_ptr(), ctx.tab[0].data_ptr(), g.data_ptr(), 1, full, 1, grad_q.data_ptr(),
+                    )
             elif need_q and topo is not None:
                 _call(
                     "rspace_backward_charges", lib.mipme_rspace_rows,
