@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 401
+#define MIPME_VERSION 402
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -418,12 +418,14 @@ int mipme_scaled_match_wide(void* stream, int dtype, int64_t n, const void* g, c
  * (lib/kvectors.py:17-21) would make the host wait for everything queued before it, every call. */
 int mipme_values_equal(void* stream, int dtype, int64_t n, const void* a, const void* b, void* host_flag);
 
-/* 128-bit order-sensitive checksum of a device buffer (n_bytes a multiple of 4): sums[0..1] += the hash (sums: uint64[3] of
- * device memory, ZERO on entry; sums[2] is the kernel's ticket counter).  expect (nullable, device uint64[2]) + host_flag
+/* 128-bit order-sensitive checksum of a device buffer (n_bytes a multiple of 4; two position-keyed sums of its 32-bit words):
+ * sums[0..1] += the hash.  sums: uint64[mipme_checksum_words()] of device memory, the first three ZERO on entry (sums[2] is the
+ * kernel's ticket counter, zero again on exit; the rest per-workgroup partial sums).  expect (nullable, device uint64[2]) + host_flag
  * (pinned int32 preset to -1): the last workgroup also writes 1 / 0 -- equal / different -- to host_flag.  How the host layer
  * recognises a NEW neighbour-list tensor that holds the values of the previous one (the reference's users hand a fresh list to
  * every call, examples/02-neighbor-lists-usage.py:97-164; the per-list structures -- transposition, entry streams -- are then
  * reused on the bet that the checksums agree, verified before any result is handed out). */
+int64_t mipme_checksum_words(void);
 int mipme_checksum(void* stream, const void* data, int64_t n_bytes, void* sums, const void* expect, void* host_flag);
 
 /* The same decision WITHOUT a host round trip (the poll above makes the host wait for everything queued before it: the eager

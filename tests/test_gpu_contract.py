@@ -440,3 +440,27 @@ def test_constant_distances_take_the_tabulated_pair_sum(dtype, full_list):
             gr = O.backward(cache, w)
             (torch.tensor(w, dtype=dtype, device=DEV) * V).sum().backward()
         assert rel(tq.grad, gr["charges"]) <= tol and rel(tp.grad, gr["positions"]) <= tol and rel(tc.grad, gr["cell"]) <= tol
+
+
+def test_checksum_notices_single_words_swaps_and_tails():
+    """mipme_checksum (the bet on "new list tensor, old values"): equal for copies, different after one changed word, after two
+    swapped rows, after a change in the last words that do not fill a 16-byte vector; accumulates over several buffers."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (1, 3, 4, 1000, 4_000_003):
+        a = torch.randint(-2**31, 2**31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(DEV)
+        ref = ops.device_checksum(a)[:2].clone()
+        assert torch.equal(ops.device_checksum(a.clone())[:2], ref)
+        for pos in {0, n // 2, n - 1}:
+            b = a.clone()
+            b[pos] += 1
+            assert not torch.equal(ops.device_checksum(b)[:2], ref), (n, pos)
+        if n >= 4:
+            b = a.clone()
+            b[[0, n - 1]] = b[[n - 1, 0]]
+            assert bool(a[0] == a[n - 1]) or not torch.equal(ops.device_checksum(b)[:2], ref)
+    # the pair list of a benchmark box: two rows swapped
+    pairs = torch.tensor(workloads.water_box(n_side=8, n_mesh=16).pairs, device=DEV)
+    ref = ops.device_checksum(pairs)[:2].clone()
+    swapped = pairs.clone()
+    swapped[[5, 77]] = swapped[[77, 5]]
+    assert torch.equal(ops.device_checksum(pairs.clone())[:2], ref) and not torch.equal(ops.device_checksum(swapped)[:2], ref)

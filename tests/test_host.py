@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmipme.so does not export {name}"
     assert sorted(declared) == sorted(_lib.EXPORTS)
-    assert lib.mipme_version() == 401
+    assert lib.mipme_version() == 402
 
 
 def test_compiled_front_end_loads_and_declines_cpu_tensors():

@@ -35,7 +35,7 @@ EXPORTS = (
     "mipme_ewald_filter", "mipme_ewald_structure", "mipme_ewald_potential", "mipme_ewald_backward",
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
     "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum", "mipme_energy_select_contract",
-    "mipme_kfilter_build_deriv", "mipme_cell_tail_work", "mipme_values_equal", "mipme_checksum",
+    "mipme_kfilter_build_deriv", "mipme_cell_tail_work", "mipme_values_equal", "mipme_checksum", "mipme_checksum_words",
 )
 
 
@@ -296,6 +296,8 @@ def _declare(lib):
     lib.mipme_nl_workspace_bytes.argtypes = [C.POINTER(NlDesc), i64]
     lib.mipme_rspace_rows_value_bytes.restype = i64
     lib.mipme_rspace_rows_value_bytes.argtypes = [ci, i64]
+    lib.mipme_checksum_words.restype = i64
+    lib.mipme_checksum_words.argtypes = []
     lib.mipme_cell_tail_work.restype = i64
     lib.mipme_cell_tail_work.argtypes = [vp, MP, i64]
     lib.mipme_fft_plan_xfused.restype = ci

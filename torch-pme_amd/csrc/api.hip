@@ -683,52 +683,82 @@ __global__ __launch_bounds__(64) void values_equal_kernel(int n, const T* __rest
   if (threadIdx.x == 0) __hip_atomic_store(host_flag, all ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
-  x ^= x >> 30;
-  x *= 0xbf58476d1ce4e5b9ull;
-  x ^= x >> 27;
-  x *= 0x94d049bb133111ebull;
-  x ^= x >> 31;
-  return x;
+// Two 64-bit position-keyed sums over the 32-bit words w_j of the buffer: a = sum w_j K1(j), b = sum w_j K2(j) (mod 2^64), with
+// K(j) = ((j + 1) C) mod 2^32 for two odd constants C -- bijections of the word index that are never zero below 2^32 - 1 words.
+// A change of one word moves both sums (w K < 2^64 cannot wrap to zero), so does a swap of two different words ((w - w')(K - K')),
+// and unrelated changes cancel in both with probability 2^-128.  One v_mad_u64_u32 per word and sum: the first version (four
+// splitmix64 finalisers per 16 bytes) was bound by its 64-bit multiplies -- 91 us for the 76 MB list of cfg3; this one streams.
+__device__ __forceinline__ void checksum_words(const uint4 v, unsigned j, unsigned long long& a, unsigned long long& b) {
+  constexpr unsigned C1 = 0x9e3779b1u, C2 = 0x85ebca6bu;
+  const unsigned k1 = (j + 1u) * C1, k2 = (j + 1u) * C2;  // keys of word j; the next words' keys follow by adding C
+  a += (unsigned long long)v.x * k1 + (unsigned long long)v.y * (k1 + C1) + (unsigned long long)v.z * (k1 + 2u * C1) +
+       (unsigned long long)v.w * (k1 + 3u * C1);
+  b += (unsigned long long)v.x * k2 + (unsigned long long)v.y * (k2 + C2) + (unsigned long long)v.z * (k2 + 2u * C2) +
+       (unsigned long long)v.w * (k2 + 3u * C2);
 }
 
+static constexpr int kChecksumBlocks = 512;
+
+// sums: uint64[3 + 2 kChecksumBlocks]: {a, b, ticket, per-block partial sums}.  Every block stores its two partial sums and
+// draws a ticket; the last one adds them up in block order.  (The first version added its sums to sums[0..1] with three
+// device-scope atomics per block: 2048 blocks x 3 serialised round trips were 60 of the kernel's 83 us at 76 MB.)
 __global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__ data, int64_t n_vec, const unsigned* __restrict__ tail,
                                                        int n_tail, unsigned long long* __restrict__ sums,
                                                        const unsigned long long* __restrict__ expect, int* host_flag) {
   unsigned long long a = 0, b = 0;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-    const uint4 v = data[i];
-    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
-    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
-    const unsigned long long k = 0x9e3779b97f4a7c15ull * (unsigned long long)(2 * i + 1);
-    a += mix64(lo + k);
-    b += mix64(hi ^ (k << 1 | 1));
-    a += mix64(hi + 0x632be59bd9b4e019ull * (unsigned long long)(2 * i + 2));
-    b += mix64(lo ^ (k * 3));
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {  // four loads in flight
+    const uint4 v0 = data[i], v1 = data[i + stride], v2 = data[i + 2 * stride], v3 = data[i + 3 * stride];
+    checksum_words(v0, unsigned(4 * i), a, b);
+    checksum_words(v1, unsigned(4 * (i + stride)), a, b);
+    checksum_words(v2, unsigned(4 * (i + 2 * stride)), a, b);
+    checksum_words(v3, unsigned(4 * (i + 3 * stride)), a, b);
   }
-  if (blockIdx.x == 0 && int(threadIdx.x) < n_tail) a += mix64((unsigned long long)tail[threadIdx.x] + 0x1234567ull * (threadIdx.x + 1));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off, 64);
-    b += __shfl_xor(b, off, 64);
+  for (; i < n_vec; i += stride) checksum_words(data[i], unsigned(4 * i), a, b);
+  if (blockIdx.x == 0 && int(threadIdx.x) < n_tail) {
+    const unsigned j = unsigned(4 * n_vec) + threadIdx.x;
+    a += (unsigned long long)tail[threadIdx.x] * ((j + 1u) * 0x9e3779b1u);
+    b += (unsigned long long)tail[threadIdx.x] * ((j + 1u) * 0x85ebca6bu);
   }
   __shared__ unsigned long long red[4][2];
   __shared__ bool last;
-  if ((threadIdx.x & 63) == 0) {
-    red[threadIdx.x >> 6][0] = a;
-    red[threadIdx.x >> 6][1] = b;
+  auto block_sum = [&](unsigned long long& x, unsigned long long& y) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      x += __shfl_xor(x, off, 64);
+      y += __shfl_xor(y, off, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6][0] = x;
+      red[threadIdx.x >> 6][1] = y;
+    }
+    __syncthreads();
+    x = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    y = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  };
+  block_sum(a, b);
+  unsigned long long* part = sums + 3;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&part[2 * blockIdx.x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[2 * blockIdx.x + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = __hip_atomic_fetch_add(&sums[2], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(gridDim.x - 1);
   }
   __syncthreads();
+  if (!last) return;
+  unsigned long long ta = 0, tb = 0;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += blockDim.x) {
+    ta += __hip_atomic_load(&part[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tb += __hip_atomic_load(&part[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  block_sum(ta, tb);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(&sums[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-    __threadfence();
-    last = atomicAdd(&sums[2], 1ull) == (unsigned long long)(gridDim.x - 1);
-    if (last && host_flag) {
-      __threadfence();
-      const unsigned long long s0 = __hip_atomic_load(&sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long s1 = __hip_atomic_load(&sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long s0 = sums[0] + ta, s1 = sums[1] + tb;
+    sums[0] = s0;
+    sums[1] = s1;
+    sums[2] = 0;  // (ready for a further buffer accumulated into the same sums)
+    if (host_flag) {
       const int same = expect && s0 == expect[0] && s1 == expect[1];
       __hip_atomic_store(host_flag, same ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1380,13 +1410,15 @@ int mipme_scaled_match(void* stream, int dtype, int64_t n, const void* g, const 
 
 int64_t mipme_pair_partials_size(int64_t n_pairs) { return 9 * pair_partials_blocks(n_pairs); }
 
+int64_t mipme_checksum_words(void) { return 3 + 2 * kChecksumBlocks; }
+
 int mipme_checksum(void* stream, const void* data, int64_t n_bytes, void* sums, const void* expect, void* host_flag) {
   MIPME_REQUIRE(n_bytes >= 0 && (n_bytes % 4) == 0 && sums && (n_bytes == 0 || data), "mipme_checksum: a multiple of 4 bytes, non-NULL buffers");
   MIPME_REQUIRE((reinterpret_cast<uintptr_t>(data) & 15) == 0, "mipme_checksum: the buffer must be 16-byte aligned");
   const int64_t n_vec = n_bytes / 16;
   const int n_tail = int((n_bytes % 16) / 4);
   int64_t blocks = (n_vec + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > kChecksumBlocks ? kChecksumBlocks : blocks);
   checksum_kernel<<<unsigned(blocks), 256, 0, (hipStream_t)stream>>>(
       (const uint4*)data, n_vec, (const unsigned*)((const char*)data + 16 * n_vec), n_tail, (unsigned long long*)sums,
       (const unsigned long long*)expect, (int*)host_flag);

@@ -330,7 +330,7 @@ def device_checksum(t: torch.Tensor, expect: torch.Tensor | None = None, undo=No
     """128-bit checksum of ``t`` (contiguous, 16-byte aligned storage) as a device tensor; with ``expect`` the comparison's
     verdict is queued for :func:`verify_bets` together with ``undo`` (what to forget if the bet is lost)."""
     lib = _lib.load()
-    sums = torch.zeros((3,), dtype=torch.int64, device=t.device)
+    sums = torch.zeros((lib.mipme_checksum_words(),), dtype=torch.int64, device=t.device)
     flag_ptr = None
     if expect is not None:
         flags, view, slot = _bet_slot()
@@ -464,6 +464,7 @@ class PairTopology:
             def undo(self=self):
                 self._packed = self._ent_sh = self._pair_sh = self._ent32 = None
                 self.__dict__.pop("_front", None)
+                self.__dict__.pop("_front_lazy", None)
                 self._shift_key = self._shift_sum = None
 
             device_checksum(shifts, self._shift_sum, undo)
@@ -482,6 +483,7 @@ class PairTopology:
         self._packed = self._pair_sh = self._ent32 = None
         self._ent_sh = None
         self.__dict__.pop("_front", None)
+        self.__dict__.pop("_front_lazy", None)
         self._shift_key = (weakref.ref(key), key._version)
         self._shift_meta = meta
         self._shift_sum = device_checksum(shifts) if (SPECULATE_LISTS and shifts.is_contiguous() and shifts.data_ptr() % 16 == 0
@@ -503,8 +505,14 @@ class PairTopology:
                 # the two streams only the general adjoints read are made on first use (a closure over tensors, not over this
                 # object: the handle may outlive it inside an autograd graph, and must not keep it alive in a cycle)
                 row_ptr, entries, n_pairs, n_atoms = self.row_ptr, self.entries, self.n_pairs, self.n_atoms
+                # (kept with the list, not with the handle: a new list tensor with the same values gets a new handle -- see
+                # adopt_shifts -- and must not pack them again: 0.15 ms at cfg3 for a stream that only skipped kernels name)
+                made = self.__dict__.setdefault("_front_lazy", {})
 
-                def lazy(kind, shifts=shifts):
+                def lazy(kind, shifts=shifts, made=made):
+                    packed = made.get(kind)
+                    if packed is not None:
+                        return packed
                     if kind == "row_packed":
                         packed = _pack_row_shifts(entries, shifts, n_pairs)
                     else:
@@ -512,6 +520,7 @@ class PairTopology:
                         packed = packed if fmt == 1 else None
                     if packed is None:  # cannot happen when the 4-byte stream exists
                         raise RuntimeError(f"no {kind} stream for this list")
+                    made[kind] = packed
                     return packed
 
                 handle = mod.Topology(pairs, shifts, self.pairs32, pair_packed, self.row_ptr, self.entries, ent32, self.n_atoms,
