@@ -301,3 +301,49 @@ def test_pair_list_is_not_kept_alive():
     del d, V, E, ti
     gc.collect()
     assert ref() is None
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("scheme,exponent", [("P3M", 1), ("Lagrange", 1), ("P3M", 6)])
+def test_caller_made_distances_take_the_compiled_node(dtype, tol, scheme, exponent):
+    """`neighbor_distances` without a history (a neighbour-list library's output; the reference tuner's protocol,
+    tuning/tuner.py:337-373: cloned leaves, result.sum().backward()): front.cpp's PlainCalcNode.  Values and the gradients
+    w.r.t. charges, cell, positions against the oracle -- uniform and general upstream gradients, first sighting of the distance
+    tensor (pair sum from the distances) and later ones (from the table of v_SR(d)), new list / cell tensors with old values."""
+    rng, cell, pos, q, pairs, S, dist = _system(seed=23)
+    if exponent == 6:
+        q = np.abs(q) + 0.3
+    spec = O.PotentialSpec("coulomb" if exponent == 1 else "ipl", exponent, 1.1, 1.0)
+    Vo, cache = O.forward(spec, scheme, 4, 0.9, q, cell, pos, pairs, dist, return_cache=True)
+    calc = _calc("P3M" if scheme == "P3M" else "PME", exponent)
+    tq0, tc0, tp0, ti0, _ = _tensors(cell, pos, q, pairs, S, dtype)
+    td = torch.tensor(dist, device=DEV, dtype=dtype)
+    for call in range(5):
+        tq, tc, tp = tq0.detach().clone().requires_grad_(True), tc0.detach().clone().requires_grad_(True), tp0.detach().clone().requires_grad_(True)
+        ti = ti0.clone() if call == 3 else ti0  # (a new list tensor with the old values: the structures are reused on a bet)
+        V = calc(tq, tc, tp, ti, td)
+        fp64_ipl = exponent == 6 and dtype == torch.float64  # (no fused cell gradient for fp64 1/r^6: Python nodes)
+        assert (V.grad_fn.name() == "MipmeCalculatorPlainDistancesBackward") != fp64_ipl, V.grad_fn.name()
+        assert rell2(V.detach().cpu(), Vo) < tol
+        if call % 2 == 0:
+            w = np.ones_like(q)
+            V.sum().backward()
+        else:
+            w = rng.normal(size=q.shape)
+            (torch.tensor(w, device=DEV, dtype=dtype) * V).sum().backward()
+        gr = O.backward(cache, w)
+        assert rell2(tq.grad.cpu(), gr["charges"]) < tol and rell2(tp.grad.cpu(), gr["positions"]) < tol
+        assert rell2(tc.grad.cpu(), gr["cell"]) < 30 * tol
+    # only the charges want a gradient; a distance tensor that requires one keeps the Python nodes
+    tq = tq0.detach().clone().requires_grad_(True)
+    V = calc(tq, tc0.detach(), tp0.detach(), ti0, td)
+    assert V.grad_fn.name() == "MipmeCalculatorPlainDistancesBackward"
+    V.sum().backward()
+    assert rell2(tq.grad.cpu(), O.backward(cache, np.ones_like(q))["charges"]) < tol
+    V = calc(tq, tc0.detach(), tp0.detach(), ti0, td.clone().requires_grad_(True))
+    assert V.grad_fn.name() != "MipmeCalculatorPlainDistancesBackward" and rell2(V.detach().cpu(), Vo) < tol
+    # a cell with OTHER values: the speculative geometry loses its bet, the call is repeated, same numbers as the oracle's
+    cell2 = cell * 1.01
+    Vo2 = O.forward(spec, scheme, 4, 0.9, q, cell2, pos, pairs, dist)
+    V = calc(tq, torch.tensor(cell2, device=DEV, dtype=dtype), tp0.detach(), ti0, td)
+    assert rell2(V.detach().cpu(), Vo2) < tol

@@ -365,12 +365,30 @@ class PMECalculator(Calculator):
         ``pair_distances`` (its compiled node); gradients for positions, charges and cell; ``None`` sends the call down the Python
         path, which also owns every error message: nothing is validated here beyond what decides the route."""
         mod = _front.module()
-        if (mod is None or type(neighbor_distances) is not torch.Tensor or not mod.is_front_distances(neighbor_distances)
-                or type(cell) is not torch.Tensor or cell.shape != (3, 3) or type(positions) is not torch.Tensor
-                or cell.dtype != positions.dtype or cell.device != positions.device):
+        if (mod is None or type(neighbor_distances) is not torch.Tensor or type(cell) is not torch.Tensor
+                or cell.shape != (3, 3) or type(positions) is not torch.Tensor or cell.dtype != positions.dtype
+                or cell.device != positions.device):
             return None
+        if not mod.is_front_distances(neighbor_distances):
+            if (neighbor_distances.requires_grad or not positions.is_cuda
+                    or getattr(neighbor_distances, "_mipme_src", None) is not None):  # (provenance: the Python nodes' business)
+                return None
+            return self._front_plain(mod, charges, cell, positions, neighbor_indices, neighbor_distances)
         geom, G = self._kspace_setup(cell, positions.dtype, positions.device, speculate=False)
         want_cell = cell.requires_grad
+        fc = self._front_calculator(mod, geom, G, cell, positions, want_cell)
+        if fc is None:
+            return None
+        if self.check_nan == "deferred":
+            self.check()  # a NaN seen by an earlier call surfaces here
+        out = mod.calc_forward(fc, charges, cell, positions, neighbor_indices, neighbor_distances)
+        if out is not None and self._nan_flag is not None:
+            self.__dict__["_nan_shape"] = [1, *geom.ns]
+        return out
+
+    def _front_calculator(self, mod, geom, G, cell, positions, want_cell):
+        """The extension's handle of this calculator on this geometry (descriptors, plan, G and -- for a cell that requires a
+        gradient -- its derivative table), or ``None`` when the compiled nodes do not cover the configuration."""
         key = (bool(self.full_neighbor_list), self.check_nan, want_cell)
         c = geom.__dict__.get("_front")
         if c is None or c[0] != key:
@@ -389,11 +407,45 @@ class PMECalculator(Calculator):
                 fc = mod.Calculator(bytes(geom.desc(1)), bytes(pot_desc), plan.handle.value, G, cell,
                                     bool(self.full_neighbor_list), self._nan_flag_ptr() or 0, geom.n_half, plan, deriv)
             c = geom._front = (key, fc)
-        if c[1] is None:
+        return c[1]
+
+    def _front_plain(self, mod, charges, cell, positions, neighbor_indices, neighbor_distances):
+        """Caller-made distances without a history (front.cpp, PlainCalcNode): the reference tuner's timing protocol
+        (tuning/tuner.py:337-373) and every call that hands over a neighbour-list library's distances.  The geometry may be the
+        one cached for the previous cell tensor, on the bet that the new one holds the same values (``_kspace_setup``); the bet
+        is looked at after the launches, and a lost one repeats the call through the Python path."""
+        if (type(neighbor_indices) is not torch.Tensor or type(charges) is not torch.Tensor or charges.dim() != 2
+                or charges.shape[1] != 1 or neighbor_indices.dim() != 2 or not neighbor_indices.is_contiguous()
+                or not neighbor_distances.is_contiguous() or getattr(neighbor_indices, "_mipme_stream", None) is not None
+                or not torch.is_grad_enabled() or ops.PAIR_MODE != "rows" or ops.PROFILE is not None
+                or not (charges.requires_grad or cell.requires_grad or positions.requires_grad)
+                or neighbor_indices.shape[0] == 0 or neighbor_distances.shape != (neighbor_indices.shape[0],)
+                or charges.shape[0] != positions.shape[0] or ops.inside_vmap(charges, cell, positions, neighbor_distances)):
             return None
-        if self.check_nan == "deferred":
-            self.check()  # a NaN seen by an earlier call surfaces here
-        out = mod.calc_forward(c[1], charges, cell, positions, neighbor_indices, neighbor_distances)
+        geom, G = self._kspace_setup(cell, positions.dtype, positions.device)
+        speculated = self._speculated is not None
+        out = None
+        fc = self._front_calculator(mod, geom, G, cell, positions, cell.requires_grad)
+        if fc is not None:
+            with ops.betting():
+                topo = ops.get_topology(neighbor_indices, positions.shape[0])
+                handle = topo.front_plain(neighbor_indices) if isinstance(topo, ops.PairTopology) else None
+                if handle is not None:
+                    tab = None
+                    if ops.TABULATE:
+                        tab = topo.tabulated(neighbor_distances, None, self.potential._descriptor(), bool(self.full_neighbor_list))
+                    if self.check_nan == "deferred":
+                        self.check()
+                    out = mod.calc_forward_plain(fc, handle, charges, cell, positions, neighbor_indices, neighbor_distances,
+                                                 None if tab is None else tab[0], None if tab is None else tab[1])
+            try:
+                ops.verify_bets()  # (a new list tensor with the values of the previous one: structures reused on a bet)
+            except ops.SpeculationLost:
+                out = None
+        if speculated and self._speculated is not None and not self._speculation_held():
+            out = None  # (the Python path below starts over with this cell's own geometry)
+        elif out is None and speculated:
+            self.__dict__["_speculated"] = None
         if out is not None and self._nan_flag is not None:
             self.__dict__["_nan_shape"] = [1, *geom.ns]
         return out

@@ -78,6 +78,8 @@ struct Api {
   decltype(&mipme_cell_tail_work) cell_tail_work = nullptr;
   decltype(&mipme_cellgrad_partials_size) cellgrad_partials_size = nullptr;
   decltype(&mipme_rows_partials_size) rows_partials_size = nullptr;
+  decltype(&mipme_rspace_rows) rspace_rows = nullptr;
+  decltype(&mipme_rspace_rows_tabulated) rspace_rows_tabulated = nullptr;
 };
 Api g_api;
 
@@ -110,6 +112,8 @@ void load_library(const std::string& path) {
   bind(g_api.cell_tail_work, "mipme_cell_tail_work");
   bind(g_api.cellgrad_partials_size, "mipme_cellgrad_partials_size");
   bind(g_api.rows_partials_size, "mipme_rows_partials_size");
+  bind(g_api.rspace_rows, "mipme_rspace_rows");
+  bind(g_api.rspace_rows_tabulated, "mipme_rspace_rows_tabulated");
   if (g_api.version() != MIPME_VERSION)
     throw std::runtime_error("libmipme version " + std::to_string(g_api.version()) + " != header " + std::to_string(MIPME_VERSION));
 }
@@ -749,6 +753,252 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   return out;
 }
 
+// ---- the calculator on CALLER-MADE distances -----------------------------------------------------------------------------------
+// `neighbor_distances` is a plain tensor without a history (a neighbour-list library's output; the reference tuner's timing
+// protocol, tuning/tuner.py:337-373, which clones charges / cell / positions for every call and differentiates result.sum()):
+// the pair sum reads the distances as they are -- or the table of v_SR(d) per row entry that ops.PairTopology.tabulated keeps
+// for a distance tensor seen before --, gradients go to charges, cell and positions through the mesh part and, for the charges,
+// the transposed pair sum.  Always the general adjoint: no energy-mode shortcut here, the Python nodes (~0.2 ms of host time
+// per call against ~0.05 here) were the cost of this path, not its kernels.
+struct PlainTopo {
+  c10::weak_intrusive_ptr<c10::TensorImpl> pairs{c10::intrusive_ptr<c10::TensorImpl>()};
+  uint32_t pairs_version = 0;
+  at::Tensor row_ptr, entries;
+  int64_t n_atoms = 0, n_pairs = 0;
+};
+
+struct PlainCalcNode : public Node {
+  std::shared_ptr<FrontCalc> calc;
+  std::shared_ptr<PlainTopo> topo;
+  at::Tensor q, pos, cell, dist;  // detached aliases of the inputs
+  at::Tensor q_in, cell_in, pos_in;
+  uint32_t q_version = 0, pos_version = 0, cell_version = 0, dist_version = 0;
+  at::Tensor keep;  // one slab: phi_mesh | rho_dc | atom bins
+  size_t off_phi = 0, off_dc = 0, off_bins = 0;
+  at::Tensor rho_kept, phi_atoms;      // cell gradient (see CalcNode)
+  at::Tensor tab_values, tab_row_sum;  // v_SR(d) per row entry and its transposed row sums, or undefined
+
+  std::string name() const override { return "MipmeCalculatorPlainDistancesBackward"; }
+  char* slab(size_t off) const { return static_cast<char*>(keep.data_ptr()) + off; }
+
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(3);
+    const at::Tensor& g_in = grads[0];
+    const bool need_q = task_should_compute_output(0), need_cell = task_should_compute_output(1),
+               need_pos = task_should_compute_output(2);
+    if (!g_in.defined() || (!need_q && !need_cell && !need_pos)) return out;
+    TORCH_CHECK(q._version() == q_version && pos._version() == pos_version && cell._version() == cell_version &&
+                    dist._version() == dist_version,
+                "an input of the calculator was modified in place before the backward pass");
+    const int64_t N = q.size(0);
+    const int dt = dtype_code(pos);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pos.device());
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(pos.device().index()).stream();
+    // a uniform upstream gradient (result.sum().backward()): an expanded scalar
+    const bool uniform = N > 1 && g_in.dim() == 2 && g_in.stride(0) == 0;
+    at::Tensor g = g_in.contiguous();
+    const auto opts = pos.options();
+    const size_t s = dt == MIPME_F32 ? 4 : 8;
+    const size_t mesh_bytes = align256(size_t(calc->mesh.nx) * calc->mesh.ny * calc->mesh.nz * s);
+    const size_t hat_bytes = align256(size_t(calc->n_half) * 2 * s);
+    at::Tensor work = at::empty({int64_t(2 * mesh_bytes + hat_bytes + 256)}, opts.dtype(at::kByte));
+    char* w = static_cast<char*>(work.data_ptr());
+    at::Tensor grad_pos, grad_q, grad_cell, cell_partials;
+    mipme_kspace_backward_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.size = sizeof(a);
+    a.version = MIPME_ARGS_VERSION;
+    a.plan = calc->plan;
+    a.stream = stream;
+    a.dtype = dt;
+    a.mesh = &calc->mesh;
+    a.pot = &calc->pot;
+    a.n_atoms = N;
+    a.positions = pos.data_ptr();
+    a.charges = q.data_ptr();
+    a.grad_out = g.data_ptr();
+    a.G = calc->G.data_ptr();
+    a.phi_mesh = slab(off_phi);
+    a.rho_dc = slab(off_dc);
+    a.psi_mesh = w;
+    a.chi_mesh = w + mesh_bytes;
+    a.hat_work = w + 2 * mesh_bytes;
+    a.dc = w + 2 * mesh_bytes + hat_bytes;
+    a.atom_bins = slab(off_bins);
+    if (need_pos || need_cell) {  // (the cell gradient contains the mesh forces)
+      grad_pos = at::empty_like(pos);
+      a.grad_positions = grad_pos.data_ptr();
+    }
+    if (need_q) {
+      grad_q = at::empty_like(q);
+      a.grad_charges = grad_q.data_ptr();
+    }
+    if (need_cell) {
+      grad_cell = at::empty({3, 3}, opts);
+      cell_partials = at::empty({g_api.cellgrad_partials_size(&calc->mesh, N)}, opts.dtype(at::kDouble));
+      a.rho_hat = rho_kept.data_ptr();
+      a.phi_atoms = phi_atoms.data_ptr();
+      a.partials = cell_partials.data_ptr();
+      a.grad_cell = grad_cell.data_ptr();
+      a.G_deriv = calc->G_deriv.data_ptr();
+    }
+    check(g_api.kspace_backward(&a), "kspace_backward");
+    if (need_q) {
+      if (tab_values.defined() && uniform) {
+        grad_q.addcmul_(tab_row_sum, g_in.narrow(0, 0, 1));  // c times the table's row sums
+      } else if (tab_values.defined()) {
+        check(g_api.rspace_rows_tabulated(stream, dt, N, topo->row_ptr.data_ptr(), tab_values.data_ptr(), g.data_ptr(), 1,
+                                          calc->full_list, 1, grad_q.data_ptr()),
+              "rspace_backward_charges");
+      } else {
+        check(g_api.rspace_rows(stream, dt, N, 1, topo->row_ptr.data_ptr(), topo->entries.data_ptr(), dist.data_ptr(), g.data_ptr(),
+                                nullptr, 1, calc->full_list, &calc->pot, 1, grad_q.data_ptr()),
+              "rspace_backward_charges");
+      }
+    }
+    if (at::GradMode::is_enabled()) {
+      first_order_only(grad_pos, pos_in.defined() ? pos_in : q_in.defined() ? q_in : cell_in);
+      first_order_only(grad_q, q_in.defined() ? q_in : pos_in.defined() ? pos_in : cell_in);
+      first_order_only(grad_cell, cell_in.defined() ? cell_in : pos_in.defined() ? pos_in : q_in);
+    }
+    if (need_q) out[0] = grad_q;
+    if (need_cell) out[1] = grad_cell;
+    if (need_pos) out[2] = grad_pos;
+    return out;
+  }
+
+  void release_variables() override {
+    q.reset();
+    pos.reset();
+    cell.reset();
+    dist.reset();
+    q_in.reset();
+    cell_in.reset();
+    pos_in.reset();
+    keep.reset();
+    rho_kept.reset();
+    phi_atoms.reset();
+    tab_values.reset();
+    tab_row_sum.reset();
+  }
+};
+
+// V for caller-made distances; None if the call is outside this case.  The geometry / G(k) of `calc` are the CALLER's word for
+// this cell (the Python layer verifies a speculative geometry after the call, calculators.py).
+std::optional<at::Tensor> calc_forward_plain(const std::shared_ptr<FrontCalc>& calc, const std::shared_ptr<PlainTopo>& topo,
+                                             const at::Tensor& charges, const at::Tensor& cell, const at::Tensor& positions,
+                                             const at::Tensor& pairs, const at::Tensor& dist,
+                                             const std::optional<at::Tensor>& tab_values,
+                                             const std::optional<at::Tensor>& tab_row_sum) {
+  if (!calc || !topo || !at::GradMode::is_enabled() || !eligible_real(positions) || !eligible_real(charges) ||
+      !eligible_real(cell) || !eligible_real(dist) || dist.requires_grad() || dist.grad_fn())
+    return std::nullopt;
+  const bool want_q = charges.requires_grad(), want_cell = cell.requires_grad(), want_pos = positions.requires_grad();
+  if ((!want_q && !want_cell && !want_pos) || (want_cell && !calc->G_deriv.defined())) return std::nullopt;
+  const int64_t N = topo->n_atoms, P = topo->n_pairs;
+  if (N <= 0 || P <= 0 || charges.dim() != 2 || charges.size(0) != N || charges.size(1) != 1 || positions.dim() != 2 ||
+      positions.size(0) != N || positions.size(1) != 3 || dist.dim() != 1 || dist.size(0) != P || pairs.dim() != 2 ||
+      pairs.size(0) != P || pairs.size(1) != 2 || cell.dim() != 2 || cell.size(0) != 3 || cell.size(1) != 3)
+    return std::nullopt;
+  if (charges.scalar_type() != positions.scalar_type() || cell.scalar_type() != positions.scalar_type() ||
+      dist.scalar_type() != positions.scalar_type() || charges.device() != positions.device() ||
+      cell.device() != positions.device() || dist.device() != positions.device() || calc->G.device() != positions.device() ||
+      calc->G.scalar_type() != positions.scalar_type() || topo->row_ptr.device() != positions.device())
+    return std::nullopt;
+  if (topo->pairs.expired() || topo->pairs._unsafe_get_target() != pairs.unsafeGetTensorImpl() ||
+      pairs._version() != topo->pairs_version)
+    return std::nullopt;
+  const bool tab = tab_values.has_value() && tab_row_sum.has_value() && tab_values->defined() && tab_row_sum->defined();
+
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(positions.device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(positions.device().index()).stream();
+  if (stream_is_capturing(stream)) return std::nullopt;
+  const int dt = dtype_code(positions);
+  const size_t s = dt == MIPME_F32 ? 4 : 8;
+  const int64_t bins_bytes = g_api.atom_bins_bytes(&calc->mesh, N, dt);
+  if (bins_bytes <= 0) return std::nullopt;
+  const auto opts = positions.options();
+  at::Tensor q = charges.detach(), pos = positions.detach(), cl = cell.detach();
+
+  const size_t mesh_bytes = align256(size_t(calc->mesh.nx) * calc->mesh.ny * calc->mesh.nz * s);
+  const size_t hat_bytes = align256(size_t(calc->n_half) * 2 * s);
+  auto node = std::make_shared<PlainCalcNode>();
+  node->off_phi = 0;
+  node->off_dc = mesh_bytes;
+  node->off_bins = node->off_dc + 256;
+  const size_t keep_bytes = node->off_bins + align256(size_t(bins_bytes));
+  at::Tensor keep = at::empty({int64_t(keep_bytes)}, opts.dtype(at::kByte));
+  at::Tensor work = at::empty({int64_t(mesh_bytes + hat_bytes)}, opts.dtype(at::kByte));  // rho_mesh | hat_work
+  at::Tensor out = at::empty({N, 1}, opts);
+  at::Tensor rho_kept, phi_atoms;
+  if (want_cell) {
+    rho_kept = at::empty({int64_t(hat_bytes)}, opts.dtype(at::kByte));
+    phi_atoms = at::empty({N, 1}, opts);
+  }
+  char* kp = static_cast<char*>(keep.data_ptr());
+  char* wp = static_cast<char*>(work.data_ptr());
+  // the pair sum first (it overwrites `out`), then the mesh part on top
+  if (tab)
+    check(g_api.rspace_rows_tabulated(stream, dt, N, topo->row_ptr.data_ptr(), tab_values->data_ptr(), q.data_ptr(), 0,
+                                      calc->full_list, 0, out.data_ptr()),
+          "rspace_forward");
+  else
+    check(g_api.rspace_rows(stream, dt, N, 1, topo->row_ptr.data_ptr(), topo->entries.data_ptr(), dist.data_ptr(), q.data_ptr(), nullptr,
+                            0, calc->full_list, &calc->pot, 0, out.data_ptr()),
+          "rspace_forward");
+  mipme_kspace_forward_args_t a;
+  std::memset(&a, 0, sizeof(a));
+  a.size = sizeof(a);
+  a.version = MIPME_ARGS_VERSION;
+  a.plan = calc->plan;
+  a.stream = stream;
+  a.dtype = dt;
+  a.accumulate_out = 1;
+  a.mesh = &calc->mesh;
+  a.pot = &calc->pot;
+  a.n_atoms = N;
+  a.positions = pos.data_ptr();
+  a.charges = q.data_ptr();
+  a.G = calc->G.data_ptr();
+  a.rho_mesh = wp;
+  a.rho_hat = nullptr;
+  a.hat_work = wp + mesh_bytes;
+  a.phi_mesh = kp + node->off_phi;
+  a.dc = kp + node->off_dc;
+  a.out_lr = out.data_ptr();
+  a.atom_bins = kp + node->off_bins;
+  a.nan_flag = calc->nan_flag;
+  if (want_cell) {
+    a.out_phi = phi_atoms.data_ptr();
+    a.out_rho_hat = rho_kept.data_ptr();
+  }
+  check(g_api.kspace_forward(&a), "kspace_forward");
+
+  node->calc = calc;
+  node->topo = topo;
+  node->q = q;
+  node->pos = pos;
+  node->cell = cl;
+  node->dist = dist;
+  if (want_q) node->q_in = charges;
+  if (want_cell) node->cell_in = cell;
+  if (want_pos) node->pos_in = positions;
+  node->q_version = charges._version();
+  node->pos_version = positions._version();
+  node->cell_version = cell._version();
+  node->dist_version = dist._version();
+  node->keep = keep;
+  node->rho_kept = rho_kept;
+  node->phi_atoms = phi_atoms;
+  if (tab) {
+    node->tab_values = *tab_values;
+    node->tab_row_sum = *tab_row_sum;
+  }
+  node->set_next_edges(torch::autograd::collect_next_edges(charges, cell, positions));
+  torch::autograd::create_gradient_edge(out, node);
+  return out;
+}
+
 bool is_front_distances(const at::Tensor& d) {
   return d.defined() && std::dynamic_pointer_cast<DistNode>(d.grad_fn()) != nullptr;
 }
@@ -798,6 +1048,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         c->keepalive = std::move(keepalive);
         return c;
       }));
+  py::class_<PlainTopo, std::shared_ptr<PlainTopo>>(m, "PlainTopology")
+      .def(py::init([](at::Tensor pairs, at::Tensor row_ptr, at::Tensor entries, int64_t n_atoms) {
+        auto t = std::make_shared<PlainTopo>();
+        t->pairs = c10::weak_intrusive_ptr<c10::TensorImpl>(pairs.getIntrusivePtr());
+        t->pairs_version = pairs._version();
+        t->row_ptr = row_ptr;
+        t->entries = entries;
+        t->n_atoms = n_atoms;
+        t->n_pairs = pairs.size(0);
+        return t;
+      }));
+  m.def("calc_forward_plain", &calc_forward_plain);
   m.def("pair_distances", &pair_distances);
   m.def("calc_forward", &calc_forward);
   m.def("is_front_distances", &is_front_distances);

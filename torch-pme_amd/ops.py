@@ -528,6 +528,19 @@ class PairTopology:
         self._front = (weakref.ref(key), key._version, shifts.dtype, handle)
         return handle
 
+    def front_plain(self, pairs: torch.Tensor):
+        """Handle of this list for the compiled calculator node on caller-made distances (front.cpp, PlainTopo): the row
+        structure only, no shift streams.  Cached per list tensor."""
+        c = self.__dict__.get("_front_plain")
+        if c is not None and c[0]() is pairs and c[1] == pairs._version:
+            return c[2]
+        mod = _front.module()
+        handle = None
+        if mod is not None and self.fmt_flags == 0 and self.n_pairs > 0:
+            handle = mod.PlainTopology(pairs, self.row_ptr, self.entries, self.n_atoms)
+        self._front_plain = (weakref.ref(pairs), pairs._version, handle)
+        return handle
+
     @property
     def sorted_by_first(self) -> bool:
         """True if ``pairs[:, 0]`` is non-decreasing (neighbour-list builders emit it so): the role-i entries of a row are
