@@ -60,5 +60,11 @@ PROFILE=1 python tools/prof_protocol.py 200 > $OUT/${TAG}_protocol_prof.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_pp -o t -- python $ROOT/tools/prof_protocol.py 200 > /dev/null 2>&1)
 python tools/rocpd_summary.py $(find $OUT/${TAG}_pp -name '*.db') > $OUT/${TAG}_kernel_stats_protocol.txt
 rm -rf $OUT/${TAG}_pp
+# round 4: compiled front end with charges / cell gradients; a new list tensor every call
+python tools/check_front_contract.py > $OUT/${TAG}_check_front_contract.txt 2>&1
+python tools/prof_cold.py 100 > $OUT/${TAG}_cold_list.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cold -o t -- python $ROOT/tools/prof_cold.py 100 > /dev/null 2>&1)
+python tools/rocpd_summary.py $(find $OUT/${TAG}_cold -name '*.db') > $OUT/${TAG}_kernel_stats_cold_list.txt
+rm -rf $OUT/${TAG}_cold
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2>> $OUT/${TAG}_bench_default.err
 ls -la $OUT | grep ${TAG}
