@@ -104,3 +104,36 @@ def test_force_loss_gradients_by_finite_differences(which):
     # first order is untouched by the option: same forces as the plain calculator
     F1, _ = first_order(pos)
     assert float((-g.detach() - F1).norm() / F1.norm()) < 1e-12
+
+
+@pytest.mark.parametrize("route", ["front", "python_nodes"])
+def test_force_loss_on_other_parameters_needs_no_second_order(route, monkeypatch):
+    """A model term next to the calculator (E = E_pme(r) + w * sum r^2), forces with create_graph=True, a loss on them: the
+    gradient w.r.t. the MODEL parameter never differentiates the calculator twice, so it works out of the box when only that
+    parameter is asked for (`backward(inputs=[w])` / `autograd.grad(loss, [w])`) -- the error node sits on the path to the
+    positions only.  `loss.backward()` without `inputs` also asks for d loss / d positions, which is second order through the
+    calculator: that raises the hint (round-3 advice: say so)."""
+    if route == "python_nodes":
+        monkeypatch.setattr(ops, "FRONT", False)
+    pos, q, cell, pairs, S = _system()
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.8, interpolation_nodes=4)
+    tp = torch.tensor(pos, device=DEV, dtype=torch.float64, requires_grad=True)
+    tq, tc = torch.tensor(q, device=DEV, dtype=torch.float64), torch.tensor(cell, device=DEV, dtype=torch.float64)
+    ti, tS = torch.tensor(pairs, device=DEV), torch.tensor(S, device=DEV, dtype=torch.float64)
+    w = torch.tensor(0.3, device=DEV, dtype=torch.float64, requires_grad=True)
+
+    def loss_on_forces():
+        d = tpa.pair_distances(tp, ti, tc, tS)
+        E = (tq * calc(tq, tc, tp, ti, d)).sum() + w * (tp * tp).sum()
+        (F,) = torch.autograd.grad(E, tp, create_graph=True)
+        return (F * F).sum(), F
+
+    loss, F = loss_on_forces()
+    loss.backward(inputs=[w])
+    # F = F_pme + 2 w r  =>  d loss / d w = sum 2 F . 2 r
+    want = float((4.0 * F.detach() * tp.detach()).sum())
+    assert abs(float(w.grad) - want) <= 1e-10 * abs(want)
+    (gw,) = torch.autograd.grad(loss_on_forces()[0], [w])
+    assert abs(float(gw) - want) <= 1e-10 * abs(want)
+    with pytest.raises(RuntimeError, match='double_backward = "finite-difference"'):
+        loss_on_forces()[0].backward()
