@@ -24,7 +24,15 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmipme.so does not export {name}"
     assert sorted(declared) == sorted(_lib.EXPORTS)
-    assert lib.mipme_version() == 402
+    assert lib.mipme_version() == int(re.search(r"#define\s+MIPME_VERSION\s+(\d+)", hdr).group(1)) == 402
+
+
+def test_build_hook_accepts_the_tree():
+    """__graft_entry__.build(): make (a no-op on an up-to-date tree), every export present, the library's version that of the
+    header, the compiled front end loadable."""
+    import __graft_entry__ as entry
+
+    entry.build()
 
 
 def test_compiled_front_end_loads_and_declines_cpu_tensors():
