@@ -13,7 +13,7 @@ import torchpme_amd as tpa  # noqa: E402,F401
 from torchpme_amd import _lib  # noqa: E402
 from bench import Frame, make_workload  # noqa: E402
 
-w = make_workload("water", 0)
+w = make_workload(sys.argv[1] if len(sys.argv) > 1 else "water", 0)
 f = Frame(w, torch.device("cuda:0"))
 for _ in range(5):
     f.step()
