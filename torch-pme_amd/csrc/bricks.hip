@@ -2635,6 +2635,9 @@ int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_fra
 }  // extern "C"
 
 #ifdef MIPME_WG_TIMELINE
+extern "C" int mipme_debug_rows_phase(void* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mipme::g_rows_phase), size_t(n_words) * 8);
+}
 extern "C" int mipme_debug_wg_phase(void* out, int n_words) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mipme::g_wg_phase), size_t(n_words) * 8);
 }

@@ -492,6 +492,17 @@ static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(Atom
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ d2v llvm_raw_buffer_load_d2(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f64");
 
+#ifdef MIPME_WG_TIMELINE  // measurement builds only (tools/rows_phases.py): clock stamps of the first 1024 row workgroups
+static __device__ long long g_rows_phase[8 * 1024];
+#define MIPME_ROWS_PHASE(k, wait)                                                                                   \
+  do {                                                                                                              \
+    if (wait) __builtin_amdgcn_s_waitcnt(0);                                                                        \
+    if (threadIdx.x == 0 && block < 1024) g_rows_phase[block * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define MIPME_ROWS_PHASE(k, wait)
+#endif
+
 template <int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
   static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
@@ -508,6 +519,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   unsigned a = block * (BS / kRowLanes) + threadIdx.x / kRowLanes;
   const bool valid = a < N;
   if (!valid) a = unsigned(N - 1);
+  MIPME_ROWS_PHASE(0, false);
   const int* __restrict__ rp = row_ptr + int64_t(args.row_stride) * a;
   const int r0 = rp[0], mid = rp[1], r2 = rp[2];
   // (uniform by construction; said so explicitly, or the buffer descriptor built from it is treated as divergent and every
@@ -547,7 +559,9 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   int off = (beg + sub) * 4;
   unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
   unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+  MIPME_ROWS_PHASE(1, false);
   __syncthreads();  // shift table + erfcx table
+  MIPME_ROWS_PHASE(2, true);
   double pot = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
   double cg[CELL ? 9 : 1];
 #pragma unroll
@@ -607,7 +621,12 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
         cg[6] = __builtin_fma(sh.z, tx, cg[6]); cg[7] = __builtin_fma(sh.z, ty, cg[7]); cg[8] = __builtin_fma(sh.z, tz, cg[8]);
       }
     }
+#ifdef MIPME_WG_TIMELINE
+    if (eA == beg + sub) MIPME_ROWS_PHASE(3, false);
+    if (eA == beg + sub + 2 * kRowLanes) MIPME_ROWS_PHASE(4, false);
+#endif
   }
+  MIPME_ROWS_PHASE(5, false);
   if constexpr (CELL) {
     if (args.cpart) {
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
@@ -638,6 +657,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     force[3 * a + 1] = fy;
     force[3 * a + 2] = fz;
   }
+  MIPME_ROWS_PHASE(6, true);
 }
 
 #if MIPME_ROW_LANES == 16
