@@ -697,7 +697,7 @@ __device__ __forceinline__ void checksum_words(const uint4 v, unsigned j, unsign
        (unsigned long long)v.w * (k2 + 3u * C2);
 }
 
-static constexpr int kChecksumBlocks = 512;
+static constexpr int kChecksumBlocks = 256;
 
 // sums: uint64[3 + 2 kChecksumBlocks]: {a, b, ticket, per-block partial sums}.  Every block stores its two partial sums and
 // draws a ticket; the last one adds them up in block order.  (The first version added its sums to sums[0..1] with three
@@ -708,12 +708,12 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__
   unsigned long long a = 0, b = 0;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n_vec; i += 4 * stride) {  // four loads in flight
-    const uint4 v0 = data[i], v1 = data[i + stride], v2 = data[i + 2 * stride], v3 = data[i + 3 * stride];
-    checksum_words(v0, unsigned(4 * i), a, b);
-    checksum_words(v1, unsigned(4 * (i + stride)), a, b);
-    checksum_words(v2, unsigned(4 * (i + 2 * stride)), a, b);
-    checksum_words(v3, unsigned(4 * (i + 3 * stride)), a, b);
+  for (; i + 7 * stride < n_vec; i += 8 * stride) {  // eight loads in flight
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = data[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) checksum_words(v[u], unsigned(4 * (i + u * stride)), a, b);
   }
   for (; i < n_vec; i += stride) checksum_words(data[i], unsigned(4 * i), a, b);
   if (blockIdx.x == 0 && int(threadIdx.x) < n_tail) {
