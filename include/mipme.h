@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 402
+#define MIPME_VERSION 403
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -104,6 +104,29 @@ int mipme_spread(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 /* out[i,c] = sum_stencil mesh[c,ix,iy,iz] * wx*wy*wz  (compute_weights + mesh_to_points, :428-457). */
 int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
                  const void* mesh_in, void* out);
+
+/* ---- differentiable primitives (second-order route, calculator.double_backward = "analytic") ----
+ * The reference's path is ATen ops, so autograd differentiates it to any order (a loss on forces:
+ * calculators/calculator.py:43-87,103-189; tests/calculators/test_workflow.py:164-192 for the first order).  These four
+ * linear maps are closed under differentiation -- the backward pass of each is made of the same four -- and take the
+ * FRACTIONAL mesh coordinates u = ns * (positions @ inv(cell)) (N,3) (lib/mesh_interpolator.py:326-341) as a tensor, so
+ * that the chain to positions and cell belongs to the caller's autograd:
+ *   mesh[c,m]  = sum_i values[i,c] D^k W_i(m)      (spread; zeroes the mesh first)
+ *   out[i,c]   = sum_m mesh[c,m]   D^k W_i(m)      (gather)
+ * with W_i(m) = w(x) w(y) w(z) the interpolation weights of compute_weights (:303-377) and D^k = d^kx/du_x^kx d^ky/du_y^ky
+ * d^kz/du_z^kz, every order in 0..3 (piecewise polynomials of degree order-1: higher derivatives vanish). */
+int mipme_spread_jet(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* u, const void* values,
+                     int kx, int ky, int kz, void* mesh_out);
+int mipme_gather_jet(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* u, const void* mesh_in,
+                     int kx, int ky, int kz, void* out);
+/* out[i,c] = sum_p weights[p] x[j_p,c]  (the index_add_ of _compute_rspace, calculators/calculator.py:70-84, with the bare
+ * potentials as an input).  mode 0: half list (both directions), 1: full list (i <- j), 2: full list transposed (j <- i, the
+ * adjoint of mode 1).  Zeroes `out` (n_atoms, C) first. */
+int mipme_pair_sum(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels, const void* pairs,
+                   const void* weights, const void* x, int mode, void* out);
+/* out[p] = sum_c a[i_p,c] b[j_p,c] (+ a[j_p,c] b[i_p,c] when half != 0): the adjoint of mipme_pair_sum w.r.t. its weights. */
+int mipme_pair_dot(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* a,
+                   const void* b, int half, void* out);
 
 /* ---- PMECalculator._compute_kspace, calculators/pme.py:88-143 (P3M: calculators/p3m.py:45-84) -- */
 

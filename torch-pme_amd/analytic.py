@@ -1,0 +1,309 @@
+"""``Calculator.forward`` from primitives that are closed under differentiation: exact derivatives of any order.
+
+The reference is a chain of ATen ops (``calculators/calculator.py:43-87,103-189``, ``calculators/pme.py:88-143``,
+``lib/mesh_interpolator.py:303-457``, ``lib/kspace_filter.py:122-197``), so ``create_graph=True`` works there: a loss on forces
+with learned charges, Hessian-vector products, the stress of a force loss.  The fused HIP kernels behind the calculators are
+first order.  ``calculator.double_backward = "analytic"`` routes a call through this module instead: the same mathematics, cut
+into six linear maps whose backward passes are made of the same six maps (``csrc/jets.hip``, ``mipme_convolve``,
+``mipme_fft_r2c``), glued with tensor expressions for everything that is small or elementwise (fractional coordinates, the pair
+potential ``sr_from_dist``, the filter table as a function of the cell, self / background / slab terms) -- so PyTorch
+differentiates the composition as often as it is asked to, w.r.t. charges, positions, cell and distances alike.
+
+    spread(u, x; k)   mesh = sum_i x_i D^k W_i        d/du_d -> x * gather(., k + e_d)      d/dx   -> gather(., k)
+    gather(u, phi; k) out_i = sum_m phi_m D^k W_i(m)   d/du_d -> g * gather(phi, k + e_d)    d/dphi -> spread(g, k)
+    convolve(mesh, G) irfftn(G rfftn(mesh))            d/dmesh -> convolve(g, G)             d/dG   -> spectral_dot(mesh, g)
+    spectral_dot(a,b) mu Re(a^ conj b^) per k          d/da   -> convolve(b, c)              d/db   -> convolve(a, c)
+    pair_sum(w, x)    out_i = sum_p w_p x_j (+ j<-i)    d/dw   -> pair_dot(g, x)              d/dx   -> pair_sum(w, g) (transposed)
+    pair_dot(a, b)    out_p = a_i . b_j (+ a_j . b_i)   d/da   -> pair_sum(c, b)              d/db   -> pair_sum(c, a) (transposed)
+
+The interpolation weights are piecewise polynomials of degree ``interpolation_nodes - 1``; the kernels provide their derivatives
+up to third order per axis (enough for a double backward of a force loss and one order to spare), beyond that a call raises.
+Cost: a dozen launches per evaluation instead of six, atomics in the spread and the pair sum -- this is the route for training
+on forces and for Hessians, not for molecular dynamics.  Mesh calculators (PME, P3M) and the plain pair sum; for the explicit
+Ewald sum use ``double_backward = "finite-difference"``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, lib, ops
+
+_MAX_ORDER = 3
+
+
+def _bump(k, d):
+    out = list(k)
+    out[d] += 1
+    if out[d] > _MAX_ORDER:
+        raise RuntimeError(
+            "torchpme_amd: derivative of the interpolation weights beyond third order requested "
+            '(`double_backward = "analytic"` covers up to the third derivative of the potentials w.r.t. positions / cell)')
+    return tuple(out)
+
+
+def _stream(t):
+    return _lib.current_stream(t.device)
+
+
+class _Spread(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, x, geom, k):
+        uc, xc = u.detach().contiguous(), x.detach().contiguous()
+        n_ch = xc.shape[1]
+        mesh = torch.empty((n_ch, *geom.ns), dtype=xc.dtype, device=xc.device)
+        md = geom.desc(n_ch)
+        with _lib.on_device(xc.device):
+            _lib.check(_lib.load().mipme_spread_jet(_stream(xc), _lib.dtype_code(xc.dtype), C.byref(md), xc.shape[0],
+                                                    uc.data_ptr(), xc.data_ptr(), k[0], k[1], k[2], mesh.data_ptr()))
+        ctx.save_for_backward(u, x)
+        ctx.geom, ctx.k = geom, k
+        return mesh
+
+    @staticmethod
+    def backward(ctx, g):
+        u, x = ctx.saved_tensors
+        geom, k = ctx.geom, ctx.k
+        gu = gx = None
+        if ctx.needs_input_grad[0]:
+            gu = torch.stack([(x * _Gather.apply(u, g, geom, _bump(k, d))).sum(dim=1) for d in range(3)], dim=1)
+        if ctx.needs_input_grad[1]:
+            gx = _Gather.apply(u, g, geom, k)
+        return gu, gx, None, None
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, phi, geom, k):
+        uc, pc = u.detach().contiguous(), phi.detach().contiguous()
+        n_ch, n = pc.shape[0], uc.shape[0]
+        out = torch.empty((n, n_ch), dtype=pc.dtype, device=pc.device)
+        md = geom.desc(n_ch)
+        with _lib.on_device(pc.device):
+            _lib.check(_lib.load().mipme_gather_jet(_stream(pc), _lib.dtype_code(pc.dtype), C.byref(md), n, uc.data_ptr(),
+                                                    pc.data_ptr(), k[0], k[1], k[2], out.data_ptr()))
+        ctx.save_for_backward(u, phi)
+        ctx.geom, ctx.k = geom, k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, phi = ctx.saved_tensors
+        geom, k = ctx.geom, ctx.k
+        gu = gphi = None
+        if ctx.needs_input_grad[0]:
+            gu = torch.stack([(g * _Gather.apply(u, phi, geom, _bump(k, d))).sum(dim=1) for d in range(3)], dim=1)
+        if ctx.needs_input_grad[1]:
+            gphi = _Spread.apply(u, g, geom, k)
+        return gu, gphi, None, None
+
+
+def _complex_dtype(dtype):
+    return torch.complex64 if dtype == torch.float32 else torch.complex128
+
+
+class _Convolve(torch.autograd.Function):
+    """``irfftn(G * rfftn(mesh))``, both transforms un-normalised, ``G`` real on the half grid (``KSpaceFilter.forward``)."""
+
+    @staticmethod
+    def forward(ctx, mesh, G, geom):
+        mc = mesh.detach().contiguous()
+        Gc = G.detach().to(mc.dtype).contiguous()
+        n_ch = mc.shape[0]
+        hat = torch.empty((n_ch, geom.n_half), dtype=_complex_dtype(mc.dtype), device=mc.device)
+        work = torch.empty_like(hat)
+        out = torch.empty_like(mc)
+        plan = _lib.get_plan(mc.device, mc.dtype, geom.ns, n_ch)
+        with _lib.on_device(mc.device):
+            _lib.check(_lib.load().mipme_convolve(plan.handle, _stream(mc), mc.data_ptr(), Gc.data_ptr(), hat.data_ptr(),
+                                                  work.data_ptr(), out.data_ptr(), None))
+        ctx.save_for_backward(mesh, G)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mesh, G = ctx.saved_tensors
+        gm = gG = None
+        if ctx.needs_input_grad[0]:
+            gm = _Convolve.apply(g, G, ctx.geom)
+        if ctx.needs_input_grad[1]:
+            gG = _SpectralDot.apply(mesh, g, ctx.geom).to(G.dtype)
+        return gm, gG, None
+
+
+def _rfftn(mesh, geom):
+    mc = mesh.detach().contiguous()
+    n_ch = mc.shape[0]
+    hat = torch.empty((n_ch, geom.ns[0], geom.ns[1], geom.ns[2] // 2 + 1), dtype=_complex_dtype(mc.dtype), device=mc.device)
+    plan = _lib.get_plan(mc.device, mc.dtype, geom.ns, n_ch)
+    md = geom.desc(n_ch)
+    with _lib.on_device(mc.device):
+        _lib.check(_lib.load().mipme_fft_r2c(plan.handle, _stream(mc), _lib.dtype_code(mc.dtype), C.byref(md), mc.data_ptr(),
+                                             hat.data_ptr()))
+    return hat
+
+
+def _multiplicity(geom, dtype, device):
+    nz = geom.ns[2]
+    mu = torch.full((nz // 2 + 1,), 2.0, dtype=dtype, device=device)
+    mu[0] = 1.0
+    if nz % 2 == 0:
+        mu[-1] = 1.0
+    return mu
+
+
+class _SpectralDot(torch.autograd.Function):
+    """``out(k) = mu(k) sum_c Re(a^_c(k) conj b^_c(k))`` on the half grid: the adjoint of :class:`_Convolve` w.r.t. its table."""
+
+    @staticmethod
+    def forward(ctx, a, b, geom):
+        ha, hb = _rfftn(a, geom), _rfftn(b, geom)
+        out = (ha * hb.conj()).real.sum(dim=0) * _multiplicity(geom, a.dtype, a.device)
+        ctx.save_for_backward(a, b)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, c):
+        a, b = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _Convolve.apply(b, c, ctx.geom)
+        if ctx.needs_input_grad[1]:
+            gb = _Convolve.apply(a, c, ctx.geom)
+        return ga, gb, None
+
+
+_TRANSPOSED = {0: 0, 1: 2, 2: 1}
+
+
+class _PairSum(torch.autograd.Function):
+    """mode 0: half list, ``out_i += w x_j`` and ``out_j += w x_i``; 1: full list, ``out_i += w x_j``; 2: its transpose."""
+
+    @staticmethod
+    def forward(ctx, w, x, pairs, mode):
+        wc, xc = w.detach().to(x.dtype).contiguous(), x.detach().contiguous()
+        out = torch.empty_like(xc)
+        with _lib.on_device(xc.device):
+            _lib.check(_lib.load().mipme_pair_sum(_stream(xc), _lib.dtype_code(xc.dtype), _lib.index_code(pairs.dtype),
+                                                  pairs.shape[0], xc.shape[0], xc.shape[1], pairs.data_ptr(), wc.data_ptr(),
+                                                  xc.data_ptr(), mode, out.data_ptr()))
+        ctx.save_for_backward(w, x)
+        ctx.pairs, ctx.mode = pairs, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        pairs, mode = ctx.pairs, ctx.mode
+        gw = gx = None
+        if ctx.needs_input_grad[0]:
+            gw = (_PairDot.apply(x, g, pairs, False) if mode == 2 else _PairDot.apply(g, x, pairs, mode == 0)).to(w.dtype)
+        if ctx.needs_input_grad[1]:
+            gx = _PairSum.apply(w, g, pairs, _TRANSPOSED[mode])
+        return gw, gx, None, None
+
+
+class _PairDot(torch.autograd.Function):
+    """``out_p = a_i . b_j`` (+ ``a_j . b_i`` for a half list)."""
+
+    @staticmethod
+    def forward(ctx, a, b, pairs, half):
+        ac, bc = a.detach().contiguous(), b.detach().contiguous()
+        out = torch.empty((pairs.shape[0],), dtype=ac.dtype, device=ac.device)
+        with _lib.on_device(ac.device):
+            _lib.check(_lib.load().mipme_pair_dot(_stream(ac), _lib.dtype_code(ac.dtype), _lib.index_code(pairs.dtype),
+                                                  pairs.shape[0], ac.shape[1], pairs.data_ptr(), ac.data_ptr(), bc.data_ptr(),
+                                                  1 if half else 0, out.data_ptr()))
+        ctx.save_for_backward(a, b)
+        ctx.pairs, ctx.half = pairs, half
+        return out
+
+    @staticmethod
+    def backward(ctx, c):
+        a, b = ctx.saved_tensors
+        pairs, half = ctx.pairs, ctx.half
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _PairSum.apply(c, b, pairs, 0 if half else 1)
+        if ctx.needs_input_grad[1]:
+            gb = _PairSum.apply(c, a, pairs, 0 if half else 2)
+        return ga, gb, None, None
+
+
+# ---- the composition ---------------------------------------------------------------------------------------------------------
+
+
+def _sinc_pi(y: torch.Tensor) -> torch.Tensor:
+    """sin(y) / y with derivatives of every order finite at y = 0 (``torch.sinc`` differentiates once there; its second
+    derivative is 0/0, which is how the reference's own double backward w.r.t. the cell becomes NaN)."""
+    small = y.abs() < 1e-2
+    y2 = torch.where(small, y * y, torch.zeros_like(y))
+    series = 1 - y2 / 6 * (1 - y2 / 20 * (1 - y2 / 42 * (1 - y2 / 72)))
+    ys = torch.where(small, torch.ones_like(y), y)
+    return torch.where(small, series, torch.sin(ys) / ys)
+
+
+def filter_table(calculator, cell: torch.Tensor, ns) -> torch.Tensor:
+    """G(k) on the rfft half grid as a differentiable function of the cell, in float64: ``kernel_from_k_sq(|k|^2)`` (PME,
+    ``lib/kspace_filter.py:97-120``), divided by the squared Fourier transform of the charge assignment function for P3M
+    (mode 0: ``prod_d sinc(k_d h_d / 2 pi)^(2 n)`` with h_d = |a_d| / n_d, zero where that vanishes; ``:293-329,349-361``)."""
+    c64 = cell.to(torch.float64)
+    k = lib.generate_kvectors_for_mesh(c64, ns)
+    G = calculator.potential.kernel_from_k_sq((k * k).sum(dim=-1))
+    if calculator._scheme == _lib.P3M:
+        nst = torch.tensor([float(n) for n in ns], dtype=torch.float64, device=cell.device)
+        kh = k * (torch.linalg.norm(c64, dim=1) / nst)
+        U2 = torch.prod(_sinc_pi(0.5 * kh), dim=-1) ** (2 * calculator.interpolation_nodes)
+        dead = U2 == 0
+        G = torch.where(dead, torch.zeros_like(G), G / torch.where(dead, torch.ones_like(U2), U2))
+    return G
+
+
+def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_distances, periodic=None, node_mask=None,
+               pair_mask=None, kvectors=None) -> torch.Tensor:
+    """Per-atom potentials ``(n_atoms, n_channels)``: ``Calculator.forward`` of the reference, differentiable to any order."""
+    from ._utils import _validate_parameters
+
+    _validate_parameters(charges=charges, cell=cell, positions=positions, neighbor_indices=neighbor_indices,
+                         neighbor_distances=neighbor_distances, periodic=periodic, pair_mask=pair_mask, node_mask=node_mask,
+                         kvectors=kvectors)
+    _lib.require_device(positions, "positions")
+    pot = calculator.potential
+    if pot.smearing is not None and not hasattr(calculator, "mesh_spacing"):
+        raise NotImplementedError(
+            f'`double_backward = "analytic"` covers the mesh calculators and the plain pair sum; use "finite-difference" for '
+            f"{type(calculator).__name__}")
+    if pot.smearing is not None and (node_mask is not None or kvectors is not None):
+        raise NotImplementedError("Batching not implemented for mesh-based calculators")
+    dtype = charges.dtype
+    pairs = neighbor_indices.contiguous()
+    # ---- real space: _compute_rspace (calculators/calculator.py:43-87)
+    if pot.smearing is None:
+        bare = pot.from_dist(neighbor_distances, pair_mask)
+        if pot.exclusion_radius is not None:
+            bare = bare * (1 - pot.f_cutoff(neighbor_distances, pair_mask))
+    else:
+        bare = pot.sr_from_dist(neighbor_distances, pair_mask)
+    out = _PairSum.apply(bare.to(dtype), charges, pairs, 1 if calculator.full_neighbor_list else 0) / 2
+    if pot.smearing is None:
+        return out
+    # ---- reciprocal space: _compute_kspace (calculators/pme.py:88-143, calculators/p3m.py:45-84)
+    cell_host = cell.detach().to("cpu", torch.float64).numpy()
+    ns = ops.ns_mesh_from_cell(cell_host, calculator.mesh_spacing)
+    geom = ops.MeshGeometry(cell_host, ns, calculator._scheme, calculator.interpolation_nodes)
+    nst = torch.tensor([float(n) for n in ns], dtype=dtype, device=positions.device)
+    u = nst * (positions @ torch.linalg.inv(cell))
+    G = filter_table(calculator, cell, ns).to(dtype)
+    zero = (0, 0, 0)
+    rho = _Spread.apply(u, charges, geom, zero)
+    phi = _Convolve.apply(rho, G, geom)
+    ivolume = torch.abs(torch.det(cell)).pow(-1)
+    lr = _Gather.apply(u, phi, geom, zero) * ivolume
+    lr = lr - charges * pot.self_contribution().to(dtype)
+    lr = lr - 2 * pot.background_correction().to(dtype) * charges.sum(dim=0) * ivolume
+    lr = lr + pot.pbc_correction(periodic, positions, cell, charges).to(dtype)
+    return out + lr / 2

@@ -47,10 +47,13 @@ class Calculator(torch.nn.Module):
         #:   True                 -- right after the call (synchronises, as the reference does);
         #:   False                -- never.
         self.check_nan = "deferred"
-        #: second derivatives (``create_graph=True``: training on forces).  The HIP kernels are first order; ``None`` (default)
-        #: makes a double differentiation raise a RuntimeError that names this attribute, ``"finite-difference"`` routes the
-        #: call through ``ops.second_order_by_finite_differences``: first order exactly as before, the backward of the backward
-        #: from central differences of the analytic gradients (two more evaluations; use float64)
+        #: second derivatives (``create_graph=True``: training on forces).  The fused HIP kernels are first order; ``None``
+        #: (default) makes a double differentiation raise a RuntimeError that names this attribute.  ``"analytic"`` evaluates
+        #: the call through :mod:`analytic` instead -- the same mathematics as a composition of linear primitives whose
+        #: backward passes are made of the same primitives (``csrc/jets.hip``), exact to any order w.r.t. charges, positions,
+        #: cell and distances, as the reference's ATen chain is (mesh calculators and the plain pair sum).
+        #: ``"finite-difference"`` keeps the fused first-order kernels and forms the backward of the backward from central
+        #: differences of their gradients (two more evaluations; use float64; also covers the Ewald calculator)
         self.double_backward = None
         self._nan_flag = None  # pinned int32[1], created on first use
         self._nan_shape = None
@@ -172,8 +175,9 @@ class Calculator(torch.nn.Module):
             return ops.vmap_bridge(self._forward_impl, *args)
         if self.double_backward is not None and torch.is_grad_enabled() and any(
                 isinstance(a, torch.Tensor) and a.requires_grad for a in args):
-            if self.double_backward != "finite-difference":
-                raise ValueError(f"`double_backward` is {self.double_backward!r} but must be None or 'finite-difference'")
+            if self.double_backward not in ("finite-difference", "analytic"):
+                raise ValueError(
+                    f"`double_backward` is {self.double_backward!r} but must be None, 'analytic' or 'finite-difference'")
             charges, cell, positions, pairs, dist, *rest = args
             # the distances are an ordinary differentiable input here (no fused / lazy pair gradient: the chain through
             # `pair_distances` is exact second order by itself)
@@ -181,6 +185,10 @@ class Calculator(torch.nn.Module):
             src = getattr(dist, "_mipme_src", None)
             if src is not None and src.pending:
                 src.materialize()
+            if self.double_backward == "analytic":
+                from . import analytic
+
+                return analytic.potentials(self, charges, cell, positions, pairs, dist, *rest)
 
             def first_order_eval(q, c, p, d, *others):
                 # plain (unfused) evaluation: `d` carries no provenance, so the calculator differentiates w.r.t. it as a tensor

@@ -213,6 +213,35 @@ struct StencilGroup {
   static constexpr int LANES = PLANE <= 1 ? 1 : PLANE <= 4 ? 4 : PLANE <= 16 ? 16 : PLANE <= 32 ? 32 : 64;
 };
 
+// dispatch on (scheme, order) to compile-time S, N (mesh.hip, jets.hip)
+#define MIPME_DISPATCH_STENCIL(SCHEME_V, ORDER_V, BODY)                                   \
+  do {                                                                                    \
+    bool _done = true;                                                                    \
+    if ((SCHEME_V) == MIPME_P3M) {                                                        \
+      switch (ORDER_V) {                                                                  \
+        case 1: { constexpr int S = MIPME_P3M, N = 1; BODY; } break;                      \
+        case 2: { constexpr int S = MIPME_P3M, N = 2; BODY; } break;                      \
+        case 3: { constexpr int S = MIPME_P3M, N = 3; BODY; } break;                      \
+        case 4: { constexpr int S = MIPME_P3M, N = 4; BODY; } break;                      \
+        case 5: { constexpr int S = MIPME_P3M, N = 5; BODY; } break;                      \
+        default: _done = false;                                                           \
+      }                                                                                   \
+    } else {                                                                              \
+      switch (ORDER_V) {                                                                  \
+        case 3: { constexpr int S = MIPME_LAGRANGE, N = 3; BODY; } break;                 \
+        case 4: { constexpr int S = MIPME_LAGRANGE, N = 4; BODY; } break;                 \
+        case 5: { constexpr int S = MIPME_LAGRANGE, N = 5; BODY; } break;                 \
+        case 6: { constexpr int S = MIPME_LAGRANGE, N = 6; BODY; } break;                 \
+        case 7: { constexpr int S = MIPME_LAGRANGE, N = 7; BODY; } break;                 \
+        default: _done = false;                                                           \
+      }                                                                                   \
+    }                                                                                     \
+    if (!_done) {                                                                         \
+      set_error("unsupported scheme/order %d/%d", int(SCHEME_V), int(ORDER_V));           \
+      return MIPME_EINVAL;                                                                \
+    }                                                                                     \
+  } while (0)
+
 // Host-side description of the gather's tail (energy + force assembly in the gather launch, csrc/bricks.hip GatherTail)
 struct GatherTailHost {
   const void* force;   // (N,3) pair force sums

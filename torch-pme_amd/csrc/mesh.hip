@@ -199,34 +199,6 @@ static inline unsigned blocks_for(int64_t n_atoms) {
   return unsigned((n_atoms + APB - 1) / APB);
 }
 
-#define MIPME_DISPATCH_STENCIL(SCHEME_V, ORDER_V, BODY)                                   \
-  do {                                                                                    \
-    bool _done = true;                                                                    \
-    if ((SCHEME_V) == MIPME_P3M) {                                                        \
-      switch (ORDER_V) {                                                                  \
-        case 1: { constexpr int S = MIPME_P3M, N = 1; BODY; } break;                      \
-        case 2: { constexpr int S = MIPME_P3M, N = 2; BODY; } break;                      \
-        case 3: { constexpr int S = MIPME_P3M, N = 3; BODY; } break;                      \
-        case 4: { constexpr int S = MIPME_P3M, N = 4; BODY; } break;                      \
-        case 5: { constexpr int S = MIPME_P3M, N = 5; BODY; } break;                      \
-        default: _done = false;                                                           \
-      }                                                                                   \
-    } else {                                                                              \
-      switch (ORDER_V) {                                                                  \
-        case 3: { constexpr int S = MIPME_LAGRANGE, N = 3; BODY; } break;                 \
-        case 4: { constexpr int S = MIPME_LAGRANGE, N = 4; BODY; } break;                 \
-        case 5: { constexpr int S = MIPME_LAGRANGE, N = 5; BODY; } break;                 \
-        case 6: { constexpr int S = MIPME_LAGRANGE, N = 6; BODY; } break;                 \
-        case 7: { constexpr int S = MIPME_LAGRANGE, N = 7; BODY; } break;                 \
-        default: _done = false;                                                           \
-      }                                                                                   \
-    }                                                                                     \
-    if (!_done) {                                                                         \
-      set_error("unsupported scheme/order %d/%d", int(SCHEME_V), int(ORDER_V));           \
-      return MIPME_EINVAL;                                                                \
-    }                                                                                     \
-  } while (0)
-
 template <typename T>
 int spread_impl(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, const void* val, double scale,
                 void* mesh) {

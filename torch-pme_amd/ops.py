@@ -26,9 +26,11 @@ from . import _front, _lib
 
 SECOND_ORDER_HINT = (
     "torchpme_amd: the HIP kernels provide FIRST-order gradients; this graph is being differentiated twice (create_graph=True, "
-    "e.g. a loss on forces).  Set `calculator.double_backward = \"finite-difference\"` before the forward call: the second "
-    "derivative is then formed from central differences of the analytic first-order gradients (two more evaluations per "
-    "double-backward pass; use float64), and distances from `pair_distances` differentiate twice exactly.")
+    "e.g. a loss on forces).  Set `calculator.double_backward = \"analytic\"` before the forward call (mesh calculators: the "
+    "call is evaluated through differentiable primitives, exact to any order), or `calculator.double_backward = "
+    "\"finite-difference\"`: the second derivative is then formed from central differences of the analytic first-order "
+    "gradients (two more evaluations per double-backward pass; use float64).  Distances from `pair_distances` differentiate "
+    "twice exactly either way.")
 
 
 def first_order(fn):

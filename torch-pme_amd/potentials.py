@@ -264,6 +264,26 @@ class _PowerLawPotential(Potential):
         return self.prefactor * math.pi**1.5 * (2 * self.smearing**2) ** (0.5 * (3 - p)) / ((3 - p) * math.gamma(0.5 * p))
 
 
+    def pbc_correction(self, periodic, positions, cell, charges):
+        """2-D slab term (reference ``potentials/coulomb.py:6-40,160-167``), non-zero when exactly two of ``periodic`` are
+        True: ``(4 pi / V) (z_i M - (M2 + Q z_i^2) / 2 - Q L_z^2 / 12)`` with z along the non-periodic axis, Q, M, M2 the
+        zeroth / first / second moments of the charges along it and L_z the length of that cell vector.  (The calculators
+        evaluate the same expression in ``mipme_slab_forward``; this method is the inspectable tensor form.)"""
+        if self._p != 1:  # the slab term exists for 1/r only (`potentials/inversepowerlaw.py:166-169`)
+            return self.prefactor * torch.zeros_like(charges)
+        if periodic is None:
+            periodic = torch.ones(3, dtype=torch.bool, device=charges.device)
+        flags = [bool(v) for v in periodic.tolist()]
+        if sum(flags) != 2:
+            return self.prefactor * torch.zeros_like(charges)
+        axis = flags.index(False)
+        z = positions[:, axis : axis + 1]
+        volume = torch.abs(torch.det(cell))
+        Lz = torch.linalg.norm(cell[axis])
+        Q, M, M2 = charges.sum(dim=0), (charges * z).sum(dim=0), (charges * z * z).sum(dim=0)
+        return self.prefactor * (4 * math.pi / volume) * (z * M - 0.5 * (M2 + Q * z * z) - Q / 12.0 * Lz * Lz)
+
+
 class InversePowerLawPotential(_PowerLawPotential):
     """1/r^p potential, p in 1..6 (reference ``potentials/inversepowerlaw.py:9-173``)."""
 
@@ -289,23 +309,6 @@ class CoulombPotential(_PowerLawPotential):
 
     _kind = _lib.COULOMB
     _p = 1
-
-    def pbc_correction(self, periodic, positions, cell, charges):
-        """2-D slab term (reference ``potentials/coulomb.py:6-40,160-167``), non-zero when exactly two of ``periodic`` are
-        True: ``(4 pi / V) (z_i M - (M2 + Q z_i^2) / 2 - Q L_z^2 / 12)`` with z along the non-periodic axis, Q, M, M2 the
-        zeroth / first / second moments of the charges along it and L_z the length of that cell vector.  (The calculators
-        evaluate the same expression in ``mipme_slab_forward``; this method is the inspectable tensor form.)"""
-        if periodic is None:
-            periodic = torch.ones(3, dtype=torch.bool, device=charges.device)
-        flags = [bool(v) for v in periodic.tolist()]
-        if sum(flags) != 2:
-            return self.prefactor * torch.zeros_like(charges)
-        axis = flags.index(False)
-        z = positions[:, axis : axis + 1]
-        volume = torch.abs(torch.det(cell))
-        Lz = torch.linalg.norm(cell[axis])
-        Q, M, M2 = charges.sum(dim=0), (charges * z).sum(dim=0), (charges * z * z).sum(dim=0)
-        return self.prefactor * (4 * math.pi / volume) * (z * M - 0.5 * (M2 + Q * z * z) - Q / 12.0 * Lz * Lz)
 
     def __init__(
         self,
