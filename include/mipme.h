@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 403
+#define MIPME_VERSION 404
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -124,6 +124,10 @@ int mipme_gather_jet(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t 
  * adjoint of mode 1).  Zeroes `out` (n_atoms, C) first. */
 int mipme_pair_sum(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels, const void* pairs,
                    const void* weights, const void* x, int mode, void* out);
+/* The same sum from the transposed list of mipme_topology_build (row_ptr int32[2N+1], entries int32[2P][2]): owner-computes
+ * rows, no atomics, fixed summation order.  weights (P) stay indexed by pair. */
+int mipme_pair_sum_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, const void* row_ptr, const void* entries,
+                        const void* weights, const void* x, int mode, void* out);
 /* out[p] = sum_c a[i_p,c] b[j_p,c] (+ a[j_p,c] b[i_p,c] when half != 0): the adjoint of mipme_pair_sum w.r.t. its weights. */
 int mipme_pair_dot(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* a,
                    const void* b, int half, void* out);

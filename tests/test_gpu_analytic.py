@@ -208,6 +208,32 @@ def test_pair_primitives_gradcheck(mode):
     assert relmax(analytic._PairSum.apply(w, x, pairs, mode).detach().cpu(), ref.cpu()) < 1e-14
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_pair_sum_through_the_transposed_list(dtype, monkeypatch):
+    """The owner-computes rows (lists of ROWS_MIN_PAIRS pairs and more) against the atomic kernel and ``index_add_``, all three
+    modes, two channels, int64 and int32 indices, atoms without any pair."""
+    rng = np.random.default_rng(3)
+    n_atoms, n_pairs, n_ch = 700, 9000, 2
+    ij = rng.integers(0, n_atoms - 20, (n_pairs, 2))  # the last twenty atoms have empty rows
+    w = torch.tensor(rng.normal(size=n_pairs), device=DEV, dtype=dtype)
+    x = torch.tensor(rng.normal(size=(n_atoms, n_ch)), device=DEV, dtype=dtype)
+    tol = 1e-13 if dtype == torch.float64 else 2e-5
+    for idx_dtype in (torch.int64, torch.int32):
+        pairs = torch.tensor(ij, device=DEV, dtype=idx_dtype)
+        i, j = pairs[:, 0].long(), pairs[:, 1].long()
+        for mode in (0, 1, 2):
+            ref = torch.zeros_like(x)
+            if mode != 2:
+                ref.index_add_(0, i, x[j] * w[:, None])
+            if mode != 1:
+                ref.index_add_(0, j, x[i] * w[:, None])
+            monkeypatch.setattr(analytic, "ROWS", True)
+            rows = analytic._PairSum.apply(w, x, pairs, mode)
+            monkeypatch.setattr(analytic, "ROWS", False)
+            atom = analytic._PairSum.apply(w, x, pairs, mode)
+            assert relmax(rows.cpu(), ref.cpu()) < tol and relmax(atom.cpu(), ref.cpu()) < tol
+
+
 # ---- a training-shaped use: loss on forces, learned charges -----------------------------------------------------------------
 
 

@@ -32,6 +32,9 @@ import torch
 from . import _lib, lib, ops
 
 _MAX_ORDER = 3
+#: pair sums through the transposed list (no atomics) for lists of at least ROWS_MIN_PAIRS pairs; False: the atomic kernel
+ROWS = True
+ROWS_MIN_PAIRS = 4096
 
 
 def _bump(k, d):
@@ -187,10 +190,19 @@ class _PairSum(torch.autograd.Function):
     def forward(ctx, w, x, pairs, mode):
         wc, xc = w.detach().to(x.dtype).contiguous(), x.detach().contiguous()
         out = torch.empty_like(xc)
+        lib = _lib.load()
         with _lib.on_device(xc.device):
-            _lib.check(_lib.load().mipme_pair_sum(_stream(xc), _lib.dtype_code(xc.dtype), _lib.index_code(pairs.dtype),
-                                                  pairs.shape[0], xc.shape[0], xc.shape[1], pairs.data_ptr(), wc.data_ptr(),
-                                                  xc.data_ptr(), mode, out.data_ptr()))
+            if ROWS and pairs.shape[0] >= ROWS_MIN_PAIRS and getattr(pairs, "_mipme_stream", None) is None:
+                # the transposed list of this tensor (built once, cached on its identity: ops.get_topology; no bets outside a
+                # betting scope): owner-computes rows instead of atomics
+                topo = ops.get_topology(pairs, xc.shape[0])
+                _lib.check(lib.mipme_pair_sum_rows(_stream(xc), _lib.dtype_code(xc.dtype), xc.shape[0], xc.shape[1],
+                                                   topo.row_ptr.data_ptr(), topo.entries.data_ptr(), wc.data_ptr(),
+                                                   xc.data_ptr(), mode, out.data_ptr()))
+            else:
+                _lib.check(lib.mipme_pair_sum(_stream(xc), _lib.dtype_code(xc.dtype), _lib.index_code(pairs.dtype),
+                                              pairs.shape[0], xc.shape[0], xc.shape[1], pairs.data_ptr(), wc.data_ptr(),
+                                              xc.data_ptr(), mode, out.data_ptr()))
         ctx.save_for_backward(w, x)
         ctx.pairs, ctx.mode = pairs, mode
         return out
@@ -286,6 +298,13 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
         bare = pot.from_dist(neighbor_distances, pair_mask)
         if pot.exclusion_radius is not None:
             bare = bare * (1 - pot.f_cutoff(neighbor_distances, pair_mask))
+    elif pot._exponent_int() == 1 and pot.exclusion_radius is None:
+        # 1/r - erf(r / sigma sqrt 2) / r in one piece (potentials/coulomb.py:98-120): four elementwise operations on the pair
+        # list instead of the generic incomplete-gamma expressions' eighty, each of which autograd keeps a (P,) tensor for
+        bare = pot.prefactor.to(neighbor_distances.device) * torch.erfc(
+            neighbor_distances / (pot.smearing.to(neighbor_distances.device) * 2.0**0.5)) / neighbor_distances
+        if pair_mask is not None:
+            bare = bare * pair_mask
     else:
         bare = pot.sr_from_dist(neighbor_distances, pair_mask)
     out = _PairSum.apply(bare.to(dtype), charges, pairs, 1 if calculator.full_neighbor_list else 0) / 2

@@ -172,6 +172,32 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(int64_t P, int C, const I
   }
 }
 
+// The same sum from the transposed list (topology.hip: row_ptr[2a], [2a+1], [2a+2] bound atom a's role-i and role-j entries
+// {other atom, pair index}): 16 lanes per atom, no atomics, a fixed summation order -- the atomic version above spends 0.6 ms
+// on the 4.76 M pairs of the 32k-atom water box (300 updates per address), this one streams the entries once.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_sum_rows_kernel(int64_t N, int C, const int* __restrict__ row_ptr,
+                                                           const int2* __restrict__ entries, const T* __restrict__ w,
+                                                           const T* __restrict__ x, int mode, T* __restrict__ out) {
+  constexpr int LANES = 16;
+  const int sub = threadIdx.x % LANES;
+  int64_t a = int64_t(blockIdx.x) * (256 / LANES) + threadIdx.x / LANES;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;
+  const int begin = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = row_ptr[2 * a + 2];
+  const int lo = mode == 2 ? mid : begin, hi = mode == 1 ? mid : end;
+  for (int c = 0; c < C; ++c) {
+    T acc = T(0);
+    for (int e = lo + sub; e < hi; e += LANES) {
+      const int2 en = entries[e];
+      acc += w[en.y] * x[int64_t(en.x) * C + c];
+    }
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, LANES);
+    if (sub == 0 && valid) out[a * C + c] = acc;
+  }
+}
+
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void pair_dot_kernel(int64_t P, int C, const I* __restrict__ pairs, const T* __restrict__ a,
                                                       const T* __restrict__ b, int half, T* __restrict__ out) {
@@ -221,6 +247,16 @@ static int pair_sum_impl(hipStream_t st, int64_t P, int64_t N, int C, const void
   MIPME_CHECK_HIP(zero_async(out, sizeof(T) * size_t(N) * C, st));
   if (P == 0) return MIPME_OK;
   pair_sum_kernel<T, I><<<unsigned((P + 255) / 256), 256, 0, st>>>(P, C, (const I*)pairs, (const T*)w, (const T*)x, mode, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T>
+static int pair_sum_rows_impl(hipStream_t st, int64_t N, int C, const void* row_ptr, const void* entries, const void* w,
+                              const void* x, int mode, void* out) {
+  if (N == 0) return MIPME_OK;
+  pair_sum_rows_kernel<T><<<unsigned((N + 15) / 16), 256, 0, st>>>(N, C, (const int*)row_ptr, (const int2*)entries, (const T*)w,
+                                                                  (const T*)x, mode, (T*)out);
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -282,6 +318,17 @@ int mipme_pair_sum(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int6
                                   : pair_sum_impl<float, int32_t>(st, n_pairs, n_atoms, n_channels, pairs, weights, x, mode, out);
   return idx_dtype == MIPME_I64 ? pair_sum_impl<double, int64_t>(st, n_pairs, n_atoms, n_channels, pairs, weights, x, mode, out)
                                 : pair_sum_impl<double, int32_t>(st, n_pairs, n_atoms, n_channels, pairs, weights, x, mode, out);
+}
+
+int mipme_pair_sum_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, const void* row_ptr, const void* entries,
+                        const void* weights, const void* x, int mode, void* out) {
+  MIPME_REQUIRE(n_atoms >= 0 && n_channels > 0 && mode >= 0 && mode <= 2, "invalid argument of mipme_pair_sum_rows");
+  MIPME_REQUIRE(n_atoms == 0 || (row_ptr && entries && weights && x && out), "NULL buffer passed to mipme_pair_sum_rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32) return pair_sum_rows_impl<float>(st, n_atoms, n_channels, row_ptr, entries, weights, x, mode, out);
+  if (dtype == MIPME_F64) return pair_sum_rows_impl<double>(st, n_atoms, n_channels, row_ptr, entries, weights, x, mode, out);
+  set_error("invalid dtype %d", dtype);
+  return MIPME_EINVAL;
 }
 
 int mipme_pair_dot(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* a,
