@@ -16,7 +16,8 @@ the variable of the second differentiation only (``H_cell``: the stress of a for
 the torch oracle in tests/test_gpu_analytic.py.)
 
 and, for three cases, one more level: ``T = d<w3, H_q> / dq`` with ``H_q`` formed with create_graph=True (third order).  Only
-data are written (``second_order.npz``): inputs come from ref_small.npz, outputs are arrays.
+data are written (``second_order.npz``): inputs come from ref_small.npz, outputs are arrays.  The same G, L, H for every
+``EwaldCalculator`` case of ``ref_ewald.npz`` (keys ``e..``).
 """
 
 import ast
@@ -72,7 +73,32 @@ def main():
             out[f"{nm}/w3"] = w3.numpy()
             for key, val in zip(("T_charges", "T_positions", "T_g"), T):
                 out[f"{nm}/{key}"] = val.numpy()
-    bad = [k for k, v in out.items() if k != "names" and not np.isfinite(v).all()]
+    # ---- the explicit Ewald sum: every case of ref_ewald.npz, same quantities (prefix e..)
+    ze = np.load(os.path.join(HERE, "ref_ewald.npz"))
+    out["ewald_names"] = ze["names"]
+    for nm in (str(n) for n in ze["names"]):
+        meta = ast.literal_eval(str(ze[f"{nm}/meta"]))
+        pot = (torchpme.CoulombPotential(smearing=meta["smearing"], prefactor=meta["prefactor"]) if meta["kind"] == "coulomb"
+               else torchpme.InversePowerLawPotential(exponent=meta["exponent"], smearing=meta["smearing"],
+                                                      prefactor=meta["prefactor"]))
+        calc = torchpme.EwaldCalculator(pot, lr_wavelength=meta["lr_wavelength"], full_neighbor_list=meta["full_list"])
+        t = lambda key: torch.tensor(ze[f"{nm}/{key}"], dtype=torch.float64, requires_grad=True)  # noqa: E731
+        q, pos, d, g = t("charges"), t("positions"), t("dist"), t("g")
+        cell = torch.tensor(ze["cell"], dtype=torch.float64, requires_grad=True)
+        per = None if meta["periodic"] is None else torch.tensor(meta["periodic"])
+        kv = torch.tensor(ze[f"{nm}/kvectors"]) if meta["own_kvectors"] else None
+        mask = torch.tensor(ze[f"{nm}/node_mask"]) if meta["node_mask"] else None
+        V = calc(q, cell, pos, torch.tensor(ze[f"{nm}/pairs"]), d, periodic=per, kvectors=kv, node_mask=mask)
+        G = torch.autograd.grad((V * g).sum(), (q, pos, d), create_graph=True)
+        w = [torch.tensor(rng.normal(size=tuple(x.shape))) for x in G]
+        L = sum((wk * Gk).sum() for wk, Gk in zip(w, G))
+        H = torch.autograd.grad(L, (q, cell, pos, d, g), allow_unused=True)
+        H = [torch.zeros_like(x) if h is None else h for h, x in zip(H, (q, cell, pos, d, g))]
+        for key, val in zip(("w_charges", "w_positions", "w_dist"), w):
+            out[f"{nm}/{key}"] = val.numpy()
+        for key, val in zip(("H_charges", "H_cell", "H_positions", "H_dist", "H_g"), H):
+            out[f"{nm}/{key}"] = val.detach().numpy()
+    bad = [k for k, v in out.items() if k not in ("names", "ewald_names") and not np.isfinite(v).all()]
     assert not bad, bad
     np.savez(os.path.join(HERE, "second_order.npz"), **out)
     print("second_order.npz:", len(out), "arrays")

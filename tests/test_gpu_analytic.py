@@ -97,6 +97,41 @@ def test_third_order_against_the_reference(golden_dir):
     assert n == 3
 
 
+def _ewald_case(ze, nm):
+    meta = ast.literal_eval(str(ze[f"{nm}/meta"]))
+    pot = (tpa.CoulombPotential(smearing=meta["smearing"], prefactor=meta["prefactor"]) if meta["kind"] == "coulomb"
+           else tpa.InversePowerLawPotential(exponent=meta["exponent"], smearing=meta["smearing"], prefactor=meta["prefactor"]))
+    calc = tpa.EwaldCalculator(pot, lr_wavelength=meta["lr_wavelength"], full_neighbor_list=meta["full_list"])
+    calc.double_backward = "analytic"
+    t = lambda k, grad=True: torch.tensor(ze[f"{nm}/{k}"], device=DEV, requires_grad=grad)  # noqa: E731
+    kw = dict(periodic=None if meta["periodic"] is None else torch.tensor(meta["periodic"], device=DEV),
+              kvectors=t("kvectors", False) if meta["own_kvectors"] else None,
+              node_mask=t("node_mask", False) if meta["node_mask"] else None)
+    cell = torch.tensor(ze["cell"], device=DEV, requires_grad=True)
+    return meta, calc, t("charges"), cell, t("positions"), t("pairs", False), t("dist"), t("g"), kw
+
+
+def test_ewald_first_and_second_order_against_the_reference(golden_dir):
+    """EwaldCalculator through the analytic route: V, the four gradients and every Hessian-vector block the reference can form,
+    for every case of ref_ewald.npz (Coulomb / 1/r^p, channels, slab, own k-vectors, node mask, full list)."""
+    ze, s = np.load(f"{golden_dir}/ref_ewald.npz"), np.load(f"{golden_dir}/second_order.npz")
+    for nm in (str(n) for n in ze["names"]):
+        meta, calc, q, cell, pos, pairs, d, g, kw = _ewald_case(ze, nm)
+        V = calc(q, cell, pos, pairs, d, **kw)
+        assert relmax(V.detach().cpu(), ze[f"{nm}/V"]) < 1e-9, (nm, meta)
+        S = (V * g).sum()
+        first = torch.autograd.grad(S, (q, pos, cell, d), retain_graph=True)
+        for key, got in zip(("charges", "positions", "cell", "dist"), first):
+            assert relmax(got.cpu(), ze[f"{nm}/grad_{key}"]) < 1e-9, (nm, meta, key)
+        G = torch.autograd.grad(S, (q, pos, d), create_graph=True)
+        w = [torch.tensor(s[f"{nm}/w_{k}"], device=DEV) for k in ("charges", "positions", "dist")]
+        H = torch.autograd.grad(sum((wk * Gk).sum() for wk, Gk in zip(w, G)), (q, cell, pos, d, g), allow_unused=True)
+        for key, h, x in zip(("charges", "cell", "positions", "dist", "g"), H, (q, cell, pos, d, g)):
+            ref = s[f"{nm}/H_{key}"]
+            got = np.zeros_like(ref) if h is None else h.cpu().numpy()
+            assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max() + 1e-12, (nm, meta, key)
+
+
 @pytest.mark.parametrize("nm", ["c03", "c06", "c11", "c16", "c22", "c25"])
 def test_cell_cell_block_against_differences_of_the_fused_gradients(golden_dir, nm):
     """The block the reference cannot form (NaN): H = d<w, dS/dcell>/dz.  By the symmetry of mixed partials H_z is the
@@ -319,14 +354,15 @@ def test_analytic_and_fused_paths_agree_at_first_order():
             assert relmax(y, x) < 1e-11
 
 
-def test_unsupported_calculators_say_so():
+def test_unsupported_options_say_so():
     calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=1.5)
-    calc.double_backward = "analytic"
     t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float64)  # noqa: E731
     pos = t(np.random.default_rng(0).uniform(0, 4, (5, 3))).requires_grad_(True)
     pairs = torch.tensor([[0, 1], [1, 2], [2, 3], [3, 4]], device=DEV)
-    with pytest.raises(NotImplementedError, match="finite-difference"):
-        calc(t(np.ones((5, 1))), t(4 * np.eye(3)), pos, pairs, t(np.ones(4)))
     calc.double_backward = "exact"
     with pytest.raises(ValueError, match="'analytic' or 'finite-difference'"):
         calc(t(np.ones((5, 1))), t(4 * np.eye(3)), pos, pairs, t(np.ones(4)))
+    mesh = tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0)
+    mesh.double_backward = "analytic"
+    with pytest.raises(NotImplementedError, match="Batching not implemented for mesh-based calculators"):
+        mesh(t(np.ones((5, 1))), t(4 * np.eye(3)), pos, pairs, t(np.ones(4)), node_mask=torch.ones(5, device=DEV, dtype=torch.bool))

@@ -19,8 +19,8 @@ differentiates the composition as often as it is asked to, w.r.t. charges, posit
 The interpolation weights are piecewise polynomials of degree ``interpolation_nodes - 1``; the kernels provide their derivatives
 up to third order per axis (enough for a double backward of a force loss and one order to spare), beyond that a call raises.
 Cost: a dozen launches per evaluation instead of six, atomics in the spread and the pair sum -- this is the route for training
-on forces and for Hessians, not for molecular dynamics.  Mesh calculators (PME, P3M) and the plain pair sum; for the explicit
-Ewald sum use ``double_backward = "finite-difference"``.
+on forces and for Hessians, not for molecular dynamics.  Mesh calculators (PME, P3M), the plain pair sum, and the explicit Ewald
+sum -- whose reciprocal part is written here as the reference writes it, (K, N) phase tables in tensor expressions.
 """
 
 from __future__ import annotations
@@ -285,12 +285,15 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
                          kvectors=kvectors)
     _lib.require_device(positions, "positions")
     pot = calculator.potential
-    if pot.smearing is not None and not hasattr(calculator, "mesh_spacing"):
+    is_ewald = hasattr(calculator, "lr_wavelength")
+    if pot.smearing is not None and not is_ewald and not hasattr(calculator, "mesh_spacing"):
         raise NotImplementedError(
-            f'`double_backward = "analytic"` covers the mesh calculators and the plain pair sum; use "finite-difference" for '
-            f"{type(calculator).__name__}")
-    if pot.smearing is not None and (node_mask is not None or kvectors is not None):
+            f'`double_backward = "analytic"` covers the Ewald and mesh calculators and the plain pair sum; use '
+            f'"finite-difference" for {type(calculator).__name__}')
+    if pot.smearing is not None and not is_ewald and (node_mask is not None or kvectors is not None):
         raise NotImplementedError("Batching not implemented for mesh-based calculators")
+    if charges.dim() != 2:
+        raise NotImplementedError('padded batches are not served by `double_backward = "analytic"`')
     dtype = charges.dtype
     pairs = neighbor_indices.contiguous()
     # ---- real space: _compute_rspace (calculators/calculator.py:43-87)
@@ -310,7 +313,39 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
     out = _PairSum.apply(bare.to(dtype), charges, pairs, 1 if calculator.full_neighbor_list else 0) / 2
     if pot.smearing is None:
         return out
-    # ---- reciprocal space: _compute_kspace (calculators/pme.py:88-143, calculators/p3m.py:45-84)
+    ivolume = torch.abs(torch.det(cell)).pow(-1)
+    if is_ewald:
+        # ---- explicit Ewald sum (calculators/ewald.py:72-142): k = 2 pi F A^-T from the cell, the (K, N) phase tables as
+        # tensor expressions, K in slabs (this is the reference's own formulation; the fused route is csrc/ewald.hip)
+        if kvectors is None:
+            kvectors = (2 * torch.pi) * calculator._frequencies(cell) @ torch.linalg.inv(cell).T
+        lr = _ewald_kspace(pot, charges, positions, kvectors) * ivolume
+    else:
+        lr = _mesh_kspace(calculator, charges, cell, positions) * ivolume
+    lr = lr - charges * pot.self_contribution().to(dtype)
+    lr = lr - 2 * pot.background_correction().to(dtype) * charges.sum(dim=0) * ivolume
+    lr = lr + pot.pbc_correction(periodic, positions, cell, charges).to(dtype)
+    if node_mask is not None:
+        lr = lr * node_mask.unsqueeze(-1)
+    return out + lr / 2
+
+
+def _ewald_kspace(pot, charges, positions, kvectors) -> torch.Tensor:
+    """``sum_k G(k) [cos(k r_i) sum_j q_j cos(k r_j) + sin(k r_i) sum_j q_j sin(k r_j)]`` (before the 1 / V)."""
+    G = pot.lr_from_k_sq((kvectors * kvectors).sum(dim=-1)).to(charges.dtype)
+    n_k, n = kvectors.shape[0], positions.shape[0]
+    step = max(1, (1 << 24) // max(1, n))
+    acc = torch.zeros_like(charges)
+    for a in range(0, n_k, step):
+        theta = kvectors[a:a + step] @ positions.T
+        c, s, g = torch.cos(theta), torch.sin(theta), G[a:a + step, None]
+        acc = acc + c.T @ ((c @ charges) * g) + s.T @ ((s @ charges) * g)
+    return acc
+
+
+def _mesh_kspace(calculator, charges, cell, positions) -> torch.Tensor:
+    """``mesh_to_points(filter(points_to_mesh(charges)))`` (before the 1 / V): calculators/pme.py:88-113."""
+    dtype = charges.dtype
     cell_host = cell.detach().to("cpu", torch.float64).numpy()
     ns = ops.ns_mesh_from_cell(cell_host, calculator.mesh_spacing)
     geom = ops.MeshGeometry(cell_host, ns, calculator._scheme, calculator.interpolation_nodes)
@@ -320,9 +355,4 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
     zero = (0, 0, 0)
     rho = _Spread.apply(u, charges, geom, zero)
     phi = _Convolve.apply(rho, G, geom)
-    ivolume = torch.abs(torch.det(cell)).pow(-1)
-    lr = _Gather.apply(u, phi, geom, zero) * ivolume
-    lr = lr - charges * pot.self_contribution().to(dtype)
-    lr = lr - 2 * pot.background_correction().to(dtype) * charges.sum(dim=0) * ivolume
-    lr = lr + pot.pbc_correction(periodic, positions, cell, charges).to(dtype)
-    return out + lr / 2
+    return _Gather.apply(u, phi, geom, zero)
