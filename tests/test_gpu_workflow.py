@@ -396,8 +396,9 @@ def test_torchscript_and_opcheck(name, tmp_path):
     path = str(tmp_path / "calc.pt")
     scripted.save(path)
     loaded = torch.jit.load(path)
+    direct = torch.jit.script(calc)  # the reference's spelling (the __prepare_scriptable__ hook)
     res = []
-    for module in (calc, scripted, loaded):
+    for module in (calc, scripted, loaded, direct):
         tp = t(pos).requires_grad_(True)
         tq = q.clone().requires_grad_(True)
         d = tpa.pair_distances(tp, ti, tc, tS)

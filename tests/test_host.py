@@ -297,6 +297,10 @@ def test_dispatcher_ops_and_specs(tmp_path):
         scripted = torch.jit.script(calc.scriptable())
         scripted.save(str(tmp_path / "c.pt"))
         assert torch.jit.load(str(tmp_path / "c.pt")).spec == spec
+        # and the reference's spelling, torch.jit.script(calculator) (tests/calculators/test_workflow.py:136-162), through the
+        # __prepare_scriptable__ hook
+        direct = torch.jit.script(calc)
+        assert isinstance(direct, torch.jit.ScriptModule) and direct.spec == spec
     with FakeTensorMode():
         q, cell, pos = torch.empty((7, 2), device="cuda"), torch.empty((3, 3), device="cuda"), torch.empty((7, 3), device="cuda")
         pairs, shifts = torch.empty((11, 2), dtype=torch.int64, device="cuda"), torch.empty((11, 3), device="cuda")

@@ -143,6 +143,11 @@ class Calculator(torch.nn.Module):
             raise TypeError(f"{type(self).__name__} with a {type(self.potential).__name__} has no dispatcher op")
         return library.ScriptableCalculator(spec)
 
+    def __prepare_scriptable__(self):
+        """``torch.jit.script(calculator)`` -- what the reference's users write (``tests/calculators/test_workflow.py:136-162``)
+        -- scripts :meth:`scriptable`'s module: TorchScript asks a module for its scriptable stand-in through this hook."""
+        return self.scriptable()
+
     def forward(
         self,
         charges: torch.Tensor,
