@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
     ap.add_argument("--no-frames-block", action="store_true", help="skip the `frames` block (2 / 4 / 8 frames in flight on one GPU)")
+    ap.add_argument("--no-second-order", action="store_true",
+                    help="skip the `second_order` block (one force-loss training step through the analytic route)")
     ap.add_argument("--no-contract", action="store_true",
                     help="skip the `contract` block (E+F, +dE/dq, +dE/dcell as graphs and eagerly; the TuningTimings protocol)")
     ap.add_argument("--store-distances", action="store_true",
@@ -667,6 +669,45 @@ def frames_timing(workload: str, device, counts=(2, 4, 8), n_steps: int = 100):
     return out
 
 
+def second_order_timing(frame, n_steps: int = 5, n_warm: int = 2):
+    """Secondary block: what exact second derivatives cost (`calculator.double_backward = "analytic"`, the route through
+    differentiable primitives; the reference differentiates its ATen chain to any order, calculators/calculator.py:43-87,
+    103-189).  One training step of a loss on forces with learned charges: q = theta q0, E = sum q V, F = -dE/dr with
+    create_graph=True, loss = sum F^2, loss.backward() to theta.  E is quadratic in theta, so d loss / d theta = 4 loss at
+    theta = 1 exactly: the relative deviation from that is reported next to the time."""
+    tpa = frame._tpa
+    calc = type(frame.calc)(frame.calc.potential, mesh_spacing=frame.w.mesh_spacing, interpolation_nodes=frame.w.order)
+    calc.double_backward = "analytic"
+    theta = torch.ones((), dtype=frame.dtype, device=frame.q.device, requires_grad=True)
+    pos = frame.pos.detach().clone().requires_grad_(True)
+
+    def energy():
+        q = frame.q * theta
+        d = tpa.pair_distances(pos, frame.pairs, frame.cell, frame.shifts)
+        return (q * calc(q, frame.cell, pos, frame.pairs, d)).sum()
+
+    def forces_only():
+        return torch.autograd.grad(energy(), pos)[0]
+
+    def train_step():
+        theta.grad = None
+        (g,) = torch.autograd.grad(energy(), pos, create_graph=True)
+        loss = (g * g).sum()
+        loss.backward(inputs=[theta])
+        return loss.detach()
+
+    out = {"route": 'double_backward = "analytic" (torch-pme_amd/analytic.py, csrc/jets.hip)',
+           "workload": "loss = sum F^2, F = -dE/dr (create_graph), charges = theta * q0; backward to theta"}
+    out["energy_forces_ms"] = round(_host_loop_ms(forces_only, n_steps, n_warm)[0], 4)
+    torch.cuda.reset_peak_memory_stats()
+    out["force_loss_step_ms"] = round(_host_loop_ms(train_step, n_steps, n_warm)[0], 4)
+    out["peak_allocated_GB"] = round(torch.cuda.max_memory_allocated() / 2**30, 2)
+    loss = float(train_step())
+    out["loss"] = loss
+    out["dloss_dtheta_rel_dev_from_4_loss"] = abs(float(theta.grad) - 4.0 * loss) / (4.0 * loss)
+    return out
+
+
 def oracle_accuracy(w, name, E32, F32, E64=None, F64=None):
     """The timed dtype's energy and forces (and the fp64 path's) against the PINNED ORACLE's numbers for this very box, committed
     as tests/golden/workloads.npz by tests/golden/make_workloads_golden.py (oracle/pme_numpy.py in fp64; itself pinned to the
@@ -1192,6 +1233,11 @@ def main(argv=None):
                 out["frames"] = frames_timing(args.workload, device)
             except Exception as exc:  # noqa: BLE001  (keep the line)
                 out["frames"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        if world == 1 and n_frames == 1 and not args.no_second_order and not args.no_drop_in:
+            try:
+                out["second_order"] = second_order_timing(frame)
+            except Exception as exc:  # noqa: BLE001  (keep the line)
+                out["second_order"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
