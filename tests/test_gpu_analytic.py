@@ -354,6 +354,34 @@ def test_analytic_and_fused_paths_agree_at_first_order():
             assert relmax(y, x) < 1e-11
 
 
+def test_masks_index_types_and_views_through_the_analytic_route():
+    """pair_mask, int32 indices, non-contiguous charges / positions (views of wider tensors): same potentials and gradients as
+    the fused kernels, which have their own parity tests for these inputs."""
+    rng = np.random.default_rng(4)
+    n_side, a = 5, 2.4
+    gr = (np.arange(n_side) + 0.5) * a
+    pos = np.stack(np.meshgrid(gr, gr, gr, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (n_side**3, 3))
+    cell = n_side * a * np.eye(3) + rng.uniform(-0.3, 0.3, (3, 3))
+    q = rng.normal(size=(len(pos), 2))
+    pairs, S, _ = tpa.neighbor_list(pos, cell, 4.4)
+    mask = rng.uniform(size=len(pairs)) > 0.2
+    res = []
+    for mode in (None, "analytic"):
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.1, exclusion_radius=2.0), mesh_spacing=0.9, interpolation_nodes=4)
+        calc.double_backward = mode
+        wide_q = torch.tensor(np.concatenate([q, q], axis=1), device=DEV, requires_grad=True)
+        wide_p = torch.tensor(np.concatenate([pos, pos], axis=1), device=DEV, requires_grad=True)
+        tq, tp = wide_q[:, 1:3], wide_p[:, 3:]
+        tc = torch.tensor(cell, device=DEV, requires_grad=True)
+        ti = torch.tensor(pairs, device=DEV, dtype=torch.int32)
+        d = tpa.pair_distances(tp, ti, tc, torch.tensor(S, device=DEV, dtype=torch.float64))
+        V = calc(tq, tc, tp, ti, d, pair_mask=torch.tensor(mask, device=DEV))
+        (V * V).sum().backward()
+        res.append([V.detach().cpu(), wide_q.grad.cpu(), tc.grad.cpu(), wide_p.grad.cpu()])
+    for x, y in zip(*res):
+        assert relmax(y, x) < 1e-10
+
+
 def test_unsupported_options_say_so():
     calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=1.5)
     t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float64)  # noqa: E731

@@ -284,6 +284,9 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
                          neighbor_distances=neighbor_distances, periodic=periodic, pair_mask=pair_mask, node_mask=node_mask,
                          kvectors=kvectors)
     _lib.require_device(positions, "positions")
+    if getattr(neighbor_indices, "_mipme_stream", None) is not None:
+        raise ValueError('the handles of a NeighborStream serve the fused kernels only; `double_backward = "analytic"` needs a '
+                         "list in the reference's format (`stream.pairs()`)")
     pot = calculator.potential
     is_ewald = hasattr(calculator, "lr_wavelength")
     if pot.smearing is not None and not is_ewald and not hasattr(calculator, "mesh_spacing"):
