@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 404
+#define MIPME_VERSION 405
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -128,6 +128,16 @@ int mipme_pair_sum(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int6
  * rows, no atomics, fixed summation order.  weights (P) stay indexed by pair. */
 int mipme_pair_sum_rows(void* stream, int dtype, int64_t n_atoms, int n_channels, const void* row_ptr, const void* entries,
                         const void* weights, const void* x, int mode, void* out);
+/* The distance helper compute_distances (tests/helpers.py:278-304) differentiated twice: the pair difference and its adjoint,
+ *   mipme_pair_diff     out[p,c] = x[j_p,c] - x[i_p,c]                                       (positions[j] - positions[i])
+ *   mipme_pair_scatter  out[a,c] = sum_{p: j_p = a} values[p,c] - sum_{p: i_p = a} values[p,c]   (the two index_add_ calls)
+ * each the other's adjoint.  pair_scatter walks the transposed list when row_ptr / entries (mipme_topology_build) are given
+ * (pairs may then be NULL: no atomics, fixed order) and uses atomics on the (P,2) list otherwise; `out` (n_atoms, C) is
+ * overwritten either way. */
+int mipme_pair_diff(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* x,
+                    void* out);
+int mipme_pair_scatter(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels, const void* pairs,
+                       const void* row_ptr, const void* entries, const void* values, void* out);
 /* out[p] = sum_c a[i_p,c] b[j_p,c] (+ a[j_p,c] b[i_p,c] when half != 0): the adjoint of mipme_pair_sum w.r.t. its weights. */
 int mipme_pair_dot(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* a,
                    const void* b, int half, void* out);

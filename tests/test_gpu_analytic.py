@@ -243,6 +243,58 @@ def test_pair_primitives_gradcheck(mode):
     assert relmax(analytic._PairSum.apply(w, x, pairs, mode).detach().cpu(), ref.cpu()) < 1e-14
 
 
+@pytest.mark.parametrize("use_rows", [False, True])
+def test_pair_difference_and_scatter(use_rows):
+    """``x_j - x_i`` and its adjoint (the distance helper's two index operations) against ATen's indexing, with their first and
+    second derivatives; rows of the transposed list and atomics on the list."""
+    rng = np.random.default_rng(8)
+    n_atoms, n_pairs = 40, 300
+    pairs = torch.tensor(rng.integers(0, n_atoms - 3, (n_pairs, 2)), device=DEV)
+    rows = None
+    if use_rows:
+        topo = ops.get_topology(pairs, n_atoms)
+        rows = (topo.row_ptr, topo.entries)
+    x = torch.tensor(rng.normal(size=(n_atoms, 3)), device=DEV, requires_grad=True)
+    v = torch.tensor(rng.normal(size=(n_pairs, 3)), device=DEV, requires_grad=True)
+    i, j = pairs[:, 0], pairs[:, 1]
+    assert relmax(analytic._PairDiff.apply(x, pairs, rows).detach().cpu(), (x[j] - x[i]).detach().cpu()) < 1e-15
+    ref = torch.zeros_like(x).index_add(0, j, v.detach()).index_add(0, i, -v.detach())
+    assert relmax(analytic._PairScatter.apply(v, pairs, rows, n_atoms).detach().cpu(), ref.cpu()) < 1e-13
+    kw = dict(eps=1e-3, atol=1e-8, rtol=1e-7, nondet_tol=1e-10)  # linear maps
+    assert torch.autograd.gradcheck(lambda a: analytic._PairDiff.apply(a, pairs, rows), (x,), **kw)
+    assert torch.autograd.gradgradcheck(lambda a: analytic._PairDiff.apply(a, pairs, rows), (x,), **kw)
+    assert torch.autograd.gradcheck(lambda a: analytic._PairScatter.apply(a, pairs, rows, n_atoms), (v,), **kw)
+    assert torch.autograd.gradgradcheck(lambda a: analytic._PairScatter.apply(a, pairs, rows, n_atoms), (v,), **kw)
+
+
+@pytest.mark.parametrize("route", ["front", "python_nodes"])
+def test_distance_helper_twice_differentiated(route, monkeypatch):
+    """``pair_distances`` under create_graph=True (both host paths): gradient and Hessian-vector product of sum(d^2 w) against
+    the same expression in plain tensor operations (``tests/helpers.py:278-304``), triclinic cell, w.r.t. positions and cell."""
+    if route == "python_nodes":
+        monkeypatch.setattr(ops, "FRONT", False)
+    rng = np.random.default_rng(9)
+    n = 60
+    pos_np, cell_np = rng.uniform(0, 7, (n, 3)), 7 * np.eye(3) + rng.uniform(-0.4, 0.4, (3, 3))
+    pairs_np, S_np, _ = tpa.neighbor_list(pos_np, cell_np, 3.5)
+    pairs, S = torch.tensor(pairs_np, device=DEV), torch.tensor(S_np, device=DEV, dtype=torch.float64)
+    w = torch.tensor(rng.normal(size=len(pairs_np)), device=DEV)
+    c_pos, c_cell = torch.tensor(rng.normal(size=(n, 3)), device=DEV), torch.tensor(rng.normal(size=(3, 3)), device=DEV)
+    res = []
+    for ours in (True, False):
+        pos = torch.tensor(pos_np, device=DEV, requires_grad=True)
+        cell = torch.tensor(cell_np, device=DEV, requires_grad=True)
+        if ours:
+            d = tpa.pair_distances(pos, pairs, cell, S)
+        else:
+            d = torch.linalg.norm(pos[pairs[:, 1]] - pos[pairs[:, 0]] + S @ cell, dim=1)
+        gp, gc = torch.autograd.grad((w * d * d * d).sum(), (pos, cell), create_graph=True)
+        hp, hc = torch.autograd.grad((gp * c_pos).sum() + (gc * c_cell).sum(), (pos, cell))
+        res.append([gp.detach().cpu(), gc.detach().cpu(), hp.cpu(), hc.cpu()])
+    for a, b in zip(*res):
+        assert relmax(a, b) < 1e-12
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_pair_sum_through_the_transposed_list(dtype, monkeypatch):
     """The owner-computes rows (lists of ROWS_MIN_PAIRS pairs and more) against the atomic kernel and ``index_add_``, all three

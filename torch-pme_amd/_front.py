@@ -57,7 +57,17 @@ def module():
             return None, None, g.materialize()
         return None, None, g
 
+    def recorded_distance_backward(g, positions, cell, pairs32, shifts, row_ptr, entries, want_pos, want_cell):
+        """The distances node's adjoint under create_graph=True, from the differentiable primitives (analytic.py)."""
+        from . import analytic
+
+        if isinstance(g, ops.LazyPairGradient):
+            g = g.materialize()
+        return analytic.recorded_distance_backward(g, positions, cell, pairs32, shifts, (row_ptr, entries), want_pos, want_cell)
+
     mod.set_unwrap(unwrap)
+    if hasattr(mod, "set_recorded_distance_backward"):
+        mod.set_recorded_distance_backward(recorded_distance_backward)
     mod.set_second_order_hint(ops.SECOND_ORDER_HINT)
     mod.set_device_select(select_mode())
     _mod = mod

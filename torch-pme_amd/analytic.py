@@ -16,6 +16,9 @@ differentiates the composition as often as it is asked to, w.r.t. charges, posit
     pair_sum(w, x)    out_i = sum_p w_p x_j (+ j<-i)    d/dw   -> pair_dot(g, x)              d/dx   -> pair_sum(w, g) (transposed)
     pair_dot(a, b)    out_p = a_i . b_j (+ a_j . b_i)   d/da   -> pair_sum(c, b)              d/db   -> pair_sum(c, a) (transposed)
 
+and, for the caller-side distance helper under ``create_graph=True`` (``recorded_distance_backward``), the pair difference
+``x_j - x_i`` and its adjoint, the scatter, each the other's derivative.
+
 The interpolation weights are piecewise polynomials of degree ``interpolation_nodes - 1``; the kernels provide their derivatives
 up to third order per axis (enough for a double backward of a force loss and one order to spare), beyond that a call raises.
 Cost: a dozen launches per evaluation instead of six, atomics in the spread and the pair sum -- this is the route for training
@@ -244,6 +247,59 @@ class _PairDot(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gb = _PairSum.apply(c, a, pairs, 0 if half else 2)
         return ga, gb, None, None
+
+
+class _PairDiff(torch.autograd.Function):
+    """``out_p = x_j - x_i`` (the reference helper's ``positions[j] - positions[i]``); adjoint: :class:`_PairScatter`."""
+
+    @staticmethod
+    def forward(ctx, x, pairs, rows):
+        xc = x.detach().contiguous()
+        out = torch.empty((pairs.shape[0], xc.shape[1]), dtype=xc.dtype, device=xc.device)
+        with _lib.on_device(xc.device):
+            _lib.check(_lib.load().mipme_pair_diff(_stream(xc), _lib.dtype_code(xc.dtype), _lib.index_code(pairs.dtype),
+                                                   pairs.shape[0], xc.shape[1], pairs.data_ptr(), xc.data_ptr(), out.data_ptr()))
+        ctx.pairs, ctx.rows, ctx.n = pairs, rows, xc.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PairScatter.apply(g, ctx.pairs, ctx.rows, ctx.n), None, None
+
+
+class _PairScatter(torch.autograd.Function):
+    """``out_a = sum_{p: j_p = a} v_p - sum_{p: i_p = a} v_p`` (the helper's two ``index_add_``); adjoint: :class:`_PairDiff`.
+    ``rows = (row_ptr, entries)`` of the transposed list: owner-computes, no atomics; ``None``: atomics on the (P,2) list."""
+
+    @staticmethod
+    def forward(ctx, v, pairs, rows, n_atoms):
+        vc = v.detach().contiguous()
+        out = torch.empty((n_atoms, vc.shape[1]), dtype=vc.dtype, device=vc.device)
+        with _lib.on_device(vc.device):
+            _lib.check(_lib.load().mipme_pair_scatter(
+                _stream(vc), _lib.dtype_code(vc.dtype), _lib.index_code(pairs.dtype), pairs.shape[0], n_atoms, vc.shape[1],
+                pairs.data_ptr(), None if rows is None else rows[0].data_ptr(), None if rows is None else rows[1].data_ptr(),
+                vc.data_ptr(), out.data_ptr()))
+        ctx.pairs, ctx.rows = pairs, rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PairDiff.apply(g, ctx.pairs, ctx.rows), None, None, None
+
+
+def recorded_distance_backward(grad_d, positions, cell, pairs, shifts, rows, want_pos=True, want_cell=True):
+    """The adjoint of ``d_p = |r_j - r_i + S_p cell|`` for a backward pass that is itself being recorded (create_graph=True):
+    differentiable to any order, what the reference's helper gives (``tests/helpers.py:278-304``) -- with the pair difference
+    and the scatter as primitives of this module instead of ATen's indexing kernels (whose ``index_add_`` is a compare-and-swap
+    loop in double precision: 4 ms for 1.2 M pairs, 70 % of a force-loss step).  Returns ``(grad_positions, grad_cell)``."""
+    vec = _PairDiff.apply(positions, pairs, rows)
+    if shifts is not None and cell is not None:
+        vec = vec + shifts @ cell
+    gvec = (grad_d / torch.linalg.norm(vec, dim=1)).unsqueeze(1) * vec
+    gp = _PairScatter.apply(gvec, pairs, rows, positions.shape[0]) if want_pos else None
+    gc = shifts.T @ gvec if (want_cell and shifts is not None and cell is not None) else None
+    return gp, gc
 
 
 # ---- the composition ---------------------------------------------------------------------------------------------------------

@@ -203,6 +203,12 @@ struct FrontCalc {
 py::object* g_unwrap = nullptr;  // leaked on purpose (no interpreter at static destruction time)
 void set_unwrap(py::object fn) { g_unwrap = new py::object(std::move(fn)); }
 
+// The distance adjoint of a backward pass that is itself recorded (create_graph=True), from the differentiable primitives of
+// torch-pme_amd/analytic.py: `fn(grad_d, positions, cell, pairs32, shifts, row_ptr, entries, want_pos, want_cell) -> (gp, gc)`.
+// Not set: the same expression from ATen's indexing kernels (index_add_ is a compare-and-swap loop in double precision).
+py::object* g_recorded_distance_backward = nullptr;
+void set_recorded_distance_backward(py::object fn) { g_recorded_distance_backward = new py::object(std::move(fn)); }
+
 // A backward pass that is itself recorded (create_graph=True): the kernels are first order, so their results leave the node
 // behind an Error node carrying ops.SECOND_ORDER_HINT -- differentiating them again raises instead of returning an incomplete
 // Hessian (what ops.first_order does for the Python nodes).
@@ -248,6 +254,14 @@ struct DistNode : public Node {
     if (at::GradMode::is_enabled()) {
       // create_graph=True: the adjoint as differentiable tensor ops -- exact second order, what the reference's helper gives
       // (tests/helpers.py:278-304) and what ops._PairDistances.backward does
+      if (g_recorded_distance_backward) {
+        py::gil_scoped_acquire gil;
+        py::tuple r = (*g_recorded_distance_backward)(g, pos_in, cell_in, topo->pairs32, topo->shifts, topo->row_ptr, topo->entries,
+                                                      want_pos, want_cell);
+        if (!r[0].is_none()) out[0] = r[0].cast<at::Tensor>();
+        if (!r[1].is_none()) out[1] = r[1].cast<at::Tensor>();
+        return out;
+      }
       at::Tensor i = topo->pairs32.select(1, 0).to(at::kLong), j = topo->pairs32.select(1, 1).to(at::kLong);
       at::Tensor vec = pos_in.index_select(0, j) - pos_in.index_select(0, i) + topo->shifts.matmul(cell_in);
       at::Tensor gvec = (g / at::linalg_vector_norm(vec, 2, at::IntArrayRef{1})).unsqueeze(1) * vec;
@@ -1009,6 +1023,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled host side of the reference call sequence (see front.cpp)";
   m.def("load_library", &load_library);
   m.def("set_unwrap", &set_unwrap);
+  m.def("set_recorded_distance_backward", &set_recorded_distance_backward);
   m.def("set_device_select", &set_device_select);
   m.def("set_second_order_hint", &set_second_order_hint);
   py::class_<FrontTopo, std::shared_ptr<FrontTopo>>(m, "Topology")

@@ -212,6 +212,54 @@ __global__ __launch_bounds__(256) void pair_dot_kernel(int64_t P, int C, const I
   out[p] = acc;
 }
 
+// The caller-side distance helper (tests/helpers.py:278-304) differentiated twice needs the pair DIFFERENCE and its adjoint:
+//   pair_diff    out[p,c] = x[j_p,c] - x[i_p,c]                    adjoint: pair_scatter
+//   pair_scatter out[a,c] = sum_{p: j_p = a} v[p,c] - sum_{p: i_p = a} v[p,c]     adjoint: pair_diff
+// (ATen's index_add_ does the second one with compare-and-swap loops in double precision: 4 ms for 1.2 M pairs.)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void pair_diff_kernel(int64_t P, int C, const I* __restrict__ pairs, const T* __restrict__ x,
+                                                       T* __restrict__ out) {
+  const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int64_t i = int64_t(pairs[2 * p]), j = int64_t(pairs[2 * p + 1]);
+  for (int c = 0; c < C; ++c) out[p * C + c] = x[j * C + c] - x[i * C + c];
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void pair_scatter_kernel(int64_t P, int C, const I* __restrict__ pairs, const T* __restrict__ v,
+                                                          T* __restrict__ out) {
+  const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int64_t i = int64_t(pairs[2 * p]), j = int64_t(pairs[2 * p + 1]);
+  for (int c = 0; c < C; ++c) {
+    const T val = v[p * C + c];
+    atomic_add(out + j * C + c, val);
+    atomic_add(out + i * C + c, -val);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_scatter_rows_kernel(int64_t N, int C, const int* __restrict__ row_ptr,
+                                                               const int2* __restrict__ entries, const T* __restrict__ v,
+                                                               T* __restrict__ out) {
+  constexpr int LANES = 16;
+  const int sub = threadIdx.x % LANES;
+  int64_t a = int64_t(blockIdx.x) * (256 / LANES) + threadIdx.x / LANES;
+  const bool valid = a < N;
+  if (!valid) a = N - 1;
+  const int begin = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = row_ptr[2 * a + 2];
+  for (int c = 0; c < C; ++c) {
+    T acc = T(0);
+    for (int e = begin + sub; e < end; e += LANES) {
+      const T val = v[int64_t(entries[e].y) * C + c];
+      acc += e < mid ? -val : val;  // role-i entries first (the atom is i of the pair), then role-j
+    }
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, LANES);
+    if (sub == 0 && valid) out[a * C + c] = acc;
+  }
+}
+
 template <int N>
 static inline unsigned jet_blocks(int64_t n_atoms) {
   constexpr int APB = 256 / StencilGroup<N>::LANES;
@@ -265,6 +313,29 @@ template <typename T, typename I>
 static int pair_dot_impl(hipStream_t st, int64_t P, int C, const void* pairs, const void* a, const void* b, int half, void* out) {
   if (P == 0) return MIPME_OK;
   pair_dot_kernel<T, I><<<unsigned((P + 255) / 256), 256, 0, st>>>(P, C, (const I*)pairs, (const T*)a, (const T*)b, half, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T, typename I>
+static int pair_diff_impl(hipStream_t st, int64_t P, int C, const void* pairs, const void* x, void* out) {
+  if (P == 0) return MIPME_OK;
+  pair_diff_kernel<T, I><<<unsigned((P + 255) / 256), 256, 0, st>>>(P, C, (const I*)pairs, (const T*)x, (T*)out);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+template <typename T, typename I>
+static int pair_scatter_impl(hipStream_t st, int64_t P, int64_t N, int C, const void* pairs, const void* row_ptr,
+                             const void* entries, const void* v, void* out) {
+  if (N == 0) return MIPME_OK;
+  if (row_ptr && entries) {
+    pair_scatter_rows_kernel<T><<<unsigned((N + 15) / 16), 256, 0, st>>>(N, C, (const int*)row_ptr, (const int2*)entries,
+                                                                        (const T*)v, (T*)out);
+  } else {
+    MIPME_CHECK_HIP(zero_async(out, sizeof(T) * size_t(N) * C, st));
+    if (P > 0) pair_scatter_kernel<T, I><<<unsigned((P + 255) / 256), 256, 0, st>>>(P, C, (const I*)pairs, (const T*)v, (T*)out);
+  }
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
@@ -343,6 +414,38 @@ int mipme_pair_dot(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int 
                                   : pair_dot_impl<float, int32_t>(st, n_pairs, n_channels, pairs, a, b, half, out);
   return idx_dtype == MIPME_I64 ? pair_dot_impl<double, int64_t>(st, n_pairs, n_channels, pairs, a, b, half, out)
                                 : pair_dot_impl<double, int32_t>(st, n_pairs, n_channels, pairs, a, b, half, out);
+}
+
+int mipme_pair_diff(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int n_channels, const void* pairs, const void* x,
+                    void* out) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_channels > 0, "invalid argument of mipme_pair_diff");
+  MIPME_REQUIRE(n_pairs == 0 || (pairs && x && out), "NULL buffer passed to mipme_pair_diff");
+  MIPME_REQUIRE((dtype == MIPME_F32 || dtype == MIPME_F64) && (idx_dtype == MIPME_I64 || idx_dtype == MIPME_I32),
+                "invalid dtype %d / index dtype %d", dtype, idx_dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    return idx_dtype == MIPME_I64 ? pair_diff_impl<float, int64_t>(st, n_pairs, n_channels, pairs, x, out)
+                                  : pair_diff_impl<float, int32_t>(st, n_pairs, n_channels, pairs, x, out);
+  return idx_dtype == MIPME_I64 ? pair_diff_impl<double, int64_t>(st, n_pairs, n_channels, pairs, x, out)
+                                : pair_diff_impl<double, int32_t>(st, n_pairs, n_channels, pairs, x, out);
+}
+
+int mipme_pair_scatter(void* stream, int dtype, int idx_dtype, int64_t n_pairs, int64_t n_atoms, int n_channels, const void* pairs,
+                       const void* row_ptr, const void* entries, const void* values, void* out) {
+  MIPME_REQUIRE(n_pairs >= 0 && n_atoms >= 0 && n_channels > 0, "invalid argument of mipme_pair_scatter");
+  MIPME_REQUIRE(n_atoms == 0 || out, "NULL output passed to mipme_pair_scatter");
+  MIPME_REQUIRE(n_pairs == 0 || (values && (pairs || (row_ptr && entries))), "NULL buffer passed to mipme_pair_scatter");
+  MIPME_REQUIRE((row_ptr == nullptr) == (entries == nullptr), "row_ptr and entries go together");
+  MIPME_REQUIRE((dtype == MIPME_F32 || dtype == MIPME_F64) && (idx_dtype == MIPME_I64 || idx_dtype == MIPME_I32),
+                "invalid dtype %d / index dtype %d", dtype, idx_dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32)
+    return idx_dtype == MIPME_I64
+               ? pair_scatter_impl<float, int64_t>(st, n_pairs, n_atoms, n_channels, pairs, row_ptr, entries, values, out)
+               : pair_scatter_impl<float, int32_t>(st, n_pairs, n_atoms, n_channels, pairs, row_ptr, entries, values, out);
+  return idx_dtype == MIPME_I64
+             ? pair_scatter_impl<double, int64_t>(st, n_pairs, n_atoms, n_channels, pairs, row_ptr, entries, values, out)
+             : pair_scatter_impl<double, int32_t>(st, n_pairs, n_atoms, n_channels, pairs, row_ptr, entries, values, out);
 }
 
 }  // extern "C"

@@ -1543,14 +1543,13 @@ class _PairDistances(torch.autograd.Function):
             _, _, pairs, sh = ctx.saved_tensors
             if isinstance(grad_d, LazyPairGradient):
                 grad_d = grad_d.materialize()
-            i, j = pairs[:, 0].long(), pairs[:, 1].long()
-            vec = positions[j] - positions[i]
-            if sh is not None:
-                vec = vec + sh @ cell
-            gvec = (grad_d / torch.linalg.norm(vec, dim=1)).unsqueeze(1) * vec
-            gp = torch.zeros_like(positions).index_add(0, j, gvec).index_add(0, i, -gvec)
-            gc = sh.T @ gvec if (sh is not None and cell is not None and ctx.needs_input_grad[1]) else None
-            return (gp if ctx.needs_input_grad[0] else None), gc, None, None, None
+            from . import analytic
+
+            topo = ctx.topo
+            rows = (topo.row_ptr, topo.entries) if isinstance(topo, PairTopology) else None
+            gp, gc = analytic.recorded_distance_backward(grad_d, positions, cell, pairs, sh, rows, ctx.needs_input_grad[0],
+                                                         ctx.needs_input_grad[1])
+            return gp, gc, None, None, None
         return _PairDistances._backward_first_order(ctx, grad_d)
 
     @staticmethod
