@@ -434,13 +434,79 @@ def test_masks_index_types_and_views_through_the_analytic_route():
         assert relmax(y, x) < 1e-10
 
 
+@pytest.mark.parametrize("which", ["P3M", "PME", "Ewald"])
+def test_auto_mode_fused_first_order_exact_higher_orders(which):
+    """``double_backward = "auto"``: without create_graph the values and gradients are the fused kernels' (bit for bit the plain
+    calculator's through the same unfused-distance route); with create_graph the force loss's gradients w.r.t. charges,
+    positions and cell are those of the analytic route."""
+    rng = np.random.default_rng(12)
+    n_side, a = 5, 2.3
+    gr = (np.arange(n_side) + 0.5) * a
+    pos = np.stack(np.meshgrid(gr, gr, gr, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (n_side**3, 3))
+    cell = n_side * a * np.eye(3) + rng.uniform(-0.2, 0.2, (3, 3))
+    q = rng.normal(size=(len(pos), 1))
+    pairs_np, S_np, _ = tpa.neighbor_list(pos, cell, 4.5)
+    pairs, S = torch.tensor(pairs_np, device=DEV), torch.tensor(S_np, device=DEV, dtype=torch.float64)
+    w = torch.tensor(rng.normal(size=pos.shape), device=DEV)
+
+    def make(mode):
+        pot = tpa.CoulombPotential(smearing=1.0)
+        calc = (tpa.P3MCalculator(pot, mesh_spacing=0.7, interpolation_nodes=4) if which == "P3M" else
+                tpa.PMECalculator(pot, mesh_spacing=0.7, interpolation_nodes=5) if which == "PME" else
+                tpa.EwaldCalculator(pot, lr_wavelength=1.4))
+        calc.double_backward = mode
+        return calc
+
+    def run(mode, create_graph):
+        calc = make(mode)
+        tq, tc, tp = (torch.tensor(x, device=DEV, requires_grad=True) for x in (q, cell, pos))
+        d = tpa.pair_distances(tp, pairs, tc, S)
+        E = (tq * calc(tq, tc, tp, pairs, d)).sum()
+        if not create_graph:
+            return [E.detach().cpu()] + [x.cpu() for x in torch.autograd.grad(E, (tq, tc, tp))]
+        (gp,) = torch.autograd.grad(E, tp, create_graph=True)
+        return [E.detach().cpu()] + [x.cpu() for x in torch.autograd.grad((w * gp).sum(), (tq, tc, tp))]
+
+    for a_, b_ in zip(run("auto", False), run(None, False)):
+        assert relmax(a_, b_) < 1e-12
+    for a_, b_ in zip(run("auto", True), run("analytic", True)):
+        assert relmax(a_, b_) < 1e-10
+
+
+def test_auto_mode_with_inputs_that_depend_on_each_other():
+    """Positions made from fractional coordinates and the cell (a stress-of-a-force-loss set-up), distances from both: the
+    recorded backward of the auto mode must hand out PARTIAL derivatives (the caller's graph adds the chains)."""
+    rng = np.random.default_rng(13)
+    n = 64
+    frac_np = rng.uniform(0, 1, (n, 3))
+    cell_np = 9.0 * np.eye(3) + rng.uniform(-0.3, 0.3, (3, 3))
+    q = torch.tensor(rng.normal(size=(n, 1)), device=DEV)
+    pairs_np, S_np, _ = tpa.neighbor_list(frac_np @ cell_np, cell_np, 4.0)
+    pairs, S = torch.tensor(pairs_np, device=DEV), torch.tensor(S_np, device=DEV, dtype=torch.float64)
+    w = torch.tensor(rng.normal(size=(n, 3)), device=DEV)
+    res = []
+    for mode in ("auto", "analytic"):
+        calc = tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.8, interpolation_nodes=4)
+        calc.double_backward = mode
+        frac = torch.tensor(frac_np, device=DEV, requires_grad=True)
+        cell = torch.tensor(cell_np, device=DEV, requires_grad=True)
+        pos = frac @ cell
+        d = tpa.pair_distances(pos, pairs, cell, S)
+        E = (q * calc(q, cell, pos, pairs, d)).sum()
+        gf, gc = torch.autograd.grad(E, (frac, cell), create_graph=True)
+        hf, hc = torch.autograd.grad((w * gf).sum() + gc.sum(), (frac, cell))
+        res.append([gf.detach().cpu(), gc.detach().cpu(), hf.cpu(), hc.cpu()])
+    for a_, b_ in zip(*res):
+        assert relmax(a_, b_) < 1e-10
+
+
 def test_unsupported_options_say_so():
     calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=1.5)
     t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float64)  # noqa: E731
     pos = t(np.random.default_rng(0).uniform(0, 4, (5, 3))).requires_grad_(True)
     pairs = torch.tensor([[0, 1], [1, 2], [2, 3], [3, 4]], device=DEV)
     calc.double_backward = "exact"
-    with pytest.raises(ValueError, match="'analytic' or 'finite-difference'"):
+    with pytest.raises(ValueError, match="'auto', 'analytic' or 'finite-difference'"):
         calc(t(np.ones((5, 1))), t(4 * np.eye(3)), pos, pairs, t(np.ones(4)))
     mesh = tpa.PMECalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=1.0)
     mesh.double_backward = "analytic"

@@ -52,8 +52,11 @@ class Calculator(torch.nn.Module):
         #: the call through :mod:`analytic` instead -- the same mathematics as a composition of linear primitives whose
         #: backward passes are made of the same primitives (``csrc/jets.hip``), exact to any order w.r.t. charges, positions,
         #: cell and distances, as the reference's ATen chain is (mesh calculators and the plain pair sum).
+        #: ``"auto"``: potentials and a plain backward pass from the fused kernels, and only a backward pass that is itself
+        #: recorded (``create_graph=True``) through the primitives -- for a calculator that serves training on forces and plain
+        #: energy / force evaluations alike.
         #: ``"finite-difference"`` keeps the fused first-order kernels and forms the backward of the backward from central
-        #: differences of their gradients (two more evaluations; use float64; also covers the Ewald calculator)
+        #: differences of their gradients (two more evaluations; use float64)
         self.double_backward = None
         self._nan_flag = None  # pinned int32[1], created on first use
         self._nan_shape = None
@@ -180,9 +183,9 @@ class Calculator(torch.nn.Module):
             return ops.vmap_bridge(self._forward_impl, *args)
         if self.double_backward is not None and torch.is_grad_enabled() and any(
                 isinstance(a, torch.Tensor) and a.requires_grad for a in args):
-            if self.double_backward not in ("finite-difference", "analytic"):
+            if self.double_backward not in ("finite-difference", "analytic", "auto"):
                 raise ValueError(
-                    f"`double_backward` is {self.double_backward!r} but must be None, 'analytic' or 'finite-difference'")
+                    f"`double_backward` is {self.double_backward!r} but must be None, 'auto', 'analytic' or 'finite-difference'")
             charges, cell, positions, pairs, dist, *rest = args
             # the distances are an ordinary differentiable input here (no fused / lazy pair gradient: the chain through
             # `pair_distances` is exact second order by itself)
@@ -199,6 +202,13 @@ class Calculator(torch.nn.Module):
                 # plain (unfused) evaluation: `d` carries no provenance, so the calculator differentiates w.r.t. it as a tensor
                 return self._forward_impl(q, c, p, pairs, d, *others)
 
+            if self.double_backward == "auto":
+                from . import analytic
+
+                def exact_eval(q, c, p, d, *others):
+                    return analytic.potentials(self, q, c, p, pairs, d, *others)
+
+                return ops.fused_first_analytic_higher(first_order_eval, exact_eval, (charges, cell, positions, dist), tuple(rest))
             return ops.second_order_by_finite_differences(first_order_eval, (charges, cell, positions, dist), tuple(rest))
         if ops.FRONT and ops.PROFILE is None and len(args) >= 5 and all(a is None for a in args[5:]) and self.check_nan is not True:
             out = self._front_forward(*args[:5])  # compiled host path of the common case (csrc/front.cpp); None: not that case

@@ -26,8 +26,9 @@ from . import _front, _lib
 
 SECOND_ORDER_HINT = (
     "torchpme_amd: the HIP kernels provide FIRST-order gradients; this graph is being differentiated twice (create_graph=True, "
-    "e.g. a loss on forces).  Set `calculator.double_backward = \"analytic\"` before the forward call (mesh calculators: the "
-    "call is evaluated through differentiable primitives, exact to any order), or `calculator.double_backward = "
+    "e.g. a loss on forces).  Set `calculator.double_backward = \"analytic\"` before the forward call (the call is evaluated "
+    "through differentiable primitives, exact to any order; \"auto\": only when a backward pass is itself recorded), or "
+    "`calculator.double_backward = "
     "\"finite-difference\"`: the second derivative is then formed from central differences of the analytic first-order "
     "gradients (two more evaluations per double-backward pass; use float64).  Distances from `pair_distances` differentiate "
     "twice exactly either way.")
@@ -1754,6 +1755,54 @@ class _FiniteDifferenceGradient(torch.autograd.Function):
         grad_g = (Vp - Vm) / (2 * eps)
         Hc = [((a - b) / (2 * eps)) if n else None for a, b, n in zip(Gp, Gm, needs)]
         return (None, None, None, None, grad_g, *Hc)
+
+
+class _FusedFirstAnalyticHigher(torch.autograd.Function):
+    """``V = f(*z)`` through the fused first-order kernels, with higher orders from a differentiable twin ``f_exact`` (the same
+    call through the primitives of :mod:`analytic`) that is only evaluated when a backward pass is itself being recorded.
+
+    forward: ``f`` on detached leaves with grad mode on -- the inner graph (the calculator's own first-order nodes) is kept;
+    backward, not recorded: the inner graph's vector-Jacobian product, i.e. exactly the kernels of a plain call;
+    backward, recorded (``create_graph=True``): ``grad(f_exact(*z), z, g, create_graph=True)`` on the ORIGINAL inputs -- values
+    from the primitives, differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, f, f_exact, n_diff, *z):
+        leaves = [t.detach().requires_grad_(t.requires_grad) for t in z[:n_diff]]
+        with torch.enable_grad():
+            inner = f(*leaves, *z[n_diff:])
+        ctx.f_exact, ctx.n_diff, ctx.rest = f_exact, n_diff, z[n_diff:]
+        ctx.leaves, ctx.inner = leaves, inner
+        ctx.save_for_backward(*z[:n_diff])
+        return inner.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        needs = tuple(ctx.needs_input_grad[3:3 + ctx.n_diff])
+        tail = [None] * len(ctx.rest)
+        if not torch.is_grad_enabled():
+            wanted = [t for t, n in zip(ctx.leaves, needs) if n]
+            if ctx.inner.grad_fn is None or not wanted:
+                return (None, None, None, *[None] * ctx.n_diff, *tail)
+            got = list(torch.autograd.grad(ctx.inner, wanted, g, retain_graph=True, allow_unused=True))
+            grads = [got.pop(0) if n else None for n in needs]
+            return (None, None, None, *grads, *tail)
+        with torch.enable_grad():
+            # aliases of the inputs: the inputs may depend on each other in the caller's graph (distances on positions and cell,
+            # positions on the cell), and the gradient w.r.t. an input tensor itself would then include the paths through the
+            # others -- which the caller's graph adds a second time.  The gradient w.r.t. an alias is the PARTIAL derivative, and
+            # stays connected to the original for every later differentiation.
+            z = [t.view_as(t) for t in ctx.saved_tensors]
+            V = ctx.f_exact(*z, *ctx.rest)
+            wanted = [t for t, n in zip(z, needs) if n]
+            got = list(torch.autograd.grad(V, wanted, g, create_graph=True, allow_unused=True)) if wanted else []
+        grads = [got.pop(0) if n else None for n in needs]
+        return (None, None, None, *grads, *tail)
+
+
+def fused_first_analytic_higher(f, f_exact, diff_inputs, other_inputs):
+    """See :class:`_FusedFirstAnalyticHigher` (``calculator.double_backward = "auto"``)."""
+    return _FusedFirstAnalyticHigher.apply(f, f_exact, len(diff_inputs), *diff_inputs, *other_inputs)
 
 
 def second_order_by_finite_differences(f, diff_inputs, other_inputs):
