@@ -270,7 +270,14 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # hot-loop ISA counts of the pair-row bodies, per entry (a loop iteration handles two): (VALU instructions, of which quarter-rate),
 # counted in the disassembly of spread_rows_kernel<5, T, P, true> at the end of round 3 (llvm-objdump; loop control and masks
 # included, the fp64 body's rare y >= 6.5 branch excluded; 44.5 and 43.5 for the fp32 bodies while their entry loads were waterfall loops)
-PAIR_BODY_VALU = {("f32", 1): (38, 3), ("f32", 6): (37, 2), ("f64", 1): (91, 1)}
+# Round 4: the fp32 bodies run an unmasked main loop (33.5 per entry: 65 + 2 per iteration) for the iterations in which every
+# lane has two full entries -- eight of a row's ten at cfg3 -- and the masked one (38.5) for the tails: 34.5 on average.
+PAIR_BODY_VALU = {("f32", 1): (34.5, 3), ("f32", 6): (33.5, 2), ("f64", 1): (91, 1)}
+# What the hardware counters say about the whole launch (rows AND bricks, at the clock it actually runs at): VALUBusy =
+# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_c_sq_counters.txt (cfg3, f32).
+VALU_BUSY_PMC = {"water": {"valu_busy": 0.81, "valu_instructions_per_launch": 10.28e6, "sq_clock_GHz": 1.94,
+                           "source": "profiles/r04_c_sq_counters.txt (SQ_ACTIVE_INST_VALU 337102, SQ_BUSY_CYCLES 51851, "
+                                     "SQ_INSTS_VALU 321360 per shader engine, 32 engines)"}}
 
 
 def valu_roofline(w, kernel: str, kernel_ms: float):
@@ -297,6 +304,9 @@ def valu_roofline(w, kernel: str, kernel_ms: float):
         "quarter_rate_per_entry": quarter,
         "kernel_ms": kernel_ms,
         "floor_ms": entries * (ops + 3 * quarter) / (VALU_PEAK_TLANEOPS * 1e12) * 1e3,
+        # the model above counts the rows' hot loop at the nominal 2.4 GHz; the counters of the whole launch (committed figure,
+        # not measured by this run) put its vector units at 81 % busy: the launch is bound by instruction issue
+        "pmc": VALU_BUSY_PMC.get(getattr(w, "name", "").split("_")[0]),
     }
 
 

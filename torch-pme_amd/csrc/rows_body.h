@@ -660,6 +660,9 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   MIPME_ROWS_PHASE(6, true);
 }
 
+#ifndef MIPME_ROWS_UNMASKED
+#define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed body with its tail selects (the form before round 4's end)
+#endif
 #if MIPME_ROW_LANES == 16
 template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
@@ -732,7 +735,14 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     cxy[k] = f2v{0.f, 0.f};
     cz[k] = 0.f;
   }
-  for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
+  // One iteration = two entries per lane.  MASKED: the row's tail (entries beyond `end` are neutralised by two selects: d^2 := 1,
+  // weight := 0) and full lists (the potential takes role-i entries only).  The unmasked form serves every iteration in which
+  // ALL lanes of the wavefront have both entries inside their rows of a half list -- eight of a row's ten at cfg3 --: the
+  // launch is bound by VALU issue (SQ counters: VALUBusy 81 %, profiles/r04_c_sq_counters.txt), and the selects, their compares
+  // and the exec-mask loop control were 14 of the 76 vector instructions of an iteration.
+  int eA = beg + sub;
+  auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int eB = eA + kRowLanes;
     const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
     const f4v cRB = llvm_raw_buffer_load_f4(rec_rs, int((wB & kAtomMask) << 4), 0, 0);
@@ -741,17 +751,20 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     off += 8 * kRowLanes;
     wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
     wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
-    const bool okA = eA < end, okB = eB < end;
+    const bool okA = !MASKED || eA < end, okB = !MASKED || eB < end;
     const f2v vA = (f2v{cRA.x, cRA.y} - axy) + f2v{sA.x, sA.y};
     const f2v vB = (f2v{cRB.x, cRB.y} - axy) + f2v{sB.x, sB.y};
     const float zA = (cRA.z - az) + sA.z, zB = (cRB.z - az) + sB.z;
     const f2v sqA = vA * vA, sqB = vB * vB;
     const float dA = (sqA.x + sqA.y) + zA * zA, dB = (sqB.x + sqB.y) + zB * zB;
-    const f2v d2 = f2v{okA ? dA : 1.f, okB ? dB : 1.f};
-    const f2v sv = f2v{okA ? cRA.w : 0.f, okB ? cRB.w : 0.f};
+    const f2v d2 = MASKED ? f2v{okA ? dA : 1.f, okB ? dB : 1.f} : f2v{dA, dB};
+    const f2v sv = MASKED ? f2v{okA ? cRA.w : 0.f, okB ? cRB.w : 0.f} : f2v{cRA.w, cRB.w};
     f2v v, dvd;
     fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
-    pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
+    if constexpr (MASKED)
+      pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
+    else
+      pot2 += sv * v;
     const f2v sc = sv * dvd;
     if constexpr (CELL) {
       const f2v tA = sc.x * vA, tB = sc.y * vB;
@@ -777,7 +790,15 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
       fxy -= sc.y * vB;
       fz -= sc.y * zB;
     }
+    eA += 2 * kRowLanes;
+  };
+#if MIPME_ROWS_UNMASKED
+  if (!args.full) {  // uniform
+    // (a ballot over the whole wavefront: every lane is active here; lanes of rows beyond N have end == beg and fail it)
+    while (__builtin_amdgcn_ballot_w64(eA + kRowLanes < end) == ~0ull) iteration(std::false_type{});
   }
+#endif
+  while (eA - sub < end) iteration(std::true_type{});
   if constexpr (CELL) {
     if (args.cpart) {  // uniform
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
