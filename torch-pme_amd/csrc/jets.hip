@@ -248,15 +248,23 @@ __global__ __launch_bounds__(256) void pair_scatter_rows_kernel(int64_t N, int C
   const bool valid = a < N;
   if (!valid) a = N - 1;
   const int begin = row_ptr[2 * a], mid = row_ptr[2 * a + 1], end = row_ptr[2 * a + 2];
-  for (int c = 0; c < C; ++c) {
-    T acc = T(0);
+  // (channels in chunks of four per walk over the row: the common case, three Cartesian components, reads the entries once)
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    const int nc = min(4, C - c0);
+    T acc[4] = {T(0), T(0), T(0), T(0)};
     for (int e = begin + sub; e < end; e += LANES) {
-      const T val = v[int64_t(entries[e].y) * C + c];
-      acc += e < mid ? -val : val;  // role-i entries first (the atom is i of the pair), then role-j
+      const T* vp = v + int64_t(entries[e].y) * C + c0;
+      const T sgn = e < mid ? T(-1) : T(1);  // role-i entries first (the atom is i of the pair), then role-j
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nc) acc[c] += sgn * vp[c];
     }
 #pragma unroll
-    for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, LANES);
-    if (sub == 0 && valid) out[a * C + c] = acc;
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int off = LANES / 2; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, LANES);
+      if (c < nc && sub == 0 && valid) out[a * C + c0 + c] = acc[c];
+    }
   }
 }
 
