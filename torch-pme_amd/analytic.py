@@ -372,15 +372,18 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
     out = _PairSum.apply(bare.to(dtype), charges, pairs, 1 if calculator.full_neighbor_list else 0) / 2
     if pot.smearing is None:
         return out
-    ivolume = torch.abs(torch.det(cell)).pow(-1)
+    from .calculators import _reciprocal_and_det  # inv(cell).T and det from cross products: no host synchronisation
+
+    recip, det = _reciprocal_and_det(cell)
+    ivolume = torch.abs(det).pow(-1)
     if is_ewald:
         # ---- explicit Ewald sum (calculators/ewald.py:72-142): k = 2 pi F A^-T from the cell, the (K, N) phase tables as
         # tensor expressions, K in slabs (this is the reference's own formulation; the fused route is csrc/ewald.hip)
         if kvectors is None:
-            kvectors = (2 * torch.pi) * calculator._frequencies(cell) @ torch.linalg.inv(cell).T
+            kvectors = (2 * torch.pi) * calculator._frequencies(cell) @ recip
         lr = _ewald_kspace(pot, charges, positions, kvectors) * ivolume
     else:
-        lr = _mesh_kspace(calculator, charges, cell, positions) * ivolume
+        lr = _mesh_kspace(calculator, charges, cell, positions, recip.T) * ivolume
     lr = lr - charges * pot.self_contribution().to(dtype)
     lr = lr - 2 * pot.background_correction().to(dtype) * charges.sum(dim=0) * ivolume
     lr = lr + pot.pbc_correction(periodic, positions, cell, charges).to(dtype)
@@ -402,14 +405,32 @@ def _ewald_kspace(pot, charges, positions, kvectors) -> torch.Tensor:
     return acc
 
 
-def _mesh_kspace(calculator, charges, cell, positions) -> torch.Tensor:
-    """``mesh_to_points(filter(points_to_mesh(charges)))`` (before the 1 / V): calculators/pme.py:88-113."""
-    dtype = charges.dtype
+def _geometry(calculator, cell):
+    """Mesh sizes need the cell on the host (as in the reference, ``lib/kvectors.py:5-21``): one copy per cell tensor and
+    version, remembered on the calculator -- a training loop over the same structure does not wait for the device every call."""
+    import weakref
+
+    c = calculator.__dict__.get("_analytic_geom")
+    key = (calculator.mesh_spacing, calculator._scheme, calculator.interpolation_nodes)
+    if c is not None and c[0]() is cell and c[1] == cell._version and c[2] == key:
+        return c[3]
     cell_host = cell.detach().to("cpu", torch.float64).numpy()
     ns = ops.ns_mesh_from_cell(cell_host, calculator.mesh_spacing)
     geom = ops.MeshGeometry(cell_host, ns, calculator._scheme, calculator.interpolation_nodes)
+    try:
+        calculator.__dict__["_analytic_geom"] = (weakref.ref(cell), cell._version, key, geom)
+    except TypeError:  # (a tensor subclass without weak references: no cache)
+        pass
+    return geom
+
+
+def _mesh_kspace(calculator, charges, cell, positions, inv_cell) -> torch.Tensor:
+    """``mesh_to_points(filter(points_to_mesh(charges)))`` (before the 1 / V): calculators/pme.py:88-113."""
+    dtype = charges.dtype
+    geom = _geometry(calculator, cell)
+    ns = geom.ns
     nst = torch.tensor([float(n) for n in ns], dtype=dtype, device=positions.device)
-    u = nst * (positions @ torch.linalg.inv(cell))
+    u = nst * (positions @ inv_cell)
     G = filter_table(calculator, cell, ns).to(dtype)
     zero = (0, 0, 0)
     rho = _Spread.apply(u, charges, geom, zero)

@@ -68,7 +68,7 @@ class Calculator(torch.nn.Module):
     #: per-instance device state that must not travel with a copy / pickle (FFT plans own raw device pointers, the caches
     #: hold weak references to the caller's tensors); rebuilt on first use
     _TRANSIENT = {"_cache": None, "_plan_store": dict, "_freq_cache": None, "_nan_flag": None, "_nan_shape": None,
-                  "_speculated": None, "_bet_flag": None, "_bet_flag_np": None, "_bet_won": True}
+                  "_speculated": None, "_bet_flag": None, "_bet_flag_np": None, "_bet_won": True, "_analytic_geom": None}
 
 
     def __getstate__(self):
