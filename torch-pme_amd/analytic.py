@@ -152,13 +152,31 @@ def _rfftn(mesh, geom):
     return hat
 
 
+def _constant(geom, name, dtype, device, make):
+    """Small device constants of a mesh geometry (made once per geometry, dtype and device: a host list copied to the device
+    every call is a synchronous copy, and not capturable into a HIP graph)."""
+    store = geom.__dict__.setdefault("_analytic_constants", {})
+    key = (name, dtype, device)
+    t = store.get(key)
+    if t is None:
+        t = store[key] = make()
+    return t
+
+
+def _mesh_sizes(geom, dtype, device):
+    return _constant(geom, "ns", dtype, device, lambda: torch.tensor([float(n) for n in geom.ns], dtype=dtype, device=device))
+
+
 def _multiplicity(geom, dtype, device):
-    nz = geom.ns[2]
-    mu = torch.full((nz // 2 + 1,), 2.0, dtype=dtype, device=device)
-    mu[0] = 1.0
-    if nz % 2 == 0:
-        mu[-1] = 1.0
-    return mu
+    def make():
+        nz = geom.ns[2]
+        mu = [2.0] * (nz // 2 + 1)
+        mu[0] = 1.0
+        if nz % 2 == 0:
+            mu[-1] = 1.0
+        return torch.tensor(mu, dtype=dtype, device=device)
+
+    return _constant(geom, "mu", dtype, device, make)
 
 
 class _SpectralDot(torch.autograd.Function):
@@ -315,15 +333,32 @@ def _sinc_pi(y: torch.Tensor) -> torch.Tensor:
     return torch.where(small, series, torch.sin(ys) / ys)
 
 
-def filter_table(calculator, cell: torch.Tensor, ns) -> torch.Tensor:
+def filter_table(calculator, cell: torch.Tensor, ns, geom=None) -> torch.Tensor:
     """G(k) on the rfft half grid as a differentiable function of the cell, in float64: ``kernel_from_k_sq(|k|^2)`` (PME,
     ``lib/kspace_filter.py:97-120``), divided by the squared Fourier transform of the charge assignment function for P3M
     (mode 0: ``prod_d sinc(k_d h_d / 2 pi)^(2 n)`` with h_d = |a_d| / n_d, zero where that vanishes; ``:293-329,349-361``)."""
+    from .calculators import _reciprocal_and_det
+
     c64 = cell.to(torch.float64)
-    k = lib.generate_kvectors_for_mesh(c64, ns)
+    if geom is None:
+        k = lib.generate_kvectors_for_mesh(c64, ns)
+    else:  # the same grid (lib/kvectors.py:77-102) from cached integer frequencies and a cross-product inverse: no LU
+        # factorisation per call (whose workspace handling is not capturable into a HIP graph)
+        def freq(n, half):
+            f = torch.arange(n // 2 + 1 if half else n, device=cell.device)
+            if not half:
+                f = torch.where(f < (n + 1) // 2, f, f - n)
+            return f.to(torch.float64)
+
+        fx = _constant(geom, "fx", torch.float64, cell.device, lambda: freq(ns[0], False))
+        fy = _constant(geom, "fy", torch.float64, cell.device, lambda: freq(ns[1], False))
+        fz = _constant(geom, "fz", torch.float64, cell.device, lambda: freq(ns[2], True))
+        recip = (2 * torch.pi) * _reciprocal_and_det(c64)[0]
+        k = fx[:, None, None, None] * recip[0] + fy[None, :, None, None] * recip[1] + fz[None, None, :, None] * recip[2]
     G = calculator.potential.kernel_from_k_sq((k * k).sum(dim=-1))
     if calculator._scheme == _lib.P3M:
-        nst = torch.tensor([float(n) for n in ns], dtype=torch.float64, device=cell.device)
+        nst = (_mesh_sizes(geom, torch.float64, cell.device) if geom is not None else
+               torch.tensor([float(n) for n in ns], dtype=torch.float64, device=cell.device))
         kh = k * (torch.linalg.norm(c64, dim=1) / nst)
         U2 = torch.prod(_sinc_pi(0.5 * kh), dim=-1) ** (2 * calculator.interpolation_nodes)
         dead = U2 == 0
@@ -363,8 +398,8 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
     elif pot._exponent_int() == 1 and pot.exclusion_radius is None:
         # 1/r - erf(r / sigma sqrt 2) / r in one piece (potentials/coulomb.py:98-120): four elementwise operations on the pair
         # list instead of the generic incomplete-gamma expressions' eighty, each of which autograd keeps a (P,) tensor for
-        bare = pot.prefactor.to(neighbor_distances.device) * torch.erfc(
-            neighbor_distances / (pot.smearing.to(neighbor_distances.device) * 2.0**0.5)) / neighbor_distances
+        sm, pref, _ = pot._host_params()  # Python floats (one copy per parameter set): no device copy per call
+        bare = pref * torch.erfc(neighbor_distances / (sm * 2.0**0.5)) / neighbor_distances
         if pair_mask is not None:
             bare = bare * pair_mask
     else:
@@ -429,9 +464,8 @@ def _mesh_kspace(calculator, charges, cell, positions, inv_cell) -> torch.Tensor
     dtype = charges.dtype
     geom = _geometry(calculator, cell)
     ns = geom.ns
-    nst = torch.tensor([float(n) for n in ns], dtype=dtype, device=positions.device)
-    u = nst * (positions @ inv_cell)
-    G = filter_table(calculator, cell, ns).to(dtype)
+    u = _mesh_sizes(geom, dtype, positions.device) * (positions @ inv_cell)
+    G = filter_table(calculator, cell, ns, geom).to(dtype)
     zero = (0, 0, 0)
     rho = _Spread.apply(u, charges, geom, zero)
     phi = _Convolve.apply(rho, G, geom)

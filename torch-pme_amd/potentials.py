@@ -271,8 +271,8 @@ class _PowerLawPotential(Potential):
         evaluate the same expression in ``mipme_slab_forward``; this method is the inspectable tensor form.)"""
         if self._p != 1:  # the slab term exists for 1/r only (`potentials/inversepowerlaw.py:166-169`)
             return self.prefactor * torch.zeros_like(charges)
-        if periodic is None:
-            periodic = torch.ones(3, dtype=torch.bool, device=charges.device)
+        if periodic is None:  # fully periodic: no term (and no device round trip to find that out)
+            return self.prefactor * torch.zeros_like(charges)
         flags = [bool(v) for v in periodic.tolist()]
         if sum(flags) != 2:
             return self.prefactor * torch.zeros_like(charges)
