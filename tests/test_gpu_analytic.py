@@ -500,6 +500,21 @@ def test_auto_mode_with_inputs_that_depend_on_each_other():
         assert relmax(a_, b_) < 1e-10
 
 
+def test_example_fits_charges_to_forces():
+    """examples/fit_charges_to_forces.py: L-BFGS on a force loss (second derivatives through the calculator in "auto" mode)
+    recovers the hidden charge difference of two species from P3M forces."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import fit_charges_to_forces
+
+    info = fit_charges_to_forces.run(n_side=6, steps=30)
+    assert info["last_loss"] < 1e-12 * info["first_loss"], info
+    assert abs(info["charge_difference"] - info["charge_difference_true"]) < 1e-6, info
+    assert info["relative_force_residual"] < 1e-12, info
+
+
 def test_unsupported_options_say_so():
     calc = tpa.EwaldCalculator(tpa.CoulombPotential(smearing=1.0), lr_wavelength=1.5)
     t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float64)  # noqa: E731
