@@ -53,6 +53,16 @@ class Calculator(torch.nn.Module):
         self._calculator = self._base_calculator(*args, **kwargs)
         self.fuse_distances = bool(fuse_distances)
 
+    @property
+    def double_backward(self):
+        """``None`` | ``"auto"`` | ``"analytic"`` | ``"finite-difference"``: see :attr:`torchpme_amd.Calculator.double_backward`
+        (second derivatives through the calculator: training on forces with learned charges)."""
+        return self._calculator.double_backward
+
+    @double_backward.setter
+    def double_backward(self, mode):
+        self._calculator.double_backward = mode
+
     @staticmethod
     def _validate_compute_parameters(system, neighbors) -> None:
         values = neighbors.values
