@@ -39,7 +39,7 @@ def wall_ms(fn, n, warm=2):
 
 
 out = {"workload": w.name, "n_atoms": w.n_atoms, "n_pairs": w.n_pairs, "dtype": w.dtype}
-for mode in (None, "analytic"):
+for mode in ((None, "analytic") if os.environ.get("MIPME_TIME_ANALYTIC_CHILD") != "graph" else ()):
     calc = Calc(pot, mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order)
     calc.double_backward = mode
     theta = torch.ones((), dtype=dt, device=dev, requires_grad=True)
@@ -71,4 +71,39 @@ for mode in (None, "analytic"):
         out["loss"], out["dloss_dtheta"] = float(loss.detach()), float(theta.grad)
         # E is quadratic in theta, F linear, loss quadratic: d loss / d theta = 2 loss / theta at theta = 1 ... times 2
         out["dloss_dtheta_expected"] = 4.0 * float(loss.detach())
+# The same training step captured into a HIP graph (torch.cuda.graph): the eager step is ~400 launches and bound by the host.
+# In a child process (a failed capture must not take the eager numbers with it).
+if os.environ.get("MIPME_TIME_ANALYTIC_CHILD") == "graph":
+    calc = Calc(pot, mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order)
+    calc.double_backward = "analytic"
+    theta = torch.ones((), dtype=dt, device=dev, requires_grad=True)
+    pos = pos0.clone().requires_grad_(True)
+
+    def body():
+        q = q0 * theta
+        d = tpa.pair_distances(pos, pairs, cell, shifts)
+        (g,) = torch.autograd.grad((q * calc(q, cell, pos, pairs, d)).sum(), pos, create_graph=True)
+        loss = (g * g).sum()
+        return torch.stack([loss.detach(), torch.autograd.grad(loss, theta)[0]])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ref = body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res = body()
+    ms = wall_ms(graph.replay, 20)
+    print("GRAPH " + json.dumps({"force_loss_step_graph_ms": round(ms, 3), "loss": float(res[0]), "dloss_dtheta": float(res[1]),
+                                 "eager_loss": float(ref[0])}))
+    sys.exit(0)
+import subprocess  # noqa: E402
+
+child = subprocess.run(["timeout", "150", sys.executable, os.path.abspath(__file__), name], capture_output=True, text=True,
+                       env=dict(os.environ, MIPME_TIME_ANALYTIC_CHILD="graph"))
+lines = [ln for ln in child.stdout.splitlines() if ln.startswith("GRAPH ")]
+out["graph"] = json.loads(lines[-1][6:]) if lines else {"error": f"rc {child.returncode}: " + child.stderr.strip()[-200:]}
 print(json.dumps(out))
