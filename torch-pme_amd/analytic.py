@@ -395,11 +395,16 @@ def potentials(calculator, charges, cell, positions, neighbor_indices, neighbor_
         bare = pot.from_dist(neighbor_distances, pair_mask)
         if pot.exclusion_radius is not None:
             bare = bare * (1 - pot.f_cutoff(neighbor_distances, pair_mask))
-    elif pot._exponent_int() == 1 and pot.exclusion_radius is None:
-        # 1/r - erf(r / sigma sqrt 2) / r in one piece (potentials/coulomb.py:98-120): four elementwise operations on the pair
-        # list instead of the generic incomplete-gamma expressions' eighty, each of which autograd keeps a (P,) tensor for
-        sm, pref, _ = pot._host_params()  # Python floats (one copy per parameter set): no device copy per call
-        bare = pref * torch.erfc(neighbor_distances / (sm * 2.0**0.5)) / neighbor_distances
+    elif pot.exclusion_radius is None:
+        # v_SR = (1 - P(p/2, x)) / d^p = Q(p/2, x) / d^p, x = d^2 / 2 sigma^2, in ONE piece: erfc(sqrt x) (+ a finite sum) for odd p,
+        # e^-x times a finite sum for even p (potentials/coulomb.py:98-120, potentials/inversepowerlaw.py:72-107 form it as the
+        # difference 1/d^p - P/d^p).  A handful of elementwise operations on the pair list instead of the incomplete-gamma
+        # series' eighty -- autograd keeps a (P,) tensor for each -- and no cancellation at short distances.
+        from .potentials import _reg_upper_gamma
+
+        sm, pref, p = pot._host_params()  # Python floats (one copy per parameter set): no device copy per call
+        d = neighbor_distances
+        bare = pref * _reg_upper_gamma(p, d * d * (0.5 / (sm * sm))) / (d if p == 1 else d**p)
         if pair_mask is not None:
             bare = bare * pair_mask
     else:
