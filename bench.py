@@ -274,10 +274,11 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # lane has two full entries -- eight of a row's ten at cfg3 -- and the masked one (38.5) for the tails: 34.5 on average.
 PAIR_BODY_VALU = {("f32", 1): (34.5, 3), ("f32", 6): (33.5, 2), ("f64", 1): (91, 1)}
 # What the hardware counters say about the whole launch (rows AND bricks, at the clock it actually runs at): VALUBusy =
-# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_c_sq_counters.txt (cfg3, f32).
-VALU_BUSY_PMC = {"water": {"valu_busy": 0.81, "valu_instructions_per_launch": 10.28e6, "sq_clock_GHz": 1.94,
-                           "source": "profiles/r04_c_sq_counters.txt (SQ_ACTIVE_INST_VALU 337102, SQ_BUSY_CYCLES 51851, "
-                                     "SQ_INSTS_VALU 321360 per shader engine, 32 engines)"}}
+# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_h_sq_counters.txt (cfg3, f32).
+VALU_BUSY_PMC = {"water": {"valu_busy": 0.79, "valu_instructions_per_launch": 9.72e6, "sq_clock_GHz": 1.97,
+                           "source": "profiles/r04_h_sq_counters.txt (SQ_ACTIVE_INST_VALU 319625, SQ_BUSY_CYCLES 50633, "
+                                     "SQ_INSTS_VALU 303883 per shader engine, 32 engines; before the unmasked main loop of the "
+                                     "pair body: 337102 / 51851 / 321360 = 0.81, 10.28 M, profiles/r04_c_sq_counters.txt)"}}
 
 
 def valu_roofline(w, kernel: str, kernel_ms: float):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 405
+#define MIPME_VERSION 406
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -119,6 +119,10 @@ int mipme_spread_jet(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t 
                      int kx, int ky, int kz, void* mesh_out);
 int mipme_gather_jet(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* u, const void* mesh_in,
                      int kx, int ky, int kz, void* out);
+/* out[i,c,d] = the gather of orders (kx,ky,kz) + e_d for d = x, y, z in one walk over the stencil (N,C,3): what the derivative
+ * of a spread or a gather with respect to u needs; every order + 1 must stay within 0..3. */
+int mipme_gather_jet3(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* u, const void* mesh_in,
+                      int kx, int ky, int kz, void* out);
 /* out[i,c] = sum_p weights[p] x[j_p,c]  (the index_add_ of _compute_rspace, calculators/calculator.py:70-84, with the bare
  * potentials as an input).  mode 0: half list (both directions), 1: full list (i <- j), 2: full list transposed (j <- i, the
  * adjoint of mode 1).  Zeroes `out` (n_atoms, C) first. */

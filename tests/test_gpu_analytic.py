@@ -188,6 +188,13 @@ def test_mesh_primitives_gradcheck(scheme, order):
     assert torch.autograd.gradcheck(lambda a, b: analytic._Gather.apply(a, b, geom, zero), (u, phi), **kw)
     assert torch.autograd.gradgradcheck(lambda a, b: analytic._Gather.apply(a, b, geom, zero), (u, phi), **kw)
     assert torch.autograd.gradgradcheck(lambda a, b: analytic._Spread.apply(a, b, geom, zero), (u, x), **kw)
+    # the three first-derivative gathers of one launch against the three single ones, and their own derivatives
+    g3 = analytic._GatherGrad.apply(u, phi, geom, zero)
+    for d, k in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+        assert relmax(g3[:, :, d].detach().cpu(), analytic._Gather.apply(u, phi, geom, k).detach().cpu()) < 1e-13
+    assert torch.autograd.gradcheck(lambda a, b: analytic._GatherGrad.apply(a, b, geom, zero), (u, phi), **kw)
+    if order > 3:  # (third derivatives of the weights: quadratic pieces have none)
+        assert torch.autograd.gradgradcheck(lambda a, b: analytic._GatherGrad.apply(a, b, geom, zero), (u, phi), **kw)
     lin = dict(eps=1e-3, atol=1e-6, rtol=1e-6, nondet_tol=1e-10)  # a linear map: no truncation error, less round-off
     assert torch.autograd.gradcheck(lambda a: analytic._Convolve.apply(a, G, geom), (phi,), **lin)
     assert torch.autograd.gradgradcheck(lambda a: analytic._Convolve.apply(a, G, geom), (phi,), **lin)

@@ -36,7 +36,7 @@ EXPORTS = (
     "mipme_frames_table_bytes", "mipme_frames_table_build", "mipme_frames_forward", "mipme_frames_backward",
     "mipme_scaled_match", "mipme_scaled_match_work", "mipme_scaled_match_wide", "mipme_md_supported", "mipme_md_lists_ints", "mipme_md_rebin", "mipme_md_step", "mipme_set_skip_flag", "mipme_energy_select", "mipme_energy_select_sum", "mipme_energy_select_contract",
     "mipme_kfilter_build_deriv", "mipme_cell_tail_work", "mipme_values_equal", "mipme_checksum", "mipme_checksum_words",
-    "mipme_spread_jet", "mipme_gather_jet", "mipme_pair_sum", "mipme_pair_sum_rows", "mipme_pair_dot", "mipme_pair_diff", "mipme_pair_scatter",
+    "mipme_spread_jet", "mipme_gather_jet", "mipme_gather_jet3", "mipme_pair_sum", "mipme_pair_sum_rows", "mipme_pair_dot", "mipme_pair_diff", "mipme_pair_scatter",
 )
 
 
@@ -232,6 +232,7 @@ def _declare(lib):
         "mipme_gather": [vp, ci, MP, i64, vp, vp, vp],
         "mipme_spread_jet": [vp, ci, MP, i64, vp, vp, ci, ci, ci, vp],
         "mipme_gather_jet": [vp, ci, MP, i64, vp, vp, ci, ci, ci, vp],
+        "mipme_gather_jet3": [vp, ci, MP, i64, vp, vp, ci, ci, ci, vp],
         "mipme_pair_sum": [vp, ci, ci, i64, i64, ci, vp, vp, vp, ci, vp],
         "mipme_pair_sum_rows": [vp, ci, i64, ci, vp, vp, vp, vp, ci, vp],
         "mipme_pair_dot": [vp, ci, ci, i64, ci, vp, vp, vp, ci, vp],

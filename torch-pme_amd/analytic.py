@@ -74,10 +74,41 @@ class _Spread(torch.autograd.Function):
         geom, k = ctx.geom, ctx.k
         gu = gx = None
         if ctx.needs_input_grad[0]:
-            gu = torch.stack([(x * _Gather.apply(u, g, geom, _bump(k, d))).sum(dim=1) for d in range(3)], dim=1)
+            gu = (x.unsqueeze(-1) * _GatherGrad.apply(u, g, geom, k)).sum(dim=1)
         if ctx.needs_input_grad[1]:
             gx = _Gather.apply(u, g, geom, k)
         return gu, gx, None, None
+
+
+class _GatherGrad(torch.autograd.Function):
+    """``out[i, c, d] = gather(u, phi; k + e_d)[i, c]`` for d = x, y, z in one launch: what the derivatives of spread and
+    gather with respect to ``u`` are made of.  Its own derivatives are the same primitives one order up."""
+
+    @staticmethod
+    def forward(ctx, u, phi, geom, k):
+        for d in range(3):
+            _bump(k, d)  # (raises beyond third order)
+        uc, pc = u.detach().contiguous(), phi.detach().contiguous()
+        n_ch, n = pc.shape[0], uc.shape[0]
+        out = torch.empty((n, n_ch, 3), dtype=pc.dtype, device=pc.device)
+        md = geom.desc(n_ch)
+        with _lib.on_device(pc.device):
+            _lib.check(_lib.load().mipme_gather_jet3(_stream(pc), _lib.dtype_code(pc.dtype), C.byref(md), n, uc.data_ptr(),
+                                                     pc.data_ptr(), k[0], k[1], k[2], out.data_ptr()))
+        ctx.save_for_backward(u, phi)
+        ctx.geom, ctx.k = geom, k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):  # g: (N, C, 3)
+        u, phi = ctx.saved_tensors
+        geom, k = ctx.geom, ctx.k
+        gu = gphi = None
+        if ctx.needs_input_grad[0]:
+            gu = sum((g[:, :, d].unsqueeze(-1) * _GatherGrad.apply(u, phi, geom, _bump(k, d))).sum(dim=1) for d in range(3))
+        if ctx.needs_input_grad[1]:
+            gphi = sum(_Spread.apply(u, g[:, :, d], geom, _bump(k, d)) for d in range(3))
+        return gu, gphi, None, None
 
 
 class _Gather(torch.autograd.Function):
@@ -100,7 +131,7 @@ class _Gather(torch.autograd.Function):
         geom, k = ctx.geom, ctx.k
         gu = gphi = None
         if ctx.needs_input_grad[0]:
-            gu = torch.stack([(g * _Gather.apply(u, phi, geom, _bump(k, d))).sum(dim=1) for d in range(3)], dim=1)
+            gu = (g.unsqueeze(-1) * _GatherGrad.apply(u, phi, geom, k)).sum(dim=1)
         if ctx.needs_input_grad[1]:
             gphi = _Spread.apply(u, g, geom, k)
         return gu, gphi, None, None
