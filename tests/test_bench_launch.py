@@ -33,7 +33,7 @@ def test_gpus_flag_spawns_ranks():
     assert out["parallelism"]["n_ranks"] == 2
     assert len(out["parallelism"]["per_rank_ms_per_step"]) == 2
     assert out["energies_gathered"] == 4  # 2 ranks x 2 frames through the one all-gather
-    assert out["ms_per_step"] == pytest.approx(max(out["parallelism"]["per_rank_ms_per_step"]), rel=1e-6)
+    assert out["ms_per_step"] == pytest.approx(max(out["parallelism"]["per_rank_ms_per_step"]), rel=1e-4)  # (the per-rank values are rounded to six decimals in the line)
     assert out["steps"] == 3 and out["warmup"] == 1
 
 
