@@ -503,6 +503,9 @@ static __device__ long long g_rows_phase[8 * 1024];
 #define MIPME_ROWS_PHASE(k, wait)
 #endif
 
+#ifndef MIPME_ROWS_UNMASKED
+#define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed fp32 and the fp64 bodies with its tail selects (the form before round 4's end)
+#endif
 template <int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
   static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
@@ -566,7 +569,10 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   double cg[CELL ? 9 : 1];
 #pragma unroll
   for (int k = 0; k < (CELL ? 9 : 1); ++k) cg[k] = 0.0;
-  for (int eA = beg + sub; eA - sub < end; eA += 2 * kRowLanes) {
+  // (MASKED / unmasked iterations: see the packed fp32 body below)
+  int eA = beg + sub;
+  auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int eB = eA + kRowLanes;
     const int oA = int((wA & kAtomMask) << 5), oB = int((wB & kAtomMask) << 5);
     const d2v pAxy = llvm_raw_buffer_load_d2(rec_rs, oA, 0, 0), pAzq = llvm_raw_buffer_load_d2(rec_rs, oA + 16, 0, 0);
@@ -582,8 +588,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     const double vx[2] = {(pAxy.x - ax) + sA.x, (pBxy.x - ax) + sB.x};
     const double vy[2] = {(pAxy.y - ay) + sA.y, (pBxy.y - ay) + sB.y};
     const double vz[2] = {(pAzq.x - az) + sA.z, (pBzq.x - az) + sB.z};
-    const double sv[2] = {eA < end ? pAzq.y : 0.0, eB < end ? pBzq.y : 0.0};
-    const double sp[2] = {eA < pot_end ? sv[0] : 0.0, eB < pot_end ? sv[1] : 0.0};
+    const double sv[2] = {(!MASKED || eA < end) ? pAzq.y : 0.0, (!MASKED || eB < end) ? pBzq.y : 0.0};
+    const double sp[2] = {(!MASKED || eA < pot_end) ? sv[0] : 0.0, (!MASKED || eB < pot_end) ? sv[1] : 0.0};
     double d2[2], inv[2], x[2], e[2], y[2], Q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) d2[u] = __builtin_fmax(__builtin_fma(vz[u], vz[u], __builtin_fma(vy[u], vy[u], vx[u] * vx[u])), 1e-30);
@@ -601,7 +607,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     }
     exp_neg_fast2(x, e);
     constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
-    const bool any_cross = CELL && __builtin_amdgcn_ballot_w64((eA < end && codeA != kCentre) || (eB < end && codeB != kCentre)) != 0;
+    const bool any_cross = CELL && __builtin_amdgcn_ballot_w64(((!MASKED || eA < end) && codeA != kCentre) ||
+                                                               ((!MASKED || eB < end) && codeB != kCentre)) != 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
 #pragma unroll
@@ -613,19 +620,28 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       fx = __builtin_fma(sc, vx[u], fx);
       fy = __builtin_fma(sc, vy[u], fy);
       fz = __builtin_fma(sc, vz[u], fz);
-      if (CELL && any_cross) {  // (wave-uniform: see the packed body; sc = -w v'/d here: the sign is restored below)
+      if constexpr (CELL) {
+      if (any_cross) {  // (wave-uniform: see the packed body; sc = -w v'/d here: the sign is restored below)
         const AtomRecord<double>& sh = u == 0 ? sA : sB;
         const double tx = sc * vx[u], ty = sc * vy[u], tz = sc * vz[u];
         cg[0] = __builtin_fma(sh.x, tx, cg[0]); cg[1] = __builtin_fma(sh.x, ty, cg[1]); cg[2] = __builtin_fma(sh.x, tz, cg[2]);
         cg[3] = __builtin_fma(sh.y, tx, cg[3]); cg[4] = __builtin_fma(sh.y, ty, cg[4]); cg[5] = __builtin_fma(sh.y, tz, cg[5]);
         cg[6] = __builtin_fma(sh.z, tx, cg[6]); cg[7] = __builtin_fma(sh.z, ty, cg[7]); cg[8] = __builtin_fma(sh.z, tz, cg[8]);
       }
+      }
     }
 #ifdef MIPME_WG_TIMELINE
     if (eA == beg + sub) MIPME_ROWS_PHASE(3, false);
     if (eA == beg + sub + 2 * kRowLanes) MIPME_ROWS_PHASE(4, false);
 #endif
+    eA += 2 * kRowLanes;
+  };
+#if MIPME_ROWS_UNMASKED
+  if (!args.full) {  // uniform
+    while (__builtin_amdgcn_ballot_w64(eA + kRowLanes < end) == ~0ull) iteration(std::false_type{});
   }
+#endif
+  while (eA - sub < end) iteration(std::true_type{});
   MIPME_ROWS_PHASE(5, false);
   if constexpr (CELL) {
     if (args.cpart) {
@@ -660,9 +676,6 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   MIPME_ROWS_PHASE(6, true);
 }
 
-#ifndef MIPME_ROWS_UNMASKED
-#define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed body with its tail selects (the form before round 4's end)
-#endif
 #if MIPME_ROW_LANES == 16
 template <int PFAST, int BS, bool CELL = false>
 __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args, unsigned block,
