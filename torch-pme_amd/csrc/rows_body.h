@@ -66,6 +66,28 @@ __device__ __forceinline__ T row_sum(T v) {
   return v;
 }
 
+// The sums at the end of the packed / fp64 row bodies (16 lanes per row): DPP + readlane, or the ds_bpermute shuffles they
+// replaced (-DMIPME_ROWS_SHUFFLE_SUMS=1: A/B builds only)
+#ifndef MIPME_ROWS_SHUFFLE_SUMS
+#define MIPME_ROWS_SHUFFLE_SUMS 0
+#endif
+template <typename T>
+__device__ __forceinline__ T body_row_sum(T v) {
+#if MIPME_ROWS_SHUFFLE_SUMS
+  return row_sum(v);
+#else
+  return row16_sum_dpp(v);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T body_wave_sum(T v) {
+#if MIPME_ROWS_SHUFFLE_SUMS
+  return wave_sum(v);
+#else
+  return wave_sum_dpp(v);
+#endif
+}
+
 __device__ __forceinline__ int unpack8(int word, int k) { return (word << (24 - 8 * k)) >> 24; }
 
 enum FusedMode {
@@ -653,21 +675,23 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       }
     }
   }
-  pot = row_sum(pot);
+  // (row and wave sums through DPP / readlane: the shuffle forms are ds_bpermute, six LDS operations and their index arithmetic
+  // per step -- 28 of them per wave were a quarter of the vector instructions of a wave's ten loop iterations)
+  pot = body_row_sum(pot);
   if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.0) + 0.5 * pot;
   if (args.epart) {  // see the generic body
     const bool mine = sub == 0 && valid;
-    const double e1 = wave_sum(mine ? qa * (0.5 * pot) : 0.0);
-    const double e2 = wave_sum(mine ? qa * qa : 0.0);
+    const double e1 = body_wave_sum(mine ? qa * (0.5 * pot) : 0.0);
+    const double e2 = body_wave_sum(mine ? qa * qa : 0.0);
     if ((threadIdx.x & 63) == 0) {
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
       args.epart[2 * w] = e1;
       args.epart[2 * w + 1] = e2;
     }
   }
-  fx = row_sum(fx);
-  fy = row_sum(fy);
-  fz = row_sum(fz);
+  fx = body_row_sum(fx);
+  fy = body_row_sum(fy);
+  fz = body_row_sum(fz);
   if (sub == 0 && valid) {
     force[3 * a] = fx;
     force[3 * a + 1] = fy;
@@ -827,20 +851,21 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
       }
     }
   }
-  const float pot = row_sum(pot2.x + pot2.y);
+  // (DPP / readlane sums: see the fp64 body)
+  const float pot = body_row_sum(pot2.x + pot2.y);
   if (sub == 0 && valid) out[a] = (args.accumulate ? out[a] : 0.f) + 0.5f * pot;
   if (args.epart) {  // see the generic body
     const bool mine = sub == 0 && valid;
-    const float e1 = wave_sum(mine ? qa * (0.5f * pot) : 0.f);
-    const float e2 = wave_sum(mine ? qa * qa : 0.f);
+    const float e1 = body_wave_sum(mine ? qa * (0.5f * pot) : 0.f);
+    const float e2 = body_wave_sum(mine ? qa * qa : 0.f);
     if ((threadIdx.x & 63) == 0) {
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
       args.epart[2 * w] = double(e1);
       args.epart[2 * w + 1] = double(e2);
     }
   }
-  const float fx = row_sum(fxy.x), fy = row_sum(fxy.y);
-  fz = row_sum(fz);
+  const float fx = body_row_sum(fxy.x), fy = body_row_sum(fxy.y);
+  fz = body_row_sum(fz);
   if (sub == 0 && valid) {
     force[3 * a] = fx;
     force[3 * a + 1] = fy;
