@@ -484,6 +484,31 @@ __device__ __forceinline__ void fma_row8(T (&acc)[BRICK], T w, const T (&row)[BR
   }
 }
 
+#ifdef MIPME_WG_TIMELINE  // measurement builds only (tools/wg_timeline.py): when and where every workgroup of the launch ran
+__device__ long long g_wg_timeline[4 * 16384];
+#define MIPME_WG_STAMP(k)                                                                                   \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
+      g_wg_timeline[blockIdx.x * 4 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();                    \
+      if ((k) == 0) { /* HW_ID (all 32 bits) and XCC_ID (4 bits) */                                         \
+        g_wg_timeline[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);           \
+        g_wg_timeline[blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);           \
+      }                                                                                                     \
+    }                                                                                                       \
+  } while (0)
+__device__ long long g_wg_phase[8 * 1024];
+#define MIPME_WG_PHASE(k)                                                                              \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_phase[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define MIPME_WG_STAMP(k)
+#define MIPME_WG_PHASE(k)
+#endif
+
+#ifndef MIPME_STAGE_SELECT
+#define MIPME_STAGE_SELECT 0  // 1: the staging rows of the brick spread through select chains (A/B builds)
+#endif
 #ifndef MIPME_SPREAD_UC
 #define MIPME_SPREAD_UC 3  // survivors per iteration of the spread's accumulation loop (4 measured 1 % slower, r02_experiments.txt)
 #endif
@@ -593,6 +618,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       glen[p] = bin_count_of(bins, bins.nb, args.from_live);
     }
   }
+  MIPME_WG_PHASE(0);
   if (tid == 0) maxlen = 0;
   __syncthreads();
   if (sub == 0) {
@@ -601,6 +627,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   }
   __syncthreads();
   const int total = maxlen;  // longest of the 27 candidate lists
+  MIPME_WG_PHASE(1);
   constexpr int s0 = stencil_start<N>();
   const int px = lane >> 3, py = lane & 7;  // this lane's (x,y) column of the brick
   const int64_t plane = int64_t(g.ny) * g.nz, M = plane * g.nx;
@@ -639,6 +666,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         }
       }
       __syncthreads();
+      MIPME_WG_PHASE(2);
       const int ns = nsurv;
       if (args.det && ns > 1) {  // rank by counting on the (unique) slot index: the order of the LDS atomics above drops out
         constexpr int PER = (ROUND + THREADS - 1) / THREADS;
@@ -690,6 +718,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
           }
           const T v = val[int64_t(orig) * C + c] * scale;
           const int r3[3] = {rz, rx, ry};
+#if MIPME_STAGE_SELECT
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
 #pragma unroll
@@ -700,8 +729,24 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
               dst[ax * BRICK + k] = ax == 1 ? w * v : w;
             }
           }
+#else
+          // zeros, then the stencil's weights at their places (LDS stores of one lane land in program order): 3 x N conditional
+          // stores instead of 3 x 8 x N selects -- the launch is bound by vector issue and this loop was ~240 instructions per
+          // survivor
+#pragma unroll
+          for (int k = 0; k < SW; ++k) dst[k] = T(0);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+              const int k = r3[ax] + t;
+              if (unsigned(k) < unsigned(BRICK)) dst[ax * BRICK + k] = ax == 1 ? w1[ax][t] * v : w1[ax][t];
+            }
+          }
+#endif
         }
         __syncthreads();
+        MIPME_WG_PHASE(3);
         // C: register accumulation; wave w takes survivors w, w+W, ...; UC survivors per iteration so that their LDS reads
         // overlap (the loop is a chain of dependent LDS reads otherwise).  Per survivor and wave: the z row (wave-uniform
         // address: LDS broadcast), the lane's x and y entries, one product, four packed FMAs -- about ten vector
@@ -730,6 +775,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         __syncthreads();
       }
     }
+    MIPME_WG_PHASE(4);
     // R: sum the waves' partial bricks and write the owned points (the stage is free again: last sync above)
 #pragma unroll
     for (int pz = 0; pz < BRICK; ++pz) part[wave * BRICK_PTS + (px * BRICK + py) * BRICK + pz] = acc[pz];
@@ -743,6 +789,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       if (gx < g.nx && gy < g.ny && gz < g.nz) mesh[c * M + gx * plane + int64_t(gy) * g.nz + gz] = v;
     }
     __syncthreads();
+    MIPME_WG_PHASE(5);
   }
 }
 
@@ -764,27 +811,6 @@ __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_ker
 // and the remaining ones are row workgroups of the VALU-bound pair sum, which fill those issue slots.  The two parts are
 // independent (the pair sum reads the atom records that the binning pass emitted, not the mesh); the gather adds the mesh
 // part to the potentials the pair sum wrote.
-#ifdef MIPME_WG_TIMELINE  // measurement builds only (tools/wg_timeline.py): when and where every workgroup of the launch ran
-__device__ long long g_wg_timeline[4 * 16384];
-#define MIPME_WG_STAMP(k)                                                                                   \
-  do {                                                                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
-      g_wg_timeline[blockIdx.x * 4 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();                    \
-      if ((k) == 0) { /* HW_ID (all 32 bits) and XCC_ID (4 bits) */                                         \
-        g_wg_timeline[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);           \
-        g_wg_timeline[blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);           \
-      }                                                                                                     \
-    }                                                                                                       \
-  } while (0)
-__device__ long long g_wg_phase[8 * 1024];
-#define MIPME_WG_PHASE(k)                                                                              \
-  do {                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_phase[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define MIPME_WG_STAMP(k)
-#define MIPME_WG_PHASE(k)
-#endif
 
 // Register budget of the co-scheduled kernel: 6 waves per SIMD = 3 workgroups per CU (what its LDS allows too) needs <= 80
 // VGPRs -- the allocation granule turns 82 into 88 = 2 workgroups per CU, measured 10 % slower at cfg5; asked for 6 waves the
