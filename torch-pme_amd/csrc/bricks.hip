@@ -81,7 +81,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 //   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
 //         gathers of the forward and by everything in the backward pass.
 struct BinsLayout {
-  size_t snap, over_brick, rec, wts, epart, det, det_sort_bytes, total;
+  size_t snap, over_brick, rec, wts, codes, epart, det, det_sort_bytes, total;
   int cap;
   int64_t slots;  // nb * cap + N
 };
@@ -159,6 +159,7 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.over_brick = off; off += al(sizeof(int) * size_t(N));
   l.rec = off;        off += al(sizeof(int4) * size_t(l.slots));
   l.wts = off;        off += al(wts_stride_rt(m->order, s) * s * size_t(l.slots));  // per slot: see wts_stride
+  l.codes = off;      off += al(size_t(l.slots));  // per slot: which neighbouring bricks the atom's stencil reaches (reach_code)
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.det = off;
@@ -181,7 +182,27 @@ struct BinIndex {
   const int* over_brick;  // home brick of every overflow atom
   int nb, cap;
   int64_t over_base;      // = nb * cap
+  unsigned char* codes = nullptr;  // per brick slot: reach_code of the atom (written by the binning pass, read by the spread's scan)
 };
+
+// Which of its brick's neighbours an atom's stencil reaches, from its position inside the brick: bit 2 d = the lower neighbour
+// along axis d, bit 2 d + 1 = the upper one (a stencil of <= 8 points touches at most two bricks per axis; the last brick of an
+// axis may be narrower than 8: bricks_supported keeps it >= 4 wide).  The spread's candidate scan of a brick then keeps an atom
+// of the neighbour at offset (dx, dy, dz) iff the atom reaches back along every axis with an offset -- one byte load and one
+// compare per candidate instead of its 16-byte record and three wrapped range tests.
+template <int N>
+__device__ __forceinline__ unsigned reach_code(const int (&m)[3], int nx, int ny, int nz) {
+  constexpr int s0 = stencil_start<N>();
+  const int n[3] = {nx, ny, nz};
+  unsigned code = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int i = m[d] & (BRICK - 1), size = min(BRICK, n[d] - (m[d] & ~(BRICK - 1)));
+    code |= (i + s0 < 0 ? 1u : 0u) << (2 * d);
+    code |= (i + s0 + N - 1 >= size ? 2u : 0u) << (2 * d);
+  }
+  return code;
+}
 
 int64_t bins_bytes(const mipme_mesh_t* m, int64_t N, int dtype) {
   if (!bricks_supported(m, dtype)) return 0;
@@ -284,6 +305,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
       atom_rec[i] = r;
     }
     rec[dst] = make_int4(m[0], m[1], m[2], int(i));
+    if (bi.codes && dst < bi.over_base) bi.codes[dst] = (unsigned char)reach_code<N>(m, g.nx, g.ny, g.nz);
   }
   // The 6N weights of an atom go to its slot, anywhere in the bins: written by the atom's own lane that is 6N four-byte stores
   // to 64 different cache lines per instruction.  Transposed through LDS instead: the wave stages its rows, then lane k of a
@@ -537,7 +559,7 @@ static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_ro
   const int waves = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kWaves : SPREAD_WAVES;
   const int round = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kRound : SPREAD_ROUND;
   const size_t region = std::max<size_t>(size_t(waves) * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
-  return real_bytes * region + sizeof(int) * (round + 2) + sizeof(unsigned short) * round;
+  return real_bytes * region + sizeof(int) * (round + 2);
 }
 static inline int spread_stage_rows(int order, size_t real_bytes) {
   for (int rows : {256, 192, 128})
@@ -587,12 +609,11 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   const int region = max(WAVES * BRICK_PTS, stage_rows * SW);
   T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
-  // survivors of a round: slot index (int) and stencil start relative to the brick (3 x 4 signed bits in a uint16 -- the
-  // launch's LDS caps the workgroups per CU of the co-scheduled launch, rows included: 36.6 KB = 4 per CU)
+  // survivors of a round: their slot indices (the launch's LDS caps the workgroups per CU of the co-scheduled launch, rows
+  // included)
   int* sidx = reinterpret_cast<int*>(stage + region);       // [ROUND]
   int& nsurv = sidx[ROUND];
   int& maxlen = sidx[ROUND + 1];
-  unsigned short* srel = reinterpret_cast<unsigned short*>(sidx + ROUND + 2);  // [ROUND]
   int bx, by, bz;
   brick_coords(bg, block, bx, by, bz);
   const int ox = bx * BRICK, oy = by * BRICK, oz = bz * BRICK;
@@ -603,13 +624,17 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
   // normally none)
   const int sub = tid % SPREAD_GROUP;
   int gstart[PASSES], glen[PASSES];
+  unsigned need[PASSES];  // reach_code bits a candidate of this group must have; 0x100: the overflow group (tested by position)
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int grp = p * Shape::kGroupsPerPass + tid / SPREAD_GROUP;
     gstart[p] = 0;
     glen[p] = 0;
+    need[p] = 0x100u;
     if (grp < 27) {
       const int dx = grp / 9 - 1, dy = (grp / 3) % 3 - 1, dz = grp % 3 - 1;
+      // an atom of the neighbour at offset d reaches this brick iff it reaches back: up (bit 1) from below, down (bit 0) from above
+      need[p] = (dx < 0 ? 2u : dx > 0 ? 1u : 0u) | (dy < 0 ? 8u : dy > 0 ? 4u : 0u) | (dz < 0 ? 32u : dz > 0 ? 16u : 0u);
       const int nbr = (wrap1(bx + dx, bg.nbx) * bg.nby + wrap1(by + dy, bg.nby)) * bg.nbz + wrap1(bz + dz, bg.nbz);
       gstart[p] = nbr * bins.cap;
       glen[p] = bin_count_of(bins, nbr, args.from_live);
@@ -641,7 +666,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       // A1: which candidate stencils overlap this brick?  (ROUND candidates per round = list slots)
       constexpr int NC = CPT * PASSES;
       int cidx[NC];
-      int4 crec[NC];
+      unsigned ccode[NC];
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
 #pragma unroll
@@ -650,19 +675,23 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
           cidx[p * CPT + v] = k < glen[p] ? gstart[p] + k : -1;
         }
       }
+      // candidates of the 27 neighbouring bricks: one byte each (reach_code, written by the binning pass); the overflow group
+      // (atoms whose brick was full: normally none) is tested by position as before
 #pragma unroll
-      for (int u = 0; u < NC; ++u) crec[u] = rec[cidx[u] >= 0 ? cidx[u] : 0];
+      for (int u = 0; u < NC; ++u) ccode[u] = (bins.codes && need[u / CPT] != 0x100u) ? bins.codes[cidx[u] >= 0 ? cidx[u] : 0] : 0u;
 #pragma unroll
       for (int u = 0; u < NC; ++u) {
         if (cidx[u] >= 0) {
-          const int rx = rel_start(crec[u].x, s0, ox, g.nx, N);
-          const int ry = rel_start(crec[u].y, s0, oy, g.ny, N);
-          const int rz = rel_start(crec[u].z, s0, oz, g.nz, N);
-          if (rx < BRICK && ry < BRICK && rz < BRICK) {
-            const int dst = atomicAdd(&nsurv, 1);
-            srel[dst] = (unsigned short)((rx & 0xf) | ((ry & 0xf) << 4) | ((rz & 0xf) << 8));
-            sidx[dst] = cidx[u];
+          const unsigned nd = need[u / CPT];
+          bool keep;
+          if (nd != 0x100u && bins.codes) {
+            keep = (ccode[u] & nd) == nd;
+          } else {
+            const int4 cr = rec[cidx[u]];
+            keep = rel_start(cr.x, s0, ox, g.nx, N) < BRICK && rel_start(cr.y, s0, oy, g.ny, N) < BRICK &&
+                   rel_start(cr.z, s0, oz, g.nz, N) < BRICK;
           }
+          if (keep) sidx[atomicAdd(&nsurv, 1)] = cidx[u];
         }
       }
       __syncthreads();
@@ -671,16 +700,13 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
       if (args.det && ns > 1) {  // rank by counting on the (unique) slot index: the order of the LDS atomics above drops out
         constexpr int PER = (ROUND + THREADS - 1) / THREADS;
         int key[PER], rnk[PER];
-        unsigned short rl[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int t = tid + u * THREADS;
           key[u] = 0;
           rnk[u] = 0;
-          rl[u] = 0;
           if (t < ns) {
             key[u] = sidx[t];
-            rl[u] = srel[t];
             int r = 0;
             for (int v = 0; v < ns; ++v) r += sidx[v] < key[u];
             rnk[u] = r;
@@ -689,10 +715,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-          if (tid + u * THREADS < ns) {
-            sidx[rnk[u]] = key[u];
-            srel[rnk[u]] = rl[u];
-          }
+          if (tid + u * THREADS < ns) sidx[rnk[u]] = key[u];
         }
         __syncthreads();
       }
@@ -704,11 +727,11 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         // a lane reads its x and y entries at its own coordinates and everything outside the stencil multiplies by zero.
         if (tid < nst) {
           const int si = sidx[chunk + tid];
-          const int orig = rec[si].w;
           const T* wr = wts + int64_t(si) * wts_stride<N, T>();
           T* dst = stage + tid * SW;
-          const int rel = int(srel[chunk + tid]);
-          const int rx = (rel << 28) >> 28, ry = (rel << 24) >> 28, rz = (rel << 20) >> 28;
+          const int4 sr = rec[si];  // (the scan kept the slot only: where the stencil starts relative to the brick is formed here)
+          const int orig = sr.w;
+          const int rx = rel_start(sr.x, s0, ox, g.nx, N), ry = rel_start(sr.y, s0, oy, g.ny, N), rz = rel_start(sr.z, s0, oz, g.nz, N);
           T w1[3][N];
 #pragma unroll
           for (int t = 0; t < N; ++t) {
@@ -1369,6 +1392,7 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
   v.idx = BinIndex{nullptr, (int*)(b + l.snap), v.over_brick, bg.nb, l.cap, int64_t(bg.nb) * l.cap};
   v.rec = (int4*)(b + l.rec);
   v.wts = (void*)(b + l.wts);
+  v.idx.codes = (unsigned char*)(b + l.codes);
   v.epart = (double*)(b + l.epart);
   return v;
 }
