@@ -758,9 +758,18 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   // entry words one iteration ahead, partner records fetched where they are used (62 VGPRs).  Fetching the records one
   // iteration ahead as well (two register sets alternating, +10 VGPRs) changed nothing measurable: 18.3 vs 18.1 us alone,
   // 27.2 vs 26.6 us inside the co-scheduled launch (profiles/r02_experiments.txt).
-  int off = (beg + sub) * 4;
-  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
-  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+  // Loop bookkeeping in SCALAR registers: every lane advances by the same 2 x 16 entries per iteration, so the lane keeps only
+  // loop-invariant quantities (its byte offset into the entry stream, how many entries its row has from its first one on) and
+  // the running count k32 is wave-uniform -- the entry loads take it as their scalar offset, the tail tests compare against it.
+  // (Was: a per-lane offset and entry index incremented and copied every iteration, 5 of the loop's 68 vector instructions.)
+  const int lane_e0 = beg + sub;
+  const int voff = lane_e0 * 4;
+  const int remA = end - lane_e0;          // entry eA = lane_e0 + k32 is inside the row  <=>  k32 < remA
+  const int remP = pot_end - lane_e0;      // ... feeds the potential (full lists: role-i entries only)
+  const int row_len = end - beg;
+  int k32 = 0;
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, 0));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, 0));
   __syncthreads();  // shift table
   f2v pot2 = f2v{0.f, 0.f}, fxy = f2v{0.f, 0.f};
   float fz = 0.f;
@@ -777,29 +786,41 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   // ALL lanes of the wavefront have both entries inside their rows of a half list -- eight of a row's ten at cfg3 --: the
   // launch is bound by VALU issue (SQ counters: VALUBusy 81 %, profiles/r04_c_sq_counters.txt), and the selects, their compares
   // and the exec-mask loop control were 14 of the 76 vector instructions of an iteration.
-  int eA = beg + sub;
   auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const int eB = eA + kRowLanes;
     const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
     const f4v cRB = llvm_raw_buffer_load_f4(rec_rs, int((wB & kAtomMask) << 4), 0, 0);
-    const AtomRecord<float> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
-    const unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
-    off += 8 * kRowLanes;
-    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
-    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
-    const bool okA = !MASKED || eA < end, okB = !MASKED || eB < end;
+    // shift code -> table row: shift, then ONE shift-and-add onto the table's address (the compiler's own form is shift, mask,
+    // add: the empty asm keeps it from folding the two shifts into shift + mask)
+    unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
+    asm("" : "+v"(codeA));
+    asm("" : "+v"(codeB));
+    const AtomRecord<float> sA = shift_tab[codeA], sB = shift_tab[codeB];
+    k32 += 2 * kRowLanes;
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, 0));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, 0));
+    const int kk = k32 - 2 * kRowLanes;  // (uniform) entries before this iteration
+    const bool okA = !MASKED || kk < remA, okB = !MASKED || kk + kRowLanes < remA;
     const f2v vA = (f2v{cRA.x, cRA.y} - axy) + f2v{sA.x, sA.y};
     const f2v vB = (f2v{cRB.x, cRB.y} - axy) + f2v{sB.x, sB.y};
-    const float zA = (cRA.z - az) + sA.z, zB = (cRB.z - az) + sB.z;
-    const f2v sqA = vA * vA, sqB = vB * vB;
-    const float dA = (sqA.x + sqA.y) + zA * zA, dB = (sqB.x + sqB.y) + zB * zB;
+    // z and the squared distances entry by entry (four scalar + five mixed instructions writing a register pair).  Left to
+    // itself the SLP vectoriser pairs the two entries' z chains and x^2 + y^2 sums through six register moves (the records
+    // arrive as {x, y, z, q} quads, so zA and zB are never neighbours): the empty asm statements cut its search.
+    float zA = (cRA.z - az) + sA.z, zB = (cRB.z - az) + sB.z;
+    asm("" : "+v"(zA));
+    asm("" : "+v"(zB));
+    const f2v Z = f2v{zA, zB};
+    const f2v Z2 = Z * Z;
+    float dA = __builtin_fmaf(vA.x, vA.x, __builtin_fmaf(vA.y, vA.y, Z2.x));
+    float dB = __builtin_fmaf(vB.x, vB.x, __builtin_fmaf(vB.y, vB.y, Z2.y));
+    asm("" : "+v"(dA));
+    asm("" : "+v"(dB));
     const f2v d2 = MASKED ? f2v{okA ? dA : 1.f, okB ? dB : 1.f} : f2v{dA, dB};
     const f2v sv = MASKED ? f2v{okA ? cRA.w : 0.f, okB ? cRB.w : 0.f} : f2v{cRA.w, cRB.w};
     f2v v, dvd;
     fast_rs_eval_pk<PFAST>(c_inv2s2, c1, cpref, d2, v, dvd);
     if constexpr (MASKED)
-      pot2 += f2v{eA < pot_end ? sv.x : 0.f, eB < pot_end ? sv.y : 0.f} * v;
+      pot2 += f2v{kk < remP ? sv.x : 0.f, kk + kRowLanes < remP ? sv.y : 0.f} * v;
     else
       pot2 += sv * v;
     const f2v sc = sv * dvd;
@@ -823,19 +844,18 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
       }
     } else {
       fxy -= sc.x * vA;
-      fz -= sc.x * zA;
       fxy -= sc.y * vB;
-      fz -= sc.y * zB;
+      fz = __builtin_fmaf(-sc.x, zA, fz);
+      fz = __builtin_fmaf(-sc.y, zB, fz);
     }
-    eA += 2 * kRowLanes;
   };
 #if MIPME_ROWS_UNMASKED
   if (!args.full) {  // uniform
     // (a ballot over the whole wavefront: every lane is active here; lanes of rows beyond N have end == beg and fail it)
-    while (__builtin_amdgcn_ballot_w64(eA + kRowLanes < end) == ~0ull) iteration(std::false_type{});
+    while (__builtin_amdgcn_ballot_w64(k32 + kRowLanes < remA) == ~0ull) iteration(std::false_type{});
   }
 #endif
-  while (eA - sub < end) iteration(std::true_type{});
+  while (k32 < row_len) iteration(std::true_type{});
   if constexpr (CELL) {
     if (args.cpart) {  // uniform
       const int64_t w = int64_t(block) * (BS / 64) + (threadIdx.x >> 6);
