@@ -272,7 +272,10 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # included, the fp64 body's rare y >= 6.5 branch excluded; 44.5 and 43.5 for the fp32 bodies while their entry loads were waterfall loops)
 # Round 4: the fp32 bodies run an unmasked main loop (33.5 per entry: 65 + 2 per iteration) for the iterations in which every
 # lane has two full entries -- eight of a row's ten at cfg3 -- and the masked one (38.5) for the tails: 34.5 on average.
-PAIR_BODY_VALU = {("f32", 1): (34.5, 3), ("f32", 6): (33.5, 2), ("f64", 1): (91, 1)}
+# End of round 4: loop bookkeeping in scalar registers, indexed record loads, z / d^2 chains kept scalar -- 54 (1/r) and 52 (1/r^6)
+# vector instructions per unmasked iteration, 63 / 61 per masked one (hipcc -S, spread_rows_kernel<5, float, P, true, false>):
+# 27.9 / 26.9 per entry at eight unmasked iterations in ten; the fp64 body 212 -> 203 per iteration of its masked loop.
+PAIR_BODY_VALU = {("f32", 1): (27.9, 3), ("f32", 6): (26.9, 2), ("f64", 1): (87, 1)}
 # What the hardware counters say about the whole launch (rows AND bricks, at the clock it actually runs at): VALUBusy =
 # 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_h_sq_counters.txt (cfg3, f32).
 VALU_BUSY_PMC = {"water": {"valu_busy": 0.79, "valu_instructions_per_launch": 9.72e6, "sq_clock_GHz": 1.97,

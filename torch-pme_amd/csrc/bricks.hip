@@ -534,6 +534,17 @@ __device__ long long g_wg_phase[8 * 1024];
 #ifndef MIPME_SPREAD_UC
 #define MIPME_SPREAD_UC 3  // survivors per iteration of the spread's accumulation loop (4 measured 1 % slower, r02_experiments.txt)
 #endif
+#ifndef MIPME_SPREAD_PADROWS
+// 1: zero rows behind the staged survivors, so that the accumulation loop reads UC rows at constant offsets without testing for
+// the list's end (-8 vector instructions per iteration).  Measured SLOWER in the binned launches (cfg3 20.65 -> 21.0 us, cfg5
+// 174 -> 178 us, cfg2 17.3 -> 17.65 us: all six row reads of an iteration are then in flight at once on an LDS pipe that is the
+// phase's limit anyway -- ~1.5 KB per survivor and wave); kept as a build option (profiles/r04_experiments.txt).
+#define MIPME_SPREAD_PADROWS 0
+#endif
+#ifndef MIPME_LIVE_PADROWS
+// the same for the live-list spread (live_spread_body), where it measured FASTER: live step 0.0582 -> 0.0566 ms at cfg3
+#define MIPME_LIVE_PADROWS 1
+#endif
 static constexpr int SPREAD_THREADS = 512;
 static constexpr int SPREAD_WAVES = SPREAD_THREADS / 64;
 static constexpr int SPREAD_GROUP = 16;                           // threads per neighbouring brick in the candidate scan
@@ -555,10 +566,13 @@ static constexpr int SPREAD_ROUND = SpreadShape<SPREAD_THREADS>::kRound;
 
 static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize + kErfcxLdsDoubles,
               "the shift table of a row workgroup (4 reals per code) and the fp64 body's erfcx table live in the staging region");
-static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows, bool sparse = false) {
+static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows, bool sparse = false, bool live = false) {
   const int waves = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kWaves : SPREAD_WAVES;
   const int round = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kRound : SPREAD_ROUND;
-  const size_t region = std::max<size_t>(size_t(waves) * BRICK_PTS, size_t(stage_rows) * spread_row_reals(order, real_bytes));
+  // (+ the zero rows behind the staged survivors that the accumulation loop reads instead of testing for the list's end)
+  const size_t region = std::max<size_t>(size_t(waves) * BRICK_PTS,
+                                         size_t(stage_rows + ((live ? MIPME_LIVE_PADROWS : MIPME_SPREAD_PADROWS) ? (MIPME_SPREAD_UC - 1) * waves : 0)) *
+                                             spread_row_reals(order, real_bytes));
   return real_bytes * region + sizeof(int) * (round + 2);
 }
 static inline int spread_stage_rows(int order, size_t real_bytes) {
@@ -606,8 +620,9 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
     if (block == 0) bins.snap[bins.nb] = bin_count_of(bins, bins.nb, true);
   }
   constexpr int SW = 3 * BRICK;  // staged reals per survivor (spread_row_reals)
-  const int region = max(WAVES * BRICK_PTS, stage_rows * SW);
-  T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows][SW] staged weights + value
+  constexpr int PAD_ROWS = MIPME_SPREAD_PADROWS ? (MIPME_SPREAD_UC - 1) * WAVES : 0;  // zero rows behind the staged survivors
+  const int region = max(WAVES * BRICK_PTS, (stage_rows + PAD_ROWS) * SW);
+  T* stage = reinterpret_cast<T*>(smem_raw);                // [stage_rows + PAD_ROWS][SW] staged weights + value
   T* part = stage;                                          // [waves][512] partial bricks (aliases the stage, phase R)
   // survivors of a round: their slot indices (the launch's LDS caps the workgroups per CU of the co-scheduled launch, rows
   // included)
@@ -767,6 +782,10 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
             }
           }
 #endif
+        } else if (PAD_ROWS && tid < nst + PAD_ROWS) {  // zero rows: the accumulation loop runs over them instead of testing for the end
+          T* dst = stage + tid * SW;
+#pragma unroll
+          for (int k = 0; k < SW; ++k) dst[k] = T(0);
         }
         __syncthreads();
         MIPME_WG_PHASE(3);
@@ -778,6 +797,20 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
         const int nstc = __builtin_amdgcn_readfirstlane(nst);
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         for (int sv0 = wave_u; sv0 < nstc; sv0 += WAVES * UC) {
+#if MIPME_SPREAD_PADROWS
+          // (rows sv0 + u * WAVES beyond the last survivor are zero rows: constant offsets from one address, no selects)
+          T wz[UC][BRICK], fx[UC], fy[UC];
+          const T* sw = stage + sv0 * SW;
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            const T* su = sw + u * WAVES * SW;
+            fx[u] = su[BRICK + px];
+            fy[u] = su[2 * BRICK + py];
+            load_row8<T>(su, wz[u]);  // wave-uniform address: LDS broadcast
+          }
+#pragma unroll
+          for (int u = 0; u < UC; ++u) fma_row8<T>(acc, fx[u] * fy[u], wz[u]);
+#else
           T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC];
           bool live[UC];
 #pragma unroll
@@ -794,6 +827,7 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
             wxy[u] = live[u] ? fx[u] * fy[u] : T(0);
             fma_row8<T>(acc, wxy[u], wz[u]);
           }
+#endif
         }
         __syncthreads();
       }
@@ -835,9 +869,13 @@ __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_ker
 // independent (the pair sum reads the atom records that the binning pass emitted, not the mesh); the gather adds the mesh
 // part to the potentials the pair sum wrote.
 
-// Register budget of the co-scheduled kernel: 6 waves per SIMD = 3 workgroups per CU (what its LDS allows too) needs <= 80
-// VGPRs -- the allocation granule turns 82 into 88 = 2 workgroups per CU, measured 10 % slower at cfg5; asked for 6 waves the
-// compiler fits the fp32 / 4-byte-entry kernels into 68-73 without spilling.  Other instantiations are left alone.
+// Register budget of the co-scheduled kernel: since the survivor lists lost their uint16 array the launch's LDS (35 KB) allows
+// FOUR workgroups per CU = 8 waves per SIMD, which needs <= 64 VGPRs.  The fp32 / 4-byte-entry kernels use 58 (asked for "at
+// least 6 waves", i.e. <= 80); one register more than 64 costs a workgroup per CU (measured with a 65-register build: cfg3 20.7
+// -> 22.1 us), and ASKING for 8 waves makes the compiler schedule the bodies more tightly than it has to (20.6 -> 20.8 us,
+// cfg5 174.9 -> 175.2 us): the bound stays at 6, `make vgpr-check` style vigilance is on whoever touches the bodies
+// (hipcc -S, .vgpr_count of spread_rows_kernel<5, float, 1, true, false>).  The variants with the cell sums use 68-72
+// registers (three workgroups per CU).  Other instantiations are left alone.
 // CELL: the row workgroups also form the per-wave cell-gradient sums of the energy step (FusedRowsArgs::cpart; packed fp32 body
 // and fp64 Coulomb body only: rows_cell_supported below)
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
@@ -1699,7 +1737,7 @@ __global__ __launch_bounds__(256) void frames_bin_atoms_kernel(const FrameDev<T>
 }
 
 template <int N, typename T, int PFAST, bool COMPACT>
-__global__ __launch_bounds__(SPREAD_THREADS) void frames_spread_rows_kernel(const FrameDev<T>* __restrict__ table) {
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void frames_spread_rows_kernel(const FrameDev<T>* __restrict__ table) {
   const FrameDev<T>& f = table[blockIdx.y];
   const unsigned n_spread = unsigned(f.bg.nb);
   if (blockIdx.x < n_spread)
@@ -2216,7 +2254,8 @@ __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, 
   const int stage_rows = args.stage_rows;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int SW = 3 * BRICK;
-  T* stage = reinterpret_cast<T*>(smem_raw);  // [stage_rows][SW]
+  constexpr int PAD_ROWS = MIPME_LIVE_PADROWS ? (MIPME_SPREAD_UC - 1) * WAVES : 0;
+  T* stage = reinterpret_cast<T*>(smem_raw);  // [stage_rows + PAD_ROWS][SW]
   T* part = stage;                            // [waves][512] partial bricks (aliases the stage, phase R)
   int bx, by, bz;
   brick_coords(bg, block, bx, by, bz);
@@ -2245,25 +2284,38 @@ __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, 
       // row = [wz | wx * q | wy], each placed on the brick's 8 points of its axis (zero where the stencil has no point)
       const int rz = rel_start(mz, s0, oz, g.nz, N), rx = rel_start(mx, s0, ox, g.nx, N), ry = rel_start(my, s0, oy, g.ny, N);
       T* dst = stage + tid * SW;
+      // zeros, then the stencil's weights at their places (as in spread_brick_body: 3 x N conditional stores, not 3 x 8 x N selects)
 #pragma unroll
-      for (int k = 0; k < BRICK; ++k) {
-        T vz = T(0), vx = T(0), vy = T(0);
+      for (int k = 0; k < SW; ++k) dst[k] = T(0);
 #pragma unroll
-        for (int t = 0; t < N; ++t) {
-          vz = (k - rz == t) ? wz[t] : vz;
-          vx = (k - rx == t) ? wx[t] : vx;
-          vy = (k - ry == t) ? wy[t] : vy;
-        }
-        dst[k] = vz;
-        dst[BRICK + k] = vx * r.w;
-        dst[2 * BRICK + k] = vy;
+      for (int t = 0; t < N; ++t) {
+        if (unsigned(rz + t) < unsigned(BRICK)) dst[rz + t] = wz[t];
+        if (unsigned(rx + t) < unsigned(BRICK)) dst[BRICK + rx + t] = wx[t] * r.w;
+        if (unsigned(ry + t) < unsigned(BRICK)) dst[2 * BRICK + ry + t] = wy[t];
       }
+    } else if (PAD_ROWS && tid < nst + PAD_ROWS) {  // zero rows behind the staged ones (see spread_brick_body)
+      T* dst = stage + tid * SW;
+#pragma unroll
+      for (int k = 0; k < SW; ++k) dst[k] = T(0);
     }
     __syncthreads();
     constexpr int UC = MIPME_SPREAD_UC;
     const int nstc = __builtin_amdgcn_readfirstlane(nst);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int sv0 = wave_u; sv0 < nstc; sv0 += WAVES * UC) {
+#if MIPME_LIVE_PADROWS
+      T wz[UC][BRICK], fx[UC], fy[UC];
+      const T* sw = stage + sv0 * SW;
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        const T* su = sw + u * WAVES * SW;
+        fx[u] = su[BRICK + px];
+        fy[u] = su[2 * BRICK + py];
+        load_row8<T>(su, wz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) fma_row8<T>(acc, fx[u] * fy[u], wz[u]);
+#else
       T wxy[UC], wz[UC][BRICK], fx[UC], fy[UC];
       bool live[UC];
 #pragma unroll
@@ -2280,6 +2332,7 @@ __device__ __forceinline__ void live_spread_body(const LiveSpreadArgs<T>& args, 
         wxy[u] = live[u] ? fx[u] * fy[u] : T(0);
         fma_row8<T>(acc, wxy[u], wz[u]);
       }
+#endif
     }
     __syncthreads();
   }
@@ -2302,7 +2355,7 @@ __host__ __device__ inline unsigned live_home_blocks(int64_t n_atoms, bool xcd) 
   return xcd ? (n + 7u) / 8u * 8u : n;  // a multiple of 8 keeps blockIdx % 8 (the XCD) of everything behind them
 }
 template <int N, typename T, int PFAST, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? 6 : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
+__global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? 6 : 8) : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                         unsigned n_spread) {
   const unsigned n_home = live_home_blocks(sa.n_atoms, sa.bg.xcd), n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
   if (blockIdx.x < n_home) {
@@ -2518,7 +2571,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   const BinsView v = bins_view(m, N, dtype, bins);
   const LiveLists ll = live_view(m, N, lists, nullptr);
   const int stage_rows = spread_stage_rows(m->order, sizeof(T));
-  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows);
+  const size_t lds = spread_lds_bytes(m->order, sizeof(T), stage_rows, false, true);
   LiveSpreadArgs<T> sa;
   sa.g = make_geom(m);
   sa.bg = bg;

@@ -496,6 +496,12 @@ typedef int i4v __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ f4v llvm_raw_buffer_load_f4(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ int llvm_raw_buffer_load_i1(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ f4v llvm_struct_buffer_load_f4(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
+// structured resource: `records` elements of `stride` bytes (indexed loads: address = base + index * stride, range check on the index)
+__device__ __forceinline__ i4v struct_buffer(const void* base, unsigned stride, unsigned records) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return i4v{int(unsigned(a)), int((unsigned(a >> 32) & 0xffffu) | (stride << 16)), int(records), 0x00020000};
+}
 __device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(base);
   return i4v{int(unsigned(a)), int(unsigned(a >> 32) & 0xffffu), int(bytes), 0x00020000};
@@ -513,6 +519,7 @@ __device__ __forceinline__ i4v uniform_rsrc(i4v r) {
 static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(AtomRecord<double>) + sizeof(double) * kErfcxLdsDoubles;
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ d2v llvm_raw_buffer_load_d2(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f64");
+__device__ d2v llvm_struct_buffer_load_d2(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2f64");
 
 #ifdef MIPME_WG_TIMELINE  // measurement builds only (tools/rows_phases.py): clock stamps of the first 1024 row workgroups
 static __device__ long long g_rows_phase[8 * 1024];
@@ -579,11 +586,15 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   const int pot_end = args.full ? mid : 0x7fffffff;
   const int beg = r0, end = valid ? r2 : r0;
   const i4v ent_rs = uniform_rsrc(raw_buffer(args.ent_sh, unsigned(n_entries) * 4u));
-  const i4v rec_rs = uniform_rsrc(raw_buffer(args.rec, unsigned(N) * 32u));
+  const i4v rec_rs = uniform_rsrc(struct_buffer(args.rec, 32u, unsigned(N)));  // (indexed loads: see the packed fp32 body)
   constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
-  int off = (beg + sub) * 4;
-  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
-  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+  // (loop bookkeeping in scalar registers: see the packed fp32 body)
+  const int lane_e0 = beg + sub;
+  const int voff = lane_e0 * 4;
+  const int remA = end - lane_e0, remP = pot_end - lane_e0, row_len = end - beg;
+  int k32 = 0;
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, 0));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, 0));
   MIPME_ROWS_PHASE(1, false);
   __syncthreads();  // shift table + erfcx table
   MIPME_ROWS_PHASE(2, true);
@@ -592,26 +603,28 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
 #pragma unroll
   for (int k = 0; k < (CELL ? 9 : 1); ++k) cg[k] = 0.0;
   // (MASKED / unmasked iterations: see the packed fp32 body below)
-  int eA = beg + sub;
   auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const int eB = eA + kRowLanes;
-    const int oA = int((wA & kAtomMask) << 5), oB = int((wB & kAtomMask) << 5);
-    const d2v pAxy = llvm_raw_buffer_load_d2(rec_rs, oA, 0, 0), pAzq = llvm_raw_buffer_load_d2(rec_rs, oA + 16, 0, 0);
-    const d2v pBxy = llvm_raw_buffer_load_d2(rec_rs, oB, 0, 0), pBzq = llvm_raw_buffer_load_d2(rec_rs, oB + 16, 0, 0);
-    const AtomRecord<double> sA = shift_tab[wA >> kCompactAtomBits], sB = shift_tab[wB >> kCompactAtomBits];
-    const unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
-    off += 8 * kRowLanes;
-    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, off, 0, 0));
-    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, off + 4 * kRowLanes, 0, 0));
+    const int iA = int(wA & kAtomMask), iB = int(wB & kAtomMask);
+    const d2v pAxy = llvm_struct_buffer_load_d2(rec_rs, iA, 0, 0, 0), pAzq = llvm_struct_buffer_load_d2(rec_rs, iA, 16, 0, 0);
+    const d2v pBxy = llvm_struct_buffer_load_d2(rec_rs, iB, 0, 0, 0), pBzq = llvm_struct_buffer_load_d2(rec_rs, iB, 16, 0, 0);
+    unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
+    asm("" : "+v"(codeA));
+    asm("" : "+v"(codeB));
+    const AtomRecord<double> sA = shift_tab[codeA], sB = shift_tab[codeB];
+    const int kk = k32;  // (uniform) entries before this iteration
+    k32 += 2 * kRowLanes;
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, 0));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, 0));
+    const bool okA = !MASKED || kk < remA, okB = !MASKED || kk + kRowLanes < remA;
     // the two entries side by side, operation by operation: each constant of the polynomials then serves two FMAs from the
     // same scalar register pair.  No select on d2 for entries beyond the row's end: they read some valid record (the buffer
     // descriptor bounds the loads), everything stays finite in double, and their weight sv is zero.
     const double vx[2] = {(pAxy.x - ax) + sA.x, (pBxy.x - ax) + sB.x};
     const double vy[2] = {(pAxy.y - ay) + sA.y, (pBxy.y - ay) + sB.y};
     const double vz[2] = {(pAzq.x - az) + sA.z, (pBzq.x - az) + sB.z};
-    const double sv[2] = {(!MASKED || eA < end) ? pAzq.y : 0.0, (!MASKED || eB < end) ? pBzq.y : 0.0};
-    const double sp[2] = {(!MASKED || eA < pot_end) ? sv[0] : 0.0, (!MASKED || eB < pot_end) ? sv[1] : 0.0};
+    const double sv[2] = {okA ? pAzq.y : 0.0, okB ? pBzq.y : 0.0};
+    const double sp[2] = {(!MASKED || kk < remP) ? sv[0] : 0.0, (!MASKED || kk + kRowLanes < remP) ? sv[1] : 0.0};
     double d2[2], inv[2], x[2], e[2], y[2], Q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) d2[u] = __builtin_fmax(__builtin_fma(vz[u], vz[u], __builtin_fma(vy[u], vy[u], vx[u] * vx[u])), 1e-30);
@@ -629,8 +642,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     }
     exp_neg_fast2(x, e);
     constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
-    const bool any_cross = CELL && __builtin_amdgcn_ballot_w64(((!MASKED || eA < end) && codeA != kCentre) ||
-                                                               ((!MASKED || eB < end) && codeB != kCentre)) != 0;
+    const bool any_cross = CELL && __builtin_amdgcn_ballot_w64((okA && codeA != kCentre) || (okB && codeB != kCentre)) != 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
 #pragma unroll
@@ -653,17 +665,16 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       }
     }
 #ifdef MIPME_WG_TIMELINE
-    if (eA == beg + sub) MIPME_ROWS_PHASE(3, false);
-    if (eA == beg + sub + 2 * kRowLanes) MIPME_ROWS_PHASE(4, false);
+    if (kk == 0) MIPME_ROWS_PHASE(3, false);
+    if (kk == 2 * kRowLanes) MIPME_ROWS_PHASE(4, false);
 #endif
-    eA += 2 * kRowLanes;
   };
 #if MIPME_ROWS_UNMASKED
   if (!args.full) {  // uniform
-    while (__builtin_amdgcn_ballot_w64(eA + kRowLanes < end) == ~0ull) iteration(std::false_type{});
+    while (__builtin_amdgcn_ballot_w64(k32 + kRowLanes < remA) == ~0ull) iteration(std::false_type{});
   }
 #endif
-  while (eA - sub < end) iteration(std::true_type{});
+  while (k32 < row_len) iteration(std::true_type{});
   MIPME_ROWS_PHASE(5, false);
   if constexpr (CELL) {
     if (args.cpart) {
@@ -753,7 +764,10 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   const int pot_end = args.full ? mid : 0x7fffffff;  // a full list feeds the potential from role i only
   const int beg = r0, end = valid ? r2 : r0;
   const i4v ent_rs = uniform_rsrc(raw_buffer(args.ent_sh, unsigned(n_entries) * 4u));
-  const i4v rec_rs = uniform_rsrc(raw_buffer(args.rec, unsigned(N) * 16u));
+  // partner records through a STRUCTURED resource (stride 16, indexed loads): the atom number is the address operand as it
+  // stands -- no shift per entry; an index beyond N returns zeros like a raw offset beyond the range does
+  // (tools/buffer_semantics.hip)
+  const i4v rec_rs = uniform_rsrc(struct_buffer(args.rec, 16u, unsigned(N)));
   constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
   // entry words one iteration ahead, partner records fetched where they are used (62 VGPRs).  Fetching the records one
   // iteration ahead as well (two register sets alternating, +10 VGPRs) changed nothing measurable: 18.3 vs 18.1 us alone,
@@ -788,8 +802,8 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   // and the exec-mask loop control were 14 of the 76 vector instructions of an iteration.
   auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const f4v cRA = llvm_raw_buffer_load_f4(rec_rs, int((wA & kAtomMask) << 4), 0, 0);
-    const f4v cRB = llvm_raw_buffer_load_f4(rec_rs, int((wB & kAtomMask) << 4), 0, 0);
+    const f4v cRA = llvm_struct_buffer_load_f4(rec_rs, int(wA & kAtomMask), 0, 0, 0);
+    const f4v cRB = llvm_struct_buffer_load_f4(rec_rs, int(wB & kAtomMask), 0, 0, 0);
     // shift code -> table row: shift, then ONE shift-and-add onto the table's address (the compiler's own form is shift, mask,
     // add: the empty asm keeps it from folding the two shifts into shift + mask)
     unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;
