@@ -532,6 +532,14 @@ static __device__ long long g_rows_phase[8 * 1024];
 #define MIPME_ROWS_PHASE(k, wait)
 #endif
 
+#ifndef MIPME_ENTRY_AUX
+// cache policy of the entry-stream loads of the packed fp32 / fp64 bodies (aux operand of buffer_load; 2 = nt, "non-temporal").
+// The stream is read once per launch next to partner records that are gathered ~300 times each, so marking it non-temporal
+// looked right -- and measured 18 % SLOWER (cfg3 launch 20.9 -> 24.8 us, cfg5 174.8 -> 206.7 us, 1 029 000 atoms 1.08 -> 1.22 ms;
+// profiles/r04_k_ab_nt.txt): a row's 16 lanes take 64 bytes per load, so every 128-byte line of the stream serves two loads, and
+// the hint throws the line away in between.  Default policy.
+#define MIPME_ENTRY_AUX 0
+#endif
 #ifndef MIPME_ROWS_UNMASKED
 #define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed fp32 and the fp64 bodies with its tail selects (the form before round 4's end)
 #endif
@@ -593,8 +601,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
   const int voff = lane_e0 * 4;
   const int remA = end - lane_e0, remP = pot_end - lane_e0, row_len = end - beg;
   int k32 = 0;
-  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, 0));
-  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, 0));
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, MIPME_ENTRY_AUX));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, MIPME_ENTRY_AUX));
   MIPME_ROWS_PHASE(1, false);
   __syncthreads();  // shift table + erfcx table
   MIPME_ROWS_PHASE(2, true);
@@ -614,8 +622,8 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     const AtomRecord<double> sA = shift_tab[codeA], sB = shift_tab[codeB];
     const int kk = k32;  // (uniform) entries before this iteration
     k32 += 2 * kRowLanes;
-    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, 0));
-    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, 0));
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, MIPME_ENTRY_AUX));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, MIPME_ENTRY_AUX));
     const bool okA = !MASKED || kk < remA, okB = !MASKED || kk + kRowLanes < remA;
     // the two entries side by side, operation by operation: each constant of the polynomials then serves two FMAs from the
     // same scalar register pair.  No select on d2 for entries beyond the row's end: they read some valid record (the buffer
@@ -782,8 +790,8 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   const int remP = pot_end - lane_e0;      // ... feeds the potential (full lists: role-i entries only)
   const int row_len = end - beg;
   int k32 = 0;
-  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, 0));
-  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, 0));
+  unsigned wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, 0, MIPME_ENTRY_AUX));
+  unsigned wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, 0, MIPME_ENTRY_AUX));
   __syncthreads();  // shift table
   f2v pot2 = f2v{0.f, 0.f}, fxy = f2v{0.f, 0.f};
   float fz = 0.f;
@@ -811,8 +819,8 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
     asm("" : "+v"(codeB));
     const AtomRecord<float> sA = shift_tab[codeA], sB = shift_tab[codeB];
     k32 += 2 * kRowLanes;
-    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, 0));
-    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, 0));
+    wA = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff, k32 * 4, MIPME_ENTRY_AUX));
+    wB = unsigned(llvm_raw_buffer_load_i1(ent_rs, voff + 4 * kRowLanes, k32 * 4, MIPME_ENTRY_AUX));
     const int kk = k32 - 2 * kRowLanes;  // (uniform) entries before this iteration
     const bool okA = !MASKED || kk < remA, okB = !MASKED || kk + kRowLanes < remA;
     const f2v vA = (f2v{cRA.x, cRA.y} - axy) + f2v{sA.x, sA.y};
