@@ -277,11 +277,12 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # 27.9 / 26.9 per entry at eight unmasked iterations in ten; the fp64 body 212 -> 203 per iteration of its masked loop.
 PAIR_BODY_VALU = {("f32", 1): (27.9, 3), ("f32", 6): (26.9, 2), ("f64", 1): (87, 1)}
 # What the hardware counters say about the whole launch (rows AND bricks, at the clock it actually runs at): VALUBusy =
-# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_h_sq_counters.txt (cfg3, f32).
-VALU_BUSY_PMC = {"water": {"valu_busy": 0.79, "valu_instructions_per_launch": 9.72e6, "sq_clock_GHz": 1.97,
-                           "source": "profiles/r04_h_sq_counters.txt (SQ_ACTIVE_INST_VALU 319625, SQ_BUSY_CYCLES 50633, "
-                                     "SQ_INSTS_VALU 303883 per shader engine, 32 engines; before the unmasked main loop of the "
-                                     "pair body: 337102 / 51851 / 321360 = 0.81, 10.28 M, profiles/r04_c_sq_counters.txt)"}}
+# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_k_sq_counters.txt (cfg3, f32).
+VALU_BUSY_PMC = {"water": {"valu_busy": 0.76, "valu_instructions_per_launch": 7.79e6, "sq_clock_GHz": 1.89,
+                           "source": "profiles/r04_k_sq_counters.txt (SQ_ACTIVE_INST_VALU 259149, SQ_BUSY_CYCLES 42741, "
+                                     "SQ_INSTS_VALU 243408 per shader engine, 32 engines, 22.65 us under the counters; before "
+                                     "the instruction diet of the pair body and of the bricks: 319625 / 50633 / 303883 = 0.79, "
+                                     "9.72 M, profiles/r04_h_sq_counters.txt; round 3's code 10.28 M)"}}
 
 
 def valu_roofline(w, kernel: str, kernel_ms: float):

@@ -541,6 +541,9 @@ __device__ long long g_wg_phase[8 * 1024];
 // phase's limit anyway -- ~1.5 KB per survivor and wave); kept as a build option (profiles/r04_experiments.txt).
 #define MIPME_SPREAD_PADROWS 0
 #endif
+#ifndef MIPME_CELL_WAVES
+#define MIPME_CELL_WAVES 6  // waves per SIMD asked of the co-scheduled kernels that also form the cell sums (68-72 registers)
+#endif
 #ifndef MIPME_LIVE_PADROWS
 // the same for the live-list spread (live_spread_body), where it measured FASTER: live step 0.0582 -> 0.0566 ms at cfg3
 #define MIPME_LIVE_PADROWS 1
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_ker
 // CELL: the row workgroups also form the per-wave cell-gradient sums of the energy step (FusedRowsArgs::cpart; packed fp32 body
 // and fp64 Coulomb body only: rows_cell_supported below)
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                               unsigned n_spread) {
   MIPME_WG_STAMP(0);
   // n_spread bricks (0: a rows-only launch), then the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
@@ -2355,7 +2358,7 @@ __host__ __device__ inline unsigned live_home_blocks(int64_t n_atoms, bool xcd) 
   return xcd ? (n + 7u) / 8u * 8u : n;  // a multiple of 8 keeps blockIdx % 8 (the XCD) of everything behind them
 }
 template <int N, typename T, int PFAST, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? 6 : 8) : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
+__global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? MIPME_CELL_WAVES : 8) : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                         unsigned n_spread) {
   const unsigned n_home = live_home_blocks(sa.n_atoms, sa.bg.xcd), n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
   if (blockIdx.x < n_home) {
