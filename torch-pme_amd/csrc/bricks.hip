@@ -11,6 +11,8 @@
 // Replaces, like mesh.hip, MeshInterpolator.compute_weights / points_to_mesh / mesh_to_points
 // (reference lib/mesh_interpolator.py:303-457).
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -881,18 +883,49 @@ __global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void spread_brick_sparse_ker
 // registers (three workgroups per CU).  Other instantiations are left alone.
 // CELL: the row workgroups also form the per-wave cell-gradient sums of the energy step (FusedRowsArgs::cpart; packed fp32 body
 // and fp64 Coulomb body only: rows_cell_supported below)
+// Block order of the co-scheduled launch.  pattern == 0: all bricks, then all row blocks.  pattern == a > 0 (XCD mapping only):
+// periods of 8 bricks + 8 a row blocks (one brick and a row blocks per XCD) until one kind runs out, then the rest of the other --
+// both kinds keep blockIdx % 8 = slot % 8, so the XCD-contiguous mappings of bricks and rows hold.
+static constexpr unsigned kBrickPatternMin = 2048;  // bricks of a launch from which the interleaved block order is used (two generations)
+struct CoSlot {
+  bool brick;
+  unsigned slot;  // index among the (padded) bricks / row blocks
+};
+__host__ __device__ inline unsigned cosched_periods(unsigned n_pad, unsigned n_rows_pad, unsigned a) {
+  const unsigned nb8 = n_pad >> 3, nr8 = n_rows_pad >> 3, need = (nr8 + a - 1) / a;
+  return nb8 < need ? nb8 : need;
+}
+__host__ __device__ inline unsigned cosched_grid(unsigned n_pad, unsigned n_rows_pad, unsigned a) {
+  if (a == 0) return n_pad + n_rows_pad;
+  const unsigned P = cosched_periods(n_pad, n_rows_pad, a);
+  const unsigned left_b = n_pad - 8u * P, rows_done = 8u * a * P;
+  return P * 8u * (1u + a) + left_b + (n_rows_pad > rows_done ? n_rows_pad - rows_done : 0u);
+}
+__device__ __forceinline__ CoSlot cosched_slot(unsigned b, unsigned n_pad, unsigned n_rows_pad, unsigned a) {
+  if (a == 0) return CoSlot{b < n_pad, b < n_pad ? b : b - n_pad};
+  const unsigned P = cosched_periods(n_pad, n_rows_pad, a), period = 8u * (1u + a);
+  if (b < P * period) {
+    const unsigned p = b / period, r = b - p * period;
+    return r < 8u ? CoSlot{true, 8u * p + r} : CoSlot{false, 8u * a * p + (r - 8u)};
+  }
+  const unsigned rest = b - P * period;
+  return (n_pad >> 3) > P ? CoSlot{true, 8u * P + rest} : CoSlot{false, 8u * a * P + rest};
+}
+
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
-                                                                                              unsigned n_spread) {
+                                                                                              unsigned n_spread, unsigned pattern) {
   MIPME_WG_STAMP(0);
-  // n_spread bricks (0: a rows-only launch), then the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
+  // n_spread bricks (0: a rows-only launch) and the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
   const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
-  if (blockIdx.x < n_pad) {
-    const unsigned b = brick_of(sa.bg, blockIdx.x);
-    if (b < n_spread) spread_brick_body<N, T>(sa, b);
-  } else {
-    const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_pad, n_row_blocks) : blockIdx.x - n_pad;
+  const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
+  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad, pattern);
+  if (cs.brick) {
+    const unsigned b = brick_of(sa.bg, cs.slot);
+    if (cs.slot < n_pad && b < n_spread) spread_brick_body<N, T>(sa, b);
+  } else if (cs.slot < n_rows_pad) {
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
     if (r < n_row_blocks) {
       // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
       extern __shared__ __attribute__((aligned(16))) char smem_rows[];
@@ -1564,27 +1597,43 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       MIPME_LAUNCH_CHECK();
       return MIPME_OK;
     }
-    const unsigned grid = bg.xcd ? pad8(n_spread) + pad8(n_rows_blocks) : n_spread + n_rows_blocks;
+    // Block order.  Launches of one or two generations (cfg3: 512 bricks + 999 row blocks on 1 024 slots) run best with all
+    // bricks first; launches of many generations (cfg5: 4 096 + 8 192) with one brick per `a` row blocks and XCD, a = the ratio
+    // of the two counts, so that the bricks' idle vector slots are filled from the start and neither kind is left over as a
+    // tail: cfg5 175.2 -> 168.5 us, with a = 1 or 3 there 196 / 187 us, any pattern at cfg3 +0.9 us
+    // (profiles/r04_k_ab_pattern.txt).  MIPME_BRICK_PATTERN = 0 (bricks first) or a > 0 overrides.
+    static const int pattern_env = [] { const char* e = getenv("MIPME_BRICK_PATTERN"); return e ? atoi(e) : -1; }();
+    unsigned pattern = 0;
+    if (bg.xcd && n_spread > 0) {
+      if (pattern_env >= 0)
+        pattern = unsigned(pattern_env);
+      else if (n_spread >= kBrickPatternMin) {
+        const double ratio = double(pad8(n_rows_blocks)) / double(pad8(n_spread));
+        const unsigned a = unsigned(ratio + 0.5);
+        if (a >= 1 && std::fabs(ratio - double(a)) <= 0.15 * double(a)) pattern = a;
+      }
+    }
+    const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_rows_blocks), pattern) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
     if (cpart && pfast == 1)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                               ((void)S, spread_rows_kernel<N, T, 1, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     else if (cpart) {
       if constexpr (sizeof(T) == 4)
         MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                                 ((void)S, spread_rows_kernel<N, T, 6, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                                 ((void)S, spread_rows_kernel<N, T, 6, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     } else if (pfast == 1 && compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     else if (pfast == 1)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     else if (compact)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread)));
+                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
