@@ -912,6 +912,27 @@ __device__ __forceinline__ CoSlot cosched_slot(unsigned b, unsigned n_pad, unsig
   return (n_pad >> 3) > P ? CoSlot{true, 8u * P + rest} : CoSlot{false, 8u * a * P + rest};
 }
 
+// Which block order a co-scheduled launch of n_spread bricks and n_row_blocks row blocks gets (host side).  Launches of one or
+// two generations (cfg3: 512 bricks + 999 row blocks on 1 024 slots) run best with all bricks first; launches of many
+// generations (cfg5: 4 096 + 8 192) with one brick per `a` row blocks and XCD, a = the ratio of the two counts, so that the
+// bricks' idle vector slots are filled from the start and neither kind is left over as a tail: cfg5 175.2 -> 168.5 us, with
+// a = 1 or 3 there 196 / 187 us, any pattern at cfg3 +0.9 us (profiles/r04_k_ab_pattern.txt).  MIPME_BRICK_PATTERN = 0 (bricks
+// first) or a > 0 overrides.
+static inline unsigned brick_pattern(const BrickGeom& bg, unsigned n_spread, unsigned n_row_blocks) {
+  static const int pattern_env = [] { const char* e = getenv("MIPME_BRICK_PATTERN"); return e ? atoi(e) : -1; }();
+  unsigned pattern = 0;
+  if (bg.xcd && n_spread > 0) {
+    if (pattern_env >= 0)
+      pattern = unsigned(pattern_env);
+    else if (n_spread >= kBrickPatternMin) {
+      const double ratio = double(pad8(n_row_blocks)) / double(pad8(n_spread));
+      const unsigned a = unsigned(ratio + 0.5);
+      if (a >= 1 && std::fabs(ratio - double(a)) <= 0.15 * double(a)) pattern = a;
+    }
+  }
+  return pattern;
+}
+
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
                                                                                               unsigned n_spread, unsigned pattern) {
@@ -1597,22 +1618,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       MIPME_LAUNCH_CHECK();
       return MIPME_OK;
     }
-    // Block order.  Launches of one or two generations (cfg3: 512 bricks + 999 row blocks on 1 024 slots) run best with all
-    // bricks first; launches of many generations (cfg5: 4 096 + 8 192) with one brick per `a` row blocks and XCD, a = the ratio
-    // of the two counts, so that the bricks' idle vector slots are filled from the start and neither kind is left over as a
-    // tail: cfg5 175.2 -> 168.5 us, with a = 1 or 3 there 196 / 187 us, any pattern at cfg3 +0.9 us
-    // (profiles/r04_k_ab_pattern.txt).  MIPME_BRICK_PATTERN = 0 (bricks first) or a > 0 overrides.
-    static const int pattern_env = [] { const char* e = getenv("MIPME_BRICK_PATTERN"); return e ? atoi(e) : -1; }();
-    unsigned pattern = 0;
-    if (bg.xcd && n_spread > 0) {
-      if (pattern_env >= 0)
-        pattern = unsigned(pattern_env);
-      else if (n_spread >= kBrickPatternMin) {
-        const double ratio = double(pad8(n_rows_blocks)) / double(pad8(n_spread));
-        const unsigned a = unsigned(ratio + 0.5);
-        if (a >= 1 && std::fabs(ratio - double(a)) <= 0.15 * double(a)) pattern = a;
-      }
-    }
+    const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks);
     const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_rows_blocks), pattern) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
     if (cpart && pfast == 1)
@@ -2408,16 +2414,20 @@ __host__ __device__ inline unsigned live_home_blocks(int64_t n_atoms, bool xcd) 
 }
 template <int N, typename T, int PFAST, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? MIPME_CELL_WAVES : 8) : 1) void live_spread_rows_kernel(LiveSpreadArgs<T> sa, FusedRowsArgs<T> ra,
-                                                                                        unsigned n_spread) {
+                                                                                        unsigned n_spread, unsigned pattern) {
   const unsigned n_home = live_home_blocks(sa.n_atoms, sa.bg.xcd), n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
+  const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
   if (blockIdx.x < n_home) {
     live_home_body<N, T>(sa, blockIdx.x);
-  } else if (blockIdx.x - n_home < n_pad) {
-    const unsigned b = brick_of(sa.bg, blockIdx.x - n_home);
-    if (b < n_spread) live_spread_body<N, T>(sa, b);
-  } else {
-    const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(blockIdx.x - n_home - n_pad, n_row_blocks) : blockIdx.x - n_home - n_pad;
+    return;
+  }
+  const CoSlot cs = cosched_slot(blockIdx.x - n_home, n_pad, n_rows_pad, pattern);  // (block order: see spread_rows_kernel)
+  if (cs.brick) {
+    const unsigned b = brick_of(sa.bg, cs.slot);
+    if (cs.slot < n_pad && b < n_spread) live_spread_body<N, T>(sa, b);
+  } else if (cs.slot < n_rows_pad) {
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
     if (r < n_row_blocks) {
       extern __shared__ __attribute__((aligned(16))) char smem_rows[];
       AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
@@ -2656,16 +2666,18 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
                 "the cell sums of the pair kernel need 4-byte entries and 1/r (or fp32 1/r^6)");
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
-  const unsigned grid = live_home_blocks(N, bg.xcd) + (bg.xcd ? pad8(n_spread) + pad8(n_row_blocks) : n_spread + n_row_blocks);
+  const unsigned pattern = brick_pattern(bg, n_spread, n_row_blocks);
+  const unsigned grid = live_home_blocks(N, bg.xcd) +
+                        (bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_row_blocks), pattern) : n_spread + n_row_blocks);
   if (cpart && pfast == 1)
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   else if (cpart) {
     if constexpr (sizeof(T) == 4)
-      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   } else if (pfast == 1)
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   else
-    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   MIPME_LAUNCH_CHECK();
   return MIPME_OK;
 }
