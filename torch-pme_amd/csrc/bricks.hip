@@ -917,14 +917,16 @@ __device__ __forceinline__ CoSlot cosched_slot(unsigned b, unsigned n_pad, unsig
 // generations (cfg5: 4 096 + 8 192) with one brick per `a` row blocks and XCD, a = the ratio of the two counts, so that the
 // bricks' idle vector slots are filled from the start and neither kind is left over as a tail: cfg5 175.2 -> 168.5 us, with
 // a = 1 or 3 there 196 / 187 us, any pattern at cfg3 +0.9 us (profiles/r04_k_ab_pattern.txt).  MIPME_BRICK_PATTERN = 0 (bricks
-// first) or a > 0 overrides.
-static inline unsigned brick_pattern(const BrickGeom& bg, unsigned n_spread, unsigned n_row_blocks) {
+// first) or a > 0 overrides.  (The frames launch -- blockIdx.y = frame, bricks first inside every frame -- is interleaved at
+// frame granularity as it is; one brick per two row blocks inside the frames measured 1 % slower at 4 and 8 headline frames,
+// profiles/r04_m_ab_pattern_frames.txt.)
+static inline unsigned brick_pattern(const BrickGeom& bg, unsigned n_spread, unsigned n_row_blocks, bool fp32) {
   static const int pattern_env = [] { const char* e = getenv("MIPME_BRICK_PATTERN"); return e ? atoi(e) : -1; }();
   unsigned pattern = 0;
   if (bg.xcd && n_spread > 0) {
     if (pattern_env >= 0)
       pattern = unsigned(pattern_env);
-    else if (n_spread >= kBrickPatternMin) {
+    else if (fp32 && n_spread >= kBrickPatternMin) {  // (measured for the fp32 kernels, four workgroups per CU; fp64 keeps bricks first)
       const double ratio = double(pad8(n_row_blocks)) / double(pad8(n_spread));
       const unsigned a = unsigned(ratio + 0.5);
       if (a >= 1 && std::fabs(ratio - double(a)) <= 0.15 * double(a)) pattern = a;
@@ -1618,7 +1620,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       MIPME_LAUNCH_CHECK();
       return MIPME_OK;
     }
-    const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks);
+    const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks, sizeof(T) == 4);
     const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_rows_blocks), pattern) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
     if (cpart && pfast == 1)
@@ -2666,7 +2668,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
                 "the cell sums of the pair kernel need 4-byte entries and 1/r (or fp32 1/r^6)");
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
-  const unsigned pattern = brick_pattern(bg, n_spread, n_row_blocks);
+  const unsigned pattern = brick_pattern(bg, n_spread, n_row_blocks, sizeof(T) == 4);
   const unsigned grid = live_home_blocks(N, bg.xcd) +
                         (bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_row_blocks), pattern) : n_spread + n_row_blocks);
   if (cpart && pfast == 1)
