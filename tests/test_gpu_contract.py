@@ -24,6 +24,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pme_numpy as O  # noqa: E402
 
 DEV = "cuda"
+#: does the fp64 1/r^6 pair body form the cell sums of the energy step (rows_cell_supported in csrc/bricks.hip)?
+FP64_IPL_CELL = False
 
 
 def small_box(seed, triclinic, n_side=7, a=2.3):
@@ -89,7 +91,7 @@ def test_graphed_step_returns_the_whole_contract(scheme, order, expo, tri, dtype
         args = ()
     else:
         kw, args = {}, (c["pairs"], c["shifts"])
-    fused_expected = not (expo == 6 and dtype == torch.float64)
+    fused_expected = not (expo == 6 and dtype == torch.float64) or FP64_IPL_CELL
     if live and not fused_expected:
         with pytest.raises(NotImplementedError):
             tpa.GraphedEnergyForces(c["calc"], c["q"], c["cell"], c["pos"], *args, charge_gradient=True, cell_gradient=True, **kw)
@@ -140,6 +142,27 @@ def test_eager_autograd_contract_matches_the_oracle(dtype, reduce, distances):
     assert rel(pos.grad, -0.37 * gpo) <= tol and rel(q.grad, -0.37 * dqo) <= tol and rel(cell.grad, -0.37 * dco) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_distances_from_another_cell_tensor_leave_cell_the_mesh_part(dtype):
+    """Round-4 advice: `cell.requires_grad` with distances that were built from a DIFFERENT (detached) cell tensor -- the
+    reference's graph then gives `cell` the k-space part only (the pair part flows to the distances' cell, which wants none).
+    `weighted_sum`'s direct node used to hand out mesh + pair part whenever only `cell` asked."""
+    c = setup(dtype, "P3M", 5, 1, True, seed=9)
+    spec, scheme, order, h, qn, celln, posn, pairs, S = c["np"]
+    dist, _ = O.pair_distances(posn, celln, pairs, S)
+    V, cache = O.forward(spec, "P3M", order, h, qn, celln, posn, pairs, dist, return_cache=True)
+    gr = O.backward(cache, qn)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    for reduce in ("weighted_sum", "tensor_ops"):
+        pos = c["pos"].clone().requires_grad_(True)
+        cell = c["cell"].clone().requires_grad_(True)
+        d = tpa.pair_distances(pos, c["pairs"], cell.detach(), c["shifts"], deferred="virtual" if reduce == "weighted_sum" else False)
+        Vt = c["calc"](c["q"], cell, pos, c["pairs"], d)
+        E = tpa.weighted_sum(Vt, c["q"]) if reduce == "weighted_sum" else (c["q"] * Vt).sum()
+        E.backward()
+        assert rel(cell.grad, gr["cell"]) <= tol, (reduce, rel(cell.grad, gr["cell"]))
+
+
 def test_tail_is_used_for_the_deferred_contract():
     """With deferred distances + weighted_sum the three gradients come out of the forward's launches: no kernel of the backward
     pass but the scaling of the stored results (launch names recorded by ops.PROFILE)."""
@@ -186,12 +209,15 @@ def test_sum_seed_of_the_tuning_protocol():
             assert rel(cell.grad, gr["cell"]) <= tol
 
 
-@pytest.mark.parametrize("cfg", ["ionic", "water"])
+@pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
 def test_fullsize_contract_against_committed_oracle(cfg, golden_dir):
-    """cfg2 (8 000 ions, fp64) and cfg3 (31 944-atom water box, fp32 and fp64) at full size: dE/dq (256 sampled atoms + the
-    whole-array checksum) and dE/dcell against tests/golden/workloads.npz, from the binned and the live-bin graph and from the
-    eager tail; and the TuningTimings protocol's three gradients against the committed g = 1 adjoint."""
-    w = {"ionic": workloads.ionic_box, "water": workloads.water_box}[cfg]()
+    """cfg2 (8 000 ions), cfg3 (31 944-atom water box) and cfg5 (262 144 atoms, 1/r^6, 128^3: the CELL variant of the 1/r^6 packed
+    body and the interleaved block order of launches with >= 2 048 bricks) at full size, fp64 and fp32: dE/dq (256 sampled
+    atoms + the whole-array checksum) and dE/dcell against tests/golden/workloads.npz, from the binned and the live-bin graph and
+    from the eager tail; and the TuningTimings protocol's three gradients against the committed g = 1 adjoint.  fp32 tolerances
+    are ~5 x the errors measured in round 4 (energy 1e-5, forces 2e-5, dE/dq 2e-5, dE/dcell 6e-5; cfg5's 1/r^6 forces and cell
+    gradient are small differences of large terms: 1e-4 / 3e-4)."""
+    w = {"ionic": workloads.ionic_box, "water": workloads.water_box, "dispersion": workloads.dispersion_box}[cfg]()
     z = np.load(os.path.join(golden_dir, "workloads.npz"))
     g = {k[len(cfg) + 1:]: z[k] for k in z.files if k.startswith(cfg + "_")}
     assert int(g["n_pairs"]) == w.n_pairs
@@ -199,20 +225,27 @@ def test_fullsize_contract_against_committed_oracle(cfg, golden_dir):
     rng.normal(size=(w.n_atoms, 3))
     s_vec = rng.normal(size=(w.n_atoms, 1))
     sample = g["sample"]
-    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-4)):
+    disp = cfg == "dispersion"
+    for dtype in (torch.float64, torch.float32):
+        f64 = dtype == torch.float64
+        tol_e, tol_f, tol_q, tol_c = (1e-10, 1e-9, 1e-9, 1e-9) if f64 else ((1e-5, 1e-4, 2e-5, 3e-4) if disp else (1e-5, 2e-5, 2e-5, 6e-5))
+        tol = tol_q
         t = lambda a: torch.tensor(a, dtype=dtype, device=DEV)  # noqa: E731
         pos, cell, q, shifts = t(w.positions), t(w.cell), t(w.charges), t(w.shifts)
         pairs = torch.tensor(w.pairs, device=DEV)
-        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=w.smearing), mesh_spacing=w.mesh_spacing,
-                                 interpolation_nodes=w.order)
+        pot = (tpa.InversePowerLawPotential(exponent=w.exponent, smearing=w.smearing) if disp
+               else tpa.CoulombPotential(smearing=w.smearing))
+        calc = tpa.P3MCalculator(pot, mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order)
         results = {}
+        fused_expected = not (disp and f64) or FP64_IPL_CELL  # (fp64 1/r^6: see test_graphed_step_returns_the_whole_contract)
         step = tpa.GraphedEnergyForces(calc, q, cell, pos, pairs, shifts, charge_gradient=True, cell_gradient=True)
-        assert step._fused_contract
+        assert step._fused_contract == fused_expected
         results["graph"] = tuple(x.clone() for x in step())
         del step
-        live = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=w.cutoff, charge_gradient=True, cell_gradient=True)
-        results["live"] = tuple(x.clone() for x in live())
-        del live
+        if fused_expected:
+            live = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=w.cutoff, charge_gradient=True, cell_gradient=True)
+            results["live"] = tuple(x.clone() for x in live())
+            del live
         p_, q_, c_ = pos.clone().requires_grad_(True), q.clone().requires_grad_(True), cell.clone().requires_grad_(True)
         d = tpa.pair_distances(p_, pairs, c_, shifts, deferred="virtual")
         E = tpa.weighted_sum(calc(q_, c_, p_, pairs, d), q_)
@@ -220,12 +253,12 @@ def test_fullsize_contract_against_committed_oracle(cfg, golden_dir):
         results["eager"] = (E.detach(), -p_.grad, q_.grad, c_.grad)
         for name, (E, F, dq, dc) in results.items():
             dq = dq.cpu().double().numpy()
-            assert abs(float(E) - float(g["energy"])) <= tol * abs(float(g["energy"])), (cfg, dtype, name)
-            assert rel(F.cpu()[sample], g["force_sample"]) <= 10 * tol, (cfg, dtype, name)
+            assert abs(float(E) - float(g["energy"])) <= tol_e * abs(float(g["energy"])), (cfg, dtype, name)
+            assert rel(F.cpu()[sample], g["force_sample"]) <= tol_f, (cfg, dtype, name, rel(F.cpu()[sample], g["force_sample"]))
             ref = g["charge_grad_sample"]
-            assert np.abs(dq[sample, 0] - ref).max() <= tol * np.abs(ref).max(), (cfg, dtype, name)
-            assert abs(float((s_vec * dq).sum()) - float(g["charge_grad_dot"])) <= tol * np.linalg.norm(s_vec) * np.linalg.norm(dq)
-            assert rel(dc, g["cell_grad"]) <= 10 * tol, (cfg, dtype, name, rel(dc, g["cell_grad"]))
+            assert np.abs(dq[sample, 0] - ref).max() <= tol_q * np.abs(ref).max(), (cfg, dtype, name)
+            assert abs(float((s_vec * dq).sum()) - float(g["charge_grad_dot"])) <= tol_q * np.linalg.norm(s_vec) * np.linalg.norm(dq)
+            assert rel(dc, g["cell_grad"]) <= tol_c, (cfg, dtype, name, rel(dc, g["cell_grad"]))
         # the reference's timing protocol on this box
         d_fixed = tpa.pair_distances(pos, pairs, cell, shifts).detach().clone()
         positions, cl, charges = pos.clone(), cell.clone(), q.clone()

@@ -347,3 +347,37 @@ def test_caller_made_distances_take_the_compiled_node(dtype, tol, scheme, expone
     Vo2 = O.forward(spec, scheme, 4, 0.9, q, cell2, pos, pairs, dist)
     V = calc(tq, torch.tensor(cell2, device=DEV, dtype=dtype), tp0.detach(), ti0, td)
     assert rell2(V.detach().cpu(), Vo2) < tol
+
+
+def test_cells_that_change_every_call_do_not_bet_every_call():
+    """Round-4 advice: a loop that hands a DIFFERENT cell to every call (a data set of structures, NPT) must not place -- and lose
+    -- the "same values as the previous cell tensor" bet on every call, which evaluates everything twice.  A lost bet sits the
+    next calls out (2, 4, ... 64 of them); twelve distinct cells cost at most four lost bets, every result is the oracle's, and a
+    cell tensor that comes back re-arms the bet."""
+    rng, cell, pos, q, pairs, S, dist = _system(seed=29)
+    spec = O.PotentialSpec("coulomb", 1, 1.1, 1.0)
+    calc = _calc("P3M", 1)
+    tq, tc0, tp, ti, _ = _tensors(cell, pos, q, pairs, S, torch.float64)
+    td = torch.tensor(dist, device=DEV, dtype=torch.float64)
+    verdicts = []
+    held = calc._speculation_held
+
+    def counting():
+        v = held()
+        verdicts.append(v)
+        return v
+
+    calc.__dict__["_speculation_held"] = counting
+    n = 12
+    for k in range(n):
+        cell_k = cell * (1.0 + 0.002 * k)
+        V = calc(tq.detach(), torch.tensor(cell_k, device=DEV, dtype=torch.float64), tp.detach(), ti, td)
+        Vo = O.forward(spec, "P3M", 4, 0.9, q, cell_k, pos, pairs, dist)
+        assert rell2(V.cpu(), Vo) < 1e-10, k
+    assert verdicts.count(False) <= 4 and len(verdicts) <= 5, verdicts
+    # the same values in new tensors: after the back-off has run out the bet is placed again, and won
+    verdicts.clear()
+    for k in range(8):
+        V = calc(tq.detach(), torch.tensor(cell, device=DEV, dtype=torch.float64), tp.detach(), ti, td)
+    assert rell2(V.cpu(), O.forward(spec, "P3M", 4, 0.9, q, cell, pos, pairs, dist)) < 1e-10
+    assert verdicts.count(True) >= 1 and verdicts.count(False) <= 1, verdicts

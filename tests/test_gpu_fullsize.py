@@ -255,7 +255,8 @@ def test_fullsize_against_committed_oracle(cfg, request, golden_dir):
     assert int(g["n_pairs"]) == w.n_pairs and np.allclose(chk, g["pos_checksum"], rtol=1e-13, atol=1e-9)
     Eo, sample, Fs = float(g["energy"]), g["sample"], torch.tensor(g["force_sample"])
     r = torch.tensor(np.random.default_rng(4242).normal(size=(w.n_atoms, 3)))
-    for dtype, tol_e, tol_s, tol_c in ((torch.float64, 1e-11, 1e-9, 1e-10), (torch.float32, 1e-5, 1e-4, 1e-4)):
+    tol32 = 1e-4 if cfg == "dispersion" else 2e-5  # (measured in round 4: 3.6e-6 on the water box; cfg5's forces are differences of large terms)
+    for dtype, tol_e, tol_s, tol_c in ((torch.float64, 1e-11, 1e-9, 1e-10), (torch.float32, 1e-5, tol32, tol32)):
         box = Box(w, dtype)
         results = {"eager": box.energy_forces()}
         step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts)
@@ -274,6 +275,64 @@ def test_fullsize_against_committed_oracle(cfg, request, golden_dir):
             assert abs(float((F * F).sum()) - float(g["force_sq"])) <= tol_c * float(g["force_sq"]), (cfg, dtype, name)
             scale = float(F.norm() * r.norm())
             assert abs(float((r * F).sum()) - float(g["force_dot"])) <= tol_c * scale, (cfg, dtype, name)
+
+
+@pytest.mark.parametrize("cfg", ["ionic", "water"])
+def test_fullsize_against_the_reference_itself(cfg, request, golden_dir):
+    """BASELINE.json configs[1] (8 000 ions, P3M n = 4, 32^3) and configs[2] (the 31 944-atom water box, P3M n = 5, 64^3) against
+    the REFERENCE'S OWN evaluation of the same box (tests/golden/ref_fullsize.npz, made by importing torchpme in the build
+    container: tests/golden/make_reference_fullsize.py) -- the whole first-order contract of one energy step: E, F (256 sampled
+    atoms + the two whole-array checksums), dE/dq (sample + checksum), dE/dcell, from the graph-replayed step and the eager
+    calculators; and the three gradients of the tuner's V.sum() protocol.  fp64 against the reference's fp64 numbers at 1e-10;
+    fp32 against the same fp64 numbers at five times the errors measured in round 4 (energy 1e-5 = north_star's tolerance,
+    forces rel-L2 2e-5, dE/dq 2e-5, dE/dcell 6e-5) -- the reference's own fp32 run differs from its fp64 run by 7e-6 in the
+    sampled forces and 1.6e-5 in dE/dcell on the water box."""
+    w = request.getfixturevalue(cfg)
+    z = np.load(os.path.join(golden_dir, "ref_fullsize.npz"))
+    g = {k[len(cfg) + 5:]: z[k] for k in z.files if k.startswith(cfg + "_f64_")}
+    chk = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
+    assert int(z[f"{cfg}_n_pairs"]) == w.n_pairs and np.allclose(chk, z[f"{cfg}_pos_checksum"], rtol=1e-13, atol=1e-9)
+    sample = z[f"{cfg}_sample"]
+    rng = np.random.default_rng(4242)
+    r_vec = rng.normal(size=(w.n_atoms, 3))
+    s_vec = rng.normal(size=(w.n_atoms, 1))
+    relmax = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())  # noqa: E731
+    rell2 = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))  # noqa: E731
+    for dtype, tol_e, tol_f, tol_q, tol_c in ((torch.float64, 1e-11, 1e-10, 1e-10, 1e-10), (torch.float32, 1e-5, 2e-5, 2e-5, 6e-5)):
+        box = Box(w, dtype)
+        results = {}
+        step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts, charge_gradient=True,
+                                       cell_gradient=True)
+        results["graph"] = tuple(x.clone() for x in step())
+        del step
+        p_, q_, c_ = box.pos.clone().requires_grad_(True), box.q.clone().requires_grad_(True), box.cell.clone().requires_grad_(True)
+        d = tpa.pair_distances(p_, box.pairs, c_, box.shifts)
+        E = (box.calc(q_, c_, p_, box.pairs, d) * q_).sum()  # the reference's own call sequence, eager
+        E.backward()
+        results["eager"] = (E.detach(), -p_.grad, q_.grad, c_.grad)
+        for name, (E, F, dq, dc) in results.items():
+            F, dq, dc = F.cpu().double().numpy(), dq.cpu().double().numpy(), dc.cpu().double().numpy()
+            tag = (cfg, dtype, name)
+            assert abs(float(E) - float(g["energy"])) <= tol_e * abs(float(g["energy"])), tag
+            assert rell2(F[sample], g["force_sample"]) <= tol_f, (tag, rell2(F[sample], g["force_sample"]))
+            assert abs(float((F * F).sum()) - float(g["force_sq"])) <= 10 * tol_f * float(g["force_sq"]), tag
+            assert abs(float((r_vec * F).sum()) - float(g["force_dot"])) <= tol_f * np.linalg.norm(F) * np.linalg.norm(r_vec), tag
+            assert relmax(dq[sample, 0], g["charge_grad_sample"]) <= tol_q, (tag, relmax(dq[sample, 0], g["charge_grad_sample"]))
+            assert abs(float((s_vec * dq).sum()) - float(g["charge_grad_dot"])) <= tol_q * np.linalg.norm(s_vec) * np.linalg.norm(dq), tag
+            assert rell2(dc, g["cell_grad"]) <= tol_c, (tag, rell2(dc, g["cell_grad"]))
+        # tuning/tuner.py:350-369 on this box: result.sum().backward() with constant distances
+        d_fixed = tpa.pair_distances(box.pos, box.pairs, box.cell, box.shifts).detach().clone()
+        positions, cl, charges = box.pos.clone(), box.cell.clone(), box.q.clone()
+        for x in (positions, cl, charges):
+            x.requires_grad_(True)
+        V = box.calc.forward(positions=positions, charges=charges, cell=cl, neighbor_indices=box.pairs, neighbor_distances=d_fixed)
+        V.sum().backward()
+        Vn = V.detach().cpu().double().numpy()
+        assert relmax(Vn[sample, 0], g["potential_sample"]) <= tol_q, (cfg, dtype)
+        assert abs(float((s_vec * Vn).sum()) - float(g["potential_dot"])) <= tol_q * np.linalg.norm(s_vec) * np.linalg.norm(Vn)
+        assert rell2(positions.grad.cpu().double().numpy()[sample], g["sumseed_pos_sample"]) <= 10 * tol_f, (cfg, dtype)
+        assert relmax(charges.grad.cpu().double().numpy()[sample, 0], g["sumseed_charge_sample"]) <= 10 * tol_q, (cfg, dtype)
+        assert rell2(cl.grad.cpu().double().numpy(), g["sumseed_cell"]) <= tol_c, (cfg, dtype)
 
 
 def test_eight_headline_frames_in_one_batch(golden_dir):

@@ -68,7 +68,7 @@ class Calculator(torch.nn.Module):
     #: per-instance device state that must not travel with a copy / pickle (FFT plans own raw device pointers, the caches
     #: hold weak references to the caller's tensors); rebuilt on first use
     _TRANSIENT = {"_cache": None, "_plan_store": dict, "_freq_cache": None, "_nan_flag": None, "_nan_shape": None,
-                  "_speculated": None, "_bet_flag": None, "_bet_flag_np": None, "_bet_won": True, "_analytic_geom": None}
+                  "_speculated": None, "_bet_flag": None, "_bet_flag_np": None, "_bet_skip": 0, "_bet_backoff": 2, "_analytic_geom": None}
 
 
     def __getstate__(self):
@@ -311,7 +311,7 @@ class PMECalculator(Calculator):
         self.interpolation_nodes: int = interpolation_nodes
         self._cache = None  # (weakref(cell), version, dtype, device, pot key, mesh key, geom, G, device copy of the cell)
         self._speculated = self._bet_flag = self._bet_flag_np = None  # see _kspace_setup
-        self._bet_won = True
+        self._bet_skip, self._bet_backoff = 0, 2  # calls that sit a bet out after lost ones (see _speculation_held)
         self._plan_store = {}  # FFT plans of this calculator (see _lib.get_plan)
         self._spec()
 
@@ -339,8 +339,9 @@ class PMECalculator(Calculator):
             and c[5] == (self.mesh_spacing, self.interpolation_nodes)
         ):
             if c[0]() is cell and c[1] == cell._version:
+                d["_bet_skip"], d["_bet_backoff"] = 0, 2  # a cell that comes back: bets are worth placing again
                 return c[6], c[7]
-            if (speculate and SPECULATE_CELL and self._bet_won and cell.dtype == dtype and cell.is_contiguous()
+            if (speculate and SPECULATE_CELL and self._bet_skip == 0 and cell.dtype == dtype and cell.is_contiguous()
                     and tuple(cell.shape) == (3, 3) and not torch.cuda.is_current_stream_capturing()):
                 flag = self._bet_flag
                 if flag is None:
@@ -359,7 +360,10 @@ class PMECalculator(Calculator):
         G = ops.build_filter(geom, pot_desc, dtype, device)
         d["_cache"] = (weakref.ref(cell), cell._version, dtype, device, pkey, (self.mesh_spacing, self.interpolation_nodes),
                        geom, G, cell.detach().to(dtype).clone())
-        d["_bet_won"] = True
+        # (the slow path does NOT re-arm the bet: a loop that hands over a different cell every call -- a data set of structures,
+        # NPT -- would otherwise bet and lose every time, i.e. evaluate everything twice; a lost bet sits the next calls out)
+        if speculate and self._bet_skip > 0:
+            d["_bet_skip"] = self._bet_skip - 1
         return geom, G
 
     def _speculation_held(self) -> bool:
@@ -378,8 +382,12 @@ class PMECalculator(Calculator):
         if flag[0] == 1:
             c = self._cache
             d["_cache"] = (weakref.ref(cell), cell._version) + c[2:]
+            d["_bet_skip"], d["_bet_backoff"] = 0, 2
             return True
-        d["_bet_won"] = False  # (cells that change from call to call: stop betting until a cell is seen twice)
+        # lost: the next `backoff` calls with a new cell take the plain path (doubling up to 64: cells that change from call to
+        # call cost one repeated evaluation per ever longer stretch instead of one per call)
+        d["_bet_skip"] = self._bet_backoff
+        d["_bet_backoff"] = min(2 * self._bet_backoff, 64)
         return False
 
 
@@ -443,7 +451,12 @@ class PMECalculator(Calculator):
                 or not torch.is_grad_enabled() or ops.PAIR_MODE != "rows" or ops.PROFILE is not None
                 or not (charges.requires_grad or cell.requires_grad or positions.requires_grad)
                 or neighbor_indices.shape[0] == 0 or neighbor_distances.shape != (neighbor_indices.shape[0],)
-                or charges.shape[0] != positions.shape[0] or ops.inside_vmap(charges, cell, positions, neighbor_distances)):
+                or charges.shape[0] != positions.shape[0] or ops.inside_vmap(charges, cell, positions, neighbor_distances)
+                # what _validate_parameters would refuse must not reach the native launches: the Python path owns the messages
+                or neighbor_indices.shape[1] != 2 or neighbor_indices.dtype not in (torch.int64, torch.int32)
+                or neighbor_indices.device != positions.device or charges.device != positions.device
+                or charges.dtype != positions.dtype or neighbor_distances.dtype != positions.dtype
+                or neighbor_distances.device != positions.device or positions.dim() != 2 or positions.shape[1] != 3):
             return None
         geom, G = self._kspace_setup(cell, positions.dtype, positions.device)
         speculated = self._speculated is not None

@@ -54,7 +54,9 @@ bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
 template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                        const mipme_sr_job_t*, bool, double*);
+                                        const mipme_sr_job_t*, bool, double*, const PlaneHost* = nullptr, bool* = nullptr);
+bool fft_plan_plane_forward_ok(const mipme_fft_plan*);
+void fft_plan_set_forward_done(mipme_fft_plan*, bool);
 template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int cell_tail_finalize_impl(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
                                                   const void*, const void*, const void*, void*);
@@ -180,9 +182,14 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
       const bool co = job && sr_job_fusable(job);
       const int reps = (g_prof_on && co) ? kProfRepeat : 1;
       ProfScope _ps(st, co ? "spread+rspace_forward" : "spread", reps);
+      // fused convolution ahead and planes that fit a workgroup: the spread writes the forward (y,z) transform itself
+      PlaneHost ph;
+      bool planes = false;
+      if (!rho_hat && fft_plan_plane_forward_ok(plan)) ph.hat = hat_work;
       for (int r = 0; r < reps; ++r)
         if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr,
-                                   out_grad_cell ? cw.cwave : nullptr))) return rc;
+                                   out_grad_cell ? cw.cwave : nullptr, &ph, &planes))) return rc;
+      fft_plan_set_forward_done(plan, planes);
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",

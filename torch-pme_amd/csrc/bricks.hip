@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "rows_body.h"
+#include "fft_lds.h"
 
 namespace mipme {
 
@@ -1014,6 +1015,231 @@ static inline bool rows_cell_supported(int pfast, int shift_format, const void* 
   return sizeof(T) == 4 ? (pfast == 1 || pfast == 6) : pfast == 1;
 }
 
+// ---- plane spread: the charges scattered straight into a (y,z) plane's transform tile -------------------------------------
+// Round 5.  The owner-computes bricks above cost a third of the co-scheduled launch's vector instructions (2.6 M of 7.8 M at
+// cfg3: every survivor is a 512-point rank-1 update of which 7 % is not zero), and the plane transform that follows re-reads
+// the mesh they wrote in a launch of its own (6.7 us of pure latency).  Here ONE workgroup per x plane of the mesh
+//   A  walks the atom bins of the one or two brick slabs whose atoms can reach the plane (m_x in [x - s0 - (N-1), x - s0]) and
+//      appends those that do to an LDS list {slot | stencil row << 28, atom},
+//   B  scatters every listed atom's N x N (y,z) stencil points, times its x weight and value, into the plane -- stored in LDS in
+//      the layout the forward transform starts from (rows as bit-reversed complex pairs, fft_lds.h yz_real_slot) -- with LDS
+//      float atomics (ds_add_f32 / ds_add_f64: N^2 per atom and plane, N^3 per atom in all, nothing is computed that is zero),
+//   C  transforms the plane in place (yz_forward_finish) and stores its block of the half-complex mesh: the convolution's
+//      forward (y,z) launch is gone (fft_plan_forward_done).
+// The sums' order depends on the arrival order of the atomics, so results vary in the last bits from run to run like those of the
+// one-pass binning do; MIPME_DETERMINISTIC=1 keeps the bricks.  Single channel, planes whose tile fits the co-scheduled launch's
+// LDS budget (64 x 64 fp32, 64 x 32 fp64); larger meshes keep the bricks.
+template <typename T>
+struct PlaneArgs {
+  Cplx<T>* hat = nullptr;  // (nx, ny, nz/2 + 1): receives the (y,z)-transformed planes; nullptr: no plane spread in this launch
+  T* mesh = nullptr;       // nullable: the real charge mesh as well (callers that keep it)
+  int logny = 0, loglz = 0;
+  int list_cap = 0;        // entries of the survivor list
+};
+
+static constexpr int kPlaneSlotBits = 28;
+// LDS of a launch with planes: co-scheduled with the row blocks, four workgroups per CU must fit 160 KB (and the rows need their
+// shift / erfcx tables: <= 32 KB); alone, the default dynamic limit
+static constexpr size_t kPlaneLdsCosched = 39 * 1024, kPlaneLdsAlone = 64 * 1024;
+static inline size_t plane_tile_bytes(int ny, int nz, size_t real_bytes) {
+  const size_t Lz = size_t(nz / 2), Ltab = size_t(ny) > Lz ? size_t(ny) : Lz;
+  return 2 * real_bytes * (size_t(ny) * (Lz + 1) + Ltab / 2 + (Lz + 1));
+}
+static inline size_t plane_lds_bytes(int ny, int nz, size_t real_bytes, int list_cap) {
+  return plane_tile_bytes(ny, nz, real_bytes) + sizeof(int2) * size_t(list_cap) + 16;
+}
+
+// one atom's N x N points of the plane: r = its bin record, tt = which of its x weights the plane takes, wr = its weight row
+template <int N, typename T>
+__device__ __forceinline__ void plane_scatter_one(T* __restrict__ tr, int RZ, const Geom& g, int loglz, int4 r, int tt,
+                                                  const T* __restrict__ wr_, T v) {
+  constexpr int s0 = stencil_start<N>();
+  const T* __restrict__ wr = static_cast<const T*>(__builtin_assume_aligned(wr_, 16));
+  T w[3 * N];
+#pragma unroll
+  for (int k = 0; k < 3 * N; ++k) w[k] = wr[k];
+  T wxt = w[0];
+#pragma unroll
+  for (int k = 1; k < N; ++k) wxt = tt == k ? w[k] : wxt;
+  const T vx = v * wxt;
+  int rowa[N], zo[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    rowa[j] = wrap1(r.y + s0 + j, g.ny) * (2 * RZ);
+    const int z = wrap1(r.z + s0 + j, g.nz);
+    zo[j] = ((loglz ? int(__brev(unsigned(z >> 1)) >> (32 - loglz)) : 0) << 1) | (z & 1);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const T a = vx * w[N + j];
+#pragma unroll
+    for (int k = 0; k < N; ++k) atomicAdd(&tr[rowa[j] + zo[k]], a * w[2 * N + k]);
+  }
+}
+
+template <int N, typename T>
+__device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, const PlaneArgs<T>& pa, unsigned plane,
+                                                     char* smem) {
+  const Geom& g = args.g;
+  const BrickGeom& bg = args.bg;
+  const BinIndex& bins = args.bins;
+  const int4* __restrict__ rec = args.rec;
+  const T* __restrict__ wts = args.wts;
+  const T* __restrict__ val = args.val;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+  constexpr int s0 = stencil_start<N>();
+  constexpr int W = wts_stride<N, T>();
+  const YzTile<T> yt = yz_tile_setup<T, true>(g.ny, g.nz, smem);
+  T* tr = reinterpret_cast<T*>(yt.tile);
+  const int RZ = yt.RZ, tile_reals = 2 * g.ny * RZ;
+  for (int i = tid; i < tile_reals; i += nthr) tr[i] = T(0);
+  int2* list = reinterpret_cast<int2*>(yt.twr + RZ);
+  int* nsurv = reinterpret_cast<int*>(list + pa.list_cap);
+  if (tid == 0) *nsurv = 0;
+  const int x0 = int(plane);
+  if (args.from_live) {  // per-call snapshot of the brick counts (see spread_brick_body): the planes share the bricks among them
+    for (int b = x0 + tid * g.nx; b <= bins.nb; b += g.nx * nthr) bins.snap[b] = bin_count_of(bins, b, true);
+  }
+  __syncthreads();
+  MIPME_WG_PHASE(0);
+  // A: candidates.  All lanes of a wavefront call `consider` together (ballot + one LDS atomic per wavefront and chunk).
+  auto consider = [&](int slot, int4 r, bool ok) __attribute__((always_inline)) {
+    int d = x0 - r.x - s0;  // in (-nx, nx + N)
+    d += d < 0 ? g.nx : 0;
+    d -= d >= g.nx ? g.nx : 0;
+    const bool keep = ok && d < N;
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(nsurv, __popcll(mask));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep) {
+        if (idx < pa.list_cap)
+          list[idx] = make_int2(slot | (d << kPlaneSlotBits), r.w);
+        else  // list full (a very dense plane): scatter at once
+          plane_scatter_one<N, T>(tr, RZ, g, pa.loglz, r, d, wts + int64_t(slot) * W, val[r.w] * args.scale);
+      }
+    }
+  };
+  const int nyz = bg.nby * bg.nbz;
+  int prev = -1;
+  for (int t = N - 1; t >= 0; --t) {
+    const int sx = posmod(x0 - s0 - t, g.nx) / BRICK;
+    if (sx == prev) continue;
+    prev = sx;
+    constexpr int U = 4;  // bricks in flight per wavefront
+    for (int byz0 = wave; byz0 < nyz; byz0 += nwaves * U) {
+      int cnt[U];
+      int4 r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int byz = byz0 + u * nwaves;
+        cnt[u] = byz < nyz ? bin_count_of(bins, sx * nyz + byz, args.from_live) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = sx * nyz + byz0 + u * nwaves;
+        r[u] = lane < cnt[u] ? rec[int64_t(b) * bins.cap + lane] : make_int4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = sx * nyz + byz0 + u * nwaves;
+        consider(b * bins.cap + lane, r[u], lane < cnt[u]);
+        for (int sb = 64; sb < cnt[u]; sb += 64) {  // bricks above 64 atoms
+          const int s = sb + lane;
+          const bool ok = s < cnt[u];
+          consider(b * bins.cap + s, ok ? rec[int64_t(b) * bins.cap + s] : make_int4(0, 0, 0, 0), ok);
+        }
+      }
+    }
+  }
+  {  // the overflow region (atoms whose brick was full: normally none)
+    const int oc = bin_count_of(bins, bins.nb, args.from_live);
+    for (int sb = wave * 64; sb < oc; sb += nthr) {
+      const int s = sb + lane;
+      const bool ok = s < oc;
+      consider(int(bins.over_base) + s, ok ? rec[bins.over_base + s] : make_int4(0, 0, 0, 0), ok);
+    }
+  }
+  __syncthreads();
+  MIPME_WG_PHASE(1);
+  // B: scatter
+  const int ns = min(*nsurv, pa.list_cap);
+  for (int i = tid; i < ns; i += nthr) {
+    const int2 e = list[i];
+    const int slot = e.x & ((1 << kPlaneSlotBits) - 1), tt = int(unsigned(e.x) >> kPlaneSlotBits);
+    plane_scatter_one<N, T>(tr, RZ, g, pa.loglz, rec[slot], tt, wts + int64_t(slot) * W, val[e.y] * args.scale);
+  }
+  __syncthreads();
+  MIPME_WG_PHASE(2);
+  if (pa.mesh) {  // the real plane, for callers that keep the charge mesh
+    const int Lz = yt.Lz;
+    T* dst = pa.mesh + int64_t(plane) * g.ny * g.nz;
+    for (int idx = tid; idx < g.ny * Lz; idx += nthr) {
+      const int y = idx / Lz, j = idx - y * Lz;
+      const int jr = pa.loglz ? int(__brev(unsigned(j)) >> (32 - pa.loglz)) : 0;
+      reinterpret_cast<Cplx<T>*>(dst)[idx] = yt.tile[y * RZ + jr];
+    }
+  }
+  // C: the plane's forward (y,z) transform, in place
+  yz_forward_finish<T, true>(yt, g.ny, g.nz, pa.logny, pa.loglz, pa.hat + int64_t(plane) * g.ny * RZ);
+  MIPME_WG_PHASE(3);
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, PlaneArgs<T> pa) {
+  MIPME_SKIP_IF_SET(sa.skip);
+  extern __shared__ __attribute__((aligned(16))) char smem_plane[];
+  plane_spread_yz_body<N, T>(sa, pa, blockIdx.x, smem_plane);
+}
+
+// the row workgroup of a co-scheduled launch (shared by spread_rows_kernel and plane_rows_kernel)
+template <typename T, int PFAST, bool COMPACT, bool CELL>
+__device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, unsigned r, char* smem_rows) {
+  AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
+  bool done = false;
+  if constexpr (COMPACT && std::is_same<T, float>::value) {
+    if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
+      sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
+      done = true;
+    }
+  }
+#if MIPME_ROW_LANES == 16
+  if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
+    if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
+      sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
+      done = true;
+    }
+  }
+#endif
+  if constexpr (!CELL) {
+    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
+  }
+}
+
+// planes first, then the row blocks of the pair sum (the planes are few -- nx -- and long: they must start at once)
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
+    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes) {
+  MIPME_WG_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) char smem_pr[];
+  const unsigned n_pad = pad8(n_planes);
+  const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
+  if (blockIdx.x < n_pad) {
+    const unsigned p = xcd_contiguous(blockIdx.x, n_planes);
+    if (p < n_planes) plane_spread_yz_body<N, T>(sa, pa, p, smem_pr);
+  } else {
+    const unsigned r = xcd_contiguous(blockIdx.x - n_pad, n_row_blocks);
+    if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL>(ra, r, smem_pr);
+  }
+#ifdef MIPME_WG_TIMELINE
+  __syncthreads();
+#endif
+  MIPME_WG_STAMP(1);
+}
+
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
 // NT = number of meshes staged (1: potential gather, 2: phi and chi for the gradient gather)
 static constexpr int GATHER_THREADS = 512;
@@ -1552,7 +1778,8 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
 
 template <typename T>
 int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, const void* val, double scale, void* mesh,
-                  int* clear_count, const mipme_sr_job_t* job, bool want_epart, double* cpart) {
+                  int* clear_count, const mipme_sr_job_t* job, bool want_epart, double* cpart, const PlaneHost* ph,
+                  bool* used_planes) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const BrickGeom bg = make_brick_geom(m);
   const BinsView v = bins_view(m, N, dtype, bins);
@@ -1576,6 +1803,28 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.stage_rows = stage_rows;
   sa.det = deterministic_mode();
   sa.skip = job ? nullptr : skip_flag_slot();  // (the co-scheduled forward launch is never conditional)
+  // plane spread (see plane_spread_yz_body): the charges go straight into the forward (y,z) transform's tiles
+  PlaneArgs<T> pa;
+  size_t plane_lds = 0;
+  if (used_planes) *used_planes = false;
+  {
+    static const bool plane_env = env_flag("MIPME_PLANE_SPREAD", true);
+    const bool pow2 = (m->ny & (m->ny - 1)) == 0 && (m->nz & (m->nz - 1)) == 0 && m->nz >= 4 && m->ny >= 2;
+    if (plane_env && ph && ph->hat && used_planes && sa.C == 1 && !sparse && !sa.det && pow2 && N > 0 &&
+        bins_layout(m, N, dtype).slots < (int64_t(1) << kPlaneSlotBits)) {
+      const size_t tile = plane_tile_bytes(m->ny, m->nz, sizeof(T));
+      const size_t budget = job ? kPlaneLdsCosched : kPlaneLdsAlone;
+      if (tile + 16 + sizeof(int2) * 512 <= budget) {
+        pa.hat = (Cplx<T>*)ph->hat;
+        pa.mesh = ph->keep_mesh ? (T*)mesh : nullptr;
+        while ((1 << pa.logny) < m->ny) ++pa.logny;
+        while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
+        pa.list_cap = int((budget - tile - 16) / sizeof(int2));
+        plane_lds = budget;
+        *used_planes = true;
+      }
+    }
+  }
   if (job) {
     // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
     SRPot s;
@@ -1620,6 +1869,28 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       MIPME_LAUNCH_CHECK();
       return MIPME_OK;
     }
+    if (pa.hat) {  // planes + row blocks
+      const unsigned n_planes = unsigned(m->nx);
+      const unsigned pgrid = pad8(n_planes) + pad8(n_rows_blocks);
+      const bool compact_p = (job->shift_format & kShiftFormatMask) == kShiftTable32;
+#define MIPME_PLANE_ROWS(PF, CO, CE) \
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, plane_rows_kernel<N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes)))
+      if (cpart && pfast == 1)
+        MIPME_PLANE_ROWS(1, true, true);
+      else if (cpart) {
+        if constexpr (sizeof(T) == 4) MIPME_PLANE_ROWS(6, true, true);
+      } else if (pfast == 1 && compact_p)
+        MIPME_PLANE_ROWS(1, true, false);
+      else if (pfast == 1)
+        MIPME_PLANE_ROWS(1, false, false);
+      else if (compact_p)
+        MIPME_PLANE_ROWS(6, true, false);
+      else
+        MIPME_PLANE_ROWS(6, false, false);
+#undef MIPME_PLANE_ROWS
+      MIPME_LAUNCH_CHECK();
+      return MIPME_OK;
+    }
     const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks, sizeof(T) == 4);
     const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_rows_blocks), pattern) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
@@ -1645,7 +1916,10 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
-  if (sparse)
+  if (pa.hat)
+    MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
+                             ((void)S, plane_spread_kernel<N, T><<<unsigned(m->nx), 1024, plane_lds, st>>>(sa, pa)));
+  else if (sparse)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
   else
@@ -2730,9 +3004,9 @@ template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, cons
 template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                  const mipme_sr_job_t*, bool, double*);
+                                  const mipme_sr_job_t*, bool, double*, const PlaneHost*, bool*);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
-                                   const mipme_sr_job_t*, bool, double*);
+                                   const mipme_sr_job_t*, bool, double*, const PlaneHost*, bool*);
 template int gather_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,
                                   double, double, void*, void*, int, void*, const GatherTailHost*, void*, int*);
 template int gather_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, const void*, const void*,

@@ -281,6 +281,12 @@ struct ConvCell {
 
 // Row workgroups of the co-scheduled pair sum that ride on the persistent convolution launch instead of the spread launch:
 // rows (atoms) [first_row, first_row + n_rows), first_row a multiple of 64.
+// what spread_bricks (bricks.hip) needs to use the plane spread -- the charges scattered straight into the tiles of the
+// convolution's forward (y,z) transform (api.hip fills it from the plan, see fft_plan_plane_forward_ok)
+struct PlaneHost {
+  void* hat = nullptr;    // (nx, ny, nz/2 + 1) complex: receives the transformed planes
+  bool keep_mesh = true;  // also store the real charge mesh
+};
 struct RowRideHost {
   const mipme_sr_job_t* job;
   void* epart;  // per-wave energy partial sums (bins buffer), nullable

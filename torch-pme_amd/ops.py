@@ -309,6 +309,7 @@ def _pack_entries(row_ptr, entries, shifts, n_pairs, n_atoms, table=True):
 # the cached structures is handed out; a lost bet repeats the evaluation with freshly built structures.  "0": always rebuild.
 SPECULATE_LISTS = os.environ.get("MIPME_SPECULATE_LISTS", "1") != "0"
 _BETS: list = []  # pending verdicts: (pinned flags numpy view, slot, undo callable)
+_ON_LOST: list = []  # side effects of work done on adopted structures, to take back if any pending bet is lost
 _BET_PAUSE = [0]  # list misses to sit out after a lost bet (lists that really change from call to call)
 _BET_FLAGS: dict = {}
 #: polls of a pinned verdict word that gave up and synchronised instead (diagnostics: should stay at zero)
@@ -364,15 +365,34 @@ def verify_bets() -> None:
             if undo is not None:
                 undo()
     _BETS.clear()
+    on_lost = list(_ON_LOST)
+    _ON_LOST.clear()
     if lost:
+        for f in on_lost:
+            f()
         _BET_PAUSE[0] = 16
         raise SpeculationLost()
+
+
+def _abandon_bets() -> None:
+    """An exception left a betting scope before its verdicts were looked at: treat every pending bet as lost (forget the adopted
+    structures), so that no later caller finds an unverified entry."""
+    for _view, _slot, undo in _BETS:
+        if undo is not None:
+            undo()
+    _BETS.clear()
+    for f in _ON_LOST:
+        f()
+    _ON_LOST.clear()
 
 
 class betting:
     """``with betting(): ...`` -- the caller WILL call :func:`verify_bets` before it hands out anything computed inside.  Bets are
     only placed inside such a scope (a path that looks a list up without verifying -- the Ewald and direct calculators, the graph
-    classes -- always builds or finds the structures of exactly its tensor)."""
+    classes -- always builds or finds the structures of exactly its tensor); an exception that leaves the scope takes every
+    pending bet back.  Equality is decided by a position-keyed 2 x 64-bit checksum (``mipme_checksum``: any single changed word and
+    any two swapped words change it), i.e. with certainty against accidents, not against an adversary.  The pending-bet lists are
+    module globals: one host thread per process evaluates calculators with bets (``MIPME_SPECULATE_LISTS=0`` otherwise)."""
 
     def __enter__(self):
         _BET_SCOPE[0] += 1
@@ -380,6 +400,8 @@ class betting:
 
     def __exit__(self, *exc):
         _BET_SCOPE[0] -= 1
+        if exc[0] is not None and _BET_SCOPE[0] == 0:
+            _abandon_bets()
         return False
 
 
@@ -792,6 +814,8 @@ def get_topology(pairs: torch.Tensor, n_atoms: int) -> PairTopology:
                 device_checksum(pairs, t_old._sum, lambda key=key: _TOPOLOGIES.pop(key, None))
                 _TOPOLOGIES[key] = (weakref.ref(pairs), pairs._version, t_old)
                 t_old.__dict__.pop("_front", None)  # (the compiled front end's handle names the old list tensor)
+                while len(_TOPOLOGIES) > 16:
+                    _TOPOLOGIES.popitem(last=False)
                 return t_old
     topo = PairTopology(pairs, n_atoms)
     _TOPOLOGIES[key] = (weakref.ref(pairs), pairs._version, topo)
@@ -959,6 +983,8 @@ class _PMEFunction(torch.autograd.Function):
                     )
                     if write_dist:
                         src.pending = False
+                        if _BETS:  # rows adopted on a bet: if it is lost, the rerun (or materialize()) writes the values again
+                            _ON_LOST.append(lambda src=src: setattr(src, "pending", True))
                 elif topo is not None:
                     if tab is not None:  # constant distances: v_SR(d) per row entry is already there (PairTopology.tabulated)
                         _call(
@@ -1109,6 +1135,8 @@ class _PMEFunction(torch.autograd.Function):
                     fused["records_ready"] = True
                 if job is not None and write_dist:
                     src.pending = False
+                    if _BETS:
+                        _ON_LOST.append(lambda src=src: setattr(src, "pending", True))
                 if slab_axis is not None:
                     moments = torch.empty((6 * Cn,), dtype=torch.float64, device=device)
                     _call(
@@ -1897,6 +1925,7 @@ class _EnergyDirectSum(torch.autograd.Function):
                 _call("energy_sum", lib.mipme_dot_forward, _lib.current_stream(V.device), _lib.dtype_code(V.dtype),
                       V_c.numel(), V_c.data_ptr(), q_c.data_ptr(), scratch.data_ptr(), out.data_ptr())
         ctx.q, ctx.force, ctx.field, ctx.full = q_c, node.fused["force"], node.field, int(node.full_list)
+        ctx.same_cell = src_cell is None  # the distances were formed with this very cell tensor (weighted_sum passes None then)
         return out
 
     @staticmethod
@@ -1921,8 +1950,10 @@ class _EnergyDirectSum(torch.autograd.Function):
                 gc = gc.detach() if scale is None else gc * scale
                 if need_cell and need_src_cell:
                     grad_cell, grad_src_cell = gc[0:9].view(3, 3), gc[9:18].view(3, 3)
-                elif need_cell:  # (cell and the distances' cell are the same tensor: the sum)
-                    grad_cell = gc[18:27].view(3, 3)
+                elif need_cell:
+                    # the sum of mesh and pair part only if the distances' cell IS this tensor; distances from another
+                    # (e.g. detached) cell tensor leave `cell` the mesh part alone, as the reference's graph does
+                    grad_cell = (gc[18:27] if ctx.same_cell else gc[0:9]).view(3, 3)
                 elif need_src_cell:
                     grad_src_cell = gc[9:18].view(3, 3)
         if not need_pos:
