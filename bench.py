@@ -16,8 +16,8 @@ after the last step).  Every rank binds itself to a disjoint set of host cores o
 over ranks; ``weak_efficiency`` = rank 0's time with the other ranks idle / the time with all ranks busy, same invocation.
 
 Timing protocol: >= ``--prewarm-ms`` of untimed replays (clock ramp), the W warm-up steps, then ``--blocks`` blocks of EXACTLY K
-steps, each bracketed by barrier + synchronize.  ``ms_per_step`` / ``value`` are the FIRST block's (the contract's one timed
-region); ``ms_per_step_median`` is the median over the blocks.
+steps, each bracketed by barrier + synchronize.  ``ms_per_step`` / ``value`` are the MEDIAN block's (the contract's one timed
+region; round 4 reported the first block, which was the fastest one in every run); ``ms_per_step_first_block`` is the first.
 
 Rank 0 prints ONE JSON line: metric = atom-steps/s over all ranks, plus
   roofline     -- HBM roofline of the dominant kernel, timed live with HIP events on the launch stream
@@ -85,7 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default=None, choices=["per-step", "pipelined", "final"],
                     help="all-gather of the frame energies: after every evaluation, on the compute stream (default with more "
                          "than one rank); after every evaluation but overlapped with the next one; or once after the last step")
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (first = the reported value)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (the median block is the reported value)")
     ap.add_argument("--prewarm-ms", type=float, default=30.0, help="untimed replays before the warm-up steps (clock ramp)")
     ap.add_argument("--no-list-refresh", action="store_true")
     ap.add_argument("--neighbors", default="list", choices=["list", "stream"],
@@ -1032,8 +1032,12 @@ def main(argv=None):
         gathered = own.reshape(1, -1)
     per_block = gathered[:, :-1].max(dim=0).values.tolist()  # MAX over ranks, per block
     per_rank_ms = [1e3 * float(v) / args.steps for v in gathered[:, 0].tolist()]
-    elapsed = per_block[0]  # the contract's one timed region: the first block
+    # the contract's one timed region: the MEDIAN block (each block is exactly K steps between barrier + synchronize; the first
+    # block was the fastest one in every run of round 4 -- a 1 % favourable pick, round-4 verdict); the first block is reported
+    # next to it as ms_per_step_first_block
+    elapsed = sorted(per_block)[(len(per_block) - 1) // 2]
     ms_per_step = 1e3 * elapsed / args.steps
+    ms_per_step_first_block = 1e3 * per_block[0] / args.steps
     blocks_ms = [1e3 * v / args.steps for v in per_block]
     value = world * n_frames * w.n_atoms * args.steps / elapsed
     weak_efficiency = None
@@ -1073,7 +1077,7 @@ def main(argv=None):
         "prewarm_ms": args.prewarm_ms, "prewarm_steps": n_prewarm, "blocks": len(blocks_ms),
         "blocks_ms_per_step": [round(v, 6) for v in blocks_ms],
         "protocol": "untimed replays for >= prewarm_ms, W warm-up steps, then `blocks` blocks of exactly K steps, each bracketed by "
-                    "barrier + synchronize; ms_per_step / value = first block, ms_per_step_median = median over the blocks",
+                    "barrier + synchronize; ms_per_step / value = the median block (lower median), ms_per_step_first_block = the first one",
     }
     ms_per_step_median = float(np.median(blocks_ms))
 
@@ -1171,6 +1175,7 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_median": ms_per_step_median,
+            "ms_per_step_first_block": ms_per_step_first_block,
             "value_median": world * n_frames * w.n_atoms / (ms_per_step_median * 1e-3),
             "timing": timing,
             "weak_efficiency": weak_efficiency,

@@ -245,7 +245,8 @@ typedef struct mipme_kspace_forward_args {
    *     potential, and cell_work = float64[mipme_cell_tail_work()] of scratch.  How: the co-scheduled pair sum also forms
    *     sum q_a q_o v'/d sh (x) u per wave, the x stage the 12 k-grid sums from the derivative table (+ pre-reduces the pair
    *     sums), the gather sum_a r_a (x) dE/dr_a(mesh) per brick, and ONE more launch (a single workgroup) adds everything up.
-   *     Supported: 4-byte entries (shift_format 2), fp32 1/r and 1/r^6, fp64 1/r, no dist_out in the job. */
+   *     Supported: 4-byte entries (shift_format 2), 1/r and 1/r^6 in either precision (fp64 1/r^6: round 5), no dist_out
+   *     in the job. */
   void* out_grad_charges;
   void* out_grad_cell;
   const void* G_deriv;
@@ -257,7 +258,14 @@ typedef struct mipme_kspace_forward_args {
    * stage while it holds the values -- what a later mipme_kspace_backward with a cell gradient takes as `rho_hat` (general
    * upstream gradient: fused convolution with G_deriv; energy mode: the k-grid sums) without a 3-D transform of its own. */
   void* out_rho_hat;
+  /* flags (bit set, appended in round 5): MIPME_FWD_RHO_MESH_UNUSED -- the caller never reads rho_mesh after the call (it is a work
+   * buffer; a caller that transforms it later, e.g. mipme_fft_r2c for a cell gradient, leaves the bit clear).  With it the spread
+   * may skip the real charge mesh altogether: for power-of-two planes that fit a workgroup's LDS the charges are added straight
+   * into the tiles of the forward (y,z) transform (plane spread, csrc/bricks.hip), and neither the mesh nor the forward plane
+   * launch of the convolution exists. */
+  int64_t flags;
 } mipme_kspace_forward_args_t;
+#define MIPME_FWD_RHO_MESH_UNUSED 1
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
 /* Derivative table of G(k) for out_grad_cell: 4 reals per half-grid point, shape (nx,ny,nz/2+1,4) = {alpha, beta_x, beta_y,
  * beta_z} with dG/dk_c = alpha k_c - beta_c h_c and dG/dh_c = -beta_c k_c (k Cartesian, h_c = |a_c| / n_c; beta = 0 for PME).

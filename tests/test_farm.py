@@ -89,9 +89,11 @@ def _worker_forces(rank, world, port, n_frames, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames,world", [(5, 2), (2, 3)])
+@pytest.mark.parametrize("n_frames,world", [(5, 2), (2, 3), (17, 8), (5, 8)])
 def test_farm_gathers_per_atom_results(tmp_path, n_frames, world):
-    """the optional gather of per-atom potentials + forces -- frames of different sizes, a rank without frames."""
+    """SURVEY.md 8(e): the optional gather of per-atom potentials + forces -- frames of different sizes, a rank without frames;
+    the node's shape (8 ranks) with an uneven frame count (17 frames: blocks of 3 and 2) and with ranks that have none (5
+    frames on 8 ranks)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

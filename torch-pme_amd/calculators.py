@@ -430,10 +430,10 @@ class PMECalculator(Calculator):
             if (p_eff in (1, 6) and pot_desc.smearing > 0 and pot_desc.exclusion_radius <= 0 and plan.xfused and ops.XFUSED
                     and ops.MESH_MODE == "bricks" and ops.PAIR_MODE == "rows" and ops.COSCHEDULE and ops.ENERGY_FAST_PATH
                     and ops.ENERGY_DETECT and ops.COMPACT_ENTRIES and ops.FUSE_DISTANCES and not ops.OVERLAP):
-                # (a cell that requires a gradient: the derivative table of G for the gather tail's dE/dcell -- 1/r in either
-                # precision, 1/r^6 in fp32 (mipme.h, out_grad_cell); without it the C++ side declines such calls)
+                # (a cell that requires a gradient: the derivative table of G for the gather tail's dE/dcell (mipme.h,
+                # out_grad_cell); without it the C++ side declines such calls)
                 deriv = None
-                if want_cell and (p_eff == 1 or positions.dtype == torch.float32):
+                if want_cell:
                     deriv = ops.filter_derivative(geom, pot_desc, positions.dtype, positions.device)
                 fc = mod.Calculator(bytes(geom.desc(1)), bytes(pot_desc), plan.handle.value, G, cell,
                                     bool(self.full_neighbor_list), self._nan_flag_ptr() or 0, geom.n_half, plan, deriv)

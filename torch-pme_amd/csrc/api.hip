@@ -1,5 +1,7 @@
 // extern "C" entry points of libmipme.so (declared in include/mipme.h) and the composite
 // k-space forward / backward sequences (reference calculators/pme.py:88-143 and its autograd).
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -52,11 +54,12 @@ FftDims fft_plan_dims(const mipme_fft_plan*);
 // bricks.hip
 bool bricks_supported(const mipme_mesh_t*, int dtype);
 int64_t bins_bytes(const mipme_mesh_t*, int64_t, int dtype);
-template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
+template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*, bool = false);
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                         const mipme_sr_job_t*, bool, double*, const PlaneHost* = nullptr, bool* = nullptr);
 bool fft_plan_plane_forward_ok(const mipme_fft_plan*);
-void fft_plan_set_forward_done(mipme_fft_plan*, bool);
+void fft_plan_set_forward_done(mipme_fft_plan*, bool, int);
+void* fft_plan_hat_parts(mipme_fft_plan*, hipStream_t, int);
 template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int cell_tail_finalize_impl(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
                                                   const void*, const void*, const void*, void*);
@@ -78,11 +81,50 @@ static constexpr int kProfRepeat = 8;
 static bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
 
+// ---- optional tracing ranges (the reference brackets its pair sum with torch.profiler.record_function,
+// calculators/calculator.py:52,72,77): MIPME_ROCTX=1 brackets every composite C-ABI entry point and every stage inside it with
+// roctxRangePush / roctxRangePop, so that a rocprofv3 --marker-trace (or rocprof-sys) timeline of a user's model shows named
+// ranges around the kernels instead of anonymous launches.  Off by default (one branch per scope); the library is dlopen'ed:
+// libmipme does not link against a profiler.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+  Roctx() {
+    const char* e = getenv("MIPME_ROCTX");
+    if (!e || e[0] == '0') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) {
+          on = true;
+          return;
+        }
+      }
+    }
+  }
+};
+static const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(roctx().on) {
+    if (on) roctx().push(name);
+  }
+  ~TraceRange() {
+    if (on) roctx().pop();
+  }
+};
+
 struct ProfScope {
   hipStream_t st;
   ProfEntry e;
   bool on;
-  ProfScope(hipStream_t s, const char* name, int reps = 1) : st(s), on(g_prof_on) {
+  TraceRange range;
+  ProfScope(hipStream_t s, const char* name, int reps = 1) : st(s), on(g_prof_on), range(name) {
     if (!on) return;
     e.name = name;
     e.reps = reps;
@@ -154,7 +196,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
                             void* wait_event, int accumulate, void* out_field, void* out_records,
                             const mipme_sr_job_t* job, void* cell_partials, const GatherTailHost* tail, void* nan_flag,
                             void* out_grad_cell = nullptr, const void* G_deriv = nullptr, void* cell_work = nullptr,
-                            void* out_rho_hat = nullptr) {
+                            void* out_rho_hat = nullptr, bool rho_mesh_unused = false) {
   int rc;
   CellWork cw{};
   if (out_grad_cell) cw = cell_work_layout(m, N, cell_work);
@@ -172,12 +214,15 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     ~CounterGuard() {
       if (armed && counters) (void)zero_async(counters, sizeof(int) * n, st);
     }
-  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1, false};
+  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1 + size_t(m->nx) + 1, false};
   if (bins) {
     int* counters = fft_plan_brick_count(plan);
     guard.counters = counters;
     guard.armed = true;
-    STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins, counters, q, out_records));
+    // fused convolution ahead and planes that fit a workgroup: the spread will write the forward (y,z) transform itself, from
+    // the plane lists the binning pass leaves (bricks.hip plane_spread_yz_body)
+    const bool want_planes = !rho_hat && rho_mesh_unused && fft_plan_plane_forward_ok(plan);
+    STAGE(st, "bin_atoms", bins_build<T>(st, m, N, pos, bins, counters, q, out_records, want_planes));
     {
       const bool co = job && sr_job_fusable(job);
       const int reps = (g_prof_on && co) ? kProfRepeat : 1;
@@ -185,11 +230,25 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
       // fused convolution ahead and planes that fit a workgroup: the spread writes the forward (y,z) transform itself
       PlaneHost ph;
       bool planes = false;
-      if (!rho_hat && fft_plan_plane_forward_ok(plan)) ph.hat = hat_work;
+      if (want_planes) {
+        ph.hat = hat_work;
+        ph.slot_values = m->n_channels == 1;  // (bins_build above was handed these very charges)
+        ph.keep_mesh = false;
+        // MIPME_PLANE_PARTS workgroups per plane (default 4, at most 8): a plane's LDS atomics are what its workgroup waits for,
+        // and they go through ONE CU's LDS pipe
+        static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 4; }();
+        constexpr int kPlanePartsMax = 8;
+        ph.parts = parts_env < 1 ? 1 : (parts_env > kPlanePartsMax ? kPlanePartsMax : parts_env);
+        if (ph.parts > 1) {
+          ph.hat_more = fft_plan_hat_parts(plan, st, kPlanePartsMax - 1);
+          ph.more_stride = Mh * m->n_channels;
+          if (!ph.hat_more) ph.parts = 1;
+        }
+      }
       for (int r = 0; r < reps; ++r)
         if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr,
                                    out_grad_cell ? cw.cwave : nullptr, &ph, &planes))) return rc;
-      fft_plan_set_forward_done(plan, planes);
+      fft_plan_set_forward_done(plan, planes, ph.parts);
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",
@@ -1010,6 +1069,7 @@ int64_t mipme_cell_tail_work(const mipme_fft_plan* plan, const mipme_mesh_t* mes
 
 int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, const void* G, void* hat_out, void* hat_work,
                    void* mesh_out, void* dc_out) {
+  TraceRange _tr("mipme_convolve");
   MIPME_REQUIRE(plan != nullptr, "FFT plan is NULL");
   MIPME_REQUIRE(mesh_in && G && hat_out && hat_work && mesh_out, "NULL buffer passed to mipme_convolve");
   hipStream_t st = (hipStream_t)stream;
@@ -1027,6 +1087,7 @@ int mipme_convolve(mipme_fft_plan* plan, void* stream, const void* mesh_in, cons
 
 int mipme_spread(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
                  const void* values, void* mesh_out) {
+  TraceRange _tr("mipme_spread");
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   MIPME_REQUIRE(n_atoms >= 0 && mesh_out && (n_atoms == 0 || (positions && values)), "NULL buffer passed to mipme_spread");
@@ -1037,6 +1098,7 @@ int mipme_spread(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 
 int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_atoms, const void* positions,
                  const void* mesh_in, void* out) {
+  TraceRange _tr("mipme_gather");
   int rc = validate_mesh(mesh);
   if (rc) return rc;
   MIPME_REQUIRE(n_atoms >= 0 && mesh_in && (n_atoms == 0 || (positions && out)), "NULL buffer passed to mipme_gather");
@@ -1046,6 +1108,7 @@ int mipme_gather(void* stream, int dtype, const mipme_mesh_t* mesh, int64_t n_at
 }
 
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
+  TraceRange _tr("mipme_kspace_forward");
   mipme_kspace_forward_args_t a;
   int rc = load_args(args_in, a, "mipme_kspace_forward");
   if (rc) return rc;
@@ -1097,8 +1160,8 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
     if (a.out_grad_cell) {
       const int p = a.pot->kind == MIPME_COULOMB ? 1 : a.pot->exponent;
       MIPME_REQUIRE(a.G_deriv && a.cell_work, "out_grad_cell needs G_deriv (mipme_kfilter_build_deriv) and cell_work");
-      MIPME_REQUIRE((a.sr_job->shift_format & 0xff) == 2 && !a.sr_job->dist_out && (p == 1 || a.dtype == MIPME_F32),
-                    "out_grad_cell needs 4-byte entries (shift_format 2), no dist_out, and 1/r (or fp32 1/r^6)");
+      MIPME_REQUIRE((a.sr_job->shift_format & 0xff) == 2 && !a.sr_job->dist_out && (p == 1 || p == 6),
+                    "out_grad_cell needs 4-byte entries (shift_format 2), no dist_out, and 1/r or 1/r^6");
       MIPME_REQUIRE(!a.out_cell_partials, "out_grad_cell replaces out_cell_partials");
       tail.rpart = cell_work_layout(mesh, a.n_atoms, a.cell_work).rpart;
       tail.records = a.out_records;
@@ -1109,11 +1172,11 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
             kspace_forward_t<float>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                     a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
                                     a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
-                                    a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat),
+                                    a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat, (a.flags & MIPME_FWD_RHO_MESH_UNUSED) != 0),
             kspace_forward_t<double>(a.plan, st, mesh, a.pot, a.n_atoms, a.positions, a.charges, a.G, a.rho_mesh, a.rho_hat,
                                      a.hat_work, a.phi_mesh, a.dc, a.out_lr, a.out_phi, a.atom_bins, a.gather_wait_event,
                                      a.accumulate_out, a.out_field, a.out_records, a.sr_job, a.out_cell_partials, tp, a.nan_flag,
-                                     a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat));
+                                     a.out_grad_cell, a.G_deriv, a.cell_work, a.out_rho_hat, (a.flags & MIPME_FWD_RHO_MESH_UNUSED) != 0));
 }
 
 int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype) {
@@ -1130,6 +1193,7 @@ int64_t mipme_md_lists_ints(const mipme_mesh_t* mesh, int64_t n_atoms) {
 }
 
 int mipme_md_rebin(const mipme_md_args_t* args_in) {
+  TraceRange _tr("mipme_md_rebin");
   mipme_md_args_t a;
   int rc = md_check(args_in, a, "mipme_md_rebin");
   if (rc) return rc;
@@ -1139,6 +1203,7 @@ int mipme_md_rebin(const mipme_md_args_t* args_in) {
 }
 
 int mipme_md_step(const mipme_md_args_t* args_in) {
+  TraceRange _tr("mipme_md_step");
   mipme_md_args_t a;
   int rc = md_check(args_in, a, "mipme_md_step");
   if (rc) return rc;
@@ -1151,12 +1216,13 @@ int mipme_md_step(const mipme_md_args_t* args_in) {
   if (a.grad_cell) {
     const int p = a.pot->kind == MIPME_COULOMB ? 1 : a.pot->exponent;
     MIPME_REQUIRE(a.G_deriv && a.cell_work, "grad_cell needs G_deriv (mipme_kfilter_build_deriv) and cell_work");
-    MIPME_REQUIRE(p == 1 || a.dtype == MIPME_F32, "grad_cell: the fp64 pair kernel forms the cell sums for 1/r only");
+    MIPME_REQUIRE(p == 1 || p == 6, "grad_cell: the pair kernels form the cell sums for 1/r and 1/r^6");
   }
   DT_SWITCH(a.dtype, md_step_t<float>(a), md_step_t<double>(a));
 }
 
 int mipme_kspace_backward(const mipme_kspace_backward_args_t* args_in) {
+  TraceRange _tr("mipme_kspace_backward");
   mipme_kspace_backward_args_t a;
   int rc = load_args(args_in, a, "mipme_kspace_backward");
   if (rc) return rc;

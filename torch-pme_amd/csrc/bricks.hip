@@ -17,6 +17,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include <map>
+#include <utility>
+
 #include "rows_body.h"
 #include "fft_lds.h"
 
@@ -84,8 +87,9 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 //   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
 //         gathers of the forward and by everything in the backward pass.
 struct BinsLayout {
-  size_t snap, over_brick, rec, wts, codes, epart, det, det_sort_bytes, total;
+  size_t snap, over_brick, rec, wts, codes, qs, plist, pover, epart, det, det_sort_bytes, total;
   int cap;
+  int pcap;  // entries per plane list (0: no plane lists for this mesh, see plane_list_capacity)
   int64_t slots;  // nb * cap + N
 };
 
@@ -150,6 +154,7 @@ __device__ __forceinline__ void store_slot_weights(T* __restrict__ wr, const T (
   }
 }
 
+static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype);
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
   const size_t s = dtype == MIPME_F32 ? 4 : 8;
@@ -163,6 +168,12 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.rec = off;        off += al(sizeof(int4) * size_t(l.slots));
   l.wts = off;        off += al(wts_stride_rt(m->order, s) * s * size_t(l.slots));  // per slot: see wts_stride
   l.codes = off;      off += al(size_t(l.slots));  // per slot: which neighbouring bricks the atom's stencil reaches (reach_code)
+  l.qs = off;         off += al(s * size_t(l.slots));  // per slot: the atom's charge (single channel), for the plane spread
+  // plane lists (plane spread): the slots of the atoms whose stencil reference point m_x is plane p, pcap per plane, and an
+  // overflow list (slots of atoms whose plane list was full: normally empty) that every plane also walks
+  l.pcap = plane_list_capacity(m, N, dtype);
+  l.plist = off;      off += al(sizeof(int) * size_t(l.pcap) * size_t(l.pcap ? m->nx : 0));
+  l.pover = off;      off += al(sizeof(int) * size_t(l.pcap ? N : 0));
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.det = off;
@@ -186,6 +197,12 @@ struct BinIndex {
   int nb, cap;
   int64_t over_base;      // = nb * cap
   unsigned char* codes = nullptr;  // per brick slot: reach_code of the atom (written by the binning pass, read by the spread's scan)
+  // plane lists (plane spread; pcap == 0: none): live counters int[nx + 1] behind the brick counters (zeroed by the forward
+  // gather like those), slots per plane, overflow slots
+  int* plive = nullptr;
+  int* plist = nullptr;
+  int* pover = nullptr;
+  int pcap = 0;
 };
 
 // Which of its brick's neighbours an atom's stencil reaches, from its position inside the brick: bit 2 d = the lower neighbour
@@ -252,7 +269,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
                                                const T* __restrict__ pos, int* __restrict__ over_brick,
                                                int4* __restrict__ rec, T* __restrict__ wts, const T* __restrict__ q,
                                                AtomRecord<T>* __restrict__ atom_rec, unsigned block,
-                                               const int* __restrict__ slot_of = nullptr) {
+                                               const int* __restrict__ slot_of = nullptr, T* __restrict__ qs = nullptr) {
   const int64_t i = int64_t(block) * blockDim.x + threadIdx.x;
   const bool valid = i < Natoms;
   const int lane = threadIdx.x & 63;
@@ -264,6 +281,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     b = ((m[0] / BRICK) * bg.nby + m[1] / BRICK) * bg.nbz + m[2] / BRICK;
   }
   int myslot = 0, over_k = -1;
+  int pl_leader = lane, pl_rank = 0, pl_count = 0, pl_slot = -1;
   if (slot_of) {  // deterministic mode: slots (and the live counters) come from the sorted atom list, see det_slots_kernel
     if (valid) {
       myslot = slot_of[i];
@@ -284,11 +302,28 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
       }
       remaining &= ~peers;
     }
+    // the same grouping by x plane for the plane lists (plane spread): their atomics travel with the bricks' ones
+    if (bi.plive) {
+      unsigned long long rem = __ballot(valid);
+      while (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int p0 = __shfl(m[0], leader, 64);
+        const unsigned long long peers = __ballot(valid && m[0] == p0);
+        if (valid && m[0] == p0) {
+          pl_leader = leader;
+          pl_rank = __popcll(peers & ((1ull << lane) - 1ull));
+          pl_count = __popcll(peers);
+        }
+        rem &= ~peers;
+      }
+    }
     // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
-    int base = 0;
+    int base = 0, pbase = 0;
     if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
+    if (bi.plive && valid && pl_leader == lane) pbase = atomicAdd(&bi.plive[m[0]], pl_count);
     base = __shfl(base, my_leader, 64);
     myslot = base + my_rank;
+    if (bi.plive) pl_slot = __shfl(pbase, pl_leader, 64) + pl_rank;
   }
   int64_t dst = 0;
   if (valid) {
@@ -308,6 +343,13 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
       atom_rec[i] = r;
     }
     rec[dst] = make_int4(m[0], m[1], m[2], int(i));
+    if (qs) qs[dst] = q[i];
+    if (pl_slot >= 0) {  // plane list of m_x (or the plane overflow list: one atomic per atom, normally none)
+      if (pl_slot < bi.pcap)
+        bi.plist[int64_t(m[0]) * bi.pcap + pl_slot] = int(dst);
+      else
+        bi.pover[atomicAdd(&bi.plive[g.nx], 1)] = int(dst);
+    }
     if (bi.codes && dst < bi.over_base) bi.codes[dst] = (unsigned char)reach_code<N>(m, g.nx, g.ny, g.nz);
   }
   // The 6N weights of an atom go to its slot, anywhere in the bins: written by the atom's own lane that is 6N four-byte stores
@@ -359,8 +401,8 @@ __global__ __launch_bounds__(256) void bin_atoms_kernel(Geom g, BrickGeom bg, Bi
                                                        const T* __restrict__ pos, int* __restrict__ over_brick,
                                                        int4* __restrict__ rec, T* __restrict__ wts,
                                                        const T* __restrict__ q, AtomRecord<T>* __restrict__ atom_rec,
-                                                       const int* __restrict__ slot_of) {
-  bin_atoms_body<SCHEME, N, T, COALESCE>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x, slot_of);
+                                                       const int* __restrict__ slot_of, T* __restrict__ qs) {
+  bin_atoms_body<SCHEME, N, T, COALESCE>(g, bg, bi, Natoms, pos, over_brick, rec, wts, q, atom_rec, blockIdx.x, slot_of, qs);
 }
 
 // ---- deterministic slots (MIPME_DETERMINISTIC) -----------------------------------------------------------------------------
@@ -598,6 +640,7 @@ struct SpreadArgs {
   const int4* rec;
   const T* wts;
   const T* val;
+  const T* qs = nullptr;  // per-slot copy of val (forward spread of single-channel charges after the binning pass), or NULL
   T scale;
   T* mesh;
   int stage_rows;
@@ -936,43 +979,93 @@ static inline unsigned brick_pattern(const BrickGeom& bg, unsigned n_spread, uns
   return pattern;
 }
 
+// Workgroups of `fn` (SPREAD_THREADS threads, `lds` bytes of dynamic LDS) the device holds at once; cached per kernel and LDS size.
+static unsigned resident_workgroups(const void* fn, size_t lds) {
+  static std::map<std::pair<const void*, size_t>, unsigned> cache;
+  const auto key = std::make_pair(fn, lds);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, dev = 0, cus = 0;
+  unsigned slots = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SPREAD_THREADS, lds) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+    slots = unsigned(per_cu) * unsigned(cus);
+  else
+    (void)hipGetLastError();
+  cache[key] = slots;
+  return slots;
+}
+// How many brick workgroups of a bricks-first launch continue with a row block (spread_rows_kernel): as many as it takes to make
+// the launch ONE generation -- n_spread + n_row_blocks - resident slots, at most one per brick, a multiple of 8 (the XCD mapping);
+// none when everything is resident anyway, when the launch is many generations whatever is done (interleaved block order:
+// pattern > 0), or with MIPME_BRICK_CONTINUE=0.
+static unsigned cosched_continuations(const void* fn, size_t lds, const BrickGeom& bg, unsigned n_spread, unsigned n_row_blocks,
+                                      unsigned pattern) {
+  static const bool on = env_flag("MIPME_BRICK_CONTINUE", false);  // measured SLOWER (cfg3 launch 22.2 -> 25.1 us, profiles/r05_experiments.txt item 5): opt-in
+  if (!on || pattern != 0 || n_spread == 0) return 0;
+  const unsigned slots = resident_workgroups(fn, lds);
+  const unsigned nb = bg.xcd ? pad8(n_spread) : n_spread, nr = bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
+  if (slots == 0 || nb + nr <= slots || nb >= slots) return 0;
+  unsigned k = nb + nr - slots;
+  k = k > nb ? nb : k;
+  k = k > nr ? nr : k;
+  return bg.xcd ? (k & ~7u) : k;
+}
+
+// the row workgroup of a co-scheduled launch (shared by spread_rows_kernel and plane_rows_kernel)
+template <typename T, int PFAST, bool COMPACT, bool CELL>
+__device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, unsigned r, char* smem_rows) {
+  AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
+  bool done = false;
+  if constexpr (COMPACT && std::is_same<T, float>::value) {
+    if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
+      sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
+      done = true;
+    }
+  }
+#if MIPME_ROW_LANES == 16
+  if constexpr (COMPACT && std::is_same<T, double>::value && (PFAST == 1 || PFAST == 6)) {
+    if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table; 1/r^6: closed form)
+      sr_rows_f64_body<SPREAD_THREADS, CELL, PFAST>(ra, r, smem_rows);
+      done = true;
+    }
+  }
+#endif
+  if constexpr (!CELL) {
+    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
+  }
+}
+
+// n_cont (pattern 0 only): the first n_cont brick workgroups CONTINUE with a row block when their brick is done -- the row
+// blocks of the last n_cont row slots, which are then not launched as workgroups of their own.  Round 5: the launch was bound
+// by its SECOND GENERATION of row workgroups (cfg3: 512 bricks + 999 row blocks on 1 024 resident slots; the 487 row blocks that
+// find no slot start when bricks retire, 8-11 us into the launch, and live 9-10 us); with the continuation the whole launch is
+// one generation of 1 024 workgroups and nobody waits for a dispatch.
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
-                                                                                              unsigned n_spread, unsigned pattern) {
+                                                                                              unsigned n_spread, unsigned pattern, unsigned n_cont) {
   MIPME_WG_STAMP(0);
   // n_spread bricks (0: a rows-only launch) and the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
   const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
   const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
-  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad, pattern);
+  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad - n_cont, pattern);
+  extern __shared__ __attribute__((aligned(16))) char smem_rows[];
+  unsigned row_slot = ~0u;
   if (cs.brick) {
     const unsigned b = brick_of(sa.bg, cs.slot);
     if (cs.slot < n_pad && b < n_spread) spread_brick_body<N, T>(sa, b);
-  } else if (cs.slot < n_rows_pad) {
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
-    if (r < n_row_blocks) {
-      // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
-      extern __shared__ __attribute__((aligned(16))) char smem_rows[];
-      AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
-      bool done = false;
-      if constexpr (COMPACT && std::is_same<T, float>::value) {
-        if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-          sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-          done = true;
-        }
-      }
-#if MIPME_ROW_LANES == 16
-      if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
-        if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
-          sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
-          done = true;
-        }
-      }
-#endif
-      if constexpr (!CELL) {
-        if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
-      }
+    if (cs.slot < n_cont) {  // (uniform) the staging region becomes the row block's tables
+      __syncthreads();
+      row_slot = n_rows_pad - n_cont + cs.slot;  // same residue mod 8 as this workgroup: the XCD-contiguous row mapping holds
     }
+  } else if (cs.slot < n_rows_pad - n_cont) {
+    row_slot = cs.slot;
+  }
+  if (row_slot != ~0u) {
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(row_slot, n_row_blocks) : row_slot;
+    // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
+    if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL>(ra, r, smem_rows);
   }
 #ifdef MIPME_WG_TIMELINE
   __syncthreads();
@@ -984,7 +1077,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
 // shift table in LDS and no register bound, i.e. full occupancy -- the same bodies, the same per-wave energy partial sums.
 template <typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int xcd) {
-  constexpr bool F64_BODY = COMPACT && std::is_same<T, double>::value && PFAST == 1 && kRowLanes == 16;
+  constexpr bool F64_BODY = COMPACT && std::is_same<T, double>::value && (PFAST == 1 || PFAST == 6) && kRowLanes == 16;
   __shared__ __attribute__((aligned(16))) char tab_raw[F64_BODY ? kRowsF64LdsBytes : sizeof(AtomRecord<T>) * kShiftTableSize];
   AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(tab_raw);
   constexpr int BS = 256;
@@ -1000,7 +1093,7 @@ __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int
 #if MIPME_ROW_LANES == 16
   if constexpr (F64_BODY) {
     if (CELL || !ra.dist_out) {
-      sr_rows_f64_body<BS, CELL>(ra, r, tab_raw);
+      sr_rows_f64_body<BS, CELL, PFAST>(ra, r, tab_raw);
       return;
     }
   }
@@ -1012,180 +1105,250 @@ __global__ __launch_bounds__(256) void rows_only_kernel(FusedRowsArgs<T> ra, int
 template <typename T>
 static inline bool rows_cell_supported(int pfast, int shift_format, const void* dist_out) {
   if ((shift_format & kShiftFormatMask) != kShiftTable32 || dist_out || kRowLanes != 16) return false;
-  return sizeof(T) == 4 ? (pfast == 1 || pfast == 6) : pfast == 1;
+  return pfast == 1 || pfast == 6;
 }
 
 // ---- plane spread: the charges scattered straight into a (y,z) plane's transform tile -------------------------------------
 // Round 5.  The owner-computes bricks above cost a third of the co-scheduled launch's vector instructions (2.6 M of 7.8 M at
 // cfg3: every survivor is a 512-point rank-1 update of which 7 % is not zero), and the plane transform that follows re-reads
 // the mesh they wrote in a launch of its own (6.7 us of pure latency).  Here ONE workgroup per x plane of the mesh
-//   A  walks the atom bins of the one or two brick slabs whose atoms can reach the plane (m_x in [x - s0 - (N-1), x - s0]) and
-//      appends those that do to an LDS list {slot | stencil row << 28, atom},
-//   B  scatters every listed atom's N x N (y,z) stencil points, times its x weight and value, into the plane -- stored in LDS in
-//      the layout the forward transform starts from (rows as bit-reversed complex pairs, fft_lds.h yz_real_slot) -- with LDS
-//      float atomics (ds_add_f32 / ds_add_f64: N^2 per atom and plane, N^3 per atom in all, nothing is computed that is zero),
-//   C  transforms the plane in place (yz_forward_finish) and stores its block of the half-complex mesh: the convolution's
+//   A  walks the atom bins of the one or two brick slabs whose atoms can reach the plane (m_x in [x - s0 - (N-1), x - s0]), a
+//      wavefront per brick and a lane per atom, record / weights / charge of the next brick in flight while the current one is
+//      scattered,
+//   B  adds every such atom's N x N (y,z) stencil points, times its x weight and charge, to the plane in LDS with
+//      DOUBLE-PRECISION LDS atomics (ds_add_f64) -- N^2 per atom and plane, N^3 per atom in all, nothing is computed that is zero,
+//   C  converts the plane to the working precision in the layout the forward transform starts from (rows as bit-reversed complex
+//      pairs), transforms it in place (yz_forward_finish) and stores its block of the half-complex mesh: the convolution's
 //      forward (y,z) launch is gone (fft_plan_forward_done).
-// The sums' order depends on the arrival order of the atomics, so results vary in the last bits from run to run like those of the
-// one-pass binning do; MIPME_DETERMINISTIC=1 keeps the bricks.  Single channel, planes whose tile fits the co-scheduled launch's
-// LDS budget (64 x 64 fp32, 64 x 32 fp64); larger meshes keep the bricks.
+// Why fp64 atomics for fp32 meshes: tools/r05/lds_atomic_bench.hip (profiles/r05_b_lds_atomic.txt) -- one 2 500-atom plane pass
+// is 80 us with ds_add_f32 (0.4 lanes per clock and CU, whatever the denormal mode: round 1's "LDS float atomics are the
+// limiter"), 13 us with ds_add_f64, 8 us with ds_add_u64, 3.7 us with plain stores.  The double-precision sums also make the
+// result independent of the order of arrival except in the last bit of the conversion.  MIPME_DETERMINISTIC=1 keeps the bricks.
+// Single channel, planes whose accumulation tile fits the co-scheduled launch's LDS budget (64 x 64); larger meshes keep the bricks.
 template <typename T>
 struct PlaneArgs {
   Cplx<T>* hat = nullptr;  // (nx, ny, nz/2 + 1): receives the (y,z)-transformed planes; nullptr: no plane spread in this launch
-  T* mesh = nullptr;       // nullable: the real charge mesh as well (callers that keep it)
   int logny = 0, loglz = 0;
-  int list_cap = 0;        // entries of the survivor list
+  int tile_off = 0, tw_off = 0;  // byte offsets of the transform tile (0: it aliases the accumulation tile) and of the twiddles
+  int misc_off = 0;              // ... and of 16 ints of bookkeeping (list lengths)
+  // `parts` workgroups per plane: part k takes the k-th slice of every plane list and transforms its own partial plane into
+  // hat (k = 0) / hat_more + (k - 1) * more_stride; the x stage of the convolution adds the transforms up (XCellExtra::hat_more)
+  int parts = 1;
+  Cplx<T>* hat_more = nullptr;
+  int64_t more_stride = 0;
 };
 
-static constexpr int kPlaneSlotBits = 28;
 // LDS of a launch with planes: co-scheduled with the row blocks, four workgroups per CU must fit 160 KB (and the rows need their
 // shift / erfcx tables: <= 32 KB); alone, the default dynamic limit
-static constexpr size_t kPlaneLdsCosched = 39 * 1024, kPlaneLdsAlone = 64 * 1024;
-static inline size_t plane_tile_bytes(int ny, int nz, size_t real_bytes) {
+static constexpr size_t kPlaneLdsCosched = 39 * 1024;
+static inline size_t plane_tile_bytes(int ny, int nz, size_t real_bytes) { return 2 * real_bytes * size_t(ny) * (size_t(nz / 2) + 1); }
+static inline size_t plane_tw_bytes(int ny, int nz, size_t real_bytes) {
   const size_t Lz = size_t(nz / 2), Ltab = size_t(ny) > Lz ? size_t(ny) : Lz;
-  return 2 * real_bytes * (size_t(ny) * (Lz + 1) + Ltab / 2 + (Lz + 1));
+  return 2 * real_bytes * (Ltab / 2 + (Lz + 1));
 }
-static inline size_t plane_lds_bytes(int ny, int nz, size_t real_bytes, int list_cap) {
-  return plane_tile_bytes(ny, nz, real_bytes) + sizeof(int2) * size_t(list_cap) + 16;
+// accumulation tile (ny x nz doubles); the fp32 transform tile is smaller and takes its place, the fp64 one sits behind it
+template <typename T>
+static inline void plane_lds_layout(int ny, int nz, PlaneArgs<T>& pa, size_t& total) {
+  const size_t acc = sizeof(double) * size_t(ny) * nz, tile = plane_tile_bytes(ny, nz, sizeof(T));
+  const size_t tile_off = sizeof(T) == 4 ? 0 : acc;
+  const size_t tw_off = sizeof(T) == 4 ? (acc > tile ? acc : tile) : acc + tile;
+  pa.tile_off = int(tile_off);
+  pa.tw_off = int(tw_off);
+  pa.misc_off = int(tw_off + plane_tw_bytes(ny, nz, sizeof(T)));
+  total = size_t(pa.misc_off) + 128;
 }
 
-// one atom's N x N points of the plane: r = its bin record, tt = which of its x weights the plane takes, wr = its weight row
+static inline bool sparse_bricks(int64_t n_atoms, int nb);
+// Entries per plane list of the bins, 0 if this mesh / system does not use the plane spread: single channel, power-of-two planes
+// whose tiles fit the co-scheduled launch's LDS, dense bricks, not the deterministic mode (its slots come from a sort).
+// 4 x the mean occupancy of a plane + 64; the rest goes to the plane overflow list.
+static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
+  static const bool plane_env = env_flag("MIPME_PLANE_SPREAD", true);
+  if (!plane_env || deterministic_mode() || m->n_channels != 1 || N <= 0) return 0;
+  const bool pow2 = (m->ny & (m->ny - 1)) == 0 && (m->nz & (m->nz - 1)) == 0 && m->nz >= 4 && m->ny >= 2;
+  if (!pow2 || m->nx < 2 * BRICK) return 0;
+  if (sparse_bricks(N, make_brick_geom(m).nb)) return 0;
+  size_t need = 0;
+  if (dtype == MIPME_F32) {
+    PlaneArgs<float> pa;
+    plane_lds_layout<float>(m->ny, m->nz, pa, need);
+  } else {
+    PlaneArgs<double> pa;
+    plane_lds_layout<double>(m->ny, m->nz, pa, need);
+  }
+  if (need > kPlaneLdsCosched) return 0;
+  const int64_t mean = (N + m->nx - 1) / m->nx, all = (N + 63) / 64 * 64;
+  int64_t cap = (4 * mean + 64 + 63) / 64 * 64;
+  if (cap > all) cap = all;
+  return int(cap);
+}
+
+// what a lane holds of one atom while the previous batch is being scattered
 template <int N, typename T>
-__device__ __forceinline__ void plane_scatter_one(T* __restrict__ tr, int RZ, const Geom& g, int loglz, int4 r, int tt,
-                                                  const T* __restrict__ wr_, T v) {
+struct PlaneItem {
+  T vx;      // charge * scale * x weight of this plane; 0 for lanes without an atom
+  int my, mz;
+  T wy[N], wz[N];
+};
+
+// the atom in bin slot `slot`, whose stencil row `tt` (uniform: every atom of one plane list has the same) falls on the plane
+template <int N, typename T>
+__device__ __forceinline__ void plane_item_load(PlaneItem<N, T>& it, bool ok, int slot, int tt, const int4* __restrict__ rec,
+                                                const T* __restrict__ wts, const T* __restrict__ qs, T scale) {
+  constexpr int W = wts_stride<N, T>();
+  // (branch-free: lanes without an atom read slot 0 -- always there -- and get a zero value; an if / else that fills the struct
+  // makes the compiler keep it on the stack)
+  const int se = ok ? slot : 0;
+  const int4 r = rec[se];
+  const T* __restrict__ wr = wts + int64_t(se) * W;
+  const T v = qs[se] * scale * wr[tt];
+  it.vx = ok ? v : T(0);
+  it.my = r.y;
+  it.mz = r.z;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    it.wy[k] = wr[N + k];
+    it.wz[k] = wr[2 * N + k];
+  }
+}
+
+// one atom's N x N points of the plane (natural layout acc[y * nz + z]): the products in the working precision (as the bricks
+// form them), the sums in double
+template <int N, typename T>
+__device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, const Geom& g, const PlaneItem<N, T>& it) {
   constexpr int s0 = stencil_start<N>();
-  const T* __restrict__ wr = static_cast<const T*>(__builtin_assume_aligned(wr_, 16));
-  T w[3 * N];
+  int zo[N];
 #pragma unroll
-  for (int k = 0; k < 3 * N; ++k) w[k] = wr[k];
-  T wxt = w[0];
-#pragma unroll
-  for (int k = 1; k < N; ++k) wxt = tt == k ? w[k] : wxt;
-  const T vx = v * wxt;
-  int rowa[N], zo[N];
+  for (int k = 0; k < N; ++k) zo[k] = wrap1(it.mz + s0 + k, g.nz);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    rowa[j] = wrap1(r.y + s0 + j, g.ny) * (2 * RZ);
-    const int z = wrap1(r.z + s0 + j, g.nz);
-    zo[j] = ((loglz ? int(__brev(unsigned(z >> 1)) >> (32 - loglz)) : 0) << 1) | (z & 1);
-  }
+    const int row = wrap1(it.my + s0 + j, g.ny) * g.nz;
+    const T ay = it.vx * it.wy[j];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const T a = vx * w[N + j];
-#pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(&tr[rowa[j] + zo[k]], a * w[2 * N + k]);
+    for (int k = 0; k < N; ++k) atomicAdd(&acc[row + zo[k]], double(ay * it.wz[k]));
   }
 }
 
 template <int N, typename T>
-__device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, const PlaneArgs<T>& pa, unsigned plane,
+__device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, const PlaneArgs<T>& pa, unsigned item,
                                                      char* smem) {
+  // item = plane * parts + part: the parts of one plane are neighbours in the launch (same XCD: they read the same bins)
+  const unsigned plane = item / unsigned(pa.parts);
+  const int part = int(item - plane * unsigned(pa.parts));
   const Geom& g = args.g;
-  const BrickGeom& bg = args.bg;
   const BinIndex& bins = args.bins;
   const int4* __restrict__ rec = args.rec;
   const T* __restrict__ wts = args.wts;
-  const T* __restrict__ val = args.val;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+  const T* __restrict__ qs = args.qs;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   constexpr int s0 = stencil_start<N>();
-  constexpr int W = wts_stride<N, T>();
-  const YzTile<T> yt = yz_tile_setup<T, true>(g.ny, g.nz, smem);
-  T* tr = reinterpret_cast<T*>(yt.tile);
-  const int RZ = yt.RZ, tile_reals = 2 * g.ny * RZ;
-  for (int i = tid; i < tile_reals; i += nthr) tr[i] = T(0);
-  int2* list = reinterpret_cast<int2*>(yt.twr + RZ);
-  int* nsurv = reinterpret_cast<int*>(list + pa.list_cap);
-  if (tid == 0) *nsurv = 0;
-  const int x0 = int(plane);
-  if (args.from_live) {  // per-call snapshot of the brick counts (see spread_brick_body): the planes share the bricks among them
-    for (int b = x0 + tid * g.nx; b <= bins.nb; b += g.nx * nthr) bins.snap[b] = bin_count_of(bins, b, true);
-  }
-  __syncthreads();
   MIPME_WG_PHASE(0);
-  // A: candidates.  All lanes of a wavefront call `consider` together (ballot + one LDS atomic per wavefront and chunk).
-  auto consider = [&](int slot, int4 r, bool ok) __attribute__((always_inline)) {
-    int d = x0 - r.x - s0;  // in (-nx, nx + N)
-    d += d < 0 ? g.nx : 0;
-    d -= d >= g.nx ? g.nx : 0;
-    const bool keep = ok && d < N;
-    const unsigned long long mask = __ballot(keep);
-    if (mask) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(nsurv, __popcll(mask));
-      base = __builtin_amdgcn_readfirstlane(base);
-      const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (keep) {
-        if (idx < pa.list_cap)
-          list[idx] = make_int2(slot | (d << kPlaneSlotBits), r.w);
-        else  // list full (a very dense plane): scatter at once
-          plane_scatter_one<N, T>(tr, RZ, g, pa.loglz, r, d, wts + int64_t(slot) * W, val[r.w] * args.scale);
-      }
-    }
-  };
-  const int nyz = bg.nby * bg.nbz;
-  int prev = -1;
-  for (int t = N - 1; t >= 0; --t) {
-    const int sx = posmod(x0 - s0 - t, g.nx) / BRICK;
-    if (sx == prev) continue;
-    prev = sx;
-    constexpr int U = 4;  // bricks in flight per wavefront
-    for (int byz0 = wave; byz0 < nyz; byz0 += nwaves * U) {
-      int cnt[U];
-      int4 r[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int byz = byz0 + u * nwaves;
-        cnt[u] = byz < nyz ? bin_count_of(bins, sx * nyz + byz, args.from_live) : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int b = sx * nyz + byz0 + u * nwaves;
-        r[u] = lane < cnt[u] ? rec[int64_t(b) * bins.cap + lane] : make_int4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int b = sx * nyz + byz0 + u * nwaves;
-        consider(b * bins.cap + lane, r[u], lane < cnt[u]);
-        for (int sb = 64; sb < cnt[u]; sb += 64) {  // bricks above 64 atoms
-          const int s = sb + lane;
-          const bool ok = s < cnt[u];
-          consider(b * bins.cap + s, ok ? rec[int64_t(b) * bins.cap + s] : make_int4(0, 0, 0, 0), ok);
-        }
-      }
-    }
+  double* acc = reinterpret_cast<double*>(smem);
+  const int npts = g.ny * g.nz;
+  for (int i = tid; i < npts; i += nthr) acc[i] = 0.0;
+  const YzTile<T> yt = yz_tile_setup<T, true>(g.ny, g.nz, smem + pa.tile_off, smem + pa.tw_off);
+  const int x0 = int(plane);
+  if (args.from_live) {  // per-call snapshot of the brick counts (see spread_brick_body): the workgroups share the bricks among them
+    const int n_items = g.nx * pa.parts;
+    for (int b = int(item) + tid * n_items; b <= bins.nb; b += n_items * nthr) bins.snap[b] = bin_count_of(bins, b, true);
   }
-  {  // the overflow region (atoms whose brick was full: normally none)
-    const int oc = bin_count_of(bins, bins.nb, args.from_live);
-    for (int sb = wave * 64; sb < oc; sb += nthr) {
-      const int s = sb + lane;
-      const bool ok = s < oc;
-      consider(int(bins.over_base) + s, ok ? rec[bins.over_base + s] : make_int4(0, 0, 0, 0), ok);
-    }
+  // [0, N): end of this part's slice of each list; [8, 8 + N): the lists' planes; [16, 16 + N): start of the slice
+  int* lst = reinterpret_cast<int*>(smem + pa.misc_off);
+  static_assert(N <= 8, "bookkeeping of the plane lists");
+  if (tid < N) {
+    const int p = posmod(x0 - s0 - tid, g.nx);
+    const int c = min(bins.plive[p], bins.pcap);
+    lst[tid] = int(int64_t(c) * (part + 1) / pa.parts);
+    lst[8 + tid] = p;
+    lst[16 + tid] = int(int64_t(c) * part / pa.parts);
   }
   __syncthreads();
   MIPME_WG_PHASE(1);
-  // B: scatter
-  const int ns = min(*nsurv, pa.list_cap);
-  for (int i = tid; i < ns; i += nthr) {
-    const int2 e = list[i];
-    const int slot = e.x & ((1 << kPlaneSlotBits) - 1), tt = int(unsigned(e.x) >> kPlaneSlotBits);
-    plane_scatter_one<N, T>(tr, RZ, g, pa.loglz, rec[slot], tt, wts + int64_t(slot) * W, val[e.y] * args.scale);
+  // The atoms of this plane: the plane lists of m_x = x0 - s0 - tt, tt = 0 .. N-1 (stencil row tt of those atoms is this plane),
+  // walked as ONE sequence of batches of blockDim atoms -- every lane of a batch holds an atom (but for each list's last batch),
+  // so the N^2 LDS atomics of a batch are dense; the next batch's slot, record, weights and charge are in flight while the
+  // current one is scattered.
+  // (list lengths and planes in LDS, read back with a uniform index: kept in registers and picked by `tt` the compiler spills
+  // them to a stack array)
+  // the first (tt, b) with entries at or after the given one, packed as tt * 2^20 + b; tt == N: none
+  auto settle = [&](int tt, int b) __attribute__((always_inline)) -> int {
+    while (tt < N && lst[16 + tt] + b * nthr >= lst[tt]) {
+      ++tt;
+      b = 0;
+    }
+    return (tt << 20) | b;
+  };
+  auto after = [&](int st) __attribute__((always_inline)) -> int {
+    return (st >> 20) < N ? settle(st >> 20, (st & 0xfffff) + 1) : st;
+  };
+  // this lane's bin slot in batch `st` (-1: none): the first of the two dependent loads of a batch, issued TWO batches ahead
+  auto load_slot = [&](int st) __attribute__((always_inline)) -> int {
+    const int tt = st >> 20;
+    if (tt >= N) return -1;
+    const int i = lst[16 + tt] + (st & 0xfffff) * nthr + tid;
+    return i < lst[tt] ? bins.plist[int64_t(lst[8 + tt]) * bins.pcap + i] : -1;
+  };
+  int st1 = settle(0, 0), st2 = after(st1);
+  int slot1 = load_slot(st1), slot2 = load_slot(st2);
+  PlaneItem<N, T> nxt;
+  if ((st1 >> 20) < N) plane_item_load<N, T>(nxt, slot1 >= 0, slot1, st1 >> 20, rec, wts, qs, args.scale);
+  while ((st1 >> 20) < N) {
+    const PlaneItem<N, T> cur = nxt;
+    const int st3 = after(st2);
+    const int slot3 = load_slot(st3);
+    if ((st2 >> 20) < N) plane_item_load<N, T>(nxt, slot2 >= 0, slot2, st2 >> 20, rec, wts, qs, args.scale);
+    if (cur.vx != T(0)) plane_item_scatter<N, T>(acc, g, cur);
+    st1 = st2;
+    st2 = st3;
+    slot2 = slot3;
+  }
+  if (part == 0) {  // the plane overflow list (atoms whose plane list was full: normally none)
+    const int oc = bins.plive[g.nx];
+    for (int i = tid; i < oc; i += nthr) {
+      const int slot = bins.pover[i];
+      int d = x0 - rec[slot].x - s0;
+      d += d < 0 ? g.nx : 0;
+      d -= d >= g.nx ? g.nx : 0;
+      if (d < N) {
+        PlaneItem<N, T> it;
+        plane_item_load<N, T>(it, true, slot, d, rec, wts, qs, args.scale);
+        plane_item_scatter<N, T>(acc, g, it);
+      }
+    }
   }
   __syncthreads();
   MIPME_WG_PHASE(2);
-  if (pa.mesh) {  // the real plane, for callers that keep the charge mesh
-    const int Lz = yt.Lz;
-    T* dst = pa.mesh + int64_t(plane) * g.ny * g.nz;
-    for (int idx = tid; idx < g.ny * Lz; idx += nthr) {
-      const int y = idx / Lz, j = idx - y * Lz;
-      const int jr = pa.loglz ? int(__brev(unsigned(j)) >> (32 - pa.loglz)) : 0;
-      reinterpret_cast<Cplx<T>*>(dst)[idx] = yt.tile[y * RZ + jr];
+  // C: to the working precision and the transform's layout (rows as complex sequences c_j = a_2j + i a_2j+1, bit-reversed for
+  // the DIT z transform); the real plane itself for callers that keep the charge mesh.  The fp32 tile aliases the accumulation
+  // tile: a chunk's values travel through registers, and rows are written in the order they were read (a tile row is shorter
+  // than an accumulation row, so the writes never reach rows that are still to be read).
+  {
+    const int Lz = yt.Lz, RZ = yt.RZ, npairs = g.ny * Lz;
+    constexpr int CH = 4;
+    for (int base = 0; base < npairs; base += CH * nthr) {
+      Cplx<T> v[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = base + u * nthr + tid;
+        v[u] = idx < npairs ? Cplx<T>{T(acc[2 * idx]), T(acc[2 * idx + 1])} : Cplx<T>{T(0), T(0)};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = base + u * nthr + tid;
+        if (idx < npairs) {
+          const int y = idx / Lz, j = idx - y * Lz;
+          const int jr = pa.loglz ? int(__brev(unsigned(j)) >> (32 - pa.loglz)) : 0;
+          yt.tile[y * RZ + jr] = v[u];
+        }
+      }
+      __syncthreads();
     }
   }
-  // C: the plane's forward (y,z) transform, in place
-  yz_forward_finish<T, true>(yt, g.ny, g.nz, pa.logny, pa.loglz, pa.hat + int64_t(plane) * g.ny * RZ);
   MIPME_WG_PHASE(3);
+  Cplx<T>* dst = part == 0 ? pa.hat : pa.hat_more + int64_t(part - 1) * pa.more_stride;
+  yz_forward_finish<T, true>(yt, g.ny, g.nz, pa.logny, pa.loglz, dst + int64_t(plane) * g.ny * yt.RZ);
+  MIPME_WG_PHASE(4);
 }
 
 template <int N, typename T>
@@ -1195,34 +1358,10 @@ __global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, Pl
   plane_spread_yz_body<N, T>(sa, pa, blockIdx.x, smem_plane);
 }
 
-// the row workgroup of a co-scheduled launch (shared by spread_rows_kernel and plane_rows_kernel)
-template <typename T, int PFAST, bool COMPACT, bool CELL>
-__device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, unsigned r, char* smem_rows) {
-  AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
-  bool done = false;
-  if constexpr (COMPACT && std::is_same<T, float>::value) {
-    if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-      sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
-      done = true;
-    }
-  }
-#if MIPME_ROW_LANES == 16
-  if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
-    if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table)
-      sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
-      done = true;
-    }
-  }
-#endif
-  if constexpr (!CELL) {
-    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
-  }
-}
-
 // planes first, then the row blocks of the pair sum (the planes are few -- nx -- and long: they must start at once)
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
-    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes) {
+    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */) {
   MIPME_WG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_pr[];
   const unsigned n_pad = pad8(n_planes);
@@ -1393,6 +1532,7 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   if (bins.live && threadIdx.x == 0) {  // forward pass, last consumer of the live counters: leave them zero for the next call
     bins.live[block] = 0;
     if (block == 0) bins.live[bins.nb] = 0;
+    if (bins.plive && int(block) <= g.nx) bins.plive[block] = 0;  // (nb >= nx + 1: bricks_supported)
   }
   T seed = T(1), seed_aux = T(1);
   if constexpr (TAIL) {
@@ -1703,6 +1843,7 @@ struct BinsView {
   int* over_brick;
   int4* rec;
   void* wts;
+  void* qs;  // per-slot charge (written by the binning pass for single-channel charges)
   double* epart;
 };
 
@@ -1716,6 +1857,10 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
   v.rec = (int4*)(b + l.rec);
   v.wts = (void*)(b + l.wts);
   v.idx.codes = (unsigned char*)(b + l.codes);
+  v.qs = (void*)(b + l.qs);
+  v.idx.pcap = l.pcap;
+  v.idx.plist = l.pcap ? (int*)(b + l.plist) : nullptr;
+  v.idx.pover = l.pcap ? (int*)(b + l.pover) : nullptr;
   v.epart = (double*)(b + l.epart);
   return v;
 }
@@ -1730,12 +1875,15 @@ const void* bins_epart(const mipme_mesh_t* m, int64_t N, int dtype, void* bins, 
 // again.  q + atom_rec (nullable, single channel): also emit the (position, charge) records.  One launch.
 template <typename T>
 int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const void* pos, void* bins, int* live,
-               const void* q, void* atom_rec) {
+               const void* q, void* atom_rec, bool plane_lists) {
   const int dtype = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
   const Geom g = make_geom(m);
   const BrickGeom bg = make_brick_geom(m);
   BinsView v = bins_view(m, n_atoms, dtype, bins);
   MIPME_REQUIRE(live, "the binning pass needs the live brick counters");
+  // plane lists: counters behind the brick counters of the plan (plan_counter_words); not in deterministic mode (slots from a sort)
+  if (plane_lists && v.idx.pcap > 0 && !deterministic_mode()) v.idx.plive = live + bg.nb + 1;
+  else v.idx.pcap = 0;
   MIPME_REQUIRE(bins_layout(m, n_atoms, dtype).slots < (int64_t(1) << 31), "too many bin slots for 32-bit slot indices");
   v.idx.live = live;
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
@@ -1760,17 +1908,18 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
     MIPME_LAUNCH_CHECK();
     slot_of = slots;
   }
+  T* qs = (q && m->n_channels == 1) ? (T*)v.qs : nullptr;  // the plane spread reads the charge by slot
   if (n_atoms > 0) {
     if (n_atoms >= kCoalescedBinAtoms)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_atoms_kernel<S, N, T, true><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
                                                                                        v.rec, (T*)v.wts, (const T*)q,
-                                                                                       (AtomRecord<T>*)atom_rec, slot_of)));
+                                                                                       (AtomRecord<T>*)atom_rec, slot_of, qs)));
     else
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                (bin_atoms_kernel<S, N, T, false><<<blocks, 256, 0, st>>>(g, bg, v.idx, n_atoms, (const T*)pos, v.over_brick,
                                                                                         v.rec, (T*)v.wts, (const T*)q,
-                                                                                        (AtomRecord<T>*)atom_rec, slot_of)));
+                                                                                        (AtomRecord<T>*)atom_rec, slot_of, qs)));
     MIPME_LAUNCH_CHECK();
   }
   return MIPME_OK;
@@ -1798,32 +1947,33 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.rec = v.rec;
   sa.wts = (const T*)v.wts;
   sa.val = (const T*)val;
+  sa.qs = nullptr;
   sa.scale = T(scale);
   sa.mesh = (T*)mesh;
   sa.stage_rows = stage_rows;
   sa.det = deterministic_mode();
   sa.skip = job ? nullptr : skip_flag_slot();  // (the co-scheduled forward launch is never conditional)
-  // plane spread (see plane_spread_yz_body): the charges go straight into the forward (y,z) transform's tiles
+  // plane spread (see plane_spread_yz_body): the charges go straight into the forward (y,z) transform's tiles; the binning pass
+  // of this call has left the plane lists (bins_build(plane_lists = true), same conditions: plane_list_capacity)
   PlaneArgs<T> pa;
   size_t plane_lds = 0;
   if (used_planes) *used_planes = false;
-  {
-    static const bool plane_env = env_flag("MIPME_PLANE_SPREAD", true);
-    const bool pow2 = (m->ny & (m->ny - 1)) == 0 && (m->nz & (m->nz - 1)) == 0 && m->nz >= 4 && m->ny >= 2;
-    if (plane_env && ph && ph->hat && used_planes && sa.C == 1 && !sparse && !sa.det && pow2 && N > 0 &&
-        bins_layout(m, N, dtype).slots < (int64_t(1) << kPlaneSlotBits)) {
-      const size_t tile = plane_tile_bytes(m->ny, m->nz, sizeof(T));
-      const size_t budget = job ? kPlaneLdsCosched : kPlaneLdsAlone;
-      if (tile + 16 + sizeof(int2) * 512 <= budget) {
-        pa.hat = (Cplx<T>*)ph->hat;
-        pa.mesh = ph->keep_mesh ? (T*)mesh : nullptr;
-        while ((1 << pa.logny) < m->ny) ++pa.logny;
-        while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
-        pa.list_cap = int((budget - tile - 16) / sizeof(int2));
-        plane_lds = budget;
-        *used_planes = true;
-      }
-    }
+  if (ph && ph->hat && ph->slot_values && !ph->keep_mesh && used_planes && clear_count && v.idx.pcap > 0 && sa.C == 1 && !sparse &&
+      !sa.det && N > 0) {
+    size_t need = 0;
+    plane_lds_layout<T>(m->ny, m->nz, pa, need);
+    pa.hat = (Cplx<T>*)ph->hat;
+    pa.parts = (ph->parts > 1 && ph->hat_more) ? ph->parts : 1;
+    pa.hat_more = (Cplx<T>*)ph->hat_more;
+    pa.more_stride = ph->more_stride;
+    while ((1 << pa.logny) < m->ny) ++pa.logny;
+    while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
+    // (the row blocks of a co-scheduled launch keep their shift / erfcx tables in the same dynamic region)
+    const size_t rows_lds = job ? sizeof(T) * size_t(SPREAD_WAVES) * BRICK_PTS : 0;
+    plane_lds = need > rows_lds ? need : rows_lds;
+    sa.qs = (const T*)v.qs;
+    sa.bins.plive = clear_count + bg.nb + 1;
+    *used_planes = true;
   }
   if (job) {
     // co-scheduled pair sum (sr_job_fusable() holds): potentials + speculative force sums (+ distances) of the fused row kernel
@@ -1842,7 +1992,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     ra_e.epart = want_epart ? v.epart : nullptr;
     ra_e.cpart = cpart;
     MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
-                  "the cell sums of the pair kernel need 4-byte entries, 1/r (or fp32 1/r^6) and no distance by-product");
+                  "the cell sums of the pair kernel need 4-byte entries, 1/r or 1/r^6 and no distance by-product");
     const unsigned rows_per_block = SPREAD_THREADS / kRowLanes;
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned n_spread = unsigned(bg.nb);
@@ -1857,7 +2007,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       if (cpart && pfast == 1)
         rows_only_kernel<T, 1, true, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
       else if (cpart) {
-        if constexpr (sizeof(T) == 4) rows_only_kernel<T, 6, true, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
+        rows_only_kernel<T, 6, true, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
       } else if (pfast == 1 && compact_r)
         rows_only_kernel<T, 1, true><<<rgrid, 256, 0, st>>>(ra_e, bg.xcd);
       else if (pfast == 1)
@@ -1870,7 +2020,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       return MIPME_OK;
     }
     if (pa.hat) {  // planes + row blocks
-      const unsigned n_planes = unsigned(m->nx);
+      const unsigned n_planes = unsigned(m->nx) * unsigned(pa.parts);
       const unsigned pgrid = pad8(n_planes) + pad8(n_rows_blocks);
       const bool compact_p = (job->shift_format & kShiftFormatMask) == kShiftTable32;
 #define MIPME_PLANE_ROWS(PF, CO, CE) \
@@ -1878,7 +2028,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       if (cpart && pfast == 1)
         MIPME_PLANE_ROWS(1, true, true);
       else if (cpart) {
-        if constexpr (sizeof(T) == 4) MIPME_PLANE_ROWS(6, true, true);
+        MIPME_PLANE_ROWS(6, true, true);
       } else if (pfast == 1 && compact_p)
         MIPME_PLANE_ROWS(1, true, false);
       else if (pfast == 1)
@@ -1892,33 +2042,36 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       return MIPME_OK;
     }
     const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks, sizeof(T) == 4);
-    const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_rows_blocks), pattern) : n_spread + n_rows_blocks;
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
+    // One launch of one kernel instantiation: how many of its brick workgroups continue with a row block (spread_rows_kernel:
+    // n_cont) follows from how many workgroups of THAT kernel are resident at once.
+#define MIPME_SPREAD_ROWS(PF, CO, CE)                                                                                          \
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, [&] {                                                                \
+    const void* fn = (const void*)spread_rows_kernel<N, T, PF, CO, CE>;                                                        \
+    const unsigned n_cont = cosched_continuations(fn, lds_k, bg, n_spread, n_rows_blocks, pattern);                            \
+    const unsigned n_rp = bg.xcd ? pad8(n_rows_blocks) : n_rows_blocks;                                                        \
+    const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), n_rp - n_cont, pattern) : n_spread + n_rp - n_cont;            \
+    spread_rows_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);             \
+  }()))
     if (cpart && pfast == 1)
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
-    else if (cpart) {
-      if constexpr (sizeof(T) == 4)
-        MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                                 ((void)S, spread_rows_kernel<N, T, 6, true, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
-    } else if (pfast == 1 && compact)
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
+      MIPME_SPREAD_ROWS(1, true, true);
+    else if (cpart)
+      MIPME_SPREAD_ROWS(6, true, true);
+    else if (pfast == 1 && compact)
+      MIPME_SPREAD_ROWS(1, true, false);
     else if (pfast == 1)
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 1, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
+      MIPME_SPREAD_ROWS(1, false, false);
     else if (compact)
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
+      MIPME_SPREAD_ROWS(6, true, false);
     else
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, spread_rows_kernel<N, T, 6, false><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern)));
+      MIPME_SPREAD_ROWS(6, false, false);
+#undef MIPME_SPREAD_ROWS
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
   if (pa.hat)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, plane_spread_kernel<N, T><<<unsigned(m->nx), 1024, plane_lds, st>>>(sa, pa)));
+                             ((void)S, plane_spread_kernel<N, T><<<unsigned(m->nx) * unsigned(pa.parts), 1024, plane_lds, st>>>(sa, pa)));
   else if (sparse)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
@@ -1952,6 +2105,7 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   const BrickGeom bg = make_brick_geom(m);
   BinsView v = bins_view(m, N, dtype, bins);
   v.idx.live = live;  // forward pass: this gather is the last consumer of the live counters and zeroes them
+  v.idx.plive = (live && v.idx.pcap > 0) ? live + bg.nb + 1 : nullptr;  // (zero already if the binning pass left them alone)
   MIPME_REQUIRE(!field || m->n_channels == 1, "the field output of the gather is single-channel");
   if (th) {
     MIPME_REQUIRE(field && accumulate && q && qsum && th->force && th->grad_pos && th->energy && th->epart_k,
@@ -2086,9 +2240,9 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
       }
     }
 #if MIPME_ROW_LANES == 16
-    if constexpr (COMPACT && std::is_same<T, double>::value && PFAST == 1) {
+    if constexpr (COMPACT && std::is_same<T, double>::value && (PFAST == 1 || PFAST == 6)) {
       if (!f.rows.dist_out) {
-        sr_rows_f64_body<SPREAD_THREADS>(f.rows, blockIdx.x - n_spread, smem_rows);
+        sr_rows_f64_body<SPREAD_THREADS, false, PFAST>(f.rows, blockIdx.x - n_spread, smem_rows);
         return;
       }
     }
@@ -2710,8 +2864,8 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? MIPME_CELL
       if constexpr (std::is_same<T, float>::value)
         sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
 #if MIPME_ROW_LANES == 16
-      else if constexpr (PFAST == 1)
-        sr_rows_f64_body<SPREAD_THREADS, CELL>(ra, r, smem_rows);
+      else if constexpr (PFAST == 1 || PFAST == 6)
+        sr_rows_f64_body<SPREAD_THREADS, CELL, PFAST>(ra, r, smem_rows);
 #endif
       else if constexpr (!CELL)
         sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, true>(ra, r, tab);
@@ -2939,7 +3093,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   ra.epart = v.epart;
   ra.cpart = cpart;
   MIPME_REQUIRE(!cpart || rows_cell_supported<T>(pfast, job->shift_format, job->dist_out),
-                "the cell sums of the pair kernel need 4-byte entries and 1/r (or fp32 1/r^6)");
+                "the cell sums of the pair kernel need 4-byte entries and 1/r or 1/r^6");
   const unsigned n_row_blocks = unsigned((job->n_atoms + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_spread = unsigned(bg.nb);
   const unsigned pattern = brick_pattern(bg, n_spread, n_row_blocks, sizeof(T) == 4);
@@ -2948,8 +3102,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   if (cpart && pfast == 1)
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   else if (cpart) {
-    if constexpr (sizeof(T) == 4)
-      MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
+    MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 6, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   } else if (pfast == 1)
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   else
@@ -3001,8 +3154,8 @@ template int live_gather<float>(hipStream_t, const mipme_mesh_t*, int64_t, const
 template int live_gather<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, void*, const void*, const void*,
                                  double, double, void*, void*, const GatherTailHost*, void*);
 
-template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
-template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*);
+template int bins_build<float>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*, bool);
+template int bins_build<double>(hipStream_t, const mipme_mesh_t*, int64_t, const void*, void*, int*, const void*, void*, bool);
 template int spread_bricks<float>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                   const mipme_sr_job_t*, bool, double*, const PlaneHost*, bool*);
 template int spread_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,

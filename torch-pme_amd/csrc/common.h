@@ -285,7 +285,13 @@ struct ConvCell {
 // convolution's forward (y,z) transform (api.hip fills it from the plan, see fft_plan_plane_forward_ok)
 struct PlaneHost {
   void* hat = nullptr;    // (nx, ny, nz/2 + 1) complex: receives the transformed planes
-  bool keep_mesh = true;  // also store the real charge mesh
+  bool keep_mesh = true;  // the caller reads the real charge mesh afterwards: no plane spread (it does not form it)
+  bool slot_values = false;  // the binning pass of this call wrote the spread's values (single-channel charges) by bin slot
+  // several workgroups per plane, each with a part of the plane's atoms and a transform of its own: part 0 -> hat, part k ->
+  // hat_more + (k - 1) * more_stride (complex values); the x stage of the convolution adds them up
+  int parts = 1;
+  void* hat_more = nullptr;
+  int64_t more_stride = 0;
 };
 struct RowRideHost {
   const mipme_sr_job_t* job;

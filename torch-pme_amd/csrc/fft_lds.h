@@ -277,12 +277,13 @@ struct YzTile {
   int Ltab, Lz, RZ;
 };
 template <typename T, bool YSTAGE = true>
-__device__ __forceinline__ YzTile<T> yz_tile_setup(int ny, int nz, char* smem_yz) {
+__device__ __forceinline__ YzTile<T> yz_tile_setup(int ny, int nz, char* smem_yz, char* smem_tw = nullptr) {
   YzTile<T> t;
   t.Lz = nz >> 1;
   t.RZ = t.Lz + 1;
   t.tile = reinterpret_cast<Cplx<T>*>(smem_yz);      // [ny][RZ]
-  t.tw = t.tile + size_t(ny) * t.RZ;                 // exp(-2 pi i j / Ltab), j < Ltab / 2
+  // exp(-2 pi i j / Ltab), j < Ltab / 2: behind the tile, or where the caller says
+  t.tw = smem_tw ? reinterpret_cast<Cplx<T>*>(smem_tw) : t.tile + size_t(ny) * t.RZ;
   t.Ltab = (YSTAGE && ny > t.Lz) ? ny : t.Lz;
   t.twr = t.tw + (t.Ltab >> 1);                      // exp(-2 pi i k / nz), k <= nz / 2 (split / merge steps)
   const int tid = threadIdx.x, nthr = blockDim.x;

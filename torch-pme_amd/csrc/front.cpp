@@ -727,6 +727,7 @@ std::optional<at::Tensor> calc_forward(const std::shared_ptr<FrontCalc>& calc, c
   a.out_records = kp + node->off_rec;
   a.sr_job = &job;
   a.nan_flag = calc->nan_flag;
+  a.flags = MIPME_FWD_RHO_MESH_UNUSED;  // (rho_mesh is a scratch tensor of this call)
   if (tail_e.defined()) {
     a.out_energy = tail_e.data_ptr();
     a.out_grad_positions = tail_gp.data_ptr();
@@ -982,6 +983,7 @@ std::optional<at::Tensor> calc_forward_plain(const std::shared_ptr<FrontCalc>& c
   a.out_lr = out.data_ptr();
   a.atom_bins = kp + node->off_bins;
   a.nan_flag = calc->nan_flag;
+  a.flags = MIPME_FWD_RHO_MESH_UNUSED;  // (rho_mesh is a scratch tensor of this call)
   if (want_cell) {
     a.out_phi = phi_atoms.data_ptr();
     a.out_rho_hat = rho_kept.data_ptr();

@@ -385,6 +385,10 @@ struct mipme_fft_plan {
   // set by the plane spread (bricks.hip plane_spread_yz_body) when it has already written the forward (y,z) transform of the
   // charge mesh into the convolution's half-complex buffer: the next convolve_xfused skips its forward plane launch
   bool forward_done = false;
+  // ... as `forward_parts` partial transforms that add up: part 0 in the convolution's buffer, the others in hat_parts
+  int forward_parts = 1;
+  void* hat_parts = nullptr;
+  int64_t hat_parts_bytes = 0;
 };
 
 namespace mipme {
@@ -757,6 +761,11 @@ struct XCellExtra {
   void* wbuf;
   void* rho_hat_out;
   const void* rho_hat_in;
+  // the forward (y,z) transforms of `n_more` MORE partial charge meshes (plane spread with several workgroups per plane: each
+  // transforms its own partial plane, and the transform is linear), `more_stride` complex values apart: added on load
+  const void* hat_more = nullptr;
+  int n_more = 0;
+  int64_t more_stride = 0;
 };
 template <typename T, int CELLSUMS>
 __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log2nx, int kzs, int nchunk,
@@ -805,6 +814,17 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       const int x = idx >> kzs, z = idx & (KZ - 1);
       tpre[u] = (active && idx < n_el && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
     }
+    if (xc.n_more > 0) {  // uniform
+      const Cplx<T>* more = static_cast<const Cplx<T>*>(xc.hat_more) + (col - hat);
+      for (int p = 0; p < xc.n_more; ++p, more += xc.more_stride) {
+#pragma unroll
+        for (int u = 0; u < kGPrefetch; ++u) {
+          const int idx = tid + u * nthr;
+          const int x = idx >> kzs, z = idx & (KZ - 1);
+          if (active && idx < n_el && z < kzn) tpre[u] = cadd(tpre[u], more[x * xs + z]);
+        }
+      }
+    }
   }
   for (int j = tid; j < half_n; j += nthr) unit_root(j, nx, tw[j].re, tw[j].im);
   if (g_prefetched) {
@@ -816,7 +836,12 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
   } else {
     for (int idx = tid; idx < n_el; idx += nthr) {
       const int x = idx >> kzs, z = idx & (KZ - 1);
-      tile[x * KP + z] = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+      Cplx<T> v = (active && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
+      if (xc.n_more > 0 && active && z < kzn) {
+        const Cplx<T>* more = static_cast<const Cplx<T>*>(xc.hat_more) + (col - hat);
+        for (int p = 0; p < xc.n_more; ++p, more += xc.more_stride) v = cadd(v, more[x * xs + z]);
+      }
+      tile[x * KP + z] = v;
     }
   }
   // the filter values this thread will need after the forward transform: fetched now, behind the tile's own loads, instead of
@@ -1186,6 +1211,11 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     kg = make_kgeom(cell_mesh);
   }
   XCellExtra xc{cc ? cc->wbuf : nullptr, cc ? cc->rho_hat_out : nullptr, cc ? cc->rho_hat_in : nullptr};
+  if (p->forward_done && p->forward_parts > 1) {
+    xc.hat_more = p->hat_parts;
+    xc.n_more = p->forward_parts - 1;
+    xc.more_stride = int64_t(p->nx) * p->ny * nzh * p->batch;
+  }
   CellRider rider{};
   const bool riders = cc && cc->n_riders > 0;
   if (riders) {
@@ -1278,8 +1308,29 @@ int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out);
 bool fft_plan_plane_forward_ok(const mipme_fft_plan* p) {
   return p && p->own_yz && !p->split_yz && p->batch == 1 && !conv_persistent_ok(p);
 }
-void fft_plan_set_forward_done(mipme_fft_plan* p, bool done) {
-  if (p) p->forward_done = done;
+void fft_plan_set_forward_done(mipme_fft_plan* p, bool done, int parts) {
+  if (!p) return;
+  p->forward_done = done;
+  p->forward_parts = done ? parts : 1;
+}
+// room for `n_more` more half-complex meshes (the partial transforms of a plane spread with several workgroups per plane);
+// allocated on first use -- not possible during stream capture: NULL then (the caller runs with one part)
+void* fft_plan_hat_parts(mipme_fft_plan* p, hipStream_t st, int n_more) {
+  const int64_t bytes = int64_t(n_more) * p->nx * p->ny * (p->nz / 2 + 1) * p->batch * (p->dtype == MIPME_F32 ? 8 : 16);
+  if (p->hat_parts) return p->hat_parts_bytes >= bytes ? p->hat_parts : nullptr;  // (never re-allocated: graphs hold the pointer)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  void* buf = nullptr;
+  if (hipMalloc(&buf, size_t(bytes)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  p->hat_parts = buf;
+  p->hat_parts_bytes = bytes;
+  return buf;
 }
 
 // ---- plan self-test ------------------------------------------------------------------------------------------------
@@ -1470,7 +1521,8 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     delete p;
     return MIPME_EFFT;
   }
-  const size_t n_count = size_t((nx + 7) / 8) * size_t((ny + 7) / 8) * size_t((nz + 7) / 8) + 1;
+  // brick counters + overflow counter, then the plane-list counters of the plane spread + their overflow counter (bricks.hip)
+  const size_t n_count = size_t((nx + 7) / 8) * size_t((ny + 7) / 8) * size_t((nz + 7) / 8) + 1 + size_t(nx) + 1;
   if (hipMalloc((void**)&p->brick_count, n_count * sizeof(int)) != hipSuccess ||
       hipMemset(p->brick_count, 0, n_count * sizeof(int)) != hipSuccess) {
     set_error("could not allocate the brick counters of the plan (plans cannot be created during stream capture)");
@@ -1524,6 +1576,7 @@ int fft_plan_destroy(mipme_fft_plan* p) {
   if (p->inv2d) hipfftDestroy(p->inv2d);
   if (p->brick_count) (void)hipFree(p->brick_count);
   if (p->tail_scratch) (void)hipFree(p->tail_scratch);
+  if (p->hat_parts) (void)hipFree(p->hat_parts);
   if (p->conv_flags) (void)hipFree(p->conv_flags);
   delete p;
   return MIPME_OK;

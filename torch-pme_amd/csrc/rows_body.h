@@ -497,6 +497,12 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ f4v llvm_raw_buffer_load_f4(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ int llvm_raw_buffer_load_i1(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 __device__ f4v llvm_struct_buffer_load_f4(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ f3v llvm_struct_buffer_load_f3(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v3f32");
+__device__ float llvm_struct_buffer_load_f1(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.f32");
+#ifndef MIPME_ROWS_FROM_POS
+#define MIPME_ROWS_FROM_POS 0  // 1 (experiment builds): the packed fp32 body gathers its partners from positions (N,3) + charges instead of the (x,y,z,q) records
+#endif
 // structured resource: `records` elements of `stride` bytes (indexed loads: address = base + index * stride, range check on the index)
 __device__ __forceinline__ i4v struct_buffer(const void* base, unsigned stride, unsigned records) {
   const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -543,9 +549,11 @@ static __device__ long long g_rows_phase[8 * 1024];
 #ifndef MIPME_ROWS_UNMASKED
 #define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed fp32 and the fp64 bodies with its tail selects (the form before round 4's end)
 #endif
-template <int BS, bool CELL = false>
+// PFAST = 1: Coulomb (erfc from the LDS table); PFAST even (6: round 5): Q_p(x) = e^{-x} sum_{k < p/2} x^k / k!, no table
+template <int BS, bool CELL = false, int PFAST = 1>
 __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
   static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
+  static_assert(PFAST == 1 || PFAST % 2 == 0, "odd exponents above 1 take the generic body");
   AtomRecord<double>* __restrict__ shift_tab = reinterpret_cast<AtomRecord<double>*>(lds);
   double* __restrict__ etab = reinterpret_cast<double*>(lds + size_t(kShiftTableSize) * sizeof(AtomRecord<double>));
   const int64_t N = args.N;
@@ -589,7 +597,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       shift_tab[k] = AtomRecord<double>{sx * A[0] + sy * A[3] + sz * A[6], sx * A[1] + sy * A[4] + sz * A[7],
                                         sx * A[2] + sy * A[5] + sz * A[8], 0.0};
     }
-    erfcx_table_to_lds(etab, threadIdx.x, BS);
+    if constexpr (PFAST == 1) erfcx_table_to_lds(etab, threadIdx.x, BS);
   }
   const int pot_end = args.full ? mid : 0x7fffffff;
   const int beg = r0, end = valid ? r2 : r0;
@@ -651,14 +659,34 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
     exp_neg_fast2(x, e);
     constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
     const bool any_cross = CELL && __builtin_amdgcn_ballot_w64((okA && codeA != kCentre) || (okB && codeB != kCentre)) != 0;
+    double dens[2];  // 2 x * (density term of Q_p): term_1 for Coulomb, 2 x e x^{p/2-1} / (p/2-1)! for even p
+    if constexpr (PFAST == 1) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
+      for (int u = 0; u < 2; ++u) Q[u] = erfc_from_table(y[u], e[u], etab);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) dens[u] = (2.0 * 0.56418958354775628695) * y[u] * e[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        double term = 1.0, sum = 1.0;
+#pragma unroll
+        for (int k = 1; k < PFAST / 2; ++k) {
+          term *= x[u] * (1.0 / k);
+          sum += term;
+        }
+        Q[u] = e[u] * sum;
+        dens[u] = 2.0 * x[u] * e[u] * term;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const double term = (2.0 * 0.56418958354775628695) * y[u] * e[u];
-      const double pi = cpref * inv[u];
+      const double term = dens[u];
+      double invp = inv[u];
+#pragma unroll
+      for (int k = 1; k < PFAST; ++k) invp *= inv[u];
+      const double pi = cpref * invp;
       pot = __builtin_fma(sp[u], pi * Q[u], pot);
-      const double sc = sv[u] * ((pi * (inv[u] * inv[u])) * (term + Q[u]));  // = -sv dv/dd / d
+      const double sc = sv[u] * ((pi * (inv[u] * inv[u])) * (term + double(PFAST) * Q[u]));  // = -sv dv/dd / d
       fx = __builtin_fma(sc, vx[u], fx);
       fy = __builtin_fma(sc, vy[u], fy);
       fz = __builtin_fma(sc, vz[u], fz);
@@ -776,6 +804,10 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   // stands -- no shift per entry; an index beyond N returns zeros like a raw offset beyond the range does
   // (tools/buffer_semantics.hip)
   const i4v rec_rs = uniform_rsrc(struct_buffer(args.rec, 16u, unsigned(N)));
+#if MIPME_ROWS_FROM_POS
+  const i4v pos_rs = uniform_rsrc(struct_buffer(args.pos, 12u, unsigned(N)));
+  const i4v q_rs = uniform_rsrc(struct_buffer(args.q, 4u, unsigned(N)));
+#endif
   constexpr unsigned kAtomMask = unsigned(kCompactMaxAtoms - 1);
   // entry words one iteration ahead, partner records fetched where they are used (62 VGPRs).  Fetching the records one
   // iteration ahead as well (two register sets alternating, +10 VGPRs) changed nothing measurable: 18.3 vs 18.1 us alone,
@@ -810,8 +842,15 @@ __device__ __forceinline__ void sr_rows_pk_body(const FusedRowsArgs<float>& args
   // and the exec-mask loop control were 14 of the 76 vector instructions of an iteration.
   auto iteration = [&](auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
+#if MIPME_ROWS_FROM_POS
+    const f3v pA3 = llvm_struct_buffer_load_f3(pos_rs, int(wA & kAtomMask), 0, 0, 0);
+    const f3v pB3 = llvm_struct_buffer_load_f3(pos_rs, int(wB & kAtomMask), 0, 0, 0);
+    const f4v cRA = f4v{pA3.x, pA3.y, pA3.z, llvm_struct_buffer_load_f1(q_rs, int(wA & kAtomMask), 0, 0, 0)};
+    const f4v cRB = f4v{pB3.x, pB3.y, pB3.z, llvm_struct_buffer_load_f1(q_rs, int(wB & kAtomMask), 0, 0, 0)};
+#else
     const f4v cRA = llvm_struct_buffer_load_f4(rec_rs, int(wA & kAtomMask), 0, 0, 0);
     const f4v cRB = llvm_struct_buffer_load_f4(rec_rs, int(wB & kAtomMask), 0, 0, 0);
+#endif
     // shift code -> table row: shift, then ONE shift-and-add onto the table's address (the compiler's own form is shift, mask,
     // add: the empty asm keeps it from folding the two shifts into shift + mask)
     unsigned codeA = wA >> kCompactAtomBits, codeB = wB >> kCompactAtomBits;

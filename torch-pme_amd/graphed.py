@@ -59,8 +59,6 @@ class _LiveStep:
         self.grad_q = torch.empty((N, 1), dtype=dtype, device=device) if charge_gradient else None
         self.grad_cell = self.G_deriv = self.cell_work = None
         if cell_gradient:
-            if dtype != torch.float32 and not (self.pot.kind == _lib.COULOMB or self.pot.exponent == 1):
-                raise NotImplementedError("the fp64 pair kernel forms the cell sums for 1/r only")
             self.grad_cell = torch.empty((27,), dtype=dtype, device=device)
             self.G_deriv = ops.filter_derivative(geom, self.pot, dtype, device)
             self.cell_work = torch.empty((lib.mipme_cell_tail_work(self.plan.handle, C.byref(self.md), N),),
@@ -129,7 +127,7 @@ class GraphedEnergyForces:
         provides the shape/dtype and the values for the warm-up.
     :param cell_gradient: also return ``dE/dcell`` (3,3) from every call (the virial is ``-cell.T @ dE/dcell``): the co-scheduled
         pair sum, the x stage of the convolution and the gather leave partial sums behind and ONE more single-workgroup launch
-        assembles them (``mipme_kspace_forward_args_t.out_grad_cell``); cases those kernels do not cover (fp64 1/r^6, stored
+        assembles them (``mipme_kspace_forward_args_t.out_grad_cell``); cases those kernels do not cover (stored
         distances, non-integer shifts) go through the calculator's general autograd nodes instead -- same numbers
     :param charge_gradient: also return ``dE/dcharges`` (N,1) from every call (``= 2 V``, written by the gather launch).  With
         both flags a call returns ``E, F, dE/dq, dE/dcell`` -- the whole first-order autograd contract of the reference

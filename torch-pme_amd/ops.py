@@ -1052,8 +1052,8 @@ class _PMEFunction(torch.autograd.Function):
                 symmetric = (not full_list) or bool(topo is not None and topo.fmt_flags)
                 want_q, want_cell, aux_seed = TAIL_REQUEST
                 tail_q = bool(ni[0] or want_q) and symmetric
-                tail_cell = bool(ni[1] or ni[12] or want_cell) and ent32 is not None and not write_dist and slab_axis is None and (
-                    p_eff == 1 or dtype == torch.float32) and src_cell is not None
+                tail_cell = (bool(ni[1] or ni[12] or want_cell) and ent32 is not None and not write_dist and slab_axis is None
+                             and src_cell is not None)
                 tail_ok = bool(
                     TAIL_FUSION and cosched and field is not None and fused["force"] is not None and ENERGY_FAST_PATH
                     and not ni[3] and (tail_q or not ni[0]) and (tail_cell or not (ni[1] or ni[12])) and rho_hat is None
@@ -1113,6 +1113,7 @@ class _PMEFunction(torch.autograd.Function):
                         tail["G_deriv"] = filter_derivative(geom, pot_desc, dtype, device)
                         tail["cell_work"] = torch.empty((lib.mipme_cell_tail_work(plan.handle, C.byref(md), N),),
                                                         dtype=torch.float64, device=device)
+                keep_rho_mesh = (cell_partials is not None or tail_cell) and rho_keep is None and rho_hat is None
                 args = _lib.KspaceForwardArgs(
                     plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if (overlap or job is not None) else 0,
                     mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N, positions=pos.data_ptr(), charges=q.data_ptr(),
@@ -1129,6 +1130,8 @@ class _PMEFunction(torch.autograd.Function):
                     G_deriv=None if tail is None else _lib.ptr(tail.get("G_deriv")),
                     cell_work=None if tail is None else _lib.ptr(tail.get("cell_work")),
                     aux_seed=None if tail is None else _lib.ptr(tail["aux_seed"]), out_rho_hat=_lib.ptr(rho_keep),
+                    # the charge mesh is only read again (fft_r2c in the backward pass) if rfftn(rho) was not kept
+                    flags=0 if keep_rho_mesh else _lib.FWD_RHO_MESH_UNUSED,
                 )
                 _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
@@ -1146,7 +1149,7 @@ class _PMEFunction(torch.autograd.Function):
                 ctx.rho_kept = rho_keep is not None
                 saved = dict(phi_mesh=phi_mesh, rho_hat=(rho_hat if rho_keep is None else rho_keep) if need_cell else None,
                              rho_dc=dc, phi_atoms=phi_atoms,
-                             bins=bins, rho_mesh=rho_mesh if (cell_partials is not None or tail_cell) else None,
+                             bins=bins, rho_mesh=rho_mesh if keep_rho_mesh else None,
                              cell_partials=cell_partials)
                 if not overlap and job is None:
                     run_rspace(1)
