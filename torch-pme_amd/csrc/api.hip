@@ -230,13 +230,13 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
       // fused convolution ahead and planes that fit a workgroup: the spread writes the forward (y,z) transform itself
       PlaneHost ph;
       bool planes = false;
+      ph.slot_values = m->n_channels == 1;  // (bins_build above was handed these very charges)
       if (want_planes) {
         ph.hat = hat_work;
-        ph.slot_values = m->n_channels == 1;  // (bins_build above was handed these very charges)
         ph.keep_mesh = false;
-        // MIPME_PLANE_PARTS workgroups per plane (default 4, at most 8): a plane's LDS atomics are what its workgroup waits for,
+        // MIPME_PLANE_PARTS workgroups per plane (default 2, at most 8; measured 1 / 2 / 3 / 4 / 8: profiles/r05_experiments.txt): a plane's LDS atomics are what its workgroup waits for,
         // and they go through ONE CU's LDS pipe
-        static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 4; }();
+        static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 2; }();
         constexpr int kPlanePartsMax = 8;
         ph.parts = parts_env < 1 ? 1 : (parts_env > kPlanePartsMax ? kPlanePartsMax : parts_env);
         if (ph.parts > 1) {

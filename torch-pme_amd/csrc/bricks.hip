@@ -87,7 +87,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 //   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
 //         gathers of the forward and by everything in the backward pass.
 struct BinsLayout {
-  size_t snap, over_brick, rec, wts, codes, qs, plist, pover, epart, det, det_sort_bytes, total;
+  size_t snap, over_brick, rec, wts, codes, qs, plist, pover, wmax, epart, det, det_sort_bytes, total;
   int cap;
   int pcap;  // entries per plane list (0: no plane lists for this mesh, see plane_list_capacity)
   int64_t slots;  // nb * cap + N
@@ -174,6 +174,9 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   l.pcap = plane_list_capacity(m, N, dtype);
   l.plist = off;      off += al(sizeof(int) * size_t(l.pcap) * size_t(l.pcap ? m->nx : 0));
   l.pover = off;      off += al(sizeof(int) * size_t(l.pcap ? N : 0));
+  // max |charge| of every wavefront of the binning pass (one plain store each): max over them x atoms of a plane = the bound that
+  // fixes the scale of the fp32 plane spread's fixed-point sums (plane_spread_yz_body)
+  l.wmax = off;       off += al(sizeof(float) * size_t(l.pcap ? (N + 63) / 64 : 0));
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
   l.det = off;
@@ -203,6 +206,9 @@ struct BinIndex {
   int* plist = nullptr;
   int* pover = nullptr;
   int pcap = 0;
+  // max |value| per wavefront of the binning pass (float[ceil(N / 64)], rewritten by every pass): see BinsLayout::wmax
+  float* wmax = nullptr;
+  int n_wmax = 0;
 };
 
 // Which of its brick's neighbours an atom's stencil reaches, from its position inside the brick: bit 2 d = the lower neighbour
@@ -303,6 +309,16 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
       remaining &= ~peers;
     }
     // the same grouping by x plane for the plane lists (plane spread): their atomics travel with the bricks' ones
+    if (bi.plive && bi.wmax && qs) {  // (uniform) this wavefront's largest |charge|: a plain store, no atomics (a float atomic per
+      // plane and wavefront on nx addresses cost the pass 6.6 us: same-address atomics serialise at ~250 ns each)
+      float a = valid ? fabsf(float(q[i])) : 0.f;
+      a = fmaxf(a, dpp_mov<0xB1>(a));
+      a = fmaxf(a, dpp_mov<0x4E>(a));
+      a = fmaxf(a, dpp_mov<0x141>(a));
+      a = fmaxf(a, dpp_mov<0x140>(a));
+      a = fmaxf(fmaxf(read_lane(a, 0), read_lane(a, 16)), fmaxf(read_lane(a, 32), read_lane(a, 48)));
+      if (lane == 0) bi.wmax[(int64_t(block) * blockDim.x + threadIdx.x) >> 6] = a;
+    }
     if (bi.plive) {
       unsigned long long rem = __ballot(valid);
       while (rem) {
@@ -803,7 +819,8 @@ __device__ __forceinline__ void spread_brick_body(const SpreadArgs<T>& args, uns
             w1[1][t] = wr[t];
             w1[2][t] = wr[N + t];
           }
-          const T v = val[int64_t(orig) * C + c] * scale;
+          // (forward spread of single-channel charges: the binning pass left them by slot -- no load that waits for the record)
+          const T v = (args.qs ? args.qs[si] : val[int64_t(orig) * C + c]) * scale;
           const int r3[3] = {rz, rx, ry};
 #if MIPME_STAGE_SELECT
 #pragma unroll
@@ -1155,7 +1172,7 @@ static inline void plane_lds_layout(int ny, int nz, PlaneArgs<T>& pa, size_t& to
   pa.tile_off = int(tile_off);
   pa.tw_off = int(tw_off);
   pa.misc_off = int(tw_off + plane_tw_bytes(ny, nz, sizeof(T)));
-  total = size_t(pa.misc_off) + 128;
+  total = size_t(pa.misc_off) + 192;
 }
 
 static inline bool sparse_bricks(int64_t n_atoms, int nb);
@@ -1213,9 +1230,14 @@ __device__ __forceinline__ void plane_item_load(PlaneItem<N, T>& it, bool ok, in
 }
 
 // one atom's N x N points of the plane (natural layout acc[y * nz + z]): the products in the working precision (as the bricks
-// form them), the sums in double
+// form them).  The sums: fp64 meshes in double with ds_add_f64; fp32 meshes in 64-bit FIXED POINT with ds_add_u64 (8.0 against
+// 13.1 us per 2 500-atom pass, tools/r05/lds_atomic_bench.hip) -- value * fx_scale (a power of two chosen so that the sum of
+// ALL |contributions| of the plane stays below 2^50: the atoms of its lists x the largest |charge|, BinIndex::wmax) rounded to an integer by the add-a-magic-number conversion
+// (x + 1.5 * 2^52 holds round(x) in its low 52 bits, two's complement; the constant's bit pattern has a zero low word, so taking
+// it off is one 32-bit subtraction), and integer sums do not depend on the order of arrival: the mesh is bit-reproducible.
+static constexpr unsigned kFxMagicHi = 0x43380000u;  // high word of the bit pattern of 1.5 * 2^52
 template <int N, typename T>
-__device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, const Geom& g, const PlaneItem<N, T>& it) {
+__device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, const Geom& g, const PlaneItem<N, T>& it, double fx_scale) {
   constexpr int s0 = stencil_start<N>();
   int zo[N];
 #pragma unroll
@@ -1225,7 +1247,15 @@ __device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, con
     const int row = wrap1(it.my + s0 + j, g.ny) * g.nz;
     const T ay = it.vx * it.wy[j];
 #pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(&acc[row + zo[k]], double(ay * it.wz[k]));
+    for (int k = 0; k < N; ++k) {
+      if constexpr (sizeof(T) == 4) {
+        const double t = __builtin_fma(double(ay * it.wz[k]), fx_scale, 6755399441055744.0);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t) - ((unsigned long long)kFxMagicHi << 32);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row + zo[k]]), bits);
+      } else {
+        atomicAdd(&acc[row + zo[k]], double(ay * it.wz[k]));
+      }
+    }
   }
 }
 
@@ -1252,55 +1282,91 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     const int n_items = g.nx * pa.parts;
     for (int b = int(item) + tid * n_items; b <= bins.nb; b += n_items * nthr) bins.snap[b] = bin_count_of(bins, b, true);
   }
-  // [0, N): end of this part's slice of each list; [8, 8 + N): the lists' planes; [16, 16 + N): start of the slice
+  // The atoms of this plane: the plane lists of m_x = x0 - s0 - tt, tt = 0 .. N-1 (stencil row tt of those atoms is this plane),
+  // taken as ONE sequence (list 0, then list 1, ...) of which this part owns an even slice, walked in batches of blockDim atoms --
+  // every lane of a batch but the last holds an atom, so the N^2 LDS atomics of a batch are dense; the next batch's record,
+  // weights and charge are in flight while the current one is scattered, its list entry one batch further ahead.
+  // lst[tt] = entries of the sequence before list tt (lst[N] = all); lst[8 + tt] = the plane of list tt  (LDS, read back with
+  // a per-lane index: kept in registers and picked by tt the compiler spills them to a stack array)
   int* lst = reinterpret_cast<int*>(smem + pa.misc_off);
-  static_assert(N <= 8, "bookkeeping of the plane lists");
-  if (tid < N) {
-    const int p = posmod(x0 - s0 - tid, g.nx);
-    const int c = min(bins.plive[p], bins.pcap);
-    lst[tid] = int(int64_t(c) * (part + 1) / pa.parts);
-    lst[8 + tid] = p;
-    lst[16 + tid] = int(int64_t(c) * part / pa.parts);
+  static_assert(N <= 7, "bookkeeping of the plane lists");
+  double* fxs = reinterpret_cast<double*>(lst + 16);  // fixed-point scale and its inverse (fp32 meshes)
+  float* wred = reinterpret_cast<float*>(lst + 20);   // per-wavefront maxima of the largest |charge| (<= 12 wavefronts)
+  if constexpr (sizeof(T) == 4) {
+    // the largest |charge| of the system: max over the binning pass's per-wavefront maxima (NaN-propagating: a NaN charge must
+    // reach the result)
+    float a = 0.f;
+    bool bad = false;
+    for (int i = tid; i < bins.n_wmax; i += nthr) {
+      const float w = bins.wmax[i];
+      bad |= !(w == w);
+      a = fmaxf(a, w);
+    }
+    a = fmaxf(a, dpp_mov<0xB1>(a));
+    a = fmaxf(a, dpp_mov<0x4E>(a));
+    a = fmaxf(a, dpp_mov<0x141>(a));
+    a = fmaxf(a, dpp_mov<0x140>(a));
+    a = fmaxf(fmaxf(read_lane(a, 0), read_lane(a, 16)), fmaxf(read_lane(a, 32), read_lane(a, 48)));
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) a = __builtin_nanf("");
+    if ((tid & 63) == 0) wred[tid >> 6] = a;
+  }
+  if (tid == 0) {
+    int run = 0;
+    for (int tt = 0; tt < N; ++tt) {
+      const int p = posmod(x0 - s0 - tt, g.nx);
+      lst[tt] = run;
+      lst[8 + tt] = p;
+      run += min(bins.plive[p], bins.pcap);
+    }
+    lst[N] = run;
   }
   __syncthreads();
-  MIPME_WG_PHASE(1);
-  // The atoms of this plane: the plane lists of m_x = x0 - s0 - tt, tt = 0 .. N-1 (stencil row tt of those atoms is this plane),
-  // walked as ONE sequence of batches of blockDim atoms -- every lane of a batch holds an atom (but for each list's last batch),
-  // so the N^2 LDS atomics of a batch are dense; the next batch's slot, record, weights and charge are in flight while the
-  // current one is scattered.
-  // (list lengths and planes in LDS, read back with a uniform index: kept in registers and picked by `tt` the compiler spills
-  // them to a stack array)
-  // the first (tt, b) with entries at or after the given one, packed as tt * 2^20 + b; tt == N: none
-  auto settle = [&](int tt, int b) __attribute__((always_inline)) -> int {
-    while (tt < N && lst[16 + tt] + b * nthr >= lst[tt]) {
-      ++tt;
-      b = 0;
+  if constexpr (sizeof(T) == 4) {
+    if (tid == 0) {
+      // |sum over the plane's atoms of q w| <= (atoms of the plane's lists + overflow list) x max |q| x |scale| < 2^e  ->  times
+      // 2^(50 - e) every sum stays below 2^50.  A bound that is not finite (NaN / inf charges) makes the scale NaN, and with it
+      // every point of the plane: the NaN guard of the gather then sees what the reference's would
+      float qmax = 0.f;
+      bool bad = false;
+      for (int w = 0; w < (nthr >> 6); ++w) {
+        bad |= !(wred[w] == wred[w]);
+        qmax = fmaxf(qmax, wred[w]);
+      }
+      int e = 0;
+      const double bd = double(qmax) * 1.00001 * fabs(double(args.scale)) * double(lst[N] + bins.plive[g.nx] + 1);
+      (void)frexp(bd, &e);
+      const bool finite = !bad && bd == bd && bd < 1e300;
+      fxs[0] = finite ? ldexp(1.0, 50 - e) : __builtin_nan("");
+      fxs[1] = finite ? ldexp(1.0, e - 50) : __builtin_nan("");
     }
-    return (tt << 20) | b;
+    __syncthreads();
+  }
+  MIPME_WG_PHASE(1);
+  const double fx_scale = sizeof(T) == 4 ? fxs[0] : 1.0, fx_inv = sizeof(T) == 4 ? fxs[1] : 1.0;
+  const int total = lst[N];
+  const int lo = int(int64_t(total) * part / pa.parts), hi = int(int64_t(total) * (part + 1) / pa.parts);
+  const int n_batches = (hi - lo + nthr - 1) / nthr;
+  // this lane's entry of batch b: its stencil row tt and its bin slot (-1: none)
+  auto load_slot = [&](int b, int& tt) __attribute__((always_inline)) -> int {
+    const int gidx = lo + b * nthr + tid;
+    tt = 0;
+#pragma unroll
+    for (int u = 1; u < N; ++u) tt += gidx >= lst[u] ? 1 : 0;
+    if (b >= n_batches || gidx >= hi) return -1;
+    return bins.plist[int64_t(lst[8 + tt]) * bins.pcap + (gidx - lst[tt])];
   };
-  auto after = [&](int st) __attribute__((always_inline)) -> int {
-    return (st >> 20) < N ? settle(st >> 20, (st & 0xfffff) + 1) : st;
-  };
-  // this lane's bin slot in batch `st` (-1: none): the first of the two dependent loads of a batch, issued TWO batches ahead
-  auto load_slot = [&](int st) __attribute__((always_inline)) -> int {
-    const int tt = st >> 20;
-    if (tt >= N) return -1;
-    const int i = lst[16 + tt] + (st & 0xfffff) * nthr + tid;
-    return i < lst[tt] ? bins.plist[int64_t(lst[8 + tt]) * bins.pcap + i] : -1;
-  };
-  int st1 = settle(0, 0), st2 = after(st1);
-  int slot1 = load_slot(st1), slot2 = load_slot(st2);
+  int tt1 = 0, tt2 = 0;
+  int slot1 = load_slot(0, tt1), slot2 = load_slot(1, tt2);
   PlaneItem<N, T> nxt;
-  if ((st1 >> 20) < N) plane_item_load<N, T>(nxt, slot1 >= 0, slot1, st1 >> 20, rec, wts, qs, args.scale);
-  while ((st1 >> 20) < N) {
+  if (n_batches > 0) plane_item_load<N, T>(nxt, slot1 >= 0, slot1, tt1, rec, wts, qs, args.scale);
+  for (int b = 0; b < n_batches; ++b) {
     const PlaneItem<N, T> cur = nxt;
-    const int st3 = after(st2);
-    const int slot3 = load_slot(st3);
-    if ((st2 >> 20) < N) plane_item_load<N, T>(nxt, slot2 >= 0, slot2, st2 >> 20, rec, wts, qs, args.scale);
-    if (cur.vx != T(0)) plane_item_scatter<N, T>(acc, g, cur);
-    st1 = st2;
-    st2 = st3;
+    int tt3 = 0;
+    const int slot3 = load_slot(b + 2, tt3);
+    if (b + 1 < n_batches) plane_item_load<N, T>(nxt, slot2 >= 0, slot2, tt2, rec, wts, qs, args.scale);
+    if (cur.vx != T(0)) plane_item_scatter<N, T>(acc, g, cur, fx_scale);
     slot2 = slot3;
+    tt2 = tt3;
   }
   if (part == 0) {  // the plane overflow list (atoms whose plane list was full: normally none)
     const int oc = bins.plive[g.nx];
@@ -1312,7 +1378,7 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
       if (d < N) {
         PlaneItem<N, T> it;
         plane_item_load<N, T>(it, true, slot, d, rec, wts, qs, args.scale);
-        plane_item_scatter<N, T>(acc, g, it);
+        plane_item_scatter<N, T>(acc, g, it, fx_scale);
       }
     }
   }
@@ -1330,7 +1396,12 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int idx = base + u * nthr + tid;
-        v[u] = idx < npairs ? Cplx<T>{T(acc[2 * idx]), T(acc[2 * idx + 1])} : Cplx<T>{T(0), T(0)};
+        if constexpr (sizeof(T) == 4) {
+          const long long* ai = reinterpret_cast<const long long*>(acc);
+          v[u] = idx < npairs ? Cplx<T>{T(double(ai[2 * idx]) * fx_inv), T(double(ai[2 * idx + 1]) * fx_inv)} : Cplx<T>{T(0), T(0)};
+        } else {
+          v[u] = idx < npairs ? Cplx<T>{T(acc[2 * idx]), T(acc[2 * idx + 1])} : Cplx<T>{T(0), T(0)};
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -1861,6 +1932,8 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
   v.idx.pcap = l.pcap;
   v.idx.plist = l.pcap ? (int*)(b + l.plist) : nullptr;
   v.idx.pover = l.pcap ? (int*)(b + l.pover) : nullptr;
+  v.idx.wmax = l.pcap ? (float*)(b + l.wmax) : nullptr;
+  v.idx.n_wmax = l.pcap ? int((N + 63) / 64) : 0;
   v.epart = (double*)(b + l.epart);
   return v;
 }
@@ -1882,8 +1955,12 @@ int bins_build(hipStream_t st, const mipme_mesh_t* m, int64_t n_atoms, const voi
   BinsView v = bins_view(m, n_atoms, dtype, bins);
   MIPME_REQUIRE(live, "the binning pass needs the live brick counters");
   // plane lists: counters behind the brick counters of the plan (plan_counter_words); not in deterministic mode (slots from a sort)
-  if (plane_lists && v.idx.pcap > 0 && !deterministic_mode()) v.idx.plive = live + bg.nb + 1;
-  else v.idx.pcap = 0;
+  if (plane_lists && v.idx.pcap > 0 && !deterministic_mode()) {
+    v.idx.plive = live + bg.nb + 1;
+  } else {
+    v.idx.pcap = 0;
+    v.idx.wmax = nullptr;
+  }
   MIPME_REQUIRE(bins_layout(m, n_atoms, dtype).slots < (int64_t(1) << 31), "too many bin slots for 32-bit slot indices");
   v.idx.live = live;
   const unsigned blocks = unsigned((n_atoms + 255) / 256);
@@ -1947,7 +2024,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   sa.rec = v.rec;
   sa.wts = (const T*)v.wts;
   sa.val = (const T*)val;
-  sa.qs = nullptr;
+  // the values by bin slot, if the binning pass of this call wrote them (forward spread of single-channel charges)
+  sa.qs = (ph && ph->slot_values && clear_count && m->n_channels == 1) ? (const T*)v.qs : nullptr;
   sa.scale = T(scale);
   sa.mesh = (T*)mesh;
   sa.stage_rows = stage_rows;

@@ -814,15 +814,25 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
       const int x = idx >> kzs, z = idx & (KZ - 1);
       tpre[u] = (active && idx < n_el && z < kzn) ? col[x * xs + z] : Cplx<T>{T(0), T(0)};
     }
-    if (xc.n_more > 0) {  // uniform
-      const Cplx<T>* more = static_cast<const Cplx<T>*>(xc.hat_more) + (col - hat);
-      for (int p = 0; p < xc.n_more; ++p, more += xc.more_stride) {
+  }
+  // partial transforms of a plane spread with several workgroups per plane: the first extra part travels in registers of its own
+  // (all loads of the tile in flight together: one round trip, not one per part), further parts are added one after the other
+  Cplx<T> tpre2[kGPrefetch];
+  if (g_prefetched && xc.n_more > 0) {  // uniform
+    const Cplx<T>* more = static_cast<const Cplx<T>*>(xc.hat_more) + (col - hat);
 #pragma unroll
-        for (int u = 0; u < kGPrefetch; ++u) {
-          const int idx = tid + u * nthr;
-          const int x = idx >> kzs, z = idx & (KZ - 1);
-          if (active && idx < n_el && z < kzn) tpre[u] = cadd(tpre[u], more[x * xs + z]);
-        }
+    for (int u = 0; u < kGPrefetch; ++u) {
+      const int idx = tid + u * nthr;
+      const int x = idx >> kzs, z = idx & (KZ - 1);
+      tpre2[u] = (active && idx < n_el && z < kzn) ? more[x * xs + z] : Cplx<T>{T(0), T(0)};
+    }
+    more += xc.more_stride;
+    for (int p = 1; p < xc.n_more; ++p, more += xc.more_stride) {
+#pragma unroll
+      for (int u = 0; u < kGPrefetch; ++u) {
+        const int idx = tid + u * nthr;
+        const int x = idx >> kzs, z = idx & (KZ - 1);
+        if (active && idx < n_el && z < kzn) tpre2[u] = cadd(tpre2[u], more[x * xs + z]);
       }
     }
   }
@@ -831,7 +841,7 @@ __device__ __forceinline__ void xconv_tile_body(int nx, int ny, int nzh, int log
 #pragma unroll
     for (int u = 0; u < kGPrefetch; ++u) {
       const int idx = tid + u * nthr;
-      if (idx < n_el) tile[(idx >> kzs) * KP + (idx & (KZ - 1))] = tpre[u];
+      if (idx < n_el) tile[(idx >> kzs) * KP + (idx & (KZ - 1))] = xc.n_more > 0 ? cadd(tpre[u], tpre2[u]) : tpre[u];
     }
   } else {
     for (int idx = tid; idx < n_el; idx += nthr) {
