@@ -402,6 +402,11 @@ int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
  * mipme_atom_bins_bytes returns 0 when the mesh is too small for bricks (< 17 points on an axis, or a last brick narrower
  * than 4 points): pass NULL then (atomic-scatter kernels). */
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
+/* Workgroups per x plane of the PLANE SPREAD that mipme_kspace_forward uses for this mesh / system when the caller sets
+ * MIPME_FWD_RHO_MESH_UNUSED and rho_hat == NULL (0: the owner-computes bricks + the forward plane launch): single channel,
+ * power-of-two nx, ny, nz, planes whose accumulation tile fits a workgroup's LDS, dense bricks, not MIPME_DETERMINISTIC.  For
+ * callers that account for the launches of a step (bench.py); nothing needs it to call the library. */
+int mipme_plane_spread_parts(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
 
 /* Per-stage timing for benchmarks: HIP events on the launch stream around every stage of the composite calls.
  * mipme_profile_report writes "stage calls total_ms" lines into buf and returns the byte count needed. */

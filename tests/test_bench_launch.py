@@ -45,7 +45,9 @@ def test_exchange_modes_gather_the_same_energies():
         out = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-gpu", "2", "--blocks", "2", "--exchange", mode)
         assert out["parallelism"]["exchange"] == mode and out["energies_gathered"] == 4
         assert out["timing"]["blocks"] == 2 and len(out["timing"]["blocks_ms_per_step"]) == 2
-        assert out["ms_per_step"] == pytest.approx(out["timing"]["blocks_ms_per_step"][0], rel=1e-4)
+        # (the reported timed region is the median block -- the lower one of two --, the first block is reported next to it)
+        assert out["ms_per_step"] == pytest.approx(min(out["timing"]["blocks_ms_per_step"]), rel=1e-4)
+        assert out["ms_per_step_first_block"] == pytest.approx(out["timing"]["blocks_ms_per_step"][0], rel=1e-4)
         assert out["weak_efficiency"]["value"] > 0 and out["weak_efficiency"]["one_rank_ms_per_step"] > 0
         assert [r["rank"] for r in out["parallelism"]["ranks"]] == [0, 1]
         cores = [r["affinity"].get("cores") for r in out["parallelism"]["ranks"]]

@@ -971,7 +971,7 @@ def test_split_plane_kernels_256(dtype, cell_diag, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("blob", ["corner", "two"])
+@pytest.mark.parametrize("blob", ["corner", "two", "slab"])
 def test_bin_overflow_region(dtype, blob):
     """One-pass binning: a brick owns a fixed number of slots (4 x the mean occupancy + 8) and the atoms that find it full go
     to the overflow region, which every particle <-> mesh kernel also walks.  A dense blob in an otherwise empty cell puts
@@ -983,6 +983,12 @@ def test_bin_overflow_region(dtype, blob):
     N = 260
     if blob == "corner":
         pos = rng.uniform(0.2, 2.8, (N, 3))  # a 2.6 A cube: one or two mesh bricks out of 512
+    elif blob == "slab":
+        # round 5, the PLANE lists of the plane spread (4 x the mean occupancy of an x plane + 64 entries each): a sheet of atoms
+        # perpendicular to x puts ~300 atoms into each of two lists of 128 -- the rest goes through the plane overflow list
+        N = 600
+        gy, gz = np.meshgrid((np.arange(25) + 0.5) * L / 25, (np.arange(24) + 0.5) * L / 24, indexing="ij")
+        pos = np.stack([rng.uniform(3.0, 3.35, N), gy.ravel() + rng.uniform(-0.2, 0.2, N), gz.ravel() + rng.uniform(-0.2, 0.2, N)], 1)
     else:
         pos = np.concatenate([rng.uniform(3.0, 5.5, (N // 2, 3)), rng.uniform(15.0, 17.5, (N - N // 2, 3))])
     q = rng.normal(size=(N, 1))

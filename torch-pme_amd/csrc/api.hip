@@ -58,6 +58,7 @@ template <typename T> int bins_build(hipStream_t, const mipme_mesh_t*, int64_t, 
 template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_t, void*, const void*, double, void*, int*,
                                         const mipme_sr_job_t*, bool, double*, const PlaneHost* = nullptr, bool* = nullptr);
 bool fft_plan_plane_forward_ok(const mipme_fft_plan*);
+int plane_bins_capacity(const mipme_mesh_t*, int64_t, int);
 void fft_plan_set_forward_done(mipme_fft_plan*, bool, int);
 void* fft_plan_hat_parts(mipme_fft_plan*, hipStream_t, int);
 template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
@@ -189,6 +190,12 @@ static CellWork cell_work_layout(const mipme_mesh_t* m, int64_t N, void* base) {
   return w;
 }
 
+static constexpr int kPlanePartsMax = 8;
+static int plane_spread_parts_setting() {
+  static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 2; }();
+  return parts_env < 1 ? 1 : (parts_env > kPlanePartsMax ? kPlanePartsMax : parts_env);
+}
+
 template <typename T>
 static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_mesh_t* m, const mipme_potential_t* pot,
                             int64_t N, const void* pos, const void* q, const void* G, void* rho_mesh, void* rho_hat,
@@ -236,9 +243,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
         ph.keep_mesh = false;
         // MIPME_PLANE_PARTS workgroups per plane (default 2, at most 8; measured 1 / 2 / 3 / 4 / 8: profiles/r05_experiments.txt): a plane's LDS atomics are what its workgroup waits for,
         // and they go through ONE CU's LDS pipe
-        static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 2; }();
-        constexpr int kPlanePartsMax = 8;
-        ph.parts = parts_env < 1 ? 1 : (parts_env > kPlanePartsMax ? kPlanePartsMax : parts_env);
+        ph.parts = plane_spread_parts_setting();
         if (ph.parts > 1) {
           ph.hat_more = fft_plan_hat_parts(plan, st, kPlanePartsMax - 1);
           ph.more_stride = Mh * m->n_channels;
@@ -1258,6 +1263,12 @@ int mipme_fft_r2c(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mes
   if ((rc = check_plan(plan, dtype, mesh))) return rc;
   MIPME_REQUIRE(mesh_in && hat, "NULL buffer passed to mipme_fft_r2c");
   return fft_forward(plan, (hipStream_t)stream, mesh_in, hat);
+}
+
+int mipme_plane_spread_parts(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
+  if (!mesh || validate_mesh(mesh) || !bricks_supported(mesh, dtype)) return 0;
+  if (mesh->nx < 2 || (mesh->nx & (mesh->nx - 1)) || plane_bins_capacity(mesh, n_atoms, dtype) <= 0) return 0;
+  return plane_spread_parts_setting();
 }
 
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {

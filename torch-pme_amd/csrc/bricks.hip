@@ -230,6 +230,8 @@ __device__ __forceinline__ unsigned reach_code(const int (&m)[3], int nx, int ny
   return code;
 }
 
+int plane_bins_capacity(const mipme_mesh_t* m, int64_t N, int dtype) { return plane_list_capacity(m, N, dtype); }
+
 int64_t bins_bytes(const mipme_mesh_t* m, int64_t N, int dtype) {
   if (!bricks_supported(m, dtype)) return 0;
   return int64_t(bins_layout(m, N, dtype).total);
@@ -1128,20 +1130,26 @@ static inline bool rows_cell_supported(int pfast, int shift_format, const void* 
 // ---- plane spread: the charges scattered straight into a (y,z) plane's transform tile -------------------------------------
 // Round 5.  The owner-computes bricks above cost a third of the co-scheduled launch's vector instructions (2.6 M of 7.8 M at
 // cfg3: every survivor is a 512-point rank-1 update of which 7 % is not zero), and the plane transform that follows re-reads
-// the mesh they wrote in a launch of its own (6.7 us of pure latency).  Here ONE workgroup per x plane of the mesh
-//   A  walks the atom bins of the one or two brick slabs whose atoms can reach the plane (m_x in [x - s0 - (N-1), x - s0]), a
-//      wavefront per brick and a lane per atom, record / weights / charge of the next brick in flight while the current one is
-//      scattered,
-//   B  adds every such atom's N x N (y,z) stencil points, times its x weight and charge, to the plane in LDS with
-//      DOUBLE-PRECISION LDS atomics (ds_add_f64) -- N^2 per atom and plane, N^3 per atom in all, nothing is computed that is zero,
-//   C  converts the plane to the working precision in the layout the forward transform starts from (rows as bit-reversed complex
-//      pairs), transforms it in place (yz_forward_finish) and stores its block of the half-complex mesh: the convolution's
-//      forward (y,z) launch is gone (fft_plan_forward_done).
-// Why fp64 atomics for fp32 meshes: tools/r05/lds_atomic_bench.hip (profiles/r05_b_lds_atomic.txt) -- one 2 500-atom plane pass
+// the mesh they wrote in a launch of its own (6.7 us of pure latency).  Here `parts` workgroups per x plane of the mesh each
+//   A  walk their slice of the plane's atoms -- the PLANE LISTS the binning pass leaves (bin slots by reference point m_x; a
+//      plane takes the lists of m_x = x - s0 - t, t < N) as one sequence, in batches of blockDim atoms, a lane per atom, the next
+//      batch's record / weights / charge in flight while the current one is scattered,
+//   B  add every atom's N x N (y,z) stencil points, times its x weight and charge, to the plane in LDS with 64-bit LDS atomics --
+//      N^2 per atom and plane, N^3 per atom in all, nothing is computed that is zero: fp32 meshes in 64-bit fixed point
+//      (ds_add_u64, plane_item_scatter), fp64 meshes with ds_add_f64,
+//   C  convert the plane to the working precision in the layout the forward transform starts from (rows as bit-reversed complex
+//      pairs), transform it in place (yz_forward_finish) and store their block of a half-complex mesh: part 0 into the
+//      convolution's buffer, the others into the plan's part buffers -- the transform is linear, and the x stage of the convolution
+//      adds the parts on load (kfilter.hip XCellExtra::hat_more).  The convolution's forward (y,z) launch is gone
+//      (fft_plan_forward_done), and so is the real charge mesh (callers say they do not read it: MIPME_FWD_RHO_MESH_UNUSED).
+// Why 64-bit atomics for fp32 meshes: tools/r05/lds_atomic_bench.hip (profiles/r05_b_lds_atomic.txt) -- one 2 500-atom plane pass
 // is 80 us with ds_add_f32 (0.4 lanes per clock and CU, whatever the denormal mode: round 1's "LDS float atomics are the
-// limiter"), 13 us with ds_add_f64, 8 us with ds_add_u64, 3.7 us with plain stores.  The double-precision sums also make the
-// result independent of the order of arrival except in the last bit of the conversion.  MIPME_DETERMINISTIC=1 keeps the bricks.
-// Single channel, planes whose accumulation tile fits the co-scheduled launch's LDS budget (64 x 64); larger meshes keep the bricks.
+// limiter"), 13 us with ds_add_f64, 8 us with ds_add_u64, 3.7 us with plain stores; the cost is per wave-level instruction, which
+// is why the lanes must be dense (the lists).  Why several workgroups per plane: a plane's atomics go through ONE CU's LDS pipe
+// (18 us of a 25 us workgroup with one per plane, profiles/r05_g_plane_timeline.txt).  Integer sums do not depend on the order
+// of arrival: with one workgroup per plane the fp32 mesh is bit-reproducible.  MIPME_DETERMINISTIC=1 keeps the bricks (its slots
+// come from a sort).  Single channel, planes whose accumulation tile fits the co-scheduled launch's LDS budget (64 x 64); larger
+// meshes keep the bricks.  Numbers: profiles/r05_experiments.txt item 3.
 template <typename T>
 struct PlaneArgs {
   Cplx<T>* hat = nullptr;  // (nx, ny, nz/2 + 1): receives the (y,z)-transformed planes; nullptr: no plane spread in this launch
