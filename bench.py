@@ -1184,14 +1184,17 @@ def main(argv=None):
         # labelled as such; null for workloads without a committed profile
         traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.workload == "water" and n_frames == 1 and os.path.exists(pmc_path):
+        if n_frames == 1 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
+            if args.workload != "water":  # other workloads with a committed counter pass (tools/pmc_to_json.py <...> <workload>)
+                pmc = pmc.get("workloads", {}).get(args.workload, {"kernels": {}})
             traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-            traffic_source = (f"committed profile profiles/pmc_traffic.json (from {pmc.get('source')}; separate rocprofv3 "
-                              "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrections in the file), not "
-                              "measured in this run")
+            if traffic is not None:
+                traffic_source = (f"committed profile profiles/pmc_traffic.json (from {pmc.get('source')}; separate rocprofv3 "
+                                  "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrections in the file), not "
+                                  "measured in this run")
         table = {
-            k: {"ms_per_launch": round(v, 5), "launches_per_step": stage_calls.get(k, 1.0), "kernels_in_stage": 3 if k in composite else 1,
+            k: {"ms_per_launch": round(v, 5), "launches_per_step": stage_calls.get(k, 1.0), "kernels_in_stage": (2 if n_parts > 0 else 3) if k in composite else 1,
                 "algorithmic_MB": round(per_kernel[k] / 1e6, 3), "GBps": round(per_kernel[k] / (v * 1e-3) / 1e9, 1)}
             for k, v in sorted(kernels.items(), key=lambda kv: -kv[1])
         }
