@@ -1032,26 +1032,26 @@ static unsigned cosched_continuations(const void* fn, size_t lds, const BrickGeo
 }
 
 // the row workgroup of a co-scheduled launch (shared by spread_rows_kernel and plane_rows_kernel)
-template <typename T, int PFAST, bool COMPACT, bool CELL>
+template <typename T, int PFAST, bool COMPACT, bool CELL, int BS = SPREAD_THREADS>
 __device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, unsigned r, char* smem_rows) {
   AtomRecord<T>* tab = reinterpret_cast<AtomRecord<T>*>(smem_rows);
   bool done = false;
   if constexpr (COMPACT && std::is_same<T, float>::value) {
     if (CELL || !ra.dist_out) {  // uniform: nobody asked for the distances -> the packed body (rows_body.h)
-      sr_rows_pk_body<PFAST, SPREAD_THREADS, CELL>(ra, r, tab);
+      sr_rows_pk_body<PFAST, BS, CELL>(ra, r, tab);
       done = true;
     }
   }
 #if MIPME_ROW_LANES == 16
   if constexpr (COMPACT && std::is_same<T, double>::value && (PFAST == 1 || PFAST == 6)) {
     if (CELL || !ra.dist_out) {  // ... and its fp64 counterpart (erfc from the LDS table; 1/r^6: closed form)
-      sr_rows_f64_body<SPREAD_THREADS, CELL, PFAST>(ra, r, smem_rows);
+      sr_rows_f64_body<BS, CELL, PFAST>(ra, r, smem_rows);
       done = true;
     }
   }
 #endif
   if constexpr (!CELL) {
-    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 0, COMPACT>(ra, r, tab);
+    if (!done) sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, BS, 0, COMPACT>(ra, r, tab);
   }
 }
 
@@ -1090,6 +1090,28 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   __syncthreads();
 #endif
   MIPME_WG_STAMP(1);
+}
+
+// Sparse bricks (256^3 meshes at water density: 32 768 bricks of ~16 atoms) co-scheduled with the pair sum, round 5: 128-thread
+// workgroups for BOTH kinds -- quarter-size bricks (spread_brick_body<.., 128>) and row blocks of 8 rows --, interleaved in the
+// block order (one brick per `pattern` row blocks and XCD: the launch is many generations anyway).  Until now the sparse spread
+// (a chain of memory round trips, 130 us for 526 848 atoms) and the VALU-bound pair sum (253 us) ran one after the other.
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
+__global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void sparse_spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread,
+                                                                                 unsigned pattern) {
+  constexpr int BS = SPREAD_THREADS_SPARSE;
+  const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
+  const unsigned n_row_blocks = unsigned((ra.N + BS / kRowLanes - 1) / (BS / kRowLanes));
+  const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
+  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad, pattern);
+  extern __shared__ __attribute__((aligned(16))) char smem_sp[];
+  if (cs.brick) {
+    const unsigned b = brick_of(sa.bg, cs.slot);
+    if (cs.slot < n_pad && b < n_spread) spread_brick_body<N, T, BS>(sa, b);
+  } else if (cs.slot < n_rows_pad) {
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
+    if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL, BS>(ra, r, smem_sp);
+  }
 }
 
 // The pair sum alone (sparse-brick path: the bricks ran in a launch of their own): 256-thread workgroups with nothing but the
@@ -2083,6 +2105,39 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned n_spread = unsigned(bg.nb);
     const size_t lds_k = lds;
+    static const bool sparse_cosched = env_flag("MIPME_SPARSE_COSCHED", false);  // measured: no gain (526 848 atoms 0.781-0.787 -> 0.789-0.791 ms, 1 029 000 atoms 1.084-1.092 -> 1.118-1.121 ms; r05_experiments.txt item 6): opt-in
+    if (sparse && sparse_cosched) {  // quarter-size bricks and 8-row blocks in ONE launch (sparse_spread_rows_kernel)
+      constexpr int BS = SPREAD_THREADS_SPARSE;
+      const unsigned nrb = unsigned((job->n_atoms + BS / kRowLanes - 1) / (BS / kRowLanes));
+      const unsigned nbp = bg.xcd ? pad8(n_spread) : n_spread, nrp = bg.xcd ? pad8(nrb) : nrb;
+      unsigned pattern = 0;
+      if (bg.xcd) {  // one brick per a row blocks and XCD, a = the ratio of the counts (at least 1)
+        const unsigned a = unsigned(double(nrp) / double(nbp) + 0.5);
+        pattern = a < 1 ? 1 : a;
+      }
+      const unsigned grid = bg.xcd ? cosched_grid(nbp, nrp, pattern) : n_spread + nrb;
+      // the row blocks keep their shift (and erfcx) tables where the bricks stage their survivors
+      const size_t rows_lds = sizeof(T) == 4 ? sizeof(AtomRecord<T>) * size_t(kShiftTableSize) : kRowsF64LdsBytes;
+      const size_t lds_s = lds > rows_lds ? lds : rows_lds;
+      const bool compact_s = (job->shift_format & kShiftFormatMask) == kShiftTable32;
+#define MIPME_SPARSE_ROWS(PF, CO, CE) \
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, sparse_spread_rows_kernel<N, T, PF, CO, CE><<<grid, BS, lds_s, st>>>(sa, ra_e, n_spread, pattern)))
+      if (cpart && pfast == 1)
+        MIPME_SPARSE_ROWS(1, true, true);
+      else if (cpart)
+        MIPME_SPARSE_ROWS(6, true, true);
+      else if (pfast == 1 && compact_s)
+        MIPME_SPARSE_ROWS(1, true, false);
+      else if (pfast == 1)
+        MIPME_SPARSE_ROWS(1, false, false);
+      else if (compact_s)
+        MIPME_SPARSE_ROWS(6, true, false);
+      else
+        MIPME_SPARSE_ROWS(6, false, false);
+#undef MIPME_SPARSE_ROWS
+      MIPME_LAUNCH_CHECK();
+      return MIPME_OK;
+    }
     if (sparse) {  // the bricks first, by themselves; then the pair sum in a launch of its own (rows_only_kernel)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
