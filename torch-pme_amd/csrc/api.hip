@@ -221,7 +221,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     ~CounterGuard() {
       if (armed && counters) (void)zero_async(counters, sizeof(int) * n, st);
     }
-  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1 + size_t(m->nx) + 1, false};
+  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1 + 8 * size_t(m->nx) + 1, false};
   if (bins) {
     int* counters = fft_plan_brick_count(plan);
     guard.counters = counters;

@@ -86,10 +86,14 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 //         reads them and copies them to `snap`, the forward gather -- the last consumer -- zeroes them again.
 //   snap  (inside the bins buffer): int[nb + 1] per-call copy {min(count, cap) per brick, overflow count}, read by the
 //         gathers of the forward and by everything in the backward pass.
+// Plane lists come in kPlaneSub sub-lists per plane, keyed by the wavefront of the binning pass that appends (its index mod
+// kPlaneSub): the appends are returning atomics on the lists' counters, and same-address atomics serialise -- 1 000 of them on
+// nx = 64 counters were ~16 per address and +1.5 us on the pass; on 512 counters they are 2 per address, like the bricks'.
+static constexpr int kPlaneSub = 8;
 struct BinsLayout {
   size_t snap, over_brick, rec, wts, codes, qs, plist, pover, wmax, epart, det, det_sort_bytes, total;
   int cap;
-  int pcap;  // entries per plane list (0: no plane lists for this mesh, see plane_list_capacity)
+  int pcap;  // entries per plane SUB-list (0: no plane lists for this mesh, see plane_list_capacity)
   int64_t slots;  // nb * cap + N
 };
 
@@ -172,7 +176,7 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   // plane lists (plane spread): the slots of the atoms whose stencil reference point m_x is plane p, pcap per plane, and an
   // overflow list (slots of atoms whose plane list was full: normally empty) that every plane also walks
   l.pcap = plane_list_capacity(m, N, dtype);
-  l.plist = off;      off += al(sizeof(int) * size_t(l.pcap) * size_t(l.pcap ? m->nx : 0));
+  l.plist = off;      off += al(sizeof(int) * size_t(l.pcap) * size_t(l.pcap ? m->nx * kPlaneSub : 0));
   l.pover = off;      off += al(sizeof(int) * size_t(l.pcap ? N : 0));
   // max |charge| of every wavefront of the binning pass (one plain store each): max over them x atoms of a plane = the bound that
   // fixes the scale of the fp32 plane spread's fixed-point sums (plane_spread_yz_body)
@@ -200,7 +204,7 @@ struct BinIndex {
   int nb, cap;
   int64_t over_base;      // = nb * cap
   unsigned char* codes = nullptr;  // per brick slot: reach_code of the atom (written by the binning pass, read by the spread's scan)
-  // plane lists (plane spread; pcap == 0: none): live counters int[nx + 1] behind the brick counters (zeroed by the forward
+  // plane lists (plane spread; pcap == 0: none): live counters int[nx * kPlaneSub + 1] behind the brick counters (zeroed by the forward
   // gather like those), slots per plane, overflow slots
   int* plive = nullptr;
   int* plist = nullptr;
@@ -290,6 +294,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
   }
   int myslot = 0, over_k = -1;
   int pl_leader = lane, pl_rank = 0, pl_count = 0, pl_slot = -1;
+  const int pl_key = int(((int64_t(block) * blockDim.x + threadIdx.x) >> 6) & (kPlaneSub - 1));  // (uniform) this wavefront's sub-list
   if (slot_of) {  // deterministic mode: slots (and the live counters) come from the sorted atom list, see det_slots_kernel
     if (valid) {
       myslot = slot_of[i];
@@ -338,7 +343,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
     int base = 0, pbase = 0;
     if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
-    if (bi.plive && valid && pl_leader == lane) pbase = atomicAdd(&bi.plive[m[0]], pl_count);
+    if (bi.plive && valid && pl_leader == lane) pbase = atomicAdd(&bi.plive[m[0] * kPlaneSub + pl_key], pl_count);
     base = __shfl(base, my_leader, 64);
     myslot = base + my_rank;
     if (bi.plive) pl_slot = __shfl(pbase, pl_leader, 64) + pl_rank;
@@ -364,9 +369,9 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     if (qs) qs[dst] = q[i];
     if (pl_slot >= 0) {  // plane list of m_x (or the plane overflow list: one atomic per atom, normally none)
       if (pl_slot < bi.pcap)
-        bi.plist[int64_t(m[0]) * bi.pcap + pl_slot] = int(dst);
+        bi.plist[(int64_t(m[0]) * kPlaneSub + pl_key) * bi.pcap + pl_slot] = int(dst);
       else
-        bi.pover[atomicAdd(&bi.plive[g.nx], 1)] = int(dst);
+        bi.pover[atomicAdd(&bi.plive[g.nx * kPlaneSub], 1)] = int(dst);
     }
     if (bi.codes && dst < bi.over_base) bi.codes[dst] = (unsigned char)reach_code<N>(m, g.nx, g.ny, g.nz);
   }
@@ -1202,13 +1207,13 @@ static inline void plane_lds_layout(int ny, int nz, PlaneArgs<T>& pa, size_t& to
   pa.tile_off = int(tile_off);
   pa.tw_off = int(tw_off);
   pa.misc_off = int(tw_off + plane_tw_bytes(ny, nz, sizeof(T)));
-  total = size_t(pa.misc_off) + 192;
+  total = size_t(pa.misc_off) + 640;
 }
 
 static inline bool sparse_bricks(int64_t n_atoms, int nb);
 // Entries per plane list of the bins, 0 if this mesh / system does not use the plane spread: single channel, power-of-two planes
 // whose tiles fit the co-scheduled launch's LDS, dense bricks, not the deterministic mode (its slots come from a sort).
-// 4 x the mean occupancy of a plane + 64; the rest goes to the plane overflow list.
+// Per SUB-list (kPlaneSub of them per plane): 4 x its mean occupancy + 32; the rest goes to the plane overflow list.
 static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
   static const bool plane_env = env_flag("MIPME_PLANE_SPREAD", true);
   if (!plane_env || deterministic_mode() || m->n_channels != 1 || N <= 0) return 0;
@@ -1224,8 +1229,8 @@ static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
     plane_lds_layout<double>(m->ny, m->nz, pa, need);
   }
   if (need > kPlaneLdsCosched) return 0;
-  const int64_t mean = (N + m->nx - 1) / m->nx, all = (N + 63) / 64 * 64;
-  int64_t cap = (4 * mean + 64 + 63) / 64 * 64;
+  const int64_t lists = int64_t(m->nx) * kPlaneSub, mean = (N + lists - 1) / lists, all = (N + 15) / 16 * 16;
+  int64_t cap = (4 * mean + 32 + 15) / 16 * 16;
   if (cap > all) cap = all;
   return int(cap);
 }
@@ -1305,9 +1310,16 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   MIPME_WG_PHASE(0);
   double* acc = reinterpret_cast<double*>(smem);
   const int npts = g.ny * g.nz;
+  const int x0 = int(plane);
+  constexpr int NL = N * kPlaneSub;  // lists of this plane: list l = sub-list (l % kPlaneSub) of plane x0 - s0 - l / kPlaneSub
+  // the prologue's global loads first (list lengths, this lane's share of the per-wavefront charge maxima), the tile zeroing and
+  // the twiddles while they are in flight: the prologue was 3 us of a 17 us workgroup
+  int my_count = 0;
+  if (tid < NL) my_count = bins.plive[posmod(x0 - s0 - tid / kPlaneSub, g.nx) * kPlaneSub + (tid % kPlaneSub)];
+  float my_wmax = 0.f;
+  if (sizeof(T) == 4 && tid < bins.n_wmax) my_wmax = bins.wmax[tid];
   for (int i = tid; i < npts; i += nthr) acc[i] = 0.0;
   const YzTile<T> yt = yz_tile_setup<T, true>(g.ny, g.nz, smem + pa.tile_off, smem + pa.tw_off);
-  const int x0 = int(plane);
   if (args.from_live) {  // per-call snapshot of the brick counts (see spread_brick_body): the workgroups share the bricks among them
     const int n_items = g.nx * pa.parts;
     for (int b = int(item) + tid * n_items; b <= bins.nb; b += n_items * nthr) bins.snap[b] = bin_count_of(bins, b, true);
@@ -1316,18 +1328,18 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   // taken as ONE sequence (list 0, then list 1, ...) of which this part owns an even slice, walked in batches of blockDim atoms --
   // every lane of a batch but the last holds an atom, so the N^2 LDS atomics of a batch are dense; the next batch's record,
   // weights and charge are in flight while the current one is scattered, its list entry one batch further ahead.
-  // lst[tt] = entries of the sequence before list tt (lst[N] = all); lst[8 + tt] = the plane of list tt  (LDS, read back with
+  // lst[l] = entries of the sequence before list l (lst[NL] = all), lst[64 + l] = the length of list l  (LDS, read back with
   // a per-lane index: kept in registers and picked by tt the compiler spills them to a stack array)
   int* lst = reinterpret_cast<int*>(smem + pa.misc_off);
-  static_assert(N <= 7, "bookkeeping of the plane lists");
-  double* fxs = reinterpret_cast<double*>(lst + 16);  // fixed-point scale and its inverse (fp32 meshes)
-  float* wred = reinterpret_cast<float*>(lst + 20);   // per-wavefront maxima of the largest |charge| (<= 12 wavefronts)
+  static_assert(N * kPlaneSub < 64, "bookkeeping of the plane lists");
+  double* fxs = reinterpret_cast<double*>(lst + 128);  // fixed-point scale and its inverse (fp32 meshes)
+  float* wred = reinterpret_cast<float*>(lst + 132);   // per-wavefront maxima of the largest |charge| (<= 16 wavefronts)
   if constexpr (sizeof(T) == 4) {
     // the largest |charge| of the system: max over the binning pass's per-wavefront maxima (NaN-propagating: a NaN charge must
     // reach the result)
-    float a = 0.f;
-    bool bad = false;
-    for (int i = tid; i < bins.n_wmax; i += nthr) {
+    float a = my_wmax;
+    bool bad = !(my_wmax == my_wmax);
+    for (int i = tid + nthr; i < bins.n_wmax; i += nthr) {
       const float w = bins.wmax[i];
       bad |= !(w == w);
       a = fmaxf(a, w);
@@ -1340,19 +1352,17 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     if (__builtin_amdgcn_ballot_w64(bad) != 0) a = __builtin_nanf("");
     if ((tid & 63) == 0) wred[tid >> 6] = a;
   }
-  if (tid == 0) {
-    int run = 0;
-    for (int tt = 0; tt < N; ++tt) {
-      const int p = posmod(x0 - s0 - tt, g.nx);
-      lst[tt] = run;
-      lst[8 + tt] = p;
-      run += min(bins.plive[p], bins.pcap);
-    }
-    lst[N] = run;
-  }
+  if (tid < NL) lst[64 + tid] = min(my_count, bins.pcap);
   __syncthreads();
+  // prefix sums by NL + 1 lanes in parallel (a single lane walking 40 LDS reads one after the other was 1 us of every plane
+  // workgroup), the fixed-point scale by a lane of another wavefront
+  if (tid <= NL) {
+    int run = 0;
+    for (int u = 0; u < tid; ++u) run += lst[64 + u];
+    lst[tid] = run;
+  }
   if constexpr (sizeof(T) == 4) {
-    if (tid == 0) {
+    if (tid == 64) {
       // |sum over the plane's atoms of q w| <= (atoms of the plane's lists + overflow list) x max |q| x |scale| < 2^e  ->  times
       // 2^(50 - e) every sum stays below 2^50.  A bound that is not finite (NaN / inf charges) makes the scale NaN, and with it
       // every point of the plane: the NaN guard of the gather then sees what the reference's would
@@ -1362,28 +1372,31 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
         bad |= !(wred[w] == wred[w]);
         qmax = fmaxf(qmax, wred[w]);
       }
+      int n_atoms = bins.plive[g.nx * kPlaneSub] + 1;
+      for (int u = 0; u < NL; ++u) n_atoms += lst[64 + u];
       int e = 0;
-      const double bd = double(qmax) * 1.00001 * fabs(double(args.scale)) * double(lst[N] + bins.plive[g.nx] + 1);
+      const double bd = double(qmax) * 1.00001 * fabs(double(args.scale)) * double(n_atoms);
       (void)frexp(bd, &e);
       const bool finite = !bad && bd == bd && bd < 1e300;
       fxs[0] = finite ? ldexp(1.0, 50 - e) : __builtin_nan("");
       fxs[1] = finite ? ldexp(1.0, e - 50) : __builtin_nan("");
     }
-    __syncthreads();
   }
+  __syncthreads();
   MIPME_WG_PHASE(1);
   const double fx_scale = sizeof(T) == 4 ? fxs[0] : 1.0, fx_inv = sizeof(T) == 4 ? fxs[1] : 1.0;
-  const int total = lst[N];
+  const int total = lst[NL];
   const int lo = int(int64_t(total) * part / pa.parts), hi = int(int64_t(total) * (part + 1) / pa.parts);
   const int n_batches = (hi - lo + nthr - 1) / nthr;
   // this lane's entry of batch b: its stencil row tt and its bin slot (-1: none)
   auto load_slot = [&](int b, int& tt) __attribute__((always_inline)) -> int {
     const int gidx = lo + b * nthr + tid;
-    tt = 0;
-#pragma unroll
-    for (int u = 1; u < N; ++u) tt += gidx >= lst[u] ? 1 : 0;
+    int l = 0;
+    for (int u = 1; u < NL; ++u) l += gidx >= lst[u] ? 1 : 0;
+    tt = l / kPlaneSub;
     if (b >= n_batches || gidx >= hi) return -1;
-    return bins.plist[int64_t(lst[8 + tt]) * bins.pcap + (gidx - lst[tt])];
+    const int list_id = posmod(x0 - s0 - tt, g.nx) * kPlaneSub + (l % kPlaneSub);
+    return bins.plist[int64_t(list_id) * bins.pcap + (gidx - lst[l])];
   };
   int tt1 = 0, tt2 = 0;
   int slot1 = load_slot(0, tt1), slot2 = load_slot(1, tt2);
@@ -1399,7 +1412,7 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     tt2 = tt3;
   }
   if (part == 0) {  // the plane overflow list (atoms whose plane list was full: normally none)
-    const int oc = bins.plive[g.nx];
+    const int oc = bins.plive[g.nx * kPlaneSub];
     for (int i = tid; i < oc; i += nthr) {
       const int slot = bins.pover[i];
       int d = x0 - rec[slot].x - s0;
@@ -1633,7 +1646,9 @@ __device__ __forceinline__ void gather_brick_body(const Geom& g, const BrickGeom
   if (bins.live && threadIdx.x == 0) {  // forward pass, last consumer of the live counters: leave them zero for the next call
     bins.live[block] = 0;
     if (block == 0) bins.live[bins.nb] = 0;
-    if (bins.plive && int(block) <= g.nx) bins.plive[block] = 0;  // (nb >= nx + 1: bricks_supported)
+    if (bins.plive) {  // the plane lists' counters (nx * kPlaneSub + the overflow counter), shared out among the bricks
+      for (int i = int(block); i <= g.nx * kPlaneSub; i += bins.nb) bins.plive[i] = 0;
+    }
   }
   T seed = T(1), seed_aux = T(1);
   if constexpr (TAIL) {
