@@ -303,7 +303,7 @@ typedef struct mipme_frame {
   const void* cell;           /* (3,3) device copy of mesh.cell in the working dtype */
   mipme_mesh_t mesh;          /* n_channels = 1 */
   void* atom_bins;            /* mipme_atom_bins_bytes(mesh, N, dtype) */
-  void* brick_counters;       /* int32[bricks + 1], zero before the first use (every forward leaves them zero) */
+  void* brick_counters;       /* int32[bricks + 1] (or counter_ints of them, below), zero before the first use (every forward leaves them zero) */
   const void* row_ptr;        /* pair topology, see mipme_sr_rows_fused */
   const void* entries_shift;
   const void* entries;
@@ -323,9 +323,13 @@ typedef struct mipme_frame {
    * the forward call also forms energy and grad_positions = grad_seed[0] q_a (c force_a + field_a) (grad_seed: device
    * scalar, NULL = 1) -- no energy launch, and mipme_frames_backward is only needed for a different seed. */
   int32_t use_tail;
-  int32_t _pad;
+  /* int32 words the brick_counters buffer holds; 0 = bricks + 1 (the field was padding until round 5).  With
+   * mipme_frames_counter_ints(mesh, n_atoms, dtype) words (zero before the first use, left zero by every forward) the frame
+   * batch uses the plane spread where it applies: the plane lists' counters live behind the brick counters. */
+  int32_t counter_ints;
   const void* grad_seed;
 } mipme_frame_t;
+int64_t mipme_frames_counter_ints(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
 int64_t mipme_frames_table_bytes(int dtype, int n_frames);
 int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frames, const mipme_potential_t* pot,
                              void* host_table, int64_t host_table_bytes);

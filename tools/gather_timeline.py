@@ -1,5 +1,6 @@
 """Workgroup timeline of the gather launches (live-bin step and binned step): library built with
-``bash tools/build_variant.sh timeline -DMIPME_WG_TIMELINE``; run with MIPME_LIB=<that .so>.  This is how the three
+``bash tools/build_variant.sh gtimeline -DMIPME_WG_TIMELINE=2`` (the gather stamps are a build of their own: the spread launch shares the
+buffer); run with MIPME_LIB=<that .so>.  This is how the three
 slow-downs of the first live gather were found (profiles/r03_experiments.txt): scratch arrays, vector loads from the kernarg
 segment, and an LDS-promoted private array that made every wave read the AQL dispatch packet in host memory."""
 import ctypes as C, os, sys, numpy as np, torch

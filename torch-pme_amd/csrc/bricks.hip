@@ -27,6 +27,12 @@ namespace mipme {
 
 static constexpr int BRICK = 8;
 static constexpr int BRICK_PTS = BRICK * BRICK * BRICK;
+
+// Residency on gfx950 is also a matter of SCALAR registers (MI355X_MICROARCH.md, "Residency"): waves per SIMD <=
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) -- 80 admit 8 waves (four 512-thread workgroups per CU), 82-96 only 7 (three).  The
+// compiler takes what it likes up to 102 unless told otherwise (the attribute takes a literal: capped kernels are kernels of
+// their own, chosen at dispatch for the instantiations that take the cap without spilling).
+#define MIPME_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
 // spread: survivors staged together (rows of spread_row_reals reals); fewer than 256 when they would not fit next to the lists
 static inline int spread_stage_rows(int order, size_t real_bytes);
 // reals staged per survivor by the spread: its three 1-D weight vectors PLACED on the brick's 8 points of each axis (zero
@@ -182,7 +188,8 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   // fixes the scale of the fp32 plane spread's fixed-point sums (plane_spread_yz_body)
   l.wmax = off;       off += al(sizeof(float) * size_t(l.pcap ? (N + 63) / 64 : 0));
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
-  l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * ((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock));
+  // (an EVEN number of 32-row blocks: the 64-row blocks of planes_inv_rows_kernel write the slots of both of their halves)
+  l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * (((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock + 1) & ~size_t(1)));
   l.det = off;
   l.det_sort_bytes = 0;
   if (deterministic_mode()) {  // keys, vals, keys2, vals2, slot_of, over_flag (N words each) + the sort's scratch
@@ -594,6 +601,15 @@ __device__ long long g_wg_phase[8 * 1024];
 #else
 #define MIPME_WG_STAMP(k)
 #define MIPME_WG_PHASE(k)
+#endif
+// The gather launch shares the stamp buffer with the spread launch and comes after it in a step: its stamps are a build of their
+// own (-DMIPME_WG_TIMELINE=2, tools/gather_timeline.py), or a step's spread timeline is overwritten from workgroup 0 up.
+#if defined(MIPME_WG_TIMELINE) && MIPME_WG_TIMELINE == 2
+#define MIPME_WG_TIMELINE_GATHER 1
+#define MIPME_WG_STAMP_GATHER(k) MIPME_WG_STAMP(k)
+#else
+#define MIPME_WG_TIMELINE_GATHER 0
+#define MIPME_WG_STAMP_GATHER(k)
 #endif
 
 #ifndef MIPME_STAGE_SELECT
@@ -1065,9 +1081,9 @@ __device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, un
 // by its SECOND GENERATION of row workgroups (cfg3: 512 bricks + 999 row blocks on 1 024 resident slots; the 487 row blocks that
 // find no slot start when bricks retire, 8-11 us into the launch, and live 9-10 us); with the continuation the whole launch is
 // one generation of 1 024 workgroups and nobody waits for a dispatch.
-template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra,
-                                                                                              unsigned n_spread, unsigned pattern, unsigned n_cont) {
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL>
+__device__ __forceinline__ void spread_rows_body(const SpreadArgs<T>& sa, const FusedRowsArgs<T>& ra, unsigned n_spread,
+                                                 unsigned pattern, unsigned n_cont) {
   MIPME_WG_STAMP(0);
   // n_spread bricks (0: a rows-only launch) and the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
   const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
@@ -1095,6 +1111,29 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   __syncthreads();
 #endif
   MIPME_WG_STAMP(1);
+}
+
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(
+    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern, unsigned n_cont) {
+  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern, n_cont);
+}
+// ... the same kernel held to 80 scalar registers (MIPME_SGPR_CAP), for the instantiations whose VECTOR registers admit four
+// workgroups per CU and that take the cap without spilling -- spread_rows_sgpr_capped() names them.  Left to itself the compiler
+// gives them 88-94, i.e. three workgroups per CU: cfg5 (1/r^6, 262 144 atoms, 12 generations of workgroups) 0.280 -> 0.270 ms,
+// launch 180 -> 169 us; cfg3 on the bricks 0.0631 -> 0.0624 ms (profiles/r05_experiments.txt item 8).
+template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) MIPME_SGPR_CAP void spread_rows_capped_kernel(
+    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern, unsigned n_cont) {
+  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern, n_cont);
+}
+template <int N, typename T, bool CELL>
+constexpr bool spread_rows_sgpr_capped() {
+#ifdef MIPME_SGPR_CAP_OFF
+  return false;
+#else
+  return sizeof(T) == 4 && N == 5 && !CELL;  // (N = 4 fp32 and every fp64 instantiation answer the cap with scratch or more VGPRs)
+#endif
 }
 
 // Sparse bricks (256^3 meshes at water density: 32 768 bricks of ~16 atoms) co-scheduled with the pair sum, round 5: 128-thread
@@ -1188,6 +1227,9 @@ struct PlaneArgs {
   int parts = 1;
   Cplx<T>* hat_more = nullptr;
   int64_t more_stride = 0;
+  // co-scheduled launches: the plane workgroups raise their waves' issue priority over the row blocks' they share SIMDs with
+  // (the planes are few and long -- the launch waits for them; MIPME_PLANE_PRIO, 0: off)
+  int prio = 0;
 };
 
 // LDS of a launch with planes: co-scheduled with the row blocks, four workgroups per CU must fit 160 KB (and the rows need their
@@ -1475,12 +1517,13 @@ __global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, Pl
 // planes first, then the row blocks of the pair sum (the planes are few -- nx -- and long: they must start at once)
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
-    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */) {
+    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */,
+    unsigned n_row_blocks /* of this launch: the first ones (the rest ride on the inverse plane launch, planes_inv_rows_kernel) */) {
   MIPME_WG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_pr[];
   const unsigned n_pad = pad8(n_planes);
-  const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   if (blockIdx.x < n_pad) {
+    if (pa.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned p = xcd_contiguous(blockIdx.x, n_planes);
     if (p < n_planes) plane_spread_yz_body<N, T>(sa, pa, p, smem_pr);
   } else {
@@ -1491,6 +1534,81 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   __syncthreads();
 #endif
   MIPME_WG_STAMP(1);
+}
+
+// ---- the last row blocks of the pair sum behind the INVERSE (y,z) planes of the convolution ----------------------------------------
+// The co-scheduled forward launch is bound by whatever finishes last: its plane workgroups (~19 us with the chip full) and the
+// row blocks that find no slot in its first generation (cfg3: 128 planes + 999 row blocks on 1 024 slots).  The convolution's
+// inverse plane launch, two launches later, is nx workgroups of 1024 threads on 256 CUs for ~7 us -- three quarters of the
+// chip idle at 64^3.  The LAST `n_tail` 64-row blocks of the pair sum run THERE (rows depend on the binning pass only, and
+// their consumer is the gather that follows the inverse planes): kfilter.hip's convolve_xfused hands its inverse plane launch
+// to the co-runner registered here (common.h InverseCoRunner), which starts ONE kernel -- planes first, row blocks of 1024
+// threads behind them (two 32-row halves of the 512-thread blocks' layout: same per-wave partial-sum slots).
+// MIPME_ROWS_TAIL = number of such blocks (default: see rows_tail_blocks).
+template <typename T>
+struct YzInverseDev {
+  int ny, nz, logny, loglz;
+  Cplx<T>* hat;
+  T* real_out;
+  unsigned n_planes;
+  const int* skip;
+};
+
+template <typename T, int PFAST, bool COMPACT>
+__global__ __launch_bounds__(1024) void planes_inv_rows_kernel(YzInverseDev<T> yz, FusedRowsArgs<T> ra, unsigned first_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ir[];
+  if (blockIdx.x < yz.n_planes) {
+    MIPME_SKIP_IF_SET(yz.skip);
+    __builtin_amdgcn_s_setprio(3);
+    yz_plane_body<T, true, true>(yz.ny, yz.nz, yz.logny, yz.loglz, nullptr, yz.hat, yz.real_out, blockIdx.x, smem_ir);
+  } else {
+    cosched_row_block<T, PFAST, COMPACT, false, 1024>(ra, first_block + (blockIdx.x - yz.n_planes), smem_ir);
+  }
+}
+
+// what the co-runner needs between spread_bricks (which registers it) and convolve_xfused (which calls it): both happen inside
+// ONE host call (api.hip kspace_forward_t), on one thread
+template <typename T>
+struct RowsTailCtx {
+  FusedRowsArgs<T> ra;
+  unsigned first_block = 0, n_blocks = 0;
+  int pfast = 1;
+  bool compact = true;
+};
+template <typename T>
+static RowsTailCtx<T>& rows_tail_ctx() {
+  static thread_local RowsTailCtx<T> ctx;
+  return ctx;
+}
+
+template <typename T>
+static int rows_tail_launch(void* ctx_, hipStream_t st, const YzInverseLaunch* L) {
+  const RowsTailCtx<T>& c = *static_cast<const RowsTailCtx<T>*>(ctx_);
+  MIPME_REQUIRE(L->threads == 1024, "the row tail rides on 1024-thread plane launches");
+  YzInverseDev<T> yz{L->ny, L->nz, L->logny, L->loglz, (Cplx<T>*)L->hat, (T*)L->real_out, L->n_planes, L->skip};
+  const size_t rows_lds = sizeof(T) == 4 ? sizeof(AtomRecord<T>) * size_t(kShiftTableSize) : kRowsF64LdsBytes;
+  const size_t lds = L->lds > rows_lds ? L->lds : rows_lds;
+  const unsigned grid = L->n_planes + c.n_blocks;
+  if (c.pfast == 1 && c.compact)
+    planes_inv_rows_kernel<T, 1, true><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
+  else if (c.pfast == 1)
+    planes_inv_rows_kernel<T, 1, false><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
+  else if (c.compact)
+    planes_inv_rows_kernel<T, 6, true><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
+  else
+    planes_inv_rows_kernel<T, 6, false><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+// How many 64-row blocks of the pair sum leave the co-scheduled forward launch for the inverse plane launch: MIPME_ROWS_TAIL
+// (0: none).  Default: what does not fit the forward launch's first generation of workgroups, at least ..., at most a quarter.
+static unsigned rows_tail_blocks(unsigned n_plane_wgs, unsigned n_row_blocks_512) {
+  static const int env = [] { const char* e = getenv("MIPME_ROWS_TAIL"); return e ? atoi(e) : 0; }();
+  if (env <= 0) return 0;
+  unsigned k = unsigned(env);
+  const unsigned most = n_row_blocks_512 / 2 / 2;  // (in 1024-thread blocks; at most half of the rows)
+  return k > most ? most : k;
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -1560,6 +1678,9 @@ struct GatherTail {
   const double* epart_sr;  // [2 * n_sr]
   const double* epart_k;   // [n_k]
   int n_sr, n_k;
+  // per-wave partial sums of row blocks that finished after the x stage's pre-reduction (planes_inv_rows_kernel): added here
+  const double* epart_sr2 = nullptr;  // [2 * n_sr2]
+  int n_sr2 = 0;
   // the rest of the autograd contract of E = sum q V (nullable): s dE/dq_a = 2 s V_a (V is a symmetric bilinear form of the
   // charges), and per brick the nine sums  R[c][e] = sum_a r_{a,c} (s q_a field_{a,e})  of the cell gradient's atom part
   T* grad_q;
@@ -1603,6 +1724,10 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
     v[1] += tail.epart_sr[2 * i + 1];
   }
   for (int i = threadIdx.x; i < tail.n_k; i += THREADS) v[2] += tail.epart_k[i];
+  for (int i = threadIdx.x; i < tail.n_sr2; i += THREADS) {
+    v[0] += tail.epart_sr2[2 * i];
+    v[1] += tail.epart_sr2[2 * i + 1];
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -1812,15 +1937,15 @@ __global__ __launch_bounds__(THREADS) void gather_tail_kernel(Geom g, BrickGeom 
                                                              const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
                                                              T* __restrict__ out, T* __restrict__ raw, T* __restrict__ field,
                                                              GatherTail<T> tail, int* __restrict__ nan_flag) {
-  MIPME_WG_STAMP(0);
+  MIPME_WG_STAMP_GATHER(0);
   const unsigned b = brick_of(bg, blockIdx.x);
   if (b < unsigned(bg.nb))
     gather_brick_body<N, true, T, true, THREADS>(g, bg, 1, bins, rec, wts, mesh, q, qsum, inv_vol, self_c, bg_c, true, out, raw,
                                                  field, b, &tail, nan_flag);
-#ifdef MIPME_WG_TIMELINE
+#if MIPME_WG_TIMELINE_GATHER
   __syncthreads();
 #endif
-  MIPME_WG_STAMP(1);
+  MIPME_WG_STAMP_GATHER(1);
 }
 
 // Same lane mapping as gather_brick_kernel (8 lanes per atom, lane = t_z, N x N points per lane).
@@ -2089,6 +2214,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     pa.parts = (ph->parts > 1 && ph->hat_more) ? ph->parts : 1;
     pa.hat_more = (Cplx<T>*)ph->hat_more;
     pa.more_stride = ph->more_stride;
+    static const int prio_env = [] { const char* e = getenv("MIPME_PLANE_PRIO"); return e ? atoi(e) : 0; }();
+    pa.prio = job ? prio_env : 0;
     while ((1 << pa.logny) < m->ny) ++pa.logny;
     while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
     // (the row blocks of a co-scheduled launch keep their shift / erfcx tables in the same dynamic region)
@@ -2177,10 +2304,29 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     }
     if (pa.hat) {  // planes + row blocks
       const unsigned n_planes = unsigned(m->nx) * unsigned(pa.parts);
-      const unsigned pgrid = pad8(n_planes) + pad8(n_rows_blocks);
       const bool compact_p = (job->shift_format & kShiftFormatMask) == kShiftTable32;
+      // the last row blocks ride on the convolution's inverse plane launch (planes_inv_rows_kernel)
+      unsigned n_here = n_rows_blocks;
+      if (ph->plan) {
+        fft_plan_set_inverse_corunner(ph->plan, nullptr, nullptr);
+        const bool body_ok = !cpart && !job->dist_out && (pfast == 1 || pfast == 6) && MIPME_ROW_LANES == 16 && compact_p;
+        const unsigned n_tail = (body_ok && fft_plan_inverse_corun_ok(ph->plan)) ? rows_tail_blocks(n_planes, n_rows_blocks) : 0u;
+        if (n_tail > 0) {
+          const unsigned n1024 = (n_rows_blocks + 1) / 2;  // 64-row blocks in all
+          RowsTailCtx<T>& c = rows_tail_ctx<T>();
+          c.ra = ra_e;
+          c.n_blocks = n_tail;
+          c.first_block = n1024 - n_tail;
+          c.pfast = pfast;
+          c.compact = compact_p;
+          n_here = 2 * c.first_block;
+          ph->rows_tail_first = int64_t(c.first_block) * 64;
+          fft_plan_set_inverse_corunner(ph->plan, &rows_tail_launch<T>, &c);
+        }
+      }
+      const unsigned pgrid = pad8(n_planes) + pad8(n_here);
 #define MIPME_PLANE_ROWS(PF, CO, CE) \
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, plane_rows_kernel<N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes)))
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, plane_rows_kernel<N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here)))
       if (cpart && pfast == 1)
         MIPME_PLANE_ROWS(1, true, true);
       else if (cpart) {
@@ -2203,11 +2349,19 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     // n_cont) follows from how many workgroups of THAT kernel are resident at once.
 #define MIPME_SPREAD_ROWS(PF, CO, CE)                                                                                          \
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, [&] {                                                                \
-    const void* fn = (const void*)spread_rows_kernel<N, T, PF, CO, CE>;                                                        \
+    constexpr bool capped = spread_rows_sgpr_capped<N, T, CE>();                                                               \
+    const void* fn;                                                                                                            \
+    if constexpr (capped)                                                                                                      \
+      fn = (const void*)spread_rows_capped_kernel<N, T, PF, CO, CE>;                                                           \
+    else                                                                                                                       \
+      fn = (const void*)spread_rows_kernel<N, T, PF, CO, CE>;                                                                  \
     const unsigned n_cont = cosched_continuations(fn, lds_k, bg, n_spread, n_rows_blocks, pattern);                            \
     const unsigned n_rp = bg.xcd ? pad8(n_rows_blocks) : n_rows_blocks;                                                        \
     const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), n_rp - n_cont, pattern) : n_spread + n_rp - n_cont;            \
-    spread_rows_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);             \
+    if constexpr (capped)                                                                                                      \
+      spread_rows_capped_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);    \
+    else                                                                                                                       \
+      spread_rows_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);           \
   }()))
     if (cpart && pfast == 1)
       MIPME_SPREAD_ROWS(1, true, true);
@@ -2279,6 +2433,12 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     if (th->sr_reduced) {  // pre-reduced by the x stage of the convolution (kfilter.hip xconv_kernel, sr_part)
       tail.epart_sr = tail.epart_k + tail.n_k;
       tail.n_sr = tail.n_k;
+      if (th->sr2_count > 0) {
+        tail.epart_sr2 = (const double*)v.epart + 2 * th->sr2_first;
+        tail.n_sr2 = int(th->sr2_count);
+      }
+    } else {
+      MIPME_REQUIRE(th->sr2_count <= 0, "late row partial sums come with the x stage's pre-reduction");
     }
     tail.grad_q = (T*)th->grad_q;
     tail.rpart = th->rpart;
@@ -2377,7 +2537,8 @@ template <int SCHEME, int N, typename T>
 __global__ __launch_bounds__(256) void frames_bin_atoms_kernel(const FrameDev<T>* __restrict__ table) {
   const FrameDev<T>& f = table[blockIdx.y];
   if (int64_t(blockIdx.x) * 256 >= f.N) return;
-  bin_atoms_body<SCHEME, N, T>(f.g, f.bg, f.bins, f.N, f.pos, f.over_brick, f.rec, f.wts, f.q, f.atom_rec, blockIdx.x);
+  bin_atoms_body<SCHEME, N, T>(f.g, f.bg, f.bins, f.N, f.pos, f.over_brick, f.rec, f.wts, f.q, f.atom_rec, blockIdx.x, nullptr,
+                               const_cast<T*>(f.spread.qs));
 }
 
 template <int N, typename T, int PFAST, bool COMPACT>
@@ -2404,6 +2565,24 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
     }
 #endif
     sr_fused_rows_body<T, kPotForce, false, PFAST, false, true, SPREAD_THREADS, 2, COMPACT>(f.rows, blockIdx.x - n_spread, tab);
+  }
+}
+
+// Plane spread for frame batches (round 5): blockIdx.y = frame; the first nx * parts workgroups of a frame are plane workgroups
+// (plane_spread_yz_body: part 0 of frame f into its block of the batched half-complex mesh, the other parts into the plan's part
+// buffers), the rest its row blocks.  `pa` holds the frame-independent fields; frame_stride = complex values per frame.
+template <int N, typename T, int PFAST, bool COMPACT>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void frames_plane_rows_kernel(const FrameDev<T>* __restrict__ table,
+                                                                                                        PlaneArgs<T> pa, int64_t frame_stride) {
+  const FrameDev<T>& f = table[blockIdx.y];
+  const unsigned n_items = unsigned(f.g.nx) * unsigned(pa.parts);
+  extern __shared__ __attribute__((aligned(16))) char smem_fp[];
+  if (blockIdx.x < n_items) {
+    pa.hat += int64_t(blockIdx.y) * frame_stride;
+    if (pa.hat_more) pa.hat_more += int64_t(blockIdx.y) * frame_stride;
+    plane_spread_yz_body<N, T>(f.spread, pa, blockIdx.x, smem_fp);
+  } else if (blockIdx.x - n_items < f.n_row_blocks) {
+    cosched_row_block<T, PFAST, COMPACT, false>(f.rows, blockIdx.x - n_items, smem_fp);
   }
 }
 
@@ -2464,6 +2643,19 @@ static void frame_correction_terms(const mipme_potential_t* pot, double& self_c,
                 : pot->prefactor * std::pow(3.14159265358979323846, 1.5) * std::pow(two_s2, 0.5 * (3 - p)) /
                       ((3 - p) * std::tgamma(0.5 * p));
 }
+
+// int32 words of a frame's counter buffer: brick counters + overflow counter, and -- when the plane spread applies to the frame
+// (plane_list_capacity) -- the plane lists' counters + their overflow counter
+static int64_t frame_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dtype) {
+  const BrickGeom bg = make_brick_geom(m);
+  int64_t n = int64_t(bg.nb) + 1;
+  if (plane_list_capacity(m, n_atoms, dtype) > 0) n += int64_t(m->nx) * kPlaneSub + 1;
+  return n;
+}
+static bool frame_plane_lists(const mipme_frame_t& f, int dtype) {
+  return plane_list_capacity(&f.mesh, f.n_atoms, dtype) > 0 && int64_t(f.counter_ints) >= frame_counter_ints(&f.mesh, f.n_atoms, dtype);
+}
+int64_t frames_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dtype) { return frame_counter_ints(m, n_atoms, dtype); }
 
 static int frames_check(int dtype, int n_frames, const mipme_frame_t* fr) {
   MIPME_REQUIRE(n_frames > 0 && fr, "no frames");
@@ -2530,6 +2722,14 @@ static int frames_table_build_t(int n_frames, const mipme_frame_t* fr, const mip
     d.spread.stage_rows = spread_stage_rows(m->order, sizeof(T));
     d.spread.skip = nullptr;
     d.spread.det = false;  // (the frames path keeps the one-pass binning: MIPME_DETERMINISTIC covers single-frame evaluations)
+    d.spread.qs = (const T*)v.qs;  // the charge by bin slot (written by the binning pass: bricks' staging and the plane spread)
+    if (frame_plane_lists(f, dtype)) {  // plane lists: counters behind the brick counters (mipme_frames_counter_ints)
+      d.bins.plive = d.bins.live + d.bg.nb + 1;
+    } else {
+      d.bins.pcap = 0;
+      d.bins.wmax = nullptr;
+    }
+    d.spread.bins = d.bins;
     d.rows = make_fused_rows_args<T>(s, cf, f.n_atoms, f.row_ptr, f.entries_shift, f.entries, nullptr, f.positions, f.records,
                                      f.cell, f.charges, nullptr, 0, f.full_list ? 0 : 1, f.full_list, 0, f.out, f.force, nullptr,
                                      f.dist_out);
@@ -2573,6 +2773,13 @@ int64_t xconv_blocks(const mipme_fft_plan*);
 void* fft_plan_tail_scratch(mipme_fft_plan*, int64_t bytes);
 bool fft_plan_xfused(const mipme_fft_plan*);
 int fft_plan_batch(const mipme_fft_plan*);
+bool fft_plan_plane_forward_ok_batched(const mipme_fft_plan*);
+void fft_plan_set_forward_done(mipme_fft_plan*, bool, int);
+void* fft_plan_hat_parts(mipme_fft_plan*, hipStream_t, int);
+static int plane_parts_setting() {  // (as api.hip plane_spread_parts_setting)
+  static const int parts_env = [] { const char* e = getenv("MIPME_PLANE_PARTS"); return e ? atoi(e) : 2; }();
+  return parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
+}
 
 template <typename T>
 static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, const mipme_frame_t* fr, const void* table,
@@ -2592,7 +2799,45 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   const int64_t rpb = SPREAD_THREADS / kRowLanes;
   const unsigned grid_x = unsigned(bg.nb) + unsigned((max_atoms + rpb - 1) / rpb);
   const bool compact = fr[0].shift_format == kShiftTable32;  // frames_check: the same format for every frame
-  if (pfast == 1 && compact)
+  // plane spread (every frame of the batch has its plane lists: frame_plane_lists, decided when the table was built)
+  const int dtype_f = sizeof(T) == 4 ? MIPME_F32 : MIPME_F64;
+  bool planes = fft_plan_plane_forward_ok_batched(plan);
+  for (int k = 0; k < n_frames && planes; ++k) planes = frame_plane_lists(fr[k], dtype_f);
+  fft_plan_set_forward_done(plan, false, 1);
+  if (planes) {
+    PlaneArgs<T> pa;
+    size_t need = 0;
+    plane_lds_layout<T>(m->ny, m->nz, pa, need);
+    const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
+    pa.hat = (Cplx<T>*)hat_all;
+    // a batch has its frames for parallelism: as many parts as keep the plane workgroups of the launch at or below 128 (the
+    // single-frame optimum at 64^3: 2 x 64); measured on 8 x 8000 ions / 32^3 fp64: 1 part 0.1243, 2 parts 0.1291, 3 parts
+    // 0.1322 ms (bricks 0.1336); 16 x 1000 atoms / 32^3 fp32: 0.0569 / 0.0633 / 0.0691 (bricks 0.0600)
+    pa.parts = plane_parts_setting();
+    while (pa.parts > 1 && int64_t(pa.parts) * m->nx * n_frames > 128) --pa.parts;
+    if (pa.parts > 1) {
+      pa.hat_more = (Cplx<T>*)fft_plan_hat_parts(plan, st, 7);
+      pa.more_stride = Mh * n_frames;
+      if (!pa.hat_more) pa.parts = 1;
+    }
+    while ((1 << pa.logny) < m->ny) ++pa.logny;
+    while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
+    const size_t rows_lds = sizeof(T) * size_t(SPREAD_WAVES) * BRICK_PTS;
+    const size_t plds = need > rows_lds ? need : rows_lds;
+    const unsigned pgrid_x = unsigned(m->nx) * unsigned(pa.parts) + unsigned((max_atoms + rpb - 1) / rpb);
+#define MIPME_FRAMES_PLANES(PF, CO) \
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, frames_plane_rows_kernel<N, T, PF, CO><<<dim3(pgrid_x, F), SPREAD_THREADS, plds, st>>>(tb, pa, Mh)))
+    if (pfast == 1 && compact)
+      MIPME_FRAMES_PLANES(1, true);
+    else if (pfast == 1)
+      MIPME_FRAMES_PLANES(1, false);
+    else if (compact)
+      MIPME_FRAMES_PLANES(6, true);
+    else
+      MIPME_FRAMES_PLANES(6, false);
+#undef MIPME_FRAMES_PLANES
+    fft_plan_set_forward_done(plan, true, pa.parts);
+  } else if (pfast == 1 && compact)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, frames_spread_rows_kernel<N, T, 1, true><<<dim3(grid_x, F), SPREAD_THREADS, lds, st>>>(tb)));
   else if (pfast == 1)
@@ -3044,7 +3289,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
                                                                          T* __restrict__ field, GatherTail<T> tail,
                                                                          int* __restrict__ nan_flag) {
   static_assert(N <= kGatherLanes, "one lane per z point of the stencil");
-  MIPME_WG_STAMP(0);
+  MIPME_WG_STAMP_GATHER(0);
   constexpr int THREADS = GATHER_THREADS, LANES = kGatherLanes, GROUPS = THREADS / LANES, MG = kLiveMargin;
   constexpr int TL = BRICK + N - 1 + 2 * MG;
   __shared__ T tile[TL * TL * TL];
@@ -3162,10 +3407,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g
     }
   }
   if (tail.rpart) tail_rpart<THREADS>(r3, tail.rpart, block);  // uniform
-#ifdef MIPME_WG_TIMELINE
+#if MIPME_WG_TIMELINE_GATHER
   __syncthreads();
 #endif
-  MIPME_WG_STAMP(1);
+  MIPME_WG_STAMP_GATHER(1);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -3365,6 +3610,11 @@ int mipme_frames_forward(mipme_fft_plan* plan, void* stream, int dtype, int n_fr
                                    phi_mesh_all, dc_all, pfast);
   return frames_forward_t<double>(plan, st, n_frames, frames, device_table, pot, G, G_stride, rho_mesh_all, hat_work_all,
                                   phi_mesh_all, dc_all, pfast);
+}
+
+int64_t mipme_frames_counter_ints(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
+  if (!mesh || validate_mesh(mesh) || !bricks_supported(mesh, dtype)) return 0;
+  return frames_counter_ints(mesh, n_atoms, dtype);
 }
 
 int mipme_frames_backward(void* stream, int dtype, int n_frames, const mipme_frame_t* frames, const void* device_table,

@@ -292,7 +292,31 @@ struct PlaneHost {
   int parts = 1;
   void* hat_more = nullptr;
   int64_t more_stride = 0;
+  // the plan of the convolution that follows (nullable): lets the spread hand the LAST row blocks of the co-scheduled pair sum
+  // to the convolution's inverse (y,z) launch (fft_plan_set_inverse_corunner below)
+  mipme_fft_plan* plan = nullptr;
+  // out: first row (atom) of the row blocks handed to that launch, -1: none.  Their energy partial sums are written AFTER the
+  // x stage of the convolution: the caller keeps them out of the x stage's pre-reduction and gives them to the gather's tail
+  // (GatherTailHost::sr2_first / sr2_count)
+  mutable int64_t rows_tail_first = -1;
 };
+// Co-runner of the inverse (y,z) plane launch of convolve_xfused (kfilter.hip): that launch is nx workgroups of 1024 threads --
+// a quarter of the chip at 64^3 -- for ~7 us.  A caller that has independent work of the same workgroup size registers a
+// launcher; convolve_xfused then calls it INSTEAD of launching the planes itself, with the shape of the plane launch, and the
+// launcher starts one kernel that runs the planes (fft_lds.h yz_plane_body) in its first n_planes workgroups and its own work
+// behind them.  One-shot: cleared when used; kspace_forward clears it at entry (a failed call must not leave it behind).
+struct YzInverseLaunch {
+  int ny, nz, logny, loglz;
+  void* hat;       // half-complex planes in
+  void* real_out;  // real mesh out
+  unsigned n_planes;
+  int threads;     // 1024 (the co-runner is only offered launches of that shape: fft_plan_inverse_corun_ok)
+  size_t lds;      // dynamic LDS the planes need
+  const int* skip;
+};
+typedef int (*InverseCoRunner)(void* ctx, hipStream_t st, const YzInverseLaunch* launch);
+bool fft_plan_inverse_corun_ok(const mipme_fft_plan* p);
+void fft_plan_set_inverse_corunner(mipme_fft_plan* p, InverseCoRunner fn, void* ctx);
 struct RowRideHost {
   const mipme_sr_job_t* job;
   void* epart;  // per-wave energy partial sums (bins buffer), nullable

@@ -389,6 +389,9 @@ struct mipme_fft_plan {
   int forward_parts = 1;
   void* hat_parts = nullptr;
   int64_t hat_parts_bytes = 0;
+  // one-shot co-runner of the inverse (y,z) plane launch (common.h InverseCoRunner): the next convolve_xfused hands it the launch
+  mipme::InverseCoRunner inv_co = nullptr;
+  void* inv_co_ctx = nullptr;
 };
 
 namespace mipme {
@@ -687,6 +690,19 @@ static int cell_riders_alone(hipStream_t st, const CellRider& r) {
   return MIPME_OK;
 }
 
+// shape of the single-launch plane kernels (yz_planes_kernel with its y stage)
+static void yz_launch_shape(const mipme_fft_plan* p, size_t real_bytes, int& logny, int& loglz, size_t& lds, int& threads) {
+  logny = loglz = 0;
+  while ((1 << logny) < p->ny) ++logny;
+  while ((1 << loglz) < p->nz / 2) ++loglz;
+  const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
+  lds = 2 * real_bytes * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
+  const int work = p->ny * (Lz + 1);
+  // latency-bound, one workgroup per plane: the widest workgroup wins (1024 threads 24.0 us per convolution at 64^3 fp32,
+  // 512 threads 25.6, 256 threads 30.9; the two hipFFT plans it replaces 25.3)
+  threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
+}
+
 // rider (inverse only, nullable): the cell-gradient riders of an energy step, appended to the launch where there is ONE launch
 // per direction, a launch of their own otherwise
 template <typename T>
@@ -702,18 +718,12 @@ static int yz_planes(mipme_fft_plan* p, hipStream_t st, bool inverse, const void
     if ((rc = ycols<T>(p, st, true, hat))) return rc;
     return zrows<T>(p, st, true, nullptr, hat, real_out);
   }
-  int logny = 0, loglz = 0;
-  while ((1 << logny) < p->ny) ++logny;
-  while ((1 << loglz) < p->nz / 2) ++loglz;
-  const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
-  size_t lds = sizeof(Cplx<T>) * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
+  int logny = 0, loglz = 0, threads = 0;
+  size_t lds = 0;
+  yz_launch_shape(p, sizeof(T), logny, loglz, lds, threads);
   const unsigned grid = unsigned(p->nx) * unsigned(p->batch);
   const unsigned n_riders = (inverse && rider) ? unsigned(rider->n_riders) : 0u;
   if (n_riders && lds < sizeof(double) * 16 * kCellRow) lds = sizeof(double) * 16 * kCellRow;  // the riders' reduction scratch
-  const int work = p->ny * (Lz + 1);
-  // latency-bound, one workgroup per plane: the widest workgroup wins (1024 threads 24.0 us per convolution at 64^3 fp32,
-  // 512 threads 25.6, 256 threads 30.9; the two hipFFT plans it replaces 25.3)
-  const int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
   if (lds > 64 * 1024) {  // once per instantiation: allow the large dynamic allocation
     static bool raised[2] = {false, false};
     if (!raised[inverse ? 1 : 0]) {
@@ -1274,7 +1284,23 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     MIPME_XCONV_LAUNCH(0);
 #undef MIPME_XCONV_LAUNCH
   MIPME_LAUNCH_CHECK();
-  if (p->own_yz) {
+  const InverseCoRunner co = p->inv_co;
+  void* const co_ctx = p->inv_co_ctx;
+  p->inv_co = nullptr;
+  p->inv_co_ctx = nullptr;
+  if (co) {  // somebody's work rides behind the inverse planes, in a kernel of theirs (common.h InverseCoRunner)
+    MIPME_REQUIRE(fft_plan_inverse_corun_ok(p) && !riders, "the inverse plane launch cannot take a co-runner here");
+    YzInverseLaunch L{};
+    L.ny = p->ny;
+    L.nz = p->nz;
+    yz_launch_shape(p, sizeof(T), L.logny, L.loglz, L.lds, L.threads);
+    L.hat = hat;
+    L.real_out = mesh_out;
+    L.n_planes = unsigned(p->nx);
+    L.skip = skip_flag_slot();
+    int rc = co(co_ctx, st, &L);
+    if (rc) return rc;
+  } else if (p->own_yz) {
     int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out, riders ? &rider : nullptr);
     if (rc) return rc;
   } else {
@@ -1295,6 +1321,7 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
                     void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part, const RowRideHost* rh,
                     void* err_flag, const ConvCell* cc) {
   if (!cell_partials && G_stride == 0 && conv_persistent_ok(p)) {
+    MIPME_REQUIRE(!p->inv_co, "the persistent convolution has no inverse plane launch for a co-runner");
     if (p->dtype == MIPME_F32)
       return convolve_persistent_t<float>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
     return convolve_persistent_t<double>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
@@ -1317,6 +1344,21 @@ int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out);
 // the plane spread can stand in for the forward (y,z) launch of convolve_xfused_t: own single-launch plane kernels, one mesh
 bool fft_plan_plane_forward_ok(const mipme_fft_plan* p) {
   return p && p->own_yz && !p->split_yz && p->batch == 1 && !conv_persistent_ok(p);
+}
+// ... the same for a batched plan (frame batches: bricks.hip frames_plane_rows_kernel)
+bool fft_plan_plane_forward_ok_batched(const mipme_fft_plan* p) { return p && p->own_yz && !p->split_yz && !conv_persistent_ok(p); }
+// the inverse (y,z) launch can take a co-runner (common.h): own single-launch plane kernels of 1024 threads, one mesh
+bool fft_plan_inverse_corun_ok(const mipme_fft_plan* p) {
+  if (!p || !p->own_yz || p->split_yz || p->batch != 1 || conv_persistent_ok(p)) return false;
+  int logny, loglz, threads;
+  size_t lds;
+  yz_launch_shape(p, p->dtype == MIPME_F32 ? 4 : 8, logny, loglz, lds, threads);
+  return threads == 1024 && lds <= 64 * 1024;
+}
+void fft_plan_set_inverse_corunner(mipme_fft_plan* p, InverseCoRunner fn, void* ctx) {
+  if (!p) return;
+  p->inv_co = fn;
+  p->inv_co_ctx = fn ? ctx : nullptr;
 }
 void fft_plan_set_forward_done(mipme_fft_plan* p, bool done, int parts) {
   if (!p) return;

@@ -505,7 +505,9 @@ class GraphedFrameBatch:
             nb = ((ns[0] + 7) // 8) * ((ns[1] + 7) // 8) * ((ns[2] + 7) // 8)
             buf = dict(
                 bins=torch.empty((nbytes,), dtype=torch.uint8, device=device),
-                counters=torch.zeros((nb + 1,), dtype=torch.int32, device=device),
+                # (brick counters + the plane lists' counters where the plane spread applies: mipme_frame_t.counter_ints)
+                counters=torch.zeros((max(nb + 1, int(lib.mipme_frames_counter_ints(C.byref(md), N, dt))),), dtype=torch.int32,
+                                     device=device),
                 records=torch.empty((N, 4), dtype=dtype, device=device),
                 out=torch.empty((N,), dtype=dtype, device=device),
                 force=torch.empty((N, 3), dtype=dtype, device=device),
@@ -517,6 +519,7 @@ class GraphedFrameBatch:
             f = self._frames[k]
             f.n_atoms, f.positions, f.charges, f.cell, f.mesh = N, p.data_ptr(), qc.data_ptr(), cl.data_ptr(), md
             f.atom_bins, f.brick_counters = buf["bins"].data_ptr(), buf["counters"].data_ptr()
+            f.counter_ints = int(buf["counters"].numel())
             f.row_ptr, f.entries_shift, f.entries = topo.row_ptr.data_ptr(), ent_sh.data_ptr(), topo.entries.data_ptr()
             f.full_list, f.shift_format = int(full), int(fmt)
             f.records = buf["records"].data_ptr()
