@@ -1167,7 +1167,12 @@ def main(argv=None):
         accuracy = oracle_accuracy(w, args.workload, float(Ed), Fd)
 
     if rank == 0:
-        n_parts = plane_parts(w, s) if (n_frames == 1 and args.neighbors == "list") else 0
+        # (the per-kernel stage times below are those of ONE frame's step whatever the number of frames per GPU)
+        n_parts = plane_parts(w, s) if args.neighbors == "list" else 0
+        # a frame batch (GraphedFrameBatch) keeps its plane workgroups at <= 128 per launch (csrc/bricks.hip frames_forward_t)
+        label_parts = n_parts
+        while batch is not None and label_parts > 1 and label_parts * w.n_mesh * n_frames > 128:
+            label_parts -= 1
         step_bytes, per_kernel = algorithmic_bytes(w, s, fused=ops.FUSE_DISTANCES, store_distances=args.store_distances,
                                                    parts=n_parts)
         kernels = {k: v for k, v in prof.items() if k in per_kernel}
@@ -1224,8 +1229,8 @@ def main(argv=None):
                 "preset": args.preset,
                 "frames_per_gpu": n_frames,
                 "neighbors": args.neighbors,
-                "spread": (f"plane spread, {n_parts} workgroup(s) per x plane (charges into the forward plane transform's LDS tiles; "
-                           "no forward plane launch)" if n_parts > 0 else "owner-computes bricks + forward plane launch"),
+                "spread": (f"plane spread, {label_parts} workgroup(s) per x plane (charges into the forward plane transform's LDS "
+                           "tiles; no forward plane launch)" if n_parts > 0 else "owner-computes bricks + forward plane launch"),
                 "launch": ("HIP graph replay of the captured step"
                            + (", all frames in one launch per kernel (GraphedFrameBatch)" if batch is not None
                               else ", one stream per frame" if streams is not None else ""))

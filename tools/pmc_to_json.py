@@ -20,6 +20,7 @@ FETCH_CORRECTION = 2.0
 
 NAMES = {
     "spread_rows_kernel": "spread+rspace_forward",
+    "spread_rows_capped_kernel": "spread+rspace_forward",
     "plane_rows_kernel": "spread+rspace_forward",
     "gather_tail_kernel": "gather+energy+forces",
     "gather_brick_kernel": "gather",

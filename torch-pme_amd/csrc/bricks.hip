@@ -1930,8 +1930,18 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_brick_kernel(Geom g, Br
 }
 
 // gather + energy + force assembly (see GatherTail)
-template <int N, typename T, int THREADS = GATHER_THREADS>
-__global__ __launch_bounds__(THREADS) void gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
+// Waves per SIMD the fp32 gather + tail kernels of launches with MANY generations of workgroups are compiled for.  Left alone
+// they take 84-93 vector registers at order 5 = 5 waves = TWO 512-thread workgroups per CU; told to fit 6 waves (80 registers)
+// they admit THREE at the price of 0 (live bins) or 8 (binned) bytes of scratch: cfg5 (4 096 bricks) gather 39.7 -> 33.2 us,
+// step 0.2705 -> 0.2643 ms binned, 0.2727 -> 0.2635 ms with live bins, one box (profiles/r05_experiments.txt item 10).  A
+// launch of one generation (cfg3: 512 bricks) only pays for the spill (+0.2 us): the binned gather keeps both builds and picks
+// by the number of bricks (DENSE); the frame batches' gather (20 bytes of scratch: no gain on 8 x 512 bricks) is left alone, as
+// are orders above 5 (24-92 bytes).  -DMIPME_GATHER_TAIL_WAVES=1: the compiler's own choice everywhere (A/B builds).
+#ifndef MIPME_GATHER_TAIL_WAVES
+#define MIPME_GATHER_TAIL_WAVES 6
+#endif
+template <int N, typename T, int THREADS = GATHER_THREADS, bool DENSE = false>
+__global__ __launch_bounds__(THREADS, DENSE ? MIPME_GATHER_TAIL_WAVES : 1) void gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
                                                              const int4* __restrict__ rec, const T* __restrict__ wts,
                                                              const T* __restrict__ mesh, const T* __restrict__ q,
                                                              const T* __restrict__ qsum, T inv_vol, T self_c, T bg_c,
@@ -2452,10 +2462,20 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
                                    g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
                                    T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
     else
-      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                               ((void)S, gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
-                                   g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum,
-                                   T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag)));
+      MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, [&] {
+        // more bricks than two workgroups per CU hold at once: the build that admits three (see MIPME_GATHER_TAIL_WAVES)
+        if constexpr (sizeof(T) == 4 && N <= 5) {
+          if (bg.nb > 2 * 256) {
+            gather_tail_kernel<N, T, GATHER_THREADS, true><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
+                g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum, T(1.0 / m->volume), T(self_c),
+                T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag);
+            return;
+          }
+        }
+        gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
+            g, bg, v.idx, v.rec, (const T*)v.wts, (const T*)mesh, (const T*)q, (const T*)qsum, T(1.0 / m->volume), T(self_c),
+            T(bg_c), (T*)out, (T*)raw, (T*)field, tail, (int*)nan_flag);
+      }()));
     MIPME_LAUNCH_CHECK();
     return MIPME_OK;
   }
@@ -3280,7 +3300,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, sizeof(T) == 4 ? (CELL ? MIPME_CELL
 // q) record.  (The first version evaluated the weights here, in each of the 8 lanes of an atom: 12.2 us against 7.4; now the spread,
 // which evaluates them anyway for its staging, leaves them in the bins for its home atoms.)
 template <int N, typename T>
-__global__ __launch_bounds__(GATHER_THREADS) void live_gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
+__global__ __launch_bounds__(GATHER_THREADS, (sizeof(T) == 4 && N <= 5) ? MIPME_GATHER_TAIL_WAVES : 1) void live_gather_tail_kernel(Geom g, BrickGeom bg, BinIndex bins,
                                                                          const int4* __restrict__ rec_now,
                                                                          const T* __restrict__ wts,
                                                                          const AtomRecord<T>* __restrict__ rec4,
