@@ -550,6 +550,13 @@ static __device__ long long g_rows_phase[8 * 1024];
 #define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed fp32 and the fp64 bodies with its tail selects (the form before round 4's end)
 #endif
 // PFAST = 1: Coulomb (erfc from the LDS table); PFAST even (6: round 5): Q_p(x) = e^{-x} sum_{k < p/2} x^k / k!, no table
+// Newton steps behind v_rsq_f64 in the fp64 pair body.  ONE: the instruction is good to ~2^-26 on gfx950, a step squares that --
+// energies and forces of cfg2 / cfg4 against the fp64 oracle are the same to the digit with one step as with two (3.2e-16 /
+// 2.4e-15), three fp64 instructions per entry less (cfg4 0.1223 -> 0.1202 ms; profiles/r05_experiments.txt item 14).
+// -DMIPME_F64_NEWTON=2: the old two (A/B builds).
+#ifndef MIPME_F64_NEWTON
+#define MIPME_F64_NEWTON 1
+#endif
 template <int BS, bool CELL = false, int PFAST = 1>
 __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& args, unsigned block, char* __restrict__ lds) {
   static_assert(kRowLanes == 16, "two groups of 16 entries per row and iteration");
@@ -647,7 +654,7 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
 #pragma unroll
     for (int u = 0; u < 2; ++u) inv[u] = __builtin_amdgcn_rsq(d2[u]);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < MIPME_F64_NEWTON; ++k) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) inv[u] = inv[u] * __builtin_fma(-0.5 * d2[u] * inv[u], inv[u], 1.5);
     }
