@@ -651,7 +651,7 @@ template <int THREADS> struct SpreadShape {
 };
 static constexpr int SPREAD_ROUND = SpreadShape<SPREAD_THREADS>::kRound;
 
-static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize + kErfcxLdsDoubles,
+static_assert(SPREAD_WAVES * BRICK_PTS >= 4 * kShiftTableSize + kErfcxLdsDoubles + kExp2Tab,
               "the shift table of a row workgroup (4 reals per code) and the fp64 body's erfcx table live in the staging region");
 static inline size_t spread_lds_bytes(int order, size_t real_bytes, int stage_rows, bool sparse = false, bool live = false) {
   const int waves = sparse ? SpreadShape<SPREAD_THREADS_SPARSE>::kWaves : SPREAD_WAVES;

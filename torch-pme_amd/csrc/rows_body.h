@@ -517,12 +517,13 @@ __device__ __forceinline__ i4v raw_buffer(const void* base, unsigned bytes) {
 // distances): raw buffer loads (no 64-bit address arithmetic), no distance by-product and its branches, erfc from the LDS table
 // of srpot.h instead of the whole-range polynomial whose 21 scalar-register constants made the generic body spill.  ISA of the
 // hot loop: 223 -> ... VALU per two entries (profiles/r03_experiments.txt).
-// lds: kShiftTableSize AtomRecord<double> (the shift table) followed by kErfcxLdsDoubles doubles (the erfcx table).
+// lds: kShiftTableSize AtomRecord<double> (the shift table) followed by kErfcxLdsDoubles doubles (the erfcx table) and kExp2Tab
+// doubles (2^(j/64) for exp_neg_table2).
 __device__ __forceinline__ i4v uniform_rsrc(i4v r) {
   return i4v{__builtin_amdgcn_readfirstlane(r.x), __builtin_amdgcn_readfirstlane(r.y), __builtin_amdgcn_readfirstlane(r.z),
              __builtin_amdgcn_readfirstlane(r.w)};
 }
-static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(AtomRecord<double>) + sizeof(double) * kErfcxLdsDoubles;
+static constexpr size_t kRowsF64LdsBytes = size_t(kShiftTableSize) * sizeof(AtomRecord<double>) + sizeof(double) * (kErfcxLdsDoubles + kExp2Tab);
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ d2v llvm_raw_buffer_load_d2(i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f64");
 __device__ d2v llvm_struct_buffer_load_d2(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2f64");
@@ -550,6 +551,10 @@ static __device__ long long g_rows_phase[8 * 1024];
 #define MIPME_ROWS_UNMASKED 1  // 0: every iteration of the packed fp32 and the fp64 bodies with its tail selects (the form before round 4's end)
 #endif
 // PFAST = 1: Coulomb (erfc from the LDS table); PFAST even (6: round 5): Q_p(x) = e^{-x} sum_{k < p/2} x^k / k!, no table
+// exp(-x) of the fp64 pair body from a 64-entry table + 5 FMAs (srpot.h exp_neg_table2) instead of 13 FMAs; 0: the latter (A/B)
+#ifndef MIPME_F64_EXP_TABLE
+#define MIPME_F64_EXP_TABLE 1
+#endif
 // Newton steps behind v_rsq_f64 in the fp64 pair body.  ONE: the instruction is good to ~2^-26 on gfx950, a step squares that --
 // energies and forces of cfg2 / cfg4 against the fp64 oracle are the same to the digit with one step as with two (3.2e-16 /
 // 2.4e-15), three fp64 instructions per entry less (cfg4 0.1223 -> 0.1202 ms; profiles/r05_experiments.txt item 14).
@@ -605,6 +610,9 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
                                         sx * A[2] + sy * A[5] + sz * A[8], 0.0};
     }
     if constexpr (PFAST == 1) erfcx_table_to_lds(etab, threadIdx.x, BS);
+#if MIPME_F64_EXP_TABLE
+    exp2_table_to_lds(etab + kErfcxLdsDoubles, threadIdx.x, BS);
+#endif
   }
   const int pot_end = args.full ? mid : 0x7fffffff;
   const int beg = r0, end = valid ? r2 : r0;
@@ -663,7 +671,11 @@ __device__ __forceinline__ void sr_rows_f64_body(const FusedRowsArgs<double>& ar
       x[u] = d2[u] * c_inv2s2;
       y[u] = c1 * (d2[u] * inv[u]);
     }
+#if MIPME_F64_EXP_TABLE
+    exp_neg_table2(x, e, etab + kErfcxLdsDoubles);
+#else
     exp_neg_fast2(x, e);
+#endif
     constexpr unsigned kCentre = unsigned(kShiftTableRange * (1 + kShiftTableBase + kShiftTableBase * kShiftTableBase));
     const bool any_cross = CELL && __builtin_amdgcn_ballot_w64((okA && codeA != kCentre) || (okB && codeB != kCentre)) != 0;
     double dens[2];  // 2 x * (density term of Q_p): term_1 for Coulomb, 2 x e x^{p/2-1} / (p/2-1)! for even p

@@ -196,6 +196,51 @@ __device__ __forceinline__ void erfcx_table_to_lds(double* __restrict__ lds, int
   for (int k = tid; k < kErfcxIntervals * kErfcxRow; k += nthr) lds[k] = kErfcxTabDevice[k];
   for (int k = tid; k < kErfcChebTerms; k += nthr) lds[kErfcxIntervals * kErfcxRow + k] = kErfcChebDevice[k];
 }
+// exp(-x) with a table (round 5; the fp64 pair body is bound by fp64 issue at ~8 clocks per wavefront and instruction):
+// -x = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128, exp(-x) = 2^m T[j] exp(r) with T[j] = 2^(j/64) from LDS and a degree-5 Taylor
+// polynomial for exp(r) (r^6 / 720 < 3.5e-17) -- 5 dependent FMAs where exp_neg_fast2 below has 13; max relative error 4e-16
+// (the 13-term form: 3e-16).  kExp2Tab doubles behind the erfcx table in the body's LDS (exp2_table_to_lds).
+static constexpr int kExp2Tab = 64;
+#define MIPME_EXP2_TAB                                                                                                        \
+  1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, \
+  1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,       \
+  1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,         \
+  1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,          \
+  1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,        \
+  1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,         \
+  1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,       \
+  1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,         \
+  1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,       \
+  1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,         \
+  1.9360617934922943, 1.9571441241754002, 1.978456026387951
+static __device__ const double kExp2TabDevice[kExp2Tab] = {MIPME_EXP2_TAB};
+__device__ __forceinline__ void exp2_table_to_lds(double* __restrict__ lds, int tid, int nthr) {
+  for (int k = tid; k < kExp2Tab; k += nthr) lds[k] = kExp2TabDevice[k];
+}
+__device__ __forceinline__ void exp_neg_table2(const double (&xin)[2], double (&out)[2], const double* __restrict__ tab) {
+  double nf[2], r[2], q[2];
+  int n[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const double x = __builtin_fmin(xin[u], 700.0);
+    nf[u] = __builtin_rint(-x * 92.33248261689366);                 // 64 / ln2
+    r[u] = __builtin_fma(nf[u], -0.01083042469326756, -x);          // ln2 / 64: 32 significant bits (n * hi is exact)
+    r[u] = __builtin_fma(nf[u], -2.9815858269852933e-12, r[u]);     // ... and the rest
+    n[u] = int(nf[u]);
+    q[u] = 1.0 / 120.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0 / 24.0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0 / 6.0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = __builtin_fma(q[u], r[u], 0.5);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = __builtin_fma(q[u], r[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    out[u] = __builtin_amdgcn_ldexp(tab[n[u] & (kExp2Tab - 1)] * __builtin_fma(q[u], r[u], 1.0), n[u] >> 6);
+}
 // erfc(y) given e = exp(-y^2), y >= 0, with the table in LDS
 __device__ __forceinline__ double erfc_from_table(double y, double e, const double* __restrict__ lds) {
   struct alignas(16) D2 {
