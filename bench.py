@@ -82,9 +82,14 @@ def parse_args(argv=None):
     ap.add_argument("--store-distances", action="store_true",
                     help="also store the pair distances the fused pair kernel forms (a by-product nobody reads in an energy + "
                          "forces step; off: they stay in registers)")
-    ap.add_argument("--exchange", default=None, choices=["per-step", "pipelined", "final"],
-                    help="all-gather of the frame energies: after every evaluation, on the compute stream (default with more "
-                         "than one rank); after every evaluation but overlapped with the next one; or once after the last step")
+    ap.add_argument("--exchange", default=None, choices=["log", "per-step", "pipelined", "final", "in-graph"],
+                    help="all-gather of the frame energies.  log (default with more than one rank; SURVEY 8(e): ONE collective): "
+                         "every step appends its energies to a device-resident log (last node of the step's HIP graph) and the "
+                         "whole K x frames log is all-gathered once per timed region; per-step: a collective after every "
+                         "evaluation, on the compute stream; pipelined: the same, overlapped with the next evaluation; final: "
+                         "only the LAST step's energies, once; in-graph: the per-step collective captured into the step's graph")
+    ap.add_argument("--no-exchange-sweep", action="store_true",
+                    help="with several ranks: skip the one timed block per OTHER exchange protocol (parallelism.other_exchange_modes_ms_per_step)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (the median block is the reported value)")
     ap.add_argument("--prewarm-ms", type=float, default=30.0, help="untimed replays before the warm-up steps (clock ramp)")
     ap.add_argument("--no-list-refresh", action="store_true")
@@ -914,9 +919,9 @@ def main(argv=None):
     frame, w = frames[0], frames[0].w
     s = 4 if w.dtype == "f32" else 8
     # the farm's exchange: every rank contributes its frame energies to an all-gather (8 B per frame)
-    exchange_mode = (args.exchange or "per-step") if (distributed and world > 1) else ("final" if distributed else "none")
-    if distributed and args.exchange is not None:
-        exchange_mode = args.exchange
+    exchange_mode = (args.exchange or "log") if distributed else "none"
+    mode = {"x": exchange_mode}  # (the secondary blocks at the end time the other modes with the same closures)
+    log_cap = max(1, args.steps)
     my_energy = torch.zeros(n_frames, dtype=frame.dtype, device=device)
     all_energies = torch.zeros(world * n_frames, dtype=frame.dtype, device=device)
     ring = [(torch.zeros_like(my_energy), torch.zeros_like(all_energies)) for _ in range(2)]
@@ -928,13 +933,34 @@ def main(argv=None):
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     launch = "eager" if stub else args.launch
+    use_batch = launch == "graph" and n_frames > 1 and args.frame_batch == "one-launch"
+    # exchange "log": the step's graph appends its energies to a device-resident log (graphed.EnergyLog: one more node);
+    # "in-graph": the per-step RCCL all-gather is captured as the tail of the step's graph
+    elog = None
+    extra = {}
+    if distributed and not stub and launch == "graph" and (use_batch or n_frames == 1):
+        if exchange_mode == "log":
+            elog = tpa.EnergyLog(log_cap, n_frames, device)
+            extra["energy_log"] = elog
+        elif exchange_mode == "in-graph":
+            def _gather_in_graph(step):
+                src = step.energies if hasattr(step, "energies") else step.energy.reshape(1)
+                dist.all_gather_into_tensor(all_energies, src)
+
+            extra["epilogue"] = _gather_in_graph
+    elif exchange_mode == "in-graph":
+        raise SystemExit("--exchange in-graph needs --launch graph and one graph per rank (one frame, or --frame-batch one-launch)")
+    # without a graph of its own to ride on (eager launches, one graph per frame on its own stream, the CPU stub) the log is
+    # filled by a copy after every step
+    host_log = torch.zeros((log_cap, n_frames), dtype=torch.float64, device=device) if (distributed and elog is None) else None
     graphed = None
     if launch == "graph":
         try:
+            own = extra if not use_batch else {}
             if args.neighbors == "stream":
-                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, neighbors=f.w.cutoff) for f in frames]
+                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, neighbors=f.w.cutoff, **own) for f in frames]
             else:
-                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames]
+                graphed = [tpa.GraphedEnergyForces(f.calc, f.q, f.cell, f.pos, f.pairs, f.shifts, **own) for f in frames]
         except Exception as exc:  # capture not possible on this stack: fall back to eager launches, and say so
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
             launch, graphed = "eager", None
@@ -945,7 +971,7 @@ def main(argv=None):
     batch = None
     if streams is not None and args.frame_batch == "one-launch":
         # all frames of this rank with one launch per kernel (blockIdx.y = frame) from one HIP graph
-        batch = tpa.GraphedFrameBatch(frames[0].calc, [(f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames])
+        batch = tpa.GraphedFrameBatch(frames[0].calc, [(f.q, f.cell, f.pos, f.pairs, f.shifts) for f in frames], **extra)
 
     def one_step():
         """One pass of the hot path over this rank's batch of frames; returns the frame energies (device tensors)."""
@@ -981,7 +1007,7 @@ def main(argv=None):
         if not distributed:
             return
         src = energies_tensor(energies)
-        if exchange_mode == "pipelined":
+        if mode["x"] == "pipelined":
             k = i % 2
             if pending[k] is not None:
                 pending[k].wait()
@@ -991,28 +1017,48 @@ def main(argv=None):
             dist.all_gather_into_tensor(all_energies, src)
 
     def drain(last_i):
-        if distributed and exchange_mode == "pipelined":
+        if distributed and mode["x"] == "pipelined":
             for k in range(2):
                 if pending[k] is not None:
                     pending[k].wait()
                     pending[k] = None
             all_energies.copy_(ring[last_i % 2][1])
 
+    logged = {"entries": 0}
+
+    def exchange_log(n):
+        """ONE collective for the n evaluations of a timed region: all-gather of this rank's (min(n, capacity), frames) log."""
+        from torchpme_amd import farm
+
+        rows = min(n, log_cap)
+        values = elog.values if elog is not None else host_log
+        gathered = farm.gather_energy_log(values[:rows])  # (world, rows, frames)
+        all_energies.copy_(gathered[:, (n - 1) % log_cap, :].reshape(-1))
+        logged["entries"] = int(gathered.numel())
+
     def run_steps(n, with_exchange=True):
         E = None
+        x = mode["x"] if with_exchange else "none"
+        if x == "log" and elog is not None:
+            elog.reset()  # (a fill kernel in front of the first step: inside the timed region)
         for i in range(n):
             E = one_step()
-            if with_exchange and exchange_mode in ("per-step", "pipelined"):
+            if x in ("per-step", "pipelined"):
                 join_streams()
                 exchange(i, E)
+            elif x == "log" and elog is None:
+                join_streams()
+                host_log[i % log_cap].copy_(energies_tensor(E))
         join_streams()
-        if with_exchange and exchange_mode == "final" and E is not None:
+        if x == "final" and E is not None:
             exchange(0, E)
+        if x == "log" and n > 0:
+            exchange_log(n)
         if with_exchange and n > 0:
             drain(n - 1)
         return E
 
-    def timed_block(n, only_rank0=False):
+    def timed_block(n, only_rank0=False, with_exchange=True):
         """EXACTLY n steps bracketed by barrier + synchronize on both sides; only_rank0: the other ranks stay idle (and there
         is no exchange), for the one-rank reference time of weak_efficiency."""
         sync()
@@ -1022,7 +1068,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         E = None
         if not only_rank0 or rank == 0:
-            E = run_steps(n, with_exchange=not only_rank0)
+            E = run_steps(n, with_exchange=with_exchange and not only_rank0)
         sync()
         dt_own = time.perf_counter() - t0  # this rank's own time (before it waits for the others)
         if distributed:
@@ -1034,14 +1080,16 @@ def main(argv=None):
     # clock ramp: a fresh box needs tens of ms of work before its clocks settle (round 2: 7 % between a 1.5 ms timed region
     # right after 5 replays and a long run)
     n_prewarm, t_pre = 0, time.perf_counter()
-    while not stub and 1e3 * (time.perf_counter() - t_pre) < args.prewarm_ms:
+    while not stub and (1e3 * (time.perf_counter() - t_pre) < args.prewarm_ms or (exchange_mode == "in-graph" and n_prewarm < 400)):
         run_steps(20, with_exchange=False)
         sync()
         n_prewarm += 20
+        if exchange_mode == "in-graph" and n_prewarm >= 400:  # every replay is a collective: the same count on every rank
+            break
     E = run_steps(args.warmup)
     dbg("warm-up done")
     t_alone = None
-    if distributed and world > 1:
+    if distributed and world > 1 and exchange_mode != "in-graph":  # (an in-graph collective cannot run on one rank alone)
         t_alone, _ = timed_block(args.steps, only_rank0=True)
     block_times = []
     for b in range(max(1, args.blocks)):
@@ -1049,14 +1097,30 @@ def main(argv=None):
         E = Eb if Eb is not None else E
         block_times.append(dt_own)
     dbg("timed loops done")
-    own = torch.tensor(block_times + [t_alone or 0.0], dtype=torch.float64, device=device)
+    log_entries = logged["entries"]  # (of the last timed block)
+    # the other exchange protocols, one block each, same invocation (reported under parallelism.other_exchange_modes; never `value`)
+    other_modes, other_times = [], []
+    if distributed and not args.no_exchange_sweep and exchange_mode != "in-graph":
+        for m in ("none", "log", "per-step", "pipelined", "final"):
+            if m == exchange_mode or (m == "log" and exchange_mode == "in-graph"):
+                continue
+            mode["x"] = m
+            run_steps(min(args.warmup, 5), with_exchange=m != "none")
+            dt_m, _ = timed_block(args.steps, with_exchange=m != "none")
+            other_modes.append(m)
+            other_times.append(dt_m)
+        mode["x"] = exchange_mode
+        run_steps(1)  # (all_energies = the reported mode's, for the check below)
+    n_blocks = len(block_times)
+    own = torch.tensor(block_times + other_times + [t_alone or 0.0], dtype=torch.float64, device=device)
     if distributed:
         flat = torch.zeros(world * own.numel(), dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(flat, own)
         gathered = flat.reshape(world, own.numel())
     else:
         gathered = own.reshape(1, -1)
-    per_block = gathered[:, :-1].max(dim=0).values.tolist()  # MAX over ranks, per block
+    per_block = gathered[:, :n_blocks].max(dim=0).values.tolist()  # MAX over ranks, per block
+    other_ms = {m: round(1e3 * float(gathered[:, n_blocks + k].max()) / args.steps, 6) for k, m in enumerate(other_modes)}
     # the contract's one timed region: the MEDIAN block (each block is exactly K steps between barrier + synchronize; the first
     # block was the fastest one in every run of round 4 -- a 1 % favourable pick, round-4 verdict); the first block is reported
     # next to it as ms_per_step_first_block
@@ -1092,11 +1156,19 @@ def main(argv=None):
         "backend": (f"{backend} ({'RCCL' if backend == 'nccl' else 'CPU test'}), world size reported by the backend"
                     if distributed else "none (single process)"),
         "exchange": exchange_mode,
-        "collective": ({"per-step": "all_gather_into_tensor of the frame energies after EVERY evaluation, on the compute stream, "
+        "collective": ({"log": "every step appends its frame energies to a device-resident log ("
+                               + ("last node of the step's HIP graph" if elog is not None else "a copy after the step")
+                               + "); ONE all_gather_into_tensor of the K x frames log per timed region, inside it (SURVEY 8(e))",
+                        "per-step": "all_gather_into_tensor of the frame energies after EVERY evaluation, on the compute stream, "
                                     "inside the timed loop",
                         "pipelined": "all_gather_into_tensor after every evaluation, asynchronous (two slots), inside the timed loop",
-                        "final": "one all_gather_into_tensor of the frame energies per timed region"}[exchange_mode]
+                        "in-graph": "all_gather_into_tensor of the frame energies captured as the tail of the step's HIP graph",
+                        "final": "one all_gather_into_tensor of the LAST step's frame energies per timed region"}[exchange_mode]
                        if distributed else None),
+        "log_entries_gathered": log_entries if exchange_mode == "log" else None,
+        "energies_gathered": int(all_energies.numel()) if distributed else n_frames,
+        "energies_sum": float(all_energies.double().sum()) if distributed else None,
+        "other_exchange_modes_ms_per_step": other_ms if distributed else None,
         "per_rank_ms_per_step": [round(v, 6) for v in per_rank_ms],
         "ranks": ranks,
     }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 406
+#define MIPME_VERSION 407
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -453,6 +453,15 @@ int mipme_dot_forward(void* stream, int dtype, int64_t n, const void* a, const v
                       void* out);
 int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, const void* a, const void* b, void* grad_a,
                        void* grad_b);
+
+/* ---- frame farm (the reference loops over frames on the host, calculators/pme.py:102-105): the energy log.
+ * A rank evaluates batch after batch of independent frames and keeps every batch's frame energies in a device-resident log
+ * that is exchanged ONCE (one all-gather of the whole log) -- no collective between two evaluations.  One tiny launch, meant to
+ * be captured as the last node of a step's HIP graph: log[(cursor[0] mod capacity) * n + f] = (double) src[f] for f < n, then
+ * cursor[0] += 1.  src: n reals of `dtype` (the step's energy outputs); log: float64[capacity * n]; cursor: ONE int32 of
+ * device memory that counts the pushes (the caller zeroes it to start a new log).  Slots wrap around: the log holds the
+ * last `capacity` pushes. */
+int mipme_energy_log_push(void* stream, int dtype, int n, const void* src, void* log, void* cursor, int capacity);
 
 /* Energy-mode detection for callers that reduce with plain tensor ops, E = (charges * V).sum() (README.rst:112-114): the
  * gradient arriving at the calculator's backward is then gE * charges.  result[0] = s = g[k] / q[k] at the k of the largest

@@ -38,10 +38,11 @@ def test_gpus_flag_spawns_ranks():
 
 
 def test_exchange_modes_gather_the_same_energies():
-    """per-step (default with > 1 rank: the all-gather after EVERY evaluation, inside the timed loop), pipelined (asynchronous,
-    two slots) and final (round 2's single exchange) must deliver the same frame energies; the line carries the protocol."""
+    """log (default with > 1 rank, SURVEY 8(e): every step's energies kept in a log, ONE all-gather of the K x frames log per
+    timed region), per-step (the all-gather after EVERY evaluation, inside the timed loop), pipelined (asynchronous, two slots)
+    and final (only the last step's energies) must deliver the same frame energies; the line carries the protocol."""
     sums = {}
-    for mode in ("per-step", "pipelined", "final"):
+    for mode in ("log", "per-step", "pipelined", "final"):
         out = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-gpu", "2", "--blocks", "2", "--exchange", mode)
         assert out["parallelism"]["exchange"] == mode and out["energies_gathered"] == 4
         assert out["timing"]["blocks"] == 2 and len(out["timing"]["blocks_ms_per_step"]) == 2
@@ -53,19 +54,25 @@ def test_exchange_modes_gather_the_same_energies():
         cores = [r["affinity"].get("cores") for r in out["parallelism"]["ranks"]]
         assert cores[0] != cores[1] or cores[0] is None  # disjoint core sets when the host has more than one core
         sums[mode] = out["energies_sum"]
+        others = out["parallelism"]["other_exchange_modes_ms_per_step"]  # one timed block per other protocol, same invocation
+        assert set(others) == {"none", "log", "per-step", "pipelined", "final"} - {mode} and all(v > 0 for v in others.values())
+        if mode == "log":  # 2 ranks x 4 steps x 2 frames crossed in ONE collective
+            assert out["parallelism"]["log_entries_gathered"] == 16
     assert sums["per-step"] == pytest.approx(sums["final"], rel=1e-12) == pytest.approx(sums["pipelined"], rel=1e-12)
-    out = _run("--gpus", "2", "--steps", "2", "--warmup", "1")
-    assert out["parallelism"]["exchange"] == "per-step"  # the default with more than one rank
+    assert sums["log"] == pytest.approx(sums["final"], rel=1e-12)
+    out = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-exchange-sweep")
+    assert out["parallelism"]["exchange"] == "log"  # the default with more than one rank
+    assert out["parallelism"]["other_exchange_modes_ms_per_step"] == {}
 
 
 def test_eight_ranks_cfg4_preset():
     """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node -- ``bench.py --gpus 8 --preset cfg4`` -- on eight CPU
-    ranks (gloo, stub evaluator): rank binding, the per-step exchange of 8 x 8 frame energies inside the timed loop and
+    ranks (gloo, stub evaluator): rank binding, the one exchange of the 8 x 2 x 8 logged frame energies inside the timed region and
     ``weak_efficiency`` are all exercised; only the evaluator and the fabric differ from the real run."""
     out = _run("--gpus", "8", "--preset", "cfg4", "--steps", "2", "--warmup", "1", "--blocks", "1")
     assert out["n_gpus"] == 8 and out["parallelism"]["n_ranks"] == 8
     assert out["energies_gathered"] == 64 and out["config"]["frames_per_gpu"] == 8
-    assert out["parallelism"]["exchange"] == "per-step"
+    assert out["parallelism"]["exchange"] == "log" and out["parallelism"]["log_entries_gathered"] == 8 * 2 * 8
     assert len(out["parallelism"]["per_rank_ms_per_step"]) == 8
     assert sorted(r["rank"] for r in out["parallelism"]["ranks"]) == list(range(8))
     assert out["weak_efficiency"]["value"] > 0

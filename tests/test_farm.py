@@ -105,3 +105,36 @@ def test_farm_gathers_per_atom_results(tmp_path, n_frames, world):
         np.testing.assert_array_equal(np.load(tmp_path / f"f{r}.npy"), torch.cat(arr_ser).numpy())
     for f, a in enumerate(arr_ser):
         assert a.shape == (sizes[f], 4)
+
+
+def _log_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # K = 3 evaluations of F = 2 frames per rank: value = 100 rank + 10 k + f
+        k, f = torch.meshgrid(torch.arange(3), torch.arange(2), indexing="ij")
+        log = (100.0 * rank + 10.0 * k + f).to(torch.float64)
+        out = farm.gather_energy_log(log)
+        np.save(os.path.join(out_dir, f"log{rank}.npy"), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_energy_log_crosses_in_one_collective(tmp_path):
+    """``gather_energy_log``: K evaluations x F frames per rank, ONE all-gather; every rank ends up with every
+    rank's log in rank order.  Without a process group it is the identity with a leading axis of one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_log_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    l0, l1 = np.load(tmp_path / "log0.npy"), np.load(tmp_path / "log1.npy")
+    np.testing.assert_array_equal(l0, l1)
+    assert l0.shape == (2, 3, 2)
+    for r in range(2):
+        for k in range(3):
+            np.testing.assert_array_equal(l0[r, k], [100.0 * r + 10.0 * k, 100.0 * r + 10.0 * k + 1])
+    alone = farm.gather_energy_log(torch.arange(6.0, dtype=torch.float64).reshape(3, 2))
+    assert alone.shape == (1, 3, 2) and float(alone[0, 2, 1]) == 5.0
+    with pytest.raises(ValueError):
+        farm.gather_energy_log(torch.zeros(4))

@@ -9,7 +9,7 @@ repository root).  All compute runs in ``libmipme.so`` (hand-written HIP, C-ABI 
 from . import lib, library, ops, prefactors, tuning, workloads  # noqa: F401  (library registers the torch.ops.mipme ops)
 from ._lib import LIB_PATH, MipmeError  # noqa: F401
 from .calculators import Calculator, EwaldCalculator, P3MCalculator, PMECalculator
-from .graphed import GraphedEnergyForces, GraphedFrameBatch
+from .graphed import EnergyLog, GraphedEnergyForces, GraphedFrameBatch
 from .neighbors import NeighborStream, neighbor_list, neighbor_list_device
 from .ops import pair_distances, weighted_sum
 from .potentials import CoulombPotential, InversePowerLawPotential, Potential
@@ -27,6 +27,7 @@ __all__ = [
     "Potential",
     "pair_distances",
     "weighted_sum",
+    "EnergyLog",
     "GraphedEnergyForces",
     "GraphedFrameBatch",
     "neighbor_list",

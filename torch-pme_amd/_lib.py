@@ -28,7 +28,7 @@ EXPORTS = (
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
     "mipme_rspace_rows", "mipme_rspace_rows_value_bytes", "mipme_rspace_rows_tabulate", "mipme_rspace_rows_tabulated", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes", "mipme_plane_spread_parts", "mipme_frames_counter_ints",
-    "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward",
+    "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward", "mipme_energy_log_push",
     "mipme_nl_workspace_bytes", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill", "mipme_nl_stream",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
@@ -268,6 +268,7 @@ def _declare(lib):
         "mipme_ewald_backward": [vp, ci, i64, ci, i64] + [vp] * 12 + [i64],
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
+        "mipme_energy_log_push": [vp, ci, ci, vp, vp, vp, ci],
         "mipme_scaled_match": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_scaled_match_work": [i64],
         "mipme_scaled_match_wide": [vp, ci, i64, vp, vp, vp, vp, vp],

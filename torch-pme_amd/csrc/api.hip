@@ -501,6 +501,16 @@ static constexpr int kDotBlocks = 64;
 // One kernel: per-block partial sums, then the block that draws the last ticket adds them in index order (deterministic)
 // and resets the ticket counter.  scratch: kDotBlocks doubles + one int counter that is zero between calls.
 template <typename T>
+__global__ __launch_bounds__(64) void energy_log_push_kernel(int n, const T* __restrict__ src, double* __restrict__ log,
+                                                             int* __restrict__ cursor, int capacity) {
+  const int k = cursor[0];
+  const int slot = int(unsigned(k) % unsigned(capacity));
+  for (int f = threadIdx.x; f < n; f += 64) log[int64_t(slot) * n + f] = double(src[f]);
+  __syncthreads();  // every lane has read the cursor
+  if (threadIdx.x == 0) cursor[0] = k + 1;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
                                                  double* partials, int* counter, T* __restrict__ out) {
   double acc = 0.0;
@@ -1465,6 +1475,21 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
     dot_backward_kernel<double><<<blocks, 256, 0, st>>>(n, (const double*)grad, (const double*)a, (const double*)b,
                                                         (double*)grad_a, (double*)grad_b);
   else {
+    set_error("invalid dtype %d", dtype);
+    return MIPME_EINVAL;
+  }
+  MIPME_LAUNCH_CHECK();
+  return MIPME_OK;
+}
+
+int mipme_energy_log_push(void* stream, int dtype, int n, const void* src, void* log, void* cursor, int capacity) {
+  MIPME_REQUIRE(n > 0 && capacity > 0 && src && log && cursor, "invalid arguments to mipme_energy_log_push");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIPME_F32) {
+    energy_log_push_kernel<float><<<1, 64, 0, st>>>(n, (const float*)src, (double*)log, (int*)cursor, capacity);
+  } else if (dtype == MIPME_F64) {
+    energy_log_push_kernel<double><<<1, 64, 0, st>>>(n, (const double*)src, (double*)log, (int*)cursor, capacity);
+  } else {
     set_error("invalid dtype %d", dtype);
     return MIPME_EINVAL;
   }

@@ -119,6 +119,50 @@ class _LiveStep:
                                "system); construct with live_bins=False")
 
 
+class EnergyLog:
+    """Device-resident log of the frame energies of successive evaluations (the frames a rank owns).
+
+    A rank of the frame farm evaluates batch after batch of independent frames; with a log the energies of every batch stay
+    on the device -- ``values[k]`` (``n_frames`` float64) = the energies of the k-th evaluation since :meth:`reset` -- and are
+    exchanged ONCE (``farm.gather_energy_log``: one all-gather of the whole log) instead of once per evaluation.  The push is
+    one small launch (``mipme_energy_log_push``) that the graphed steps capture as the LAST node of their HIP graph, so a
+    replay costs the host nothing extra.  Slots wrap around: the log holds the last ``capacity`` evaluations; ``cursor``
+    (one int32 on the device) counts them."""
+
+    def __init__(self, capacity: int, n_frames: int, device):
+        if capacity < 1 or n_frames < 1:
+            raise ValueError("an energy log needs capacity >= 1 and n_frames >= 1")
+        self.capacity, self.n_frames = int(capacity), int(n_frames)
+        self.values = torch.zeros((self.capacity, self.n_frames), dtype=torch.float64, device=device)
+        self.cursor = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def push(self, energies: torch.Tensor) -> None:
+        """Append ``energies`` (``n_frames`` reals on the log's device) -- one launch on the current stream, capturable."""
+        if energies.numel() != self.n_frames or not energies.is_contiguous():
+            raise ValueError(f"the log holds {self.n_frames} energies per evaluation, got a tensor of {tuple(energies.shape)}")
+        _lib.require_device(energies, "energies")
+        with _lib.on_device(energies.device):
+            _lib.check(_lib.load().mipme_energy_log_push(
+                _lib.current_stream(energies.device), _lib.dtype_code(energies.dtype), self.n_frames, energies.data_ptr(),
+                self.values.data_ptr(), self.cursor.data_ptr(), self.capacity))
+
+    def reset(self) -> None:
+        """Start a new log (asynchronous, on the current stream)."""
+        self.cursor.zero_()
+
+    def count(self) -> int:
+        """Evaluations pushed since :meth:`reset` (synchronises)."""
+        return int(self.cursor.item())
+
+
+def _as_energy_log(energy_log, n_frames, device):
+    if energy_log is None or isinstance(energy_log, EnergyLog):
+        if energy_log is not None and energy_log.n_frames != n_frames:
+            raise ValueError(f"the energy log holds {energy_log.n_frames} energies per evaluation, the step produces {n_frames}")
+        return energy_log
+    return EnergyLog(int(energy_log), n_frames, device)
+
+
 class GraphedEnergyForces:
     """``E, F = step(positions)`` with ``E = sum_i q_i V_i`` and ``F = -dE/dpositions``, replayed from a HIP graph.
 
@@ -151,12 +195,19 @@ class GraphedEnergyForces:
         returns -- one stream synchronisation -- and, on a violation, refreshes the neighbour structures and evaluates again,
         so that what it returns is always valid.  In this mode the charges live in the object's records: change them with
         :meth:`set_charges`.  Default: on where the kernels cover the case (mesh calculators with 1/r or 1/r^6).
+    :param energy_log: an :class:`EnergyLog` (or a capacity, for a new one: ``self.energy_log``) that every replay appends its
+        energy to -- one more node at the end of the captured graph (frame farm: one exchange for many evaluations)
+    :param epilogue: ``epilogue(step)`` is called once, INSIDE the capture, after everything else: whatever it launches on the
+        current stream (e.g. an RCCL collective on ``step.energy``) becomes the tail of the replayed graph
     """
 
     def __init__(self, calculator, charges, cell, positions, neighbor_indices=None, neighbor_shifts=None, warmup: int = 3,
                  cell_gradient: bool = False, store_distances: bool = False, neighbors=None,
-                 periodic=(True, True, True), live_bins: bool | None = None, charge_gradient: bool = False):
+                 periodic=(True, True, True), live_bins: bool | None = None, charge_gradient: bool = False,
+                 energy_log=None, epilogue=None):
         self.calc = calculator
+        self.energy_log = _as_energy_log(energy_log, 1, positions.device)
+        self._epilogue = epilogue
         self.store_distances = bool(store_distances)
         self.charge_gradient = bool(charge_gradient)
         self.stream = None
@@ -286,6 +337,11 @@ class GraphedEnergyForces:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._live.step()
+            self.energy = self._live.energy
+            if self.energy_log is not None:
+                self.energy_log.push(self._live.energy.reshape(1))
+            if self._epilogue is not None:
+                self._epilogue(self)
         self.energy, self.forces, self.distances = self._live.energy, self._live.grad, None
         self.charge_grad = self._live.grad_q
         self.cell_grad = None if self._live.grad_cell is None else self._live.grad_cell[18:27].view(3, 3)
@@ -337,6 +393,10 @@ class GraphedEnergyForces:
         with torch.cuda.graph(self.graph):
             self.energy = self._eval()
             self.forces = self.pos.grad
+            if self.energy_log is not None:
+                self.energy_log.push(self.energy.reshape(1))
+            if self._epilogue is not None:
+                self._epilogue(self)
             if self._fused_contract:
                 t = self._tail
                 self._keepalive.append(t)  # (G_deriv, cell_work, the output buffers)
@@ -444,9 +504,11 @@ class GraphedFrameBatch:
     :param frames: sequence of ``(charges, cell, positions, neighbor_indices, neighbor_shifts)``
     :param store_distances: keep every frame's pair distances in ``self.distances[f]`` (by-product of the pair kernel; needs a
         list ordered by its first index); off by default, see :class:`GraphedEnergyForces`
+    :param energy_log: an :class:`EnergyLog` (or a capacity) that every replay appends its F energies to, see there
+    :param epilogue: ``epilogue(batch)``, called once inside the capture after everything else (see :class:`GraphedEnergyForces`)
     """
 
-    def __init__(self, calculator, frames, warmup: int = 2, store_distances: bool = False):
+    def __init__(self, calculator, frames, warmup: int = 2, store_distances: bool = False, energy_log=None, epilogue=None):
         lib = _lib.load()
         self.calc = calculator
         self.store_distances = bool(store_distances)
@@ -548,9 +610,14 @@ class GraphedFrameBatch:
                 self._eval()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
+        self.energy_log = _as_energy_log(energy_log, F, device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._eval()
+            if self.energy_log is not None:
+                self.energy_log.push(self.energies)
+            if epilogue is not None:
+                epilogue(self)
         self.forces = [p.grad for p in self.pos]
 
     def _launch_forward(self):
