@@ -901,7 +901,7 @@ def main(argv=None):
     if not stub:
         torch.cuda.set_device(device)
     affinity = None
-    if distributed or os.environ.get("MIPME_BIND") == "1":
+    if (distributed and os.environ.get("MIPME_BIND") != "0") or os.environ.get("MIPME_BIND") == "1":
         affinity = bind_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None if stub else local_rank)
 
     def sync():

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MIPME_VERSION 407
+#define MIPME_VERSION 408
 
 enum { MIPME_F32 = 0, MIPME_F64 = 1 };
 enum { MIPME_I64 = 0, MIPME_I32 = 1 };
@@ -264,6 +264,12 @@ typedef struct mipme_kspace_forward_args {
    * into the tiles of the forward (y,z) transform (plane spread, csrc/bricks.hip), and neither the mesh nor the forward plane
    * launch of the convolution exists. */
   int64_t flags;
+  /* frame farm (appended in round 6; see mipme_energy_log_push): with the gather tail above, out_energy is also appended to
+   * energy_log (float64[energy_log_capacity], slot = energy_log_cursor[0] mod capacity; the cursor, ONE int32 of device
+   * memory, is then incremented) by the thread that writes out_energy -- all three NULL / 0 to switch it off. */
+  void* energy_log;
+  void* energy_log_cursor;
+  int64_t energy_log_capacity;
 } mipme_kspace_forward_args_t;
 #define MIPME_FWD_RHO_MESH_UNUSED 1
 int mipme_kspace_forward(const mipme_kspace_forward_args_t* args);
@@ -457,11 +463,18 @@ int mipme_dot_backward(void* stream, int dtype, int64_t n, const void* grad, con
 /* ---- frame farm (the reference loops over frames on the host, calculators/pme.py:102-105): the energy log.
  * A rank evaluates batch after batch of independent frames and keeps every batch's frame energies in a device-resident log
  * that is exchanged ONCE (one all-gather of the whole log) -- no collective between two evaluations.  One tiny launch, meant to
- * be captured as the last node of a step's HIP graph: log[(cursor[0] mod capacity) * n + f] = (double) src[f] for f < n, then
- * cursor[0] += 1.  src: n reals of `dtype` (the step's energy outputs); log: float64[capacity * n]; cursor: ONE int32 of
- * device memory that counts the pushes (the caller zeroes it to start a new log).  Slots wrap around: the log holds the
- * last `capacity` pushes. */
+ * be captured as the last node of a step's HIP graph: log[(cursor[f] mod capacity) * n + f] = (double) src[f], cursor[f] += 1
+ * for f < n.  src: n reals of `dtype` (the step's energy outputs); log: float64[capacity * n]; cursor: int32[n] of device
+ * memory, one counter per frame (all equal: the number of pushes; the caller zeroes them to start a new log -- a counter per
+ * frame so that the writers of a batch, one workgroup per frame, share nothing).  Slots wrap around: the log holds the last
+ * `capacity` pushes.
+ * The steps that form their energy in the gather launch append to the log THERE, at no cost (no extra launch):
+ * mipme_kspace_forward_args_t.energy_log / mipme_md_args_t.energy_log (n = 1) and mipme_frames_table_energy_log (n =
+ * n_frames: patches the host table between mipme_frames_table_build and the upload; log == NULL switches it off); this entry
+ * point serves every other way of producing energies. */
 int mipme_energy_log_push(void* stream, int dtype, int n, const void* src, void* log, void* cursor, int capacity);
+int mipme_frames_table_energy_log(int dtype, int n_frames, void* host_table, int64_t host_table_bytes, void* log, void* cursors,
+                                  int capacity);
 
 /* Energy-mode detection for callers that reduce with plain tensor ops, E = (charges * V).sum() (README.rst:112-114): the
  * gradient arriving at the calculator's backward is then gE * charges.  result[0] = s = g[k] / q[k] at the k of the largest
@@ -753,6 +766,10 @@ typedef struct {
   const void* G_deriv;
   void* cell_work;
   const void* aux_seed;     /* device scalar, nullable (= grad_seed): the factor of grad_charges / grad_cell */
+  /* appended in version 408: the energy log of the frame farm as in the arguments of mipme_kspace_forward; all NULL / 0: off */
+  void* energy_log;
+  void* energy_log_cursor;
+  int64_t energy_log_capacity;
 } mipme_md_args_t;
 int mipme_md_supported(const mipme_mesh_t* mesh, const mipme_potential_t* pot, int64_t n_atoms, int dtype);
 int64_t mipme_md_lists_ints(const mipme_mesh_t* mesh, int64_t n_atoms);

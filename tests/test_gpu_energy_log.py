@@ -42,8 +42,15 @@ def test_push_wraps_and_counts(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("neighbors", ["list", "stream"])
-def test_graphed_step_logs_every_replay(dtype, neighbors):
+@pytest.mark.parametrize("neighbors", ["list", "stream", "list-no-tail"])
+def test_graphed_step_logs_every_replay(dtype, neighbors, monkeypatch):
+    """binned step (the gather tail appends: mipme_kspace_forward_args_t.energy_log), live-bin step (mipme_md_args_t.energy_log)
+    and a step without the gather tail (one more graph node: mipme_energy_log_push)."""
+    from torchpme_amd import ops
+
+    if neighbors == "list-no-tail":
+        monkeypatch.setattr(ops, "TAIL_FUSION", False)
+        neighbors = "list"
     rng = np.random.default_rng(11)
     q, cell, pos, pairs, S = _frame(rng, dtype)
     calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=0.6, interpolation_nodes=5).to(dtype)
@@ -54,6 +61,8 @@ def test_graphed_step_logs_every_replay(dtype, neighbors):
         step = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=4.0, energy_log=4)
         plain = tpa.GraphedEnergyForces(calc, q, cell, pos, neighbors=4.0)
     assert step.energy_log.count() == 0  # warm-up and capture push nothing
+    if neighbors == "list":
+        assert bool(step._tail is not None and step._tail.get("logged")) == ops.TAIL_FUSION
     want = []
     for k in range(6):
         p = pos + 0.01 * k * torch.tensor(rng.normal(size=tuple(pos.shape)), device=DEV, dtype=dtype)

@@ -28,7 +28,7 @@ EXPORTS = (
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
     "mipme_rspace_rows", "mipme_rspace_rows_value_bytes", "mipme_rspace_rows_tabulate", "mipme_rspace_rows_tabulated", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes", "mipme_plane_spread_parts", "mipme_frames_counter_ints",
-    "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward", "mipme_energy_log_push",
+    "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward", "mipme_energy_log_push", "mipme_frames_table_energy_log",
     "mipme_nl_workspace_bytes", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill", "mipme_nl_stream",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
     "mipme_pack_pair_shifts", "mipme_pair_distance_forward_packed", "mipme_fft_plan_xfused", "mipme_fft_plan_kgrid_blocks", "mipme_fft_r2c",
@@ -149,6 +149,7 @@ class KspaceForwardArgs(_VersionedArgs):
         ("nan_flag", C.c_void_p),
         ("out_grad_charges", C.c_void_p), ("out_grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
         ("aux_seed", C.c_void_p), ("out_rho_hat", C.c_void_p), ("flags", C.c_int64),
+        ("energy_log", C.c_void_p), ("energy_log_cursor", C.c_void_p), ("energy_log_capacity", C.c_int64),
     ]
 
 
@@ -198,6 +199,7 @@ class MdArgs(_VersionedArgs):
         ("grad_seed", C.c_void_p), ("nan_flag", C.c_void_p), ("host_flags", C.c_void_p),
         ("grad_charges", C.c_void_p), ("grad_cell", C.c_void_p), ("G_deriv", C.c_void_p), ("cell_work", C.c_void_p),
         ("aux_seed", C.c_void_p),
+        ("energy_log", C.c_void_p), ("energy_log_cursor", C.c_void_p), ("energy_log_capacity", C.c_int64),
     ]
 
     def __init__(self, **fields):
@@ -269,6 +271,7 @@ def _declare(lib):
         "mipme_dot_forward": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_dot_backward": [vp, ci, i64, vp, vp, vp, vp, vp],
         "mipme_energy_log_push": [vp, ci, ci, vp, vp, vp, ci],
+        "mipme_frames_table_energy_log": [ci, ci, vp, i64, vp, vp, ci],
         "mipme_scaled_match": [vp, ci, i64, vp, vp, vp, vp],
         "mipme_scaled_match_work": [i64],
         "mipme_scaled_match_wide": [vp, ci, i64, vp, vp, vp, vp, vp],

@@ -503,11 +503,11 @@ static constexpr int kDotBlocks = 64;
 template <typename T>
 __global__ __launch_bounds__(64) void energy_log_push_kernel(int n, const T* __restrict__ src, double* __restrict__ log,
                                                              int* __restrict__ cursor, int capacity) {
-  const int k = cursor[0];
-  const int slot = int(unsigned(k) % unsigned(capacity));
-  for (int f = threadIdx.x; f < n; f += 64) log[int64_t(slot) * n + f] = double(src[f]);
-  __syncthreads();  // every lane has read the cursor
-  if (threadIdx.x == 0) cursor[0] = k + 1;
+  for (int f = threadIdx.x; f < n; f += 64) {  // a cursor per frame (the gather tails of a batch own one each: mipme.h)
+    const int k = cursor[f];
+    log[int64_t(unsigned(k) % unsigned(capacity)) * n + f] = double(src[f]);
+    cursor[f] = k + 1;
+  }
 }
 
 template <typename T>
@@ -1036,6 +1036,12 @@ static int md_step_t(const mipme_md_args_t& a) {
   tail.grad_q = a.grad_charges;
   tail.aux_seed = a.aux_seed;
   tail.live_flags = a.host_flags;
+  if (a.energy_log) {
+    MIPME_REQUIRE(a.energy_log_cursor && a.energy_log_capacity > 0, "energy_log needs energy_log_cursor and a capacity > 0");
+    tail.elog = (double*)a.energy_log;
+    tail.elog_cursor = (int*)a.energy_log_cursor;
+    tail.elog_cap = int(a.energy_log_capacity);
+  }
   STAGE(st, "spread+rspace_forward", live_spread<T>(st, m, a.n_atoms, a.records, a.atom_bins, a.live_lists, a.rho_mesh, &job, a.host_flags,
                                                      a.grad_cell ? cw.cwave : nullptr));
   int64_t n_sr_part = 0;
@@ -1180,6 +1186,13 @@ int mipme_kspace_forward(const mipme_kspace_forward_args_t* args_in) {
     MIPME_REQUIRE(tail.epart_k, "could not allocate the energy partial sums of the plan (not possible during stream "
                                 "capture: run one evaluation before capturing)");
     tp = &tail;
+  }
+  if (a.energy_log) {
+    MIPME_REQUIRE(tp && a.energy_log_cursor && a.energy_log_capacity > 0,
+                  "energy_log rides on the gather tail (out_energy, out_grad_positions) and needs energy_log_cursor and a capacity > 0");
+    tail.elog = (double*)a.energy_log;
+    tail.elog_cursor = (int*)a.energy_log_cursor;
+    tail.elog_cap = int(a.energy_log_capacity);
   }
   if (a.out_grad_charges || a.out_grad_cell) {
     MIPME_REQUIRE(tp, "out_grad_charges / out_grad_cell ride on the gather tail (out_energy, out_grad_positions)");

@@ -1690,6 +1690,11 @@ struct GatherTail {
   // live-bin step (nullable): the pinned flag word of the step; if the spread of THIS step has flagged an atom beyond the margin
   // (bit 1) the energy is written as NaN -- a step whose results are invalid says so in what it returns, not only at the next call
   const int* live_flags;
+  // frame farm: the energy also goes to a float64 log (mipme.h, energy_log) -- elog[(cursor mod cap) * stride] with elog / cursor
+  // already offset by the frame's index in its batch (a cursor per frame: every frame's writer owns one)
+  double* elog = nullptr;
+  int* elog_cursor = nullptr;
+  int elog_cap = 0, elog_stride = 1;
 };
 
 // R sums of a workgroup -> rpart[9 * block ...].  r3: lanes 0..2 of every 8-lane atom group hold r_c * gp_l for c = 0..2 (l = the
@@ -1745,6 +1750,11 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
     double e = t[0] + 0.5 * double(inv_vol) * t[2] - 0.5 * double(self_c) * t[1] - double(bg_c) * double(inv_vol) * Q * Q;
     if (tail.live_flags && (__hip_atomic_load(tail.live_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & 2)) e = __builtin_nan("");
     tail.energy[0] = T(e);
+    if (tail.elog) {
+      const int k = tail.elog_cursor[0];
+      tail.elog[int64_t(unsigned(k) % unsigned(tail.elog_cap)) * tail.elog_stride] = double(T(e));
+      tail.elog_cursor[0] = k + 1;
+    }
   }
 }
 
@@ -2455,6 +2465,9 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     tail.rec4 = (const AtomRecord<T>*)th->records;
     tail.aux_seed = (const T*)th->aux_seed;
     tail.live_flags = nullptr;
+    tail.elog = th->elog;
+    tail.elog_cursor = th->elog_cursor;
+    tail.elog_cap = th->elog_cap;
     MIPME_REQUIRE(!tail.rpart || tail.rec4, "the cell sums of the gather need the atom records");
     if (sparse_bricks(N, bg.nb))
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
@@ -3556,6 +3569,9 @@ int live_gather(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   tail.rec4 = (const AtomRecord<T>*)rec4;
   tail.aux_seed = (const T*)th->aux_seed;
   tail.live_flags = (const int*)th->live_flags;
+  tail.elog = th->elog;
+  tail.elog_cursor = th->elog_cursor;
+  tail.elog_cap = th->elog_cap;
   MIPME_DISPATCH_ORDER(m->order, (live_gather_tail_kernel<N, T><<<brick_grid(bg), GATHER_THREADS, 0, st>>>(
                                      g, bg, v.idx, ll.rec_now, (const T*)v.wts, (const AtomRecord<T>*)rec4, (const T*)mesh,
                                      (const T*)qsum, T(1.0 / m->volume), T(self_c), T(bg_c), (T*)out, (T*)field, tail,
@@ -3594,6 +3610,19 @@ template int gather_grad_bricks<double>(hipStream_t, const mipme_mesh_t*, int64_
 
 using namespace mipme;
 
+template <typename T>
+static int frames_table_energy_log_t(int n_frames, void* host_table, void* log, void* cursors, int capacity) {
+  FrameDev<T>* d = (FrameDev<T>*)host_table;
+  for (int f = 0; f < n_frames; ++f) {
+    MIPME_REQUIRE(!log || d[f].use_tail, "the energy log rides on the gather tail (mipme_frame_t.use_tail) of every frame");
+    d[f].tail.elog = log ? (double*)log + f : nullptr;
+    d[f].tail.elog_cursor = log ? (int*)cursors + f : nullptr;
+    d[f].tail.elog_cap = capacity;
+    d[f].tail.elog_stride = n_frames;
+  }
+  return MIPME_OK;
+}
+
 extern "C" {
 
 int64_t mipme_frames_table_bytes(int dtype, int n_frames) {
@@ -3609,6 +3638,15 @@ int mipme_frames_table_build(int dtype, int n_frames, const mipme_frame_t* frame
                 "invalid arguments to mipme_frames_table_build");
   if (dtype == MIPME_F32) return frames_table_build_t<float>(n_frames, frames, pot, host_table);
   return frames_table_build_t<double>(n_frames, frames, pot, host_table);
+}
+
+int mipme_frames_table_energy_log(int dtype, int n_frames, void* host_table, int64_t host_table_bytes, void* log, void* cursors,
+                                  int capacity) {
+  MIPME_REQUIRE((dtype == MIPME_F32 || dtype == MIPME_F64) && n_frames > 0 && host_table &&
+                    host_table_bytes >= mipme_frames_table_bytes(dtype, n_frames) && (!log || (cursors && capacity > 0)),
+                "invalid arguments to mipme_frames_table_energy_log");
+  if (dtype == MIPME_F32) return frames_table_energy_log_t<float>(n_frames, host_table, log, cursors, capacity);
+  return frames_table_energy_log_t<double>(n_frames, host_table, log, cursors, capacity);
 }
 
 int mipme_frames_forward(mipme_fft_plan* plan, void* stream, int dtype, int n_frames, const mipme_frame_t* frames,

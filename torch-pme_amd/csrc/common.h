@@ -261,6 +261,10 @@ struct GatherTailHost {
   const void* records; // (N,4) reals x, y, z, q: the atoms' positions for rpart
   const void* aux_seed; // device scalar, nullable (= seed): the factor of grad_q and of the cell gradient
   const void* live_flags; // live-bin step: its pinned flag word (bit 1 = an atom beyond the margin -> the energy becomes NaN)
+  // frame farm (mipme.h, energy_log): the energy is also appended to a float64 log, slot = cursor mod capacity (nullable)
+  double* elog;
+  int* elog_cursor;
+  int elog_cap;
 };
 
 // The cell gradient of an energy step inside the fused convolution (kfilter.hip, convolve_xfused): the x stage stores

@@ -68,6 +68,7 @@ class _LiveStep:
         self.nan_flag = calculator._nan_flag_ptr()
         calculator._nan_shape = [1, *geom.ns]
         self.rows = None  # (row_ptr, words, shift_format)
+        self.log = None  # an EnergyLog the step's gather appends the energy to (set by GraphedEnergyForces before its capture)
 
     def _args(self):
         row_ptr, words, fmt = self.rows if self.rows is not None else (self.lists, self.lists, 2)  # (rebin reads no rows)
@@ -80,7 +81,10 @@ class _LiveStep:
             potentials=self.potentials.data_ptr(), pair_force=self.pair_force.data_ptr(), energy=self.energy.data_ptr(),
             grad_positions=self.grad.data_ptr(), grad_seed=self.minus_one.data_ptr(), nan_flag=self.nan_flag,
             host_flags=self.flags.data_ptr(), grad_charges=_lib.ptr(self.grad_q), grad_cell=_lib.ptr(self.grad_cell),
-            G_deriv=_lib.ptr(self.G_deriv), cell_work=_lib.ptr(self.cell_work), aux_seed=self.one.data_ptr())
+            G_deriv=_lib.ptr(self.G_deriv), cell_work=_lib.ptr(self.cell_work), aux_seed=self.one.data_ptr(),
+            energy_log=None if self.log is None else self.log.values.data_ptr(),
+            energy_log_cursor=None if self.log is None else self.log.cursor.data_ptr(),
+            energy_log_capacity=0 if self.log is None else self.log.capacity)
 
     def rebin(self):
         with _lib.on_device(self.device):
@@ -124,17 +128,19 @@ class EnergyLog:
 
     A rank of the frame farm evaluates batch after batch of independent frames; with a log the energies of every batch stay
     on the device -- ``values[k]`` (``n_frames`` float64) = the energies of the k-th evaluation since :meth:`reset` -- and are
-    exchanged ONCE (``farm.gather_energy_log``: one all-gather of the whole log) instead of once per evaluation.  The push is
-    one small launch (``mipme_energy_log_push``) that the graphed steps capture as the LAST node of their HIP graph, so a
-    replay costs the host nothing extra.  Slots wrap around: the log holds the last ``capacity`` evaluations; ``cursor``
-    (one int32 on the device) counts them."""
+    exchanged ONCE (``farm.gather_energy_log``: one all-gather of the whole log) instead of once per evaluation.  The graphed
+    steps append inside their gather launch -- the thread that writes a frame's energy also writes its log slot
+    (``mipme_kspace_forward_args_t.energy_log``, ``mipme_md_args_t.energy_log``, ``mipme_frames_table_energy_log``): no extra
+    launch, a replay costs neither the host nor the GPU anything (a separate push node measured +2.0 us on a 58 us step).
+    Evaluations that do not end in the gather tail use :meth:`push` (``mipme_energy_log_push``, one small launch).  Slots wrap
+    around: the log holds the last ``capacity`` evaluations; ``cursor`` (int32 per frame on the device, all equal) counts them."""
 
     def __init__(self, capacity: int, n_frames: int, device):
         if capacity < 1 or n_frames < 1:
             raise ValueError("an energy log needs capacity >= 1 and n_frames >= 1")
         self.capacity, self.n_frames = int(capacity), int(n_frames)
         self.values = torch.zeros((self.capacity, self.n_frames), dtype=torch.float64, device=device)
-        self.cursor = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.cursor = torch.zeros((self.n_frames,), dtype=torch.int32, device=device)
 
     def push(self, energies: torch.Tensor) -> None:
         """Append ``energies`` (``n_frames`` reals on the log's device) -- one launch on the current stream, capturable."""
@@ -152,7 +158,7 @@ class EnergyLog:
 
     def count(self) -> int:
         """Evaluations pushed since :meth:`reset` (synchronises)."""
-        return int(self.cursor.item())
+        return int(self.cursor[0].item())
 
 
 def _as_energy_log(energy_log, n_frames, device):
@@ -334,12 +340,11 @@ class GraphedEnergyForces:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self._keepalive = [self._live, self.stream, getattr(self.calc, "_cache", None)]
+        self._live.log = self.energy_log  # (from here on: the gather of the step appends its energy to the log)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._live.step()
             self.energy = self._live.energy
-            if self.energy_log is not None:
-                self.energy_log.push(self._live.energy.reshape(1))
             if self._epilogue is not None:
                 self._epilogue(self)
         self.energy, self.forces, self.distances = self._live.energy, self._live.grad, None
@@ -391,10 +396,10 @@ class GraphedEnergyForces:
             self._keepalive += [self.stream.row_ptr, self.stream.words]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.energy = self._eval()
+            self.energy = self._eval(log=self.energy_log)
             self.forces = self.pos.grad
-            if self.energy_log is not None:
-                self.energy_log.push(self.energy.reshape(1))
+            if self.energy_log is not None and not (self._tail is not None and self._tail.get("logged")):
+                self.energy_log.push(self.energy.reshape(1))  # (no gather tail in this step: one more node)
             if self._epilogue is not None:
                 self._epilogue(self)
             if self._fused_contract:
@@ -407,7 +412,7 @@ class GraphedEnergyForces:
                 self.charge_grad = -self.q.grad if self.charge_gradient else None
                 self.cell_grad = -self.cell.grad if self.cell_gradient else None
 
-    def _eval(self):
+    def _eval(self, log=None):
         # the pair kernel of the calculator forms the distances itself (no separate pass over the list); "virtual": in
         # registers only, True: stored as a by-product
         if self.stream is not None:
@@ -422,7 +427,7 @@ class GraphedEnergyForces:
         # request, dE/dcharges and dE/dcell with a seed of +1
         fused = self._fused_contract
         with ops.seed_promise(self._minus_one, charges=fused and self.charge_gradient, cell=fused and self.cell_gradient,
-                              aux_seed=self._one):
+                              aux_seed=self._one, energy_log=log):
             V = self.calc(self.q, self.cell, self.pos, self.pairs, d)
         self._tail = getattr(V.grad_fn, "tail", None)
         E = ops.weighted_sum(V, self.q)
@@ -601,6 +606,10 @@ class GraphedFrameBatch:
         nbytes = lib.mipme_frames_table_bytes(dt, F)
         host = np.zeros((nbytes,), dtype=np.uint8)
         _lib.check(lib.mipme_frames_table_build(dt, F, self._frames, C.byref(self._pot), host.ctypes.data, nbytes))
+        self.energy_log = _as_energy_log(energy_log, F, device)
+        if self.energy_log is not None:  # every frame's gather tail also writes its slot of the log (no extra launch)
+            _lib.check(lib.mipme_frames_table_energy_log(dt, F, host.ctypes.data, nbytes, self.energy_log.values.data_ptr(),
+                                                         self.energy_log.cursor.data_ptr(), self.energy_log.capacity))
         self._table = torch.from_numpy(host).to(device)
         # warm-up (plans, lazy module loads) off the default stream, then capture
         side = torch.cuda.Stream(device)
@@ -610,12 +619,11 @@ class GraphedFrameBatch:
                 self._eval()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        self.energy_log = _as_energy_log(energy_log, F, device)
+        if self.energy_log is not None:
+            self.energy_log.reset()  # (the warm-up evaluations above appended too)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._eval()
-            if self.energy_log is not None:
-                self.energy_log.push(self.energies)
             if epilogue is not None:
                 epilogue(self)
         self.forces = [p.grad for p in self.pos]

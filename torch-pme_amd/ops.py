@@ -197,6 +197,8 @@ TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
 SEED_PROMISE = None
 #: (charges, cell, aux_seed) asked of the gather's tail irrespective of requires_grad (see seed_promise)
 TAIL_REQUEST = (False, False, None)
+#: a graphed.EnergyLog the gather's tail appends the energy to (see seed_promise)
+TAIL_LOG = None
 
 
 class seed_promise:
@@ -210,19 +212,24 @@ class seed_promise:
     node's ``tail`` itself -- :class:`~torchpme_amd.graphed.GraphedEnergyForces` -- gets forces (seed -1) and the derivatives
     w.r.t. charges and cell (aux seed +1) from one forward pass without a sign-flip launch."""
 
-    def __init__(self, seed, charges: bool = False, cell: bool = False, aux_seed=None):
+    def __init__(self, seed, charges: bool = False, cell: bool = False, aux_seed=None, energy_log=None):
         self.seed, self.want_q, self.want_cell, self.aux_seed = seed, bool(charges), bool(cell), aux_seed
+        #: frame farm: an ``EnergyLog`` of one energy per evaluation that the tail's energy is also appended to (the node's
+        #: ``tail["logged"]`` says whether the tail took it)
+        self.energy_log = energy_log
 
     def __enter__(self):
-        global SEED_PROMISE, TAIL_REQUEST
+        global SEED_PROMISE, TAIL_REQUEST, TAIL_LOG
         self._prev, SEED_PROMISE = SEED_PROMISE, self.seed
         self._prev_req, TAIL_REQUEST = TAIL_REQUEST, (self.want_q, self.want_cell, self.aux_seed)
+        self._prev_log, TAIL_LOG = TAIL_LOG, self.energy_log
         return self
 
     def __exit__(self, *exc):
-        global SEED_PROMISE, TAIL_REQUEST
+        global SEED_PROMISE, TAIL_REQUEST, TAIL_LOG
         SEED_PROMISE = self._prev
         TAIL_REQUEST = self._prev_req
+        TAIL_LOG = self._prev_log
         return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
 ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
@@ -1108,6 +1115,8 @@ class _PMEFunction(torch.autograd.Function):
                                 aux_seed=aux_seed)
                     if tail_q:
                         tail["grad_q"] = torch.empty((N, 1), dtype=dtype, device=device)
+                    if TAIL_LOG is not None and TAIL_LOG.n_frames == 1 and TAIL_LOG.values.device == device:
+                        tail["log"], tail["logged"] = TAIL_LOG, True
                     if tail_cell:
                         tail["grad_cell"] = torch.empty((27,), dtype=dtype, device=device)
                         tail["G_deriv"] = filter_derivative(geom, pot_desc, dtype, device)
@@ -1132,6 +1141,9 @@ class _PMEFunction(torch.autograd.Function):
                     aux_seed=None if tail is None else _lib.ptr(tail["aux_seed"]), out_rho_hat=_lib.ptr(rho_keep),
                     # the charge mesh is only read again (fft_r2c in the backward pass) if rfftn(rho) was not kept
                     flags=0 if keep_rho_mesh else _lib.FWD_RHO_MESH_UNUSED,
+                    energy_log=None if tail is None or "log" not in tail else tail["log"].values.data_ptr(),
+                    energy_log_cursor=None if tail is None or "log" not in tail else tail["log"].cursor.data_ptr(),
+                    energy_log_capacity=0 if tail is None or "log" not in tail else tail["log"].capacity,
                 )
                 _call("kspace_forward", lib.mipme_kspace_forward, C.byref(args))
                 if records_out is not None:
