@@ -551,6 +551,35 @@ def drop_in_timing(frame, n_steps: int = 60, n_warm: int = 10):
     return out
 
 
+class _Committed:
+    """The committed full-size numbers of a benchmark box, by key suffix (``energy``, ``force_sample``, ...): the REFERENCE'S OWN
+    fp64 evaluation (tests/golden/ref_fullsize.npz, made by importing torchpme: tests/golden/make_reference_fullsize.py) where
+    the box has one, else the pinned oracle's (tests/golden/workloads.npz).  Nothing under oracle/ or /root/reference runs here."""
+
+    def __init__(self, name: str):
+        self.name, self.z, self.prefix, self.source = name, None, None, None
+        for fname, prefix, what in (("ref_fullsize.npz", f"{name}_f64_", "the reference itself (torchpme, fp64)"),
+                                    ("workloads.npz", f"{name}_", "pinned oracle (oracle/pme_numpy.py, fp64)")):
+            path = os.path.join(ROOT, "tests", "golden", fname)
+            if os.path.exists(path):
+                z = np.load(path)
+                if prefix + "energy" in z.files:
+                    self.z, self.prefix, self.source = z, prefix, f"{what} for this box: tests/golden/{fname}"
+                    break
+
+    def __contains__(self, key):
+        return self.z is not None and (self.prefix + key in self.z.files or f"{self.name}_{key}" in self.z.files)
+
+    def __getitem__(self, key):  # (n_pairs, sample, pos_checksum carry no precision tag)
+        k = self.prefix + key
+        return self.z[k if k in self.z.files else f"{self.name}_{key}"]
+
+    def matches(self, w) -> bool:
+        chk = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
+        return (self.z is not None and int(self["n_pairs"]) == w.n_pairs
+                and bool(np.allclose(chk, self["pos_checksum"], rtol=1e-12, atol=1e-9)))
+
+
 def contract_timing(frame, name: str):
     """The whole first-order autograd contract of the reference on the headline box (rank 0, one GPU): ms per evaluation of
     {E, F}, {E, F, dE/dq}, {E, F, dE/dq, dE/dcell} as a replayed HIP graph (binned step and live-bin step) and eagerly, and the
@@ -561,31 +590,29 @@ def contract_timing(frame, name: str):
     tpa, w = frame._tpa, frame.w
     out = {"reference": "tests/calculators/test_workflow.py:164-192 (gradients w.r.t. positions, charges, cell from one backward "
                         "pass); tuning/tuner.py:337-373 (TuningTimings protocol)"}
-    z = None
-    path = os.path.join(ROOT, "tests", "golden", "workloads.npz")
-    if os.path.exists(path):
-        z = np.load(path)
-        if f"{name}_cell_grad" not in z.files or int(z[f"{name}_n_pairs"]) != w.n_pairs:
-            z = None
+    z = _Committed(name)
+    if "cell_grad" not in z or not z.matches(w):
+        z = None
+    out["vs_committed_source"] = None if z is None else z.source
     rng = np.random.default_rng(4242)
     rng.normal(size=(w.n_atoms, 3))
     s_vec = rng.normal(size=(w.n_atoms, 1))  # (the checksum vectors of tests/golden/make_workloads_golden.py)
 
     def errors(E, F, dq=None, dc=None):
         if z is None:
-            return {"oracle": "no committed contract numbers for this box"}
-        sample = z[f"{name}_sample"]
-        e = {"rel_energy": abs(float(E) - float(z[f"{name}_energy"])) / abs(float(z[f"{name}_energy"]))}
-        Fs = z[f"{name}_force_sample"]
+            return {"reference": "no committed contract numbers for this box"}
+        sample = z["sample"]
+        e = {"rel_energy": abs(float(E) - float(z["energy"])) / abs(float(z["energy"]))}
+        Fs = z["force_sample"]
         e["force_rel_l2_256_atoms"] = float(np.linalg.norm(F.detach().cpu().double().numpy()[sample] - Fs) / np.linalg.norm(Fs))
         if dq is not None:
             q_ = dq.detach().cpu().double().numpy()
-            ref = z[f"{name}_charge_grad_sample"]
+            ref = z["charge_grad_sample"]
             e["charge_grad_rel_l2_256_atoms"] = float(np.linalg.norm(q_[sample, 0] - ref) / np.linalg.norm(ref))
-            e["charge_grad_checksum_rel"] = abs(float((s_vec * q_).sum()) - float(z[f"{name}_charge_grad_dot"])) / (
+            e["charge_grad_checksum_rel"] = abs(float((s_vec * q_).sum()) - float(z["charge_grad_dot"])) / (
                 np.linalg.norm(s_vec) * np.linalg.norm(q_))
         if dc is not None:
-            ref = z[f"{name}_cell_grad"]
+            ref = z["cell_grad"]
             e["cell_grad_rel_max"] = float(np.abs(dc.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max())
         return e
 
@@ -602,7 +629,7 @@ def contract_timing(frame, name: str):
                 torch.cuda.synchronize()
                 entry = {"ms_per_step": round(min(_event_ms(step.graph.replay, 300, 30) for _ in range(3)), 6),
                          "fused_in_the_step": bool(step._fused_contract), "live_bins": step._live is not None}
-                entry["vs_oracle"] = errors(res[0], res[1], res[2] if "dq" in label else None,
+                entry["vs_reference"] = errors(res[0], res[1], res[2] if "dq" in label else None,
                                             res[-1] if "dcell" in label else None)
                 graph[f"{label} ({mode})"] = entry
                 del step
@@ -632,7 +659,7 @@ def contract_timing(frame, name: str):
 
         ms, med, E = _host_loop_ms(step, n, warm)
         return {"ms_per_step": round(ms, 5), "host_ms_per_step_median": round(med, 5),
-                "vs_oracle": errors(E.detach(), -pos.grad, q.grad, cell.grad)}
+                "vs_reference": errors(E.detach(), -pos.grad, q.grad, cell.grad)}
 
     out["eager"] = {}
     for label, leaves in (("E+F", ()), ("E+F+dq", ("q",)), ("E+F+dq+dcell", ("q", "cell"))):
@@ -660,13 +687,13 @@ def contract_timing(frame, name: str):
                       "calculator.forward(...).sum().backward(retain_graph=True) -- tuning/tuner.py:350-369"}
     timer = tpa.tuning.TuningTimings(q0, c0, p0, frame.pairs, d_fixed, n_repeat=20, n_warmup=4)
     tt["TuningTimings_median_ms"] = round(1e3 * float(timer(frame.calc)), 5)
-    if z is not None and f"{name}_sumseed_cell" in z.files:
-        sample = z[f"{name}_sample"]
-        rp = z[f"{name}_sumseed_pos_sample"]
-        rq = z[f"{name}_sumseed_charge_sample"]
-        rc = z[f"{name}_sumseed_cell"]
-        tt["vs_oracle"] = {
-            "rel_value": abs(float(val) - float(z[f"{name}_sumseed_value"])) / abs(float(z[f"{name}_sumseed_value"])),
+    if z is not None and "sumseed_cell" in z:
+        sample = z["sample"]
+        rp = z["sumseed_pos_sample"]
+        rq = z["sumseed_charge_sample"]
+        rc = z["sumseed_cell"]
+        tt["vs_reference"] = {
+            "rel_value": abs(float(val) - float(z["sumseed_value"])) / abs(float(z["sumseed_value"])),
             "positions_grad_rel_l2_256_atoms": float(np.linalg.norm(gp.cpu().double().numpy()[sample] - rp) / np.linalg.norm(rp)),
             "charges_grad_rel_l2_256_atoms": float(np.linalg.norm(gq.cpu().double().numpy()[sample, 0] - rq) / np.linalg.norm(rq)),
             "cell_grad_rel_max": float(np.abs(gc.cpu().double().numpy() - rc).max() / np.abs(rc).max()),
@@ -755,31 +782,26 @@ def second_order_timing(frame, n_steps: int = 5, n_warm: int = 2):
 
 
 def oracle_accuracy(w, name, E32, F32, E64=None, F64=None):
-    """The timed dtype's energy and forces (and the fp64 path's) against the PINNED ORACLE's numbers for this very box, committed
-    as tests/golden/workloads.npz by tests/golden/make_workloads_golden.py (oracle/pme_numpy.py in fp64; itself pinned to the
-    reference's golden vectors, tests/test_oracle_golden.py).  Nothing under oracle/ runs here."""
-    path = os.path.join(ROOT, "tests", "golden", "workloads.npz")
-    if not os.path.exists(path):
-        return {"reference": "tests/golden/workloads.npz missing"}
-    z = np.load(path)
-    if f"{name}_energy" not in z.files:
-        return {"reference": f"no committed oracle numbers for workload {name}"}
-    chk = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
-    if int(z[f"{name}_n_pairs"]) != w.n_pairs or not np.allclose(chk, z[f"{name}_pos_checksum"], rtol=1e-12, atol=1e-9):
-        return {"reference": "committed oracle numbers belong to a different box (seed / size)"}
-    Eo, sample, Fs = float(z[f"{name}_energy"]), z[f"{name}_sample"], z[f"{name}_force_sample"]
+    """The timed dtype's energy and forces (and the fp64 path's) against the committed full-size numbers of this very box: the
+    REFERENCE'S OWN fp64 evaluation (tests/golden/ref_fullsize.npz) where there is one, else the pinned oracle's
+    (tests/golden/workloads.npz) -- see _Committed.  Nothing under oracle/ runs here."""
+    z = _Committed(name)
+    if z.z is None:
+        return {"reference": f"no committed numbers for workload {name}"}
+    if not z.matches(w):
+        return {"reference": "committed numbers belong to a different box (seed / size)"}
+    Eo, sample, Fs = float(z["energy"]), z["sample"], z["force_sample"]
 
     def errs(E, F):
         F = F.detach().cpu().double().numpy()
         return {"rel_energy_error": abs(E - Eo) / abs(Eo),
                 "force_rel_l2_error_256_atoms": float(np.linalg.norm(F[sample] - Fs) / np.linalg.norm(Fs)),
-                "force_sq_rel_error": abs(float((F * F).sum()) - float(z[f"{name}_force_sq"])) / float(z[f"{name}_force_sq"])}
+                "force_sq_rel_error": abs(float((F * F).sum()) - float(z["force_sq"])) / float(z["force_sq"])}
 
-    out = {"reference": "pinned oracle (oracle/pme_numpy.py, fp64) for this box: tests/golden/workloads.npz",
-           "oracle_energy": Eo}
+    out = {"reference": z.source, "reference_energy": Eo}
     out.update(errs(E32, F32))
     if E64 is not None:
-        out["fp64_path_vs_oracle"] = errs(E64, F64)
+        out["fp64_path_vs_reference"] = errs(E64, F64)
     return out
 
 

@@ -35,15 +35,19 @@ import torchpme  # noqa: E402  (the reference)
 
 from torchpme_amd import workloads  # noqa: E402  (inputs only: the synthetic boxes of SURVEY 8d)
 
-MAKERS = {"ionic": workloads.ionic_box, "water": workloads.water_box}
+# "dispersion" = BASELINE.json configs[4] (cfg5: 262 144 atoms, 1/r^6, P3M n=5, 128^3): round-5 verdict, missing 2 -- until round 6
+# it was held by the oracle's numbers only, and the oracle's p = 6 branch was pinned to the reference on a 7-atom cell
+MAKERS = {"ionic": workloads.ionic_box, "water": workloads.water_box, "dispersion": workloads.dispersion_box}
 
 
 def evaluate(w, dtype):
     t = lambda a: torch.tensor(np.asarray(a), dtype=dtype)  # noqa: E731
     pairs = torch.tensor(w.pairs)
     shifts = t(w.shifts)
-    calc = torchpme.P3MCalculator(torchpme.CoulombPotential(smearing=w.smearing), mesh_spacing=w.mesh_spacing,
-                                  interpolation_nodes=w.order).to(dtype)
+    # (potentials/coulomb.py, potentials/inversepowerlaw.py:55-169 with lib/math.py:85-104 for p = 6)
+    pot = (torchpme.CoulombPotential(smearing=w.smearing) if w.exponent == 1
+           else torchpme.InversePowerLawPotential(exponent=w.exponent, smearing=w.smearing))
+    calc = torchpme.P3MCalculator(pot, mesh_spacing=w.mesh_spacing, interpolation_nodes=w.order).to(dtype)
     pos, q, cell = t(w.positions).requires_grad_(True), t(w.charges).requires_grad_(True), t(w.cell).requires_grad_(True)
     # the reference's caller-side distances (tests/helpers.py:278-304)
     vec = pos[pairs[:, 1]] - pos[pairs[:, 0]] + shifts @ cell
@@ -76,7 +80,9 @@ def main(names):
         out[f"{name}_pos_checksum"] = np.array([w.positions.sum(), (w.positions**2).sum(), w.charges.sum(), (w.charges**2).sum()])
         t1 = time.time()
         for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+            t2 = time.time()
             res = evaluate(w, dtype)
+            print(f"{name} {tag}: reference forward + 2 x autograd in {time.time() - t2:.0f} s", flush=True)
             k = f"{name}_{tag}_"
             out[k + "energy"] = np.asarray(res["E"])
             out[k + "potential_sample"] = res["V"][sample, 0]

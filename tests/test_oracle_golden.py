@@ -229,9 +229,10 @@ FULLSIZE_KEYS = ("energy", "potential_sample", "potential_dot", "force_sample", 
                  "sumseed_charge_sample", "sumseed_charge_dot", "sumseed_cell")
 
 
-@pytest.mark.parametrize("cfg", ["ionic", "water"])
+@pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
 def test_fullsize_goldens_are_pinned_by_the_reference(golden_dir, cfg):
-    """BASELINE.json configs[1] / configs[2] at FULL size: the committed oracle numbers (workloads.npz -- what bench.py's accuracy
+    """BASELINE.json configs[1] / configs[2] / configs[4] (round 6: the 262 144-atom 1/r^6 box, InversePowerLawPotential(6),
+    potentials/inversepowerlaw.py:55-169 + lib/math.py:85-104 at the size the HBM-stress configuration runs) at FULL size: the committed oracle numbers (workloads.npz -- what bench.py's accuracy
     block and the full-size GPU tests compare with) against the reference's own evaluation of the same synthetic box
     (ref_fullsize.npz: torchpme.P3MCalculator + autograd, fp64): energy, sampled potentials / forces / dE/dq, the whole-array
     checksums, dE/dcell and the three gradients of the tuner's V.sum() protocol.  The headline configuration is thereby pinned by

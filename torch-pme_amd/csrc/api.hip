@@ -211,6 +211,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
   fft_plan_set_inverse_corunner(plan, nullptr, nullptr);  // (a failed call must not leave one behind)
+  fft_plan_set_forward_done(plan, false, 1);               // (nor the plane spread's "forward planes done": set below, consumed by convolve_xfused)
   GatherTailHost tail_late{};
   int64_t rows_tail_first = -1;  // first row of the pair-sum blocks that ride on the inverse plane launch (bricks.hip), -1: none
   // the plan's brick counters are zero here; the binning pass fills them and the gather -- the last consumer -- zeroes them
@@ -224,7 +225,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     ~CounterGuard() {
       if (armed && counters) (void)zero_async(counters, sizeof(int) * n, st);
     }
-  } guard{st, nullptr, size_t((m->nx + 7) / 8) * ((m->ny + 7) / 8) * ((m->nz + 7) / 8) + 1 + 8 * size_t(m->nx) + 1, false};
+  } guard{st, nullptr, plan_counter_words(m->nx, m->ny, m->nz), false};
   if (bins) {
     int* counters = fft_plan_brick_count(plan);
     guard.counters = counters;
@@ -321,6 +322,7 @@ static int kspace_backward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_m
   int rc;
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
+  fft_plan_set_forward_done(plan, false, 1);  // (a forward call that failed after its plane spread must not make this call's convolution skip its forward planes)
   if (grad_scale) {
     // energy mode: grad_out = grad_scale * charges  =>  psi = (grad_scale/2V) rho, chi = (grad_scale/2V) phi:
     // no second spread / FFT / filter / inverse FFT (special case L = sum q V)

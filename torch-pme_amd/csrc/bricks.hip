@@ -95,7 +95,7 @@ bool bricks_supported(const mipme_mesh_t* m, int dtype) {
 // Plane lists come in kPlaneSub sub-lists per plane, keyed by the wavefront of the binning pass that appends (its index mod
 // kPlaneSub): the appends are returning atomics on the lists' counters, and same-address atomics serialise -- 1 000 of them on
 // nx = 64 counters were ~16 per address and +1.5 us on the pass; on 512 counters they are 2 per address, like the bricks'.
-static constexpr int kPlaneSub = 8;
+// (kPlaneSub = 8: common.h, next to plan_counter_words)
 struct BinsLayout {
   size_t snap, over_brick, rec, wts, codes, qs, plist, pover, wmax, epart, det, det_sort_bytes, total;
   int cap;
@@ -1426,7 +1426,16 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   }
   __syncthreads();
   MIPME_WG_PHASE(1);
-  const double fx_scale = sizeof(T) == 4 ? fxs[0] : 1.0, fx_inv = sizeof(T) == 4 ? fxs[1] : 1.0;
+  const double fx_scale = sizeof(T) == 4 ? fxs[0] : 1.0;
+  // A product that is not finite (NaN / inf weights: positions that are not finite) would become a large finite integer in the
+  // magic-number conversion below; the lane that meets one poisons the plane's inverse scale instead, so that the plane comes out
+  // NaN as it does with float sums (one weight per axis decides: all N weights of an axis come from the same coordinate)
+  auto guard_item = [&](const PlaneItem<N, T>& it) __attribute__((always_inline)) {
+    if constexpr (sizeof(T) == 4) {
+      const T chk = it.vx * it.wy[0] * it.wz[0];
+      if (!(__builtin_fabsf(chk) <= 3.0e38f)) fxs[1] = __builtin_nan("");
+    }
+  };
   const int total = lst[NL];
   const int lo = int(int64_t(total) * part / pa.parts), hi = int(int64_t(total) * (part + 1) / pa.parts);
   const int n_batches = (hi - lo + nthr - 1) / nthr;
@@ -1449,7 +1458,10 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     int tt3 = 0;
     const int slot3 = load_slot(b + 2, tt3);
     if (b + 1 < n_batches) plane_item_load<N, T>(nxt, slot2 >= 0, slot2, tt2, rec, wts, qs, args.scale);
-    if (cur.vx != T(0)) plane_item_scatter<N, T>(acc, g, cur, fx_scale);
+    if (cur.vx != T(0)) {
+      guard_item(cur);
+      plane_item_scatter<N, T>(acc, g, cur, fx_scale);
+    }
     slot2 = slot3;
     tt2 = tt3;
   }
@@ -1463,12 +1475,14 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
       if (d < N) {
         PlaneItem<N, T> it;
         plane_item_load<N, T>(it, true, slot, d, rec, wts, qs, args.scale);
+        guard_item(it);
         plane_item_scatter<N, T>(acc, g, it, fx_scale);
       }
     }
   }
   __syncthreads();
   MIPME_WG_PHASE(2);
+  const double fx_inv = sizeof(T) == 4 ? fxs[1] : 1.0;  // (read AFTER the scatter: a lane may have poisoned it, guard_item)
   // C: to the working precision and the transform's layout (rows as complex sequences c_j = a_2j + i a_2j+1, bit-reversed for
   // the DIT z transform); the real plane itself for callers that keep the charge mesh.  The fp32 tile aliases the accumulation
   // tile: a chunk's values travel through registers, and rows are written in the order they were read (a tile row is shorter
@@ -2686,7 +2700,7 @@ static int64_t frame_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dt
   return n;
 }
 static bool frame_plane_lists(const mipme_frame_t& f, int dtype) {
-  return plane_list_capacity(&f.mesh, f.n_atoms, dtype) > 0 && int64_t(f.counter_ints) >= frame_counter_ints(&f.mesh, f.n_atoms, dtype);
+  return plane_list_capacity(&f.mesh, f.n_atoms, dtype) > 0 && int64_t(f.counter_ints) == frame_counter_ints(&f.mesh, f.n_atoms, dtype);
 }
 int64_t frames_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dtype) { return frame_counter_ints(m, n_atoms, dtype); }
 
@@ -2707,6 +2721,13 @@ static int frames_check(int dtype, int n_frames, const mipme_frame_t* fr) {
                       f.entries_shift && f.entries && f.records && f.rho_mesh && f.phi_mesh && f.dc && f.out && f.force &&
                       f.field && f.energy && f.grad_positions,
                   "frame %d: NULL buffer or no atoms", k);
+    // counter_ints was padding before round 5: a caller built against the old header may pass garbage.  Only the three
+    // legal values are accepted, so that garbage cannot switch the plane lists on (they write behind the brick counters)
+    MIPME_REQUIRE(f.counter_ints == 0 || int64_t(f.counter_ints) == int64_t(make_brick_geom(&f.mesh).nb) + 1 ||
+                      int64_t(f.counter_ints) == frame_counter_ints(&f.mesh, f.n_atoms, dtype),
+                  "frame %d: counter_ints = %d is neither 0, bricks + 1 = %d nor mipme_frames_counter_ints() = %lld (zero-initialise "
+                  "mipme_frame_t)", k, f.counter_ints, make_brick_geom(&f.mesh).nb + 1,
+                  (long long)frame_counter_ints(&f.mesh, f.n_atoms, dtype));
     MIPME_REQUIRE((f.shift_format == kShiftTable || f.shift_format == kShiftTable32) && f.shift_format == fr[0].shift_format,
                   "frame %d: the frames path needs the table shift format (1 or 2), the same for every frame", k);
   }

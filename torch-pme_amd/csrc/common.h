@@ -242,6 +242,14 @@ struct StencilGroup {
     }                                                                                     \
   } while (0)
 
+// Plane lists of the plane spread (bricks.hip) come in kPlaneSub sub-lists per x plane; their live counters follow the brick
+// counters in one int32 buffer.  plan_counter_words: the words of that buffer -- bricks + their overflow counter + the plane
+// sub-lists + their overflow counter -- for everyone who allocates or clears it (fft_plan_create, CounterGuard, the frames).
+static constexpr int kPlaneSub = 8;
+static inline size_t plan_counter_words(int nx, int ny, int nz) {
+  return size_t((nx + 7) / 8) * size_t((ny + 7) / 8) * size_t((nz + 7) / 8) + 1 + size_t(kPlaneSub) * size_t(nx) + 1;
+}
+
 // Host-side description of the gather's tail (energy + force assembly in the gather launch, csrc/bricks.hip GatherTail)
 struct GatherTailHost {
   const void* force;   // (N,3) pair force sums

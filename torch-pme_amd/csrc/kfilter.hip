@@ -1574,7 +1574,7 @@ int fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan
     return MIPME_EFFT;
   }
   // brick counters + overflow counter, then the plane-list counters of the plane spread + their overflow counter (bricks.hip)
-  const size_t n_count = size_t((nx + 7) / 8) * size_t((ny + 7) / 8) * size_t((nz + 7) / 8) + 1 + 8 * size_t(nx) + 1;  // (8 = kPlaneSub, bricks.hip)
+  const size_t n_count = plan_counter_words(nx, ny, nz);
   if (hipMalloc((void**)&p->brick_count, n_count * sizeof(int)) != hipSuccess ||
       hipMemset(p->brick_count, 0, n_count * sizeof(int)) != hipSuccess) {
     set_error("could not allocate the brick counters of the plan (plans cannot be created during stream capture)");
