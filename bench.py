@@ -281,16 +281,26 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # vector instructions per unmasked iteration, 63 / 61 per masked one (hipcc -S, spread_rows_kernel<5, float, P, true, false>):
 # 27.9 / 26.9 per entry at eight unmasked iterations in ten; the fp64 body 212 -> 203 per iteration of its masked loop.
 PAIR_BODY_VALU = {("f32", 1): (27.9, 3), ("f32", 6): (26.9, 2), ("f64", 1): (87, 1)}
-# What the hardware counters say about the whole launch (rows AND bricks, at the clock it actually runs at): VALUBusy =
-# 4 SQ_ACTIVE_INST_VALU / (SIMDs per shader engine x SQ_BUSY_CYCLES) from profiles/r04_k_sq_counters.txt (cfg3, f32).
-VALU_BUSY_PMC = {"water": {"valu_busy": 0.76, "valu_instructions_per_launch": 7.79e6, "sq_clock_GHz": 1.89,
-                           "source": "profiles/r04_k_sq_counters.txt (SQ_ACTIVE_INST_VALU 259149, SQ_BUSY_CYCLES 42741, "
-                                     "SQ_INSTS_VALU 243408 per shader engine, 32 engines, 22.65 us under the counters; before "
-                                     "the instruction diet of the pair body and of the bricks: 319625 / 50633 / 303883 = 0.79, "
-                                     "9.72 M, profiles/r04_h_sq_counters.txt; round 3's code 10.28 M)"}}
+def sq_counters_of(workload: str, launched_kernel_family: str):
+    """What the hardware counters say about the dominant launch (VALUBusy, vector instructions, waiting share): the committed
+    figures of ONE rocprofv3 --pmc pass of this command (profiles/sq_counters.json, generated by tools/sq_to_json.py from the
+    pass named in its `source`) -- bench.py cannot profile itself.  Refused, loudly, when the kernel the counters belong to is
+    not the kernel family this run launches (round 5 quoted round 4's spread_rows_kernel counters next to plane_rows_kernel)."""
+    path = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if not os.path.exists(path):
+        return {"error": "profiles/sq_counters.json missing (tools/sq_to_json.py)"}
+    entry = json.load(open(path)).get("workloads", {}).get(workload)
+    if entry is None:
+        return None
+    family = entry["kernel"].split("<")[0]
+    if family != launched_kernel_family:
+        return {"error": f"STALE COUNTERS: profiles/sq_counters.json holds {entry['kernel']} (from {entry['source']}) but this run "
+                         f"launches {launched_kernel_family}: re-run tools/profile_final.sh + tools/sq_to_json.py"}
+    return {k: entry[k] for k in ("kernel", "valu_busy", "valu_instructions_per_launch", "wait_frac", "sq_clock_GHz",
+                                  "launch_us_under_counters", "source")}
 
 
-def valu_roofline(w, kernel: str, kernel_ms: float):
+def valu_roofline(w, kernel: str, kernel_ms: float, launched_kernel_family: str = ""):
     """Second roofline of the dominant launch (the pair sum co-scheduled with the spread): instruction-lanes issued by the pair
     rows (entries x VALU instructions per entry, ISA count of the packed body's hot loop) against the chip's VALU issue rate.
     The spread bricks that share the launch are left out of the numerator, so `frac` understates the launch's VALU use by their
@@ -316,8 +326,41 @@ def valu_roofline(w, kernel: str, kernel_ms: float):
         "floor_ms": entries * (ops + 3 * quarter) / (VALU_PEAK_TLANEOPS * 1e12) * 1e3,
         # the model above counts the rows' hot loop at the nominal 2.4 GHz; the counters of the whole launch (committed figure,
         # not measured by this run) put its vector units at 81 % busy: the launch is bound by instruction issue
-        "pmc": VALU_BUSY_PMC.get(getattr(w, "name", "").split("_")[0]),
+        "pmc": sq_counters_of(getattr(w, "name", "").split("_")[0], launched_kernel_family),
     }
+
+
+def dominant_kernel_family(w=None, n_parts: int = 0, n_frames: int = 1) -> str:
+    """Name (without template arguments) of the co-scheduled spread + pair-sum kernel this process launched / captured last, as
+    the library reports it (mipme_last_cosched_kernel: what RAN, not what the geometry would allow)."""
+    from torchpme_amd import _lib
+
+    return _lib.load().mipme_last_cosched_kernel().decode()
+
+
+def host_identification():
+    """CPU model, logical cores and max clock of the box (the eager / drop-in lines are host-bound: comparable only with this)."""
+    info = {"logical_cores": os.cpu_count()}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        info["max_MHz"] = round(int(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read()) / 1e3)
+    except (OSError, ValueError):
+        try:
+            mhz = [float(line.split(":")[1]) for line in open("/proc/cpuinfo") if line.startswith("cpu MHz")]
+            info["observed_MHz_max"] = round(max(mhz)) if mhz else None
+        except (OSError, ValueError):
+            pass
+    try:
+        info["affinity_cores"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return info
 
 
 def plane_parts(w, s: int) -> int:
@@ -391,13 +434,15 @@ def algorithmic_bytes(w, s: int, fused: bool = True, store_distances: bool = Fal
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def _time_cpu_steps(fn, n_warm: int, n_max: int, budget_s: float):
+def _time_cpu_steps(fn, n_warm: int, n_max: int, budget_s: float, n_min: int = 1):
+    """n_warm untimed + up to n_max timed calls (monotonic clock, median); stops early once the budget would be exceeded, but
+    never before n_min timed calls."""
     times, t_all = [], time.monotonic()
     while True:
         t0 = time.monotonic()
         res = fn()
         times.append(time.monotonic() - t0)
-        if len(times) >= n_warm + n_max or (len(times) > n_warm and time.monotonic() - t_all + times[-1] > budget_s):
+        if len(times) >= n_warm + n_max or (len(times) >= n_warm + n_min and time.monotonic() - t_all + times[-1] > budget_s):
             break
     timed = times[n_warm:] if len(times) > n_warm else times[-1:]
     return float(np.median(timed)), len(timed), len(times) - len(timed), res
@@ -428,14 +473,22 @@ def cpu_baseline(w, budget_s: float = 40.0):
             torch.set_num_threads(t)
             med, n_timed, n_warm, (E, _F) = _time_cpu_steps(
                 lambda: OT.energy_forces_step(spec, scheme, w.order, w.mesh_spacing, q, cell, pos, pairs, S),
-                n_warm=1, n_max=4, budget_s=per)
+                n_warm=1, n_max=2, budget_s=per)
             sweep[t] = {"s_per_step": round(med, 4), "atom_steps_per_s": w.n_atoms / med, "timed": n_timed, "warmup": n_warm}
             energy = float(E)
+        # the reported figure: SURVEY 8(d)'s protocol (tuning/tuner.py:337-373: >= 4 warm-ups, >= 4 repeats, median) at the
+        # thread count the sweep found best
+        best = min(sweep, key=lambda t: sweep[t]["s_per_step"])
+        torch.set_num_threads(best)
+        med, n_timed, n_warm, _ = _time_cpu_steps(
+            lambda: OT.energy_forces_step(spec, scheme, w.order, w.mesh_spacing, q, cell, pos, pairs, S),
+            n_warm=4, n_max=4, budget_s=max(10.0, 10 * sweep[best]["s_per_step"]), n_min=4)
+        final = {"s_per_step": round(med, 4), "atom_steps_per_s": w.n_atoms / med, "timed": n_timed, "warmup": n_warm, "threads": best}
     finally:
         torch.set_num_threads(saved)
-    best = min(sweep, key=lambda t: sweep[t]["s_per_step"])
     return {
-        "value": sweep[best]["atom_steps_per_s"],
+        "value": final["atom_steps_per_s"],
+        "protocol_run": final,
         "unit": "atom-steps/s",
         "cores": best,
         "kind": "port",
@@ -443,9 +496,10 @@ def cpu_baseline(w, budget_s: float = 40.0):
         "host_logical_cores": n_logical,
         "thread_sweep": {str(t): v for t, v in sweep.items()},
         "sample": f"full energy+forces steps of the same {w.n_atoms}-atom frame with oracle/pme_torch.py (PyTorch-CPU ATen "
-                  f"ops + autograd), 1 warm-up + up to 4 timed steps per thread count in {counts} (torch.set_num_threads; "
-                  f"host has {n_logical} logical cores), median per count; best = {best} threads at "
-                  f"{sweep[best]['s_per_step']:.3f} s/step, energy {energy:.4f}",
+                  f"ops + autograd): thread sweep with 1 warm-up + up to 2 timed steps per count in {counts} (torch.set_num_threads; "
+                  f"host has {n_logical} logical cores), then the TuningTimings protocol (tuning/tuner.py:337-373) at the best "
+                  f"count: {final['warmup']} warm-ups + {final['timed']} timed steps, median = {final['s_per_step']:.3f} s/step at "
+                  f"{best} threads; energy {energy:.4f}",
     }
 
 
@@ -1119,6 +1173,7 @@ def main(argv=None):
         E = Eb if Eb is not None else E
         block_times.append(dt_own)
     dbg("timed loops done")
+    dom_family = "" if stub else dominant_kernel_family()  # (asked NOW: the secondary blocks below launch other variants)
     log_entries = logged["entries"]  # (of the last timed block)
     # the other exchange protocols, one block each, same invocation (reported under parallelism.other_exchange_modes; never `value`)
     other_modes, other_times = [], []
@@ -1332,9 +1387,11 @@ def main(argv=None):
                 "parallelism": f"{world * n_frames} independent frame(s), {n_frames} per GPU, {world} rank(s)",
             },
             "parallelism": parallelism,
+            "host": host_identification(),
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
+                "kernel_name": dom_family,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -1354,7 +1411,7 @@ def main(argv=None):
                                                     + (0 if args.store_distances else w.n_pairs * s))
                                                    / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if "rspace" in dom else None,
             },
-            "roofline_valu": valu_roofline(w, dom, kernels[dom]),
+            "roofline_valu": valu_roofline(w, dom, kernels[dom], dom_family),
             # whole step: bytes the kernels of this build move in their own formats (sum of the per-kernel figures below)
             # against the step time; SURVEY 8(d)'s figure for the reference's unfused formats is given for orientation only
             "step_bytes": {

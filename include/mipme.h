@@ -412,6 +412,11 @@ int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
  * mipme_atom_bins_bytes returns 0 when the mesh is too small for bricks (< 17 points on an axis, or a last brick narrower
  * than 4 points): pass NULL then (atomic-scatter kernels). */
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
+/* Name (without template arguments) of the co-scheduled spread + pair-sum kernel the calling thread launched -- or captured
+ * into a graph -- last: "plane_rows_kernel", "spread_rows_capped_kernel", "spread_rows_kernel", "sparse_spread_rows_kernel",
+ * "live_spread_rows_kernel", "frames_plane_rows_kernel", "frames_spread_rows_kernel"; "" before the first one.  What ran, as
+ * opposed to mipme_plane_spread_parts (what the geometry allows): a benchmark labels its dominant launch with this. */
+const char* mipme_last_cosched_kernel(void);
 /* Workgroups per x plane of the PLANE SPREAD that mipme_kspace_forward uses for this mesh / system when the caller sets
  * MIPME_FWD_RHO_MESH_UNUSED and rho_hat == NULL (0: the owner-computes bricks + the forward plane launch): single channel,
  * power-of-two nx, ny, nz, planes whose accumulation tile fits a workgroup's LDS, dense bricks, not MIPME_DETERMINISTIC.  For

@@ -1,0 +1,160 @@
+"""Round-6 parity edges (round-5 verdict "weak 1c", advisor findings): the fixed-point plane spread with a very wide charge
+range and at every power-of-two boundary of its scale; non-finite positions and distances must come out as NaN (as the
+reference's float sums would), not as large finite numbers; a ``mipme_frame_t`` with garbage in the former padding word is
+refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import torchpme_amd as tpa
+from oracle import pme_numpy as O
+from torchpme_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rell2(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / (np.linalg.norm(np.asarray(b)) + 1e-300))
+
+
+def _box(rng, n_side=12, a=2.0):
+    L = n_side * a
+    g = (np.arange(n_side) + 0.5) * a
+    pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (n_side**3, 3))
+    cell = L * np.eye(3)
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 4.0)
+    return L, pos, cell, pairs, S, dist
+
+
+def _plane_calc(L, dtype=torch.float32):
+    # 64^3 mesh, P3M n = 5, one channel: the plane spread (mipme_plane_spread_parts > 0)
+    return tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=2 * L / 62, interpolation_nodes=5).to(dtype)
+
+
+def test_plane_spread_wide_charge_range():
+    """One |q| = 1e4 among |q| ~ 1e-2 (a 1e6 : 1 range): the fp32 plane spread sums in 64-bit fixed point with ONE scale per plane,
+    taken from the largest |charge| of the system -- the small charges' contributions sit 2^-20 below the bound and must still be
+    there.  Potentials against the oracle, at the accuracy the float sums of the brick path have, and the small-charge potentials
+    far from the big one (where a lost contribution would show) against the same box without the big charge."""
+    rng = np.random.default_rng(61)
+    L, pos, cell, pairs, S, dist = _box(rng)
+    N = len(pos)
+    q = rng.normal(size=(N, 1)) * 1e-2
+    big = int(np.argmin(np.linalg.norm(pos - pos.mean(0), axis=1)))
+    q[big] = 1e4
+    calc = _plane_calc(L)
+    md = calc._kspace_setup(torch.tensor(cell, device=DEV, dtype=torch.float32), torch.float32, torch.device(DEV), speculate=False)[0].desc(1)
+    assert _lib.load().mipme_plane_spread_parts(C.byref(md), N, _lib.dtype_code(torch.float32)) > 0
+    t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float32)  # noqa: E731
+    ti, td = torch.tensor(pairs, device=DEV), t(dist)
+    spec = O.PotentialSpec("coulomb", 1, 1.0, 1.0)
+    h = 2 * L / 62
+    V = calc(t(q), t(cell), t(pos), ti, td).cpu().double().numpy()
+    Vo = O.forward(spec, "P3M", 5, h, q, cell, pos, pairs, dist)
+    assert rell2(V, Vo) < 5e-6
+    # linearity isolates the small charges: V(q) - V(big only) = V(small only), compared where the big charge's own potential
+    # is smallest (the far half of the box) -- fixed point keeps 2^-50 of the plane's bound, float sums would keep 2^-24 of it
+    q_big = np.zeros_like(q)
+    q_big[big] = q[big]
+    q_small = q - q_big
+    V_big = calc(t(q_big), t(cell), t(pos), ti, td).cpu().double().numpy()
+    Vo_small = O.forward(spec, "P3M", 5, h, q_small, cell, pos, pairs, dist)
+    assert rell2(V - V_big, Vo_small) < 2e-2  # (fp32 cancellation of two ~1e4-scale potentials: 1e4 x 6e-8 / 1e-2)
+    V_small = calc(t(q_small), t(cell), t(pos), ti, td).cpu().double().numpy()
+    assert rell2(V_small, Vo_small) < 5e-6
+
+
+def test_plane_spread_scale_at_every_power_of_two():
+    """The fixed-point scale is 2^(50 - e) with 2^e the first power of two above (atoms of the plane's lists) x max |q|: charges
+    scaled through 2^k (1 -+ 1e-6) for small, moderate and huge k walk the bound across its power-of-two edges.  The potentials
+    must scale with the charges (V is linear), to fp32 rounding -- an off-by-one in e would cost a factor of two in resolution
+    or, the other way, overflow the 2^50 head room."""
+    rng = np.random.default_rng(62)
+    L, pos, cell, pairs, S, dist = _box(rng, n_side=10, a=2.4)
+    N = len(pos)
+    q = rng.normal(size=(N, 1))
+    calc = _plane_calc(L)
+    t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float32)  # noqa: E731
+    ti, td, tc, tp = torch.tensor(pairs, device=DEV), t(dist), t(cell), t(pos)
+    V1 = calc(t(q), tc, tp, ti, td).cpu().double().numpy()
+    Vo = O.forward(O.PotentialSpec("coulomb", 1, 1.0, 1.0), "P3M", 5, 2 * L / 62, q, cell, pos, pairs, dist)
+    assert rell2(V1, Vo) < 5e-6
+    qmax = float(np.abs(q).max())
+    for k in (-30, -18, -1, 0, 1, 7, 23, 40):
+        for eps in (-1e-6, 0.0, 1e-6):
+            c = 2.0**k * (1 + eps) / qmax * 1.0  # max |c q| = 2^k (1 + eps): the bound's mantissa walks past 1.0
+            Vc = calc(t(c * q), tc, tp, ti, td).cpu().double().numpy()
+            assert np.isfinite(Vc).all(), (k, eps)
+            assert rell2(Vc / c, V1) < 3e-6, (k, eps, rell2(Vc / c, V1))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_nonfinite_position_reaches_the_nan_guard(bad, axis):
+    """A position that is not finite gives NaN / inf interpolation weights.  The reference's float sums turn them into NaN
+    potentials and its guard raises (lib/kspace_filter.py:189-195); the fixed-point plane spread must not launder them into
+    finite integers (advisor, round 5): the lane that meets a non-finite product poisons its plane."""
+    rng = np.random.default_rng(63)
+    L, pos, cell, pairs, S, dist = _box(rng, n_side=10, a=2.4)
+    q = rng.normal(size=(len(pos), 1))
+    calc = _plane_calc(L)
+    calc.check_nan = True
+    t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float32)  # noqa: E731
+    ti, td = torch.tensor(pairs, device=DEV), t(dist)
+    assert torch.isfinite(calc(t(q), t(cell), t(pos), ti, td)).all()
+    pos_bad = pos.copy()
+    pos_bad[37, axis] = bad
+    with pytest.raises(ValueError, match="NaNs detected in the k-space filter result"):
+        calc(t(q), t(cell), t(pos_bad), ti, td)
+    assert torch.isfinite(calc(t(q), t(cell), t(pos), ti, td)).all()  # and the next clean call is clean
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("exponent", [1, 6])
+def test_nan_distance_gives_nan_potentials(dtype, exponent):
+    """A NaN in the caller's ``neighbor_distances`` must reach the potentials of both atoms of that pair (the reference's
+    ``sr_from_dist`` is plain tensor arithmetic); the fp64 pair body's table-assisted exp clamps its argument with a min that
+    drops NaN (advisor, round 5) -- the other factors of v_SR (1/d, d^-p) carry it."""
+    rng = np.random.default_rng(64)
+    L, pos, cell, pairs, S, dist = _box(rng, n_side=6, a=2.4)
+    q = rng.normal(size=(len(pos), 1))
+    pot = (tpa.CoulombPotential(smearing=1.0) if exponent == 1 else tpa.InversePowerLawPotential(exponent=6, smearing=1.0))
+    calc = tpa.P3MCalculator(pot, mesh_spacing=0.5, interpolation_nodes=4).to(dtype)
+    t = lambda x: torch.tensor(x, device=DEV, dtype=dtype)  # noqa: E731
+    d = dist.copy()
+    d[5] = float("nan")
+    i, j = pairs[5]
+    for td in (t(d), t(d).clone()):  # first sight of the tensor and the constant-distance table of its second
+        V = calc(t(q), t(cell), t(pos), torch.tensor(pairs, device=DEV), td).cpu().numpy()
+        assert np.isnan(V[i, 0]) and np.isnan(V[j, 0])
+        assert np.isfinite(np.delete(V[:, 0], [i, j])).all()
+
+
+def test_frame_descriptor_with_garbage_counter_word_is_refused():
+    """``mipme_frame_t.counter_ints`` was padding until round 5: a caller built against the old header may pass anything there.
+    Only 0, bricks + 1 and mipme_frames_counter_ints() are accepted -- garbage must not switch the plane lists on (their
+    counters would be written behind the caller's brick counters)."""
+    rng = np.random.default_rng(65)
+    frames = []
+    for _ in range(2):
+        L, pos, cell, pairs, S, dist = _box(rng, n_side=6, a=2.4)
+        t = lambda x: torch.tensor(x, device=DEV, dtype=torch.float64)  # noqa: E731
+        frames.append((t(rng.normal(size=(len(pos), 1))), t(cell), t(pos), torch.tensor(pairs, device=DEV), t(S)))
+    calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.0), mesh_spacing=2 * 14.4 / 30, interpolation_nodes=4).to(torch.float64)
+    batch = tpa.GraphedFrameBatch(calc, frames)
+    lib = _lib.load()
+    nbytes = lib.mipme_frames_table_bytes(batch._dt, 2)
+    host = np.zeros((nbytes,), dtype=np.uint8)
+    build = lambda: lib.mipme_frames_table_build(batch._dt, 2, batch._frames, C.byref(batch._pot), host.ctypes.data, nbytes)  # noqa: E731
+    assert build() == 0
+    good = batch._frames[1].counter_ints
+    for garbage in (good + 1, 0x7F7F7F7F, -3):
+        batch._frames[1].counter_ints = garbage
+        assert build() != 0 and b"counter_ints" in lib.mipme_last_error()
+    batch._frames[1].counter_ints = 0  # the old meaning: bricks + 1 words, no plane lists
+    assert build() == 0
+    batch._frames[1].counter_ints = good
+    assert build() == 0

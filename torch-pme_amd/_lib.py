@@ -27,7 +27,7 @@ EXPORTS = (
     "mipme_cellgrad_partials_size", "mipme_slab_forward", "mipme_slab_backward", "mipme_rspace_forward",
     "mipme_rspace_backward", "mipme_pair_distance_forward", "mipme_pair_distance_backward",
     "mipme_pair_partials_size", "mipme_topology_workspace_bytes", "mipme_topology_build", "mipme_topology_pack_shifts",
-    "mipme_rspace_rows", "mipme_rspace_rows_value_bytes", "mipme_rspace_rows_tabulate", "mipme_rspace_rows_tabulated", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes", "mipme_plane_spread_parts", "mipme_frames_counter_ints",
+    "mipme_rspace_rows", "mipme_rspace_rows_value_bytes", "mipme_rspace_rows_tabulate", "mipme_rspace_rows_tabulated", "mipme_pair_distance_backward_rows", "mipme_rows_partials_size", "mipme_atom_bins_bytes", "mipme_plane_spread_parts", "mipme_last_cosched_kernel", "mipme_frames_counter_ints",
     "mipme_profile_enable", "mipme_profile_report", "mipme_dot_forward", "mipme_dot_backward", "mipme_energy_log_push", "mipme_frames_table_energy_log",
     "mipme_nl_workspace_bytes", "mipme_nl_bin", "mipme_nl_count", "mipme_nl_fill", "mipme_nl_stream",
     "mipme_topology_pack_entries", "mipme_sr_rows_fused", "mipme_sr_rows_finalize",
@@ -302,6 +302,8 @@ def _declare(lib):
     lib.mipme_rows_partials_size.argtypes = [i64]
     lib.mipme_atom_bins_bytes.restype = i64
     lib.mipme_atom_bins_bytes.argtypes = [MP, i64, ci]
+    lib.mipme_last_cosched_kernel.restype = C.c_char_p
+    lib.mipme_last_cosched_kernel.argtypes = []
     lib.mipme_plane_spread_parts.restype = ci
     lib.mipme_plane_spread_parts.argtypes = [MP, i64, ci]
     lib.mipme_frames_counter_ints.restype = i64

@@ -14,6 +14,8 @@ namespace mipme {
 
 static thread_local char g_error[512] = "";
 
+static thread_local const char* g_last_cosched = "";
+void note_cosched_kernel(const char* name) { g_last_cosched = name ? name : ""; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -1077,6 +1079,7 @@ static int scaled_match_wide_t(hipStream_t st, int64_t n, const void* g, const v
 extern "C" {
 
 const char* mipme_last_error(void) { return g_error; }
+const char* mipme_last_cosched_kernel(void) { return g_last_cosched; }
 int mipme_version(void) { return MIPME_VERSION; }
 
 int mipme_fft_plan_create(int dtype, int nx, int ny, int nz, int batch, mipme_fft_plan** out) {

@@ -164,6 +164,21 @@ __device__ __forceinline__ void store_slot_weights(T* __restrict__ wr, const T (
   }
 }
 
+// Plane-list ENTRIES (round 6): what a plane workgroup needs of an atom, written by the binning pass while the atom's weights are
+// in registers -- word 0 the packed stencil reference point (mx << 20 | my << 10 | mz), words 1, 2 the offsets x_y, x_z the y / z
+// weights are functions of, words 3 .. 3 + N the products charge * w_x[t] of the atom's N planes --, padded to whole 16-byte
+// chunks (fp32, N <= 5: 32 bytes).  Until round 5 an entry was the atom's bin SLOT and a plane workgroup gathered record (16 B),
+// weights (44 B of a 120-byte row) and charge behind it: three dependent levels, ~7 gather instructions of 64 cache lines each
+// per wavefront and batch.  The entries of a list are contiguous, so consecutive lanes now stream consecutive 32-byte entries
+// (four lanes to a 128-byte line), there is no index to wait for, and the 2 N weights are 2 x ~25 FMAs (weights_1d).
+template <int N, typename T>
+constexpr int plane_entry_words() {
+  constexpr int V = 16 / int(sizeof(T));
+  return (3 + N + V - 1) / V * V;
+}
+static inline size_t plane_entry_bytes_rt(int order, size_t elem) { return ((3 + size_t(order)) * elem + 15) / 16 * 16; }
+static constexpr int kPlanePackBits = 10;  // my, mz < 1024 (the plane tiles are far smaller), mx < 4096
+
 static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype);
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
   const BrickGeom b = make_brick_geom(m);
@@ -182,8 +197,8 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   // plane lists (plane spread): the slots of the atoms whose stencil reference point m_x is plane p, pcap per plane, and an
   // overflow list (slots of atoms whose plane list was full: normally empty) that every plane also walks
   l.pcap = plane_list_capacity(m, N, dtype);
-  l.plist = off;      off += al(sizeof(int) * size_t(l.pcap) * size_t(l.pcap ? m->nx * kPlaneSub : 0));
-  l.pover = off;      off += al(sizeof(int) * size_t(l.pcap ? N : 0));
+  l.plist = off;      off += al(plane_entry_bytes_rt(m->order, s) * size_t(l.pcap) * size_t(l.pcap ? m->nx * kPlaneSub : 0));
+  l.pover = off;      off += al(plane_entry_bytes_rt(m->order, s) * size_t(l.pcap ? N : 0));
   // max |charge| of every wavefront of the binning pass (one plain store each): max over them x atoms of a plane = the bound that
   // fixes the scale of the fp32 plane spread's fixed-point sums (plane_spread_yz_body)
   l.wmax = off;       off += al(sizeof(float) * size_t(l.pcap ? (N + 63) / 64 : 0));
@@ -214,8 +229,8 @@ struct BinIndex {
   // plane lists (plane spread; pcap == 0: none): live counters int[nx * kPlaneSub + 1] behind the brick counters (zeroed by the forward
   // gather like those), slots per plane, overflow slots
   int* plive = nullptr;
-  int* plist = nullptr;
-  int* pover = nullptr;
+  void* plist = nullptr;  // entries: plane_entry_words<N, T>() reals each, [nx * kPlaneSub lists][pcap]
+  void* pover = nullptr;  // entries of the atoms whose list was full
   int pcap = 0;
   // max |value| per wavefront of the binning pass (float[ceil(N / 64)], rewritten by every pass): see BinsLayout::wmax
   float* wmax = nullptr;
@@ -374,12 +389,6 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     }
     rec[dst] = make_int4(m[0], m[1], m[2], int(i));
     if (qs) qs[dst] = q[i];
-    if (pl_slot >= 0) {  // plane list of m_x (or the plane overflow list: one atomic per atom, normally none)
-      if (pl_slot < bi.pcap)
-        bi.plist[(int64_t(m[0]) * kPlaneSub + pl_key) * bi.pcap + pl_slot] = int(dst);
-      else
-        bi.pover[atomicAdd(&bi.plive[g.nx * kPlaneSub], 1)] = int(dst);
-    }
     if (bi.codes && dst < bi.over_base) bi.codes[dst] = (unsigned char)reach_code<N>(m, g.nx, g.ny, g.nz);
   }
   // The 6N weights of an atom go to its slot, anywhere in the bins: written by the atom's own lane that is 6N four-byte stores
@@ -387,6 +396,40 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
   // group of 6N lanes writes value k of one atom -- contiguous 24N-byte segments, two atoms per instruction at N = 5
   // (1 029 000 atoms: 95 -> ... us for this kernel).
   constexpr int W = wts_stride<N, T>();
+  // the atom's plane-list entry (plane_entry_words): written once the x weights are known
+  auto store_plane_entry = [&](const T (&wx)[N]) __attribute__((always_inline)) {
+    if (!valid || pl_slot < 0) return;
+    constexpr int EW = plane_entry_words<N, T>(), V = 16 / int(sizeof(T));
+    struct alignas(16) Chunk {
+      T e[V];
+    };
+    T* e;
+    if (pl_slot < bi.pcap)  // plane list of m_x (else the plane overflow list: one atomic per atom, normally none)
+      e = (T*)bi.plist + ((int64_t(m[0]) * kPlaneSub + pl_key) * bi.pcap + pl_slot) * EW;
+    else
+      e = (T*)bi.pover + int64_t(atomicAdd(&bi.plive[g.nx * kPlaneSub], 1)) * EW;
+    T v[EW];
+    const int packed = (m[0] << (2 * kPlanePackBits)) | (m[1] << kPlanePackBits) | m[2];
+    if constexpr (sizeof(T) == 4)
+      v[0] = __int_as_float(packed);
+    else
+      v[0] = __longlong_as_double((long long)packed);
+    v[1] = T(x[1]);
+    v[2] = T(x[2]);
+    const T qa = q[i];
+#pragma unroll
+    for (int t = 0; t < N; ++t) v[3 + t] = qa * wx[t];
+#pragma unroll
+    for (int t = 3 + N; t < EW; ++t) v[t] = T(0);
+    Chunk* d = reinterpret_cast<Chunk*>(e);
+#pragma unroll
+    for (int k = 0; k < EW / V; ++k) {
+      Chunk c;
+#pragma unroll
+      for (int u = 0; u < V; ++u) c.e[u] = v[k * V + u];
+      d[k] = c;
+    }
+  };
   // COALESCE is chosen by the launcher for large systems, where the kernel is bound by its store transactions (1 029 000 atoms:
   // 95 -> 45 us); at 32k atoms it is a chain of latencies and the extra LDS round trip costs 1.3 us.  fp64 rows of n >= 5 nodes
   // do not fit 48 KB of LDS and keep the direct stores.
@@ -403,6 +446,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
         mine[d * N + t] = w[t];
         mine[(3 + d) * N + t] = dw[t];
       }
+      if (d == 0 && bi.plive) store_plane_entry(w);
     }
     // (one wave reads what the same wave wrote: no workgroup barrier needed, only the LDS writes to have landed)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -423,6 +467,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     weights_1d<SCHEME, N, true, T>(T(x[1]), wy, dwy);
     weights_1d<SCHEME, N, true, T>(T(x[2]), wz, dwz);
     store_slot_weights<N, T>(wts + dst * W, wx, wy, wz, dwx, dwy, dwz);
+    if (bi.plive) store_plane_entry(wx);
   }
 }
 
@@ -1277,7 +1322,7 @@ static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
   return int(cap);
 }
 
-// what a lane holds of one atom while the previous batch is being scattered
+// what a lane holds of one atom when it scatters it
 template <int N, typename T>
 struct PlaneItem {
   T vx;      // charge * scale * x weight of this plane; 0 for lanes without an atom
@@ -1285,25 +1330,50 @@ struct PlaneItem {
   T wy[N], wz[N];
 };
 
-// the atom in bin slot `slot`, whose stencil row `tt` (uniform: every atom of one plane list has the same) falls on the plane
+// a plane-list entry as loaded (plane_entry_words): what a lane holds of the NEXT batches while the current one is scattered
 template <int N, typename T>
-__device__ __forceinline__ void plane_item_load(PlaneItem<N, T>& it, bool ok, int slot, int tt, const int4* __restrict__ rec,
-                                                const T* __restrict__ wts, const T* __restrict__ qs, T scale) {
-  constexpr int W = wts_stride<N, T>();
-  // (branch-free: lanes without an atom read slot 0 -- always there -- and get a zero value; an if / else that fills the struct
-  // makes the compiler keep it on the stack)
-  const int se = ok ? slot : 0;
-  const int4 r = rec[se];
-  const T* __restrict__ wr = wts + int64_t(se) * W;
-  const T v = qs[se] * scale * wr[tt];
-  it.vx = ok ? v : T(0);
-  it.my = r.y;
-  it.mz = r.z;
+struct PlaneRaw {
+  T w[plane_entry_words<N, T>()];
+};
+
+// entry `idx` of the entry array `base` (lanes without an atom read entry 0 -- always inside the buffer -- and get zero products)
+template <int N, typename T>
+__device__ __forceinline__ void plane_raw_load(PlaneRaw<N, T>& r, bool ok, const T* __restrict__ base, int64_t idx) {
+  constexpr int EW = plane_entry_words<N, T>(), V = 16 / int(sizeof(T));
+  struct alignas(16) Chunk {
+    T e[V];
+  };
+  const Chunk* src = reinterpret_cast<const Chunk*>(base + (ok ? idx : 0) * EW);
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    it.wy[k] = wr[N + k];
-    it.wz[k] = wr[2 * N + k];
+  for (int k = 0; k < EW / V; ++k) {
+    const Chunk c = src[k];
+#pragma unroll
+    for (int u = 0; u < V; ++u) r.w[k * V + u] = c.e[u];
   }
+#pragma unroll
+  for (int t = 3; t < EW; ++t) r.w[t] = ok ? r.w[t] : T(0);
+}
+template <typename T>
+__device__ __forceinline__ int plane_raw_packed(T w0) {
+  if constexpr (sizeof(T) == 4)
+    return __float_as_int(w0);
+  else
+    return int(__double_as_longlong(w0));
+}
+
+// entry -> item of stencil row tt: the y / z weights from their offsets (the same weights_1d the binning pass evaluates for the
+// gather's rows), the product charge * w_x[tt] picked from the entry
+template <int SCHEME, int N, typename T>
+__device__ __forceinline__ void plane_item_make(PlaneItem<N, T>& it, const PlaneRaw<N, T>& r, int tt, T scale) {
+  const int packed = plane_raw_packed(r.w[0]);
+  it.my = (packed >> kPlanePackBits) & ((1 << kPlanePackBits) - 1);
+  it.mz = packed & ((1 << kPlanePackBits) - 1);
+  T qwx[N], unused[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) qwx[t] = r.w[3 + t];
+  it.vx = pick<N, T>(qwx, tt) * scale;
+  weights_1d<SCHEME, N, false, T>(r.w[1], it.wy, unused);
+  weights_1d<SCHEME, N, false, T>(r.w[2], it.wz, unused);
 }
 
 // one atom's N x N points of the plane (natural layout acc[y * nz + z]): the products in the working precision (as the bricks
@@ -1336,7 +1406,7 @@ __device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, con
   }
 }
 
-template <int N, typename T>
+template <int SCHEME, int N, typename T>
 __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, const PlaneArgs<T>& pa, unsigned item,
                                                      char* smem) {
   // item = plane * parts + part: the parts of one plane are neighbours in the launch (same XCD: they read the same bins)
@@ -1344,9 +1414,8 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   const int part = int(item - plane * unsigned(pa.parts));
   const Geom& g = args.g;
   const BinIndex& bins = args.bins;
-  const int4* __restrict__ rec = args.rec;
-  const T* __restrict__ wts = args.wts;
-  const T* __restrict__ qs = args.qs;
+  const T* __restrict__ plist = (const T*)bins.plist;
+  const T* __restrict__ pover = (const T*)bins.pover;
   const int tid = threadIdx.x, nthr = blockDim.x;
   constexpr int s0 = stencil_start<N>();
   MIPME_WG_PHASE(0);
@@ -1439,42 +1508,51 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   const int total = lst[NL];
   const int lo = int(int64_t(total) * part / pa.parts), hi = int(int64_t(total) * (part + 1) / pa.parts);
   const int n_batches = (hi - lo + nthr - 1) / nthr;
-  // this lane's entry of batch b: its stencil row tt and its bin slot (-1: none)
-  auto load_slot = [&](int b, int& tt) __attribute__((always_inline)) -> int {
+  // this lane's entry of batch b: its stencil row tt and the entry's index in the list array (-1: none) -- arithmetic on the
+  // prologue's list lengths, no load: the entries of batches b + 1 and b + 2 are in flight while batch b is scattered
+  auto entry_of = [&](int b, int& tt) __attribute__((always_inline)) -> int64_t {
     const int gidx = lo + b * nthr + tid;
     int l = 0;
     for (int u = 1; u < NL; ++u) l += gidx >= lst[u] ? 1 : 0;
     tt = l / kPlaneSub;
     if (b >= n_batches || gidx >= hi) return -1;
     const int list_id = posmod(x0 - s0 - tt, g.nx) * kPlaneSub + (l % kPlaneSub);
-    return bins.plist[int64_t(list_id) * bins.pcap + (gidx - lst[l])];
+    return int64_t(list_id) * bins.pcap + (gidx - lst[l]);
   };
-  int tt1 = 0, tt2 = 0;
-  int slot1 = load_slot(0, tt1), slot2 = load_slot(1, tt2);
-  PlaneItem<N, T> nxt;
-  if (n_batches > 0) plane_item_load<N, T>(nxt, slot1 >= 0, slot1, tt1, rec, wts, qs, args.scale);
+  int tt0 = 0, tt1 = 0;
+  PlaneRaw<N, T> r0, r1;
+  {
+    const int64_t e0 = entry_of(0, tt0), e1 = entry_of(1, tt1);
+    plane_raw_load<N, T>(r0, e0 >= 0, plist, e0);
+    plane_raw_load<N, T>(r1, e1 >= 0, plist, e1);
+  }
   for (int b = 0; b < n_batches; ++b) {
-    const PlaneItem<N, T> cur = nxt;
-    int tt3 = 0;
-    const int slot3 = load_slot(b + 2, tt3);
-    if (b + 1 < n_batches) plane_item_load<N, T>(nxt, slot2 >= 0, slot2, tt2, rec, wts, qs, args.scale);
+    int tt2 = 0;
+    const int64_t e2 = entry_of(b + 2, tt2);
+    PlaneRaw<N, T> r2;
+    plane_raw_load<N, T>(r2, e2 >= 0, plist, e2);  // (past the last batch: entry 0, never used)
+    PlaneItem<N, T> cur;
+    plane_item_make<SCHEME, N, T>(cur, r0, tt0, args.scale);
     if (cur.vx != T(0)) {
       guard_item(cur);
       plane_item_scatter<N, T>(acc, g, cur, fx_scale);
     }
-    slot2 = slot3;
-    tt2 = tt3;
+    r0 = r1;
+    tt0 = tt1;
+    r1 = r2;
+    tt1 = tt2;
   }
   if (part == 0) {  // the plane overflow list (atoms whose plane list was full: normally none)
     const int oc = bins.plive[g.nx * kPlaneSub];
     for (int i = tid; i < oc; i += nthr) {
-      const int slot = bins.pover[i];
-      int d = x0 - rec[slot].x - s0;
+      PlaneRaw<N, T> r;
+      plane_raw_load<N, T>(r, true, pover, i);
+      int d = x0 - (plane_raw_packed(r.w[0]) >> (2 * kPlanePackBits)) - s0;
       d += d < 0 ? g.nx : 0;
       d -= d >= g.nx ? g.nx : 0;
       if (d < N) {
         PlaneItem<N, T> it;
-        plane_item_load<N, T>(it, true, slot, d, rec, wts, qs, args.scale);
+        plane_item_make<SCHEME, N, T>(it, r, d, args.scale);
         guard_item(it);
         plane_item_scatter<N, T>(acc, g, it, fx_scale);
       }
@@ -1521,15 +1599,15 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   MIPME_WG_PHASE(4);
 }
 
-template <int N, typename T>
+template <int SCHEME, int N, typename T>
 __global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, PlaneArgs<T> pa) {
   MIPME_SKIP_IF_SET(sa.skip);
   extern __shared__ __attribute__((aligned(16))) char smem_plane[];
-  plane_spread_yz_body<N, T>(sa, pa, blockIdx.x, smem_plane);
+  plane_spread_yz_body<SCHEME, N, T>(sa, pa, blockIdx.x, smem_plane);
 }
 
 // planes first, then the row blocks of the pair sum (the planes are few -- nx -- and long: they must start at once)
-template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
+template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
     SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */,
     unsigned n_row_blocks /* of this launch: the first ones (the rest ride on the inverse plane launch, planes_inv_rows_kernel) */) {
@@ -1539,7 +1617,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   if (blockIdx.x < n_pad) {
     if (pa.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned p = xcd_contiguous(blockIdx.x, n_planes);
-    if (p < n_planes) plane_spread_yz_body<N, T>(sa, pa, p, smem_pr);
+    if (p < n_planes) plane_spread_yz_body<SCHEME, N, T>(sa, pa, p, smem_pr);
   } else {
     const unsigned r = xcd_contiguous(blockIdx.x - n_pad, n_row_blocks);
     if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL>(ra, r, smem_pr);
@@ -2134,8 +2212,8 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
   v.idx.codes = (unsigned char*)(b + l.codes);
   v.qs = (void*)(b + l.qs);
   v.idx.pcap = l.pcap;
-  v.idx.plist = l.pcap ? (int*)(b + l.plist) : nullptr;
-  v.idx.pover = l.pcap ? (int*)(b + l.pover) : nullptr;
+  v.idx.plist = l.pcap ? (void*)(b + l.plist) : nullptr;
+  v.idx.pover = l.pcap ? (void*)(b + l.pover) : nullptr;
   v.idx.wmax = l.pcap ? (float*)(b + l.wmax) : nullptr;
   v.idx.n_wmax = l.pcap ? int((N + 63) / 64) : 0;
   v.epart = (double*)(b + l.epart);
@@ -2298,6 +2376,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       const bool compact_s = (job->shift_format & kShiftFormatMask) == kShiftTable32;
 #define MIPME_SPARSE_ROWS(PF, CO, CE) \
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, sparse_spread_rows_kernel<N, T, PF, CO, CE><<<grid, BS, lds_s, st>>>(sa, ra_e, n_spread, pattern)))
+      note_cosched_kernel("sparse_spread_rows_kernel");
       if (cpart && pfast == 1)
         MIPME_SPARSE_ROWS(1, true, true);
       else if (cpart)
@@ -2360,7 +2439,8 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       }
       const unsigned pgrid = pad8(n_planes) + pad8(n_here);
 #define MIPME_PLANE_ROWS(PF, CO, CE) \
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, plane_rows_kernel<N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here)))
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (plane_rows_kernel<S, N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here)))
+      note_cosched_kernel("plane_rows_kernel");
       if (cpart && pfast == 1)
         MIPME_PLANE_ROWS(1, true, true);
       else if (cpart) {
@@ -2392,6 +2472,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const unsigned n_cont = cosched_continuations(fn, lds_k, bg, n_spread, n_rows_blocks, pattern);                            \
     const unsigned n_rp = bg.xcd ? pad8(n_rows_blocks) : n_rows_blocks;                                                        \
     const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), n_rp - n_cont, pattern) : n_spread + n_rp - n_cont;            \
+    note_cosched_kernel(capped ? "spread_rows_capped_kernel" : "spread_rows_kernel");                                          \
     if constexpr (capped)                                                                                                      \
       spread_rows_capped_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);    \
     else                                                                                                                       \
@@ -2415,7 +2496,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   }
   if (pa.hat)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             ((void)S, plane_spread_kernel<N, T><<<unsigned(m->nx) * unsigned(pa.parts), 1024, plane_lds, st>>>(sa, pa)));
+                             (plane_spread_kernel<S, N, T><<<unsigned(m->nx) * unsigned(pa.parts), 1024, plane_lds, st>>>(sa, pa)));
   else if (sparse)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
@@ -2618,7 +2699,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
 // Plane spread for frame batches (round 5): blockIdx.y = frame; the first nx * parts workgroups of a frame are plane workgroups
 // (plane_spread_yz_body: part 0 of frame f into its block of the batched half-complex mesh, the other parts into the plan's part
 // buffers), the rest its row blocks.  `pa` holds the frame-independent fields; frame_stride = complex values per frame.
-template <int N, typename T, int PFAST, bool COMPACT>
+template <int SCHEME, int N, typename T, int PFAST, bool COMPACT>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1) void frames_plane_rows_kernel(const FrameDev<T>* __restrict__ table,
                                                                                                         PlaneArgs<T> pa, int64_t frame_stride) {
   const FrameDev<T>& f = table[blockIdx.y];
@@ -2627,7 +2708,7 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? 6 : 1
   if (blockIdx.x < n_items) {
     pa.hat += int64_t(blockIdx.y) * frame_stride;
     if (pa.hat_more) pa.hat_more += int64_t(blockIdx.y) * frame_stride;
-    plane_spread_yz_body<N, T>(f.spread, pa, blockIdx.x, smem_fp);
+    plane_spread_yz_body<SCHEME, N, T>(f.spread, pa, blockIdx.x, smem_fp);
   } else if (blockIdx.x - n_items < f.n_row_blocks) {
     cosched_row_block<T, PFAST, COMPACT, false>(f.rows, blockIdx.x - n_items, smem_fp);
   }
@@ -2858,6 +2939,7 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
   bool planes = fft_plan_plane_forward_ok_batched(plan);
   for (int k = 0; k < n_frames && planes; ++k) planes = frame_plane_lists(fr[k], dtype_f);
   fft_plan_set_forward_done(plan, false, 1);
+  if (!planes) note_cosched_kernel("frames_spread_rows_kernel");
   if (planes) {
     PlaneArgs<T> pa;
     size_t need = 0;
@@ -2880,7 +2962,8 @@ static int frames_forward_t(mipme_fft_plan* plan, hipStream_t st, int n_frames, 
     const size_t plds = need > rows_lds ? need : rows_lds;
     const unsigned pgrid_x = unsigned(m->nx) * unsigned(pa.parts) + unsigned((max_atoms + rpb - 1) / rpb);
 #define MIPME_FRAMES_PLANES(PF, CO) \
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, frames_plane_rows_kernel<N, T, PF, CO><<<dim3(pgrid_x, F), SPREAD_THREADS, plds, st>>>(tb, pa, Mh)))
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (frames_plane_rows_kernel<S, N, T, PF, CO><<<dim3(pgrid_x, F), SPREAD_THREADS, plds, st>>>(tb, pa, Mh)))
+    note_cosched_kernel("frames_plane_rows_kernel");
     if (pfast == 1 && compact)
       MIPME_FRAMES_PLANES(1, true);
     else if (pfast == 1)
@@ -3554,6 +3637,7 @@ int live_spread(hipStream_t st, const mipme_mesh_t* m, int64_t N, const void* re
   const unsigned pattern = brick_pattern(bg, n_spread, n_row_blocks, sizeof(T) == 4);
   const unsigned grid = live_home_blocks(N, bg.xcd) +
                         (bg.xcd ? cosched_grid(pad8(n_spread), pad8(n_row_blocks), pattern) : n_spread + n_row_blocks);
+  note_cosched_kernel("live_spread_rows_kernel");
   if (cpart && pfast == 1)
     MIPME_DISPATCH_ORDER(m->order, (live_spread_rows_kernel<N, T, 1, true><<<grid, SPREAD_THREADS, lds, st>>>(sa, ra, n_spread, pattern)));
   else if (cpart) {

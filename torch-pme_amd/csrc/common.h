@@ -12,6 +12,9 @@
 namespace mipme {
 
 void set_error(const char* fmt, ...);
+// name (without template arguments) of the last co-scheduled spread + pair-sum kernel this thread launched or captured
+// (mipme_last_cosched_kernel: what a benchmark labels its dominant launch with)
+void note_cosched_kernel(const char* name);
 
 #define MIPME_CHECK_HIP(expr)                                                                 \
   do {                                                                                        \

@@ -336,7 +336,7 @@ __device__ __forceinline__ void sr_fused_rows_body(const FusedRowsArgs<T>& args,
       }
       if constexpr (CAN_WRITE_D) {
         if (dist_out && role_i && ok[u]) {
-          const T d2c = d2 > T(1e-30) ? d2 : T(1e-30);
+          const T d2c = d2 < T(1e-30) ? T(1e-30) : d2;
           dist_out[pair_base + e] = PFAST > 0 ? d2c * rs_rsqrt(d2c) : fsqrt(d2);
         }
       }

@@ -379,7 +379,7 @@ __device__ __forceinline__ T lower_gamma_series(int p, T x) {
 template <typename T, bool DERIV>
 __device__ __forceinline__ void sr_eval(const SRPot& s, T d, T& v, T& dv) {
   const T pref = T(s.pref);
-  const T dc = d > T(1e-15) ? d : T(1e-15);
+  const T dc = d < T(1e-15) ? T(1e-15) : d;  // (this way round a NaN distance stays NaN: the reference's sr_from_dist propagates it)
   const T inv = T(1) / dc;
   const T invp = powi(inv, s.p);
   T fc = T(0), dfc = T(0);
@@ -449,7 +449,7 @@ __device__ __forceinline__ double rs_erfc(double y, double e, const double* c) {
 
 template <int P, bool DERIV, typename T>
 __device__ __forceinline__ void fast_rs_eval(T inv_2s2, T c1, T pref, T d2, T& v, T& dvd, const double* cheb) {
-  d2 = d2 > T(1e-30) ? d2 : T(1e-30);
+  d2 = d2 < T(1e-30) ? T(1e-30) : d2;  // (NaN stays NaN)
   const T inv = rs_rsqrt(d2);
   const T inv2 = inv * inv;
   const T x = d2 * inv_2s2;
