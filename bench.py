@@ -88,6 +88,9 @@ def parse_args(argv=None):
                          "whole K x frames log is all-gathered once per timed region; per-step: a collective after every "
                          "evaluation, on the compute stream; pipelined: the same, overlapped with the next evaluation; final: "
                          "only the LAST step's energies, once; in-graph: the per-step collective captured into the step's graph")
+    ap.add_argument("--sweep-orders", action="store_true",
+                    help="instead of the bench line: the order / scheme sweep of the graph-replayed step on the headline box "
+                         "(tools/r06/order_sweep.py: P3M 3-5, Lagrange 4, 6, 7 x fp32 / fp64, ms per step + scratch per kernel)")
     ap.add_argument("--no-exchange-sweep", action="store_true",
                     help="with several ranks: skip the one timed block per OTHER exchange protocol (parallelism.other_exchange_modes_ms_per_step)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (the median block is the reported value)")
@@ -936,6 +939,11 @@ def list_refresh_timing(frame, frozen_list_ms: float):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.sweep_orders:
+        sys.path.insert(0, os.path.join(ROOT, "tools", "r06"))
+        import order_sweep
+
+        return order_sweep.main(as_json=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args, argv))
 
