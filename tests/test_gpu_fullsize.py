@@ -229,15 +229,23 @@ def test_fullsize_forces(cfg, request):
     assert rel(F32.double(), F) < 1e-4
 
 
-def test_cfg5_energy_forces(dispersion):
-    """262 144 atoms, 39 M pairs, 128^3, 1/r^6: fp32 energy + forces against the same path in fp64."""
+def test_cfg5_energy_forces(dispersion, golden_dir):
+    """262 144 atoms, 39 M pairs, 128^3, 1/r^6: fp32 and fp64 energy + forces against the REFERENCE'S OWN fp64 evaluation of this box
+    (ref_fullsize.npz, round 6; until then the fp32 path was compared with the fp64 path of the same library), the fp32 path against
+    the fp64 path (all atoms), and the general-gradient route against the energy route.  fp32 force tolerance 8e-5 = five times the
+    measured 1.58e-5 (the reference's own fp32 run: 1.59e-5)."""
     w = dispersion
+    z = np.load(os.path.join(golden_dir, "ref_fullsize.npz"))
+    Er, sample, Fr = float(z["dispersion_f64_energy"]), z["dispersion_sample"], torch.tensor(z["dispersion_f64_force_sample"])
+    assert int(z["dispersion_n_pairs"]) == w.n_pairs
     E64, F64 = Box(w, torch.float64).energy_forces()
     E32, F32 = Box(w, torch.float32).energy_forces()
+    assert abs(E64 - Er) < 1e-11 * abs(Er) and rel(F64.cpu()[sample], Fr) < 1e-10
+    assert abs(E32 - Er) < 1e-5 * abs(Er) and rel(F32.double().cpu()[sample], Fr) < 8e-5
     assert abs(E32 - E64) < 1e-5 * abs(E64)
-    assert rel(F32.double(), F64) < 1e-4
+    assert rel(F32.double(), F64) < 8e-5
     Eg, Fg = Box(w, torch.float32).energy_forces(general=True)
-    assert abs(Eg - E32) < 2e-6 * abs(E32) and rel(Fg, F32) < 1e-4
+    assert abs(Eg - E32) < 2e-6 * abs(E32) and rel(Fg, F32) < 8e-5
 
 
 @pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
@@ -277,16 +285,19 @@ def test_fullsize_against_committed_oracle(cfg, request, golden_dir):
             assert abs(float((r * F).sum()) - float(g["force_dot"])) <= tol_c * scale, (cfg, dtype, name)
 
 
-@pytest.mark.parametrize("cfg", ["ionic", "water"])
+@pytest.mark.parametrize("cfg", ["ionic", "water", "dispersion"])
 def test_fullsize_against_the_reference_itself(cfg, request, golden_dir):
-    """BASELINE.json configs[1] (8 000 ions, P3M n = 4, 32^3) and configs[2] (the 31 944-atom water box, P3M n = 5, 64^3) against
+    """BASELINE.json configs[1] (8 000 ions, P3M n = 4, 32^3), configs[2] (the 31 944-atom water box, P3M n = 5, 64^3) and -- round 6
+    -- configs[4] (262 144 atoms, InversePowerLawPotential(6), P3M n = 5, 128^3: potentials/inversepowerlaw.py:55-169) against
     the REFERENCE'S OWN evaluation of the same box (tests/golden/ref_fullsize.npz, made by importing torchpme in the build
     container: tests/golden/make_reference_fullsize.py) -- the whole first-order contract of one energy step: E, F (256 sampled
     atoms + the two whole-array checksums), dE/dq (sample + checksum), dE/dcell, from the graph-replayed step and the eager
     calculators; and the three gradients of the tuner's V.sum() protocol.  fp64 against the reference's fp64 numbers at 1e-10;
     fp32 against the same fp64 numbers at five times the errors measured in round 4 (energy 1e-5 = north_star's tolerance,
     forces rel-L2 2e-5, dE/dq 2e-5, dE/dcell 6e-5) -- the reference's own fp32 run differs from its fp64 run by 7e-6 in the
-    sampled forces and 1.6e-5 in dE/dcell on the water box."""
+    sampled forces and 1.6e-5 in dE/dcell on the water box.  cfg5's fp32 tolerances are five times the errors measured in round 6
+    (profiles/r06_c_fullsize_errors.txt: forces 1.58e-5 -- the reference's OWN fp32 run is 1.59e-5 from its fp64 run there --, dE/dq
+    1.35e-5): 8e-5 / 7e-5."""
     w = request.getfixturevalue(cfg)
     z = np.load(os.path.join(golden_dir, "ref_fullsize.npz"))
     g = {k[len(cfg) + 5:]: z[k] for k in z.files if k.startswith(cfg + "_f64_")}
@@ -298,7 +309,8 @@ def test_fullsize_against_the_reference_itself(cfg, request, golden_dir):
     s_vec = rng.normal(size=(w.n_atoms, 1))
     relmax = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())  # noqa: E731
     rell2 = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))  # noqa: E731
-    for dtype, tol_e, tol_f, tol_q, tol_c in ((torch.float64, 1e-11, 1e-10, 1e-10, 1e-10), (torch.float32, 1e-5, 2e-5, 2e-5, 6e-5)):
+    f32 = (torch.float32, 1e-5, 8e-5, 7e-5, 6e-5) if cfg == "dispersion" else (torch.float32, 1e-5, 2e-5, 2e-5, 6e-5)
+    for dtype, tol_e, tol_f, tol_q, tol_c in ((torch.float64, 1e-11, 1e-10, 1e-10, 1e-10), f32):
         box = Box(w, dtype)
         results = {}
         step = tpa.GraphedEnergyForces(box.calc, box.q, box.cell, box.pos, box.pairs, box.shifts, charge_gradient=True,
