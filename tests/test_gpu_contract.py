@@ -408,8 +408,8 @@ def test_compiled_front_end_serves_charges_and_cell(scheme, order, expo, tri, mo
 
 
 def test_compiled_front_end_contract_with_the_polled_verdict():
-    """The verdict of the energy-mode test read on the host (MIPME_FRONT_POLL=1; the default when charges / cell want
-    gradients) or acted on by the device (MIPME_FRONT_SELECT=always): same numbers."""
+    """The verdict of the energy-mode test read on the host (set_device_select(0); the default when charges / cell want
+    gradients) or acted on by the device (set_device_select(2)): same numbers."""
     from torchpme_amd import _front
 
     mod = _front.module()

@@ -18,12 +18,14 @@ _mod = None
 _tried = False
 
 
+#: how the C++ calculator node decides the energy mode (front.cpp, g_device_select): 1 the default mix (polled when charges / cell
+#: want gradients, on the device for positions only), 0 always polled, 2 always on the device -- ``module().set_device_select(k)``
+#: switches a loaded module (tests/test_gpu_contract.py runs all three)
+SELECT_MODE = 1
+
+
 def select_mode() -> int:
-    """How the C++ calculator node decides the energy mode (front.cpp, g_device_select): 0 polled (``MIPME_FRONT_POLL=1``), 2 on
-    the device for every request (``MIPME_FRONT_SELECT=always``), 1 the default mix."""
-    if os.environ.get("MIPME_FRONT_POLL", "0") != "0":
-        return 0
-    return 2 if os.environ.get("MIPME_FRONT_SELECT", "") == "always" else 1
+    return SELECT_MODE
 
 
 def module():

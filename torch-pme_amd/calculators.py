@@ -23,7 +23,7 @@ import os
 
 #: a NEW cell tensor is first assumed to hold the values of the previous one (verified on the device, see
 #: PMECalculator._kspace_setup); "0": always copy it to the host first, as the reference does
-SPECULATE_CELL = os.environ.get("MIPME_SPECULATE_CELL", "1") != "0"
+SPECULATE_CELL = True
 
 
 class Calculator(torch.nn.Module):
@@ -429,7 +429,7 @@ class PMECalculator(Calculator):
             plan = _lib.get_plan(positions.device, positions.dtype, geom.ns, 1, geom.plan_store)
             if (p_eff in (1, 6) and pot_desc.smearing > 0 and pot_desc.exclusion_radius <= 0 and plan.xfused and ops.XFUSED
                     and ops.MESH_MODE == "bricks" and ops.PAIR_MODE == "rows" and ops.COSCHEDULE and ops.ENERGY_FAST_PATH
-                    and ops.ENERGY_DETECT and ops.COMPACT_ENTRIES and ops.FUSE_DISTANCES and not ops.OVERLAP):
+                    and ops.ENERGY_DETECT and ops.COMPACT_ENTRIES and ops.FUSE_DISTANCES):
                 # (a cell that requires a gradient: the derivative table of G for the gather tail's dE/dcell (mipme.h,
                 # out_grad_cell); without it the C++ side declines such calls)
                 deriv = None

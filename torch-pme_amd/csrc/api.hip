@@ -212,10 +212,7 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
   const int64_t Mh = int64_t(m->nx) * m->ny * (m->nz / 2 + 1);
   double self_c, bg_c;
   correction_terms(pot, self_c, bg_c);
-  fft_plan_set_inverse_corunner(plan, nullptr, nullptr);  // (a failed call must not leave one behind)
   fft_plan_set_forward_done(plan, false, 1);               // (nor the plane spread's "forward planes done": set below, consumed by convolve_xfused)
-  GatherTailHost tail_late{};
-  int64_t rows_tail_first = -1;  // first row of the pair-sum blocks that ride on the inverse plane launch (bricks.hip), -1: none
   // the plan's brick counters are zero here; the binning pass fills them and the gather -- the last consumer -- zeroes them
   // again (no memset launch per call).  If anything in between fails they are cleared explicitly, so that a failed call does
   // not poison the next one.
@@ -255,15 +252,11 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
           ph.more_stride = Mh * m->n_channels;
           if (!ph.hat_more) ph.parts = 1;
         }
-        // the fused convolution follows on this plan: its inverse plane launch can take the last row blocks of the pair sum
-        // (only with the energy tail's bookkeeping, or without any: the late blocks' partial sums need the gather's tail)
-        if (!rho_hat && !out_grad_cell && !out_rho_hat && !cell_partials) ph.plan = plan;
       }
       for (int r = 0; r < reps; ++r)
         if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr,
                                    out_grad_cell ? cw.cwave : nullptr, &ph, &planes))) return rc;
       fft_plan_set_forward_done(plan, planes, ph.parts);
-      rows_tail_first = ph.rows_tail_first;
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",
@@ -278,14 +271,6 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
     // nobody needs rfftn(rho) itself: (y,z) hipFFT planes + one kernel for x-FFT * G * inverse x-FFT
     int64_t n_sr_part = 0;
     const void* sr_part = tail ? bins_epart(m, N, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64, bins, &n_sr_part) : nullptr;
-    if (tail && rows_tail_first >= 0) {  // the late row blocks' partial sums do not exist yet when the x stage runs
-      const int64_t early = rows_tail_first / (64 / 16);  // (waves: 4 rows of 16 lanes each)
-      tail_late = *tail;
-      tail_late.sr2_first = early;
-      tail_late.sr2_count = n_sr_part - early;
-      tail = &tail_late;
-      n_sr_part = early;
-    }
     ConvCell cc{};
     if (out_grad_cell) cc = ConvCell{G_deriv, cw.cwave, cw.n_waves, cw.wbuf, cw.rows, int(cw.n_riders), nullptr, nullptr, nullptr, nullptr};
     cc.rho_hat_out = out_rho_hat;

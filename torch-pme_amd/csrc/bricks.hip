@@ -203,7 +203,6 @@ static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype
   // fixes the scale of the fp32 plane spread's fixed-point sums (plane_spread_yz_body)
   l.wmax = off;       off += al(sizeof(float) * size_t(l.pcap ? (N + 63) / 64 : 0));
   // energy partial sums of the co-scheduled pair sum: 2 doubles per wave of its row workgroups (FusedRowsArgs::epart)
-  // (an EVEN number of 32-row blocks: the 64-row blocks of planes_inv_rows_kernel write the slots of both of their halves)
   l.epart = off; off += al(2 * sizeof(double) * kSpreadWaves * (((size_t(N) + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock + 1) & ~size_t(1)));
   l.det = off;
   l.det_sort_bytes = 0;
@@ -1064,39 +1063,6 @@ static inline unsigned brick_pattern(const BrickGeom& bg, unsigned n_spread, uns
   return pattern;
 }
 
-// Workgroups of `fn` (SPREAD_THREADS threads, `lds` bytes of dynamic LDS) the device holds at once; cached per kernel and LDS size.
-static unsigned resident_workgroups(const void* fn, size_t lds) {
-  static std::map<std::pair<const void*, size_t>, unsigned> cache;
-  const auto key = std::make_pair(fn, lds);
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
-  int per_cu = 0, dev = 0, cus = 0;
-  unsigned slots = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SPREAD_THREADS, lds) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-    slots = unsigned(per_cu) * unsigned(cus);
-  else
-    (void)hipGetLastError();
-  cache[key] = slots;
-  return slots;
-}
-// How many brick workgroups of a bricks-first launch continue with a row block (spread_rows_kernel): as many as it takes to make
-// the launch ONE generation -- n_spread + n_row_blocks - resident slots, at most one per brick, a multiple of 8 (the XCD mapping);
-// none when everything is resident anyway, when the launch is many generations whatever is done (interleaved block order:
-// pattern > 0), or with MIPME_BRICK_CONTINUE=0.
-static unsigned cosched_continuations(const void* fn, size_t lds, const BrickGeom& bg, unsigned n_spread, unsigned n_row_blocks,
-                                      unsigned pattern) {
-  static const bool on = env_flag("MIPME_BRICK_CONTINUE", false);  // measured SLOWER (cfg3 launch 22.2 -> 25.1 us, profiles/r05_experiments.txt item 5): opt-in
-  if (!on || pattern != 0 || n_spread == 0) return 0;
-  const unsigned slots = resident_workgroups(fn, lds);
-  const unsigned nb = bg.xcd ? pad8(n_spread) : n_spread, nr = bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
-  if (slots == 0 || nb + nr <= slots || nb >= slots) return 0;
-  unsigned k = nb + nr - slots;
-  k = k > nb ? nb : k;
-  k = k > nr ? nr : k;
-  return bg.xcd ? (k & ~7u) : k;
-}
-
 // the row workgroup of a co-scheduled launch (shared by spread_rows_kernel and plane_rows_kernel)
 template <typename T, int PFAST, bool COMPACT, bool CELL, int BS = SPREAD_THREADS>
 __device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, unsigned r, char* smem_rows) {
@@ -1121,34 +1087,21 @@ __device__ __forceinline__ void cosched_row_block(const FusedRowsArgs<T>& ra, un
   }
 }
 
-// n_cont (pattern 0 only): the first n_cont brick workgroups CONTINUE with a row block when their brick is done -- the row
-// blocks of the last n_cont row slots, which are then not launched as workgroups of their own.  Round 5: the launch was bound
-// by its SECOND GENERATION of row workgroups (cfg3: 512 bricks + 999 row blocks on 1 024 resident slots; the 487 row blocks that
-// find no slot start when bricks retire, 8-11 us into the launch, and live 9-10 us); with the continuation the whole launch is
-// one generation of 1 024 workgroups and nobody waits for a dispatch.
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL>
 __device__ __forceinline__ void spread_rows_body(const SpreadArgs<T>& sa, const FusedRowsArgs<T>& ra, unsigned n_spread,
-                                                 unsigned pattern, unsigned n_cont) {
+                                                 unsigned pattern) {
   MIPME_WG_STAMP(0);
   // n_spread bricks (0: a rows-only launch) and the row blocks; both through the XCD-contiguous mapping when sa.bg.xcd
   const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
   const unsigned n_row_blocks = unsigned((ra.N + kRowsPerSpreadBlock - 1) / kRowsPerSpreadBlock);
   const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
-  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad - n_cont, pattern);
+  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad, pattern);
   extern __shared__ __attribute__((aligned(16))) char smem_rows[];
-  unsigned row_slot = ~0u;
   if (cs.brick) {
     const unsigned b = brick_of(sa.bg, cs.slot);
     if (cs.slot < n_pad && b < n_spread) spread_brick_body<N, T>(sa, b);
-    if (cs.slot < n_cont) {  // (uniform) the staging region becomes the row block's tables
-      __syncthreads();
-      row_slot = n_rows_pad - n_cont + cs.slot;  // same residue mod 8 as this workgroup: the XCD-contiguous row mapping holds
-    }
-  } else if (cs.slot < n_rows_pad - n_cont) {
-    row_slot = cs.slot;
-  }
-  if (row_slot != ~0u) {
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(row_slot, n_row_blocks) : row_slot;
+  } else if (cs.slot < n_rows_pad) {
+    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
     // row workgroups keep their shift table in the launch's dynamic LDS (the spread's staging area, which they do not use)
     if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL>(ra, r, smem_rows);
   }
@@ -1160,8 +1113,8 @@ __device__ __forceinline__ void spread_rows_body(const SpreadArgs<T>& sa, const 
 
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void spread_rows_kernel(
-    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern, unsigned n_cont) {
-  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern, n_cont);
+    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern) {
+  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern);
 }
 // ... the same kernel held to 80 scalar registers (MIPME_SGPR_CAP), for the instantiations whose VECTOR registers admit four
 // workgroups per CU and that take the cap without spilling -- spread_rows_sgpr_capped() names them.  Left to itself the compiler
@@ -1169,8 +1122,8 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
 // launch 180 -> 169 us; cfg3 on the bricks 0.0631 -> 0.0624 ms (profiles/r05_experiments.txt item 8).
 template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) MIPME_SGPR_CAP void spread_rows_capped_kernel(
-    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern, unsigned n_cont) {
-  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern, n_cont);
+    SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread, unsigned pattern) {
+  spread_rows_body<N, T, PFAST, COMPACT, CELL>(sa, ra, n_spread, pattern);
 }
 template <int N, typename T, bool CELL>
 constexpr bool spread_rows_sgpr_capped() {
@@ -1179,28 +1132,6 @@ constexpr bool spread_rows_sgpr_capped() {
 #else
   return sizeof(T) == 4 && N == 5 && !CELL;  // (N = 4 fp32 and every fp64 instantiation answer the cap with scratch or more VGPRs)
 #endif
-}
-
-// Sparse bricks (256^3 meshes at water density: 32 768 bricks of ~16 atoms) co-scheduled with the pair sum, round 5: 128-thread
-// workgroups for BOTH kinds -- quarter-size bricks (spread_brick_body<.., 128>) and row blocks of 8 rows --, interleaved in the
-// block order (one brick per `pattern` row blocks and XCD: the launch is many generations anyway).  Until now the sparse spread
-// (a chain of memory round trips, 130 us for 526 848 atoms) and the VALU-bound pair sum (253 us) ran one after the other.
-template <int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS_SPARSE) void sparse_spread_rows_kernel(SpreadArgs<T> sa, FusedRowsArgs<T> ra, unsigned n_spread,
-                                                                                 unsigned pattern) {
-  constexpr int BS = SPREAD_THREADS_SPARSE;
-  const unsigned n_pad = sa.bg.xcd ? pad8(n_spread) : n_spread;
-  const unsigned n_row_blocks = unsigned((ra.N + BS / kRowLanes - 1) / (BS / kRowLanes));
-  const unsigned n_rows_pad = sa.bg.xcd ? pad8(n_row_blocks) : n_row_blocks;
-  const CoSlot cs = cosched_slot(blockIdx.x, n_pad, n_rows_pad, pattern);
-  extern __shared__ __attribute__((aligned(16))) char smem_sp[];
-  if (cs.brick) {
-    const unsigned b = brick_of(sa.bg, cs.slot);
-    if (cs.slot < n_pad && b < n_spread) spread_brick_body<N, T, BS>(sa, b);
-  } else if (cs.slot < n_rows_pad) {
-    const unsigned r = sa.bg.xcd ? xcd_contiguous(cs.slot, n_row_blocks) : cs.slot;
-    if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL, BS>(ra, r, smem_sp);
-  }
 }
 
 // The pair sum alone (sparse-brick path: the bricks ran in a launch of their own): 256-thread workgroups with nothing but the
@@ -1272,9 +1203,6 @@ struct PlaneArgs {
   int parts = 1;
   Cplx<T>* hat_more = nullptr;
   int64_t more_stride = 0;
-  // co-scheduled launches: the plane workgroups raise their waves' issue priority over the row blocks' they share SIMDs with
-  // (the planes are few and long -- the launch waits for them; MIPME_PLANE_PRIO, 0: off)
-  int prio = 0;
 };
 
 // LDS of a launch with planes: co-scheduled with the row blocks, four workgroups per CU must fit 160 KB (and the rows need their
@@ -1610,12 +1538,11 @@ __global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, Pl
 template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
 __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
     SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */,
-    unsigned n_row_blocks /* of this launch: the first ones (the rest ride on the inverse plane launch, planes_inv_rows_kernel) */) {
+    unsigned n_row_blocks) {
   MIPME_WG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_pr[];
   const unsigned n_pad = pad8(n_planes);
   if (blockIdx.x < n_pad) {
-    if (pa.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned p = xcd_contiguous(blockIdx.x, n_planes);
     if (p < n_planes) plane_spread_yz_body<SCHEME, N, T>(sa, pa, p, smem_pr);
   } else {
@@ -1626,81 +1553,6 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   __syncthreads();
 #endif
   MIPME_WG_STAMP(1);
-}
-
-// ---- the last row blocks of the pair sum behind the INVERSE (y,z) planes of the convolution ----------------------------------------
-// The co-scheduled forward launch is bound by whatever finishes last: its plane workgroups (~19 us with the chip full) and the
-// row blocks that find no slot in its first generation (cfg3: 128 planes + 999 row blocks on 1 024 slots).  The convolution's
-// inverse plane launch, two launches later, is nx workgroups of 1024 threads on 256 CUs for ~7 us -- three quarters of the
-// chip idle at 64^3.  The LAST `n_tail` 64-row blocks of the pair sum run THERE (rows depend on the binning pass only, and
-// their consumer is the gather that follows the inverse planes): kfilter.hip's convolve_xfused hands its inverse plane launch
-// to the co-runner registered here (common.h InverseCoRunner), which starts ONE kernel -- planes first, row blocks of 1024
-// threads behind them (two 32-row halves of the 512-thread blocks' layout: same per-wave partial-sum slots).
-// MIPME_ROWS_TAIL = number of such blocks (default: see rows_tail_blocks).
-template <typename T>
-struct YzInverseDev {
-  int ny, nz, logny, loglz;
-  Cplx<T>* hat;
-  T* real_out;
-  unsigned n_planes;
-  const int* skip;
-};
-
-template <typename T, int PFAST, bool COMPACT>
-__global__ __launch_bounds__(1024) void planes_inv_rows_kernel(YzInverseDev<T> yz, FusedRowsArgs<T> ra, unsigned first_block) {
-  extern __shared__ __attribute__((aligned(16))) char smem_ir[];
-  if (blockIdx.x < yz.n_planes) {
-    MIPME_SKIP_IF_SET(yz.skip);
-    __builtin_amdgcn_s_setprio(3);
-    yz_plane_body<T, true, true>(yz.ny, yz.nz, yz.logny, yz.loglz, nullptr, yz.hat, yz.real_out, blockIdx.x, smem_ir);
-  } else {
-    cosched_row_block<T, PFAST, COMPACT, false, 1024>(ra, first_block + (blockIdx.x - yz.n_planes), smem_ir);
-  }
-}
-
-// what the co-runner needs between spread_bricks (which registers it) and convolve_xfused (which calls it): both happen inside
-// ONE host call (api.hip kspace_forward_t), on one thread
-template <typename T>
-struct RowsTailCtx {
-  FusedRowsArgs<T> ra;
-  unsigned first_block = 0, n_blocks = 0;
-  int pfast = 1;
-  bool compact = true;
-};
-template <typename T>
-static RowsTailCtx<T>& rows_tail_ctx() {
-  static thread_local RowsTailCtx<T> ctx;
-  return ctx;
-}
-
-template <typename T>
-static int rows_tail_launch(void* ctx_, hipStream_t st, const YzInverseLaunch* L) {
-  const RowsTailCtx<T>& c = *static_cast<const RowsTailCtx<T>*>(ctx_);
-  MIPME_REQUIRE(L->threads == 1024, "the row tail rides on 1024-thread plane launches");
-  YzInverseDev<T> yz{L->ny, L->nz, L->logny, L->loglz, (Cplx<T>*)L->hat, (T*)L->real_out, L->n_planes, L->skip};
-  const size_t rows_lds = sizeof(T) == 4 ? sizeof(AtomRecord<T>) * size_t(kShiftTableSize) : kRowsF64LdsBytes;
-  const size_t lds = L->lds > rows_lds ? L->lds : rows_lds;
-  const unsigned grid = L->n_planes + c.n_blocks;
-  if (c.pfast == 1 && c.compact)
-    planes_inv_rows_kernel<T, 1, true><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
-  else if (c.pfast == 1)
-    planes_inv_rows_kernel<T, 1, false><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
-  else if (c.compact)
-    planes_inv_rows_kernel<T, 6, true><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
-  else
-    planes_inv_rows_kernel<T, 6, false><<<grid, 1024, lds, st>>>(yz, c.ra, c.first_block);
-  MIPME_LAUNCH_CHECK();
-  return MIPME_OK;
-}
-
-// How many 64-row blocks of the pair sum leave the co-scheduled forward launch for the inverse plane launch: MIPME_ROWS_TAIL
-// (0: none).  Default: what does not fit the forward launch's first generation of workgroups, at least ..., at most a quarter.
-static unsigned rows_tail_blocks(unsigned n_plane_wgs, unsigned n_row_blocks_512) {
-  static const int env = [] { const char* e = getenv("MIPME_ROWS_TAIL"); return e ? atoi(e) : 0; }();
-  if (env <= 0) return 0;
-  unsigned k = unsigned(env);
-  const unsigned most = n_row_blocks_512 / 2 / 2;  // (in 1024-thread blocks; at most half of the rows)
-  return k > most ? most : k;
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -1770,9 +1622,6 @@ struct GatherTail {
   const double* epart_sr;  // [2 * n_sr]
   const double* epart_k;   // [n_k]
   int n_sr, n_k;
-  // per-wave partial sums of row blocks that finished after the x stage's pre-reduction (planes_inv_rows_kernel): added here
-  const double* epart_sr2 = nullptr;  // [2 * n_sr2]
-  int n_sr2 = 0;
   // the rest of the autograd contract of E = sum q V (nullable): s dE/dq_a = 2 s V_a (V is a symmetric bilinear form of the
   // charges), and per brick the nine sums  R[c][e] = sum_a r_{a,c} (s q_a field_{a,e})  of the cell gradient's atom part
   T* grad_q;
@@ -1821,10 +1670,6 @@ __device__ __forceinline__ void tail_energy(const GatherTail<T>& tail, const T* 
     v[1] += tail.epart_sr[2 * i + 1];
   }
   for (int i = threadIdx.x; i < tail.n_k; i += THREADS) v[2] += tail.epart_k[i];
-  for (int i = threadIdx.x; i < tail.n_sr2; i += THREADS) {
-    v[0] += tail.epart_sr2[2 * i];
-    v[1] += tail.epart_sr2[2 * i + 1];
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -2326,8 +2171,6 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     pa.parts = (ph->parts > 1 && ph->hat_more) ? ph->parts : 1;
     pa.hat_more = (Cplx<T>*)ph->hat_more;
     pa.more_stride = ph->more_stride;
-    static const int prio_env = [] { const char* e = getenv("MIPME_PLANE_PRIO"); return e ? atoi(e) : 0; }();
-    pa.prio = job ? prio_env : 0;
     while ((1 << pa.logny) < m->ny) ++pa.logny;
     while ((1 << pa.loglz) < m->nz / 2) ++pa.loglz;
     // (the row blocks of a co-scheduled launch keep their shift / erfcx tables in the same dynamic region)
@@ -2359,40 +2202,6 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     const unsigned n_rows_blocks = unsigned((job->n_atoms + rows_per_block - 1) / rows_per_block);
     const unsigned n_spread = unsigned(bg.nb);
     const size_t lds_k = lds;
-    static const bool sparse_cosched = env_flag("MIPME_SPARSE_COSCHED", false);  // measured: no gain (526 848 atoms 0.781-0.787 -> 0.789-0.791 ms, 1 029 000 atoms 1.084-1.092 -> 1.118-1.121 ms; r05_experiments.txt item 6): opt-in
-    if (sparse && sparse_cosched) {  // quarter-size bricks and 8-row blocks in ONE launch (sparse_spread_rows_kernel)
-      constexpr int BS = SPREAD_THREADS_SPARSE;
-      const unsigned nrb = unsigned((job->n_atoms + BS / kRowLanes - 1) / (BS / kRowLanes));
-      const unsigned nbp = bg.xcd ? pad8(n_spread) : n_spread, nrp = bg.xcd ? pad8(nrb) : nrb;
-      unsigned pattern = 0;
-      if (bg.xcd) {  // one brick per a row blocks and XCD, a = the ratio of the counts (at least 1)
-        const unsigned a = unsigned(double(nrp) / double(nbp) + 0.5);
-        pattern = a < 1 ? 1 : a;
-      }
-      const unsigned grid = bg.xcd ? cosched_grid(nbp, nrp, pattern) : n_spread + nrb;
-      // the row blocks keep their shift (and erfcx) tables where the bricks stage their survivors
-      const size_t rows_lds = sizeof(T) == 4 ? sizeof(AtomRecord<T>) * size_t(kShiftTableSize) : kRowsF64LdsBytes;
-      const size_t lds_s = lds > rows_lds ? lds : rows_lds;
-      const bool compact_s = (job->shift_format & kShiftFormatMask) == kShiftTable32;
-#define MIPME_SPARSE_ROWS(PF, CO, CE) \
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, sparse_spread_rows_kernel<N, T, PF, CO, CE><<<grid, BS, lds_s, st>>>(sa, ra_e, n_spread, pattern)))
-      note_cosched_kernel("sparse_spread_rows_kernel");
-      if (cpart && pfast == 1)
-        MIPME_SPARSE_ROWS(1, true, true);
-      else if (cpart)
-        MIPME_SPARSE_ROWS(6, true, true);
-      else if (pfast == 1 && compact_s)
-        MIPME_SPARSE_ROWS(1, true, false);
-      else if (pfast == 1)
-        MIPME_SPARSE_ROWS(1, false, false);
-      else if (compact_s)
-        MIPME_SPARSE_ROWS(6, true, false);
-      else
-        MIPME_SPARSE_ROWS(6, false, false);
-#undef MIPME_SPARSE_ROWS
-      MIPME_LAUNCH_CHECK();
-      return MIPME_OK;
-    }
     if (sparse) {  // the bricks first, by themselves; then the pair sum in a launch of its own (rows_only_kernel)
       MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                                ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));
@@ -2418,25 +2227,7 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     if (pa.hat) {  // planes + row blocks
       const unsigned n_planes = unsigned(m->nx) * unsigned(pa.parts);
       const bool compact_p = (job->shift_format & kShiftFormatMask) == kShiftTable32;
-      // the last row blocks ride on the convolution's inverse plane launch (planes_inv_rows_kernel)
-      unsigned n_here = n_rows_blocks;
-      if (ph->plan) {
-        fft_plan_set_inverse_corunner(ph->plan, nullptr, nullptr);
-        const bool body_ok = !cpart && !job->dist_out && (pfast == 1 || pfast == 6) && MIPME_ROW_LANES == 16 && compact_p;
-        const unsigned n_tail = (body_ok && fft_plan_inverse_corun_ok(ph->plan)) ? rows_tail_blocks(n_planes, n_rows_blocks) : 0u;
-        if (n_tail > 0) {
-          const unsigned n1024 = (n_rows_blocks + 1) / 2;  // 64-row blocks in all
-          RowsTailCtx<T>& c = rows_tail_ctx<T>();
-          c.ra = ra_e;
-          c.n_blocks = n_tail;
-          c.first_block = n1024 - n_tail;
-          c.pfast = pfast;
-          c.compact = compact_p;
-          n_here = 2 * c.first_block;
-          ph->rows_tail_first = int64_t(c.first_block) * 64;
-          fft_plan_set_inverse_corunner(ph->plan, &rows_tail_launch<T>, &c);
-        }
-      }
+      const unsigned n_here = n_rows_blocks;
       const unsigned pgrid = pad8(n_planes) + pad8(n_here);
 #define MIPME_PLANE_ROWS(PF, CO, CE) \
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (plane_rows_kernel<S, N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here)))
@@ -2459,24 +2250,16 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     }
     const unsigned pattern = brick_pattern(bg, n_spread, n_rows_blocks, sizeof(T) == 4);
     const bool compact = (job->shift_format & kShiftFormatMask) == kShiftTable32;
-    // One launch of one kernel instantiation: how many of its brick workgroups continue with a row block (spread_rows_kernel:
-    // n_cont) follows from how many workgroups of THAT kernel are resident at once.
 #define MIPME_SPREAD_ROWS(PF, CO, CE)                                                                                          \
   MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ((void)S, [&] {                                                                \
     constexpr bool capped = spread_rows_sgpr_capped<N, T, CE>();                                                               \
-    const void* fn;                                                                                                            \
-    if constexpr (capped)                                                                                                      \
-      fn = (const void*)spread_rows_capped_kernel<N, T, PF, CO, CE>;                                                           \
-    else                                                                                                                       \
-      fn = (const void*)spread_rows_kernel<N, T, PF, CO, CE>;                                                                  \
-    const unsigned n_cont = cosched_continuations(fn, lds_k, bg, n_spread, n_rows_blocks, pattern);                            \
     const unsigned n_rp = bg.xcd ? pad8(n_rows_blocks) : n_rows_blocks;                                                        \
-    const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), n_rp - n_cont, pattern) : n_spread + n_rp - n_cont;            \
+    const unsigned grid = bg.xcd ? cosched_grid(pad8(n_spread), n_rp, pattern) : n_spread + n_rp;                              \
     note_cosched_kernel(capped ? "spread_rows_capped_kernel" : "spread_rows_kernel");                                          \
     if constexpr (capped)                                                                                                      \
-      spread_rows_capped_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);    \
+      spread_rows_capped_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern);            \
     else                                                                                                                       \
-      spread_rows_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern, n_cont);           \
+      spread_rows_kernel<N, T, PF, CO, CE><<<grid, SPREAD_THREADS, lds_k, st>>>(sa, ra_e, n_spread, pattern);                   \
   }()))
     if (cpart && pfast == 1)
       MIPME_SPREAD_ROWS(1, true, true);
@@ -2548,12 +2331,6 @@ int gather_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
     if (th->sr_reduced) {  // pre-reduced by the x stage of the convolution (kfilter.hip xconv_kernel, sr_part)
       tail.epart_sr = tail.epart_k + tail.n_k;
       tail.n_sr = tail.n_k;
-      if (th->sr2_count > 0) {
-        tail.epart_sr2 = (const double*)v.epart + 2 * th->sr2_first;
-        tail.n_sr2 = int(th->sr2_count);
-      }
-    } else {
-      MIPME_REQUIRE(th->sr2_count <= 0, "late row partial sums come with the x stage's pre-reduction");
     }
     tail.grad_q = (T*)th->grad_q;
     tail.rpart = th->rpart;

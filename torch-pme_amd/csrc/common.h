@@ -263,9 +263,6 @@ struct GatherTailHost {
   const void* epart_k; // fp64[n_k]: per-workgroup sums of mu G |rho^|^2 written by the x stage of the convolution
   int64_t n_k;
   int sr_reduced;      // the x stage has also reduced the pair kernel's per-wave partial sums to epart_k[n_k + 2 b ...]
-  // rows that ride on the convolution launch finish after its x stage: their per-wave partial sums (waves sr2_first ..
-  // sr2_first + sr2_count of the bins buffer's epart array) are added up by the gather itself
-  int64_t sr2_first, sr2_count;
   // the rest of the autograd contract of E = sum q V from the same launch (all nullable; see mipme_kspace_forward_args_t)
   void* grad_q;        // (N): seed * dE/dq = 2 seed V
   double* rpart;       // fp64[9 * bricks]: per-brick sums r_a (x) (seed q_a field_a) for the cell gradient
@@ -307,31 +304,7 @@ struct PlaneHost {
   int parts = 1;
   void* hat_more = nullptr;
   int64_t more_stride = 0;
-  // the plan of the convolution that follows (nullable): lets the spread hand the LAST row blocks of the co-scheduled pair sum
-  // to the convolution's inverse (y,z) launch (fft_plan_set_inverse_corunner below)
-  mipme_fft_plan* plan = nullptr;
-  // out: first row (atom) of the row blocks handed to that launch, -1: none.  Their energy partial sums are written AFTER the
-  // x stage of the convolution: the caller keeps them out of the x stage's pre-reduction and gives them to the gather's tail
-  // (GatherTailHost::sr2_first / sr2_count)
-  mutable int64_t rows_tail_first = -1;
 };
-// Co-runner of the inverse (y,z) plane launch of convolve_xfused (kfilter.hip): that launch is nx workgroups of 1024 threads --
-// a quarter of the chip at 64^3 -- for ~7 us.  A caller that has independent work of the same workgroup size registers a
-// launcher; convolve_xfused then calls it INSTEAD of launching the planes itself, with the shape of the plane launch, and the
-// launcher starts one kernel that runs the planes (fft_lds.h yz_plane_body) in its first n_planes workgroups and its own work
-// behind them.  One-shot: cleared when used; kspace_forward clears it at entry (a failed call must not leave it behind).
-struct YzInverseLaunch {
-  int ny, nz, logny, loglz;
-  void* hat;       // half-complex planes in
-  void* real_out;  // real mesh out
-  unsigned n_planes;
-  int threads;     // 1024 (the co-runner is only offered launches of that shape: fft_plan_inverse_corun_ok)
-  size_t lds;      // dynamic LDS the planes need
-  const int* skip;
-};
-typedef int (*InverseCoRunner)(void* ctx, hipStream_t st, const YzInverseLaunch* launch);
-bool fft_plan_inverse_corun_ok(const mipme_fft_plan* p);
-void fft_plan_set_inverse_corunner(mipme_fft_plan* p, InverseCoRunner fn, void* ctx);
 struct RowRideHost {
   const mipme_sr_job_t* job;
   void* epart;  // per-wave energy partial sums (bins buffer), nullable

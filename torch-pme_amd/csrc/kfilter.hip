@@ -373,8 +373,6 @@ struct mipme_fft_plan {
   // (yz_planes_kernel without its y stage, `split_rows` rows per workgroup) and y columns (ycols_kernel) -- still no hipFFT
   bool split_yz = false;
   int split_rows = 0;
-  // barrier counters of the persistent convolution launch (conv_persistent_kernel): 4 words, zero between calls
-  unsigned* conv_flags = nullptr;
   int dtype = 0, nx = 0, ny = 0, nz = 0, batch = 0;
   // per-brick atom counters of the binning pass (csrc/bricks.hip): zero between calls -- the spread kernel that consumes
   // the bins clears them again, which saves a memset launch per evaluation
@@ -389,9 +387,6 @@ struct mipme_fft_plan {
   int forward_parts = 1;
   void* hat_parts = nullptr;
   int64_t hat_parts_bytes = 0;
-  // one-shot co-runner of the inverse (y,z) plane launch (common.h InverseCoRunner): the next convolve_xfused hands it the launch
-  mipme::InverseCoRunner inv_co = nullptr;
-  void* inv_co_ctx = nullptr;
 };
 
 namespace mipme {
@@ -1034,91 +1029,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(int nx, int ny, int nzh, int
                                xc);
 }
 
-// ---- the convolution as ONE persistent launch ----------------------------------------------------------------------------
-// (y,z) forward planes -> grid barrier -> x stage -> grid barrier -> (y,z) inverse planes, by n_conv = nx workgroups of 1024
-// threads that stay resident (n_conv <= 256 CUs, first in the workgroup index order), instead of three launches: two kernel
-// boundaries become two flag barriers.  EXPERIMENT, off by default (MIPME_PERSISTENT_CONV=1): measured slower than the three
-// launches (34.8 against 25.1 us at cfg3, profiles/r02_experiments.txt item 8) -- kept because it documents the hand-off
-// protocol and the cost of a software grid barrier on this part.
-// Inter-workgroup hand-off (MI355X: per-XCD L2s are not coherent): every wave drains its stores, the workgroup meets at a
-// barrier, ONE lane releases at agent scope (writes this XCD's dirty L2 lines back), takes a ticket on an agent-scope counter,
-// spins -- bounded -- until all n_conv tickets are taken, acquires at agent scope (invalidates), and the workgroup meets again;
-// plain loads after that see every other workgroup's data.  Nothing depends on dispatch order or placement beyond
-// co-residency, which the grid size guarantees.  A spin that gives up sets *err (results of that call are garbage, the GPU
-// does not hang).  The last workgroup to finish leaves the three counters at zero for the next call.
-template <typename T>
-struct ConvArgs {
-  int nx, ny, nz, nzh, log2nx, logny, loglz, kzs, nchunk, x_threads;
-  unsigned n_conv, n_tiles;
-  size_t x_group_lds;
-  const T* mesh_in;
-  Cplx<T>* hat;
-  T* mesh_out;
-  const T* G;
-  T* dc;
-  double* epart;
-  const double* sr_part;
-  int n_sr_part;
-  unsigned* flags;
-  int* err;
-};
-
-__device__ __forceinline__ void conv_grid_barrier(unsigned* counter, unsigned n, int* err) {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 21)) {  // >> any legitimate wait (a few microseconds): give up rather than hang the device
-        if (err) *err = 1;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-
-template <typename T>
-__global__ __launch_bounds__(1024) void conv_persistent_kernel(ConvArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  const unsigned w = blockIdx.x;
-  // ---- (y,z) forward: plane w = x (one channel)
-  yz_plane_body<T, false, true>(a.ny, a.nz, a.logny, a.loglz, a.mesh_in, a.hat, nullptr, int64_t(w), smem_c);
-  conv_grid_barrier(a.flags + 0, a.n_conv, a.err);
-  // ---- x stage: groups of x_threads threads, one tile each per round
-  {
-    const int G = 1024 / a.x_threads;
-    const int grp = int(threadIdx.x) / a.x_threads, gtid = int(threadIdx.x) % a.x_threads;
-    KGeom kg{};
-    KPot kp{};
-    for (unsigned base = 0; base < a.n_tiles; base += a.n_conv * unsigned(G)) {
-      const unsigned tile = base + w * unsigned(G) + unsigned(grp);
-      xconv_tile_body<T, 0>(a.nx, a.ny, a.nzh, a.log2nx, a.kzs, a.nchunk, a.hat, a.G, 0, a.dc, kg, kp, nullptr, a.epart,
-                                a.sr_part, a.n_sr_part, tile < a.n_tiles ? tile : 0u, a.n_tiles, tile < a.n_tiles, gtid,
-                                a.x_threads, grp, smem_c + size_t(grp) * a.x_group_lds);
-      __syncthreads();  // the groups' LDS regions are reused by the next round
-    }
-  }
-  conv_grid_barrier(a.flags + 1, a.n_conv, a.err);
-  // ---- (y,z) inverse
-  yz_plane_body<T, true, true>(a.ny, a.nz, a.logny, a.loglz, nullptr, a.hat, a.mesh_out, int64_t(w), smem_c);
-  // ---- the last workgroup to get here resets the counters (everybody has left both spins by then)
-  if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(a.flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == a.n_conv - 1) {
-      __hip_atomic_store(a.flags + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.flags + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.flags + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 bool fft_plan_xfused(const mipme_fft_plan* p) { return p->own_yz || (p->fwd2d != 0 && p->inv2d != 0); }
-bool fft_plan_persistent(const mipme_fft_plan* p);
 int fft_plan_batch(const mipme_fft_plan* p) { return p->batch; }
 
 // mesh_in (C,nx,ny,nz) -> mesh_out, hat: one half-complex work buffer; dc[c] = Re rfftn(mesh_in)[c,0,0,0] (nullable)
@@ -1143,63 +1054,6 @@ int64_t xconv_waves(const mipme_fft_plan* p) {
 }
 
 // cell_mesh + cell_pot + cell_partials (all nullable together): also write the energy-mode k-grid sums of the cell gradient
-// One persistent launch for the whole convolution (+ riding row workgroups of the pair sum), when the plan allows it
-static bool conv_persistent_ok(const mipme_fft_plan* p);
-bool fft_plan_persistent(const mipme_fft_plan* p) { return conv_persistent_ok(p); }
-static bool conv_persistent_ok(const mipme_fft_plan* p) {
-  if (!p->own_yz || p->split_yz || p->batch != 1 || p->nx > 256) return false;
-  if (p->ny * (p->nz / 2 + 1) < 2048) return false;  // the plane kernels then use fewer than 1024 threads
-  // measured (cfg3, 64^3 fp32): 34.8 us against 25.1 us for the three separate launches -- a software grid barrier
-  // (agent-scope release + counter + poll + acquire) costs MORE here than a kernel boundary inside a replayed graph, and
-  // the x stage of a resident grid has 64 workgroups to spread its tiles over instead of 320.  Opt-in, for experiments.
-  const char* e = getenv("MIPME_PERSISTENT_CONV");
-  return e && e[0] == '1';
-}
-
-template <typename T>
-static int convolve_persistent_t(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat,
-                                 void* mesh_out, void* dc, void* epart, const void* sr_part, int64_t n_sr_part,
-                                 const RowRideHost* rh, void* err_flag) {
-  ConvArgs<T> a{};
-  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz; a.nzh = p->nz / 2 + 1;
-  while ((1 << a.log2nx) < p->nx) ++a.log2nx;
-  while ((1 << a.logny) < p->ny) ++a.logny;
-  while ((1 << a.loglz) < p->nz / 2) ++a.loglz;
-  const size_t cs = sizeof(Cplx<T>);
-  a.kzs = sizeof(T) == 4 ? 3 : 2;
-  while (a.kzs > 0 && cs * (size_t(p->nx) << a.kzs) > 32768) --a.kzs;
-  a.nchunk = (a.nzh + (1 << a.kzs) - 1) >> a.kzs;
-  int threads = (p->nx >> 2) << a.kzs;
-  a.x_threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
-  a.n_conv = unsigned(p->nx);
-  a.n_tiles = unsigned(a.nchunk) * unsigned(p->ny);
-  a.x_group_lds = (cs * (size_t(p->nx) * ((size_t(1) << a.kzs) + kXPad) + size_t(p->nx / 2)) + 15) & ~size_t(15);
-  a.mesh_in = (const T*)mesh_in; a.hat = (Cplx<T>*)hat; a.mesh_out = (T*)mesh_out; a.G = (const T*)G; a.dc = (T*)dc;
-  a.epart = (double*)epart; a.sr_part = (const double*)sr_part; a.n_sr_part = int(n_sr_part);
-  if (!p->conv_flags) {  // first use (not during stream capture: the callers warm up)
-    if (hipMalloc((void**)&p->conv_flags, 4 * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(p->conv_flags, 0, 4 * sizeof(unsigned)) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("could not allocate the barrier counters of the convolution (not possible during stream capture: run one "
-                "evaluation before capturing)");
-      return MIPME_EHIP;
-    }
-  }
-  a.flags = p->conv_flags;
-  a.err = err_flag ? (int*)err_flag : (int*)(p->conv_flags + 3);
-  const int Lz = p->nz / 2, Ltab = p->ny > Lz ? p->ny : Lz;
-  const size_t lds_yz = cs * (size_t(p->ny) * (Lz + 1) + size_t(Ltab) / 2 + size_t(Lz + 1));
-  const size_t lds_x = a.x_group_lds * size_t(1024 / a.x_threads);
-  const size_t lds = lds_yz > lds_x ? lds_yz : lds_x;
-  MIPME_REQUIRE(!rh || rh->n_rows <= 0, "row riders are not implemented");
-  if (lds > 64 * 1024)
-    MIPME_CHECK_HIP(hipFuncSetAttribute((const void*)conv_persistent_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        int(kYzMaxLds)));
-  conv_persistent_kernel<T><<<a.n_conv, 1024, lds, st>>>(a);
-  MIPME_LAUNCH_CHECK();
-  return MIPME_OK;
-}
-
 template <typename T>
 static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, const void* G, void* hat, void* mesh_out,
                              void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
@@ -1284,23 +1138,7 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     MIPME_XCONV_LAUNCH(0);
 #undef MIPME_XCONV_LAUNCH
   MIPME_LAUNCH_CHECK();
-  const InverseCoRunner co = p->inv_co;
-  void* const co_ctx = p->inv_co_ctx;
-  p->inv_co = nullptr;
-  p->inv_co_ctx = nullptr;
-  if (co) {  // somebody's work rides behind the inverse planes, in a kernel of theirs (common.h InverseCoRunner)
-    MIPME_REQUIRE(fft_plan_inverse_corun_ok(p) && !riders, "the inverse plane launch cannot take a co-runner here");
-    YzInverseLaunch L{};
-    L.ny = p->ny;
-    L.nz = p->nz;
-    yz_launch_shape(p, sizeof(T), L.logny, L.loglz, L.lds, L.threads);
-    L.hat = hat;
-    L.real_out = mesh_out;
-    L.n_planes = unsigned(p->nx);
-    L.skip = skip_flag_slot();
-    int rc = co(co_ctx, st, &L);
-    if (rc) return rc;
-  } else if (p->own_yz) {
+  if (p->own_yz) {
     int rc = yz_planes<T>(p, st, true, nullptr, hat, mesh_out, riders ? &rider : nullptr);
     if (rc) return rc;
   } else {
@@ -1320,13 +1158,7 @@ int convolve_xfused(mipme_fft_plan* p, hipStream_t st, const void* mesh_in, cons
                     void* dc, int64_t G_stride, const mipme_mesh_t* cell_mesh, const mipme_potential_t* cell_pot,
                     void* cell_partials, void* epart, const void* sr_part, int64_t n_sr_part, const RowRideHost* rh,
                     void* err_flag, const ConvCell* cc) {
-  if (!cell_partials && G_stride == 0 && conv_persistent_ok(p)) {
-    MIPME_REQUIRE(!p->inv_co, "the persistent convolution has no inverse plane launch for a co-runner");
-    if (p->dtype == MIPME_F32)
-      return convolve_persistent_t<float>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
-    return convolve_persistent_t<double>(p, st, mesh_in, G, hat, mesh_out, dc, epart, sr_part, n_sr_part, rh, err_flag);
-  }
-  MIPME_REQUIRE(!rh || rh->n_rows <= 0, "row riders need the persistent convolution launch");
+  MIPME_REQUIRE(!rh || rh->n_rows <= 0, "row riders on the convolution launches were an experiment of round 2 (tools/r06/pruned_experiments.patch)");
   if (!p->own_yz) {
     MIPME_CHECK_FFT(hipfftSetStream(p->fwd2d, st));
     MIPME_CHECK_FFT(hipfftSetStream(p->inv2d, st));
@@ -1343,23 +1175,10 @@ int fft_inverse(mipme_fft_plan* p, hipStream_t st, void* in, void* out);
 
 // the plane spread can stand in for the forward (y,z) launch of convolve_xfused_t: own single-launch plane kernels, one mesh
 bool fft_plan_plane_forward_ok(const mipme_fft_plan* p) {
-  return p && p->own_yz && !p->split_yz && p->batch == 1 && !conv_persistent_ok(p);
+  return p && p->own_yz && !p->split_yz && p->batch == 1;
 }
 // ... the same for a batched plan (frame batches: bricks.hip frames_plane_rows_kernel)
-bool fft_plan_plane_forward_ok_batched(const mipme_fft_plan* p) { return p && p->own_yz && !p->split_yz && !conv_persistent_ok(p); }
-// the inverse (y,z) launch can take a co-runner (common.h): own single-launch plane kernels of 1024 threads, one mesh
-bool fft_plan_inverse_corun_ok(const mipme_fft_plan* p) {
-  if (!p || !p->own_yz || p->split_yz || p->batch != 1 || conv_persistent_ok(p)) return false;
-  int logny, loglz, threads;
-  size_t lds;
-  yz_launch_shape(p, p->dtype == MIPME_F32 ? 4 : 8, logny, loglz, lds, threads);
-  return threads == 1024 && lds <= 64 * 1024;
-}
-void fft_plan_set_inverse_corunner(mipme_fft_plan* p, InverseCoRunner fn, void* ctx) {
-  if (!p) return;
-  p->inv_co = fn;
-  p->inv_co_ctx = fn ? ctx : nullptr;
-}
+bool fft_plan_plane_forward_ok_batched(const mipme_fft_plan* p) { return p && p->own_yz && !p->split_yz; }
 void fft_plan_set_forward_done(mipme_fft_plan* p, bool done, int parts) {
   if (!p) return;
   p->forward_done = done;
@@ -1629,7 +1448,6 @@ int fft_plan_destroy(mipme_fft_plan* p) {
   if (p->brick_count) (void)hipFree(p->brick_count);
   if (p->tail_scratch) (void)hipFree(p->tail_scratch);
   if (p->hat_parts) (void)hipFree(p->hat_parts);
-  if (p->conv_flags) (void)hipFree(p->conv_flags);
   delete p;
   return MIPME_OK;
 }

@@ -168,30 +168,30 @@ def filter_derivative(geom: MeshGeometry, pot_desc: _lib.PotentialDesc, dtype, d
 #   "rows"   (default) owner-computes sums over a transposed pair list (csrc/topology.hip); needs a
 #            one-off build per neighbour-list tensor, no atomics, deterministic.
 #   "atomic" one pass over the list with hardware float atomics (csrc/rspace.hip); no preprocessing.
-PAIR_MODE = os.environ.get("MIPME_PAIR_MODE", "rows")
+PAIR_MODE = "rows"
 
 #: constant ``neighbor_distances`` (the same tensor, unmodified, seen a second time by the same list): v_SR(d) per row entry is
 #: tabulated once and the pair sum becomes a sparse matrix-vector product (PairTopology.tabulated); "0" disables
-TABULATE = os.environ.get("MIPME_TABULATE", "1") != "0"
+TABULATE = True
 
 # How atoms meet the mesh: "bricks" (default; atoms binned by 8^3 mesh brick, owner-computes LDS-tile spread,
 # LDS-tiled gathers -- csrc/bricks.hip) or "atomic" (global float atomics -- csrc/mesh.hip).  Meshes too small
 # for bricks always take the atomic kernels.
-MESH_MODE = os.environ.get("MIPME_MESH_MODE", "bricks")
+MESH_MODE = "bricks"
 
 # When the gradient arriving at the calculator's backward was produced by ``weighted_sum(V, charges)`` (E = sum q V, the
 # reduction every energy/force evaluation performs) it equals gE * charges and the adjoint mesh is a multiple of the
 # forward mesh: the backward then skips the second spread + FFT pair.  Any other upstream gradient takes the general path.
 #: run the short-range pair sum inside the spread launch of the mesh part (see mipme_sr_job_t in include/mipme.h)
-COSCHEDULE = os.environ.get("MIPME_COSCHEDULE", "1") != "0"
-ENERGY_FAST_PATH = os.environ.get("MIPME_ENERGY_FAST_PATH", "1") != "0"
+COSCHEDULE = True
+ENERGY_FAST_PATH = True
 #: 4-byte entries {partner | shift code << 22} for the co-scheduled pair sum (half the entry stream; needs < 2^22 atoms)
-COMPACT_ENTRIES = os.environ.get("MIPME_COMPACT_ENTRIES", "1") != "0"
+COMPACT_ENTRIES = True
 #: bytes per entry of the pair stream the co-scheduled kernel reads (bench.py's algorithmic byte count)
 FUSED_ENTRY_BYTES = 4 if COMPACT_ENTRIES else 8
 #: energy reduction + force assembly inside the gather launch when the forward can tell they will be wanted (see the tail
 #: block of _PMEFunction.forward and _EnergyDirectSum)
-TAIL_FUSION = os.environ.get("MIPME_TAIL_FUSION", "1") != "0"
+TAIL_FUSION = True
 #: a device scalar the caller promises to seed the next backward pass with (set by GraphedEnergyForces around its
 #: evaluation): the gather's tail then writes seed * dE/dpositions and the backward pass launches nothing
 SEED_PROMISE = None
@@ -232,21 +232,21 @@ class seed_promise:
         TAIL_LOG = self._prev_log
         return False
 #: recognise an energy gradient (grad == gE * charges) that carries no tag from ``weighted_sum`` by comparing on the device
-ENERGY_DETECT = os.environ.get("MIPME_ENERGY_DETECT", "1") != "0"
+ENERGY_DETECT = True
 #: compiled host side of the reference call sequence for its common case (csrc/front.cpp, _front.py); "0": Python nodes only
 FRONT = os.environ.get("MIPME_FRONT", "1") != "0"
 #: ... and act on the verdict ON THE DEVICE (mipme_set_skip_flag / mipme_energy_select) where only position gradients are asked
 #: for, instead of polling it on the host: the poll makes the host wait for everything queued before it, i.e. the eager
 #: reference call sequence ran GPU and host one after the other
-DEVICE_SELECT = os.environ.get("MIPME_DEVICE_SELECT", "1") != "0"
+DEVICE_SELECT = True
 #: ... from this many atoms on: below, the eager step is bound by the host (0.3 ms of Python for 0.13 ms of kernels at 32k atoms)
 #: and the extra launches of the skipped general adjoint cost more host time than the poll (measured on one box: 0.39 against
 #: 0.33-0.37 ms at 31 944 atoms, 0.69 against 0.75 ms at 262 144)
-DEVICE_SELECT_MIN_ATOMS = int(os.environ.get("MIPME_DEVICE_SELECT_MIN_ATOMS", "65536"))
+DEVICE_SELECT_MIN_ATOMS = 65536
 
 # Reciprocal-space convolution as (y,z) plane transforms + one kernel doing x-FFT, * G and the inverse x-FFT (power-of-two
 # nx); "0" keeps the 3-D hipFFT plans + filter kernel.
-XFUSED = os.environ.get("MIPME_XFUSED", "1") != "0"
+XFUSED = True
 
 
 # When ``neighbor_distances`` is the untouched output of :func:`pair_distances`, the calculator differentiates straight through
@@ -254,24 +254,7 @@ XFUSED = os.environ.get("MIPME_XFUSED", "1") != "0"
 # gather per entry instead of random reads of P-sized arrays) and neither ``d`` nor ``dL/dd`` is read or written by the
 # calculator.  The gradient then reaches ``positions`` directly, NOT via ``neighbor_distances`` -- set to 0 if you need
 # ``torch.autograd.grad(E, neighbor_distances)`` for such a tensor (a leaf ``neighbor_distances`` is never fused).
-FUSE_DISTANCES = os.environ.get("MIPME_FUSE_DISTANCES", "1") != "0"
-
-
-# The bandwidth-bound pair kernels and the latency-bound mesh kernels of one evaluation are independent until
-# the final sum, so they run concurrently: pair work on a per-device side stream, mesh work on the caller's stream,
-# joined with HIP events (SURVEY.md 7 "hard part 2": at 32k atoms the step is launch/latency limited).
-OVERLAP = os.environ.get("MIPME_OVERLAP", "0") != "0"  # measured: cross-stream event joins cost more than they hide in eager mode
-_SIDE = {}
-
-
-def _side_stream(device):
-    """(side stream, fork event, join event) of ``device``; events are re-recorded every call."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    entry = _SIDE.get(key)
-    if entry is None:
-        entry = (torch.cuda.Stream(device), torch.cuda.Event(), torch.cuda.Event())
-        _SIDE[key] = entry
-    return entry
+FUSE_DISTANCES = True
 
 
 def _pack_row_shifts(entries, shifts, n_pairs):
@@ -314,7 +297,7 @@ def _pack_entries(row_ptr, entries, shifts, n_pairs, n_atoms, table=True):
 # nothing.  The bet: ``mipme_checksum`` hashes the new tensor on the device and compares with the hash of the tensor the cached
 # structures were built from; the verdict lands in pinned memory and is looked at (``verify_bets``) before any result that used
 # the cached structures is handed out; a lost bet repeats the evaluation with freshly built structures.  "0": always rebuild.
-SPECULATE_LISTS = os.environ.get("MIPME_SPECULATE_LISTS", "1") != "0"
+SPECULATE_LISTS = True
 _BETS: list = []  # pending verdicts: (pinned flags numpy view, slot, undo callable)
 _ON_LOST: list = []  # side effects of work done on adopted structures, to take back if any pending bet is lost
 _BET_PAUSE = [0]  # list misses to sit out after a lost bet (lists that really change from call to call)
@@ -1033,11 +1016,9 @@ class _PMEFunction(torch.autograd.Function):
                 # speculative: the mesh force per unit gE q_a, formed by the same gather (see the backward's energy mode)
                 if ENERGY_FAST_PATH and bins is not None and Cn == 1 and ctx.needs_input_grad[2] and slab_axis is None:
                     field = torch.empty((N, 3), dtype=dtype, device=device)
-                overlap = OVERLAP and topo is not None
-                join = None
                 # the binning pass can emit the (position, charge) records of the fused pair kernel for free
                 records_out = None
-                if fused is not None and bins is not None and Cn == 1 and src_positions is positions and not overlap:
+                if fused is not None and bins is not None and Cn == 1 and src_positions is positions:
                     records_out = fused["records"]
                 # co-scheduled pair sum: the spread launch also carries the row workgroups of the fused distance + pair kernel
                 # (mipme_sr_job_t); the gather then adds the mesh part to the potentials the pair sum wrote
@@ -1095,15 +1076,6 @@ class _PMEFunction(torch.autograd.Function):
                         records=records_out.data_ptr(), out=out.data_ptr(), force=_lib.ptr(fused["force"]),
                         dist_out=dist.data_ptr() if write_dist else None,
                     )
-                if overlap:
-                    # short-range sum on the side stream (writes `out`); the gather at the end of the mesh
-                    # pipeline waits for it and adds the long-range part
-                    side, fork, join = _side_stream(device)
-                    fork.record()
-                    side.wait_event(fork)
-                    with torch.cuda.stream(side):
-                        run_rspace(0)
-                        join.record()
                 if tail_ok:
                     seed = SEED_PROMISE
                     if seed is not None and (seed.dtype != dtype or seed.device != device or seed.numel() != 1):
@@ -1124,11 +1096,11 @@ class _PMEFunction(torch.autograd.Function):
                                                         dtype=torch.float64, device=device)
                 keep_rho_mesh = (cell_partials is not None or tail_cell) and rho_keep is None and rho_hat is None
                 args = _lib.KspaceForwardArgs(
-                    plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if (overlap or job is not None) else 0,
+                    plan=plan.handle, stream=st, dtype=dt, accumulate_out=1 if job is not None else 0,
                     mesh=C.pointer(md), pot=C.pointer(pot_desc), n_atoms=N, positions=pos.data_ptr(), charges=q.data_ptr(),
                     G=G.data_ptr(), rho_mesh=rho_mesh.data_ptr(), rho_hat=_lib.ptr(rho_hat), hat_work=hat_work.data_ptr(),
                     phi_mesh=phi_mesh.data_ptr(), dc=dc.data_ptr(), out_lr=out.data_ptr(), out_phi=_lib.ptr(phi_atoms),
-                    atom_bins=_lib.ptr(bins), gather_wait_event=join.cuda_event if overlap else None,
+                    atom_bins=_lib.ptr(bins), gather_wait_event=None,
                     out_field=_lib.ptr(field), out_records=_lib.ptr(records_out),
                     sr_job=C.pointer(job) if job is not None else None, out_cell_partials=_lib.ptr(cell_partials),
                     out_energy=None if tail is None else tail["energy"].data_ptr(),
@@ -1163,7 +1135,7 @@ class _PMEFunction(torch.autograd.Function):
                              rho_dc=dc, phi_atoms=phi_atoms,
                              bins=bins, rho_mesh=rho_mesh if keep_rho_mesh else None,
                              cell_partials=cell_partials)
-                if not overlap and job is None:
+                if job is None:
                     run_rspace(1)
             else:
                 run_rspace(0)
@@ -1305,14 +1277,6 @@ class _PMEFunction(torch.autograd.Function):
                     _lib.ptr(sr_scale), _lib.ptr(grad_dist), _lib.ptr(grad_q) if with_charges else None,
                 )
 
-            overlap = OVERLAP and topo is not None and do_kspace and need_dist
-            if overlap:
-                side, fork, join = _side_stream(device)
-                fork.record()
-                side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    run_grad_dist(False)
-                    join.record()
             if do_kspace and gscale is not None:
                 kb_q = need_q and not energy_q
                 # with the field at hand the C call only finalises the cell gradient (no gradient gather)
@@ -1390,9 +1354,7 @@ class _PMEFunction(torch.autograd.Function):
             elif need_q and not energy_q:
                 grad_q = torch.zeros((N, Cn), dtype=dtype, device=device)
             atomic_q = need_q and topo is None and not energy_q
-            if overlap:
-                torch.cuda.current_stream(device).wait_event(join)
-            elif need_dist or atomic_q:
+            if need_dist or atomic_q:
                 run_grad_dist(atomic_q)
 
             # ---- gradients that end in per-atom sums formed by the forward pass (energy mode) ----
