@@ -424,14 +424,17 @@ def algorithmic_bytes(w, s: int, fused: bool = True, store_distances: bool = Fal
         "forces_finalize": N * 10 * s,
     }
     if parts > 0:
-        # Plane spread (round 5): the co-scheduled launch reads the plane lists (4 B per atom) and, per atom, its record, 3 n
-        # weights and charge -- counted ONCE although every atom is read by the n planes it reaches (they hit L2) -- and writes
-        # `parts` half-complex meshes instead of the real one; the convolution loses its forward plane launch (reads M s, writes
-        # M s) and reads the parts instead; the binning pass also writes the list entry, the charge by slot and a per-wavefront max.
+        # Plane spread (round 5; streamed entries: round 6): the co-scheduled launch reads, per atom, ONE plane-list entry -- packed
+        # mesh coordinates, the y / z offsets and the n products charge * w_x, (3 + n) s bytes padded to 16 (32 B at n = 5, fp32;
+        # round 5: list slot + record + 3 n weights + charge = 84 B) -- counted ONCE although every atom is read by the n planes it
+        # reaches (they hit L2), and writes `parts` half-complex meshes instead of the real one; the convolution loses its forward
+        # plane launch (reads M s, writes M s) and reads the parts instead; the binning pass also writes the entry, the charge by
+        # slot and a per-wavefront max.
         Mh2 = 2 * w.n_mesh * w.n_mesh * (w.n_mesh // 2 + 1) * s  # bytes of a half-complex mesh
-        per_kernel["spread+rspace_forward"] = (2 * P * eb + dw + N * 8 * s) + N * (4 + 16 + 3 * n * s + s) + parts * Mh2
+        entry = ((3 + n) * s + 15) // 16 * 16
+        per_kernel["spread+rspace_forward"] = (2 * P * eb + dw + N * 8 * s) + N * entry + parts * Mh2
         per_kernel["convolve_xfused"] = int(4.5 * M * s) + (parts - 1) * Mh2
-        per_kernel["bin_atoms"] += N * (4 + s) + (N // 64 + 1) * 4
+        per_kernel["bin_atoms"] += N * (entry + s) + (N // 64 + 1) * 4
     step = P * (32 + 3 * s) + P * (32 + 8 * s) + N * 25 * s + 19 * M * s
     return step, per_kernel
 
@@ -1326,6 +1329,8 @@ def main(argv=None):
     if rank == 0:
         # (the per-kernel stage times below are those of ONE frame's step whatever the number of frames per GPU)
         n_parts = plane_parts(w, s) if args.neighbors == "list" else 0
+        if "plane" not in dom_family:  # what RAN decides (mipme_last_cosched_kernel), not what the geometry would allow
+            n_parts = 0
         # a frame batch (GraphedFrameBatch) keeps its plane workgroups at <= 128 per launch (csrc/bricks.hip frames_forward_t)
         label_parts = n_parts
         while batch is not None and label_parts > 1 and label_parts * w.n_mesh * n_frames > 128:

@@ -9,7 +9,7 @@ OBJ=/tmp/mipme_variant_$NAME
 mkdir -p $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function $*"
 pids=()
-for f in api mesh kfilter rspace topology bricks neighbors ewald jets; do
+for f in api mesh kfilter rspace topology bricks frames live neighbors ewald jets; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o &
   pids+=($!)
 done
