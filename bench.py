@@ -93,6 +93,9 @@ def parse_args(argv=None):
                          "(tools/r06/order_sweep.py: P3M 3-5, Lagrange 4, 6, 7 x fp32 / fp64, ms per step + scratch per kernel)")
     ap.add_argument("--no-exchange-sweep", action="store_true",
                     help="with several ranks: skip the one timed block per OTHER exchange protocol (parallelism.other_exchange_modes_ms_per_step)")
+    ap.add_argument("--exchange-sweep", default="basic", choices=["basic", "full"],
+                    help="which other protocols get their one timed block: basic = none, per-step, final (blocking collectives on the "
+                         "compute stream, the primitive the log's own exchange uses); full = also log / pipelined (asynchronous)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (the median block is the reported value)")
     ap.add_argument("--prewarm-ms", type=float, default=30.0, help="untimed replays before the warm-up steps (clock ramp)")
     ap.add_argument("--no-list-refresh", action="store_true")
@@ -1189,7 +1192,8 @@ def main(argv=None):
     # the other exchange protocols, one block each, same invocation (reported under parallelism.other_exchange_modes; never `value`)
     other_modes, other_times = [], []
     if distributed and not args.no_exchange_sweep and exchange_mode != "in-graph":
-        for m in ("none", "log", "per-step", "pipelined", "final"):
+        sweep = ("none", "log", "per-step", "pipelined", "final") if args.exchange_sweep == "full" else ("none", "per-step", "final")
+        for m in sweep:
             if m == exchange_mode or (m == "log" and exchange_mode == "in-graph"):
                 continue
             mode["x"] = m

@@ -43,7 +43,8 @@ def test_exchange_modes_gather_the_same_energies():
     and final (only the last step's energies) must deliver the same frame energies; the line carries the protocol."""
     sums = {}
     for mode in ("log", "per-step", "pipelined", "final"):
-        out = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-gpu", "2", "--blocks", "2", "--exchange", mode)
+        out = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-gpu", "2", "--blocks", "2", "--exchange", mode,
+                   "--exchange-sweep", "full")
         assert out["parallelism"]["exchange"] == mode and out["energies_gathered"] == 4
         assert out["timing"]["blocks"] == 2 and len(out["timing"]["blocks_ms_per_step"]) == 2
         # (the reported timed region is the median block -- the lower one of two --, the first block is reported next to it)
@@ -73,6 +74,8 @@ def test_eight_ranks_cfg4_preset():
     assert out["n_gpus"] == 8 and out["parallelism"]["n_ranks"] == 8
     assert out["energies_gathered"] == 64 and out["config"]["frames_per_gpu"] == 8
     assert out["parallelism"]["exchange"] == "log" and out["parallelism"]["log_entries_gathered"] == 8 * 2 * 8
+    # the default sweep of the other protocols: blocking collectives only (the asynchronous ones are --exchange-sweep full)
+    assert set(out["parallelism"]["other_exchange_modes_ms_per_step"]) == {"none", "per-step", "final"}
     assert len(out["parallelism"]["per_rank_ms_per_step"]) == 8
     assert sorted(r["rank"] for r in out["parallelism"]["ranks"]) == list(range(8))
     assert out["weak_efficiency"]["value"] > 0

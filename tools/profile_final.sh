@@ -68,13 +68,7 @@ python tools/rocpd_summary.py $(find $OUT/${TAG}_cold -name '*.db') > $OUT/${TAG
 rm -rf $OUT/${TAG}_cold
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2>> $OUT/${TAG}_bench_default.err
 ls -la $OUT | grep ${TAG}
-# round 5: the plane spread against the owner-computes bricks on THIS box (interleaved), the cfg5 counter passes, the timeline
-for rep in 1 2; do
-  MIPME_PLANE_SPREAD=0 python bench.py --steps 300 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_ab_bricks_$rep.json 2>> $OUT/${TAG}_bench_default.err
-  python bench.py --steps 300 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_ab_planes_$rep.json 2>> $OUT/${TAG}_bench_default.err
-  MIPME_PLANE_SPREAD=0 python bench.py --preset cfg2 --steps 300 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_ab_cfg2_bricks_$rep.json 2>> $OUT/${TAG}_bench_default.err
-  python bench.py --preset cfg2 --steps 300 --warmup 20 --no-drop-in --no-cpu-baseline > $OUT/${TAG}_ab_cfg2_planes_$rep.json 2>> $OUT/${TAG}_bench_default.err
-done
+# cfg5 counter passes, the plane workgroups' timeline
 bash tools/profile_gpu.sh ${TAG}_cfg5 --preset cfg5 --steps 50 --warmup 5
 cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
@@ -85,4 +79,11 @@ rm -rf $OUT/${TAG}_sq5
 if [ -f torch-pme_amd/libmipme_timeline.so ]; then
   MIPME_LIB=$ROOT/torch-pme_amd/libmipme_timeline.so python tools/r05/plane_timeline.py water > $OUT/${TAG}_plane_timeline.txt 2>&1
 fi
+ls -la $OUT | grep ${TAG}
+# round 6: the distributed path with one rank over RCCL (every exchange protocol), the order / scheme sweep, measured errors against
+# the reference's own full-size numbers
+bash tools/r06/dist_matrix.sh 1 > /dev/null 2>&1
+cp $OUT/r06_dist_1rank.txt $OUT/${TAG}_dist_1rank.txt
+python tools/r06/order_sweep.py > $OUT/${TAG}_order_sweep.txt 2>&1
+python tools/r06/fullsize_errors.py > $OUT/${TAG}_fullsize_errors.txt 2>&1
 ls -la $OUT | grep ${TAG}

@@ -12,7 +12,7 @@ mkdir -p gpurun_out
 run() {
   env MIPME_FORCE_DIST=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
       --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) bench.py --gpus $N --steps 500 --warmup 20 --no-cpu-baseline \
-      --no-drop-in --no-contract --no-frames-block --no-second-order --no-list-refresh "$@" 2>>$OUT.err | grep '^{' >> $OUT.jsonl
+      --no-drop-in --no-contract --no-frames-block --no-second-order --no-list-refresh --exchange-sweep full "$@" 2>>$OUT.err | grep '^{' >> $OUT.jsonl
   echo "rc=$? $*" >> $OUT.err
 }
 run
