@@ -1054,6 +1054,10 @@ def main(argv=None):
         except Exception as exc:  # capture not possible on this stack: fall back to eager launches, and say so
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
             launch, graphed = "eager", None
+            if elog is not None:  # nobody appends to a graph's log now: the log is filled by a copy after every step
+                elog, extra = None, {}
+                host_log = torch.zeros((log_cap, n_frames), dtype=torch.float64, device=device)
+            use_batch = False
 
     # several frames per rank: every frame replays its graph on its own stream, so the (latency-bound, small) kernels of
     # independent frames overlap on the GPU; each stream orders the successive steps of its frame

@@ -178,7 +178,7 @@ constexpr int plane_entry_words() {
   return (3 + N + V - 1) / V * V;
 }
 static inline size_t plane_entry_bytes_rt(int order, size_t elem) { return ((3 + size_t(order)) * elem + 15) / 16 * 16; }
-static constexpr int kPlanePackBits = 10;  // my, mz < 1024 (the plane tiles are far smaller), mx < 4096
+static constexpr int kPlanePackBits = 10;  // my, mz < 1024 (the plane tiles are far smaller), mx < 2048
 
 static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype);
 static inline BinsLayout bins_layout(const mipme_mesh_t* m, int64_t N, int dtype) {
@@ -1243,6 +1243,8 @@ static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
   if (!plane_env || deterministic_mode() || m->n_channels != 1 || N <= 0) return 0;
   const bool pow2 = (m->ny & (m->ny - 1)) == 0 && (m->nz & (m->nz - 1)) == 0 && m->nz >= 4 && m->ny >= 2;
   if (!pow2 || m->nx < 2 * BRICK) return 0;
+  // (the entries pack (m_x, m_y, m_z) into 11 + 10 + 10 bits of a non-negative int)
+  if (m->nx > (1 << 11) || m->ny > (1 << kPlanePackBits) || m->nz > (1 << kPlanePackBits)) return 0;
   if (sparse_bricks(N, make_brick_geom(m).nb)) return 0;
   size_t need = 0;
   if (dtype == MIPME_F32) {
