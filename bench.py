@@ -1118,36 +1118,42 @@ def main(argv=None):
                     pending[k] = None
             all_energies.copy_(ring[last_i % 2][1])
 
-    logged = {"entries": 0}
+    logged = {"entries": 0, "pushes": 0}
+    log_gathered = torch.zeros((world, log_cap, n_frames), dtype=torch.float64, device=device) if distributed else None
 
-    def exchange_log(n):
-        """ONE collective for the n evaluations of a timed region: all-gather of this rank's (min(n, capacity), frames) log."""
+    def exchange_log():
+        """ONE collective for the evaluations of a timed region: all-gather of this rank's whole (capacity, frames) log -- the
+        last `capacity` evaluations, whatever the slot the newest one sits in (the log wraps around; no reset, no allocation and
+        no copy inside the timed region: with the driver's 20-step regions every launch of this epilogue is ~1 % of the region)."""
         from torchpme_amd import farm
 
-        rows = min(n, log_cap)
-        values = elog.values if elog is not None else host_log
-        gathered = farm.gather_energy_log(values[:rows])  # (world, rows, frames)
-        all_energies.copy_(gathered[:, (n - 1) % log_cap, :].reshape(-1))
-        logged["entries"] = int(gathered.numel())
+        farm.gather_energy_log(elog.values if elog is not None else host_log, out=log_gathered)
+        logged["entries"] = int(log_gathered.numel())
+
+    def newest_logged_energies():
+        """(after the timed regions) the newest evaluation of every rank from the gathered log -> all_energies"""
+        if logged["pushes"] > 0:
+            all_energies.copy_(log_gathered[:, (logged["pushes"] - 1) % log_cap, :].reshape(-1))
 
     def run_steps(n, with_exchange=True):
         E = None
         x = mode["x"] if with_exchange else "none"
-        if x == "log" and elog is not None:
-            elog.reset()  # (a fill kernel in front of the first step: inside the timed region)
         for i in range(n):
             E = one_step()
+            if elog is not None:
+                logged["pushes"] += 1  # (every replay of a graph with a log appends, whatever the exchange protocol)
             if x in ("per-step", "pipelined"):
                 join_streams()
                 exchange(i, E)
             elif x == "log" and elog is None:
                 join_streams()
-                host_log[i % log_cap].copy_(energies_tensor(E))
+                host_log[logged["pushes"] % log_cap].copy_(energies_tensor(E))
+                logged["pushes"] += 1
         join_streams()
         if x == "final" and E is not None:
             exchange(0, E)
         if x == "log" and n > 0:
-            exchange_log(n)
+            exchange_log()
         if with_exchange and n > 0:
             drain(n - 1)
         return E
@@ -1207,6 +1213,8 @@ def main(argv=None):
             other_times.append(dt_m)
         mode["x"] = exchange_mode
         run_steps(1)  # (all_energies = the reported mode's, for the check below)
+    if distributed and exchange_mode == "log":
+        newest_logged_energies()
     n_blocks = len(block_times)
     own = torch.tensor(block_times + other_times + [t_alone or 0.0], dtype=torch.float64, device=device)
     if distributed:

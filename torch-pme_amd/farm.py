@@ -102,19 +102,26 @@ def farm_energies_forces(n_atoms: Sequence[int], evaluate: Callable[[int], tuple
     return energies, arrays
 
 
-def gather_energy_log(values: torch.Tensor, group=None) -> torch.Tensor:
+def gather_energy_log(values: torch.Tensor, group=None, out: torch.Tensor | None = None) -> torch.Tensor:
     """ONE all-gather for MANY evaluations: ``values`` (K, F) = this rank's frame energies of K successive evaluations of its
     F frames (``graphed.EnergyLog.values[:K]``, filled on the device by the captured steps, or any tensor of that shape; the
     same K and F on every rank).  Returns (world, K, F): ``out[r, k, f]`` = energy of frame f of rank r's k-th batch, on every
     rank.  This is the exchange of a farm that streams batches of frames through each GPU: nothing is communicated between two
-    evaluations, the log (8 bytes per frame and evaluation) crosses xGMI once."""
+    evaluations, the log (8 bytes per frame and evaluation) crosses xGMI once.  ``out`` (world, K, F), contiguous: a caller that
+    exchanges the same log again and again passes its own buffer (no allocation inside a timed region)."""
     if values.dim() != 2:
         raise ValueError(f"expected a (K, F) log, got {tuple(values.shape)}")
     values = values.contiguous()
     if not (dist.is_available() and dist.is_initialized()):
+        if out is not None:
+            out.copy_(values.unsqueeze(0))
+            return out
         return values.unsqueeze(0).clone()
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(values.shape), dtype=values.dtype, device=values.device)
+    if out is None:
+        out = torch.empty((world,) + tuple(values.shape), dtype=values.dtype, device=values.device)
+    elif tuple(out.shape) != (world,) + tuple(values.shape) or not out.is_contiguous() or out.dtype != values.dtype:
+        raise ValueError(f"`out` must be a contiguous {(world,) + tuple(values.shape)} tensor of {values.dtype}")
     dist.all_gather_into_tensor(out.view(-1), values.view(-1), group=group)
     return out
 
