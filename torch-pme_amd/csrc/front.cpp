@@ -342,8 +342,8 @@ std::optional<at::Tensor> pair_distances(const std::shared_ptr<FrontTopo>& topo,
 
 // ---- the calculator node -----------------------------------------------------------------------------------------------------
 thread_local at::Tensor t_match_flag;  // pinned int32[1] per thread: the verdict of mipme_scaled_match
-// How the energy mode is decided: 0 = the verdict polled in pinned memory (MIPME_FRONT_POLL=1), 2 = on the device for every
-// request (MIPME_FRONT_SELECT=always), 1 (default) = on the device when only the positions want a gradient, polled when the
+// How the energy mode is decided: 0 = the verdict polled in pinned memory (set_device_select(0)), 2 = on the device for every
+// request (set_device_select(2)), 1 (default) = on the device when only the positions want a gradient, polled when the
 // charges or the cell do too: the device-side decision launches the whole general adjoint as kernels that return at once, and
 // with the charge / cell adjoints on top that is ~12 launches -- more than the wait they avoid (tools/check_front_contract.py:
 // E+F+dq 0.149 polled vs 0.168 ms, E+F+dq+dcell 0.168 vs 0.196 ms; positions only 0.131 vs 0.137 on a fast host, 0.171 vs 0.157

@@ -382,7 +382,7 @@ class betting:
     classes -- always builds or finds the structures of exactly its tensor); an exception that leaves the scope takes every
     pending bet back.  Equality is decided by a position-keyed 2 x 64-bit checksum (``mipme_checksum``: any single changed word and
     any two swapped words change it), i.e. with certainty against accidents, not against an adversary.  The pending-bet lists are
-    module globals: one host thread per process evaluates calculators with bets (``MIPME_SPECULATE_LISTS=0`` otherwise)."""
+    module globals: one host thread per process evaluates calculators with bets (``ops.SPECULATE_LISTS = False`` otherwise)."""
 
     def __enter__(self):
         _BET_SCOPE[0] += 1
