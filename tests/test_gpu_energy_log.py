@@ -112,3 +112,37 @@ def test_epilogue_is_the_tail_of_the_graph():
     for k in range(2):
         E, _ = step(pos + 0.02 * k)
         assert float(twice) == 2 * float(E)
+
+
+def test_c_abi_refusals():
+    """The log's entry points say no loudly: missing buffers, a capacity of zero, a host table that is too small, a frame batch
+    without the gather tail."""
+    import ctypes as C
+
+    from torchpme_amd import _lib
+
+    lib = _lib.load()
+    log = tpa.EnergyLog(4, 2, DEV)
+    src = torch.zeros(2, device=DEV, dtype=torch.float64)
+    st = _lib.current_stream(torch.device(DEV))
+    f64 = _lib.dtype_code(torch.float64)
+    ok = lib.mipme_energy_log_push(st, f64, 2, src.data_ptr(), log.values.data_ptr(), log.cursor.data_ptr(), 4)
+    assert ok == 0
+    for args in ((st, f64, 0, src.data_ptr(), log.values.data_ptr(), log.cursor.data_ptr(), 4),
+                 (st, f64, 2, None, log.values.data_ptr(), log.cursor.data_ptr(), 4),
+                 (st, f64, 2, src.data_ptr(), None, log.cursor.data_ptr(), 4),
+                 (st, f64, 2, src.data_ptr(), log.values.data_ptr(), None, 4),
+                 (st, f64, 2, src.data_ptr(), log.values.data_ptr(), log.cursor.data_ptr(), 0),
+                 (st, 77, 2, src.data_ptr(), log.values.data_ptr(), log.cursor.data_ptr(), 4)):
+        assert lib.mipme_energy_log_push(*args) != 0 and lib.mipme_last_error()
+    torch.cuda.synchronize()
+    assert log.count() == 1
+    # a host table that is too small / a log without cursors
+    nbytes = lib.mipme_frames_table_bytes(f64, 2)
+    host = np.zeros((nbytes,), dtype=np.uint8)
+    assert lib.mipme_frames_table_energy_log(f64, 2, host.ctypes.data, nbytes - 1, log.values.data_ptr(), log.cursor.data_ptr(), 4) != 0
+    assert lib.mipme_frames_table_energy_log(f64, 2, host.ctypes.data, nbytes, log.values.data_ptr(), None, 4) != 0
+    # an all-zero table has use_tail = 0 in every frame: the log rides on the gather tail and is refused; switching it off is fine
+    assert lib.mipme_frames_table_energy_log(f64, 2, host.ctypes.data, nbytes, log.values.data_ptr(), log.cursor.data_ptr(), 4) != 0
+    assert b"gather tail" in lib.mipme_last_error()
+    assert lib.mipme_frames_table_energy_log(f64, 2, host.ctypes.data, nbytes, None, None, 0) == 0

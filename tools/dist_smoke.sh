@@ -1,6 +1,6 @@
 #!/bin/bash
 # RCCL smoke test of bench.py's distributed path (run on a GPU box):  bash tools/dist_smoke.sh [N]   (default N = 1)
-# torchrun + nccl process group + HIP graph replay + the per-step all-gather, N ranks on N GPUs of one node; with N = 8 and
+# torchrun + nccl process group + HIP graph replay + the energy-log exchange (default) or a per-step all-gather, N ranks on N GPUs of one node; with N = 8 and
 # `--preset cfg4` this is BASELINE.json configs[3] (64 frames, 8 per GPU).  One line per run: OK n_gpus launch ms/step value
 # weak_efficiency.
 N=${1:-1}
