@@ -334,6 +334,7 @@ class GraphedEnergyForces:
         device = self.pos.device
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
+        self._live.log = None  # (a re-capture after an overflow warms up again: those evaluations are not the caller's)
         with torch.cuda.stream(side):  # warm-up off the default stream (the plan allocates its scratch on first use)
             for _ in range(self._warmup):
                 self._live.step()
