@@ -413,7 +413,7 @@ int64_t mipme_cellgrad_partials_size(const mipme_mesh_t* mesh, int64_t n_atoms);
  * than 4 points): pass NULL then (atomic-scatter kernels). */
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype);
 /* Name (without template arguments) of the co-scheduled spread + pair-sum kernel the calling thread launched -- or captured
- * into a graph -- last: "plane_rows_kernel", "spread_rows_capped_kernel", "spread_rows_kernel", "sparse_spread_rows_kernel",
+ * into a graph -- last: "plane_rows_capped_kernel", "plane_rows_kernel", "spread_rows_capped_kernel", "spread_rows_kernel", "sparse_spread_rows_kernel",
  * "live_spread_rows_kernel", "frames_plane_rows_kernel", "frames_spread_rows_kernel"; "" before the first one.  What ran, as
  * opposed to mipme_plane_spread_parts (what the geometry allows): a benchmark labels its dominant launch with this. */
 const char* mipme_last_cosched_kernel(void);

@@ -158,3 +158,81 @@ def test_frame_descriptor_with_garbage_counter_word_is_refused():
     assert build() == 0
     batch._frames[1].counter_ints = good
     assert build() == 0
+
+
+def _banded_case(rng, dtype, n_atoms=700, blob=False, triclinic=False):
+    """A (32, 128, 128) mesh: planes of 128 x 128 do not fit the co-scheduled launch's LDS and are spread in bands of rows."""
+    diag = np.array([10.0, 40.0, 40.0])
+    cell = np.diag(diag)
+    if triclinic:
+        cell = cell + np.array([[0, 0, 0], [0.8, 0, 0], [-0.5, 1.1, 0]])
+    frac = rng.uniform(0, 1, (n_atoms, 3))
+    if blob:  # a rod of atoms in one y slice of three x planes (~230 per sub-list of 48 entries): the plane overflow list
+        frac[:, 0] = rng.uniform(0.45, 0.55, n_atoms)
+        frac[:, 1] = rng.uniform(0.30, 0.33, n_atoms)
+    frac[:8, 1] = [0.0, 0.001, 0.999, 0.2499, 0.2501, 0.5, 0.7499, 0.7501]  # stencils that straddle band boundaries
+    pos = frac @ cell
+    q = rng.normal(size=(n_atoms, 1))
+    pairs, S, dist = tpa.neighbor_list(pos, cell, 3.0)
+    return cell, pos, q, pairs, S, dist
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("scheme,order", [("P3M", 5), ("P3M", 3), ("PME", 7), ("PME", 4)])
+@pytest.mark.parametrize("kind", ["uniform", "blob", "triclinic"])
+def test_banded_plane_spread(dtype, scheme, order, kind):
+    """Planes that do not fit the co-scheduled launch's LDS whole (128 x 128, BASELINE configs[4]'s mesh) are spread in bands of
+    rows -- 32 (fp32) or 16 (fp64) rows per workgroup, plane lists keyed by y slice, z transform in the tile, y columns as a launch
+    of their own (round 6).  Potentials, energy and forces of the eager calculator and of the graph-replayed step against the
+    oracle; atoms on band boundaries, a sheet that overflows its slice's lists, a triclinic cell."""
+    rng = np.random.default_rng(71)
+    cell, pos, q, pairs, S, dist = _banded_case(rng, dtype, blob=kind == "blob", triclinic=kind == "triclinic")
+    h = 0.7
+    Calc = tpa.P3MCalculator if scheme == "P3M" else tpa.PMECalculator
+    calc = Calc(tpa.CoulombPotential(smearing=1.2), mesh_spacing=h, interpolation_nodes=order).to(dtype)
+    t = lambda x: torch.tensor(x, device=DEV, dtype=dtype)  # noqa: E731
+    ti, tS = torch.tensor(pairs, device=DEV), t(S)
+    spec = O.PotentialSpec("coulomb", 1, 1.2, 1.0)
+    Vo, cache = O.forward(spec, "P3M" if scheme == "P3M" else "Lagrange", order, h, q, cell, pos, pairs, dist, return_cache=True)
+    gr = O.backward(cache, q)
+    gpos_d, _ = O.pair_distances_backward(pos, cell, pairs, S, gr["dist"])
+    tol_v, tol_f = (1e-10, 1e-9) if dtype == torch.float64 else (2e-5, 5e-4)
+    tp = t(pos).requires_grad_(True)
+    V = calc(t(q), t(cell), tp, ti, tpa.pair_distances(tp, ti, t(cell), tS))
+    assert calc._cache[6].ns == (32, 128, 128)
+    lib = _lib.load()
+    assert lib.mipme_last_cosched_kernel().decode() in ("plane_rows_capped_kernel", "plane_rows_kernel")
+    md = calc._cache[6].desc(1)
+    assert lib.mipme_plane_spread_parts(C.byref(md), len(pos), _lib.dtype_code(dtype)) == 1  # (bands: one workgroup per band)
+    tpa.weighted_sum(V, t(q)).backward()
+    assert rell2(V.detach().cpu().double().numpy(), Vo) < tol_v
+    assert rell2(tp.grad.cpu().double().numpy(), gr["positions"] + gpos_d) < tol_f
+    step = tpa.GraphedEnergyForces(calc, t(q), t(cell), t(pos), ti, tS)
+    E, F = step()
+    Eo = float((Vo * q).sum())
+    assert abs(float(E) - Eo) < (1e-10 if dtype == torch.float64 else 2e-5) * float(np.abs(Vo * q).sum())
+    assert rell2(F.cpu().double().numpy(), -(gr["positions"] + gpos_d)) < tol_f
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_banded_plane_spread_off_the_co_scheduled_launch(dtype, monkeypatch):
+    """The same mesh without a co-scheduled pair sum (the stand-alone banded plane kernel) and with 8-byte pair entries (no banded
+    co-scheduled kernel: the bricks take over): same potentials."""
+    from torchpme_amd import ops
+
+    rng = np.random.default_rng(72)
+    cell, pos, q, pairs, S, dist = _banded_case(rng, dtype)
+    t = lambda x: torch.tensor(x, device=DEV, dtype=dtype)  # noqa: E731
+    ti, tS = torch.tensor(pairs, device=DEV), t(S)
+    Vo = O.forward(O.PotentialSpec("coulomb", 1, 1.2, 1.0), "P3M", 5, 0.7, q, cell, pos, pairs, dist)
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    lib = _lib.load()
+    for flag, kernel in (("COSCHEDULE", None), ("COMPACT_ENTRIES", "spread_rows")):
+        monkeypatch.setattr(ops, flag, False)
+        calc = tpa.P3MCalculator(tpa.CoulombPotential(smearing=1.2), mesh_spacing=0.7, interpolation_nodes=5).to(dtype)
+        tp = t(pos).requires_grad_(True)  # (force sums wanted: the forward would co-schedule the pair sum with the spread)
+        V = calc(t(q), t(cell), tp, ti, tpa.pair_distances(tp, ti, t(cell), tS))
+        assert rell2(V.detach().cpu().double().numpy(), Vo) < tol, flag
+        if kernel:
+            assert lib.mipme_last_cosched_kernel().decode().startswith(kernel)
+        monkeypatch.setattr(ops, flag, True)

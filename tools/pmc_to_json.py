@@ -22,6 +22,7 @@ NAMES = {
     "spread_rows_kernel": "spread+rspace_forward",
     "spread_rows_capped_kernel": "spread+rspace_forward",
     "plane_rows_kernel": "spread+rspace_forward",
+    "plane_rows_capped_kernel": "spread+rspace_forward",
     "gather_tail_kernel": "gather+energy+forces",
     "gather_brick_kernel": "gather",
     "bin_atoms_kernel": "bin_atoms",

@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-DOMINANT = ("plane_rows_kernel", "spread_rows_capped_kernel", "spread_rows_kernel", "frames_plane_rows_kernel", "frames_spread_rows_kernel")
+DOMINANT = ("plane_rows_capped_kernel", "plane_rows_kernel", "spread_rows_capped_kernel", "spread_rows_kernel", "frames_plane_rows_kernel", "frames_spread_rows_kernel")
 N_SE = 32           # shader engines x XCDs the per-engine averages are over (rocpd_summary.py divides by it)
 SIMD_PER_SE = 32    # 8 CUs x 4 SIMDs
 

@@ -61,7 +61,9 @@ template <typename T> int spread_bricks(hipStream_t, const mipme_mesh_t*, int64_
                                         const mipme_sr_job_t*, bool, double*, const PlaneHost* = nullptr, bool* = nullptr);
 bool fft_plan_plane_forward_ok(const mipme_fft_plan*);
 int plane_bins_capacity(const mipme_mesh_t*, int64_t, int);
+int plane_bands(const mipme_mesh_t*, int);
 void fft_plan_set_forward_done(mipme_fft_plan*, bool, int);
+void fft_plan_set_forward_ycols(mipme_fft_plan*, bool);
 void* fft_plan_hat_parts(mipme_fft_plan*, hipStream_t, int);
 template <typename T> int kfilter_deriv_impl(hipStream_t, const mipme_mesh_t*, const mipme_potential_t*, void*);
 template <typename T> int cell_tail_finalize_impl(hipStream_t, const mipme_mesh_t*, double, double, int64_t, int64_t, const void*,
@@ -256,7 +258,8 @@ static int kspace_forward_t(mipme_fft_plan* plan, hipStream_t st, const mipme_me
       for (int r = 0; r < reps; ++r)
         if ((rc = spread_bricks<T>(st, m, N, bins, q, 1.0, rho_mesh, counters, co ? job : nullptr, tail != nullptr,
                                    out_grad_cell ? cw.cwave : nullptr, &ph, &planes))) return rc;
-      fft_plan_set_forward_done(plan, planes, ph.parts);
+      fft_plan_set_forward_done(plan, planes, planes ? ph.parts_used : 1);
+      fft_plan_set_forward_ycols(plan, planes && ph.ycols_pending);
     }
     if (job && !sr_job_fusable(job))  // no co-scheduled kernel for this potential / shift format: one after the other
       STAGE(st, "rspace_forward",
@@ -1296,7 +1299,7 @@ int mipme_fft_r2c(mipme_fft_plan* plan, void* stream, int dtype, const mipme_mes
 int mipme_plane_spread_parts(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {
   if (!mesh || validate_mesh(mesh) || !bricks_supported(mesh, dtype)) return 0;
   if (mesh->nx < 2 || (mesh->nx & (mesh->nx - 1)) || plane_bins_capacity(mesh, n_atoms, dtype) <= 0) return 0;
-  return plane_spread_parts_setting();
+  return plane_bands(mesh, dtype) > 1 ? 1 : plane_spread_parts_setting();  // (planes spread in bands of rows: one workgroup per band)
 }
 
 int64_t mipme_atom_bins_bytes(const mipme_mesh_t* mesh, int64_t n_atoms, int dtype) {

@@ -15,6 +15,11 @@
 #include "bricks_device.h"
 
 namespace mipme {
+// bands of rows a plane of this mesh is spread in (1: whole planes; 0: no plane spread) -- api.hip mipme_plane_spread_parts
+int plane_bands(const mipme_mesh_t* m, int dtype) {
+  const int rows = plane_band_rows(m, dtype);
+  return rows > 0 ? m->ny / rows : 0;
+}
 // the per-wave energy partial sums of the co-scheduled pair sum inside the bins buffer (n = number of {e, q^2} pairs)
 const void* bins_epart(const mipme_mesh_t* m, int64_t N, int dtype, void* bins, int64_t* n) {
   *n = (N + 64 / kRowLanes - 1) / (64 / kRowLanes);  // waves that hold a valid row
@@ -113,12 +118,20 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   PlaneArgs<T> pa;
   size_t plane_lds = 0;
   if (used_planes) *used_planes = false;
+  // whole planes, or bands of rows for planes whose tile does not fit the launch's LDS (PlaneArgs::band_rows); the banded
+  // co-scheduled kernels exist for 4-byte pair entries only (what every caller of this package uses): others keep the bricks
+  const int band_rows = v.idx.pcap > 0 ? plane_band_rows(m, sizeof(T) == 4 ? MIPME_F32 : MIPME_F64) : 0;
+  const bool bands_ok = band_rows == m->ny || !job || (job->shift_format & kShiftFormatMask) == kShiftTable32;
   if (ph && ph->hat && ph->slot_values && !ph->keep_mesh && used_planes && clear_count && v.idx.pcap > 0 && sa.C == 1 && !sparse &&
-      !sa.det && N > 0) {
+      !sa.det && N > 0 && band_rows > 0 && bands_ok) {
     size_t need = 0;
-    plane_lds_layout<T>(m->ny, m->nz, pa, need);
+    pa.band_rows = band_rows;
+    pa.bands = m->ny / pa.band_rows;
+    plane_lds_layout<T>(pa.band_rows, m->nz, pa, need, pa.bands == 1);
     pa.hat = (Cplx<T>*)ph->hat;
-    pa.parts = (ph->parts > 1 && ph->hat_more) ? ph->parts : 1;
+    pa.parts = (pa.bands == 1 && ph->parts > 1 && ph->hat_more) ? ph->parts : 1;
+    ph->ycols_pending = pa.bands > 1;
+    ph->parts_used = pa.parts;
     pa.hat_more = (Cplx<T>*)ph->hat_more;
     pa.more_stride = ph->more_stride;
     while ((1 << pa.logny) < m->ny) ++pa.logny;
@@ -175,13 +188,30 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
       return MIPME_OK;
     }
     if (pa.hat) {  // planes + row blocks
-      const unsigned n_planes = unsigned(m->nx) * unsigned(pa.parts);
+      const unsigned n_planes = unsigned(m->nx) * unsigned(pa.bands) * unsigned(pa.parts);
       const bool compact_p = (job->shift_format & kShiftFormatMask) == kShiftTable32;
       const unsigned n_here = n_rows_blocks;
       const unsigned pgrid = pad8(n_planes) + pad8(n_here);
 #define MIPME_PLANE_ROWS(PF, CO, CE) \
-  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, (plane_rows_kernel<S, N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here)))
-      note_cosched_kernel("plane_rows_kernel");
+  MIPME_DISPATCH_STENCIL_B(m->scheme, m->order, ([&] {                                                                          \
+    /* fp32: the build held to 80 scalar registers; planes spread in bands of rows: an instantiation of its own (4-byte entries) */ \
+    if constexpr (sizeof(T) == 4) {                                                                                            \
+      if (pa.bands > 1) {                                                                                                      \
+        if constexpr (CO)                                                                                                      \
+          plane_rows_capped_kernel<S, N, T, PF, CO, CE, true><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here); \
+      } else {                                                                                                                 \
+        plane_rows_capped_kernel<S, N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here); \
+      }                                                                                                                        \
+    } else {                                                                                                                   \
+      if (pa.bands > 1) {                                                                                                      \
+        if constexpr (CO)                                                                                                      \
+          plane_rows_kernel<S, N, T, PF, CO, CE, true><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here); \
+      } else {                                                                                                                 \
+        plane_rows_kernel<S, N, T, PF, CO, CE><<<pgrid, SPREAD_THREADS, plane_lds, st>>>(sa, pa, ra_e, n_planes, n_here);       \
+      }                                                                                                                        \
+    }                                                                                                                          \
+  }()))
+      note_cosched_kernel(sizeof(T) == 4 ? "plane_rows_capped_kernel" : "plane_rows_kernel");
       if (cpart && pfast == 1)
         MIPME_PLANE_ROWS(1, true, true);
       else if (cpart) {
@@ -229,7 +259,13 @@ int spread_bricks(hipStream_t st, const mipme_mesh_t* m, int64_t N, void* bins, 
   }
   if (pa.hat)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
-                             (plane_spread_kernel<S, N, T><<<unsigned(m->nx) * unsigned(pa.parts), 1024, plane_lds, st>>>(sa, pa)));
+                             ([&] {
+                               const unsigned pg = unsigned(m->nx) * unsigned(pa.bands) * unsigned(pa.parts);
+                               if (pa.bands > 1)
+                                 plane_spread_kernel<S, N, T, true><<<pg, 1024, plane_lds, st>>>(sa, pa);
+                               else
+                                 plane_spread_kernel<S, N, T><<<pg, 1024, plane_lds, st>>>(sa, pa);
+                             }()));
   else if (sparse)
     MIPME_DISPATCH_STENCIL_B(m->scheme, m->order,
                              ((void)S, spread_brick_sparse_kernel<N, T><<<brick_grid(bg), SPREAD_THREADS_SPARSE, lds, st>>>(sa)));

@@ -229,6 +229,9 @@ struct BinIndex {
   // plane lists (plane spread; pcap == 0: none): live counters int[nx * kPlaneSub + 1] behind the brick counters (zeroed by the forward
   // gather like those), slots per plane, overflow slots
   int* plive = nullptr;
+  // sub-list of an atom: >= 0: its y slice, m_y >> pband_shift (bands: a workgroup reads the slices of its rows); -1: the index of
+  // the binning pass's wavefront mod kPlaneSub (whole planes: spreads same-address atomics, every plane reads all sub-lists)
+  int pband_shift = -1;
   void* plist = nullptr;  // entries: plane_entry_words<N, T>() reals each, [nx * kPlaneSub lists][pcap]
   void* pover = nullptr;  // entries of the atoms whose list was full
   int pcap = 0;
@@ -258,8 +261,10 @@ __device__ __forceinline__ unsigned reach_code(const int (&m)[3], int nx, int ny
 
 #ifdef MIPME_BRICKS_MAIN_TU
 int plane_bins_capacity(const mipme_mesh_t* m, int64_t N, int dtype) { return plane_list_capacity(m, N, dtype); }
+int plane_bands(const mipme_mesh_t* m, int dtype);
 #else
 int plane_bins_capacity(const mipme_mesh_t* m, int64_t N, int dtype);
+int plane_bands(const mipme_mesh_t* m, int dtype);
 #endif
 
 #ifdef MIPME_BRICKS_MAIN_TU
@@ -324,7 +329,10 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
   }
   int myslot = 0, over_k = -1;
   int pl_leader = lane, pl_rank = 0, pl_count = 0, pl_slot = -1;
-  const int pl_key = int(((int64_t(block) * blockDim.x + threadIdx.x) >> 6) & (kPlaneSub - 1));  // (uniform) this wavefront's sub-list
+  // this atom's sub-list of its plane: the wavefront's index (uniform) or, for bands, the atom's y slice
+  const int pl_key = bi.pband_shift >= 0 ? ((m[1] >> bi.pband_shift) & (kPlaneSub - 1))
+                                         : int(((int64_t(block) * blockDim.x + threadIdx.x) >> 6) & (kPlaneSub - 1));
+  const int pl_list = m[0] * kPlaneSub + pl_key;
   if (slot_of) {  // deterministic mode: slots (and the live counters) come from the sorted atom list, see det_slots_kernel
     if (valid) {
       myslot = slot_of[i];
@@ -360,9 +368,9 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
       unsigned long long rem = __ballot(valid);
       while (rem) {
         const int leader = __ffsll((long long)rem) - 1;
-        const int p0 = __shfl(m[0], leader, 64);
-        const unsigned long long peers = __ballot(valid && m[0] == p0);
-        if (valid && m[0] == p0) {
+        const int p0 = __shfl(pl_list, leader, 64);
+        const unsigned long long peers = __ballot(valid && pl_list == p0);
+        if (valid && pl_list == p0) {
           pl_leader = leader;
           pl_rank = __popcll(peers & ((1ull << lane) - 1ull));
           pl_count = __popcll(peers);
@@ -373,7 +381,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     // pass 2: all leaders issue their returning atomic together (one memory round trip per wave, not one per brick)
     int base = 0, pbase = 0;
     if (valid && my_leader == lane) base = atomicAdd(&bi.live[b], my_count);
-    if (bi.plive && valid && pl_leader == lane) pbase = atomicAdd(&bi.plive[m[0] * kPlaneSub + pl_key], pl_count);
+    if (bi.plive && valid && pl_leader == lane) pbase = atomicAdd(&bi.plive[pl_list], pl_count);
     base = __shfl(base, my_leader, 64);
     myslot = base + my_rank;
     if (bi.plive) pl_slot = __shfl(pbase, pl_leader, 64) + pl_rank;
@@ -413,7 +421,7 @@ __device__ __forceinline__ void bin_atoms_body(const Geom& g, const BrickGeom& b
     };
     T* e;
     if (pl_slot < bi.pcap)  // plane list of m_x (else the plane overflow list: one atomic per atom, normally none)
-      e = (T*)bi.plist + ((int64_t(m[0]) * kPlaneSub + pl_key) * bi.pcap + pl_slot) * EW;
+      e = (T*)bi.plist + (int64_t(pl_list) * bi.pcap + pl_slot) * EW;
     else
       e = (T*)bi.pover + int64_t(atomicAdd(&bi.plive[g.nx * kPlaneSub], 1)) * EW;
     T v[EW];
@@ -1212,27 +1220,54 @@ struct PlaneArgs {
   int parts = 1;
   Cplx<T>* hat_more = nullptr;
   int64_t more_stride = 0;
+  // Planes whose accumulation tile does not fit the co-scheduled launch's LDS (128 x 128: round 6) are spread in BANDS of
+  // band_rows rows (a power of two, ny = bands * band_rows; bands == 1: the whole plane): a workgroup per (plane, band) accumulates
+  // its rows, transforms them along z only and stores them; the y columns follow as a launch of their own (kfilter.hip ycols,
+  // fft_plan_set_forward_ycols).  The plane lists are then keyed by y slice (BinIndex::pband_shift) and a band reads the sub-lists
+  // of its own slices and of the two neighbouring ones (an atom's stencil reaches at most one slice beyond its own).
+  int band_rows = 0, bands = 1;
 };
 
 // LDS of a launch with planes: co-scheduled with the row blocks, four workgroups per CU must fit 160 KB (and the rows need their
 // shift / erfcx tables: <= 32 KB); alone, the default dynamic limit
 static constexpr size_t kPlaneLdsCosched = 39 * 1024;
 static inline size_t plane_tile_bytes(int ny, int nz, size_t real_bytes) { return 2 * real_bytes * size_t(ny) * (size_t(nz / 2) + 1); }
-static inline size_t plane_tw_bytes(int ny, int nz, size_t real_bytes) {
+static inline size_t plane_tw_bytes(int ny, int nz, size_t real_bytes) {  // (ny = 0: no y stage, z twiddles only)
   const size_t Lz = size_t(nz / 2), Ltab = size_t(ny) > Lz ? size_t(ny) : Lz;
   return 2 * real_bytes * (Ltab / 2 + (Lz + 1));
 }
-// accumulation tile (ny x nz doubles); the fp32 transform tile is smaller and takes its place, the fp64 one sits behind it
+// accumulation tile (rows x nz doubles); the fp32 transform tile is smaller and takes its place, the fp64 one sits behind it.
+// rows = ny: a whole plane (y stage in the tile); rows < ny: a band (z stage only)
 template <typename T>
-static inline void plane_lds_layout(int ny, int nz, PlaneArgs<T>& pa, size_t& total) {
-  const size_t acc = sizeof(double) * size_t(ny) * nz, tile = plane_tile_bytes(ny, nz, sizeof(T));
+static inline void plane_lds_layout(int rows, int nz, PlaneArgs<T>& pa, size_t& total, bool ystage = true) {
+  const size_t acc = sizeof(double) * size_t(rows) * nz, tile = plane_tile_bytes(rows, nz, sizeof(T));
   const size_t tile_off = sizeof(T) == 4 ? 0 : acc;
   const size_t tw_off = sizeof(T) == 4 ? (acc > tile ? acc : tile) : acc + tile;
   pa.tile_off = int(tile_off);
   pa.tw_off = int(tw_off);
-  pa.misc_off = int(tw_off + plane_tw_bytes(ny, nz, sizeof(T)));
+  pa.misc_off = int(tw_off + plane_tw_bytes(ystage ? rows : 0, nz, sizeof(T)));
   total = size_t(pa.misc_off) + 640;
 }
+// rows of a plane one workgroup of the co-scheduled launch accumulates: the whole plane if its tile fits, else the largest band
+// of ny / 2, ny / 4, ny / 8 rows that does (at least as many rows as a y slice of the plane lists: ny / kPlaneSub); 0: none fits
+static inline int plane_band_rows(const mipme_mesh_t* m, int dtype) {
+  static const bool bands_env = env_flag("MIPME_PLANE_BANDS", true);
+  for (int rows = m->ny; rows >= 4 && rows * kPlaneSub >= m->ny; rows >>= 1) {
+    size_t need = 0;
+    if (dtype == MIPME_F32) {
+      PlaneArgs<float> pa;
+      plane_lds_layout<float>(rows, m->nz, pa, need, rows == m->ny);
+    } else {
+      PlaneArgs<double> pa;
+      plane_lds_layout<double>(rows, m->nz, pa, need, rows == m->ny);
+    }
+    if (need <= kPlaneLdsCosched) return rows;
+    if (!bands_env) break;
+  }
+  return 0;
+}
+// whole planes in the co-scheduled launch (the frame batches' condition: no bands there)?
+static inline bool plane_fits_cosched(const mipme_mesh_t* m, int dtype) { return plane_band_rows(m, dtype) == m->ny; }
 
 static inline bool sparse_bricks(int64_t n_atoms, int nb);
 // Entries per plane list of the bins, 0 if this mesh / system does not use the plane spread: single channel, power-of-two planes
@@ -1246,15 +1281,9 @@ static int plane_list_capacity(const mipme_mesh_t* m, int64_t N, int dtype) {
   // (the entries pack (m_x, m_y, m_z) into 11 + 10 + 10 bits of a non-negative int)
   if (m->nx > (1 << 11) || m->ny > (1 << kPlanePackBits) || m->nz > (1 << kPlanePackBits)) return 0;
   if (sparse_bricks(N, make_brick_geom(m).nb)) return 0;
-  size_t need = 0;
-  if (dtype == MIPME_F32) {
-    PlaneArgs<float> pa;
-    plane_lds_layout<float>(m->ny, m->nz, pa, need);
-  } else {
-    PlaneArgs<double> pa;
-    plane_lds_layout<double>(m->ny, m->nz, pa, need);
-  }
-  if (need > kPlaneLdsCosched) return 0;
+  const int band_rows = plane_band_rows(m, dtype);
+  if (band_rows == 0) return 0;
+  if (band_rows < m->ny && m->ny / kPlaneSub < 8) return 0;  // (bands: a y slice must hold a stencil's reach, N - 1 <= 6 rows)
   const int64_t lists = int64_t(m->nx) * kPlaneSub, mean = (N + lists - 1) / lists, all = (N + 15) / 16 * 16;
   int64_t cap = (4 * mean + 32 + 15) / 16 * 16;
   if (cap > all) cap = all;
@@ -1322,15 +1351,23 @@ __device__ __forceinline__ void plane_item_make(PlaneItem<N, T>& it, const Plane
 // (x + 1.5 * 2^52 holds round(x) in its low 52 bits, two's complement; the constant's bit pattern has a zero low word, so taking
 // it off is one 32-bit subtraction), and integer sums do not depend on the order of arrival: the mesh is bit-reproducible.
 static constexpr unsigned kFxMagicHi = 0x43380000u;  // high word of the bit pattern of 1.5 * 2^52
-template <int N, typename T>
-__device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, const Geom& g, const PlaneItem<N, T>& it, double fx_scale) {
+template <int N, typename T, bool BANDED>
+__device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, const Geom& g, const PlaneItem<N, T>& it, double fx_scale,
+                                                   int row_lo, int rows) {
+  // (row_lo, rows): the rows of the plane this tile holds -- (0, ny) for a whole plane, a band's otherwise: stencil rows outside
+  // it belong to another workgroup
   constexpr int s0 = stencil_start<N>();
   int zo[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) zo[k] = wrap1(it.mz + s0 + k, g.nz);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const int row = wrap1(it.my + s0 + j, g.ny) * g.nz;
+    int r = wrap1(it.my + s0 + j, g.ny);
+    if constexpr (BANDED) {
+      r -= row_lo;
+      if (unsigned(r) >= unsigned(rows)) continue;
+    }
+    const int row = r * g.nz;
     const T ay = it.vx * it.wy[j];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1345,13 +1382,20 @@ __device__ __forceinline__ void plane_item_scatter(double* __restrict__ acc, con
   }
 }
 
-template <int SCHEME, int N, typename T>
+template <int SCHEME, int N, typename T, bool BANDED = false>
 __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, const PlaneArgs<T>& pa, unsigned item,
                                                      char* smem) {
-  // item = plane * parts + part: the parts of one plane are neighbours in the launch (same XCD: they read the same bins)
-  const unsigned plane = item / unsigned(pa.parts);
-  const int part = int(item - plane * unsigned(pa.parts));
+  // item = (plane * bands + band) * parts + part: the workgroups of one plane are neighbours in the launch (same XCD: they read the
+  // same lists).  bands == 1: the tile is the whole plane; else band_rows rows of it (parts == 1 then)
+  // (BANDED is a template argument: the whole-plane instantiation is round 5's code, constants and all)
+  constexpr bool banded = BANDED;
+  const int n_bands = banded ? pa.bands : 1;
+  const unsigned unit = item / unsigned(pa.parts);
+  const int part = int(item - unit * unsigned(pa.parts));
+  const unsigned plane = banded ? unit / unsigned(n_bands) : unit;
+  const int band = banded ? int(unit - plane * unsigned(n_bands)) : 0;
   const Geom& g = args.g;
+  const int rows = banded ? pa.band_rows : g.ny, row_lo = band * rows;
   const BinIndex& bins = args.bins;
   const T* __restrict__ plist = (const T*)bins.plist;
   const T* __restrict__ pover = (const T*)bins.pover;
@@ -1359,27 +1403,34 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   constexpr int s0 = stencil_start<N>();
   MIPME_WG_PHASE(0);
   double* acc = reinterpret_cast<double*>(smem);
-  const int npts = g.ny * g.nz;
+  const int npts = rows * g.nz;
   const int x0 = int(plane);
-  constexpr int NL = N * kPlaneSub;  // lists of this plane: list l = sub-list (l % kPlaneSub) of plane x0 - s0 - l / kPlaneSub
+  // Lists of this workgroup: list l = sub-list sub0 + (l % SUBS) (mod kPlaneSub) of plane x0 - s0 - l / SUBS.  Whole planes read
+  // all kPlaneSub sub-lists (keyed by wavefront); a band reads the y slices of its rows and one more on either side.
+  const int spb = kPlaneSub / n_bands;                        // y slices per band
+  const int SUBS = banded ? min(spb + 2, kPlaneSub) : kPlaneSub;
+  const int sub0 = banded ? band * spb - 1 : 0;
+  const int NL = N * SUBS;
+  auto list_of = [&](int l) __attribute__((always_inline)) {
+    return posmod(x0 - s0 - l / SUBS, g.nx) * kPlaneSub + ((sub0 + (l % SUBS)) & (kPlaneSub - 1));
+  };
   // the prologue's global loads first (list lengths, this lane's share of the per-wavefront charge maxima), the tile zeroing and
   // the twiddles while they are in flight: the prologue was 3 us of a 17 us workgroup
   int my_count = 0;
-  if (tid < NL) my_count = bins.plive[posmod(x0 - s0 - tid / kPlaneSub, g.nx) * kPlaneSub + (tid % kPlaneSub)];
+  if (tid < NL) my_count = bins.plive[list_of(tid)];
   float my_wmax = 0.f;
   if (sizeof(T) == 4 && tid < bins.n_wmax) my_wmax = bins.wmax[tid];
   for (int i = tid; i < npts; i += nthr) acc[i] = 0.0;
-  const YzTile<T> yt = yz_tile_setup<T, true>(g.ny, g.nz, smem + pa.tile_off, smem + pa.tw_off);
+  const YzTile<T> yt = banded ? yz_tile_setup<T, false>(rows, g.nz, smem + pa.tile_off, smem + pa.tw_off)
+                              : yz_tile_setup<T, true>(g.ny, g.nz, smem + pa.tile_off, smem + pa.tw_off);
   if (args.from_live) {  // per-call snapshot of the brick counts (see spread_brick_body): the workgroups share the bricks among them
-    const int n_items = g.nx * pa.parts;
+    const int n_items = g.nx * n_bands * pa.parts;
     for (int b = int(item) + tid * n_items; b <= bins.nb; b += n_items * nthr) bins.snap[b] = bin_count_of(bins, b, true);
   }
-  // The atoms of this plane: the plane lists of m_x = x0 - s0 - tt, tt = 0 .. N-1 (stencil row tt of those atoms is this plane),
-  // taken as ONE sequence (list 0, then list 1, ...) of which this part owns an even slice, walked in batches of blockDim atoms --
-  // every lane of a batch but the last holds an atom, so the N^2 LDS atomics of a batch are dense; the next batch's record,
-  // weights and charge are in flight while the current one is scattered, its list entry one batch further ahead.
-  // lst[l] = entries of the sequence before list l (lst[NL] = all), lst[64 + l] = the length of list l  (LDS, read back with
-  // a per-lane index: kept in registers and picked by tt the compiler spills them to a stack array)
+  // The atoms of this tile: the lists above, taken as ONE sequence (list 0, then list 1, ...) of which this part owns an even slice,
+  // walked in batches of blockDim atoms -- every lane of a batch but the last holds an atom, so the N^2 LDS atomics of a batch are
+  // dense.  lst[l] = entries of the sequence before list l (lst[NL] = all), lst[64 + l] = the length of list l  (LDS, read back
+  // with a per-lane index: kept in registers and picked by tt the compiler spills them to a stack array)
   int* lst = reinterpret_cast<int*>(smem + pa.misc_off);
   static_assert(N * kPlaneSub < 64, "bookkeeping of the plane lists");
   double* fxs = reinterpret_cast<double*>(lst + 128);  // fixed-point scale and its inverse (fp32 meshes)
@@ -1453,10 +1504,9 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     const int gidx = lo + b * nthr + tid;
     int l = 0;
     for (int u = 1; u < NL; ++u) l += gidx >= lst[u] ? 1 : 0;
-    tt = l / kPlaneSub;
+    tt = l / SUBS;
     if (b >= n_batches || gidx >= hi) return -1;
-    const int list_id = posmod(x0 - s0 - tt, g.nx) * kPlaneSub + (l % kPlaneSub);
-    return int64_t(list_id) * bins.pcap + (gidx - lst[l]);
+    return int64_t(list_of(l)) * bins.pcap + (gidx - lst[l]);
   };
   int tt0 = 0, tt1 = 0;
   PlaneRaw<N, T> r0, r1;
@@ -1474,7 +1524,7 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
     plane_item_make<SCHEME, N, T>(cur, r0, tt0, args.scale);
     if (cur.vx != T(0)) {
       guard_item(cur);
-      plane_item_scatter<N, T>(acc, g, cur, fx_scale);
+      plane_item_scatter<N, T, BANDED>(acc, g, cur, fx_scale, row_lo, rows);
     }
     r0 = r1;
     tt0 = tt1;
@@ -1493,7 +1543,7 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
         PlaneItem<N, T> it;
         plane_item_make<SCHEME, N, T>(it, r, d, args.scale);
         guard_item(it);
-        plane_item_scatter<N, T>(acc, g, it, fx_scale);
+        plane_item_scatter<N, T, BANDED>(acc, g, it, fx_scale, row_lo, rows);
       }
     }
   }
@@ -1505,7 +1555,7 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   // tile: a chunk's values travel through registers, and rows are written in the order they were read (a tile row is shorter
   // than an accumulation row, so the writes never reach rows that are still to be read).
   {
-    const int Lz = yt.Lz, RZ = yt.RZ, npairs = g.ny * Lz;
+    const int Lz = yt.Lz, RZ = yt.RZ, npairs = rows * Lz;
     constexpr int CH = 4;
     for (int base = 0; base < npairs; base += CH * nthr) {
       Cplx<T> v[CH];
@@ -1534,28 +1584,30 @@ __device__ __forceinline__ void plane_spread_yz_body(const SpreadArgs<T>& args, 
   }
   MIPME_WG_PHASE(3);
   Cplx<T>* dst = part == 0 ? pa.hat : pa.hat_more + int64_t(part - 1) * pa.more_stride;
-  yz_forward_finish<T, true>(yt, g.ny, g.nz, pa.logny, pa.loglz, dst + int64_t(plane) * g.ny * yt.RZ);
+  if (banded)  // z rows only, y in natural order: the y columns are a launch of their own (kfilter.hip ycols)
+    yz_forward_finish<T, false>(yt, rows, g.nz, 0, pa.loglz, dst + (int64_t(plane) * g.ny + row_lo) * yt.RZ);
+  else
+    yz_forward_finish<T, true>(yt, g.ny, g.nz, pa.logny, pa.loglz, dst + int64_t(plane) * g.ny * yt.RZ);
   MIPME_WG_PHASE(4);
 }
 
-template <int SCHEME, int N, typename T>
+template <int SCHEME, int N, typename T, bool BANDED = false>
 __global__ __launch_bounds__(1024) void plane_spread_kernel(SpreadArgs<T> sa, PlaneArgs<T> pa) {
   MIPME_SKIP_IF_SET(sa.skip);
   extern __shared__ __attribute__((aligned(16))) char smem_plane[];
-  plane_spread_yz_body<SCHEME, N, T>(sa, pa, blockIdx.x, smem_plane);
+  plane_spread_yz_body<SCHEME, N, T, BANDED>(sa, pa, blockIdx.x, smem_plane);
 }
 
 // planes first, then the row blocks of the pair sum (the planes are few -- nx -- and long: they must start at once)
-template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL = false>
-__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
-    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * parts */,
-    unsigned n_row_blocks) {
+template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL, bool BANDED>
+__device__ __forceinline__ void plane_rows_body(const SpreadArgs<T>& sa, const PlaneArgs<T>& pa, const FusedRowsArgs<T>& ra,
+                                                unsigned n_planes, unsigned n_row_blocks) {
   MIPME_WG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_pr[];
   const unsigned n_pad = pad8(n_planes);
   if (blockIdx.x < n_pad) {
     const unsigned p = xcd_contiguous(blockIdx.x, n_planes);
-    if (p < n_planes) plane_spread_yz_body<SCHEME, N, T>(sa, pa, p, smem_pr);
+    if (p < n_planes) plane_spread_yz_body<SCHEME, N, T, BANDED>(sa, pa, p, smem_pr);
   } else {
     const unsigned r = xcd_contiguous(blockIdx.x - n_pad, n_row_blocks);
     if (r < n_row_blocks) cosched_row_block<T, PFAST, COMPACT, CELL>(ra, r, smem_pr);
@@ -1564,6 +1616,19 @@ __global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL
   __syncthreads();
 #endif
   MIPME_WG_STAMP(1);
+}
+template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL = false, bool BANDED = false>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) void plane_rows_kernel(
+    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes /* plane workgroups: nx * bands * parts */,
+    unsigned n_row_blocks) {
+  plane_rows_body<SCHEME, N, T, PFAST, COMPACT, CELL, BANDED>(sa, pa, ra, n_planes, n_row_blocks);
+}
+// ... held to 80 scalar registers for the fp32 instantiations (four workgroups per CU: 82 would admit three -- see
+// spread_rows_capped_kernel; the fp64 ones are bound by their vector registers and answer the cap with scratch)
+template <int SCHEME, int N, typename T, int PFAST, bool COMPACT, bool CELL = false, bool BANDED = false>
+__global__ __launch_bounds__(SPREAD_THREADS, (sizeof(T) == 4 && COMPACT) ? (CELL ? MIPME_CELL_WAVES : 6) : 1) MIPME_SGPR_CAP void plane_rows_capped_kernel(
+    SpreadArgs<T> sa, PlaneArgs<T> pa, FusedRowsArgs<T> ra, unsigned n_planes, unsigned n_row_blocks) {
+  plane_rows_body<SCHEME, N, T, PFAST, COMPACT, CELL, BANDED>(sa, pa, ra, n_planes, n_row_blocks);
 }
 
 // ---- gather with an LDS halo tile ----------------------------------------------------------------
@@ -2068,6 +2133,14 @@ static inline BinsView bins_view(const mipme_mesh_t* m, int64_t N, int dtype, vo
   v.idx.codes = (unsigned char*)(b + l.codes);
   v.qs = (void*)(b + l.qs);
   v.idx.pcap = l.pcap;
+  if (l.pcap) {
+    const int rows = plane_band_rows(m, dtype);
+    if (rows > 0 && rows < m->ny) {
+      int sh = 0;
+      while ((kPlaneSub << sh) < m->ny) ++sh;
+      v.idx.pband_shift = sh;
+    }
+  }
   v.idx.plist = l.pcap ? (void*)(b + l.plist) : nullptr;
   v.idx.pover = l.pcap ? (void*)(b + l.pover) : nullptr;
   v.idx.wmax = l.pcap ? (float*)(b + l.wmax) : nullptr;

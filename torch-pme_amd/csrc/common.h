@@ -304,6 +304,10 @@ struct PlaneHost {
   int parts = 1;
   void* hat_more = nullptr;
   int64_t more_stride = 0;
+  // out: how the spread left `hat` -- parts_used partial transforms that add up, and (planes spread in bands of rows) only the z
+  // rows transformed: the convolution runs the y columns before its x stage (fft_plan_set_forward_ycols)
+  mutable int parts_used = 1;
+  mutable bool ycols_pending = false;
 };
 struct RowRideHost {
   const mipme_sr_job_t* job;

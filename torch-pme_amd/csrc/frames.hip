@@ -156,11 +156,13 @@ static void frame_correction_terms(const mipme_potential_t* pot, double& self_c,
 static int64_t frame_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dtype) {
   const BrickGeom bg = make_brick_geom(m);
   int64_t n = int64_t(bg.nb) + 1;
-  if (plane_list_capacity(m, n_atoms, dtype) > 0) n += int64_t(m->nx) * kPlaneSub + 1;
+  if (plane_list_capacity(m, n_atoms, dtype) > 0 && plane_fits_cosched(m, dtype)) n += int64_t(m->nx) * kPlaneSub + 1;
   return n;
 }
 static bool frame_plane_lists(const mipme_frame_t& f, int dtype) {
-  return plane_list_capacity(&f.mesh, f.n_atoms, dtype) > 0 && int64_t(f.counter_ints) == frame_counter_ints(&f.mesh, f.n_atoms, dtype);
+  // (whole planes only: the frame batches have no band variant; larger planes keep the bricks there)
+  return plane_list_capacity(&f.mesh, f.n_atoms, dtype) > 0 && plane_fits_cosched(&f.mesh, dtype) &&
+         int64_t(f.counter_ints) == frame_counter_ints(&f.mesh, f.n_atoms, dtype);
 }
 int64_t frames_counter_ints(const mipme_mesh_t* m, int64_t n_atoms, int dtype) { return frame_counter_ints(m, n_atoms, dtype); }
 

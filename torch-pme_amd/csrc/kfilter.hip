@@ -385,6 +385,8 @@ struct mipme_fft_plan {
   bool forward_done = false;
   // ... as `forward_parts` partial transforms that add up: part 0 in the convolution's buffer, the others in hat_parts
   int forward_parts = 1;
+  // ... with the y columns still to do (planes spread in bands of rows: only the z rows are transformed)
+  bool forward_ycols = false;
   void* hat_parts = nullptr;
   int64_t hat_parts_bytes = 0;
 };
@@ -1116,10 +1118,14 @@ static int convolve_xfused_t(mipme_fft_plan* p, hipStream_t st, const void* mesh
     rider.n_tiles = int(grid);
     rider.rows = cc->rows;
   }
-  const bool forward_done = p->forward_done;
-  p->forward_done = false;
+  const bool forward_done = p->forward_done, forward_ycols = p->forward_ycols;
+  p->forward_done = p->forward_ycols = false;
   if (forward_done) {
-    // the plane spread left the transformed planes in `hat`
+    // the plane spread left the transformed planes in `hat` -- or, spread in bands, their z rows: the y columns in place
+    if (forward_ycols) {
+      int rc = ycols<T>(p, st, false, hat);
+      if (rc) return rc;
+    }
   } else if (p->own_yz) {
     int rc = yz_planes<T>(p, st, false, mesh_in, hat, nullptr);
     if (rc) return rc;
@@ -1183,6 +1189,10 @@ void fft_plan_set_forward_done(mipme_fft_plan* p, bool done, int parts) {
   if (!p) return;
   p->forward_done = done;
   p->forward_parts = done ? parts : 1;
+  p->forward_ycols = false;
+}
+void fft_plan_set_forward_ycols(mipme_fft_plan* p, bool pending) {
+  if (p) p->forward_ycols = pending && p->forward_done;
 }
 // room for `n_more` more half-complex meshes (the partial transforms of a plane spread with several workgroups per plane);
 // allocated on first use -- not possible during stream capture: NULL then (the caller runs with one part)
