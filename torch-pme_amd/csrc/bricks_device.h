@@ -47,8 +47,7 @@ static inline BrickGeom make_brick_geom(const mipme_mesh_t* m) {
   b.nby = (m->ny + BRICK - 1) / BRICK;
   b.nbz = (m->nz + BRICK - 1) / BRICK;
   b.nb = b.nbx * b.nby * b.nbz;
-  static const bool xcd_map = env_flag("MIPME_XCD_MAP", true);
-  b.xcd = xcd_map ? 1 : 0;
+  b.xcd = 1;  // (XCD-contiguous workgroup -> brick / row-block mapping: +1-3 %, profiles/r02_experiments.txt; a switch until round 6)
   return b;
 }
 // workgroups of a one-workgroup-per-brick launch, and the brick of a workgroup (>= nb: nothing to do)
