@@ -1410,8 +1410,9 @@ def main(argv=None):
                 "preset": args.preset,
                 "frames_per_gpu": n_frames,
                 "neighbors": args.neighbors,
-                "spread": (f"plane spread, {label_parts} workgroup(s) per x plane (charges into the forward plane transform's LDS "
-                           "tiles; no forward plane launch)" if n_parts > 0 else "owner-computes bricks + forward plane launch"),
+                "spread": (f"plane spread, {label_parts} workgroup(s) per x plane -- per band of rows where a plane's tile does not fit "
+                           "the launch's LDS (128 x 128: z transform in the tile, y columns as a launch of their own) -- (charges "
+                           "into the forward plane transform's LDS tiles; no forward plane launch)" if n_parts > 0 else "owner-computes bricks + forward plane launch"),
                 "launch": ("HIP graph replay of the captured step"
                            + (", all frames in one launch per kernel (GraphedFrameBatch)" if batch is not None
                               else ", one stream per frame" if streams is not None else ""))
